@@ -1,0 +1,384 @@
+"""Synthetic TPC-H-format workload + the flat "workload pack" the HIP path reads.
+
+The reference draws every job from 22 queries x 7 input sizes of a downloaded
+TPC-H trace set (reference `spark_sched_sim/data_samplers/tpch.py:13-15,117-132`):
+per (size, query) one `adj_mat_<q>.npy` (stage DAG) and one pickled
+`task_duration_<q>.npy` dict `stage -> wave -> executor level -> [durations]`.
+That download is not reproducible offline, so this module
+
+  * generates a *synthetic* trace set with the same schema from a frozen seed
+    (`make_raw_workload`),
+  * can write it out in the reference's on-disk layout (`write_reference_layout`)
+    so that the reference itself can be run on it when fixtures are (re)generated,
+  * compiles it into one flat, pointer-free binary blob (`build_pack`) that the
+    C oracle and the HIP kernels both consume.
+
+Everything that the reference computes per job at `reset()` but that is in fact a
+constant of the (query, size) template is folded into the pack:
+
+  * `num_tasks` from the *pre-cleaning* first key (tpch.py:185-187),
+  * the multiset "cleaning" of first_wave and nearest-lower-level fill
+    (tpch.py:134-159),
+  * the rough mean duration over all three waves after cleaning, duplicates from
+    the fill included (tpch.py:161-174),
+  * parent/child sets and the row-major `(u, v)` edge list networkx yields for
+    `from_numpy_array(adj, DiGraph)` (tpch.py:199; job.py:76-79).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import os.path as osp
+import struct
+from typing import Any
+
+import numpy as np
+
+QUERY_SIZES = ["2g", "5g", "10g", "20g", "50g", "80g", "100g"]  # tpch.py:14
+NUM_QUERIES = 22  # tpch.py:15
+NUM_TEMPLATES = NUM_QUERIES * len(QUERY_SIZES)
+WAVES = ("fresh_durations", "first_wave", "rest_wave")
+W_FRESH, W_FIRST, W_REST = 0, 1, 2
+
+DEFAULT_SEED = 20240607
+PACK_MAGIC = b"SSSPACK2"
+
+_SIZE_SCALE = {"2g": 1, "5g": 2, "10g": 4, "20g": 8, "50g": 20, "80g": 32, "100g": 40}
+_LEVELS = [2, 5, 10, 20, 40, 50, 60, 80, 100]
+
+
+def template_index(query_num: int, size_idx: int) -> int:
+    """template id used by the pack: query-major. `query_num` is 1-based as in
+    tpch.py:177, `size_idx` indexes QUERY_SIZES as drawn in tpch.py:178."""
+    return (query_num - 1) * len(QUERY_SIZES) + size_idx
+
+
+# --------------------------------------------------------------------------
+# raw synthetic trace set (reference schema)
+# --------------------------------------------------------------------------
+
+
+def _make_dag(rng: np.random.Generator, n: int) -> np.ndarray:
+    """random DAG on n >= 2 stages, edges u < v, in-degree <= 3, >= 1 edge
+    (the reference's `_reset_edge_links` cannot handle an edge-less job,
+    spark_sched_sim.py:254)."""
+    adj = np.zeros((n, n), dtype=np.int64)
+    for v in range(1, n):
+        max_par = min(v, 3)
+        # sources are allowed (k = 0) but get rarer further down the DAG
+        k = int(rng.integers(0, max_par + 1))
+        if k == 0 and rng.random() < 0.7:
+            k = 1
+        if k:
+            lo = max(0, v - 6)
+            cand = np.arange(lo, v)
+            k = min(k, cand.size)
+            par = rng.choice(cand, size=k, replace=False)
+            adj[par, v] = 1
+    if adj.sum() == 0:
+        adj[0, n - 1] = 1
+    return adj
+
+
+def _make_stage_durations(
+    rng: np.random.Generator, scale: int, variant: int
+) -> dict[str, dict[int, list[int]]]:
+    """one stage's `{wave: {level: [ms, ...]}}` dict.
+
+    `variant` rotates through corner cases so that every branch of
+    `TPCHDataSampler.task_duration` (tpch.py:75-106) and of the cleaning pass
+    (tpch.py:134-159) is hit by some template:
+      1 -> highest levels missing from first_wave (=> `max(first_wave)` path)
+      2 -> rest_wave misses some levels (KeyError fallback)
+      3 -> a mid level whose first_wave is exactly its fresh list
+           (cleaning empties it => inherits the lower level's list)
+      4 -> empty fresh list at some level (ValueError fallback + warmup)
+      5 -> keys inserted in descending order (first key != smallest)
+    """
+    num_tasks = max(1, int(rng.integers(1, 12)) * scale // 2)
+    base = int(rng.integers(200, 4000))
+
+    levels = list(_LEVELS)
+    if variant == 1:
+        levels = levels[: int(rng.integers(3, 6))]
+    if variant == 5:
+        levels = levels[::-1]
+
+    first: dict[int, list[int]] = {}
+    rest: dict[int, list[int]] = {}
+    fresh: dict[int, list[int]] = {}
+    for e in levels:
+        n_first = max(1, min(num_tasks, e))
+        n_rest = num_tasks - n_first
+        fw = rng.integers(base, 2 * base, size=n_first).tolist()
+        rw = rng.integers(max(1, base // 2), base, size=n_rest).tolist()
+        # fresh durations: a prefix of the first wave (these get removed from
+        # first_wave by the cleaning pass) plus a few values of their own
+        k = (n_first + 1) // 2
+        fr = fw[:k] if n_first > 1 else []
+        fr = fr + (rng.integers(base, 2 * base, size=max(1, k // 2)) + base).tolist()
+        first[e], rest[e], fresh[e] = fw, rw, fr
+
+    lv_sorted = sorted(levels)
+    if variant == 2 and len(lv_sorted) > 2:
+        for e in lv_sorted[1:]:
+            if rng.random() < 0.5:
+                del rest[e]
+    if variant == 3 and len(lv_sorted) > 3:
+        e = lv_sorted[int(rng.integers(1, 4))]
+        fresh[e] = list(first[e])
+    if variant == 4:
+        e = lv_sorted[int(rng.integers(0, min(4, len(lv_sorted))))]
+        fresh[e] = []
+
+    return {"fresh_durations": fresh, "first_wave": first, "rest_wave": rest}
+
+
+def make_raw_workload(seed: int = DEFAULT_SEED) -> dict[tuple[str, int], tuple[np.ndarray, dict]]:
+    """-> {(size, query_num): (adj_mat int64[S,S], {stage: {wave: {level: [int]}}})}"""
+    rng = np.random.default_rng(seed)
+    raw: dict[tuple[str, int], tuple[np.ndarray, dict]] = {}
+    for q in range(1, NUM_QUERIES + 1):
+        n_stages = int(rng.integers(2, 19))
+        adj = _make_dag(rng, n_stages)
+        for size in QUERY_SIZES:
+            scale = _SIZE_SCALE[size]
+            td = {}
+            for s in range(n_stages):
+                variant = int(rng.integers(0, 8))
+                td[s] = _make_stage_durations(rng, scale, variant)
+            raw[(size, q)] = (adj.copy(), td)
+    return raw
+
+
+def write_reference_layout(raw: dict, root: str) -> None:
+    """writes `<root>/data/tpch/<size>/{adj_mat,task_duration}_<q>.npy`, the layout
+    `TPCHDataSampler._load_query` reads relative to cwd (tpch.py:117-132)."""
+    for (size, q), (adj, td) in raw.items():
+        d = osp.join(root, "data", "tpch", size)
+        os.makedirs(d, exist_ok=True)
+        np.save(osp.join(d, f"adj_mat_{q}.npy"), adj, allow_pickle=True)
+        np.save(osp.join(d, f"task_duration_{q}.npy"), np.array(td, dtype=object), allow_pickle=True)
+
+
+# --------------------------------------------------------------------------
+# template constants the reference recomputes per job
+# --------------------------------------------------------------------------
+
+
+def clean_first_wave(td: dict[str, dict[int, list[int]]]) -> dict[int, list[int]]:
+    """multiset-subtract the fresh durations from first_wave per level, then let an
+    emptied level inherit the nearest lower level's list (tpch.py:134-159)."""
+    clean: dict[int, list[int]] = {}
+    for e, fw in td["first_wave"].items():
+        budget: dict[int, int] = {}
+        for d in td["fresh_durations"][e]:
+            budget[d] = budget.get(d, 0) + 1
+        kept = []
+        for d in fw:
+            if budget.get(d, 0) > 0:
+                budget[d] -= 1
+            else:
+                kept.append(d)
+        clean[e] = kept
+    last: list[int] = []
+    for e in sorted(clean):
+        if not clean[e]:
+            clean[e] = last
+        last = clean[e]
+    return clean
+
+
+def _template_constants(adj: np.ndarray, td: dict) -> dict[str, Any]:
+    n = adj.shape[0]
+    assert adj.shape == (n, n) and len(td) == n
+    stages = []
+    for s in range(n):
+        data = td[s]
+        e0 = next(iter(data["first_wave"]))
+        num_tasks = len(data["first_wave"][e0]) + len(data["rest_wave"][e0])  # tpch.py:185-187
+        first = clean_first_wave(data)
+        allv = (
+            [t for ts in data["fresh_durations"].values() for t in ts]
+            + [t for ts in first.values() for t in ts]
+            + [t for ts in data["rest_wave"].values() for t in ts]
+        )
+        rough = float(np.mean(allv))  # tpch.py:161-174
+        stages.append(
+            {
+                "num_tasks": num_tasks,
+                "rough": rough,
+                "waves": (data["fresh_durations"], first, data["rest_wave"]),
+            }
+        )
+    us, vs = np.nonzero(adj)  # row-major == networkx edge order for from_numpy_array
+    return {"n": n, "stages": stages, "edges": list(zip(us.tolist(), vs.tolist()))}
+
+
+# --------------------------------------------------------------------------
+# pack
+# --------------------------------------------------------------------------
+
+_SECTIONS = (
+    ("levels", np.int32),
+    ("tmpl_stage_off", np.int32),
+    ("tmpl_edge_off", np.int32),
+    ("stage_num_tasks", np.int32),
+    ("stage_rough", np.float64),
+    ("stage_parent_mask", np.uint64),
+    ("stage_child_mask", np.uint64),
+    ("stage_first_keymask", np.uint32),
+    ("stage_max_first_lvl", np.int32),
+    ("edges", np.int32),
+    ("desc", np.int32),
+    ("durations", np.int32),
+)
+
+
+def build_pack_arrays(raw: dict) -> dict[str, np.ndarray]:
+    level_set = set()
+    for _, td in raw.values():
+        for st in td.values():
+            for w in WAVES:
+                level_set.update(st[w].keys())
+    levels = sorted(level_set)
+    L = len(levels)
+    assert L <= 32, "first_keymask is 32 bits"
+    lvl_idx = {e: i for i, e in enumerate(levels)}
+
+    tmpl_stage_off = [0]
+    tmpl_edge_off = [0]
+    num_tasks, rough, pmask, cmask, keymask, maxlvl = [], [], [], [], [], []
+    edges: list[tuple[int, int]] = []
+    desc_rows = []
+    dur_chunks: list[np.ndarray] = []
+    dur_off = 0
+
+    for q in range(1, NUM_QUERIES + 1):
+        for size in QUERY_SIZES:
+            adj, td = raw[(size, q)]
+            tc = _template_constants(np.asarray(adj), td)
+            n = tc["n"]
+            assert 1 <= n <= 64, "stage bit masks are 64 bits"
+            assert tc["edges"], "every template needs >= 1 edge (spark_sched_sim.py:254)"
+            pm = [0] * n
+            cm = [0] * n
+            for u, v in tc["edges"]:
+                pm[v] |= 1 << u
+                cm[u] |= 1 << v
+            edges += tc["edges"]
+            for s, st in enumerate(tc["stages"]):
+                num_tasks.append(st["num_tasks"])
+                rough.append(st["rough"])
+                pmask.append(pm[s])
+                cmask.append(cm[s])
+                fresh, first, rest = st["waves"]
+                km = 0
+                for e in first:
+                    km |= 1 << lvl_idx[e]
+                keymask.append(km)
+                maxlvl.append(lvl_idx[max(first)])
+                d = np.full((3, L, 2), -1, dtype=np.int32)
+                d[:, :, 0] = 0
+                seen: dict[int, tuple[int, int]] = {}
+                for w, wave in enumerate((fresh, first, rest)):
+                    for e, lst in wave.items():
+                        key = id(lst)
+                        if key not in seen:  # inherited lists share storage
+                            arr = np.asarray(lst, dtype=np.int32)
+                            seen[key] = (dur_off, arr.size)
+                            dur_chunks.append(arr)
+                            dur_off += arr.size
+                        d[w, lvl_idx[e]] = seen[key]
+                desc_rows.append(d)
+            tmpl_stage_off.append(len(num_tasks))
+            tmpl_edge_off.append(len(edges))
+
+    return {
+        "levels": np.asarray(levels, dtype=np.int32),
+        "tmpl_stage_off": np.asarray(tmpl_stage_off, dtype=np.int32),
+        "tmpl_edge_off": np.asarray(tmpl_edge_off, dtype=np.int32),
+        "stage_num_tasks": np.asarray(num_tasks, dtype=np.int32),
+        "stage_rough": np.asarray(rough, dtype=np.float64),
+        "stage_parent_mask": np.asarray(pmask, dtype=np.uint64),
+        "stage_child_mask": np.asarray(cmask, dtype=np.uint64),
+        "stage_first_keymask": np.asarray(keymask, dtype=np.uint32),
+        "stage_max_first_lvl": np.asarray(maxlvl, dtype=np.int32),
+        "edges": np.asarray(edges, dtype=np.int32).reshape(-1, 2),
+        "desc": np.stack(desc_rows).astype(np.int32),
+        "durations": np.concatenate(dur_chunks).astype(np.int32),
+    }
+
+
+def serialize_pack(arrs: dict[str, np.ndarray]) -> bytes:
+    """flat little-endian blob:
+    magic[8] | i64 header[8] | i64 toc[nsec][2] (byte offset, byte length) | sections (8-aligned)
+
+    header = (n_templates, n_levels, s_max, total_stages, total_edges,
+              total_durations, n_sections, 0)
+    """
+    T = arrs["tmpl_stage_off"].size - 1
+    L = arrs["levels"].size
+    per_t = np.diff(arrs["tmpl_stage_off"])
+    header = [
+        T,
+        L,
+        int(per_t.max()),
+        int(arrs["stage_num_tasks"].size),
+        int(arrs["edges"].shape[0]),
+        int(arrs["durations"].size),
+        len(_SECTIONS),
+        0,
+    ]
+    head_bytes = 8 + 8 * len(header) + 16 * len(_SECTIONS)
+    off = (head_bytes + 7) & ~7
+    toc = []
+    blobs = []
+    for name, dt in _SECTIONS:
+        b = np.ascontiguousarray(arrs[name], dtype=dt).tobytes()
+        toc.append((off, len(b)))
+        pad = (-len(b)) & 7
+        blobs.append(b + b"\0" * pad)
+        off += len(b) + pad
+    out = bytearray()
+    out += PACK_MAGIC
+    out += struct.pack("<8q", *header)
+    for o, n in toc:
+        out += struct.pack("<2q", o, n)
+    out += b"\0" * (((head_bytes + 7) & ~7) - head_bytes)
+    for b in blobs:
+        out += b
+    return bytes(out)
+
+
+def build_pack(raw: dict | None = None, seed: int = DEFAULT_SEED) -> bytes:
+    if raw is None:
+        raw = make_raw_workload(seed)
+    return serialize_pack(build_pack_arrays(raw))
+
+
+def pack_digest(pack: bytes) -> str:
+    return hashlib.sha256(pack).hexdigest()
+
+
+_CACHE: dict[int, bytes] = {}
+
+
+def default_pack(seed: int = DEFAULT_SEED) -> bytes:
+    """the frozen synthetic pack (cached per process)."""
+    if seed not in _CACHE:
+        _CACHE[seed] = build_pack(seed=seed)
+    return _CACHE[seed]
+
+
+def pack_from_reference_layout(root: str) -> bytes:
+    """compile a trace set stored in the reference's on-disk layout (e.g. the real
+    TPC-H traces, if a user has them) into a pack."""
+    raw = {}
+    for size in QUERY_SIZES:
+        for q in range(1, NUM_QUERIES + 1):
+            d = osp.join(root, "data", "tpch", size)
+            adj = np.load(osp.join(d, f"adj_mat_{q}.npy"), allow_pickle=True)
+            td = np.load(osp.join(d, f"task_duration_{q}.npy"), allow_pickle=True).item()
+            raw[(size, q)] = (adj, td)
+    return build_pack(raw)
