@@ -159,9 +159,8 @@ def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls):
         record_obs(obs, reward, info["wall_time"], terminated)
         step += 1
 
-    out = {k: np.asarray(v) for k, v in rec.items()}
-    for k in ("reward", "wall_time", "d_nodes", "d_edges", "d_ptr", "d_sup"):
-        out[k] = out[k].astype(np.uint64)
+    u64_keys = ("reward", "wall_time", "d_nodes", "d_edges", "d_ptr", "d_sup")
+    out = {k: np.array([int(x) for x in v], dtype=np.uint64 if k in u64_keys else np.int64) for k, v in rec.items()}
     out["job_durations"] = np.asarray(metrics.job_durations(env), dtype=np.float64)
     out["avg_job_duration"] = np.float64(env.unwrapped.avg_job_duration) if len(env.unwrapped.job_duration_buff) else np.float64("nan")
     out["num_jobs"] = np.int64(len(env.unwrapped.jobs))

@@ -1,0 +1,35 @@
+"""helpers shared by the golden-fixture tests"""
+from __future__ import annotations
+
+import os.path as osp
+
+import numpy as np
+
+GOLDEN_DIR = osp.join(osp.dirname(osp.abspath(__file__)), "golden")
+ALL_SETS = ["tiny_hash", "tiny_fair_tlimit", "c1_fair", "c1_hash", "c1_fifo", "c3_fair", "c3_hash",
+            "testyaml_fair", "bige_hash"]
+
+
+class Golden:
+    def __init__(self, name: str):
+        self.name = name
+        self.z = np.load(osp.join(GOLDEN_DIR, f"{name}.npz"))
+        keys = self.z["cfg_keys"].tolist()
+        vals = self.z["cfg_vals"].tolist()
+        self.cfg = {}
+        for k, v in zip(keys, vals):
+            if k in ("num_executors", "job_arrival_cap"):
+                self.cfg[k] = None if np.isnan(v) else int(v)
+            else:
+                self.cfg[k] = float(v)
+        self.time_limit = float(self.z["time_limit"])
+        self.seeds = [int(s) for s in self.z["seeds"]]
+        self.policy = str(self.z["policy"])
+        self.pack_sha256 = str(self.z["pack_sha256"])
+
+    def ep(self, seed: int, key: str):
+        return self.z[f"s{seed}_{key}"]
+
+
+def bits(x) -> int:
+    return int(np.float64(x).view(np.uint64))
