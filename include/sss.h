@@ -1,0 +1,106 @@
+/* include/sss.h - C ABI of the MI355X-native batched Spark-scheduling simulator.
+ *
+ * This is the drop-in boundary for the reference's hot path: everything below
+ * `SparkSchedSimEnv.reset()/step()` (reference spark_sched_sim/spark_sched_sim.py:127-221),
+ * batched over `num_envs` independent environments, one wavefront per environment.
+ * The reference is pure Python with no FFI of its own; these entry points are what a binding
+ * for this path binds (INTEGRATION.md shows the ctypes stub the reference would add, and
+ * spark_sched_sim_amd/binding.py is that stub in this repo).
+ *
+ * Conventions: plain C types only; every pointer named *_dev is a device pointer owned by the
+ * caller (torch tensors in the Python host); calls are asynchronous on the HIP stream passed
+ * as `void* stream` (NULL = default stream); return 0 on success, otherwise a negative code
+ * and sss_last_error() describes it. A handle is not re-entrant.
+ */
+#ifndef SSS_H
+#define SSS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sss_handle sss_handle;
+
+/* env_cfg of the reference (spark_sched_sim.py:34-52, data_samplers/tpch.py:19-26) */
+typedef struct sss_cfg {
+  int32_t num_executors;   /* env_cfg["num_executors"], 1..64 */
+  int32_t job_arrival_cap; /* env_cfg.get("job_arrival_cap"); <= 0 means None */
+  int32_t max_jobs;        /* arena capacity in jobs; 0 = job_arrival_cap (required when cap is None) */
+  int32_t reserved;
+  double job_arrival_rate; /* tpch.py:21,42 (jobs per ms) */
+  double moving_delay;     /* spark_sched_sim.py:40 */
+  double warmup_delay;     /* tpch.py:24,43 */
+  double beta;             /* spark_sched_sim.py:44 */
+} sss_cfg;
+
+/* sizes the caller needs to allocate the buffers below (all per env unless noted) */
+typedef struct sss_dims {
+  int32_t num_envs, num_executors, job_cap, stage_stride;
+  int32_t node_cap;    /* rows of nodes[env]            */
+  int32_t edge_cap;    /* rows of edge_links[env]       */
+  int32_t obs_i32;     /* ints per env in obs_i32       */
+  int32_t obs_f64;     /* doubles per env in obs_f64    */
+  int64_t state_bytes; /* whole arena, all envs; must be zero-initialised */
+  int64_t env_stride;  /* bytes per env inside the arena */
+  /* byte offsets inside one env's arena block of arrays the host may view zero-copy
+   * (replaces the attribute reads of reference metrics.py:4-23, rollout_worker.py:122-129) */
+  int64_t off_t_arrival, off_t_completed, off_jobs, off_active, off_dur_ring;
+  int32_t job_rec_bytes, hdr_bytes;
+} sss_dims;
+
+/* raw device pointers of caller-allocated buffers (observation = reference spark_sched_sim.py:345-406) */
+typedef struct sss_buffers {
+  void* state_dev;            /* uint8 [state_bytes]                                   */
+  float* nodes_dev;           /* f32  [num_envs][node_cap][3]  dag_batch.nodes          */
+  int32_t* edge_links_dev;    /* i32  [num_envs][edge_cap][2]  dag_batch.edge_links     */
+  int32_t* dag_ptr_dev;       /* i32  [num_envs][job_cap + 1]  dag_ptr                  */
+  int32_t* exec_supplies_dev; /* i32  [num_envs][job_cap]      exec_supplies            */
+  int32_t* obs_i32_dev;       /* i32  [num_envs][8]: n_nodes, n_edges, n_active_jobs, n_schedulable,
+                                 num_committable_execs, source_job_idx, terminated, err */
+  double* obs_f64_dev;        /* f64  [num_envs][2]: reward, wall_time                  */
+} sss_buffers;
+
+/* per-env error codes reported in obs_i32[..][7] (reference exceptions they stand for) */
+enum {
+  SSS_E_OK = 0,
+  SSS_E_ACTION_SPACE = 1, /* ValueError spark_sched_sim.py:276-277 */
+  SSS_E_STAGE_IDX = 2,    /* KeyError   spark_sched_sim.py:284     */
+  SSS_E_TOO_MANY = 4,     /* ValueError spark_sched_sim.py:294-295 */
+  SSS_E_STALLED = 5,      /* AssertionError "[step]" spark_sched_sim.py:212-215 */
+  SSS_E_NO_DURATION = 6,  /* KeyError/ValueError out of tpch.py:88-106 */
+  SSS_E_INVARIANT = 7,    /* any other reference assert */
+  SSS_E_NEED_RESET = 8,   /* step() on a finished / failed episode */
+  SSS_E_NO_LIMIT = 9,     /* ValueError spark_sched_sim.py:137-138 */
+  SSS_E_CAPACITY = 10     /* more jobs than max_jobs (time-limit mode) */
+};
+
+/* Host-only: validates cfg + workload pack (spark_sched_sim_amd/workload.py format) and reports
+ * buffer sizes. Replaces nothing in the reference (Python allocates as it goes). */
+int sss_query_dims(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, sss_dims* out);
+
+/* Replaces SparkSchedSimEnv.__init__ (spark_sched_sim.py:34-125) + TPCHDataSampler.__init__
+ * (tpch.py:19-52): copies the pack and the derived constants to device `device`. */
+int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, int device, sss_handle** out);
+
+int sss_bind_buffers(sss_handle* h, const sss_buffers* buffers);
+
+/* Replaces SparkSchedSimEnv.reset(seed, options) (spark_sched_sim.py:127-186) for every env whose
+ * mask byte is non-zero (mask_dev NULL = all). seeds_dev: u64[num_envs]; time_limits_dev:
+ * f64[num_envs] or NULL (= inf, options["time_limit"]). Writes the first observation. */
+int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double* time_limits_dev, const uint8_t* mask_dev, void* stream);
+
+/* Replaces SparkSchedSimEnv.step(action) (spark_sched_sim.py:188-221) for all envs:
+ * action = {"stage_idx": stage_idx_dev[i], "num_exec": num_exec_dev[i]}. Writes reward, wall_time,
+ * terminated, err and the next observation. auto_reset != 0: an env found terminated at entry
+ * starts its next episode instead (seed = previous seed + seed_stride), reward 0. */
+int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, void* stream);
+
+const char* sss_last_error(void);
+void sss_destroy(sss_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

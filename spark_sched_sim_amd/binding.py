@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI in include/sss.h (libsss_hip.so, built by spark_sched_sim_amd/build.py).
+
+The product path is the HIP library and nothing else: `load_library()` raises if it is missing
+or cannot be loaded - there is no CPU fallback. (The test-suite can inject another library
+object that exports the same ABI - the CPU wave emulator under tests/emu - through the `lib`
+argument of `Binding`; that is test plumbing, not a fallback: nothing in this package looks for it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os.path as osp
+
+CSRC = osp.join(osp.dirname(osp.abspath(__file__)), "csrc")
+LIB_NAME = "libsss_hip.so"
+
+
+class SssCfg(C.Structure):
+    _fields_ = [("num_executors", C.c_int32), ("job_arrival_cap", C.c_int32), ("max_jobs", C.c_int32),
+                ("reserved", C.c_int32), ("job_arrival_rate", C.c_double), ("moving_delay", C.c_double),
+                ("warmup_delay", C.c_double), ("beta", C.c_double)]
+
+
+class SssDims(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_executors", C.c_int32), ("job_cap", C.c_int32),
+                ("stage_stride", C.c_int32), ("node_cap", C.c_int32), ("edge_cap", C.c_int32),
+                ("obs_i32", C.c_int32), ("obs_f64", C.c_int32), ("state_bytes", C.c_int64),
+                ("env_stride", C.c_int64), ("off_t_arrival", C.c_int64), ("off_t_completed", C.c_int64),
+                ("off_jobs", C.c_int64), ("off_active", C.c_int64), ("off_dur_ring", C.c_int64),
+                ("job_rec_bytes", C.c_int32), ("hdr_bytes", C.c_int32)]
+
+
+class SssBuffers(C.Structure):
+    _fields_ = [("state_dev", C.c_void_p), ("nodes_dev", C.c_void_p), ("edge_links_dev", C.c_void_p),
+                ("dag_ptr_dev", C.c_void_p), ("exec_supplies_dev", C.c_void_p), ("obs_i32_dev", C.c_void_p),
+                ("obs_f64_dev", C.c_void_p)]
+
+
+ERROR_NAMES = {
+    1: "invalid action: does not belong to the action space",
+    2: "invalid action: stage_idx is not a schedulable stage",
+    4: "invalid action: too many executors requested",
+    5: "[step]: simulation stalled with no committable executors or schedulable stages",
+    6: "no task-duration data for the sampled executor level",
+    7: "internal invariant violated",
+    8: "episode is over or failed: reset() required",
+    9: "must either have a limit on job arrivals or time.",
+    10: "more job arrivals than max_jobs",
+}
+
+EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_last_error", "sss_destroy"]
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or osp.join(CSRC, LIB_NAME)
+    if not osp.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or spark_sched_sim_amd/build.py). "
+            "There is no CPU fallback.")
+    return C.CDLL(path)
+
+
+class Binding:
+    def __init__(self, lib: C.CDLL | None = None):
+        self.lib = lib if lib is not None else load_library()
+        L = self.lib
+        L.sss_query_dims.argtypes = [C.POINTER(SssCfg), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(SssDims)]
+        L.sss_create.argtypes = [C.POINTER(SssCfg), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.sss_bind_buffers.argtypes = [C.c_void_p, C.POINTER(SssBuffers)]
+        L.sss_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sss_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+        L.sss_last_error.restype = C.c_char_p
+        L.sss_destroy.argtypes = [C.c_void_p]
+
+    def check(self, rc: int) -> None:
+        if rc != 0:
+            raise ValueError(f"sss error {rc}: {self.lib.sss_last_error().decode()}")
+
+    def query_dims(self, cfg: SssCfg, pack: bytes, num_envs: int) -> SssDims:
+        d = SssDims()
+        self.check(self.lib.sss_query_dims(C.byref(cfg), pack, len(pack), num_envs, C.byref(d)))
+        return d
+
+    def create(self, cfg: SssCfg, pack: bytes, num_envs: int, device: int) -> C.c_void_p:
+        h = C.c_void_p()
+        self.check(self.lib.sss_create(C.byref(cfg), pack, len(pack), num_envs, device, C.byref(h)))
+        return h

@@ -1,0 +1,33 @@
+// sss_hip.hip - gfx950 build of the simulator: kernels (sss_sim.h) + the C ABI (sss_host.h) on
+// the HIP runtime. Built by __graft_entry__.build() / spark_sched_sim_amd/build.py with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// (-ffp-contract=off: the f64 arithmetic must round exactly like the reference's; no FMA fusion).
+#include <hip/hip_runtime.h>
+
+#include "sss_sim.h"
+
+#include <stdint.h>
+#include "zig_tables.inc"
+
+static int be_set_device(int device) { return (int)hipSetDevice(device); }
+static const char* be_error(int rc) { return hipGetErrorString((hipError_t)rc); }
+static void* be_alloc(size_t n) {
+  void* p = nullptr;
+  return hipMalloc(&p, n) == hipSuccess ? p : nullptr;
+}
+static void be_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+static int be_h2d(void* dst, const void* src, size_t n) { return (int)hipMemcpy(dst, src, n, hipMemcpyHostToDevice); }
+
+static int be_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* seeds, const double* tl, const uint8_t* mask, void* stream) {
+  hipLaunchKernelGGL(sss_reset_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, seeds, tl, mask);
+  return (int)hipGetLastError();
+}
+static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
+                          void* stream) {
+  hipLaunchKernelGGL(sss_step_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset, seed_stride);
+  return (int)hipGetLastError();
+}
+
+#include "sss_host.h"

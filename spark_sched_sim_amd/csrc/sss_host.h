@@ -1,0 +1,220 @@
+// sss_host.h - host side of the C ABI (include/sss.h): argument checking, layout, constant
+// upload, kernel launches. The including translation unit supplies the five be_* primitives
+// (spark_sched_sim_amd/csrc/sss_hip.hip: HIP runtime; tests/emu/emu_backend.cpp: the CPU wave
+// emulator used by the test-suite) and includes sss_sim.h for SssKernelArgs.
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sss.h"
+#include "sss_layout.h"
+
+static thread_local std::string g_sss_err;
+static int sss_fail(int code, const std::string& msg) {
+  g_sss_err = msg;
+  return code;
+}
+
+struct SssPackHost {
+  int T, L, s_max, total_stages, total_edges, total_durations;
+  int64_t sec_off[12], sec_len[12];
+  int max_edges_per_job;
+};
+
+static int sss_pack_parse(const uint8_t* p, size_t n, SssPackHost* v) {
+  if (!p || n < 8 + 64 + 12 * 16 || memcmp(p, "SSSPACK2", 8) != 0) return -1;
+  int64_t h[8];
+  memcpy(h, p + 8, sizeof(h));
+  v->T = (int)h[0], v->L = (int)h[1], v->s_max = (int)h[2], v->total_stages = (int)h[3];
+  v->total_edges = (int)h[4], v->total_durations = (int)h[5];
+  if (h[6] != 12) return -1;
+  for (int i = 0; i < 12; i++) {
+    int64_t e[2];
+    memcpy(e, p + 8 + 64 + 16 * i, 16);
+    if (e[0] < 0 || e[1] < 0 || (size_t)(e[0] + e[1]) > n || (e[0] & 7)) return -1;
+    v->sec_off[i] = e[0], v->sec_len[i] = e[1];
+  }
+  if (v->T != 154 || v->L < 1 || v->L > SSS_MAX_LEVELS || v->s_max < 1 || v->s_max > SSS_MAX_STAGES) return -1;
+  const int32_t* eo = (const int32_t*)(p + v->sec_off[2]);
+  int me = 0;
+  for (int t = 0; t < v->T; t++) me = eo[t + 1] - eo[t] > me ? eo[t + 1] - eo[t] : me;
+  v->max_edges_per_job = me;
+  if (me > 255) return -1;
+  return 0;
+}
+
+struct sss_handle {
+  sss_cfg cfg;
+  SssPackHost ph;
+  SssLayout L;
+  SssBuffers B;
+  bool bound;
+  int device;
+  void* pack_dev;
+  void* zig_dev;
+  SssCfgDev* cfg_dev;
+  SssPackDev* pk_dev;
+};
+
+static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, SssPackHost* ph, int* J_cap) {
+  if (!cfg) return sss_fail(-1, "cfg is NULL");
+  if (sss_pack_parse((const uint8_t*)pack, pack_bytes, ph)) return sss_fail(-2, "workload pack is malformed (expected SSSPACK2, 154 templates, <= 64 stages/job, <= 255 edges/job)");
+  if (num_envs < 1) return sss_fail(-3, "num_envs must be >= 1");
+  if (cfg->num_executors < 1 || cfg->num_executors > SSS_MAX_EXEC) return sss_fail(-4, "num_executors must be in [1, 64] (one lane per executor)");
+  int cap = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0;
+  int jc = cfg->max_jobs > 0 ? cfg->max_jobs : cap;
+  if (jc <= 0) return sss_fail(-5, "max_jobs is required when job_arrival_cap is None");
+  if (cap > jc) return sss_fail(-5, "max_jobs is smaller than job_arrival_cap");
+  if (jc > SSS_MAX_JOBS) return sss_fail(-5, "job capacity above 1024 is not supported by this build");
+  if (!(cfg->job_arrival_rate > 0)) return sss_fail(-6, "job_arrival_rate must be > 0");
+  if (!(cfg->beta >= 0)) return sss_fail(-6, "beta must be >= 0");
+  *J_cap = jc;
+  return 0;
+}
+
+// TPCHDataSampler._init_executor_intervals (reference data_samplers/tpch.py:237-262)
+static void sss_executor_intervals(int cap, double iv[][2]) {
+  static const int lv[8] = {5, 10, 20, 40, 50, 60, 80, 100};
+  for (int r = 0; r <= cap; r++) iv[r][0] = iv[r][1] = 0;
+  auto rows = [&](int lo, int hi, double a, double b) {
+    for (int r = lo < 0 ? 0 : lo; r < hi && r <= cap; r++) iv[r][0] = a, iv[r][1] = b;
+  };
+  rows(0, lv[0] + 1, lv[0], lv[0]);
+  for (int i = 0; i < 7; i++) {
+    rows(lv[i] + 1, lv[i + 1], lv[i], lv[i + 1]);
+    if (lv[i + 1] > cap) break;
+    rows(lv[i + 1], lv[i + 1] + 1, lv[i + 1], lv[i + 1]);
+  }
+  if (cap > lv[7])
+    for (int r = lv[7] + 1; r < cap; r++) iv[r][0] = iv[r][1] = lv[7];
+}
+
+static void sss_fill_dims(const SssLayout& L, sss_dims* d) {
+  memset(d, 0, sizeof(*d));
+  d->num_envs = L.num_envs, d->num_executors = L.E, d->job_cap = L.J_cap, d->stage_stride = L.SP;
+  d->node_cap = L.n_cap, d->edge_cap = L.ed_cap, d->obs_i32 = SSS_OBS_I32, d->obs_f64 = SSS_OBS_F64;
+  d->state_bytes = L.state_bytes, d->env_stride = L.env_stride;
+  d->off_t_arrival = L.off_t_arrival, d->off_t_completed = L.off_t_completed, d->off_jobs = L.off_jobs;
+  d->off_active = L.off_active, d->off_dur_ring = L.off_dur_ring;
+  d->job_rec_bytes = (int32_t)sizeof(SssJob), d->hdr_bytes = (int32_t)sizeof(SssHdr);
+}
+
+extern "C" int sss_query_dims(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, sss_dims* out) {
+  SssPackHost ph;
+  int J_cap;
+  if (int rc = sss_validate(cfg, pack, pack_bytes, num_envs, &ph, &J_cap)) return rc;
+  if (!out) return sss_fail(-1, "out is NULL");
+  SssLayout L;
+  sss_compute_layout(&L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job);
+  sss_fill_dims(L, out);
+  return 0;
+}
+
+extern "C" const char* sss_last_error(void) { return g_sss_err.c_str(); }
+
+extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, int device, sss_handle** out) {
+  SssPackHost ph;
+  int J_cap;
+  if (int rc = sss_validate(cfg, pack, pack_bytes, num_envs, &ph, &J_cap)) return rc;
+  if (!out) return sss_fail(-1, "out is NULL");
+  if (int rc = be_set_device(device)) return sss_fail(-10, "cannot select device " + std::to_string(device) + ": " + be_error(rc));
+  sss_handle* h = new sss_handle();
+  h->cfg = *cfg, h->ph = ph, h->device = device, h->bound = false;
+  sss_compute_layout(&h->L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job);
+  memset(&h->B, 0, sizeof(h->B));
+
+  // pack + ziggurat tables -> device
+  h->pack_dev = be_alloc(pack_bytes);
+  std::vector<uint8_t> zig(256 * 8 * 3);
+  memcpy(zig.data(), ZIG_KE, 2048), memcpy(zig.data() + 2048, ZIG_WE, 2048), memcpy(zig.data() + 4096, ZIG_FE, 2048);
+  h->zig_dev = be_alloc(zig.size());
+  h->cfg_dev = (SssCfgDev*)be_alloc(sizeof(SssCfgDev));
+  h->pk_dev = (SssPackDev*)be_alloc(sizeof(SssPackDev));
+  if (!h->pack_dev || !h->zig_dev || !h->cfg_dev || !h->pk_dev) {
+    sss_destroy(h);
+    return sss_fail(-11, "device allocation failed");
+  }
+  be_h2d(h->pack_dev, pack, pack_bytes);
+  be_h2d(h->zig_dev, zig.data(), zig.size());
+
+  SssPackDev pk;
+  memset(&pk, 0, sizeof(pk));
+  pk.T = ph.T, pk.L = ph.L, pk.s_max = ph.s_max, pk.total_stages = ph.total_stages, pk.total_edges = ph.total_edges;
+  pk.total_durations = ph.total_durations;
+  const uint8_t* b = (const uint8_t*)h->pack_dev;
+  pk.levels = (const int32_t*)(b + ph.sec_off[0]);
+  pk.tmpl_stage_off = (const int32_t*)(b + ph.sec_off[1]);
+  pk.tmpl_edge_off = (const int32_t*)(b + ph.sec_off[2]);
+  pk.stage_num_tasks = (const int32_t*)(b + ph.sec_off[3]);
+  pk.stage_rough = (const double*)(b + ph.sec_off[4]);
+  pk.stage_parent_mask = (const uint64_t*)(b + ph.sec_off[5]);
+  pk.stage_child_mask = (const uint64_t*)(b + ph.sec_off[6]);
+  pk.stage_first_keymask = (const uint32_t*)(b + ph.sec_off[7]);
+  pk.stage_max_first_lvl = (const int32_t*)(b + ph.sec_off[8]);
+  pk.edges = (const int32_t*)(b + ph.sec_off[9]);
+  pk.desc = (const int32_t*)(b + ph.sec_off[10]);
+  pk.durations = (const int32_t*)(b + ph.sec_off[11]);
+  pk.zig_ke = (const uint64_t*)h->zig_dev;
+  pk.zig_we = (const double*)((const uint8_t*)h->zig_dev + 2048);
+  pk.zig_fe = (const double*)((const uint8_t*)h->zig_dev + 4096);
+  be_h2d(h->pk_dev, &pk, sizeof(pk));
+
+  SssCfgDev cd;
+  memset(&cd, 0, sizeof(cd));
+  cd.E = cfg->num_executors, cd.cap_cfg = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0, cd.J_cap = J_cap, cd.SP = ph.s_max;
+  cd.mean_interarrival = 1 / cfg->job_arrival_rate;  // tpch.py:42
+  cd.moving_delay = cfg->moving_delay, cd.warmup_delay = cfg->warmup_delay, cd.beta = cfg->beta;
+  sss_executor_intervals(cd.E, cd.intervals);
+  const int32_t* levels = (const int32_t*)((const uint8_t*)pack + ph.sec_off[0]);
+  for (int r = 0; r <= cd.E; r++)
+    for (int k = 0; k < 2; k++) {
+      cd.interval_lvl[r][k] = -1;
+      for (int l = 0; l < ph.L; l++)
+        if ((double)levels[l] == cd.intervals[r][k]) cd.interval_lvl[r][k] = (int8_t)l;
+    }
+  be_h2d(h->cfg_dev, &cd, sizeof(cd));
+  *out = h;
+  return 0;
+}
+
+extern "C" int sss_bind_buffers(sss_handle* h, const sss_buffers* b) {
+  if (!h || !b) return sss_fail(-1, "NULL argument");
+  if (!b->state_dev || !b->nodes_dev || !b->edge_links_dev || !b->dag_ptr_dev || !b->exec_supplies_dev || !b->obs_i32_dev || !b->obs_f64_dev)
+    return sss_fail(-20, "every buffer in sss_buffers must be provided");
+  if (((uintptr_t)b->state_dev) & 255) return sss_fail(-21, "state_dev must be 256-byte aligned");
+  h->B.state = b->state_dev, h->B.nodes = b->nodes_dev, h->B.edge_links = b->edge_links_dev, h->B.dag_ptr = b->dag_ptr_dev;
+  h->B.exec_supplies = b->exec_supplies_dev, h->B.obs_i32 = b->obs_i32_dev, h->B.obs_f64 = b->obs_f64_dev;
+  h->bound = true;
+  return 0;
+}
+
+static SssKernelArgs sss_args(const sss_handle* h) {
+  SssKernelArgs a;
+  a.L = h->L, a.B = h->B, a.cfg = h->cfg_dev, a.pk = h->pk_dev;
+  return a;
+}
+
+extern "C" int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double* time_limits_dev, const uint8_t* mask_dev, void* stream) {
+  if (!h || !seeds_dev) return sss_fail(-1, "NULL argument");
+  if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  if (int rc = be_launch_reset(sss_args(h), h->L.num_envs, seeds_dev, time_limits_dev, mask_dev, stream)) return sss_fail(-30, std::string("reset launch failed: ") + be_error(rc));
+  return 0;
+}
+
+extern "C" int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, void* stream) {
+  if (!h || !stage_idx_dev || !num_exec_dev) return sss_fail(-1, "NULL argument");
+  if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  if (int rc = be_launch_step(sss_args(h), h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("step launch failed: ") + be_error(rc));
+  return 0;
+}
+
+extern "C" void sss_destroy(sss_handle* h) {
+  if (!h) return;
+  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->cfg_dev), be_free(h->pk_dev);
+  delete h;
+}

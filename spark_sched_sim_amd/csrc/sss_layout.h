@@ -1,0 +1,189 @@
+// sss_layout.h - how one simulated environment is laid out in HBM (host + device view).
+//
+// One env = one contiguous, 256-byte aligned block of the state arena (torch-owned). A
+// wavefront owns exactly one env for the duration of a launch, so what has to be cheap is
+// "one wave streams its env's hot block into LDS with full-width loads" - not "64 envs read
+// the same field". The block therefore starts with a fixed-size HOT region (header scalars,
+// the per-executor event slots = the event "heap", the commitment list) that is copied
+// HBM -> LDS -> HBM verbatim with 16-byte lane accesses, followed by the per-job / per-stage /
+// per-pool arrays that are touched sparsely and stay in HBM (L2 / MALL resident).
+#pragma once
+#include <stdint.h>
+
+#define SSS_MAX_EXEC 64       // one lane per executor
+#define SSS_MAX_STAGES 64     // stage bit masks are 64 bits
+#define SSS_MAX_JOBS 1024     // job ids are 16 bit; job-id set scratch lives in LDS (sss_sim.h)
+#define SSS_JOBSET_SLOTS 2048  // CPython table for <= 1228 distinct small ints
+#define SSS_MAX_LEVELS 16
+#define SSS_SET_TABLE 256     // bytes per pool-set image (max CPython table for <= 64 small ints)
+#define SSS_DUR_RING 200      // deque(maxlen=200), reference spark_sched_sim.py:83
+#define SSS_OBS_I32 8
+#define SSS_OBS_F64 2
+
+// obs_i32[env][k]
+enum { OBS_N_NODES = 0, OBS_N_EDGES, OBS_N_JOBS, OBS_N_SCHED, OBS_NUM_COMMITTABLE, OBS_SOURCE_JOB_IDX, OBS_TERMINATED, OBS_ERR };
+// obs_f64[env][k]
+enum { OBS_REWARD = 0, OBS_WALL_TIME };
+
+// error codes (per env, sticky until reset for everything but the three invalid-action codes)
+enum {
+  SSS_OK = 0,
+  SSS_ERR_ACTION_SPACE = 1,  // reference ValueError spark_sched_sim.py:276-277
+  SSS_ERR_STAGE_IDX = 2,     // reference KeyError  :284 (stage_idx >= number of schedulable stages)
+  SSS_ERR_TOO_MANY = 4,      // reference ValueError :294-295
+  SSS_ERR_STALLED = 5,       // reference AssertionError "[step]" :212-215
+  SSS_ERR_NO_DURATION = 6,   // KeyError/ValueError escaping tpch.py:88-106
+  SSS_ERR_INVARIANT = 7,     // any other reference assert / container error
+  SSS_ERR_NEED_RESET = 8,    // stepping a finished or failed episode
+  SSS_ERR_NO_LIMIT = 9,      // reference ValueError :137-138
+  SSS_ERR_CAPACITY = 10      // more jobs than the arena was sized for (time-limit mode)
+};
+
+enum { EV_NONE = 0, EV_TASK_FINISHED = 2, EV_EXECUTOR_READY = 3 };
+
+// pool keys: (job+1) << 8 | (stage+1); common pool = 0; "None" = 0xFFFFFFFF
+#define POOL_NONE 0xFFFFFFFFu
+#define POOL_COMMON 0u
+
+struct SssHdr {            // 256 bytes
+  uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
+  uint32_t rng_has32, rng_u32;
+  double wall_time;
+  double time_limit;
+  uint64_t seed;           // seed of the current episode
+  uint64_t n_steps;        // real step() calls completed over the env's lifetime
+  uint64_t n_events;       // events popped over the env's lifetime
+  uint64_t model_bytes;    // SURVEY 8(d) algorithmic byte counter (sum of B_step)
+  uint32_t counter;        // event push sequence (components/event.py:25)
+  int32_t next_arrival;    // cursor into the time-sorted arrivals
+  int32_t J;               // realised number of jobs this episode
+  int32_t n_active;        // len(active_job_ids)
+  int32_t n_completed;
+  uint32_t curr_source;    // pool key
+  int32_t n_sched;         // len(schedulable_stages)
+  int32_t obs_n_nodes;     // action_space["stage_idx"].n - 1 at the last _observe
+  int32_t obs_n_sched;     // len(stage_selection_map)
+  int32_t n_commits;       // live entries in the commitment list
+  uint32_t commit_seq;
+  int32_t supply_none;     // _total_executor_count[None]
+  int32_t terminated;
+  int32_t err;
+  int32_t need_reset;
+  int32_t dur_head, dur_n;
+  int32_t episodes;        // completed episodes (auto-reset bookkeeping)
+  double last_reward;
+  uint8_t pad[256 - 4 * 8 - 2 * 4 - 2 * 8 - 4 * 8 - 18 * 4 - 8];
+};
+
+struct SssHot {            // staged HBM <-> LDS as a flat block
+  SssHdr h;
+  // event slots: one pending event per executor at most (TASK_FINISHED while busy,
+  // EXECUTOR_READY while moving); the queue's pop is a wave-wide arg-min over (t, seq)
+  double ev_t[SSS_MAX_EXEC];
+  uint32_t ev_seq[SSS_MAX_EXEC];
+  uint32_t ex_loc[SSS_MAX_EXEC];       // pool key, POOL_NONE while moving
+  int16_t ev_job[SSS_MAX_EXEC];
+  int16_t ex_job[SSS_MAX_EXEC];        // executor.job_id, -1 = None
+  int8_t ev_stage[SSS_MAX_EXEC];
+  uint8_t ev_kind[SSS_MAX_EXEC];
+  int8_t ex_task_stage[SSS_MAX_EXEC];  // executor.task.stage_id, -1 = task is None
+  uint8_t ex_executing[SSS_MAX_EXEC];
+  // commitments: insertion-ordered dict-of-dicts flattened; order within a source = c_seq
+  uint32_t c_src[SSS_MAX_EXEC];
+  uint32_t c_dst[SSS_MAX_EXEC];
+  uint32_t c_seq[SSS_MAX_EXEC];
+  int16_t c_n[SSS_MAX_EXEC];
+  uint8_t pad2[128];
+};
+
+struct SssJob {            // 64 bytes, one cache line
+  uint64_t active_mask;    // job.active_stages
+  uint64_t frontier_mask;  // job.frontier_stages
+  uint64_t selected_mask;  // env.selected_stages restricted to this job
+  uint64_t sched_mask;     // env.schedulable_stages restricted to this job
+  uint64_t sat_mask;       // derived: bit s <=> executor demand of stage s <= 0
+  uint64_t local_mask;     // job.local_executors
+  int16_t tmpl;
+  int16_t supply;          // exec_tracker._total_executor_count[job]
+  int16_t sat_count;       // job.saturated_stage_count
+  int16_t completion_order;
+  uint8_t n_stages;
+  uint8_t n_edges;         // template edges
+  uint16_t pad;
+  int32_t gs_base;         // first stage row of the template in the pack
+};
+
+struct SssStage {          // 8 bytes
+  int16_t remaining, executing, commit_to, moving_to;
+};
+
+struct SssPoolHdr {        // 8 bytes: CPython set header + outgoing commitment count
+  uint16_t mask, fill, used;
+  int16_t commit_from;
+};
+
+// per-env byte offsets, filled on the host by sss_compute_layout
+struct SssLayout {
+  int32_t num_envs, E, J_cap, SP, L, n_pools, n_cap, ed_cap, max_edges_per_job;
+  int32_t pad_;
+  int64_t off_active, off_jobs, off_t_arrival, off_t_completed, off_stages, off_durations;
+  int64_t off_pool_hdr, off_pool_tab, off_dur_ring, off_old_active, env_stride, state_bytes;
+};
+
+struct SssCfgDev {
+  int32_t E, cap_cfg, J_cap, SP;
+  double mean_interarrival, moving_delay, warmup_delay, beta;
+  double intervals[SSS_MAX_EXEC + 1][2];  // tpch.py:237-262
+  int8_t interval_lvl[SSS_MAX_EXEC + 1][2];  // level index of each endpoint, -1 if not a pack level
+};
+
+// read-only workload pack, device pointers (see spark_sched_sim_amd/workload.py)
+struct SssPackDev {
+  int32_t T, L, s_max, total_stages, total_edges, total_durations;
+  const int32_t *levels, *tmpl_stage_off, *tmpl_edge_off, *stage_num_tasks;
+  const double* stage_rough;
+  const uint64_t *stage_parent_mask, *stage_child_mask;
+  const uint32_t* stage_first_keymask;
+  const int32_t *stage_max_first_lvl, *edges, *desc, *durations;
+  const uint64_t* zig_ke;
+  const double *zig_we, *zig_fe;
+};
+
+struct SssBuffers {        // raw device pointers of torch-allocated tensors
+  void* state;             // uint8[state_bytes]
+  float* nodes;            // f32[B][n_cap][3]
+  int32_t* edge_links;     // i32[B][ed_cap][2]
+  int32_t* dag_ptr;        // i32[B][J_cap + 1]
+  int32_t* exec_supplies;  // i32[B][J_cap]
+  int32_t* obs_i32;        // i32[B][SSS_OBS_I32]
+  double* obs_f64;         // f64[B][SSS_OBS_F64]
+};
+
+static inline int64_t sss_align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_cap, int SP, int n_levels, int max_edges_per_job) {
+  L->num_envs = num_envs, L->E = E, L->J_cap = J_cap, L->SP = SP, L->L = n_levels;
+  L->n_pools = 1 + J_cap + J_cap * SP;
+  L->n_cap = J_cap * SP;
+  L->max_edges_per_job = max_edges_per_job;
+  L->ed_cap = J_cap * max_edges_per_job;
+  L->pad_ = 0;
+  int64_t o = (int64_t)sizeof(SssHot);
+  L->off_active = o, o = sss_align(o + 2 * (int64_t)J_cap, 64);
+  L->off_jobs = o, o += (int64_t)sizeof(SssJob) * J_cap;
+  L->off_t_arrival = o, o += 8 * (int64_t)J_cap;
+  L->off_t_completed = o, o += 8 * (int64_t)J_cap;
+  L->off_stages = o, o = sss_align(o + 8 * (int64_t)J_cap * SP, 64);
+  L->off_durations = o, o = sss_align(o + 4 * (int64_t)J_cap * SP, 64);
+  L->off_pool_hdr = o, o = sss_align(o + 8 * (int64_t)L->n_pools, 64);
+  L->off_pool_tab = o, o += (int64_t)SSS_SET_TABLE * L->n_pools;
+  L->off_dur_ring = o, o += 8 * SSS_DUR_RING;
+  L->off_old_active = o, o += 2 * (int64_t)J_cap;
+  L->env_stride = sss_align(o, 256);
+  L->state_bytes = L->env_stride * num_envs;
+}
+
+static_assert(sizeof(SssHdr) == 256, "SssHdr must be 256 bytes");
+static_assert(sizeof(SssHot) % 16 == 0, "SssHot is copied with 16-byte accesses");
+static_assert(sizeof(SssJob) == 64, "SssJob must be one 64-byte line");
+static_assert(sizeof(SssStage) == 8 && sizeof(SssPoolHdr) == 8, "packed records");

@@ -1,0 +1,1474 @@
+// sss_sim.h - the batched Spark-scheduling simulator, device side (gfx950, wave64).
+//
+// One wavefront (one 64-thread workgroup) simulates one environment. The env's hot block
+// (header, per-executor event slots, commitment list) is staged HBM -> LDS at kernel entry and
+// written back at exit. Inside a launch the wave alternates between
+//   * serial phases, executed by lane 0 only (the discrete-event logic is one dependent chain
+//     per env by construction), and
+//   * wave-parallel phases: the event-queue pop (arg-min over one lane per executor), the
+//     schedulable-stage scan (one lane per stage, ballot), the observation writer (lanes over
+//     stages / edges with ballot prefix compaction), state staging and episode initialisation,
+// separated by wave_sync(). Collectives are only issued from wave-uniform control flow; the
+// branch conditions come from LDS flags lane 0 publishes before the sync.
+//
+// What each function restates is cited as ENV:n (reference spark_sched_sim/spark_sched_sim.py),
+// TRK:n (components/executor_tracker.py), JOB:n (components/job.py), STG:n (components/stage.py),
+// TPCH:n (data_samplers/tpch.py), EVQ:n (components/event.py). Behavioural quirks that must be
+// kept are listed in SURVEY.md appendix B; the CPython-set and numpy-Generator models are
+// described in DESIGN.md ("Third-party semantics").
+//
+// No oracle code is used here: this is an independent implementation on different data
+// structures (bit masks, flat slot arrays, fixed-capacity set images); tests compare the two.
+#pragma once
+#include "sss_layout.h"
+#include <wave_rt.h>  // csrc/wave_rt.h (gfx950) or tests/emu/wave_rt.h (CPU emulator), chosen by -I order
+
+// ------------------------------------------------------------------------------------------
+// per-wave context
+// ------------------------------------------------------------------------------------------
+
+struct SssScratch {  // LDS, besides SssHot
+  uint8_t setA[SSS_SET_TABLE];
+  uint8_t setB[SSS_SET_TABLE];
+  uint16_t jobset[SSS_JOBSET_SLOTS];
+  uint16_t keys[SSS_MAX_JOBS + 8];
+  // flags lane 0 publishes for the uniform control flow
+  int32_t f_done, f_scan, f_round_continues, f_pop_kind, f_pop_exec, f_pop_job;
+  int32_t m_n_active, m_src_job;  // mailbox for find_schedulable_all
+  int32_t n_old_active;
+  int32_t events_this_step;
+  double wall_old;
+};
+
+struct Ctx {
+  SssHot* hot;
+  SssScratch* sc;
+  uint16_t* active;
+  SssJob* jobs;
+  double* t_arrival;
+  double* t_completed;
+  SssStage* stages;
+  float* durations;
+  SssPoolHdr* pool_hdr;
+  uint8_t* pool_tab;
+  double* dur_ring;
+  uint16_t* old_active;
+  const SssCfgDev* cfg;
+  const SssPackDev* pk;
+  int E, J_cap, SP;
+};
+
+SSS_DEV void ctx_init(Ctx& c, SssHot* hot, SssScratch* sc, uint8_t* env_base, const SssLayout& L, const SssCfgDev* cfg,
+                      const SssPackDev* pk) {
+  c.hot = hot, c.sc = sc;
+  c.active = (uint16_t*)(env_base + L.off_active);
+  c.jobs = (SssJob*)(env_base + L.off_jobs);
+  c.t_arrival = (double*)(env_base + L.off_t_arrival);
+  c.t_completed = (double*)(env_base + L.off_t_completed);
+  c.stages = (SssStage*)(env_base + L.off_stages);
+  c.durations = (float*)(env_base + L.off_durations);
+  c.pool_hdr = (SssPoolHdr*)(env_base + L.off_pool_hdr);
+  c.pool_tab = env_base + L.off_pool_tab;
+  c.dur_ring = (double*)(env_base + L.off_dur_ring);
+  c.old_active = (uint16_t*)(env_base + L.off_old_active);
+  c.cfg = cfg, c.pk = pk;
+  c.E = L.E, c.J_cap = L.J_cap, c.SP = L.SP;
+}
+
+#define H (c.hot->h)
+#define FAIL(code)                 \
+  do {                             \
+    if (H.err == 0) H.err = (code); \
+  } while (0)
+#define CHECK(cond)                          \
+  do {                                       \
+    if (!(cond)) FAIL(SSS_ERR_INVARIANT);     \
+  } while (0)
+
+// pool keys
+SSS_DEV uint32_t key_job_pool(int j) { return (uint32_t)(j + 1) << 8; }
+SSS_DEV uint32_t key_stage_pool(int j, int s) { return ((uint32_t)(j + 1) << 8) | (uint32_t)(s + 1); }
+SSS_DEV int key_job(uint32_t k) { return k == POOL_NONE ? -1 : (int)(k >> 8) - 1; }   // pool_key[0], -1 = None
+SSS_DEV int key_stage(uint32_t k) { return k == POOL_NONE ? -1 : (int)(k & 0xFF) - 1; }  // pool_key[1], -1 = None
+SSS_DEV int pool_index(const Ctx& c, uint32_t k) {
+  int j = key_job(k), s = key_stage(k);
+  if (j < 0) return 0;
+  if (s < 0) return 1 + j;
+  return 1 + c.J_cap + j * c.SP + s;
+}
+SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
+
+// ------------------------------------------------------------------------------------------
+// numpy Generator(PCG64) stream (lane 0). Restates numpy/random: SeedSequence, pcg64 XSL-RR,
+// buffered 32-bit Lemire bounded ints, the exponential ziggurat and the FDLIBM log1p/exp its slow
+// path calls (third-party dependency of the reference: requirements.txt:21). Draw sites:
+// TPCH:70,177,178,211,225.
+// ------------------------------------------------------------------------------------------
+
+#define PCG_MH 0x2360ED051FC65DA4ull
+#define PCG_ML 0x4385DF649FCCF645ull
+
+SSS_DEV void rng_step(SssHdr& h) {
+  uint64_t lo = h.rng_state_lo, hi = h.rng_state_hi;
+  uint64_t plo = lo * PCG_ML;
+  uint64_t phi = mul64hi(lo, PCG_ML) + hi * PCG_ML + lo * PCG_MH;
+  uint64_t rlo = plo + h.rng_inc_lo;
+  uint64_t rhi = phi + h.rng_inc_hi + (rlo < plo ? 1ull : 0ull);
+  h.rng_state_lo = rlo, h.rng_state_hi = rhi;
+}
+
+SSS_DEV uint64_t rng_next64(SssHdr& h) {
+  rng_step(h);
+  uint64_t x = h.rng_state_hi ^ h.rng_state_lo;
+  unsigned rot = (unsigned)(h.rng_state_hi >> 58);
+  return (x >> rot) | (x << ((64 - rot) & 63));
+}
+
+SSS_DEV uint32_t rng_next32(SssHdr& h) {
+  if (h.rng_has32) {
+    h.rng_has32 = 0;
+    return h.rng_u32;
+  }
+  uint64_t n = rng_next64(h);
+  h.rng_has32 = 1;
+  h.rng_u32 = (uint32_t)(n >> 32);
+  return (uint32_t)n;
+}
+
+SSS_DEV double rng_random(SssHdr& h) { return (double)(rng_next64(h) >> 11) * (1.0 / 9007199254740992.0); }
+
+SSS_DEV uint32_t rng_integers(SssHdr& h, uint32_t n) {
+  uint32_t rng = n - 1;
+  if (rng == 0) return 0;
+  uint64_t m = (uint64_t)rng_next32(h) * n;
+  uint32_t leftover = (uint32_t)m;
+  if (leftover < n) {
+    uint32_t threshold = (0xFFFFFFFFu - rng) % n;
+    while (leftover < threshold) {
+      m = (uint64_t)rng_next32(h) * n;
+      leftover = (uint32_t)m;
+    }
+  }
+  return (uint32_t)(m >> 32);
+}
+
+SSS_DEV uint32_t ss_hashmix(uint32_t value, uint32_t& hash_const) {
+  value ^= hash_const;
+  hash_const *= 0x931e8875u;
+  value *= hash_const;
+  value ^= value >> 16;
+  return value;
+}
+SSS_DEV uint32_t ss_mix(uint32_t x, uint32_t y) {
+  uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y;
+  r ^= r >> 16;
+  return r;
+}
+
+// Generator(PCG64(SeedSequence(seed))): gymnasium's Env.reset(seed) (ENV:130)
+SSS_DEV_NOINLINE void rng_seed(SssHdr& h, uint64_t seed) {
+  uint32_t ent0 = (uint32_t)seed, ent1 = (uint32_t)(seed >> 32);
+  int n_ent = ent1 ? 2 : 1;
+  uint32_t pool[4];
+  uint32_t hc = 0x43b0d7e5u;
+  pool[0] = ss_hashmix(ent0, hc);
+  pool[1] = ss_hashmix(n_ent > 1 ? ent1 : 0u, hc);
+  pool[2] = ss_hashmix(0u, hc);
+  pool[3] = ss_hashmix(0u, hc);
+  for (int s = 0; s < 4; s++)
+    for (int d = 0; d < 4; d++)
+      if (s != d) pool[d] = ss_mix(pool[d], ss_hashmix(pool[s], hc));
+  uint32_t w[8];
+  uint32_t hb = 0x8b51f9ddu;
+  for (int i = 0; i < 8; i++) {
+    uint32_t v = pool[i & 3];
+    v ^= hb;
+    hb *= 0x58f38dedu;
+    v *= hb;
+    v ^= v >> 16;
+    w[i] = v;
+  }
+  uint64_t s0 = (uint64_t)w[0] | ((uint64_t)w[1] << 32), s1 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+  uint64_t s2 = (uint64_t)w[4] | ((uint64_t)w[5] << 32), s3 = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
+  // initstate = (s0 << 64) | s1 ; initseq = (s2 << 64) | s3 ; inc = (initseq << 1) | 1
+  h.rng_inc_hi = (s2 << 1) | (s3 >> 63);
+  h.rng_inc_lo = (s3 << 1) | 1ull;
+  h.rng_state_hi = 0, h.rng_state_lo = 0;
+  rng_step(h);
+  uint64_t lo = h.rng_state_lo + s1;
+  h.rng_state_hi = h.rng_state_hi + s0 + (lo < s1 ? 1ull : 0ull);
+  h.rng_state_lo = lo;
+  rng_step(h);
+  h.rng_has32 = 0, h.rng_u32 = 0;
+}
+
+// FDLIBM s_log1p.c as evaluated by glibc 2.35 (split polynomial); domain here is (-1, 0]
+SSS_DEV_NOINLINE double fd_log1p(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, two54 = 1.80143985094819840000e+16,
+               Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  double hfsq, f = 0, cc = 0, s, z, R, u, z2, z4, z6, R1, R2, R3, R4;
+  int32_t k, hx, hu = 0, ax;
+  hx = (int32_t)f64_hi32(x);
+  ax = hx & 0x7fffffff;
+  k = 1;
+  if (hx < 0x3FDA827A) {
+    if (ax >= 0x3ff00000) {
+      if (x == -1.0) return -two54 / 0.0;
+      return (x - x) / (x - x);
+    }
+    if (ax < 0x3e200000) {
+      if (two54 + x > 0.0 && ax < 0x3c900000) return x;
+      return x - x * x * 0.5;
+    }
+    if (hx > 0 || hx <= ((int32_t)0xbfd2bec3)) {
+      k = 0;
+      f = x;
+      hu = 1;
+    }
+  } else if (hx >= 0x7ff00000)
+    return x + x;
+  if (k != 0) {
+    if (hx < 0x43400000) {
+      u = 1.0 + x;
+      hu = (int32_t)f64_hi32(u);
+      k = (hu >> 20) - 1023;
+      cc = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+      cc /= u;
+    } else {
+      u = x;
+      hu = (int32_t)f64_hi32(u);
+      k = (hu >> 20) - 1023;
+      cc = 0;
+    }
+    hu &= 0x000fffff;
+    if (hu < 0x6a09e) {
+      u = f64_with_hi32(u, (uint32_t)hu | 0x3ff00000u);
+    } else {
+      k += 1;
+      u = f64_with_hi32(u, (uint32_t)hu | 0x3fe00000u);
+      hu = (0x00100000 - hu) >> 2;
+    }
+    f = u - 1.0;
+  }
+  hfsq = 0.5 * f * f;
+  if (hu == 0) {
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      cc += k * ln2_lo;
+      return k * ln2_hi + cc;
+    }
+    R = hfsq * (1.0 - 0.66666666666666666 * f);
+    if (k == 0) return f - R;
+    return k * ln2_hi - ((R - (k * ln2_lo + cc)) - f);
+  }
+  s = f / (2.0 + f);
+  z = s * s;
+  R1 = z * Lp1;
+  z2 = z * z;
+  R2 = Lp2 + z * Lp3;
+  z4 = z2 * z2;
+  R3 = Lp4 + z * Lp5;
+  z6 = z4 * z2;
+  R4 = Lp6 + z * Lp7;
+  R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + cc))) - f);
+}
+
+// FDLIBM e_exp.c for finite x <= 0 (wedge test of the ziggurat; discounted rewards)
+SSS_DEV_NOINLINE double fd_exp(double x) {
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
+               P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x < -745.2) return 0.0;
+  double y, hi = 0, lo = 0, cc, t;
+  int32_t k = 0;
+  uint32_t hx = f64_hi32(x);
+  int xsb = (int)((hx >> 31) & 1);
+  hx &= 0x7fffffff;
+  if (hx > 0x3fd62e42) {
+    if (hx < 0x3FF0A2B2) {
+      hi = xsb ? x + ln2HI : x - ln2HI;
+      lo = xsb ? -ln2LO : ln2LO;
+      k = 1 - xsb - xsb;
+    } else {
+      k = (int32_t)(invln2 * x + (xsb ? -0.5 : 0.5));
+      t = k;
+      hi = x - t * ln2HI;
+      lo = t * ln2LO;
+    }
+    x = hi - lo;
+  } else if (hx < 0x3e300000) {
+    return 1.0 + x;
+  } else
+    k = 0;
+  t = x * x;
+  cc = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * cc) / (cc - 2.0) - x);
+  y = 1.0 - ((lo - (x * cc) / (2.0 - cc)) - hi);
+  if (k >= -1021) return f64_with_hi32(y, f64_hi32(y) + ((uint32_t)k << 20));
+  y = f64_with_hi32(y, f64_hi32(y) + ((uint32_t)(k + 1000) << 20));
+  return y * 9.33263618503218878990e-302;
+}
+
+SSS_DEV_NOINLINE double rng_standard_exponential(const Ctx& c, SssHdr& h) {
+  for (;;) {
+    uint64_t ri = rng_next64(h);
+    ri >>= 3;
+    unsigned idx = (unsigned)(ri & 0xFF);
+    ri >>= 8;
+    double x = (double)ri * c.pk->zig_we[idx];
+    if (ri < c.pk->zig_ke[idx]) return x;
+    if (idx == 0) return 7.69711747013104972 - fd_log1p(-rng_random(h));
+    if ((c.pk->zig_fe[idx - 1] - c.pk->zig_fe[idx]) * rng_random(h) + c.pk->zig_fe[idx] < fd_exp(-x)) return x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CPython 3.10 set images (lane 0). Slot encoding: 0 = EMPTY, 1 = DUMMY, key + 2 otherwise.
+// Restates Objects/setobject.c set_add_entry / set_lookkey / set_insert_clean / set_table_resize
+// / set_merge / set_pop for keys with hash(k) == k. Why: SURVEY H1 (ENV:714-741,762,855-864).
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+struct SetImg {
+  T* tab;
+  uint32_t mask, fill, used, finger;
+};
+
+template <typename T>
+SSS_DEV void set_insert_clean(T* tab, uint32_t mask, uint32_t key) {
+  uint32_t perturb = key;
+  uint32_t i = key & mask;
+  for (;;) {
+    uint32_t probes = (i + 9 <= mask) ? 9 : 0;
+    for (uint32_t p = 0; p <= probes; p++) {
+      if (tab[i + p] == 0) {
+        tab[i + p] = (T)(key + 2);
+        return;
+      }
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+
+// `keys` is scratch for the live keys (>= used entries)
+template <typename T>
+SSS_DEV void set_resize(SetImg<T>& s, uint32_t minused, uint16_t* keys) {
+  uint32_t newsize = 8;
+  while (newsize <= minused) newsize <<= 1;
+  uint32_t n = 0;
+  for (uint32_t i = 0; i <= s.mask; i++) {
+    uint32_t e = s.tab[i];
+    if (e >= 2) keys[n++] = (uint16_t)(e - 2);
+  }
+  for (uint32_t i = 0; i < newsize; i++) s.tab[i] = 0;
+  for (uint32_t i = 0; i < n; i++) set_insert_clean(s.tab, newsize - 1, keys[i]);
+  s.mask = newsize - 1;
+  s.fill = s.used;
+}
+
+template <typename T>
+SSS_DEV void set_add(SetImg<T>& s, uint32_t key, uint16_t* keys) {
+  uint32_t mask = s.mask;
+  uint32_t i = key & mask;
+  uint32_t perturb = key;
+  int freeslot = -1;
+  uint32_t idx = 0;
+  for (;;) {
+    uint32_t probes = (i + 9 <= mask) ? 9 : 0;
+    bool found = false;
+    for (uint32_t p = 0; p <= probes; p++) {
+      uint32_t e = s.tab[i + p];
+      if (e == 0) {
+        idx = i + p;
+        found = true;
+        break;
+      }
+      if (e == key + 2) return;
+      if (e == 1) freeslot = (int)(i + p);
+    }
+    if (found) break;
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+  if (freeslot >= 0) {
+    s.used++;
+    s.tab[freeslot] = (T)(key + 2);
+    return;
+  }
+  s.fill++;
+  s.used++;
+  s.tab[idx] = (T)(key + 2);
+  if (s.fill * 5 < mask * 3) return;
+  set_resize(s, s.used * 4, keys);
+}
+
+template <typename T>
+SSS_DEV bool set_remove(SetImg<T>& s, uint32_t key) {
+  uint32_t mask = s.mask;
+  uint32_t i = key & mask;
+  uint32_t perturb = key;
+  for (;;) {
+    uint32_t probes = (i + 9 <= mask) ? 9 : 0;
+    for (uint32_t p = 0; p <= probes; p++) {
+      uint32_t e = s.tab[i + p];
+      if (e == 0) return false;
+      if (e == key + 2) {
+        s.tab[i + p] = 1;
+        s.used--;
+        return true;
+      }
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+
+template <typename T>
+SSS_DEV uint32_t set_pop(SetImg<T>& s) {
+  uint32_t i = s.finger & s.mask;
+  while (s.tab[i] < 2) {
+    i++;
+    if (i > s.mask) i = 0;
+  }
+  uint32_t key = (uint32_t)s.tab[i] - 2;
+  s.tab[i] = 1;
+  s.used--;
+  s.finger = i + 1;
+  return key;
+}
+
+SSS_DEV SetImg<uint8_t> pool_open(const Ctx& c, uint32_t key) {
+  int p = pool_index(c, key);
+  SssPoolHdr hd = c.pool_hdr[p];
+  SetImg<uint8_t> s;
+  s.tab = c.pool_tab + (size_t)p * SSS_SET_TABLE;
+  s.mask = hd.mask, s.fill = hd.fill, s.used = hd.used, s.finger = 0;
+  return s;
+}
+SSS_DEV void pool_close(const Ctx& c, uint32_t key, const SetImg<uint8_t>& s) {
+  int p = pool_index(c, key);
+  c.pool_hdr[p].mask = (uint16_t)s.mask;
+  c.pool_hdr[p].fill = (uint16_t)s.fill;
+  c.pool_hdr[p].used = (uint16_t)s.used;
+}
+SSS_DEV int pool_size(const Ctx& c, uint32_t key) { return key == POOL_NONE ? 0 : (int)c.pool_hdr[pool_index(c, key)].used; }
+SSS_DEV int pool_commit_from(const Ctx& c, uint32_t key) { return key == POOL_NONE ? 0 : (int)c.pool_hdr[pool_index(c, key)].commit_from; }
+
+// ------------------------------------------------------------------------------------------
+// tracker (lane 0)
+// ------------------------------------------------------------------------------------------
+
+SSS_DEV int trk_source_job_id(const Ctx& c) {  // TRK:101-105
+  uint32_t k = H.curr_source;
+  if (k == POOL_NONE || k == POOL_COMMON) return -1;
+  return key_job(k);
+}
+
+SSS_DEV void publish_scan_inputs(Ctx& c) {
+  c.sc->m_n_active = H.n_active;
+  c.sc->m_src_job = trk_source_job_id(c);
+}
+
+SSS_DEV int trk_num_committable(Ctx& c) {  // TRK:107-113
+  uint32_t k = H.curr_source;
+  if (k == POOL_NONE) return 0;
+  int p = pool_index(c, k);
+  int n = (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
+  CHECK(n >= 0);
+  return n;
+}
+
+// executor demand bookkeeping: sat bit of stage (j, s) <=> remaining - (moving_to + commit_to) <= 0 (ENV:566-582)
+SSS_DEV void update_sat(Ctx& c, int j, int s) {
+  SssStage st = c.stages[j * c.SP + s];
+  int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
+  uint64_t m = c.jobs[j].sat_mask;
+  m = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
+  c.jobs[j].sat_mask = m;
+}
+
+SSS_DEV void add_supply(Ctx& c, int job, int d) {
+  if (job < 0) {
+    H.supply_none += d;
+    CHECK(H.supply_none >= 0);
+  } else {
+    int v = (int)c.jobs[job].supply + d;
+    CHECK(v >= 0);
+    c.jobs[job].supply = (int16_t)v;
+  }
+}
+
+SSS_DEV void trk_add_commitment(Ctx& c, int n, uint32_t dst) {  // TRK:148-157, 226-238
+  uint32_t src = H.curr_source;
+  CHECK(src != POOL_NONE);
+  if (src == POOL_NONE) return;
+  SssHot& hot = *c.hot;
+  int i;
+  for (i = 0; i < H.n_commits; i++)
+    if (hot.c_src[i] == src && hot.c_dst[i] == dst) break;
+  if (i < H.n_commits)
+    hot.c_n[i] = (int16_t)(hot.c_n[i] + n);
+  else {
+    CHECK(i < SSS_MAX_EXEC);
+    if (i >= SSS_MAX_EXEC) return;
+    hot.c_src[i] = src, hot.c_dst[i] = dst, hot.c_n[i] = (int16_t)n, hot.c_seq[i] = H.commit_seq++;
+    H.n_commits = i + 1;
+  }
+  int ps = pool_index(c, src);
+  c.pool_hdr[ps].commit_from = (int16_t)(c.pool_hdr[ps].commit_from + n);
+  CHECK((int)c.pool_hdr[ps].used >= (int)c.pool_hdr[ps].commit_from);
+  int dj = key_job(dst), ds = key_stage(dst);
+  if (ds >= 0) {
+    c.stages[dj * c.SP + ds].commit_to = (int16_t)(c.stages[dj * c.SP + ds].commit_to + n);
+    update_sat(c, dj, ds);
+  }
+  if (dj != key_job(src)) add_supply(c, dj, n);
+}
+
+// returns the source pool key (TRK:159-176, 240-251)
+SSS_DEV uint32_t trk_remove_commitment(Ctx& c, int e, uint32_t dst) {
+  SssHot& hot = *c.hot;
+  uint32_t src = hot.ex_loc[e];
+  CHECK(src != POOL_NONE);
+  int i;
+  for (i = 0; i < H.n_commits; i++)
+    if (hot.c_src[i] == src && hot.c_dst[i] == dst) break;
+  CHECK(i < H.n_commits);
+  if (i >= H.n_commits) return src;
+  hot.c_n[i] = (int16_t)(hot.c_n[i] - 1);
+  int ps = pool_index(c, src);
+  c.pool_hdr[ps].commit_from = (int16_t)(c.pool_hdr[ps].commit_from - 1);
+  CHECK(c.pool_hdr[ps].commit_from >= 0);
+  int dj = key_job(dst), ds = key_stage(dst);
+  if (ds >= 0) {
+    c.stages[dj * c.SP + ds].commit_to = (int16_t)(c.stages[dj * c.SP + ds].commit_to - 1);
+    CHECK(c.stages[dj * c.SP + ds].commit_to >= 0);
+    update_sat(c, dj, ds);
+  }
+  if (hot.c_n[i] == 0) {  // dict.pop(dst): swap-remove, order lives in c_seq
+    int last = H.n_commits - 1;
+    hot.c_src[i] = hot.c_src[last], hot.c_dst[i] = hot.c_dst[last], hot.c_n[i] = hot.c_n[last], hot.c_seq[i] = hot.c_seq[last];
+    H.n_commits = last;
+  }
+  if (dj != key_job(src)) add_supply(c, dj, -1);
+  return src;
+}
+
+// first-inserted live destination of `src`, POOL_NONE if none (TRK:178-183)
+SSS_DEV uint32_t trk_peek_commitment(const Ctx& c, uint32_t src) {
+  const SssHot& hot = *c.hot;
+  uint32_t best = 0xFFFFFFFFu, dst = POOL_NONE;
+  for (int i = 0; i < H.n_commits; i++)
+    if (hot.c_src[i] == src && hot.c_seq[i] < best) best = hot.c_seq[i], dst = hot.c_dst[i];
+  return dst;
+}
+
+SSS_DEV void trk_move_executor_to_pool(Ctx& c, int e, uint32_t new_pool, bool send) {  // TRK:188-222
+  SssHot& hot = *c.hot;
+  uint32_t old = hot.ex_loc[e];
+  if (old != POOL_NONE) {
+    SetImg<uint8_t> s = pool_open(c, old);
+    bool was = set_remove(s, (uint32_t)e);
+    CHECK(was);
+    pool_close(c, old, s);
+    hot.ex_loc[e] = POOL_NONE;
+  }
+  if (!send) {
+    hot.ex_loc[e] = new_pool;
+    SetImg<uint8_t> s = pool_open(c, new_pool);
+    set_add(s, (uint32_t)e, c.sc->keys);
+    pool_close(c, new_pool, s);
+    return;
+  }
+  int nj = key_job(new_pool), ns = key_stage(new_pool);
+  CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
+  c.stages[nj * c.SP + ns].moving_to = (int16_t)(c.stages[nj * c.SP + ns].moving_to + 1);
+  update_sat(c, nj, ns);
+  int oj = key_job(old);
+  CHECK(oj != nj);
+  add_supply(c, nj, 1);
+  if (oj >= 0) add_supply(c, oj, -1);
+}
+
+// ------------------------------------------------------------------------------------------
+// jobs / stages (lane 0)
+// ------------------------------------------------------------------------------------------
+
+SSS_DEV void job_attach_executor(Ctx& c, int j, int e) {  // JOB:81-84
+  CHECK(c.hot->ex_task_stage[e] < 0);
+  c.jobs[j].local_mask |= bit64(e);
+  c.hot->ex_job[e] = (int16_t)j;
+}
+SSS_DEV void job_detach_executor(Ctx& c, int j, int e) {  // JOB:86-89
+  CHECK(c.jobs[j].local_mask & bit64(e));
+  c.jobs[j].local_mask &= ~bit64(e);
+  c.hot->ex_job[e] = -1;
+  c.hot->ex_task_stage[e] = -1;
+}
+SSS_DEV bool stage_completed(const SssStage& st) { return st.remaining == 0 && st.executing == 0; }  // STG:41-43
+
+// JOB:65-73,100-128: stage s of job j completed; returns whether the frontier gained stages
+SSS_DEV bool job_record_stage_completion(Ctx& c, int j, int s) {
+  SssJob& job = c.jobs[j];
+  CHECK((job.active_mask & bit64(s)) && (job.frontier_mask & bit64(s)));
+  uint64_t active = job.active_mask & ~bit64(s);
+  job.active_mask = active;
+  uint64_t frontier = job.frontier_mask & ~bit64(s);
+  // completed stages == stages that are no longer active
+  uint64_t all = job.n_stages >= 64 ? ~0ull : (bit64(job.n_stages) - 1);
+  uint64_t completed = all & ~active;
+  uint64_t children = c.pk->stage_child_mask[job.gs_base + s];
+  uint64_t newm = 0;
+  uint64_t cand = children & active;
+  while (cand) {
+    int ch = ctz64(cand);
+    cand &= cand - 1;
+    uint64_t parents = c.pk->stage_parent_mask[job.gs_base + ch];
+    if ((parents & ~completed) == 0) newm |= bit64(ch);
+  }
+  job.frontier_mask = frontier | newm;
+  return newm != 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// data sampler: task durations (lane 0)
+// ------------------------------------------------------------------------------------------
+
+SSS_DEV bool sample_task_duration(Ctx& c, int gs, int wave, int lvl, bool warmup, double& out) {  // TPCH:208-214
+  const int32_t* d = &c.pk->desc[((gs * 3 + wave) * c.pk->L + lvl) * 2];
+  int off = d[0], len = d[1];
+  if (len <= 0) return false;  // KeyError (missing level) / ValueError (empty list): no draw happened
+  uint32_t i = rng_integers(H, (uint32_t)len);
+  double v = (double)c.pk->durations[off + (int)i];
+  if (warmup) v += c.cfg->warmup_delay;
+  out = v;
+  return true;
+}
+
+SSS_DEV_NOINLINE double task_duration(Ctx& c, int j, int s, int e) {  // TPCH:75-106, 216-235
+  const SssJob& job = c.jobs[j];
+  int gs = job.gs_base + s;
+  int n_local = popc64(job.local_mask);
+  CHECK(n_local > 0 && n_local <= c.E);
+  if (n_local <= 0 || n_local > c.E) return 0.0;
+  double left = c.cfg->intervals[n_local][0], right = c.cfg->intervals[n_local][1];
+  int lvl;
+  if (left == right)
+    lvl = c.cfg->interval_lvl[n_local][0];
+  else {
+    int rand_pt = 1 + (int)(rng_random(H) * (right - left));
+    lvl = ((double)rand_pt <= (double)n_local - left) ? c.cfg->interval_lvl[n_local][0] : c.cfg->interval_lvl[n_local][1];
+  }
+  if (lvl < 0 || !((c.pk->stage_first_keymask[gs] >> lvl) & 1)) lvl = c.pk->stage_max_first_lvl[gs];
+  double d = 0.0;
+  int task_stage = c.hot->ex_task_stage[e];
+  if (task_stage < 0) {  // executor.is_idle
+    if (sample_task_duration(c, gs, 0, lvl, false, d)) return d;
+    if (sample_task_duration(c, gs, 1, lvl, true, d)) return d;
+    FAIL(SSS_ERR_NO_DURATION);
+    return 0.0;
+  }
+  if (task_stage == s) {  // stage ids only (TPCH:95)
+    if (sample_task_duration(c, gs, 2, lvl, false, d)) return d;
+  }
+  if (sample_task_duration(c, gs, 1, lvl, false, d)) return d;
+  if (sample_task_duration(c, gs, 0, lvl, false, d)) return d;
+  FAIL(SSS_ERR_NO_DURATION);
+  return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// schedulable-stage search, serial flavour (lane 0): single jobs and the backup search
+// ------------------------------------------------------------------------------------------
+
+// stages of job j that are active, not selected this round and ready (ENV:533-555); `pass`
+// filter (job == source or supply < E, ENV:526-531) applied by the caller
+SSS_DEV uint64_t ready_mask_of_job(const Ctx& c, const SssJob& job, bool first_only) {
+  uint64_t cand = job.active_mask & ~job.selected_mask & ~job.sat_mask;
+  uint64_t m = 0;
+  while (cand) {
+    int s = ctz64(cand);
+    cand &= cand - 1;
+    uint64_t parents = c.pk->stage_parent_mask[job.gs_base + s];
+    if ((parents & ~job.sat_mask) == 0) {
+      m |= bit64(s);
+      if (first_only) break;
+    }
+  }
+  return m;
+}
+
+SSS_DEV bool job_passes_filter(const Ctx& c, int j, int source_job_id) {
+  return j == source_job_id || (int)c.jobs[j].supply < c.E;
+}
+
+// ENV:821-845 -> (job, stage) or job = -1
+SSS_DEV_NOINLINE void find_backup_stage(Ctx& c, int e, int& out_j, int& out_s) {
+  out_j = -1, out_s = -1;
+  int ejob = c.hot->ex_job[e];
+  CHECK(ejob >= 0);
+  if (ejob < 0) return;
+  // `if not source_job_id` (ENV:521): job id 0 is falsy and gets replaced by the tracker's source
+  int src = ejob <= 0 ? trk_source_job_id(c) : ejob;
+  if (job_passes_filter(c, ejob, src)) {
+    uint64_t m = ready_mask_of_job(c, c.jobs[ejob], true);
+    if (m) {
+      out_j = ejob, out_s = ctz64(m);
+      return;
+    }
+  }
+  // other jobs; an empty list is falsy and means "all active jobs" (ENV:518-519)
+  bool ejob_active = c.jobs[ejob].active_mask != 0;
+  int n_others = H.n_active - (ejob_active ? 1 : 0);
+  for (int a = 0; a < H.n_active; a++) {
+    int j = c.active[a];
+    if (n_others > 0 && j == ejob) continue;
+    if (!job_passes_filter(c, j, src)) continue;
+    uint64_t m = ready_mask_of_job(c, c.jobs[j], true);
+    if (m) {
+      out_j = j, out_s = ctz64(m);
+      return;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// executor movement (lane 0)
+// ------------------------------------------------------------------------------------------
+
+SSS_DEV void push_event(Ctx& c, int e, double t, int kind, int j, int s) {  // EVQ:34-35
+  SssHot& hot = *c.hot;
+  CHECK(hot.ev_kind[e] == EV_NONE);
+  hot.ev_t[e] = t, hot.ev_seq[e] = H.counter++, hot.ev_kind[e] = (uint8_t)kind;
+  hot.ev_job[e] = (int16_t)j, hot.ev_stage[e] = (int8_t)s;
+}
+
+SSS_DEV void execute_next_task(Ctx& c, int e, int j, int s) {  // ENV:584-615
+  SssStage& st = c.stages[j * c.SP + s];
+  CHECK(st.remaining > 0 && c.hot->ex_job[e] == j && !c.hot->ex_executing[e]);
+  st.remaining = (int16_t)(st.remaining - 1);  // STG:53-58
+  st.executing = (int16_t)(st.executing + 1);
+  if (st.remaining == 0) c.jobs[j].sat_count = (int16_t)(c.jobs[j].sat_count + 1);
+  update_sat(c, j, s);
+  double d = task_duration(c, j, s, e);
+  c.hot->ex_task_stage[e] = (int8_t)s;
+  c.hot->ex_executing[e] = 1;
+  c.durations[j * c.SP + s] = (float)d;  // stage.most_recent_duration, observed as f32 (ENV:381)
+  push_event(c, e, H.wall_time + d, EV_TASK_FINISHED, j, s);
+}
+
+SSS_DEV void send_executor(Ctx& c, int e, int j, int s) {  // ENV:617-637
+  CHECK(!c.hot->ex_executing[e] && c.hot->ex_job[e] != j);
+  trk_move_executor_to_pool(c, e, key_stage_pool(j, s), true);
+  int oj = c.hot->ex_job[e];
+  if (oj >= 0) job_detach_executor(c, oj, e);
+  push_event(c, e, H.wall_time + c.cfg->moving_delay, EV_EXECUTOR_READY, j, s);
+}
+
+// ENV:745-782 for an explicit executor list of one
+SSS_DEV void move_idle_executor(Ctx& c, uint32_t src, int e) {
+  if (src == POOL_NONE) src = H.curr_source;
+  CHECK(src != POOL_NONE);
+  if (src == POOL_NONE || src == POOL_COMMON) return;
+  int j = key_job(src), s = key_stage(src);
+  bool is_sat = (int)c.jobs[j].sat_count == (int)c.jobs[j].n_stages;  // JOB:53-55
+  if (s < 0 && !is_sat) return;
+  uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
+  trk_move_executor_to_pool(c, e, dst, false);
+  if (dst == POOL_COMMON) job_detach_executor(c, j, e);
+}
+
+// set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
+SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(Ctx& c, uint32_t key) {
+  SetImg<uint8_t> out;
+  out.tab = c.sc->setB;
+  for (int i = 0; i < 8; i++) out.tab[i] = 0;
+  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0;
+  if (key == POOL_NONE) return out;
+  SetImg<uint8_t> src = pool_open(c, key);
+  // pool.copy() == set_merge into a fresh set (setA)
+  SetImg<uint8_t> cp;
+  cp.tab = c.sc->setA;
+  for (int i = 0; i < 8; i++) cp.tab[i] = 0;
+  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0;
+  if (src.used != 0) {
+    if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, c.sc->keys);
+    if (cp.mask == src.mask && src.fill == src.used) {
+      for (uint32_t i = 0; i <= src.mask; i++) cp.tab[i] = src.tab[i];
+    } else {
+      for (uint32_t i = 0; i <= src.mask; i++) {
+        uint32_t en = src.tab[i];
+        if (en >= 2) set_insert_clean(cp.tab, cp.mask, en - 2);
+      }
+    }
+    cp.fill = cp.used = src.used;
+  }
+  for (uint32_t i = 0; i <= cp.mask; i++) {
+    uint32_t en = cp.tab[i];
+    if (en >= 2 && !c.hot->ex_executing[en - 2]) set_add(out, en - 2, c.sc->keys);
+  }
+  return out;
+}
+
+// ENV:745-782 with executor_ids=None: all idle executors of `src`, in set order
+SSS_DEV_NOINLINE void move_idle_executors_all(Ctx& c, uint32_t src) {
+  if (src == POOL_NONE) src = H.curr_source;
+  CHECK(src != POOL_NONE);
+  if (src == POOL_NONE || src == POOL_COMMON) return;
+  SetImg<uint8_t> idle = get_idle_source_executors(c, src);
+  CHECK(idle.used > 0);  // assert executor_ids, "[_move_idle_executors],2"
+  if (H.err) return;
+  int j = key_job(src), s = key_stage(src);
+  bool is_sat = (int)c.jobs[j].sat_count == (int)c.jobs[j].n_stages;
+  if (s < 0 && !is_sat) return;
+  uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
+  for (uint32_t i = 0; i <= idle.mask; i++) {  // list(set): ascending slot order
+    uint32_t en = idle.tab[i];
+    if (en < 2) continue;
+    int e = (int)en - 2;
+    trk_move_executor_to_pool(c, e, dst, false);
+    if (dst == POOL_COMMON) job_detach_executor(c, j, e);
+  }
+}
+
+SSS_DEV_NOINLINE void move_executor_to_stage(Ctx& c, int e, int j, int s) {  // ENV:784-819
+  if (c.stages[j * c.SP + s].remaining == 0) {
+    // _try_backup_schedule
+    int bj, bs;
+    find_backup_stage(c, e, bj, bs);
+    if (bj < 0) {
+      move_idle_executor(c, c.hot->ex_loc[e], e);
+      return;
+    }
+    j = bj, s = bs;  // a schedulable stage has demand > 0, hence remaining > 0: no second detour
+    CHECK(c.stages[j * c.SP + s].remaining > 0);
+    if (H.err) return;
+  }
+  if (c.hot->ex_job[e] != j) {
+    send_executor(c, e, j, s);
+    return;
+  }
+  if (!(c.jobs[j].frontier_mask & bit64(s))) {
+    c.hot->ex_task_stage[e] = -1;
+    trk_move_executor_to_pool(c, e, key_job_pool(j), false);
+    return;
+  }
+  trk_move_executor_to_pool(c, e, key_stage_pool(j, s), false);
+  execute_next_task(c, e, j, s);
+}
+
+SSS_DEV void fulfill_commitment(Ctx& c, int e, uint32_t dst) {  // ENV:699-712
+  uint32_t src = trk_remove_commitment(c, e, dst);
+  if (H.err) return;
+  if (dst == POOL_COMMON) {
+    move_idle_executor(c, src, e);
+    return;
+  }
+  move_executor_to_stage(c, e, key_job(dst), key_stage(dst));
+}
+
+SSS_DEV_NOINLINE void fulfill_commitments_from_source(Ctx& c) {  // ENV:730-743
+  SssHot& hot = *c.hot;
+  uint32_t src = H.curr_source;
+  SetImg<uint8_t> idle = get_idle_source_executors(c, src);
+  // snapshot of the source's commitments in insertion order (dict copy, TRK:133-134)
+  uint32_t dsts[SSS_MAX_EXEC];
+  int16_t nums[SSS_MAX_EXEC];
+  int n = 0;
+  uint32_t last_seq = 0;
+  bool first = true;
+  for (;;) {
+    uint32_t best = 0xFFFFFFFFu;
+    int bi = -1;
+    for (int i = 0; i < H.n_commits; i++)
+      if (hot.c_src[i] == src && (first || hot.c_seq[i] > last_seq) && hot.c_seq[i] < best) best = hot.c_seq[i], bi = i;
+    if (bi < 0) break;
+    dsts[n] = hot.c_dst[bi], nums[n] = hot.c_n[bi], n++;
+    last_seq = best, first = false;
+  }
+  for (int i = 0; i < n && !H.err; i++) {
+    int num = nums[i];
+    while (num && idle.used && !H.err) {
+      int e = (int)set_pop(idle);
+      fulfill_commitment(c, e, dsts[i]);
+      num--;
+    }
+  }
+  CHECK(idle.used == 0);
+}
+
+SSS_DEV void commit_remaining_executors(Ctx& c) {  // ENV:487-503
+  int n = trk_num_committable(c);
+  if (n > 0) trk_add_commitment(c, n, POOL_COMMON);
+}
+
+// ------------------------------------------------------------------------------------------
+// event handlers (lane 0)
+// ------------------------------------------------------------------------------------------
+
+SSS_DEV void handle_job_arrival(Ctx& c, int j) {  // ENV:428-438 (pools were created empty at reset)
+  c.active[H.n_active] = (uint16_t)j;
+  H.n_active++;
+  if (c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
+}
+
+SSS_DEV void handle_executor_arrival(Ctx& c, int e, int j, int s) {  // ENV:440-450
+  job_attach_executor(c, j, e);
+  SssStage& st = c.stages[j * c.SP + s];
+  st.moving_to = (int16_t)(st.moving_to - 1);  // TRK:185-187
+  CHECK(st.moving_to >= 0);
+  update_sat(c, j, s);
+  trk_move_executor_to_pool(c, e, key_job_pool(j), false);
+  move_executor_to_stage(c, e, j, s);
+}
+
+SSS_DEV_NOINLINE void process_job_completion(Ctx& c, int j) {  // ENV:682-697
+  if (pool_size(c, key_job_pool(j)) > 0) move_idle_executors_all(c, key_job_pool(j));
+  CHECK(pool_size(c, key_job_pool(j)) == 0);
+  int k;
+  for (k = 0; k < H.n_active; k++)
+    if (c.active[k] == j) break;
+  CHECK(k < H.n_active);
+  if (k >= H.n_active) return;
+  for (int i = k; i + 1 < H.n_active; i++) c.active[i] = c.active[i + 1];
+  H.n_active--;
+  c.jobs[j].completion_order = (int16_t)H.n_completed;
+  H.n_completed++;
+  c.t_completed[j] = H.wall_time;
+  double dur = H.wall_time - c.t_arrival[j];
+  if (H.dur_n < SSS_DUR_RING) {
+    c.dur_ring[(H.dur_head + H.dur_n) % SSS_DUR_RING] = dur;
+    H.dur_n++;
+  } else {
+    c.dur_ring[H.dur_head] = dur;
+    H.dur_head = (H.dur_head + 1) % SSS_DUR_RING;
+  }
+}
+
+SSS_DEV_NOINLINE void handle_task_completion(Ctx& c, int e, int j, int s) {  // ENV:452-483
+  SssStage& st = c.stages[j * c.SP + s];
+  CHECK(!stage_completed(st));
+  st.executing = (int16_t)(st.executing - 1);  // STG:60-62
+  c.hot->ex_executing[e] = 0;
+  if (st.remaining > 0) {
+    execute_next_task(c, e, j, s);
+    return;
+  }
+  bool frontier_changed = false;
+  if (stage_completed(st)) frontier_changed = job_record_stage_completion(c, j, s);  // ENV:676-680
+  if (c.jobs[j].active_mask == 0) process_job_completion(c, j);                      // JOB:49-51
+  // _handle_released_executor ENV:639-660
+  uint32_t sp = key_stage_pool(j, s);
+  uint32_t dst = trk_peek_commitment(c, sp);
+  bool had_commitment = dst != POOL_NONE;
+  if (had_commitment)
+    fulfill_commitment(c, e, dst);
+  else {
+    c.hot->ex_task_stage[e] = -1;
+    if (frontier_changed) move_idle_executor(c, sp, e);
+  }
+  // _update_executor_source ENV:662-674
+  if (frontier_changed)
+    H.curr_source = key_job_pool(j);
+  else if (!had_commitment)
+    H.curr_source = sp;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-parallel phases
+// ------------------------------------------------------------------------------------------
+
+// EventQueue.pop (EVQ:44-49): arrivals are a time-sorted array with a cursor and carry the push
+// counters 0..J-1, so they win ties; executor events live one per lane. Every lane returns the
+// same value: POP_EMPTY, POP_ARRIVAL, or the executor (lane) whose event is the minimum.
+// All shared state is read BEFORE the first collective: lane 0 mutates it right after the last one.
+#define POP_EMPTY (-1)
+#define POP_ARRIVAL (-2)
+SSS_DEV int pop_event(Ctx& c) {
+  const SssHot& hot = *c.hot;
+  int lane = wave_lane();
+  bool has = lane < c.E && hot.ev_kind[lane] != EV_NONE;
+  uint64_t tb = has ? f64_bits(hot.ev_t[lane]) : ~0ull;  // times are >= +0.0: bit order == numeric order
+  uint32_t sq = has ? hot.ev_seq[lane] : 0xFFFFFFFFu;
+  int na = hot.h.next_arrival;
+  uint64_t ta = na < hot.h.J ? f64_bits(c.t_arrival[na]) : ~0ull;
+  uint64_t tmin = wave_min_u64(tb);
+  if (ta != ~0ull && ta <= tmin) return POP_ARRIVAL;
+  if (tmin == ~0ull) return POP_EMPTY;
+  if (tb != tmin) sq = 0xFFFFFFFFu;
+  uint32_t smin = wave_min_u32(sq);
+  uint64_t win = wave_ballot(has && tb == tmin && sq == smin);
+  return ctz64(win);
+}
+
+// _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
+// ballot gives the job's ready mask; sat_mask makes the parent test a mask operation.
+// Returns len(schedulable_stages); lane 0 stores the per-job masks.
+// n_active / source job come from the mailbox lane 0 filled before the preceding wave_sync
+// (publish_scan_inputs): lane 0 may already be past this function when another lane reads them.
+SSS_DEV int find_schedulable_all(Ctx& c) {
+  int lane = wave_lane();
+  int A = c.sc->m_n_active;
+  int src_job = c.sc->m_src_job;
+  int total = 0;
+  for (int a = 0; a < A; a++) {
+    int j = c.active[a];
+    const SssJob& job = c.jobs[j];
+    bool pass = j == src_job || (int)job.supply < c.E;
+    bool ready = false;
+    if (pass && lane < (int)job.n_stages) {
+      uint64_t sat = job.sat_mask;
+      uint64_t cand = job.active_mask & ~job.selected_mask & ~sat;
+      if (cand & bit64(lane)) ready = (c.pk->stage_parent_mask[job.gs_base + lane] & ~sat) == 0;
+    }
+    uint64_t m = wave_ballot(ready);
+    if (lane == 0) c.jobs[j].sched_mask = m;
+    total += popc64(m);
+  }
+  return total;
+}
+
+// _observe (ENV:345-406) + utils.subgraph (utils.py:5-22) into the env's padded output rows
+SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, int env, double reward) {
+  int lane = wave_lane();
+  const SssHdr& h = c.hot->h;
+  float* nodes = B.nodes + (size_t)env * L.n_cap * 3;
+  int32_t* el = B.edge_links + (size_t)env * L.ed_cap * 2;
+  int32_t* dag_ptr = B.dag_ptr + (size_t)env * (L.J_cap + 1);
+  int32_t* sup = B.exec_supplies + (size_t)env * L.J_cap;
+  int A = h.n_active;
+  uint32_t srck = h.curr_source;
+  int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
+  int src_idx = A;  // ENV:352
+  int base_n = 0, base_e = 0;
+  uint64_t lt = bit64(lane) - 1;
+  for (int a = 0; a < A; a++) {
+    int j = c.active[a];
+    const SssJob& job = c.jobs[j];
+    uint64_t act = job.active_mask;
+    if (j == src_job) src_idx = a;
+    if (lane == 0) {
+      dag_ptr[a] = base_n;
+      sup[a] = job.supply;
+    }
+    if (lane < (int)job.n_stages && (act & bit64(lane))) {
+      int row = base_n + popc64(act & lt);
+      SssStage st = c.stages[j * c.SP + lane];
+      nodes[row * 3 + 0] = (float)st.remaining;
+      nodes[row * 3 + 1] = c.durations[j * c.SP + lane];
+      nodes[row * 3 + 2] = (job.sched_mask & bit64(lane)) ? 1.0f : 0.0f;
+    }
+    int ne = job.n_edges;
+    int eoff = c.pk->tmpl_edge_off[job.tmpl];
+    for (int eb = 0; eb < ne; eb += 64) {
+      int i = eb + lane;
+      int u = 0, v = 0;
+      bool keep = false;
+      if (i < ne) {
+        u = c.pk->edges[2 * (eoff + i)], v = c.pk->edges[2 * (eoff + i) + 1];
+        keep = (act & bit64(u)) && (act & bit64(v));
+      }
+      uint64_t bal = wave_ballot(keep);
+      if (keep) {
+        int pos = base_e + popc64(bal & lt);
+        el[2 * pos + 0] = base_n + popc64(act & (bit64(u) - 1));
+        el[2 * pos + 1] = base_n + popc64(act & (bit64(v) - 1));
+      }
+      base_e += popc64(bal);
+    }
+    base_n += popc64(act);
+  }
+  if (lane == 0) {
+    dag_ptr[A] = base_n;
+    int32_t* oi = B.obs_i32 + (size_t)env * SSS_OBS_I32;
+    double* of = B.obs_f64 + (size_t)env * SSS_OBS_F64;
+    int ncommit = 0;
+    if (srck != POOL_NONE) {
+      int p = pool_index(c, srck);
+      ncommit = (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
+    }
+    oi[OBS_N_NODES] = base_n, oi[OBS_N_EDGES] = base_e, oi[OBS_N_JOBS] = A, oi[OBS_N_SCHED] = h.n_sched;
+    oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
+    oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
+    of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
+    c.hot->h.obs_n_nodes = base_n;
+    c.hot->h.obs_n_sched = h.n_sched;
+    c.hot->h.last_reward = reward;
+    // SURVEY 8(d) algorithmic bytes of this step: k*140 + 12N + (12N + 4(A+1) + 4A + 8Ed + 12) + 26
+    c.hot->h.model_bytes += (uint64_t)c.sc->events_this_step * 140u + 24u * (uint64_t)base_n + 4u * (uint64_t)(A + 1) +
+                            4u * (uint64_t)A + 8u * (uint64_t)base_e + 12u + 26u;
+  }
+}
+
+SSS_DEV void hot_load(SssHot* lds, const SssHot* g) {
+  const uint4* s = (const uint4*)g;
+  uint4* d = (uint4*)lds;
+  for (int i = wave_lane(); i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+}
+SSS_DEV void hot_store(SssHot* g, const SssHot* lds) {
+  const uint4* s = (const uint4*)lds;
+  uint4* d = (uint4*)g;
+  for (int i = wave_lane(); i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// step pieces (lane 0)
+// ------------------------------------------------------------------------------------------
+
+// ENV:275-315. Returns false if the action was rejected (state untouched).
+SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
+  // action_space.contains: stage_idx in [-1, n_nodes), num_exec in [1, E] (ENV:85-94, 404)
+  if (stage_idx < -1 || stage_idx >= H.obs_n_nodes || num_exec < 1 || num_exec > c.E) {
+    H.err = SSS_ERR_ACTION_SPACE;
+    return false;
+  }
+  if (stage_idx == -1) {
+    commit_remaining_executors(c);
+    return true;
+  }
+  if (stage_idx >= H.obs_n_sched) {  // KeyError on stage_selection_map (ENV:284)
+    H.err = SSS_ERR_STAGE_IDX;
+    return false;
+  }
+  if (num_exec > trk_num_committable(c)) {
+    H.err = SSS_ERR_TOO_MANY;
+    return false;
+  }
+  // stage_selection_map[stage_idx]: k-th set bit over the per-job masks in active order
+  int k = stage_idx, j = -1, s = -1;
+  for (int a = 0; a < H.n_active; a++) {
+    int jj = c.active[a];
+    uint64_t m = c.jobs[jj].sched_mask;
+    int n = popc64(m);
+    if (k < n) {
+      for (int i = 0; i < k; i++) m &= m - 1;
+      j = jj, s = ctz64(m);
+      break;
+    }
+    k -= n;
+  }
+  CHECK(j >= 0);
+  if (j < 0) return false;
+  SssStage st = c.stages[j * c.SP + s];
+  int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);  // ENV:557-578
+  int n = num_exec < demand ? num_exec : demand;
+  CHECK(n > 0);
+  trk_add_commitment(c, n, key_stage_pool(j, s));
+  SssJob& job = c.jobs[j];
+  job.selected_mask |= bit64(s);  // ENV:304
+  // ENV:307-315: only this job's slice of schedulable_stages is recomputed
+  int old_n = popc64(job.sched_mask);
+  uint64_t m = 0;
+  if (job_passes_filter(c, j, trk_source_job_id(c))) m = ready_mask_of_job(c, job, false);
+  job.sched_mask = m;
+  H.n_sched += popc64(m) - old_n;
+  return true;
+}
+
+// ENV:847-874; the float sum runs in CPython set(list + list) iteration order
+SSS_DEV_NOINLINE double compute_jobtime(Ctx& c) {
+  double wall_old = c.sc->wall_old;
+  double duration = H.wall_time - wall_old;
+  if (duration == 0.0) return 0.0;
+  SetImg<uint16_t> all;
+  all.tab = c.sc->jobset;
+  for (int i = 0; i < 8; i++) all.tab[i] = 0;
+  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0;
+  for (int k = 0; k < c.sc->n_old_active; k++) set_add(all, (uint32_t)c.old_active[k], c.sc->keys);
+  for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)c.active[k], c.sc->keys);
+  double job_time = 0.0;
+  double beta = c.cfg->beta;
+  for (uint32_t i = 0; i <= all.mask; i++) {
+    uint32_t en = all.tab[i];
+    if (en < 2) continue;
+    int j = (int)en - 2;
+    double ta = c.t_arrival[j], tc = c.t_completed[j];
+    double start = ta > wall_old ? ta : wall_old;
+    double end = tc < H.wall_time ? tc : H.wall_time;
+    if (beta == 0.0)
+      job_time += end - start;
+    else  // np.exp in the reference: <= 2 ulp agreement only
+      job_time += fd_exp(-beta * 1e-3 * (start - wall_old)) - fd_exp(-beta * 1e-3 * (end - wall_old));
+  }
+  if (beta > 0.0) job_time /= beta;
+  return job_time;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole-env procedures (all lanes)
+// ------------------------------------------------------------------------------------------
+
+// _resume_simulation (ENV:320-343). Entered and left with LDS in sync.
+SSS_DEV void resume_simulation(Ctx& c) {
+  int lane = wave_lane();
+  for (;;) {
+    int ex = pop_event(c);
+    if (lane == 0) {
+      c.sc->f_done = 0, c.sc->f_scan = 0;
+      if (ex == POP_EMPTY || H.err) {
+        c.sc->f_done = 1;
+      } else {
+        H.n_events++;
+        c.sc->events_this_step++;
+        if (ex == POP_ARRIVAL) {
+          int job = H.next_arrival;
+          H.wall_time = c.t_arrival[job];
+          H.next_arrival++;
+          handle_job_arrival(c, job);
+        } else {
+          SssHot& hot = *c.hot;
+          H.wall_time = hot.ev_t[ex];
+          int kind = hot.ev_kind[ex], job = hot.ev_job[ex], s = hot.ev_stage[ex];
+          hot.ev_kind[ex] = EV_NONE;
+          if (kind == EV_TASK_FINISHED)
+            handle_task_completion(c, ex, job, s);
+          else
+            handle_executor_arrival(c, ex, job, s);
+        }
+        if (H.err)
+          c.sc->f_done = 1;
+        else if (trk_num_committable(c) > 0) {
+          c.sc->f_scan = 1;
+          publish_scan_inputs(c);
+        }
+      }
+    }
+    wave_sync();
+    if (c.sc->f_done) {
+      // queue exhausted (or failed): schedulable_stages = [] (ENV:324,343)
+      if (lane == 0) {
+        for (int a = 0; a < H.n_active; a++) c.jobs[c.active[a]].sched_mask = 0;
+        H.n_sched = 0;
+      }
+      wave_sync();
+      return;
+    }
+    if (c.sc->f_scan) {
+      int n = find_schedulable_all(c);
+      if (n > 0) {
+        if (lane == 0) H.n_sched = n;
+        wave_sync();
+        return;
+      }
+      if (lane == 0) {
+        move_idle_executors_all(c, POOL_NONE);  // ENV:340
+        H.curr_source = POOL_NONE;               // ENV:341
+      }
+      wave_sync();
+    }
+  }
+}
+
+// episode initialisation: ENV:127-186 + TPCH:54-73,176-206 + TRK:32-71
+SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_limit) {
+  int lane = wave_lane();
+  SssHot& hot = *c.hot;
+  if (lane == 0) {
+    // lifetime counters and the duration deque survive resets (ENV:83)
+    uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
+    int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes;
+    SssHdr z = {};
+    H = z;
+    H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
+    H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
+    H.seed = seed, H.time_limit = time_limit;
+    H.curr_source = POOL_COMMON;
+    c.sc->events_this_step = 0;
+    if (!(time_limit < __builtin_inf()) && c.cfg->cap_cfg <= 0) {
+      H.err = SSS_ERR_NO_LIMIT;  // ENV:137-138
+      H.need_reset = 1;
+    } else {
+      rng_seed(H, seed);
+      // job_sequence TPCH:54-73
+      double t = 0.0;
+      int J = 0;
+      while (t < time_limit && (c.cfg->cap_cfg <= 0 || J < c.cfg->cap_cfg)) {
+        if (J >= c.J_cap) {
+          H.err = SSS_ERR_CAPACITY;
+          H.need_reset = 1;
+          break;
+        }
+        int q = (int)rng_integers(H, 22);     // TPCH:177
+        int size = (int)rng_integers(H, 7);   // TPCH:178
+        c.jobs[J].tmpl = (int16_t)(q * 7 + size);
+        c.t_arrival[J] = t;
+        J++;
+        t += c.cfg->mean_interarrival * rng_standard_exponential(c, H);  // TPCH:70
+      }
+      H.J = J;
+    }
+  }
+  // executors + event slots + commitments
+  if (lane < SSS_MAX_EXEC) {
+    hot.ev_t[lane] = 0.0, hot.ev_seq[lane] = 0, hot.ex_loc[lane] = lane < c.E ? POOL_COMMON : POOL_NONE;
+    hot.ev_job[lane] = -1, hot.ex_job[lane] = -1, hot.ev_stage[lane] = -1, hot.ev_kind[lane] = EV_NONE;
+    hot.ex_task_stage[lane] = -1, hot.ex_executing[lane] = 0;
+    hot.c_src[lane] = POOL_NONE, hot.c_dst[lane] = POOL_NONE, hot.c_seq[lane] = 0, hot.c_n[lane] = 0;
+  }
+  wave_sync();
+  int J = hot.h.J;
+  // job records: one lane per job
+  for (int j = lane; j < J; j += 64) {
+    SssJob& job = c.jobs[j];
+    int tmpl = job.tmpl;
+    int gs = c.pk->tmpl_stage_off[tmpl];
+    int ns = c.pk->tmpl_stage_off[tmpl + 1] - gs;
+    uint64_t frontier = 0;
+    for (int s = 0; s < ns; s++)
+      if (c.pk->stage_parent_mask[gs + s] == 0) frontier |= bit64(s);  // JOB:93-111
+    job.active_mask = ns >= 64 ? ~0ull : (bit64(ns) - 1);
+    job.frontier_mask = frontier;
+    job.selected_mask = 0, job.sched_mask = 0, job.sat_mask = 0, job.local_mask = 0;
+    job.supply = 0, job.sat_count = 0, job.completion_order = -1;
+    job.n_stages = (uint8_t)ns;
+    job.n_edges = (uint8_t)(c.pk->tmpl_edge_off[tmpl + 1] - c.pk->tmpl_edge_off[tmpl]);
+    job.pad = 0;
+    job.gs_base = gs;
+    c.t_completed[j] = __builtin_inf();
+  }
+  wave_sync();
+  // stage records: lanes over (job, stage)
+  for (int i = lane; i < J * c.SP; i += 64) {
+    int j = i / c.SP, s = i - j * c.SP;
+    const SssJob& job = c.jobs[j];
+    SssStage st = {0, 0, 0, 0};
+    float d = 0.0f;
+    if (s < (int)job.n_stages) {
+      st.remaining = (int16_t)c.pk->stage_num_tasks[job.gs_base + s];
+      d = (float)c.pk->stage_rough[job.gs_base + s];
+    }
+    c.stages[i] = st;
+    c.durations[i] = d;
+  }
+  // pools: every job / stage pool starts as an empty 8-slot set (TRK:73-96)
+  int n_pools = 1 + c.J_cap + J * c.SP;
+  for (int p = lane; p < n_pools; p += 64) {
+    SssPoolHdr hd = {7, 0, 0, 0};
+    c.pool_hdr[p] = hd;
+    *(uint64_t*)(c.pool_tab + (size_t)p * SSS_SET_TABLE) = 0ull;
+  }
+  wave_sync();
+  if (lane == 0 && !H.err) {
+    // common pool = set(range(E)) (TRK:41)
+    SetImg<uint8_t> s = pool_open(c, POOL_COMMON);
+    for (int e = 0; e < c.E; e++) set_add(s, (uint32_t)e, c.sc->keys);
+    pool_close(c, POOL_COMMON, s);
+    // _load_initial_jobs ENV:260-273
+    while (H.next_arrival < H.J && c.t_arrival[H.next_arrival] <= 0.0) {
+      handle_job_arrival(c, H.next_arrival);
+      H.next_arrival++;
+    }
+  }
+  if (lane == 0) publish_scan_inputs(c);
+  wave_sync();
+  int n = find_schedulable_all(c);
+  if (lane == 0) H.n_sched = n;
+  wave_sync();
+}
+
+// ENV:188-221. `reward` is valid on lane 0 (and uniform).
+SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
+  int lane = wave_lane();
+  if (lane == 0) {
+    c.sc->f_round_continues = 1;
+    c.sc->events_this_step = 0;
+    H.last_reward = 0.0;
+    if (H.need_reset || H.terminated) {
+      H.err = SSS_ERR_NEED_RESET;
+    } else {
+      H.err = 0;
+      bool ok = take_action(c, stage_idx, num_exec);
+      if (ok && !H.err) {
+        H.n_steps++;
+        if (!(trk_num_committable(c) > 0 && H.n_sched > 0)) {
+          // commitment round is over (ENV:195-203)
+          commit_remaining_executors(c);
+          fulfill_commitments_from_source(c);
+          H.curr_source = POOL_NONE;
+          for (int a = 0; a < H.n_active; a++) c.jobs[c.active[a]].selected_mask = 0;
+          c.sc->wall_old = H.wall_time;
+          c.sc->n_old_active = H.n_active;
+          for (int a = 0; a < H.n_active; a++) c.old_active[a] = c.active[a];
+          c.sc->f_round_continues = 0;
+        }
+      }
+      if (H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
+    }
+  }
+  wave_sync();
+  if (wave_ballot(c.sc->f_round_continues || c.hot->h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
+  resume_simulation(c);
+  double reward = 0.0;
+  if (lane == 0) {
+    if (!H.err) {
+      reward = -compute_jobtime(c);
+      H.terminated = H.n_completed == H.J;  // ENV:227-229
+      if (!H.terminated && !(trk_num_committable(c) > 0 && H.n_sched > 0)) H.err = SSS_ERR_STALLED;  // ENV:212-215
+      if (H.terminated) H.episodes++;
+    }
+    if (H.err) H.need_reset = 1;
+  }
+  wave_sync();
+  return reward;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+struct SssKernelArgs {
+  SssLayout L;
+  SssBuffers B;
+  const SssCfgDev* cfg;
+  const SssPackDev* pk;
+};
+
+// reset envs whose mask byte is non-zero (mask == nullptr: all)
+SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const double* time_limits, const uint8_t* mask) {
+  SSS_SHARED SssHot hot;
+  SSS_SHARED SssScratch sc;
+  int env = wave_env();
+  if (mask && !mask[env]) return;
+  uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
+  Ctx c;
+  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
+  hot_load(&hot, (const SssHot*)base);
+  wave_sync();
+  do_reset(c, a.L, seeds[env], time_limits ? time_limits[env] : __builtin_inf());
+  write_observation(c, a.L, a.B, env, 0.0);
+  wave_sync();
+  hot_store((SssHot*)base, &hot);
+}
+
+// one step() per env; with auto_reset != 0 an env that is terminated at entry starts its next
+// episode instead (seed += seed_stride), like a vector env in "next-step" autoreset mode
+SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
+  SSS_SHARED SssHot hot;
+  SSS_SHARED SssScratch sc;
+  int env = wave_env();
+  uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
+  Ctx c;
+  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
+  hot_load(&hot, (const SssHot*)base);
+  wave_sync();
+  double reward = 0.0;
+  // the ballot doubles as the barrier between "all lanes read the header" and lane 0 rewriting it
+  bool start_next_episode = wave_ballot(auto_reset && hot.h.terminated && !hot.h.err) != 0;
+  if (start_next_episode) {
+    do_reset(c, a.L, hot.h.seed + seed_stride, hot.h.time_limit);
+  } else {
+    reward = do_step(c, stage_idx[env], num_exec[env]);
+  }
+  write_observation(c, a.L, a.B, env, reward);
+  wave_sync();
+  hot_store((SssHot*)base, &hot);
+}
+
+#undef H
+#undef FAIL
+#undef CHECK

@@ -1,0 +1,230 @@
+"""Batched Spark-scheduling environment: the host-side mirror of the reference's
+`SparkSchedSimEnv` (reference spark_sched_sim/spark_sched_sim.py:29-245) over `num_envs`
+independent simulations that live in HBM and are stepped by the HIP kernels behind include/sss.h.
+
+PyTorch only provides device memory and streams here: every buffer is a torch tensor whose raw
+pointer is handed to the C ABI, so observations come back as device tensors without a copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Sequence
+
+import numpy as np
+import torch
+
+from . import workload
+from .binding import ERROR_NAMES, Binding, SssBuffers, SssCfg
+
+OBS_FIELDS = ("n_nodes", "n_edges", "n_jobs", "n_schedulable", "num_committable_execs", "source_job_idx",
+              "terminated", "err")
+NUM_NODE_FEATURES = 3  # reference spark_sched_sim.py:25
+
+
+class BatchedObs(dict):
+    """dict of device tensors; rows beyond n_nodes[i] / n_edges[i] / n_jobs[i] of env i are padding.
+
+    keys: nodes f32[B, node_cap, 3], edge_links i32[B, edge_cap, 2], dag_ptr i32[B, job_cap+1],
+    exec_supplies i32[B, job_cap], plus one i32[B] tensor per OBS_FIELDS entry.
+    """
+
+
+class VecSparkSchedSimEnv:
+    """`num_envs` reference environments in one object.
+
+    env_cfg keys are the reference's (`num_executors`, `job_arrival_cap`, `job_arrival_rate`,
+    `moving_delay`, `warmup_delay`, optional `beta`; `data_sampler_cls` must be "TPCHDataSampler"
+    if present) plus optional `max_jobs` (arena capacity when `job_arrival_cap` is None).
+    """
+
+    def __init__(self, env_cfg: dict[str, Any], num_envs: int, device: str | torch.device = "cuda:0",
+                 pack: bytes | None = None, auto_reset: bool = False, seed_stride: int | None = None,
+                 _lib: C.CDLL | None = None) -> None:
+        self.device = torch.device(device)
+        if self.device.type != "cuda" and _lib is None:
+            raise RuntimeError("VecSparkSchedSimEnv runs on an AMD GPU (device='cuda:N'); there is no CPU path")
+        sampler = env_cfg.get("data_sampler_cls", "TPCHDataSampler")
+        if sampler != "TPCHDataSampler":
+            raise ValueError(f"'{sampler}' is not a valid data sampler.")  # data_samplers/__init__.py:12-14
+        self.num_envs = int(num_envs)
+        self.num_executors = int(env_cfg["num_executors"])
+        self.env_cfg = dict(env_cfg)
+        self.auto_reset = bool(auto_reset)
+        self.seed_stride = int(seed_stride if seed_stride is not None else num_envs)
+        self._b = Binding(_lib)
+        self._pack = pack if pack is not None else workload.default_pack()
+        cap = env_cfg.get("job_arrival_cap")
+        self._cfg = SssCfg(self.num_executors, int(cap) if cap else 0, int(env_cfg.get("max_jobs") or 0), 0,
+                           float(env_cfg["job_arrival_rate"]), float(env_cfg["moving_delay"]),
+                           float(env_cfg["warmup_delay"]), float(env_cfg.get("beta", 0.0)))
+        self.dims = self._b.query_dims(self._cfg, self._pack, self.num_envs)
+        dev_index = self.device.index or 0
+        self._h = self._b.create(self._cfg, self._pack, self.num_envs, dev_index if self.device.type == "cuda" else -1)
+        d, B, dev = self.dims, self.num_envs, self.device
+        # the arena must start zeroed (lifetime counters) and 256-byte aligned
+        self._state_raw = torch.zeros(d.state_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self._state_raw.data_ptr()) % 256
+        self.state = self._state_raw[off: off + d.state_bytes]
+        self.nodes = torch.zeros((B, d.node_cap, NUM_NODE_FEATURES), dtype=torch.float32, device=dev)
+        self.edge_links = torch.zeros((B, d.edge_cap, 2), dtype=torch.int32, device=dev)
+        self.dag_ptr = torch.zeros((B, d.job_cap + 1), dtype=torch.int32, device=dev)
+        self.exec_supplies = torch.zeros((B, d.job_cap), dtype=torch.int32, device=dev)
+        self.obs_i32 = torch.zeros((B, d.obs_i32), dtype=torch.int32, device=dev)
+        self.obs_f64 = torch.zeros((B, d.obs_f64), dtype=torch.float64, device=dev)
+        bufs = SssBuffers(self.state.data_ptr(), self.nodes.data_ptr(), self.edge_links.data_ptr(),
+                          self.dag_ptr.data_ptr(), self.exec_supplies.data_ptr(), self.obs_i32.data_ptr(),
+                          self.obs_f64.data_ptr())
+        self._b.check(self._b.lib.sss_bind_buffers(self._h, C.byref(bufs)))
+        self._seeds = torch.zeros(B, dtype=torch.int64, device=dev)
+        self._tl = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+        self._mask = torch.ones(B, dtype=torch.uint8, device=dev)
+        self._env_view = self.state.view(B, d.env_stride)
+        self._closed = False
+
+    # ---- plumbing ---------------------------------------------------------------------
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+
+    def _obs(self) -> BatchedObs:
+        o = BatchedObs(nodes=self.nodes, edge_links=self.edge_links, dag_ptr=self.dag_ptr,
+                       exec_supplies=self.exec_supplies)
+        for k, name in enumerate(OBS_FIELDS):
+            o[name] = self.obs_i32[:, k]
+        return o
+
+    def close(self) -> None:
+        if not self._closed:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self._b.lib.sss_destroy(self._h)
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Gymnasium-style API ----------------------------------------------------------
+
+    def reset(self, *, seed: int | Sequence[int] | None = None, options: dict[str, Any] | None = None,
+              mask: torch.Tensor | None = None):
+        """reference `reset(seed, options)` (spark_sched_sim.py:127-186) for every env (or the
+        envs selected by `mask`). `seed`: int -> env i gets seed + i; sequence -> per env;
+        None -> fresh entropy, as `gymnasium.Env.reset(seed=None)` does."""
+        B = self.num_envs
+        if seed is None:
+            seeds = np.random.SeedSequence().generate_state(B, np.uint64) >> np.uint64(1)
+        elif isinstance(seed, (int, np.integer)):
+            seeds = np.arange(B, dtype=np.uint64) + np.uint64(int(seed))
+        else:
+            seeds = np.asarray(list(seed), dtype=np.uint64)
+            if seeds.shape != (B,):
+                raise ValueError("need one seed per env")
+        self._seeds.copy_(torch.from_numpy(seeds.view(np.int64)))
+        tl = (options or {}).get("time_limit", np.inf)
+        tl_arr = np.broadcast_to(np.asarray(tl, dtype=np.float64), (B,)).copy()
+        self._tl.copy_(torch.from_numpy(tl_arr))
+        mask_ptr = None
+        if mask is not None:
+            self._mask.copy_(mask.to(torch.uint8))
+            mask_ptr = self._mask.data_ptr()
+        self._b.check(self._b.lib.sss_reset(self._h, self._seeds.data_ptr(), self._tl.data_ptr(), mask_ptr, self._stream()))
+        return self._obs(), {"wall_time": self.obs_f64[:, 1]}
+
+    def step_async(self, stage_idx: torch.Tensor, num_exec: torch.Tensor) -> None:
+        """launches one `step(action)` per env on the current stream and returns immediately"""
+        assert stage_idx.dtype == torch.int32 and num_exec.dtype == torch.int32
+        assert stage_idx.device == self.device and stage_idx.is_contiguous() and num_exec.is_contiguous()
+        self._b.check(self._b.lib.sss_step(self._h, stage_idx.data_ptr(), num_exec.data_ptr(), int(self.auto_reset),
+                                           self.seed_stride, self._stream()))
+
+    def step(self, actions):
+        """reference `step(action)` (spark_sched_sim.py:188-221), batched.
+        `actions`: {"stage_idx": i32[B], "num_exec": i32[B]} (tensors on the env's device).
+        Returns (obs, reward f64[B], terminated bool[B], truncated bool[B], info)."""
+        if set(actions.keys()) != {"stage_idx", "num_exec"}:
+            raise ValueError("invalid action: does not belong to the action space")  # Dict.contains
+        self.step_async(actions["stage_idx"], actions["num_exec"])
+        obs = self._obs()
+        terminated = obs["terminated"] != 0
+        return obs, self.obs_f64[:, 0], terminated, torch.zeros_like(terminated), {"wall_time": self.obs_f64[:, 1], "err": obs["err"]}
+
+    def raise_on_error(self) -> None:
+        """the reference raises from inside step(); the batched env records a per-env code. This
+        turns recorded codes into the reference's exception types (one device->host sync)."""
+        err = self.obs_i32[:, 7].cpu().numpy()
+        bad = np.nonzero(err)[0]
+        if bad.size:
+            code = int(err[bad[0]])
+            msg = f"env(s) {bad.tolist()[:8]}: {ERROR_NAMES.get(code, code)}"
+            if code in (5, 7):
+                raise AssertionError(msg)
+            if code == 2:
+                raise KeyError(msg)
+            raise ValueError(msg)
+
+    # ---- per-env views (host copies) for unmodified reference-style plugins ---------------
+
+    def obs_view(self, i: int) -> dict[str, Any]:
+        """the reference observation dict of env i (spark_sched_sim.py:393-399) as numpy/python
+        objects - what `Scheduler.schedule(obs)` plugins written for the reference consume."""
+        from .spaces import GraphInstance
+
+        s = self.obs_i32[i].cpu().numpy()
+        n, ne, a = int(s[0]), int(s[1]), int(s[2])
+        nodes = self.nodes[i, :n].cpu().numpy()
+        el = self.edge_links[i, :ne].cpu().numpy().astype(np.int64)
+        return {
+            "dag_batch": GraphInstance(nodes, np.zeros(ne, dtype=int), el),
+            "dag_ptr": self.dag_ptr[i, : a + 1].cpu().tolist(),
+            "num_committable_execs": int(s[4]),
+            "source_job_idx": int(s[5]),
+            "exec_supplies": self.exec_supplies[i, :a].cpu().tolist(),
+        }
+
+    def _hdr_i32(self, i: int, byte_off: int) -> int:
+        return int(self._env_view[i, byte_off: byte_off + 4].cpu().numpy().view(np.int32)[0])
+
+    def job_times(self, i: int):
+        """(t_arrival f64[J], t_completed f64[J], completion_order i16[J]) of env i's current episode"""
+        d = self.dims
+        row = self._env_view[i].cpu().numpy()
+        hdr = row[: d.hdr_bytes]
+        J = int(hdr[HDR_OFF["J"]: HDR_OFF["J"] + 4].view(np.int32)[0])
+        ta = row[d.off_t_arrival: d.off_t_arrival + 8 * J].view(np.float64).copy()
+        tc = row[d.off_t_completed: d.off_t_completed + 8 * J].view(np.float64).copy()
+        jobs = row[d.off_jobs: d.off_jobs + d.job_rec_bytes * J].reshape(J, d.job_rec_bytes)
+        order = jobs[:, 54:56].copy().view(np.int16).ravel()
+        tmpl = jobs[:, 48:50].copy().view(np.int16).ravel()
+        return ta, tc, order, tmpl
+
+    def header(self, i: int) -> dict[str, Any]:
+        hdr = self._env_view[i, : self.dims.hdr_bytes].cpu().numpy()
+        out = {}
+        for name, off in HDR_OFF.items():
+            w = HDR_W[name]
+            out[name] = hdr[off: off + np.dtype(w).itemsize].view(w)[0].item()
+        return out
+
+    def counters(self) -> dict[str, int]:
+        """lifetime totals over all envs: real step() calls, events popped, SURVEY 8(d) model bytes"""
+        hdr = self._env_view[:, : self.dims.hdr_bytes].cpu().numpy()
+        tot = {}
+        for name in ("n_steps", "n_events", "model_bytes"):
+            off = HDR_OFF[name]
+            tot[name] = int(np.ascontiguousarray(hdr[:, off: off + 8]).view(np.uint64).sum())
+        return tot
+
+
+# byte offsets inside SssHdr (csrc/sss_layout.h); checked by tests/test_layout.py
+HDR_OFF = {"wall_time": 40, "time_limit": 48, "seed": 56, "n_steps": 64, "n_events": 72, "model_bytes": 80,
+           "counter": 88, "next_arrival": 92, "J": 96, "n_active": 100, "n_completed": 104, "curr_source": 108,
+           "n_sched": 112, "terminated": 136, "err": 140, "need_reset": 144, "dur_head": 148, "dur_n": 152,
+           "episodes": 156, "last_reward": 160}
+HDR_W = {"wall_time": np.float64, "time_limit": np.float64, "seed": np.uint64, "n_steps": np.uint64,
+         "n_events": np.uint64, "model_bytes": np.uint64, "counter": np.uint32, "next_arrival": np.int32,
+         "J": np.int32, "n_active": np.int32, "n_completed": np.int32, "curr_source": np.uint32,
+         "n_sched": np.int32, "terminated": np.int32, "err": np.int32, "need_reset": np.int32,
+         "dur_head": np.int32, "dur_n": np.int32, "episodes": np.int32, "last_reward": np.float64}

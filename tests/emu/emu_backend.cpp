@@ -1,0 +1,35 @@
+// tests/emu/emu_backend.cpp - the C ABI of include/sss.h on the CPU wave emulator
+// (TEST INFRASTRUCTURE: lets tests/ run the kernel source of spark_sched_sim_amd/csrc/sss_sim.h
+// without a GPU, also under ASan/UBSan). "Device" memory is host memory; launches are synchronous.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+#include "wave_rt.h"
+namespace emu {
+void launch(int grid, const std::function<void()>& body);
+}
+
+#include "sss_sim.h"
+#include "zig_tables.inc"
+
+static int be_set_device(int) { return 0; }
+static const char* be_error(int) { return "emulator"; }
+static void* be_alloc(size_t n) { return calloc(1, n ? n : 1); }
+static void be_free(void* p) { free(p); }
+static int be_h2d(void* dst, const void* src, size_t n) {
+  memcpy(dst, src, n);
+  return 0;
+}
+static int be_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* seeds, const double* tl, const uint8_t* mask, void*) {
+  emu::launch(num_envs, [&]() { sss_reset_kernel(a, seeds, tl, mask); });
+  return 0;
+}
+static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride, void*) {
+  emu::launch(num_envs, [&]() { sss_step_kernel(a, stage_idx, num_exec, auto_reset, seed_stride); });
+  return 0;
+}
+
+#include "sss_host.h"

@@ -1,0 +1,71 @@
+// tests/emu/wave_rt.h - CPU emulation of spark_sched_sim_amd/csrc/wave_rt.h (TEST INFRASTRUCTURE).
+//
+// Lets the unmodified kernel source (csrc/sss_sim.h) be compiled with g++ and run on the host:
+// the 64 lanes of a "wave" are 64 fibers executed strictly round-robin; a fiber runs until its
+// next collective (wave_sync / ballot / min / bcast), deposits its operand and yields to the
+// next lane. Because every lane executes the same sequence of collectives (they are only legal
+// in wave-uniform control flow), all 64 operands are present when a lane resumes. The emulator
+// aborts if lanes disagree on which collective they are at, or if some lanes finish the kernel
+// while others still wait - i.e. it also checks the uniformity the real hardware silently assumes.
+//
+// This is how the HIP code path is debugged and run under ASan/UBSan without a GPU. It is never
+// loaded by the product: only tests build tests/emu (see tests/emu/Makefile).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#define SSS_DEV static inline
+#define SSS_DEV_NOINLINE static __attribute__((noinline))
+#define SSS_KERNEL extern "C"
+#define SSS_SHARED static
+
+namespace emu {
+enum Op { OP_SYNC = 1, OP_BALLOT, OP_BCAST, OP_MIN32, OP_MIN64, OP_SUM32 };
+int lane();
+int env();
+// deposits (op, value), yields round-robin, returns once all 64 lanes have deposited; the
+// operands of all lanes are then readable through slot(i)
+void collective(int op, uint64_t value);
+uint64_t slot(int lane);
+}  // namespace emu
+
+SSS_DEV int wave_lane() { return emu::lane(); }
+SSS_DEV int wave_env() { return emu::env(); }
+SSS_DEV void wave_sync() { emu::collective(emu::OP_SYNC, 0); }
+SSS_DEV uint64_t wave_ballot(bool p) {
+  emu::collective(emu::OP_BALLOT, p ? 1 : 0);
+  uint64_t m = 0;
+  for (int i = 0; i < 64; i++) m |= (emu::slot(i) & 1ull) << i;
+  return m;
+}
+SSS_DEV uint32_t wave_bcast_u32(uint32_t v, int src) {
+  emu::collective(emu::OP_BCAST, v);
+  return (uint32_t)emu::slot(src & 63);
+}
+SSS_DEV uint32_t wave_min_u32(uint32_t v) {
+  emu::collective(emu::OP_MIN32, v);
+  uint32_t m = 0xFFFFFFFFu;
+  for (int i = 0; i < 64; i++) m = (uint32_t)emu::slot(i) < m ? (uint32_t)emu::slot(i) : m;
+  return m;
+}
+SSS_DEV uint64_t wave_min_u64(uint64_t v) {
+  emu::collective(emu::OP_MIN64, v);
+  uint64_t m = ~0ull;
+  for (int i = 0; i < 64; i++) m = emu::slot(i) < m ? emu::slot(i) : m;
+  return m;
+}
+SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
+  emu::collective(emu::OP_SUM32, v);
+  uint32_t s = 0;
+  for (int i = 0; i < 64; i++) s += (uint32_t)emu::slot(i);
+  return s;
+}
+SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+SSS_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
+SSS_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : -1; }
+SSS_DEV uint64_t f64_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+SSS_DEV double bits_f64(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+SSS_DEV uint32_t f64_hi32(double x) { return (uint32_t)(f64_bits(x) >> 32); }
+SSS_DEV double f64_with_hi32(double x, uint32_t hi) { return bits_f64((f64_bits(x) & 0xFFFFFFFFull) | ((uint64_t)hi << 32)); }
+
+struct uint4 { uint32_t x, y, z, w; };
