@@ -97,6 +97,17 @@ int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double* time_limit
  * starts its next episode instead (seed = previous seed + seed_stride), reward 0. */
 int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, void* stream);
 
+/* On-device counterparts of the reference's heuristic Scheduler plugins; they fill one action per
+ * env for the next sss_step. policy: 0 = fair (RoundRobinScheduler(dynamic_partition=True),
+ * schedulers/heuristics/round_robin.py:7-49), 1 = FIFO (dynamic_partition=False), 2 = the build's
+ * counter-based uniform-random policy (param = per-mille probability of stage_idx = -1). */
+int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_idx_dev, int32_t* num_exec_dev, void* stream);
+
+/* n_steps x (policy -> step -> observe) per env in ONE launch: the episode loop of reference
+ * examples.py:84-102 / trainers/rollout_worker.py:135-157 with an on-device policy. Per-step
+ * semantics are exactly those of sss_policy + sss_step; only the last observation survives. */
+int sss_rollout(sss_handle* h, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

@@ -47,7 +47,9 @@ ERROR_NAMES = {
     10: "more job arrivals than max_jobs",
 }
 
-EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_last_error", "sss_destroy"]
+EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
+           "sss_last_error", "sss_destroy"]
+POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
 def load_library(path: str | None = None) -> C.CDLL:
@@ -69,6 +71,8 @@ class Binding:
         L.sss_bind_buffers.argtypes = [C.c_void_p, C.POINTER(SssBuffers)]
         L.sss_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+        L.sss_policy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
 

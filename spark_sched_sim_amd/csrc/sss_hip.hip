@@ -30,4 +30,13 @@ static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* s
   return (int)hipGetLastError();
 }
 
+static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, int param, int32_t* stage_idx, int32_t* num_exec, void* stream) {
+  hipLaunchKernelGGL(sss_policy_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, policy, param, stage_idx, num_exec);
+  return (int)hipGetLastError();
+}
+static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream) {
+  hipLaunchKernelGGL(sss_rollout_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, policy, param, n_steps, auto_reset, seed_stride);
+  return (int)hipGetLastError();
+}
+
 #include "sss_host.h"

@@ -213,6 +213,23 @@ extern "C" int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32
   return 0;
 }
 
+extern "C" int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_idx_dev, int32_t* num_exec_dev, void* stream) {
+  if (!h || !stage_idx_dev || !num_exec_dev) return sss_fail(-1, "NULL argument");
+  if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  if (policy < 0 || policy > 2) return sss_fail(-23, "unknown policy");
+  if (int rc = be_launch_policy(sss_args(h), h->L.num_envs, policy, param, stage_idx_dev, num_exec_dev, stream)) return sss_fail(-30, std::string("policy launch failed: ") + be_error(rc));
+  return 0;
+}
+
+extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream) {
+  if (!h) return sss_fail(-1, "NULL argument");
+  if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  if (policy < 0 || policy > 2) return sss_fail(-23, "unknown policy");
+  if (n_steps < 0) return sss_fail(-24, "n_steps must be >= 0");
+  if (int rc = be_launch_rollout(sss_args(h), h->L.num_envs, policy, param, n_steps, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("rollout launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
   be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->cfg_dev), be_free(h->pk_dev);

@@ -72,7 +72,12 @@ struct SssHdr {            // 256 bytes
   int32_t dur_head, dur_n;
   int32_t episodes;        // completed episodes (auto-reset bookkeeping)
   double last_reward;
-  uint8_t pad[256 - 4 * 8 - 2 * 4 - 2 * 8 - 4 * 8 - 18 * 4 - 8];
+  double ep_return;        // sum of rewards of the running episode
+  double last_ep_return;   // ... of the last finished episode
+  double last_ep_wall;     // wall_time at which the last finished episode ended
+  int32_t ep_steps;        // step() calls in the running episode
+  int32_t last_ep_steps;
+  uint8_t pad[256 - 4 * 8 - 2 * 4 - 2 * 8 - 4 * 8 - 18 * 4 - 8 - 3 * 8 - 2 * 4];
 };
 
 struct SssHot {            // staged HBM <-> LDS as a flat block

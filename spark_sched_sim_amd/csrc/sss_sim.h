@@ -1271,11 +1271,13 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
   if (lane == 0) {
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
-    int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes;
+    int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
+    double last_ep_return = H.last_ep_return, last_ep_wall = H.last_ep_wall;
     SssHdr z = {};
     H = z;
     H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
+    H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
     H.seed = seed, H.time_limit = time_limit;
     H.curr_source = POOL_COMMON;
     c.sc->events_this_step = 0;
@@ -1385,6 +1387,7 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
       bool ok = take_action(c, stage_idx, num_exec);
       if (ok && !H.err) {
         H.n_steps++;
+        H.ep_steps++;
         if (!(trk_num_committable(c) > 0 && H.n_sched > 0)) {
           // commitment round is over (ENV:195-203)
           commit_remaining_executors(c);
@@ -1409,7 +1412,11 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
       reward = -compute_jobtime(c);
       H.terminated = H.n_completed == H.J;  // ENV:227-229
       if (!H.terminated && !(trk_num_committable(c) > 0 && H.n_sched > 0)) H.err = SSS_ERR_STALLED;  // ENV:212-215
-      if (H.terminated) H.episodes++;
+      H.ep_return += reward;
+      if (H.terminated) {
+        H.episodes++;
+        H.last_ep_return = H.ep_return, H.last_ep_steps = H.ep_steps, H.last_ep_wall = H.wall_time;
+      }
     }
     if (H.err) H.need_reset = 1;
   }
@@ -1466,6 +1473,160 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
   }
   write_observation(c, a.L, a.B, env, reward);
   wave_sync();
+  hot_store((SssHot*)base, &hot);
+}
+
+// ------------------------------------------------------------------------------------------
+// on-device policies: the build's batched counterparts of the reference's heuristic plugins.
+// They read the same quantities a `Scheduler.schedule(obs)` plugin gets from the observation
+// (per-job schedulable / frontier stages, exec_supplies, num_committable_execs, source_job_idx),
+// but straight from the env state, so that no observation round trip is needed.
+// ------------------------------------------------------------------------------------------
+
+SSS_DEV int obs_num_committable(const Ctx& c) {
+  uint32_t srck = c.hot->h.curr_source;
+  if (srck == POOL_NONE) return 0;
+  int p = pool_index(c, srck);
+  return (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
+}
+
+// RoundRobinScheduler.schedule (reference schedulers/heuristics/round_robin.py:14-49 with
+// find_stage / preprocess_obs of heuristics/utils.py:5-37). All lanes; results are uniform.
+SSS_DEV void policy_fair(Ctx& c, bool dynamic_partition, int& stage_idx, int& num_exec) {
+  int lane = wave_lane();
+  // shared state is read up front; at least one collective follows before anything returns
+  int A = c.hot->h.n_active;
+  uint32_t srck = c.hot->h.curr_source;
+  int ncommit = obs_num_committable(c);
+  int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
+  int denom = A > 1 ? A : 1;
+  int cap = dynamic_partition ? (c.E + denom - 1) / denom : c.E;  // int(ceil(E / max(1, A)))
+  int src_rank = -1, first_rank = -1, first_sup = 0;
+  uint32_t base = 0;
+  int n_chunks = (A + 63) / 64;
+  if (n_chunks == 0) n_chunks = 1;
+  for (int ch = 0; ch < n_chunks; ch++) {
+    int k = ch * 64 + lane;
+    bool valid = k < A;
+    int j = valid ? (int)c.active[k] : 0;
+    uint64_t sm = 0, act = 0;
+    int sup = 0, gs = 0;
+    if (valid) {
+      const SssJob& job = c.jobs[j];
+      sm = job.sched_mask, act = job.active_mask, sup = job.supply, gs = job.gs_base;
+    }
+    // find_stage: first schedulable stage with no active parent, else first schedulable stage
+    int best = -1;
+    uint64_t m = sm;
+    while (m) {
+      int s = ctz64(m);
+      m &= m - 1;
+      if ((c.pk->stage_parent_mask[gs + s] & act) == 0) {
+        best = s;
+        break;
+      }
+    }
+    if (best < 0 && sm) best = ctz64(sm);
+    uint32_t cnt = (uint32_t)popc64(sm);
+    uint32_t excl = wave_scan_excl_u32(cnt);
+    uint32_t total = wave_sum_u32(cnt);
+    uint32_t abs_rank = base + excl + (best >= 0 ? (uint32_t)popc64(sm & (bit64(best) - 1)) : 0u);
+    bool is_src = valid && j == src_job;
+    uint64_t m_src = wave_ballot(is_src && best >= 0);
+    uint64_t m_el = wave_ballot(valid && best >= 0 && !(sup >= cap || is_src));
+    if (m_src != 0 && src_rank < 0) src_rank = (int)wave_bcast_u32(abs_rank, ctz64(m_src));
+    if (m_el != 0 && first_rank < 0) {
+      int l = ctz64(m_el);
+      first_rank = (int)wave_bcast_u32(abs_rank, l);
+      first_sup = (int)wave_bcast_u32((uint32_t)sup, l);
+    }
+    base += total;
+  }
+  if (src_rank >= 0) {
+    stage_idx = src_rank, num_exec = ncommit;
+  } else if (first_rank >= 0) {
+    int room = cap - first_sup;
+    stage_idx = first_rank, num_exec = ncommit < room ? ncommit : room;
+  } else {
+    stage_idx = -1, num_exec = ncommit;
+  }
+  if (num_exec < 1) num_exec = 1;
+}
+
+SSS_DEV uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// the build's counter-based uniform-random policy, keyed (episode seed, step in episode); mirrors
+// hash_policy in tests/golden/make_golden.py. SURVEY 8(d) C2: stage uniform over the schedulable
+// stages, num_exec uniform in [1, num_committable]; `p_none_permille` adds stage_idx = -1 draws.
+SSS_DEV void policy_hash(Ctx& c, int p_none_permille, int& stage_idx, int& num_exec) {
+  uint64_t seed = c.hot->h.seed;
+  uint64_t step = (uint64_t)c.hot->h.ep_steps;
+  int n_sched = c.hot->h.n_sched;
+  int ncommit = obs_num_committable(c);
+  wave_sync();  // reads above vs. lane 0's writes in the step that follows
+  uint64_t h = splitmix64((seed << 32) ^ step), h2 = splitmix64(h), h3 = splitmix64(h2);
+  if (n_sched == 0 || (int)(h3 % 1000) < p_none_permille)
+    stage_idx = -1;
+  else
+    stage_idx = (int)(h % (uint64_t)n_sched);
+  num_exec = 1 + (int)(h2 % (uint64_t)(ncommit > 0 ? ncommit : 1));
+}
+
+enum { SSS_POLICY_FAIR = 0, SSS_POLICY_FIFO = 1, SSS_POLICY_HASH = 2 };
+
+SSS_DEV void run_policy(Ctx& c, int policy, int param, int& stage_idx, int& num_exec) {
+  if (policy == SSS_POLICY_HASH)
+    policy_hash(c, param, stage_idx, num_exec);
+  else
+    policy_fair(c, policy == SSS_POLICY_FAIR, stage_idx, num_exec);
+}
+
+// writes one action per env into stage_idx / num_exec (for sss_step)
+SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_t* stage_idx, int32_t* num_exec) {
+  SSS_SHARED SssHot hot;
+  SSS_SHARED SssScratch sc;
+  int env = wave_env();
+  uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
+  Ctx c;
+  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
+  hot_load(&hot, (const SssHot*)base);
+  wave_sync();
+  int si, ne;
+  run_policy(c, policy, param, si, ne);
+  if (wave_lane() == 0) stage_idx[env] = si, num_exec[env] = ne;
+}
+
+// n_steps x (policy -> step -> observe) per env in one launch; the env's hot block stays in LDS
+// in between. Every step still writes the full observation, as the reference's step() does.
+SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride) {
+  SSS_SHARED SssHot hot;
+  SSS_SHARED SssScratch sc;
+  int env = wave_env();
+  uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
+  Ctx c;
+  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
+  hot_load(&hot, (const SssHot*)base);
+  wave_sync();
+  for (int it = 0; it < n_steps; it++) {
+    bool over = wave_ballot(hot.h.terminated || hot.h.need_reset) != 0;
+    double reward = 0.0;
+    if (over) {
+      if (!auto_reset || wave_ballot(hot.h.err != 0) != 0) break;  // failed envs stay failed
+      do_reset(c, a.L, hot.h.seed + seed_stride, hot.h.time_limit);
+    } else {
+      int si, ne;
+      run_policy(c, policy, param, si, ne);
+      reward = do_step(c, si, ne);
+    }
+    write_observation(c, a.L, a.B, env, reward);
+    wave_sync();
+  }
   hot_store((SssHot*)base, &hot);
 }
 

@@ -49,6 +49,18 @@ SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
+// exclusive prefix sum over lanes
+SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
+  uint32_t x = v;
+  int lane = (int)threadIdx.x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = (uint32_t)__shfl_up((int)x, d, 64);
+    if (lane >= d) x += o;
+  }
+  return x - v;
+}
+
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 SSS_DEV int popc64(uint64_t x) { return __popcll(x); }
 SSS_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import workload
-from .binding import ERROR_NAMES, Binding, SssBuffers, SssCfg
+from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg
 
 OBS_FIELDS = ("n_nodes", "n_edges", "n_jobs", "n_schedulable", "num_committable_execs", "source_job_idx",
               "terminated", "err")
@@ -79,6 +79,8 @@ class VecSparkSchedSimEnv:
         self._tl = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
         self._mask = torch.ones(B, dtype=torch.uint8, device=dev)
         self._env_view = self.state.view(B, d.env_stride)
+        self._act_stage = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._act_nexec = torch.ones(B, dtype=torch.int32, device=dev)
         self._closed = False
 
     # ---- plumbing ---------------------------------------------------------------------
@@ -151,6 +153,21 @@ class VecSparkSchedSimEnv:
         terminated = obs["terminated"] != 0
         return obs, self.obs_f64[:, 0], terminated, torch.zeros_like(terminated), {"wall_time": self.obs_f64[:, 1], "err": obs["err"]}
 
+    # ---- on-device policies and fused rollouts ---------------------------------------------
+
+    def policy_actions(self, policy: str = "fair", param: int = 0):
+        """one action per env from an on-device heuristic ("fair" / "fifo" = the reference's
+        RoundRobinScheduler with / without dynamic partitioning, "hash" = the build's counter-based
+        uniform-random policy); returns {"stage_idx", "num_exec"} device tensors (re-used buffers)."""
+        self._b.check(self._b.lib.sss_policy(self._h, POLICY_IDS[policy], int(param), self._act_stage.data_ptr(),
+                                             self._act_nexec.data_ptr(), self._stream()))
+        return {"stage_idx": self._act_stage, "num_exec": self._act_nexec}
+
+    def rollout(self, policy: str, n_steps: int, param: int = 0) -> None:
+        """n_steps x (policy -> step) per env inside one kernel launch (asynchronous)"""
+        self._b.check(self._b.lib.sss_rollout(self._h, POLICY_IDS[policy], int(param), int(n_steps), int(self.auto_reset),
+                                              self.seed_stride, self._stream()))
+
     def raise_on_error(self) -> None:
         """the reference raises from inside step(); the batched env records a per-env code. This
         turns recorded codes into the reference's exception types (one device->host sync)."""
@@ -208,6 +225,13 @@ class VecSparkSchedSimEnv:
             out[name] = hdr[off: off + np.dtype(w).itemsize].view(w)[0].item()
         return out
 
+    def header_field(self, name: str) -> torch.Tensor:
+        """device tensor [B] of one header scalar (zero-copy view of the arena)"""
+        off, w = HDR_OFF[name], HDR_W[name]
+        tw = {np.float64: torch.float64, np.uint64: torch.int64, np.int32: torch.int32, np.uint32: torch.int32}[w]
+        n = np.dtype(w).itemsize
+        return self._env_view[:, off: off + n].view(tw).squeeze(1)
+
     def counters(self) -> dict[str, int]:
         """lifetime totals over all envs: real step() calls, events popped, SURVEY 8(d) model bytes"""
         hdr = self._env_view[:, : self.dims.hdr_bytes].cpu().numpy()
@@ -222,9 +246,12 @@ class VecSparkSchedSimEnv:
 HDR_OFF = {"wall_time": 40, "time_limit": 48, "seed": 56, "n_steps": 64, "n_events": 72, "model_bytes": 80,
            "counter": 88, "next_arrival": 92, "J": 96, "n_active": 100, "n_completed": 104, "curr_source": 108,
            "n_sched": 112, "terminated": 136, "err": 140, "need_reset": 144, "dur_head": 148, "dur_n": 152,
-           "episodes": 156, "last_reward": 160}
+           "episodes": 156, "last_reward": 160, "ep_return": 168, "last_ep_return": 176, "last_ep_wall": 184,
+           "ep_steps": 192, "last_ep_steps": 196}
 HDR_W = {"wall_time": np.float64, "time_limit": np.float64, "seed": np.uint64, "n_steps": np.uint64,
          "n_events": np.uint64, "model_bytes": np.uint64, "counter": np.uint32, "next_arrival": np.int32,
          "J": np.int32, "n_active": np.int32, "n_completed": np.int32, "curr_source": np.uint32,
          "n_sched": np.int32, "terminated": np.int32, "err": np.int32, "need_reset": np.int32,
-         "dur_head": np.int32, "dur_n": np.int32, "episodes": np.int32, "last_reward": np.float64}
+         "dur_head": np.int32, "dur_n": np.int32, "episodes": np.int32, "last_reward": np.float64,
+         "ep_return": np.float64, "last_ep_return": np.float64, "last_ep_wall": np.float64,
+         "ep_steps": np.int32, "last_ep_steps": np.int32}

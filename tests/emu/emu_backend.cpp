@@ -32,4 +32,13 @@ static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* s
   return 0;
 }
 
+static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, int param, int32_t* stage_idx, int32_t* num_exec, void*) {
+  emu::launch(num_envs, [&]() { sss_policy_kernel(a, policy, param, stage_idx, num_exec); });
+  return 0;
+}
+static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void*) {
+  emu::launch(num_envs, [&]() { sss_rollout_kernel(a, policy, param, n_steps, auto_reset, seed_stride); });
+  return 0;
+}
+
 #include "sss_host.h"

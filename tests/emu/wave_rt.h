@@ -20,7 +20,7 @@
 #define SSS_SHARED static
 
 namespace emu {
-enum Op { OP_SYNC = 1, OP_BALLOT, OP_BCAST, OP_MIN32, OP_MIN64, OP_SUM32 };
+enum Op { OP_SYNC = 1, OP_BALLOT, OP_BCAST, OP_MIN32, OP_MIN64, OP_SUM32, OP_SCAN32 };
 int lane();
 int env();
 // deposits (op, value), yields round-robin, returns once all 64 lanes have deposited; the
@@ -58,6 +58,12 @@ SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   emu::collective(emu::OP_SUM32, v);
   uint32_t s = 0;
   for (int i = 0; i < 64; i++) s += (uint32_t)emu::slot(i);
+  return s;
+}
+SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
+  emu::collective(emu::OP_SCAN32, v);
+  uint32_t s = 0;
+  for (int i = 0; i < emu::lane(); i++) s += (uint32_t)emu::slot(i);
   return s;
 }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }

@@ -25,6 +25,18 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
     err_step = [int(g.ep(s, "error_step")) for s in seeds]
     alive = [True] * len(seeds)
     bad: list[str] = []
+    def check_totals(k, s):
+        if err_step[k] >= 0 or (max_steps is not None and max_steps < len(g.ep(s, "reward"))):
+            return
+        ta, tc, order, tmpl = env.job_times(k)
+        if not np.array_equal(ta.view(np.uint64), g.ep(s, "t_arrival").view(np.uint64)) or not np.array_equal(tmpl.astype(np.int32), g.ep(s, "template")):
+            bad.append(f"{name} seed {s}: arrival times / templates differ")
+        wall = env.obs_f64[k, 1].item()
+        arrived = env.header(k)["next_arrival"]  # metrics.job_durations covers active + completed jobs only
+        dur = np.sort(np.minimum(tc[:arrived], wall) - ta[:arrived])
+        if not np.array_equal(dur, np.sort(g.ep(s, "job_durations"))):
+            bad.append(f"{name} seed {s}: job durations differ")
+
     i = 0
     while True:
         oi = env.obs_i32.cpu().numpy()
@@ -43,6 +55,7 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
                 continue
             if i >= n_rec[k]:
                 alive[k] = False
+                check_totals(k, s)  # now: shorter episodes keep being stepped (with no-op actions) below
                 continue
             o = oi[k]
             got = (int(o[0]), int(o[1]), int(o[2]), int(o[4]), int(o[5]))
@@ -63,6 +76,11 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
             if not ok:
                 bad.append(f"{name} seed {s} step {i}: got {got} err={int(o[7])} reward={of[k, 0]!r} wall={of[k, 1]!r}; expected {exp}")
                 alive[k] = False
+            elif i == n_rec[k] - 1 and not (err_step[k] >= 0):
+                # last recorded step: totals are checked now, before the longer episodes of the
+                # batch keep this env stepping with no-op actions
+                alive[k] = False
+                check_totals(k, s)
         if not any(alive):
             break
         si = torch.full((len(seeds),), -1, dtype=torch.int32)
@@ -73,16 +91,5 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
                 si[k], ne_[k] = int(st[i + 1]), int(g.ep(s, "num_exec")[i + 1])
         env.step({"stage_idx": si.to(env.device), "num_exec": ne_.to(env.device)})
         i += 1
-    # episode totals for envs that ran to the end
-    for k, s in enumerate(seeds):
-        if err_step[k] >= 0 or (max_steps is not None and max_steps < len(g.ep(s, "reward"))):
-            continue
-        ta, tc, order, tmpl = env.job_times(k)
-        if not np.array_equal(ta.view(np.uint64), g.ep(s, "t_arrival").view(np.uint64)) or not np.array_equal(tmpl.astype(np.int32), g.ep(s, "template")):
-            bad.append(f"{name} seed {s}: arrival times / templates differ")
-        wall = env.obs_f64[k, 1].item()
-        dur = np.sort(np.minimum(tc, wall) - ta)
-        if not np.array_equal(dur, np.sort(g.ep(s, "job_durations"))):
-            bad.append(f"{name} seed {s}: job durations differ")
     env.close()
     return bad
