@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the hot path: env-steps/s of the batched Spark-scheduling simulator.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs B] [--config c2|c3] [--policy hash|fair]
+                    [--mode step|fused] [--no-cpu-baseline]
+
+A "step" is ONE batched step of all envs of a rank: on-device policy kernel + step kernel
+(`--mode step`, the drop-in boundary: sss_policy + sss_step per step), or one iteration of the
+fused rollout kernel (`--mode fused`, sss_rollout: identical per-step work, policy -> step ->
+observe, without leaving the kernel). Envs auto-reset (next-step mode); only real step() calls are
+counted (the device counts them), so `value` = real env steps of all ranks / max-over-ranks time.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): envs are sharded, B per rank, no
+data-path collective; one RCCL all-gather of per-env episode returns after the timed region
+(the stand-in for the reference's Pipe gather, trainers/trainer.py:113-121). Weak scaling.
+
+Prints ONE JSON line on rank 0 (see the driver contract) including `roofline` (SURVEY 8(d) model
+bytes of the dominant kernel / its HIP-event-measured duration / 8 TB/s) and `cpu_baseline`
+(the C oracle, oracle/sss_oracle.c, timed on this box's host on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import os.path as osp
+import sys
+import time
+
+ROOT = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # C2 sizing = reference examples.py:15-23 (10 executors, 50 jobs); C3 = config/decima_tpch.yaml:81-85
+    "c2": dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
+    "c3": dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(cfg: dict, policy: str, budget_s: float) -> dict:
+    """the C oracle (a port of the reference env, bit-identical trajectories) on ONE host core,
+    same workload, whole episodes until ~budget_s of CPU time is spent"""
+    import ctypes as C
+
+    sys.path.insert(0, osp.join(ROOT, "tests"))
+    from oracle_binding import OracleEnv
+    from spark_sched_sim_amd import workload
+
+    env = OracleEnv(workload.default_pack(), cfg)
+    pol = {"fair": 0, "hash": 1}[policy]
+    steps, eps = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        r = C.c_double()
+        n = env.lib.sso_run_episode(env.h, 10_000 + eps, pol, 10**9, C.byref(r))
+        assert n > 0, n
+        steps += n
+        eps += 1
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{eps} episodes / {steps} steps of the same config and policy in {dt:.1f} s (C oracle, observation built every step)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--config", default="c2", choices=list(CONFIGS))
+    ap.add_argument("--policy", default=None, choices=["hash", "fair"])
+    ap.add_argument("--mode", default="step", choices=["step", "fused"])
+    ap.add_argument("--fused-chunk", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+    from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
+
+    cfg = CONFIGS[args.config]
+    policy = args.policy or ("hash" if args.config == "c2" else "fair")
+    B = args.envs
+    env = VecSparkSchedSimEnv(cfg, B, device=dev, pack=workload.default_pack(), auto_reset=True, seed_stride=B * world)
+    env.reset(seed=rank * B)  # env i of rank r: seed r*B + i  (placement-invariant global env id)
+
+    def run(n_steps: int, events=None):
+        if args.mode == "step":
+            for _ in range(n_steps):
+                act = env.policy_actions(policy)
+                if events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    env.step_async(act["stage_idx"], act["num_exec"])
+                    e1.record()
+                    events.append((e0, e1))
+                else:
+                    env.step_async(act["stage_idx"], act["num_exec"])
+        else:
+            done = 0
+            while done < n_steps:
+                n = min(args.fused_chunk, n_steps - done)
+                if events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    env.rollout(policy, n)
+                    e1.record()
+                    events.append((e0, e1))
+                else:
+                    env.rollout(policy, n)
+                done += n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    c0 = env.counters()
+    events: list = []
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, events)
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = env.counters()
+
+    steps = c1["n_steps"] - c0["n_steps"]
+    evs = c1["n_events"] - c0["n_events"]
+    model_bytes = c1["model_bytes"] - c0["model_bytes"]
+    kern_ms = sum(a.elapsed_time(b) for a, b in events)
+    n_launch = len(events)
+
+    tot = torch.tensor([float(steps), float(evs), float(model_bytes), kern_ms, float(n_launch)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # the one exchange of the path: all-gather of per-env episode returns
+        ret = env.header_field("last_ep_return").clone()
+        gathered = [torch.empty_like(ret) for _ in range(world)]
+        dist.all_gather(gathered, ret)
+        mean_return = torch.cat(gathered).mean().item()
+    else:
+        mean_return = env.header_field("last_ep_return").mean().item()
+    tot = tot.cpu().tolist()
+    dt_max = tmax.item()
+
+    if rank == 0:
+        steps_all, evs_all, bytes_all, kern_ms_all, launches_all = tot
+        value = steps_all / dt_max
+        # dominant kernel: step (or rollout) kernel. Algorithmic bytes per launch / average launch
+        # duration; per-rank averages are identical in expectation, so use the all-rank sums.
+        avg_launch_s = (kern_ms_all / launches_all) * 1e-3 if launches_all else float("nan")
+        bytes_per_launch = bytes_all / launches_all if launches_all else 0.0
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if launches_all else 0.0
+        out = {
+            "metric": "env-steps/sec at 4096 batched envs (TPC-H, 10 exec)" if (args.config == "c2" and B == 4096) else f"env-steps/sec at {B} batched envs ({args.config})",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64+f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{B} envs/GPU x ({cfg['num_executors']} executors, {cfg['job_arrival_cap']} TPC-H-format jobs, "
+                            f"job_arrival_rate {cfg['job_arrival_rate']}/ms, synthetic frozen trace set), on-device '{policy}' policy, "
+                            f"auto-reset, mode={args.mode}",
+                "envs_per_gpu": B, "policy": policy, "mode": args.mode, "parallelism": f"env-shard x{world}",
+            },
+            "events_per_s": evs_all / dt_max,
+            "events_per_step": evs_all / max(1.0, steps_all),
+            "mean_last_episode_return": mean_return,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "sss_step_kernel" if args.mode == "step" else "sss_rollout_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "kernel_time_frac_of_wall": (kern_ms_all / world) * 1e-3 / dt_max,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""The single-env facade + host-side plugin surface under the CPU wave emulator: an episode loop
+written exactly like the reference's `examples.run_episode` (examples.py:84-102) with the
+RoundRobinScheduler plugin must reproduce the recorded reference episode, metrics included, and
+invalid actions must raise what the reference raises."""
+import numpy as np
+import pytest
+
+from emu_util import load_emu
+from golden_util import Golden, bits
+from spark_sched_sim_amd import RoundRobinScheduler, SparkSchedSimEnv, metrics
+
+
+def run_episode(env_cfg, scheduler, seed, lib):
+    env = SparkSchedSimEnv(env_cfg, device="cpu", _lib=lib)
+    obs, _ = env.reset(seed=seed, options=None)
+    terminated = truncated = False
+    trace = []
+    while not (terminated or truncated):
+        action, _ = scheduler.schedule(obs)
+        obs, reward, terminated, truncated, info = env.step(action)
+        trace.append((int(action["stage_idx"]), int(action["num_exec"]), reward, info["wall_time"]))
+    return env, trace
+
+
+@pytest.mark.parametrize("name,seed,dyn", [("c1_fair", 1234, True), ("testyaml_fair", 3, True), ("c1_fifo", 5, False)])
+def test_reference_style_episode_loop(name, seed, dyn):
+    g = Golden(name)
+    env, trace = run_episode(g.cfg, RoundRobinScheduler(g.cfg["num_executors"], dynamic_partition=dyn), seed, load_emu())
+    assert len(trace) == len(g.ep(seed, "reward")) - 1
+    for i, (si, ne, r, w) in enumerate(trace, start=1):
+        assert (si, ne) == (int(g.ep(seed, "stage_idx")[i]), int(g.ep(seed, "num_exec")[i])), i
+        assert bits(r) == int(g.ep(seed, "reward")[i]) and bits(w) == int(g.ep(seed, "wall_time")[i]), i
+    # metrics: same values in the same order as the reference's list => identical mean
+    assert np.array_equal(np.asarray(metrics.job_durations(env)), g.ep(seed, "job_durations"))
+    assert bits(env.avg_job_duration) == bits(g.ep(seed, "avg_job_duration"))
+    assert env.all_jobs_complete and env.num_completed_jobs == int(g.ep(seed, "num_jobs"))
+    env.close()
+
+
+def test_invalid_actions_raise_like_the_reference():
+    g = Golden("tiny_hash")
+    env = SparkSchedSimEnv(g.cfg, device="cpu", _lib=load_emu())
+    obs, _ = env.reset(seed=0)
+    n_nodes = obs["dag_batch"].nodes.shape[0]
+    n_sched = int(obs["dag_batch"].nodes[:, 2].sum())
+    with pytest.raises(ValueError, match="action space"):
+        env.step({"stage_idx": n_nodes, "num_exec": 1})          # spark_sched_sim.py:276-277
+    with pytest.raises(ValueError, match="action space"):
+        env.step({"stage_idx": 0, "num_exec": 0})
+    with pytest.raises(ValueError, match="action space"):
+        env.step({"stage_idx": 0, "num_exec": 1, "job_idx": 0})  # Dict.contains rejects extra keys
+    if n_sched < n_nodes:
+        with pytest.raises(KeyError):
+            env.step({"stage_idx": n_sched, "num_exec": 1})      # spark_sched_sim.py:284
+    env2 = SparkSchedSimEnv(dict(g.cfg, num_executors=5), device="cpu", _lib=load_emu())
+    obs2, _ = env2.reset(seed=1)
+    # the env stays usable after a rejected action and the trajectory is unaffected
+    obs_after, r, term, trunc, _ = env.step({"stage_idx": int(g.ep(0, "stage_idx")[1]), "num_exec": int(g.ep(0, "num_exec")[1])})
+    assert bits(r) == int(g.ep(0, "reward")[1])
+    with pytest.raises(ValueError, match="limit"):
+        SparkSchedSimEnv(dict(g.cfg, job_arrival_cap=None, max_jobs=16), device="cpu", _lib=load_emu()).reset(seed=0)
+    env.close()
+    env2.close()
