@@ -1,0 +1,80 @@
+"""No-GPU checks of the product library: it builds for gfx950, loads, exports every symbol that
+include/sss.h declares, validates its inputs host-side, and the Python host refuses to run
+without the HIP path (no CPU fallback)."""
+import ctypes as C
+import os.path as osp
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    from spark_sched_sim_amd import build
+
+    return C.CDLL(build.build())
+
+
+def test_exports_match_header(hip_lib):
+    header = open(osp.join(ROOT, "include", "sss.h")).read()
+    declared = set(re.findall(r"\b(sss_[a-z_]+)\s*\(", header))
+    from spark_sched_sim_amd.binding import EXPORTS
+
+    assert declared == set(EXPORTS)
+    for sym in declared:
+        assert hasattr(hip_lib, sym), sym
+
+
+def test_query_dims_and_validation(hip_lib, pack):
+    from spark_sched_sim_amd.binding import Binding, SssCfg
+
+    b = Binding(hip_lib)
+    d = b.query_dims(SssCfg(10, 50, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), pack, 4096)
+    assert (d.num_envs, d.num_executors, d.job_cap, d.stage_stride) == (4096, 10, 50, 18)
+    assert d.node_cap == 50 * 18 and d.env_stride % 256 == 0 and d.state_bytes == d.env_stride * 4096
+    for bad_cfg, what in ((SssCfg(65, 50, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), "num_executors"),
+                          (SssCfg(10, 0, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), "max_jobs"),
+                          (SssCfg(10, 50, 0, 0, 0.0, 2000.0, 1000.0, 0.0), "job_arrival_rate")):
+        with pytest.raises(ValueError, match=what):
+            b.query_dims(bad_cfg, pack, 8)
+    with pytest.raises(ValueError, match="pack"):
+        b.query_dims(SssCfg(10, 50, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), b"garbage" * 100, 8)
+
+
+def test_no_cpu_fallback():
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.binding import load_library
+
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        VecSparkSchedSimEnv(cfg, 4, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        load_library("/nonexistent/libsss_hip.so")
+
+
+def test_header_offsets_match_layout(tmp_path):
+    """vec_env.HDR_OFF mirrors struct SssHdr (csrc/sss_layout.h)"""
+    from spark_sched_sim_amd.vec_env import HDR_OFF
+
+    src = tmp_path / "off.cpp"
+    fields = " ".join(f'P({k})' for k in HDR_OFF)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sss_layout.h"\nint main(){\n'
+                   '#define P(f) printf("%s %zu\\n", #f, offsetof(SssHdr, f));\n' + fields + "\nreturn 0;}\n")
+    exe = tmp_path / "off"
+    subprocess.run(["g++", "-I", osp.join(ROOT, "spark_sched_sim_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {l.split()[0]: int(l.split()[1]) for l in out.splitlines()}
+    assert got == HDR_OFF
+
+
+def test_workload_pack_is_frozen(pack):
+    from golden_util import Golden
+    from spark_sched_sim_amd import workload
+
+    assert workload.pack_digest(pack) == Golden("c1_fair").pack_sha256
+    arrs = workload.build_pack_arrays(workload.make_raw_workload())
+    assert arrs["tmpl_stage_off"].size == 155 and int(np.diff(arrs["tmpl_stage_off"]).max()) <= 64
