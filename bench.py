@@ -195,6 +195,8 @@ def main() -> None:
             "events_per_s": evs_all / dt_max,
             "events_per_step": evs_all / max(1.0, steps_all),
             "mean_last_episode_return": mean_return,
+            "phase_ticks_per_step": {k[6:]: (c1[k] - c0[k]) / max(1, steps) for k in c1 if k.startswith("ticks_")},
+            "fast_event_frac": (c1["n_fast_events"] - c0["n_fast_events"]) / max(1, evs),
             "roofline": {
                 "bound": "hbm",
                 "kernel": "sss_step_kernel" if args.mode == "step" else "sss_rollout_kernel",

@@ -21,21 +21,21 @@ static void be_free(void* p) {
 static int be_h2d(void* dst, const void* src, size_t n) { return (int)hipMemcpy(dst, src, n, hipMemcpyHostToDevice); }
 
 static int be_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* seeds, const double* tl, const uint8_t* mask, void* stream) {
-  hipLaunchKernelGGL(sss_reset_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, seeds, tl, mask);
+  hipLaunchKernelGGL(sss_reset_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, seeds, tl, mask);
   return (int)hipGetLastError();
 }
 static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
                           void* stream) {
-  hipLaunchKernelGGL(sss_step_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset, seed_stride);
+  hipLaunchKernelGGL(sss_step_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset, seed_stride);
   return (int)hipGetLastError();
 }
 
 static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, int param, int32_t* stage_idx, int32_t* num_exec, void* stream) {
-  hipLaunchKernelGGL(sss_policy_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, policy, param, stage_idx, num_exec);
+  hipLaunchKernelGGL(sss_policy_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, policy, param, stage_idx, num_exec);
   return (int)hipGetLastError();
 }
 static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream) {
-  hipLaunchKernelGGL(sss_rollout_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, a, policy, param, n_steps, auto_reset, seed_stride);
+  hipLaunchKernelGGL(sss_rollout_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, policy, param, n_steps, auto_reset, seed_stride);
   return (int)hipGetLastError();
 }
 

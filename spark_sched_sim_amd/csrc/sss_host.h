@@ -57,7 +57,8 @@ struct sss_handle {
   int device;
   void* pack_dev;
   void* zig_dev;
-  SssCfgDev* cfg_dev;
+  void* eff_dev;
+  SssParams P;
   SssPackDev* pk_dev;
 };
 
@@ -77,21 +78,38 @@ static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes,
   return 0;
 }
 
-// TPCHDataSampler._init_executor_intervals (reference data_samplers/tpch.py:237-262)
-static void sss_executor_intervals(int cap, double iv[][2]) {
-  static const int lv[8] = {5, 10, 20, 40, 50, 60, 80, 100};
-  for (int r = 0; r <= cap; r++) iv[r][0] = iv[r][1] = 0;
-  auto rows = [&](int lo, int hi, double a, double b) {
-    for (int r = lo < 0 ? 0 : lo; r < hi && r <= cap; r++) iv[r][0] = a, iv[r][1] = b;
-  };
-  rows(0, lv[0] + 1, lv[0], lv[0]);
-  for (int i = 0; i < 7; i++) {
-    rows(lv[i] + 1, lv[i + 1], lv[i], lv[i + 1]);
-    if (lv[i + 1] > cap) break;
-    rows(lv[i + 1], lv[i + 1] + 1, lv[i + 1], lv[i + 1]);
-  }
-  if (cap > lv[7])
-    for (int r = lv[7] + 1; r < cap; r++) iv[r][0] = iv[r][1] = lv[7];
+// Resolves TPCHDataSampler.task_duration's key substitution and fallback chain (reference
+// data_samplers/tpch.py:88-106, 231-233) per (stage, executor level, executor mode):
+//   mode 0  executor idle:        fresh_durations, else first_wave + warmup_delay
+//   mode 1  same stage as before: rest_wave, else first_wave, else fresh_durations
+//   mode 2  new to the stage:     first_wave, else fresh_durations
+// A wave "fails" when the level key is missing (KeyError) or its list is empty (ValueError from
+// Generator.choice before any draw); len 0 in the result = the exception would escape.
+static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost& ph, const int8_t lvl_of[8]) {
+  const uint32_t* keymask = (const uint32_t*)(pack + ph.sec_off[7]);
+  const int32_t* maxlvl = (const int32_t*)(pack + ph.sec_off[8]);
+  const int32_t* desc = (const int32_t*)(pack + ph.sec_off[10]);
+  std::vector<int32_t> eff((size_t)ph.total_stages * 8 * 3 * 2, 0);
+  for (int gs = 0; gs < ph.total_stages; gs++)
+    for (int i = 0; i < 8; i++) {
+      int lvl = lvl_of[i];
+      if (lvl < 0 || !((keymask[gs] >> lvl) & 1)) lvl = maxlvl[gs];
+      auto d = [&](int wave, int k) { return desc[((gs * 3 + wave) * ph.L + lvl) * 2 + k]; };
+      static const int chain[3][3] = {{0, 1, -1}, {2, 1, 0}, {1, 0, -1}};
+      for (int mode = 0; mode < 3; mode++) {
+        int32_t* out = &eff[(((size_t)gs * 8 + i) * 3 + mode) * 2];
+        for (int k = 0; k < 3; k++) {
+          int wave = chain[mode][k];
+          if (wave < 0) break;
+          if (d(wave, 1) > 0) {
+            out[0] = d(wave, 0);
+            out[1] = d(wave, 1) | ((mode == 0 && k == 1) ? (1 << 30) : 0);
+            break;
+          }
+        }
+      }
+    }
+  return eff;
 }
 
 static void sss_fill_dims(const SssLayout& L, sss_dims* d) {
@@ -133,9 +151,8 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   std::vector<uint8_t> zig(256 * 8 * 3);
   memcpy(zig.data(), ZIG_KE, 2048), memcpy(zig.data() + 2048, ZIG_WE, 2048), memcpy(zig.data() + 4096, ZIG_FE, 2048);
   h->zig_dev = be_alloc(zig.size());
-  h->cfg_dev = (SssCfgDev*)be_alloc(sizeof(SssCfgDev));
   h->pk_dev = (SssPackDev*)be_alloc(sizeof(SssPackDev));
-  if (!h->pack_dev || !h->zig_dev || !h->cfg_dev || !h->pk_dev) {
+  if (!h->pack_dev || !h->zig_dev || !h->pk_dev) {
     sss_destroy(h);
     return sss_fail(-11, "device allocation failed");
   }
@@ -162,22 +179,33 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   pk.zig_ke = (const uint64_t*)h->zig_dev;
   pk.zig_we = (const double*)((const uint8_t*)h->zig_dev + 2048);
   pk.zig_fe = (const double*)((const uint8_t*)h->zig_dev + 4096);
-  be_h2d(h->pk_dev, &pk, sizeof(pk));
 
-  SssCfgDev cd;
-  memset(&cd, 0, sizeof(cd));
-  cd.E = cfg->num_executors, cd.cap_cfg = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0, cd.J_cap = J_cap, cd.SP = ph.s_max;
-  cd.mean_interarrival = 1 / cfg->job_arrival_rate;  // tpch.py:42
-  cd.moving_delay = cfg->moving_delay, cd.warmup_delay = cfg->warmup_delay, cd.beta = cfg->beta;
-  sss_executor_intervals(cd.E, cd.intervals);
+  SssParams& P = h->P;
+  memset(&P, 0, sizeof(P));
+  P.cap_cfg = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0;
+  P.mean_interarrival = 1 / cfg->job_arrival_rate;  // tpch.py:42
+  P.moving_delay = cfg->moving_delay, P.warmup_delay = cfg->warmup_delay, P.beta = cfg->beta;
+  static const int exec_levels[8] = {5, 10, 20, 40, 50, 60, 80, 100};  // tpch.py:238
   const int32_t* levels = (const int32_t*)((const uint8_t*)pack + ph.sec_off[0]);
-  for (int r = 0; r <= cd.E; r++)
-    for (int k = 0; k < 2; k++) {
-      cd.interval_lvl[r][k] = -1;
-      for (int l = 0; l < ph.L; l++)
-        if ((double)levels[l] == cd.intervals[r][k]) cd.interval_lvl[r][k] = (int8_t)l;
-    }
-  be_h2d(h->cfg_dev, &cd, sizeof(cd));
+  for (int i = 0; i < 8; i++) {
+    P.lvl_of[i] = -1;
+    for (int l = 0; l < ph.L; l++)
+      if (levels[l] == exec_levels[i]) P.lvl_of[i] = (int8_t)l;
+  }
+  P.max_edges = ph.max_edges_per_job;
+  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, SSS_STATIC_LDS_BYTES)) {
+    sss_destroy(h);
+    return sss_fail(-12, "LDS working set does not fit");
+  }
+  std::vector<int32_t> eff = sss_build_eff((const uint8_t*)pack, ph, P.lvl_of);
+  h->eff_dev = be_alloc(eff.size() * sizeof(int32_t));
+  if (!h->eff_dev) {
+    sss_destroy(h);
+    return sss_fail(-11, "device allocation failed");
+  }
+  be_h2d(h->eff_dev, eff.data(), eff.size() * sizeof(int32_t));
+  pk.eff = (const int32_t*)h->eff_dev;
+  be_h2d(h->pk_dev, &pk, sizeof(pk));
   *out = h;
   return 0;
 }
@@ -195,7 +223,7 @@ extern "C" int sss_bind_buffers(sss_handle* h, const sss_buffers* b) {
 
 static SssKernelArgs sss_args(const sss_handle* h) {
   SssKernelArgs a;
-  a.L = h->L, a.B = h->B, a.cfg = h->cfg_dev, a.pk = h->pk_dev;
+  a.L = h->L, a.B = h->B, a.P = h->P, a.pk = h->pk_dev;
   return a;
 }
 
@@ -232,6 +260,6 @@ extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, in
 
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
-  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->cfg_dev), be_free(h->pk_dev);
+  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev), be_free(h->pk_dev);
   delete h;
 }

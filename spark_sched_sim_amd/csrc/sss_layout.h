@@ -77,7 +77,9 @@ struct SssHdr {            // 256 bytes
   double last_ep_wall;     // wall_time at which the last finished episode ended
   int32_t ep_steps;        // step() calls in the running episode
   int32_t last_ep_steps;
-  uint8_t pad[256 - 4 * 8 - 2 * 4 - 2 * 8 - 4 * 8 - 18 * 4 - 8 - 3 * 8 - 2 * 4];
+  double next_arrival_t;   // t_arrival[next_arrival] (+inf when exhausted): keeps the pop off HBM
+  uint64_t prof[5];        // shader-clock ticks spent in: slow-path event handlers, action+fulfil, event loop, reward, observe
+  uint64_t n_fast;         // events handled by the register fast path
 };
 
 struct SssHot {            // staged HBM <-> LDS as a flat block
@@ -108,14 +110,13 @@ struct SssJob {            // 64 bytes, one cache line
   uint64_t sched_mask;     // env.schedulable_stages restricted to this job
   uint64_t sat_mask;       // derived: bit s <=> executor demand of stage s <= 0
   uint64_t local_mask;     // job.local_executors
-  int16_t tmpl;
+  int32_t edge_off;        // first edge row of the template in the pack
   int16_t supply;          // exec_tracker._total_executor_count[job]
   int16_t sat_count;       // job.saturated_stage_count
   int16_t completion_order;
   uint8_t n_stages;
   uint8_t n_edges;         // template edges
-  uint16_t pad;
-  int32_t gs_base;         // first stage row of the template in the pack
+  int32_t gs_base;         // first stage row of the template in the pack (identifies the template)
 };
 
 struct SssStage {          // 8 bytes
@@ -135,11 +136,17 @@ struct SssLayout {
   int64_t off_pool_hdr, off_pool_tab, off_dur_ring, off_old_active, env_stride, state_bytes;
 };
 
-struct SssCfgDev {
-  int32_t E, cap_cfg, J_cap, SP;
+// small by-value kernel parameters (live in SGPRs)
+struct SssParams {
+  int32_t cap_cfg;         // job_arrival_cap, 0 = None
+  int32_t n_slots;         // LDS cache slots for active jobs (<= 64)
+  int32_t jobset_slots;    // capacity of the job-id set image (power of two)
+  int32_t pool_bytes;      // dynamic LDS size
+  int32_t off_active, off_old_active, off_slot_of, off_keys, off_jobset, off_cjobs, off_cstages, off_cdur;  // byte offsets in g_pool
+  int32_t max_edges;       // max template edges (flattened edge pass stride)
+  int32_t pad_;
+  int8_t lvl_of[8];        // pack level index of executor levels {5,10,20,40,50,60,80,100}, -1 if absent
   double mean_interarrival, moving_delay, warmup_delay, beta;
-  double intervals[SSS_MAX_EXEC + 1][2];  // tpch.py:237-262
-  int8_t interval_lvl[SSS_MAX_EXEC + 1][2];  // level index of each endpoint, -1 if not a pack level
 };
 
 // read-only workload pack, device pointers (see spark_sched_sim_amd/workload.py)
@@ -152,6 +159,7 @@ struct SssPackDev {
   const int32_t *stage_max_first_lvl, *edges, *desc, *durations;
   const uint64_t* zig_ke;
   const double *zig_we, *zig_fe;
+  const int32_t* eff;  // [total_stages][8 executor levels][3 modes][2] = (offset, len | warmup << 30)
 };
 
 struct SssBuffers {        // raw device pointers of torch-allocated tensors
@@ -166,7 +174,37 @@ struct SssBuffers {        // raw device pointers of torch-allocated tensors
 
 static inline int64_t sss_align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+#define SSS_LDS_BUDGET 10240  // bytes of LDS per workgroup that keep 16 workgroups (4 waves/SIMD) on a CU
+
+// carve the dynamic LDS pool; returns 0 on success, -1 if even a minimal cache does not fit
+static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int static_bytes) {
+  int jobset = J_cap <= 76 ? 128 : (J_cap <= 306 ? 512 : 2048);  // CPython resize thresholds (fill*5 >= mask*3)
+  int o = 0;
+  P->off_active = o, o += 2 * J_cap;
+  P->off_old_active = o, o += 2 * J_cap;
+  P->off_slot_of = o, o += J_cap;
+  o = (o + 1) & ~1;
+  P->off_keys = o, o += 2 * (J_cap + 8);
+  P->off_jobset = o, o += 2 * jobset;
+  o = (o + 15) & ~15;
+  int per_slot = (int)sizeof(SssJob) + 8 * SP + 4 * SP;
+  int budget = SSS_LDS_BUDGET - static_bytes;
+  int n = (budget - o) / per_slot;
+  if (n < 8) {  // large job capacities: give up the 16-workgroups/CU target instead of the cache
+    n = 24;
+  }
+  if (n > 64) n = 64;
+  if (n > J_cap) n = J_cap;
+  P->n_slots = n, P->jobset_slots = jobset;
+  P->off_cjobs = o, o += n * (int)sizeof(SssJob);
+  P->off_cstages = o, o += n * 8 * SP;
+  P->off_cdur = o, o += n * 4 * SP;
+  P->pool_bytes = (o + 15) & ~15;
+  return P->pool_bytes + static_bytes <= 65536 ? 0 : -1;
+}
+
 static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_cap, int SP, int n_levels, int max_edges_per_job) {
+  SP = (SP + 1) & ~1;  // even stride: a job's stage row (8 B records) stays 16-byte aligned
   L->num_envs = num_envs, L->E = E, L->J_cap = J_cap, L->SP = SP, L->L = n_levels;
   L->n_pools = 1 + J_cap + J_cap * SP;
   L->n_cap = J_cap * SP;

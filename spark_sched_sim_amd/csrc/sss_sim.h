@@ -27,23 +27,36 @@
 // per-wave context
 // ------------------------------------------------------------------------------------------
 
-struct SssScratch {  // LDS, besides SssHot
+// LDS of one workgroup (= one env). File-scope objects so that every access is a ds_* instruction
+// (a pointer passed through a call would degrade to flat_*). Static part: the hot block and the
+// scratch below; dynamic part (g_pool, sized by the host, see SssParams::off_*): the ordered
+// active-job list, the job -> cache-slot map, the LDS cache of the ACTIVE jobs' records and stage
+// counters (what the event chain touches on every event), and scratch for set images.
+struct alignas(16) SssScratch {
   uint8_t setA[SSS_SET_TABLE];
   uint8_t setB[SSS_SET_TABLE];
-  uint16_t jobset[SSS_JOBSET_SLOTS];
-  uint16_t keys[SSS_MAX_JOBS + 8];
   // flags lane 0 publishes for the uniform control flow
-  int32_t f_done, f_scan, f_round_continues, f_pop_kind, f_pop_exec, f_pop_job;
+  int32_t f_done, f_scan, f_round_continues;
   int32_t m_n_active, m_src_job;  // mailbox for find_schedulable_all
   int32_t n_old_active;
   int32_t events_this_step;
+  int32_t pending_free;           // job whose cache slot is to be released (-1: none)
+  int32_t jobset_mask, f_need_jobtime;
+  uint64_t free_slots;            // bit k set <=> cache slot k is free
   double wall_old;
+  uint32_t fc_dst[SSS_MAX_EXEC];  // snapshot of the source's commitments (fulfill_commitments_from_source)
+  int16_t fc_num[SSS_MAX_EXEC];
 };
 
+#define SSS_STATIC_LDS_BYTES ((int)(sizeof(SssHot) + sizeof(SssScratch)))
+
+SSS_SHARED SssHot g_hot;
+SSS_SHARED SssScratch g_sc;
+SSS_SHARED_DYN(g_pool);
+
 struct Ctx {
-  SssHot* hot;
-  SssScratch* sc;
-  uint16_t* active;
+  // HBM (this env's block of the arena)
+  uint16_t* active_g;
   SssJob* jobs;
   double* t_arrival;
   double* t_completed;
@@ -52,16 +65,13 @@ struct Ctx {
   SssPoolHdr* pool_hdr;
   uint8_t* pool_tab;
   double* dur_ring;
-  uint16_t* old_active;
-  const SssCfgDev* cfg;
   const SssPackDev* pk;
+  SssParams P;
   int E, J_cap, SP;
 };
 
-SSS_DEV void ctx_init(Ctx& c, SssHot* hot, SssScratch* sc, uint8_t* env_base, const SssLayout& L, const SssCfgDev* cfg,
-                      const SssPackDev* pk) {
-  c.hot = hot, c.sc = sc;
-  c.active = (uint16_t*)(env_base + L.off_active);
+SSS_DEV void ctx_init(Ctx& c, uint8_t* env_base, const SssLayout& L, const SssParams& P, const SssPackDev* pk) {
+  c.active_g = (uint16_t*)(env_base + L.off_active);
   c.jobs = (SssJob*)(env_base + L.off_jobs);
   c.t_arrival = (double*)(env_base + L.off_t_arrival);
   c.t_completed = (double*)(env_base + L.off_t_completed);
@@ -70,12 +80,12 @@ SSS_DEV void ctx_init(Ctx& c, SssHot* hot, SssScratch* sc, uint8_t* env_base, co
   c.pool_hdr = (SssPoolHdr*)(env_base + L.off_pool_hdr);
   c.pool_tab = env_base + L.off_pool_tab;
   c.dur_ring = (double*)(env_base + L.off_dur_ring);
-  c.old_active = (uint16_t*)(env_base + L.off_old_active);
-  c.cfg = cfg, c.pk = pk;
+  c.pk = pk;
+  c.P = P;
   c.E = L.E, c.J_cap = L.J_cap, c.SP = L.SP;
 }
 
-#define H (c.hot->h)
+#define H (g_hot.h)
 #define FAIL(code)                 \
   do {                             \
     if (H.err == 0) H.err = (code); \
@@ -84,6 +94,31 @@ SSS_DEV void ctx_init(Ctx& c, SssHot* hot, SssScratch* sc, uint8_t* env_base, co
   do {                                       \
     if (!(cond)) FAIL(SSS_ERR_INVARIANT);     \
   } while (0)
+
+// ---- LDS pool views ----
+#define SLOT_NONE 255
+SSS_DEV uint16_t* lds_active(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_active); }
+SSS_DEV uint8_t* lds_slot_of(const Ctx& c) { return g_pool + c.P.off_slot_of; }
+SSS_DEV uint16_t* lds_keys(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_keys); }
+SSS_DEV uint16_t* lds_jobset(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_jobset); }
+SSS_DEV SssJob* lds_cjobs(const Ctx& c) { return (SssJob*)(g_pool + c.P.off_cjobs); }
+SSS_DEV SssStage* lds_cstages(const Ctx& c) { return (SssStage*)(g_pool + c.P.off_cstages); }
+SSS_DEV float* lds_cdur(const Ctx& c) { return (float*)(g_pool + c.P.off_cdur); }
+SSS_DEV uint16_t* lds_old_active(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_old_active); }
+
+// record of job j: its LDS cache slot if it has one, else the HBM copy
+SSS_DEV SssJob* jobp(const Ctx& c, int j) {
+  int s = lds_slot_of(c)[j];
+  return s != SLOT_NONE ? lds_cjobs(c) + s : c.jobs + j;
+}
+SSS_DEV SssStage* stgp(const Ctx& c, int j, int st) {
+  int s = lds_slot_of(c)[j];
+  return s != SLOT_NONE ? lds_cstages(c) + s * c.SP + st : c.stages + j * c.SP + st;
+}
+SSS_DEV float* durp(const Ctx& c, int j, int st) {  // stage.most_recent_duration (observed as f32, ENV:381)
+  int s = lds_slot_of(c)[j];
+  return s != SLOT_NONE ? lds_cdur(c) + s * c.SP + st : c.durations + j * c.SP + st;
+}
 
 // pool keys
 SSS_DEV uint32_t key_job_pool(int j) { return (uint32_t)(j + 1) << 8; }
@@ -108,7 +143,8 @@ SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
 #define PCG_MH 0x2360ED051FC65DA4ull
 #define PCG_ML 0x4385DF649FCCF645ull
 
-SSS_DEV void rng_step(SssHdr& h) {
+template <class S>
+SSS_DEV void rng_step(S& h) {
   uint64_t lo = h.rng_state_lo, hi = h.rng_state_hi;
   uint64_t plo = lo * PCG_ML;
   uint64_t phi = mul64hi(lo, PCG_ML) + hi * PCG_ML + lo * PCG_MH;
@@ -117,14 +153,16 @@ SSS_DEV void rng_step(SssHdr& h) {
   h.rng_state_lo = rlo, h.rng_state_hi = rhi;
 }
 
-SSS_DEV uint64_t rng_next64(SssHdr& h) {
+template <class S>
+SSS_DEV uint64_t rng_next64(S& h) {
   rng_step(h);
   uint64_t x = h.rng_state_hi ^ h.rng_state_lo;
   unsigned rot = (unsigned)(h.rng_state_hi >> 58);
   return (x >> rot) | (x << ((64 - rot) & 63));
 }
 
-SSS_DEV uint32_t rng_next32(SssHdr& h) {
+template <class S>
+SSS_DEV uint32_t rng_next32(S& h) {
   if (h.rng_has32) {
     h.rng_has32 = 0;
     return h.rng_u32;
@@ -135,9 +173,11 @@ SSS_DEV uint32_t rng_next32(SssHdr& h) {
   return (uint32_t)n;
 }
 
-SSS_DEV double rng_random(SssHdr& h) { return (double)(rng_next64(h) >> 11) * (1.0 / 9007199254740992.0); }
+template <class S>
+SSS_DEV double rng_random(S& h) { return (double)(rng_next64(h) >> 11) * (1.0 / 9007199254740992.0); }
 
-SSS_DEV uint32_t rng_integers(SssHdr& h, uint32_t n) {
+template <class S>
+SSS_DEV uint32_t rng_integers(S& h, uint32_t n) {
   uint32_t rng = n - 1;
   if (rng == 0) return 0;
   uint64_t m = (uint64_t)rng_next32(h) * n;
@@ -470,8 +510,8 @@ SSS_DEV int trk_source_job_id(const Ctx& c) {  // TRK:101-105
 }
 
 SSS_DEV void publish_scan_inputs(Ctx& c) {
-  c.sc->m_n_active = H.n_active;
-  c.sc->m_src_job = trk_source_job_id(c);
+  g_sc.m_n_active = H.n_active;
+  g_sc.m_src_job = trk_source_job_id(c);
 }
 
 SSS_DEV int trk_num_committable(Ctx& c) {  // TRK:107-113
@@ -485,11 +525,11 @@ SSS_DEV int trk_num_committable(Ctx& c) {  // TRK:107-113
 
 // executor demand bookkeeping: sat bit of stage (j, s) <=> remaining - (moving_to + commit_to) <= 0 (ENV:566-582)
 SSS_DEV void update_sat(Ctx& c, int j, int s) {
-  SssStage st = c.stages[j * c.SP + s];
+  SssStage st = (*stgp(c, j, s));
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
-  uint64_t m = c.jobs[j].sat_mask;
+  uint64_t m = (*jobp(c, j)).sat_mask;
   m = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
-  c.jobs[j].sat_mask = m;
+  (*jobp(c, j)).sat_mask = m;
 }
 
 SSS_DEV void add_supply(Ctx& c, int job, int d) {
@@ -497,9 +537,9 @@ SSS_DEV void add_supply(Ctx& c, int job, int d) {
     H.supply_none += d;
     CHECK(H.supply_none >= 0);
   } else {
-    int v = (int)c.jobs[job].supply + d;
+    int v = (int)(*jobp(c, job)).supply + d;
     CHECK(v >= 0);
-    c.jobs[job].supply = (int16_t)v;
+    (*jobp(c, job)).supply = (int16_t)v;
   }
 }
 
@@ -507,7 +547,7 @@ SSS_DEV void trk_add_commitment(Ctx& c, int n, uint32_t dst) {  // TRK:148-157, 
   uint32_t src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE) return;
-  SssHot& hot = *c.hot;
+  SssHot& hot = g_hot;
   int i;
   for (i = 0; i < H.n_commits; i++)
     if (hot.c_src[i] == src && hot.c_dst[i] == dst) break;
@@ -524,7 +564,7 @@ SSS_DEV void trk_add_commitment(Ctx& c, int n, uint32_t dst) {  // TRK:148-157, 
   CHECK((int)c.pool_hdr[ps].used >= (int)c.pool_hdr[ps].commit_from);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
-    c.stages[dj * c.SP + ds].commit_to = (int16_t)(c.stages[dj * c.SP + ds].commit_to + n);
+    (*stgp(c, dj, ds)).commit_to = (int16_t)((*stgp(c, dj, ds)).commit_to + n);
     update_sat(c, dj, ds);
   }
   if (dj != key_job(src)) add_supply(c, dj, n);
@@ -532,7 +572,7 @@ SSS_DEV void trk_add_commitment(Ctx& c, int n, uint32_t dst) {  // TRK:148-157, 
 
 // returns the source pool key (TRK:159-176, 240-251)
 SSS_DEV uint32_t trk_remove_commitment(Ctx& c, int e, uint32_t dst) {
-  SssHot& hot = *c.hot;
+  SssHot& hot = g_hot;
   uint32_t src = hot.ex_loc[e];
   CHECK(src != POOL_NONE);
   int i;
@@ -546,8 +586,8 @@ SSS_DEV uint32_t trk_remove_commitment(Ctx& c, int e, uint32_t dst) {
   CHECK(c.pool_hdr[ps].commit_from >= 0);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
-    c.stages[dj * c.SP + ds].commit_to = (int16_t)(c.stages[dj * c.SP + ds].commit_to - 1);
-    CHECK(c.stages[dj * c.SP + ds].commit_to >= 0);
+    (*stgp(c, dj, ds)).commit_to = (int16_t)((*stgp(c, dj, ds)).commit_to - 1);
+    CHECK((*stgp(c, dj, ds)).commit_to >= 0);
     update_sat(c, dj, ds);
   }
   if (hot.c_n[i] == 0) {  // dict.pop(dst): swap-remove, order lives in c_seq
@@ -561,7 +601,7 @@ SSS_DEV uint32_t trk_remove_commitment(Ctx& c, int e, uint32_t dst) {
 
 // first-inserted live destination of `src`, POOL_NONE if none (TRK:178-183)
 SSS_DEV uint32_t trk_peek_commitment(const Ctx& c, uint32_t src) {
-  const SssHot& hot = *c.hot;
+  const SssHot& hot = g_hot;
   uint32_t best = 0xFFFFFFFFu, dst = POOL_NONE;
   for (int i = 0; i < H.n_commits; i++)
     if (hot.c_src[i] == src && hot.c_seq[i] < best) best = hot.c_seq[i], dst = hot.c_dst[i];
@@ -569,7 +609,7 @@ SSS_DEV uint32_t trk_peek_commitment(const Ctx& c, uint32_t src) {
 }
 
 SSS_DEV void trk_move_executor_to_pool(Ctx& c, int e, uint32_t new_pool, bool send) {  // TRK:188-222
-  SssHot& hot = *c.hot;
+  SssHot& hot = g_hot;
   uint32_t old = hot.ex_loc[e];
   if (old != POOL_NONE) {
     SetImg<uint8_t> s = pool_open(c, old);
@@ -581,13 +621,13 @@ SSS_DEV void trk_move_executor_to_pool(Ctx& c, int e, uint32_t new_pool, bool se
   if (!send) {
     hot.ex_loc[e] = new_pool;
     SetImg<uint8_t> s = pool_open(c, new_pool);
-    set_add(s, (uint32_t)e, c.sc->keys);
+    set_add(s, (uint32_t)e, lds_keys(c));
     pool_close(c, new_pool, s);
     return;
   }
   int nj = key_job(new_pool), ns = key_stage(new_pool);
   CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
-  c.stages[nj * c.SP + ns].moving_to = (int16_t)(c.stages[nj * c.SP + ns].moving_to + 1);
+  (*stgp(c, nj, ns)).moving_to = (int16_t)((*stgp(c, nj, ns)).moving_to + 1);
   update_sat(c, nj, ns);
   int oj = key_job(old);
   CHECK(oj != nj);
@@ -600,21 +640,21 @@ SSS_DEV void trk_move_executor_to_pool(Ctx& c, int e, uint32_t new_pool, bool se
 // ------------------------------------------------------------------------------------------
 
 SSS_DEV void job_attach_executor(Ctx& c, int j, int e) {  // JOB:81-84
-  CHECK(c.hot->ex_task_stage[e] < 0);
-  c.jobs[j].local_mask |= bit64(e);
-  c.hot->ex_job[e] = (int16_t)j;
+  CHECK(g_hot.ex_task_stage[e] < 0);
+  (*jobp(c, j)).local_mask |= bit64(e);
+  g_hot.ex_job[e] = (int16_t)j;
 }
 SSS_DEV void job_detach_executor(Ctx& c, int j, int e) {  // JOB:86-89
-  CHECK(c.jobs[j].local_mask & bit64(e));
-  c.jobs[j].local_mask &= ~bit64(e);
-  c.hot->ex_job[e] = -1;
-  c.hot->ex_task_stage[e] = -1;
+  CHECK((*jobp(c, j)).local_mask & bit64(e));
+  (*jobp(c, j)).local_mask &= ~bit64(e);
+  g_hot.ex_job[e] = -1;
+  g_hot.ex_task_stage[e] = -1;
 }
 SSS_DEV bool stage_completed(const SssStage& st) { return st.remaining == 0 && st.executing == 0; }  // STG:41-43
 
 // JOB:65-73,100-128: stage s of job j completed; returns whether the frontier gained stages
 SSS_DEV bool job_record_stage_completion(Ctx& c, int j, int s) {
-  SssJob& job = c.jobs[j];
+  SssJob& job = (*jobp(c, j));
   CHECK((job.active_mask & bit64(s)) && (job.frontier_mask & bit64(s)));
   uint64_t active = job.active_mask & ~bit64(s);
   job.active_mask = active;
@@ -639,47 +679,63 @@ SSS_DEV bool job_record_stage_completion(Ctx& c, int j, int s) {
 // data sampler: task durations (lane 0)
 // ------------------------------------------------------------------------------------------
 
-SSS_DEV bool sample_task_duration(Ctx& c, int gs, int wave, int lvl, bool warmup, double& out) {  // TPCH:208-214
-  const int32_t* d = &c.pk->desc[((gs * 3 + wave) * c.pk->L + lvl) * 2];
-  int off = d[0], len = d[1];
-  if (len <= 0) return false;  // KeyError (missing level) / ValueError (empty list): no draw happened
-  uint32_t i = rng_integers(H, (uint32_t)len);
-  double v = (double)c.pk->durations[off + (int)i];
-  if (warmup) v += c.cfg->warmup_delay;
-  out = v;
-  return true;
+// TPCHDataSampler._init_executor_intervals (TPCH:237-262) in closed form for exec_cap <= 100: the
+// row of `num_local_executors` = n is (5,5) for n <= 5, (n,n) when n is one of the executor
+// levels, else the two enclosing levels. Returns indices into {5,10,20,40,50,60,80,100}.
+SSS_DEV int exec_level_value(int i) {
+  const uint64_t packed = 5ull | (10ull << 8) | (20ull << 16) | (40ull << 24) | (50ull << 32) | (60ull << 40) | (80ull << 48) | (100ull << 56);
+  return (int)((packed >> (8 * i)) & 0xFF);
+}
+SSS_DEV void executor_interval(int n, int& li, int& ri) {
+  if (n <= 5) {
+    li = ri = 0;
+    return;
+  }
+  for (int i = 1; i < 8; i++) {
+    int v = exec_level_value(i);
+    if (n == v) {
+      li = ri = i;
+      return;
+    }
+    if (n < v) {
+      li = i - 1, ri = i;
+      return;
+    }
+  }
+  li = ri = 7;
 }
 
-SSS_DEV_NOINLINE double task_duration(Ctx& c, int j, int s, int e) {  // TPCH:75-106, 216-235
-  const SssJob& job = c.jobs[j];
-  int gs = job.gs_base + s;
-  int n_local = popc64(job.local_mask);
+// TPCH:75-106, 216-235. Which list is sampled is a pure function of (stage, executor level, executor
+// mode): the level substitution (`executor_key not in first_wave` -> max key, TPCH:231-233) and the
+// exception-driven fallback chain (TPCH:88-106; a missing key or an empty list raises before any
+// draw) are resolved once per template on the host into `eff` (sss_host.h: sss_build_eff), so the
+// device does one descriptor load, the draw, and one value load.
+SSS_DEV double task_duration(Ctx& c, int j, int s, int e) {
+  const SssJob* job = jobp(c, j);
+  int gs = job->gs_base + s;
+  int n_local = popc64(job->local_mask);
   CHECK(n_local > 0 && n_local <= c.E);
   if (n_local <= 0 || n_local > c.E) return 0.0;
-  double left = c.cfg->intervals[n_local][0], right = c.cfg->intervals[n_local][1];
-  int lvl;
-  if (left == right)
-    lvl = c.cfg->interval_lvl[n_local][0];
-  else {
+  int li, ri;
+  executor_interval(n_local, li, ri);
+  if (li != ri) {
+    double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
     int rand_pt = 1 + (int)(rng_random(H) * (right - left));
-    lvl = ((double)rand_pt <= (double)n_local - left) ? c.cfg->interval_lvl[n_local][0] : c.cfg->interval_lvl[n_local][1];
+    if (!((double)rand_pt <= (double)n_local - left)) li = ri;
   }
-  if (lvl < 0 || !((c.pk->stage_first_keymask[gs] >> lvl) & 1)) lvl = c.pk->stage_max_first_lvl[gs];
-  double d = 0.0;
-  int task_stage = c.hot->ex_task_stage[e];
-  if (task_stage < 0) {  // executor.is_idle
-    if (sample_task_duration(c, gs, 0, lvl, false, d)) return d;
-    if (sample_task_duration(c, gs, 1, lvl, true, d)) return d;
+  int task_stage = g_hot.ex_task_stage[e];
+  int mode = task_stage < 0 ? 0 : (task_stage == s ? 1 : 2);  // idle / same stage id (TPCH:95) / other
+  const int32_t* d = c.pk->eff + (((size_t)gs * 8 + li) * 3 + mode) * 2;
+  int off = d[0], lenw = d[1];
+  int len = lenw & 0x3FFFFFFF;
+  if (len == 0) {
     FAIL(SSS_ERR_NO_DURATION);
     return 0.0;
   }
-  if (task_stage == s) {  // stage ids only (TPCH:95)
-    if (sample_task_duration(c, gs, 2, lvl, false, d)) return d;
-  }
-  if (sample_task_duration(c, gs, 1, lvl, false, d)) return d;
-  if (sample_task_duration(c, gs, 0, lvl, false, d)) return d;
-  FAIL(SSS_ERR_NO_DURATION);
-  return 0.0;
+  uint32_t i = rng_integers(H, (uint32_t)len);
+  double v = (double)c.pk->durations[off + (int)i];
+  if (lenw >> 30) v += c.P.warmup_delay;
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -704,32 +760,32 @@ SSS_DEV uint64_t ready_mask_of_job(const Ctx& c, const SssJob& job, bool first_o
 }
 
 SSS_DEV bool job_passes_filter(const Ctx& c, int j, int source_job_id) {
-  return j == source_job_id || (int)c.jobs[j].supply < c.E;
+  return j == source_job_id || (int)(*jobp(c, j)).supply < c.E;
 }
 
 // ENV:821-845 -> (job, stage) or job = -1
 SSS_DEV_NOINLINE void find_backup_stage(Ctx& c, int e, int& out_j, int& out_s) {
   out_j = -1, out_s = -1;
-  int ejob = c.hot->ex_job[e];
+  int ejob = g_hot.ex_job[e];
   CHECK(ejob >= 0);
   if (ejob < 0) return;
   // `if not source_job_id` (ENV:521): job id 0 is falsy and gets replaced by the tracker's source
   int src = ejob <= 0 ? trk_source_job_id(c) : ejob;
   if (job_passes_filter(c, ejob, src)) {
-    uint64_t m = ready_mask_of_job(c, c.jobs[ejob], true);
+    uint64_t m = ready_mask_of_job(c, (*jobp(c, ejob)), true);
     if (m) {
       out_j = ejob, out_s = ctz64(m);
       return;
     }
   }
   // other jobs; an empty list is falsy and means "all active jobs" (ENV:518-519)
-  bool ejob_active = c.jobs[ejob].active_mask != 0;
+  bool ejob_active = (*jobp(c, ejob)).active_mask != 0;
   int n_others = H.n_active - (ejob_active ? 1 : 0);
   for (int a = 0; a < H.n_active; a++) {
-    int j = c.active[a];
+    int j = lds_active(c)[a];
     if (n_others > 0 && j == ejob) continue;
     if (!job_passes_filter(c, j, src)) continue;
-    uint64_t m = ready_mask_of_job(c, c.jobs[j], true);
+    uint64_t m = ready_mask_of_job(c, (*jobp(c, j)), true);
     if (m) {
       out_j = j, out_s = ctz64(m);
       return;
@@ -742,32 +798,32 @@ SSS_DEV_NOINLINE void find_backup_stage(Ctx& c, int e, int& out_j, int& out_s) {
 // ------------------------------------------------------------------------------------------
 
 SSS_DEV void push_event(Ctx& c, int e, double t, int kind, int j, int s) {  // EVQ:34-35
-  SssHot& hot = *c.hot;
+  SssHot& hot = g_hot;
   CHECK(hot.ev_kind[e] == EV_NONE);
   hot.ev_t[e] = t, hot.ev_seq[e] = H.counter++, hot.ev_kind[e] = (uint8_t)kind;
   hot.ev_job[e] = (int16_t)j, hot.ev_stage[e] = (int8_t)s;
 }
 
 SSS_DEV void execute_next_task(Ctx& c, int e, int j, int s) {  // ENV:584-615
-  SssStage& st = c.stages[j * c.SP + s];
-  CHECK(st.remaining > 0 && c.hot->ex_job[e] == j && !c.hot->ex_executing[e]);
+  SssStage& st = (*stgp(c, j, s));
+  CHECK(st.remaining > 0 && g_hot.ex_job[e] == j && !g_hot.ex_executing[e]);
   st.remaining = (int16_t)(st.remaining - 1);  // STG:53-58
   st.executing = (int16_t)(st.executing + 1);
-  if (st.remaining == 0) c.jobs[j].sat_count = (int16_t)(c.jobs[j].sat_count + 1);
+  if (st.remaining == 0) (*jobp(c, j)).sat_count = (int16_t)((*jobp(c, j)).sat_count + 1);
   update_sat(c, j, s);
   double d = task_duration(c, j, s, e);
-  c.hot->ex_task_stage[e] = (int8_t)s;
-  c.hot->ex_executing[e] = 1;
-  c.durations[j * c.SP + s] = (float)d;  // stage.most_recent_duration, observed as f32 (ENV:381)
+  g_hot.ex_task_stage[e] = (int8_t)s;
+  g_hot.ex_executing[e] = 1;
+  *durp(c, j, s) = (float)d;
   push_event(c, e, H.wall_time + d, EV_TASK_FINISHED, j, s);
 }
 
 SSS_DEV void send_executor(Ctx& c, int e, int j, int s) {  // ENV:617-637
-  CHECK(!c.hot->ex_executing[e] && c.hot->ex_job[e] != j);
+  CHECK(!g_hot.ex_executing[e] && g_hot.ex_job[e] != j);
   trk_move_executor_to_pool(c, e, key_stage_pool(j, s), true);
-  int oj = c.hot->ex_job[e];
+  int oj = g_hot.ex_job[e];
   if (oj >= 0) job_detach_executor(c, oj, e);
-  push_event(c, e, H.wall_time + c.cfg->moving_delay, EV_EXECUTOR_READY, j, s);
+  push_event(c, e, H.wall_time + c.P.moving_delay, EV_EXECUTOR_READY, j, s);
 }
 
 // ENV:745-782 for an explicit executor list of one
@@ -776,7 +832,7 @@ SSS_DEV void move_idle_executor(Ctx& c, uint32_t src, int e) {
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
   int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)c.jobs[j].sat_count == (int)c.jobs[j].n_stages;  // JOB:53-55
+  bool is_sat = (int)(*jobp(c, j)).sat_count == (int)(*jobp(c, j)).n_stages;  // JOB:53-55
   if (s < 0 && !is_sat) return;
   uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
   trk_move_executor_to_pool(c, e, dst, false);
@@ -786,18 +842,18 @@ SSS_DEV void move_idle_executor(Ctx& c, uint32_t src, int e) {
 // set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
 SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(Ctx& c, uint32_t key) {
   SetImg<uint8_t> out;
-  out.tab = c.sc->setB;
+  out.tab = g_sc.setB;
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
   out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0;
   if (key == POOL_NONE) return out;
   SetImg<uint8_t> src = pool_open(c, key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
-  cp.tab = c.sc->setA;
+  cp.tab = g_sc.setA;
   for (int i = 0; i < 8; i++) cp.tab[i] = 0;
   cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0;
   if (src.used != 0) {
-    if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, c.sc->keys);
+    if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys(c));
     if (cp.mask == src.mask && src.fill == src.used) {
       for (uint32_t i = 0; i <= src.mask; i++) cp.tab[i] = src.tab[i];
     } else {
@@ -810,7 +866,7 @@ SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(Ctx& c, uint32_t key)
   }
   for (uint32_t i = 0; i <= cp.mask; i++) {
     uint32_t en = cp.tab[i];
-    if (en >= 2 && !c.hot->ex_executing[en - 2]) set_add(out, en - 2, c.sc->keys);
+    if (en >= 2 && !g_hot.ex_executing[en - 2]) set_add(out, en - 2, lds_keys(c));
   }
   return out;
 }
@@ -824,7 +880,7 @@ SSS_DEV_NOINLINE void move_idle_executors_all(Ctx& c, uint32_t src) {
   CHECK(idle.used > 0);  // assert executor_ids, "[_move_idle_executors],2"
   if (H.err) return;
   int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)c.jobs[j].sat_count == (int)c.jobs[j].n_stages;
+  bool is_sat = (int)(*jobp(c, j)).sat_count == (int)(*jobp(c, j)).n_stages;
   if (s < 0 && !is_sat) return;
   uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
   for (uint32_t i = 0; i <= idle.mask; i++) {  // list(set): ascending slot order
@@ -837,24 +893,24 @@ SSS_DEV_NOINLINE void move_idle_executors_all(Ctx& c, uint32_t src) {
 }
 
 SSS_DEV_NOINLINE void move_executor_to_stage(Ctx& c, int e, int j, int s) {  // ENV:784-819
-  if (c.stages[j * c.SP + s].remaining == 0) {
+  if ((*stgp(c, j, s)).remaining == 0) {
     // _try_backup_schedule
     int bj, bs;
     find_backup_stage(c, e, bj, bs);
     if (bj < 0) {
-      move_idle_executor(c, c.hot->ex_loc[e], e);
+      move_idle_executor(c, g_hot.ex_loc[e], e);
       return;
     }
     j = bj, s = bs;  // a schedulable stage has demand > 0, hence remaining > 0: no second detour
-    CHECK(c.stages[j * c.SP + s].remaining > 0);
+    CHECK((*stgp(c, j, s)).remaining > 0);
     if (H.err) return;
   }
-  if (c.hot->ex_job[e] != j) {
+  if (g_hot.ex_job[e] != j) {
     send_executor(c, e, j, s);
     return;
   }
-  if (!(c.jobs[j].frontier_mask & bit64(s))) {
-    c.hot->ex_task_stage[e] = -1;
+  if (!((*jobp(c, j)).frontier_mask & bit64(s))) {
+    g_hot.ex_task_stage[e] = -1;
     trk_move_executor_to_pool(c, e, key_job_pool(j), false);
     return;
   }
@@ -873,12 +929,12 @@ SSS_DEV void fulfill_commitment(Ctx& c, int e, uint32_t dst) {  // ENV:699-712
 }
 
 SSS_DEV_NOINLINE void fulfill_commitments_from_source(Ctx& c) {  // ENV:730-743
-  SssHot& hot = *c.hot;
+  SssHot& hot = g_hot;
   uint32_t src = H.curr_source;
   SetImg<uint8_t> idle = get_idle_source_executors(c, src);
   // snapshot of the source's commitments in insertion order (dict copy, TRK:133-134)
-  uint32_t dsts[SSS_MAX_EXEC];
-  int16_t nums[SSS_MAX_EXEC];
+  uint32_t* dsts = g_sc.fc_dst;
+  int16_t* nums = g_sc.fc_num;
   int n = 0;
   uint32_t last_seq = 0;
   bool first = true;
@@ -911,15 +967,40 @@ SSS_DEV void commit_remaining_executors(Ctx& c) {  // ENV:487-503
 // event handlers (lane 0)
 // ------------------------------------------------------------------------------------------
 
+// ---- LDS cache of the active jobs' records (lane 0 flavour) ----
+SSS_DEV void cache_acquire(Ctx& c, int j) {  // on arrival: HBM -> LDS, if a slot is free
+  if (g_sc.free_slots == 0) return;
+  int k = ctz64(g_sc.free_slots);
+  g_sc.free_slots &= g_sc.free_slots - 1;
+  lds_cjobs(c)[k] = c.jobs[j];
+  for (int s = 0; s < c.SP; s++) {
+    lds_cstages(c)[k * c.SP + s] = c.stages[j * c.SP + s];
+    lds_cdur(c)[k * c.SP + s] = c.durations[j * c.SP + s];
+  }
+  lds_slot_of(c)[j] = (uint8_t)k;
+}
+SSS_DEV void cache_release(Ctx& c, int j) {  // on completion: LDS -> HBM, slot becomes free
+  int k = lds_slot_of(c)[j];
+  if (k == SLOT_NONE) return;
+  c.jobs[j] = lds_cjobs(c)[k];
+  for (int s = 0; s < c.SP; s++) {
+    c.stages[j * c.SP + s] = lds_cstages(c)[k * c.SP + s];
+    c.durations[j * c.SP + s] = lds_cdur(c)[k * c.SP + s];
+  }
+  lds_slot_of(c)[j] = SLOT_NONE;
+  g_sc.free_slots |= bit64(k);
+}
+
 SSS_DEV void handle_job_arrival(Ctx& c, int j) {  // ENV:428-438 (pools were created empty at reset)
-  c.active[H.n_active] = (uint16_t)j;
+  lds_active(c)[H.n_active] = (uint16_t)j;
   H.n_active++;
+  cache_acquire(c, j);
   if (c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
 
 SSS_DEV void handle_executor_arrival(Ctx& c, int e, int j, int s) {  // ENV:440-450
   job_attach_executor(c, j, e);
-  SssStage& st = c.stages[j * c.SP + s];
+  SssStage& st = (*stgp(c, j, s));
   st.moving_to = (int16_t)(st.moving_to - 1);  // TRK:185-187
   CHECK(st.moving_to >= 0);
   update_sat(c, j, s);
@@ -932,13 +1013,14 @@ SSS_DEV_NOINLINE void process_job_completion(Ctx& c, int j) {  // ENV:682-697
   CHECK(pool_size(c, key_job_pool(j)) == 0);
   int k;
   for (k = 0; k < H.n_active; k++)
-    if (c.active[k] == j) break;
+    if (lds_active(c)[k] == j) break;
   CHECK(k < H.n_active);
   if (k >= H.n_active) return;
-  for (int i = k; i + 1 < H.n_active; i++) c.active[i] = c.active[i + 1];
+  for (int i = k; i + 1 < H.n_active; i++) lds_active(c)[i] = lds_active(c)[i + 1];
   H.n_active--;
-  c.jobs[j].completion_order = (int16_t)H.n_completed;
+  (*jobp(c, j)).completion_order = (int16_t)H.n_completed;
   H.n_completed++;
+  g_sc.pending_free = j;  // its cache slot is written back once the handler has returned
   c.t_completed[j] = H.wall_time;
   double dur = H.wall_time - c.t_arrival[j];
   if (H.dur_n < SSS_DUR_RING) {
@@ -951,17 +1033,17 @@ SSS_DEV_NOINLINE void process_job_completion(Ctx& c, int j) {  // ENV:682-697
 }
 
 SSS_DEV_NOINLINE void handle_task_completion(Ctx& c, int e, int j, int s) {  // ENV:452-483
-  SssStage& st = c.stages[j * c.SP + s];
+  SssStage& st = (*stgp(c, j, s));
   CHECK(!stage_completed(st));
   st.executing = (int16_t)(st.executing - 1);  // STG:60-62
-  c.hot->ex_executing[e] = 0;
+  g_hot.ex_executing[e] = 0;
   if (st.remaining > 0) {
     execute_next_task(c, e, j, s);
     return;
   }
   bool frontier_changed = false;
   if (stage_completed(st)) frontier_changed = job_record_stage_completion(c, j, s);  // ENV:676-680
-  if (c.jobs[j].active_mask == 0) process_job_completion(c, j);                      // JOB:49-51
+  if ((*jobp(c, j)).active_mask == 0) process_job_completion(c, j);                      // JOB:49-51
   // _handle_released_executor ENV:639-660
   uint32_t sp = key_stage_pool(j, s);
   uint32_t dst = trk_peek_commitment(c, sp);
@@ -969,7 +1051,7 @@ SSS_DEV_NOINLINE void handle_task_completion(Ctx& c, int e, int j, int s) {  // 
   if (had_commitment)
     fulfill_commitment(c, e, dst);
   else {
-    c.hot->ex_task_stage[e] = -1;
+    g_hot.ex_task_stage[e] = -1;
     if (frontier_changed) move_idle_executor(c, sp, e);
   }
   // _update_executor_source ENV:662-674
@@ -983,27 +1065,111 @@ SSS_DEV_NOINLINE void handle_task_completion(Ctx& c, int e, int j, int s) {  // 
 // wave-parallel phases
 // ------------------------------------------------------------------------------------------
 
-// EventQueue.pop (EVQ:44-49): arrivals are a time-sorted array with a cursor and carry the push
-// counters 0..J-1, so they win ties; executor events live one per lane. Every lane returns the
-// same value: POP_EMPTY, POP_ARRIVAL, or the executor (lane) whose event is the minimum.
-// All shared state is read BEFORE the first collective: lane 0 mutates it right after the last one.
+// EventQueue.pop (EVQ:44-49), lane 0. The "heap" is one slot per executor (an executor has at
+// most one pending event; ev_t = +inf when it has none) plus the time-sorted arrival array with a
+// cursor. (t, push counter) keys are unique, so the minimum is the heapq order; arrivals carry the
+// counters 0..J-1 and therefore win ties against executor events. A linear scan of <= 64 LDS
+// slots by one lane costs less than a cross-lane reduction plus the publish/sync round trip it
+// would need per event, and lets lane 0 run whole chains of events without any wave-level sync.
 #define POP_EMPTY (-1)
 #define POP_ARRIVAL (-2)
 SSS_DEV int pop_event(Ctx& c) {
-  const SssHot& hot = *c.hot;
-  int lane = wave_lane();
-  bool has = lane < c.E && hot.ev_kind[lane] != EV_NONE;
-  uint64_t tb = has ? f64_bits(hot.ev_t[lane]) : ~0ull;  // times are >= +0.0: bit order == numeric order
-  uint32_t sq = has ? hot.ev_seq[lane] : 0xFFFFFFFFu;
-  int na = hot.h.next_arrival;
-  uint64_t ta = na < hot.h.J ? f64_bits(c.t_arrival[na]) : ~0ull;
-  uint64_t tmin = wave_min_u64(tb);
-  if (ta != ~0ull && ta <= tmin) return POP_ARRIVAL;
-  if (tmin == ~0ull) return POP_EMPTY;
-  if (tb != tmin) sq = 0xFFFFFFFFu;
-  uint32_t smin = wave_min_u32(sq);
-  uint64_t win = wave_ballot(has && tb == tmin && sq == smin);
-  return ctz64(win);
+  const SssHot& hot = g_hot;
+  double best = __builtin_inf();
+  int ex = POP_EMPTY;
+  bool tie = false;
+  // 8 independent LDS reads per round, then the compares: the scan is latency-, not issue-bound
+  for (int e0 = 0; e0 < c.E; e0 += 8) {
+    double t[8];
+_Pragma("unroll")
+    for (int k = 0; k < 8; k++) t[k] = hot.ev_t[e0 + k];  // slots >= E hold +inf (SSS_MAX_EXEC is a multiple of 8)
+_Pragma("unroll")
+    for (int k = 0; k < 8; k++) {
+      if (t[k] < best) {
+        best = t[k], ex = e0 + k, tie = false;
+      } else if (t[k] == best && ex >= 0) {
+        tie = true;
+      }
+    }
+  }
+  if (tie) {  // equal times: the earlier push wins (EVQ:35)
+    uint32_t best_seq = 0xFFFFFFFFu;
+    for (int e = 0; e < c.E; e++)
+      if (hot.ev_t[e] == best && hot.ev_seq[e] < best_seq) best_seq = hot.ev_seq[e], ex = e;
+  }
+  if (hot.h.next_arrival < hot.h.J && hot.h.next_arrival_t <= best) return POP_ARRIVAL;
+  return ex;
+}
+
+// Registers of the lane-0 event loop: the header fields every event touches. Loaded when the loop
+// is entered, written back when it is left or before any out-of-line (slow path) handler runs.
+struct EvRegs {
+  uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
+  uint32_t rng_has32, rng_u32;
+  double wall_time;
+  uint64_t n_events;
+  uint32_t counter;
+  int32_t events_this_step;
+};
+SSS_DEV void regs_load(EvRegs& r) {
+  const SssHdr& h = g_hot.h;
+  r.rng_state_hi = h.rng_state_hi, r.rng_state_lo = h.rng_state_lo, r.rng_inc_hi = h.rng_inc_hi, r.rng_inc_lo = h.rng_inc_lo;
+  r.rng_has32 = h.rng_has32, r.rng_u32 = h.rng_u32;
+  r.wall_time = h.wall_time, r.n_events = h.n_events, r.counter = h.counter, r.events_this_step = g_sc.events_this_step;
+}
+SSS_DEV void regs_store(const EvRegs& r) {
+  SssHdr& h = g_hot.h;
+  h.rng_state_hi = r.rng_state_hi, h.rng_state_lo = r.rng_state_lo;
+  h.rng_has32 = r.rng_has32, h.rng_u32 = r.rng_u32;
+  h.wall_time = r.wall_time, h.n_events = r.n_events, h.counter = r.counter, g_sc.events_this_step = r.events_this_step;
+}
+
+// The common event (97-99 % of all events are TASK_FINISHED, most of them with tasks left in the
+// stage): ENV:452-467 + ENV:584-615 + TPCH:75-106 fused for "same executor continues on the same
+// stage". executing-- / executing++ cancel, executor.task.stage_id already equals the stage
+// (=> the `rest_wave` mode of task_duration), the event slot keeps its kind/job/stage.
+// Returns false, with nothing modified, when the stage has no remaining task (slow path).
+SSS_DEV bool fast_task_completion(Ctx& c, EvRegs& r, int ex, int j, int s) {
+  int slot = lds_slot_of(c)[j];
+  SssStage* sp;
+  SssJob* jp;
+  float* dp;
+  if (slot != SLOT_NONE) {
+    sp = lds_cstages(c) + slot * c.SP + s, jp = lds_cjobs(c) + slot, dp = lds_cdur(c) + slot * c.SP + s;
+  } else {
+    sp = c.stages + j * c.SP + s, jp = c.jobs + j, dp = c.durations + j * c.SP + s;
+  }
+  SssStage st = *sp;
+  uint64_t local = jp->local_mask;
+  int gs = jp->gs_base + s;
+  if (st.remaining <= 0) return false;
+  st.remaining = (int16_t)(st.remaining - 1);
+  int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
+  if (st.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);  // stage just became saturated (ENV:595-597)
+  if (demand <= 0) jp->sat_mask |= bit64(s);
+  *sp = st;
+  // task_duration, executor mode 1 ("same stage")
+  int n_local = popc64(local);
+  int li, ri;
+  executor_interval(n_local, li, ri);
+  if (li != ri) {
+    double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+    int rand_pt = 1 + (int)(rng_random(r) * (right - left));
+    if (!((double)rand_pt <= (double)n_local - left)) li = ri;
+  }
+  const int32_t* d = c.pk->eff + (((size_t)gs * 8 + li) * 3 + 1) * 2;
+  int off = d[0], lenw = d[1];
+  int len = lenw & 0x3FFFFFFF;
+  if (len == 0 || n_local <= 0) {
+    FAIL(n_local <= 0 ? SSS_ERR_INVARIANT : SSS_ERR_NO_DURATION);
+    return true;
+  }
+  uint32_t i = rng_integers(r, (uint32_t)len);
+  double dur = (double)c.pk->durations[off + (int)i];
+  *dp = (float)dur;
+  g_hot.ev_t[ex] = r.wall_time + dur;
+  g_hot.ev_seq[ex] = r.counter++;
+  return true;
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -1013,30 +1179,31 @@ SSS_DEV int pop_event(Ctx& c) {
 // (publish_scan_inputs): lane 0 may already be past this function when another lane reads them.
 SSS_DEV int find_schedulable_all(Ctx& c) {
   int lane = wave_lane();
-  int A = c.sc->m_n_active;
-  int src_job = c.sc->m_src_job;
-  int total = 0;
-  for (int a = 0; a < A; a++) {
-    int j = c.active[a];
-    const SssJob& job = c.jobs[j];
-    bool pass = j == src_job || (int)job.supply < c.E;
-    bool ready = false;
-    if (pass && lane < (int)job.n_stages) {
-      uint64_t sat = job.sat_mask;
-      uint64_t cand = job.active_mask & ~job.selected_mask & ~sat;
-      if (cand & bit64(lane)) ready = (c.pk->stage_parent_mask[job.gs_base + lane] & ~sat) == 0;
+  int A = g_sc.m_n_active;
+  int src_job = g_sc.m_src_job;
+  uint32_t total = 0;
+  // one lane per active job; readiness of a stage is a mask test against the job's saturated mask
+  for (int a0 = 0; a0 < A; a0 += 64) {
+    int a = a0 + lane;
+    uint32_t cnt = 0;
+    if (a < A) {
+      int j = lds_active(c)[a];
+      SssJob* job = jobp(c, j);
+      uint64_t m = 0;
+      if (j == src_job || (int)job->supply < c.E) m = ready_mask_of_job(c, *job, false);
+      job->sched_mask = m;
+      cnt = (uint32_t)popc64(m);
     }
-    uint64_t m = wave_ballot(ready);
-    if (lane == 0) c.jobs[j].sched_mask = m;
-    total += popc64(m);
+    total += wave_sum_u32(cnt);
   }
-  return total;
+  return (int)total;
 }
 
 // _observe (ENV:345-406) + utils.subgraph (utils.py:5-22) into the env's padded output rows
 SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, int env, double reward) {
   int lane = wave_lane();
-  const SssHdr& h = c.hot->h;
+  uint64_t t_obs0 = wave_clock();
+  const SssHdr& h = g_hot.h;
   float* nodes = B.nodes + (size_t)env * L.n_cap * 3;
   int32_t* el = B.edge_links + (size_t)env * L.ed_cap * 2;
   int32_t* dag_ptr = B.dag_ptr + (size_t)env * (L.J_cap + 1);
@@ -1045,43 +1212,73 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
   uint32_t srck = h.curr_source;
   int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
   int src_idx = A;  // ENV:352
-  int base_n = 0, base_e = 0;
   uint64_t lt = bit64(lane) - 1;
-  for (int a = 0; a < A; a++) {
-    int j = c.active[a];
-    const SssJob& job = c.jobs[j];
-    uint64_t act = job.active_mask;
-    if (j == src_job) src_idx = a;
-    if (lane == 0) {
-      dag_ptr[a] = base_n;
-      sup[a] = job.supply;
+  uint16_t* nbase = lds_keys(c);  // first node row of each active job (scratch shared with the set code)
+  // pass 1 - lanes over jobs: dag_ptr (exclusive scan of active-stage counts), exec_supplies
+  uint32_t run = 0;
+  for (int a0 = 0; a0 < A; a0 += 64) {
+    int a = a0 + lane;
+    uint32_t cnt = 0;
+    int j = -1, supply = 0;
+    if (a < A) {
+      j = lds_active(c)[a];
+      const SssJob* job = jobp(c, j);
+      cnt = (uint32_t)popc64(job->active_mask);
+      supply = job->supply;
     }
-    if (lane < (int)job.n_stages && (act & bit64(lane))) {
-      int row = base_n + popc64(act & lt);
-      SssStage st = c.stages[j * c.SP + lane];
-      nodes[row * 3 + 0] = (float)st.remaining;
-      nodes[row * 3 + 1] = c.durations[j * c.SP + lane];
-      nodes[row * 3 + 2] = (job.sched_mask & bit64(lane)) ? 1.0f : 0.0f;
+    uint32_t excl = wave_scan_excl_u32(cnt);
+    uint32_t tot = wave_sum_u32(cnt);
+    uint64_t is_src = wave_ballot(a < A && j == src_job);
+    if (is_src) src_idx = a0 + ctz64(is_src);
+    if (a < A) {
+      nbase[a] = (uint16_t)(run + excl);
+      dag_ptr[a] = (int32_t)(run + excl);
+      sup[a] = supply;
     }
-    int ne = job.n_edges;
-    int eoff = c.pk->tmpl_edge_off[job.tmpl];
-    for (int eb = 0; eb < ne; eb += 64) {
-      int i = eb + lane;
-      int u = 0, v = 0;
-      bool keep = false;
-      if (i < ne) {
-        u = c.pk->edges[2 * (eoff + i)], v = c.pk->edges[2 * (eoff + i) + 1];
+    run += tot;
+  }
+  int base_n = (int)run;
+  wave_sync();
+  // pass 2 - lanes over (job, stage): node rows
+  int SPn = c.SP;
+  for (int i = lane; i < A * SPn; i += 64) {
+    int a = i / SPn, st = i - a * SPn;
+    int j = lds_active(c)[a];
+    const SssJob* job = jobp(c, j);
+    uint64_t act = job->active_mask;
+    if (st < (int)job->n_stages && (act & bit64(st))) {
+      int row = (int)nbase[a] + popc64(act & (bit64(st) - 1));
+      nodes[row * 3 + 0] = (float)stgp(c, j, st)->remaining;
+      nodes[row * 3 + 1] = *durp(c, j, st);
+      nodes[row * 3 + 2] = (job->sched_mask & bit64(st)) ? 1.0f : 0.0f;
+    }
+  }
+  // pass 3 - lanes over (job, template edge): active subgraph, compacted in (job, edge) order
+  int ME = c.P.max_edges;
+  int base_e = 0;
+  for (int i0 = 0; i0 < A * ME; i0 += 64) {
+    int i = i0 + lane;
+    bool keep = false;
+    int eu = 0, ev = 0;
+    if (i < A * ME) {
+      int a = i / ME, e = i - a * ME;
+      int j = lds_active(c)[a];
+      const SssJob* job = jobp(c, j);
+      if (e < (int)job->n_edges) {
+        uint64_t act = job->active_mask;
+        int u = c.pk->edges[2 * (job->edge_off + e)], v = c.pk->edges[2 * (job->edge_off + e) + 1];
         keep = (act & bit64(u)) && (act & bit64(v));
+        eu = (int)nbase[a] + popc64(act & (bit64(u) - 1));
+        ev = (int)nbase[a] + popc64(act & (bit64(v) - 1));
       }
-      uint64_t bal = wave_ballot(keep);
-      if (keep) {
-        int pos = base_e + popc64(bal & lt);
-        el[2 * pos + 0] = base_n + popc64(act & (bit64(u) - 1));
-        el[2 * pos + 1] = base_n + popc64(act & (bit64(v) - 1));
-      }
-      base_e += popc64(bal);
     }
-    base_n += popc64(act);
+    uint64_t bal = wave_ballot(keep);
+    if (keep) {
+      int pos = base_e + popc64(bal & lt);
+      el[2 * pos + 0] = eu;
+      el[2 * pos + 1] = ev;
+    }
+    base_e += popc64(bal);
   }
   if (lane == 0) {
     dag_ptr[A] = base_n;
@@ -1096,24 +1293,82 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
     oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
     of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
-    c.hot->h.obs_n_nodes = base_n;
-    c.hot->h.obs_n_sched = h.n_sched;
-    c.hot->h.last_reward = reward;
+    g_hot.h.prof[4] += wave_clock() - t_obs0;
+    g_hot.h.obs_n_nodes = base_n;
+    g_hot.h.obs_n_sched = h.n_sched;
+    g_hot.h.last_reward = reward;
     // SURVEY 8(d) algorithmic bytes of this step: k*140 + 12N + (12N + 4(A+1) + 4A + 8Ed + 12) + 26
-    c.hot->h.model_bytes += (uint64_t)c.sc->events_this_step * 140u + 24u * (uint64_t)base_n + 4u * (uint64_t)(A + 1) +
+    g_hot.h.model_bytes += (uint64_t)g_sc.events_this_step * 140u + 24u * (uint64_t)base_n + 4u * (uint64_t)(A + 1) +
                             4u * (uint64_t)A + 8u * (uint64_t)base_e + 12u + 26u;
   }
 }
 
-SSS_DEV void hot_load(SssHot* lds, const SssHot* g) {
-  const uint4* s = (const uint4*)g;
-  uint4* d = (uint4*)lds;
-  for (int i = wave_lane(); i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+// ---- staging at launch boundaries (all lanes) ----
+// HBM -> LDS: the hot block verbatim, the active-job list, and the records + stage counters of the
+// first n_slots active jobs into the cache. LDS -> HBM at the end of the launch.
+SSS_DEV void env_begin(Ctx& c, const uint8_t* base) {
+  int lane = wave_lane();
+  {
+    const uint4* s = (const uint4*)base;
+    uint4* d = (uint4*)&g_hot;
+    for (int i = lane; i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+  }
+  for (int i = lane; i < c.J_cap; i += 64) lds_slot_of(c)[i] = SLOT_NONE;
+  wave_sync();
+  int A = g_hot.h.n_active;
+  int nK = A < c.P.n_slots ? A : c.P.n_slots;
+  for (int i = lane; i < A; i += 64) {
+    int j = c.active_g[i];
+    lds_active(c)[i] = (uint16_t)j;
+    if (i < nK) lds_slot_of(c)[j] = (uint8_t)i;
+  }
+  if (lane == 0) {
+    uint64_t all = c.P.n_slots >= 64 ? ~0ull : (bit64(c.P.n_slots) - 1);
+    uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
+    g_sc.free_slots = all & ~used;
+    g_sc.pending_free = -1;
+    g_sc.events_this_step = 0;
+  }
+  wave_sync();
+  // cached records: per slot 8 x u64 of job record, SP x u64 of stage counters, SP/2 x u64 of durations
+  int per = 8 + c.SP + c.SP / 2;
+  for (int i = lane; i < nK * per; i += 64) {
+    int k = i / per, w = i - k * per;
+    int j = lds_active(c)[k];
+    if (w < 8)
+      ((uint64_t*)(lds_cjobs(c) + k))[w] = ((const uint64_t*)(c.jobs + j))[w];
+    else if (w < 8 + c.SP)
+      ((uint64_t*)(lds_cstages(c) + k * c.SP))[w - 8] = ((const uint64_t*)(c.stages + j * c.SP))[w - 8];
+    else
+      ((uint64_t*)(lds_cdur(c) + k * c.SP))[w - 8 - c.SP] = ((const uint64_t*)(c.durations + j * c.SP))[w - 8 - c.SP];
+  }
+  wave_sync();
 }
-SSS_DEV void hot_store(SssHot* g, const SssHot* lds) {
-  const uint4* s = (const uint4*)lds;
-  uint4* d = (uint4*)g;
-  for (int i = wave_lane(); i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+
+SSS_DEV void env_end(Ctx& c, uint8_t* base) {
+  int lane = wave_lane();
+  wave_sync();
+  int A = g_hot.h.n_active;
+  int per = 8 + c.SP + c.SP / 2;
+  // every cached job is active (slots are released at completion); lanes over (active job, word)
+  for (int i = lane; i < A * per; i += 64) {
+    int a = i / per, w = i - a * per;
+    int j = lds_active(c)[a];
+    int k = lds_slot_of(c)[j];
+    if (k == SLOT_NONE) continue;
+    if (w < 8)
+      ((uint64_t*)(c.jobs + j))[w] = ((const uint64_t*)(lds_cjobs(c) + k))[w];
+    else if (w < 8 + c.SP)
+      ((uint64_t*)(c.stages + j * c.SP))[w - 8] = ((const uint64_t*)(lds_cstages(c) + k * c.SP))[w - 8];
+    else
+      ((uint64_t*)(c.durations + j * c.SP))[w - 8 - c.SP] = ((const uint64_t*)(lds_cdur(c) + k * c.SP))[w - 8 - c.SP];
+  }
+  for (int i = lane; i < A; i += 64) c.active_g[i] = lds_active(c)[i];
+  {
+    const uint4* s = (const uint4*)&g_hot;
+    uint4* d = (uint4*)base;
+    for (int i = lane; i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1142,8 +1397,8 @@ SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
   // stage_selection_map[stage_idx]: k-th set bit over the per-job masks in active order
   int k = stage_idx, j = -1, s = -1;
   for (int a = 0; a < H.n_active; a++) {
-    int jj = c.active[a];
-    uint64_t m = c.jobs[jj].sched_mask;
+    int jj = lds_active(c)[a];
+    uint64_t m = (*jobp(c, jj)).sched_mask;
     int n = popc64(m);
     if (k < n) {
       for (int i = 0; i < k; i++) m &= m - 1;
@@ -1154,12 +1409,12 @@ SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
   }
   CHECK(j >= 0);
   if (j < 0) return false;
-  SssStage st = c.stages[j * c.SP + s];
+  SssStage st = (*stgp(c, j, s));
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);  // ENV:557-578
   int n = num_exec < demand ? num_exec : demand;
   CHECK(n > 0);
   trk_add_commitment(c, n, key_stage_pool(j, s));
-  SssJob& job = c.jobs[j];
+  SssJob& job = (*jobp(c, j));
   job.selected_mask |= bit64(s);  // ENV:304
   // ENV:307-315: only this job's slice of schedulable_stages is recomputed
   int old_n = popc64(job.sched_mask);
@@ -1170,30 +1425,46 @@ SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
   return true;
 }
 
-// ENV:847-874; the float sum runs in CPython set(list + list) iteration order
-SSS_DEV_NOINLINE double compute_jobtime(Ctx& c) {
-  double wall_old = c.sc->wall_old;
-  double duration = H.wall_time - wall_old;
-  if (duration == 0.0) return 0.0;
+// ENV:847-874. The float sum runs in CPython set(list + list) iteration order: lane 0 builds the
+// set image (jobtime_build_set), then all lanes evaluate one table slot each and the terms are
+// added in slot order (jobtime_sum) - the additions stay sequential, the HBM reads do not.
+SSS_DEV_NOINLINE void jobtime_build_set(Ctx& c) {
   SetImg<uint16_t> all;
-  all.tab = c.sc->jobset;
+  all.tab = lds_jobset(c);
   for (int i = 0; i < 8; i++) all.tab[i] = 0;
   all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0;
-  for (int k = 0; k < c.sc->n_old_active; k++) set_add(all, (uint32_t)c.old_active[k], c.sc->keys);
-  for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)c.active[k], c.sc->keys);
+  for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active(c)[k], lds_keys(c));
+  for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active(c)[k], lds_keys(c));
+  g_sc.jobset_mask = (int32_t)all.mask;
+}
+
+SSS_DEV double jobtime_sum(Ctx& c) {
+  int lane = wave_lane();
+  double wall_old = g_sc.wall_old, wall = g_hot.h.wall_time;
+  int mask = g_sc.jobset_mask;
+  double beta = c.P.beta;
+  const uint16_t* tab = lds_jobset(c);
   double job_time = 0.0;
-  double beta = c.cfg->beta;
-  for (uint32_t i = 0; i <= all.mask; i++) {
-    uint32_t en = all.tab[i];
-    if (en < 2) continue;
-    int j = (int)en - 2;
-    double ta = c.t_arrival[j], tc = c.t_completed[j];
-    double start = ta > wall_old ? ta : wall_old;
-    double end = tc < H.wall_time ? tc : H.wall_time;
-    if (beta == 0.0)
-      job_time += end - start;
-    else  // np.exp in the reference: <= 2 ulp agreement only
-      job_time += fd_exp(-beta * 1e-3 * (start - wall_old)) - fd_exp(-beta * 1e-3 * (end - wall_old));
+  for (int b = 0; b <= mask; b += 64) {
+    uint32_t en = tab[b + lane];  // tables are >= 8 slots; slots beyond the mask are never live
+    bool live = (b + lane) <= mask && en >= 2;
+    double term = 0.0;
+    if (live) {
+      int j = (int)en - 2;
+      double ta = c.t_arrival[j], tc = c.t_completed[j];
+      double start = ta > wall_old ? ta : wall_old;
+      double end = tc < wall ? tc : wall;
+      if (beta == 0.0)
+        term = end - start;
+      else  // np.exp in the reference: <= 2 ulp agreement only
+        term = fd_exp(-beta * 1e-3 * (start - wall_old)) - fd_exp(-beta * 1e-3 * (end - wall_old));
+    }
+    uint64_t m = wave_ballot(live);
+    while (m) {
+      int k = ctz64(m);
+      m &= m - 1;
+      job_time += wave_bcast_f64(term, k);
+    }
   }
   if (beta > 0.0) job_time /= beta;
   return job_time;
@@ -1207,81 +1478,128 @@ SSS_DEV_NOINLINE double compute_jobtime(Ctx& c) {
 SSS_DEV void resume_simulation(Ctx& c) {
   int lane = wave_lane();
   for (;;) {
-    int ex = pop_event(c);
     if (lane == 0) {
-      c.sc->f_done = 0, c.sc->f_scan = 0;
-      if (ex == POP_EMPTY || H.err) {
-        c.sc->f_done = 1;
-      } else {
-        H.n_events++;
-        c.sc->events_this_step++;
-        if (ex == POP_ARRIVAL) {
-          int job = H.next_arrival;
-          H.wall_time = c.t_arrival[job];
-          H.next_arrival++;
-          handle_job_arrival(c, job);
+      // lane 0 runs events back to back until the wave is needed: a schedulable-stage scan
+      // (committable executors exist), an empty queue, or a failure
+      g_sc.f_done = 0, g_sc.f_scan = 0;
+      EvRegs r;
+      regs_load(r);
+      uint64_t n_fast = 0, t_slow = 0;
+      for (;;) {
+        int ex = pop_event(c);
+        if (ex == POP_EMPTY) {
+          regs_store(r);
+          g_sc.f_done = 1;
+          break;
+        }
+        r.n_events++;
+        r.events_this_step++;
+        bool fast = false;
+        if (ex >= 0 && g_hot.ev_kind[ex] == EV_TASK_FINISHED) {
+          r.wall_time = g_hot.ev_t[ex];
+          fast = fast_task_completion(c, r, ex, g_hot.ev_job[ex], g_hot.ev_stage[ex]);
+        }
+        if (fast) {
+          // the source stays what it was - None right after a scheduling round - so nothing is
+          // committable and the loop continues on registers (ENV:331-332)
+          n_fast++;
+          if (H.curr_source == POOL_NONE && !H.err) continue;
+          regs_store(r);
         } else {
-          SssHot& hot = *c.hot;
-          H.wall_time = hot.ev_t[ex];
-          int kind = hot.ev_kind[ex], job = hot.ev_job[ex], s = hot.ev_stage[ex];
-          hot.ev_kind[ex] = EV_NONE;
-          if (kind == EV_TASK_FINISHED)
-            handle_task_completion(c, ex, job, s);
-          else
-            handle_executor_arrival(c, ex, job, s);
+          // everything else goes through the out-of-line handlers on the LDS copy of the state
+          regs_store(r);
+          uint64_t ts0 = wave_clock();
+          if (ex == POP_ARRIVAL) {
+            int job = H.next_arrival;
+            H.wall_time = H.next_arrival_t;
+            H.next_arrival++;
+            H.next_arrival_t = H.next_arrival < H.J ? c.t_arrival[H.next_arrival] : __builtin_inf();
+            handle_job_arrival(c, job);
+          } else {
+            SssHot& hot = g_hot;
+            H.wall_time = hot.ev_t[ex];
+            int kind = hot.ev_kind[ex], job = hot.ev_job[ex], s = hot.ev_stage[ex];
+            hot.ev_kind[ex] = EV_NONE;
+            hot.ev_t[ex] = __builtin_inf();
+            if (kind == EV_TASK_FINISHED)
+              handle_task_completion(c, ex, job, s);
+            else
+              handle_executor_arrival(c, ex, job, s);
+          }
+          if (g_sc.pending_free >= 0) {
+            cache_release(c, g_sc.pending_free);
+            g_sc.pending_free = -1;
+          }
+          t_slow += wave_clock() - ts0;
         }
-        if (H.err)
-          c.sc->f_done = 1;
-        else if (trk_num_committable(c) > 0) {
-          c.sc->f_scan = 1;
+        // the LDS header is current here
+        if (H.err) {
+          g_sc.f_done = 1;
+          break;
+        }
+        if (trk_num_committable(c) > 0) {
+          g_sc.f_scan = 1;
           publish_scan_inputs(c);
+          break;
         }
+        regs_load(r);
       }
+      H.n_fast += n_fast;
+      H.prof[0] += t_slow;
     }
     wave_sync();
-    if (c.sc->f_done) {
+    if (g_sc.f_done) {
       // queue exhausted (or failed): schedulable_stages = [] (ENV:324,343)
       if (lane == 0) {
-        for (int a = 0; a < H.n_active; a++) c.jobs[c.active[a]].sched_mask = 0;
+        for (int a = 0; a < H.n_active; a++) (*jobp(c, lds_active(c)[a])).sched_mask = 0;
         H.n_sched = 0;
       }
       wave_sync();
       return;
     }
-    if (c.sc->f_scan) {
-      int n = find_schedulable_all(c);
-      if (n > 0) {
-        if (lane == 0) H.n_sched = n;
-        wave_sync();
-        return;
-      }
-      if (lane == 0) {
-        move_idle_executors_all(c, POOL_NONE);  // ENV:340
-        H.curr_source = POOL_NONE;               // ENV:341
-      }
+    // f_scan: _find_schedulable_stages() with the whole wave
+    int n = find_schedulable_all(c);
+    if (n > 0) {
+      if (lane == 0) H.n_sched = n;
       wave_sync();
+      return;
     }
+    if (lane == 0) {
+      move_idle_executors_all(c, POOL_NONE);  // ENV:340
+      H.curr_source = POOL_NONE;               // ENV:341
+    }
+    wave_sync();
   }
 }
 
 // episode initialisation: ENV:127-186 + TPCH:54-73,176-206 + TRK:32-71
 SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_limit) {
   int lane = wave_lane();
-  SssHot& hot = *c.hot;
+  SssHot& hot = g_hot;
+  // nothing is cached while the records are (re)built in HBM
+  for (int i = lane; i < c.J_cap; i += 64) lds_slot_of(c)[i] = SLOT_NONE;
+  wave_sync();
   if (lane == 0) {
+    g_sc.free_slots = c.P.n_slots >= 64 ? ~0ull : (bit64(c.P.n_slots) - 1);
+    g_sc.pending_free = -1;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
     int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
     double last_ep_return = H.last_ep_return, last_ep_wall = H.last_ep_wall;
+    uint64_t prof[5];
+    for (int i = 0; i < 5; i++) prof[i] = H.prof[i];
+    uint64_t n_fast_keep = H.n_fast;
     SssHdr z = {};
     H = z;
+    for (int i = 0; i < 5; i++) H.prof[i] = prof[i];
+    H.n_fast = n_fast_keep;
     H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
     H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
     H.seed = seed, H.time_limit = time_limit;
     H.curr_source = POOL_COMMON;
-    c.sc->events_this_step = 0;
-    if (!(time_limit < __builtin_inf()) && c.cfg->cap_cfg <= 0) {
+    g_sc.events_this_step = 0;
+    if (!(time_limit < __builtin_inf()) && c.P.cap_cfg <= 0) {
       H.err = SSS_ERR_NO_LIMIT;  // ENV:137-138
       H.need_reset = 1;
     } else {
@@ -1289,7 +1607,7 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
       // job_sequence TPCH:54-73
       double t = 0.0;
       int J = 0;
-      while (t < time_limit && (c.cfg->cap_cfg <= 0 || J < c.cfg->cap_cfg)) {
+      while (t < time_limit && (c.P.cap_cfg <= 0 || J < c.P.cap_cfg)) {
         if (J >= c.J_cap) {
           H.err = SSS_ERR_CAPACITY;
           H.need_reset = 1;
@@ -1297,17 +1615,17 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
         }
         int q = (int)rng_integers(H, 22);     // TPCH:177
         int size = (int)rng_integers(H, 7);   // TPCH:178
-        c.jobs[J].tmpl = (int16_t)(q * 7 + size);
+        (*jobp(c, J)).gs_base = q * 7 + size;  // template id for now; resolved to pack rows below
         c.t_arrival[J] = t;
         J++;
-        t += c.cfg->mean_interarrival * rng_standard_exponential(c, H);  // TPCH:70
+        t += c.P.mean_interarrival * rng_standard_exponential(c, H);  // TPCH:70
       }
       H.J = J;
     }
   }
   // executors + event slots + commitments
   if (lane < SSS_MAX_EXEC) {
-    hot.ev_t[lane] = 0.0, hot.ev_seq[lane] = 0, hot.ex_loc[lane] = lane < c.E ? POOL_COMMON : POOL_NONE;
+    hot.ev_t[lane] = __builtin_inf(), hot.ev_seq[lane] = 0, hot.ex_loc[lane] = lane < c.E ? POOL_COMMON : POOL_NONE;
     hot.ev_job[lane] = -1, hot.ex_job[lane] = -1, hot.ev_stage[lane] = -1, hot.ev_kind[lane] = EV_NONE;
     hot.ex_task_stage[lane] = -1, hot.ex_executing[lane] = 0;
     hot.c_src[lane] = POOL_NONE, hot.c_dst[lane] = POOL_NONE, hot.c_seq[lane] = 0, hot.c_n[lane] = 0;
@@ -1316,8 +1634,8 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
   int J = hot.h.J;
   // job records: one lane per job
   for (int j = lane; j < J; j += 64) {
-    SssJob& job = c.jobs[j];
-    int tmpl = job.tmpl;
+    SssJob& job = (*jobp(c, j));
+    int tmpl = job.gs_base;
     int gs = c.pk->tmpl_stage_off[tmpl];
     int ns = c.pk->tmpl_stage_off[tmpl + 1] - gs;
     uint64_t frontier = 0;
@@ -1329,7 +1647,7 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
     job.supply = 0, job.sat_count = 0, job.completion_order = -1;
     job.n_stages = (uint8_t)ns;
     job.n_edges = (uint8_t)(c.pk->tmpl_edge_off[tmpl + 1] - c.pk->tmpl_edge_off[tmpl]);
-    job.pad = 0;
+    job.edge_off = c.pk->tmpl_edge_off[tmpl];
     job.gs_base = gs;
     c.t_completed[j] = __builtin_inf();
   }
@@ -1337,7 +1655,7 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
   // stage records: lanes over (job, stage)
   for (int i = lane; i < J * c.SP; i += 64) {
     int j = i / c.SP, s = i - j * c.SP;
-    const SssJob& job = c.jobs[j];
+    const SssJob& job = (*jobp(c, j));
     SssStage st = {0, 0, 0, 0};
     float d = 0.0f;
     if (s < (int)job.n_stages) {
@@ -1358,13 +1676,14 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
   if (lane == 0 && !H.err) {
     // common pool = set(range(E)) (TRK:41)
     SetImg<uint8_t> s = pool_open(c, POOL_COMMON);
-    for (int e = 0; e < c.E; e++) set_add(s, (uint32_t)e, c.sc->keys);
+    for (int e = 0; e < c.E; e++) set_add(s, (uint32_t)e, lds_keys(c));
     pool_close(c, POOL_COMMON, s);
     // _load_initial_jobs ENV:260-273
     while (H.next_arrival < H.J && c.t_arrival[H.next_arrival] <= 0.0) {
       handle_job_arrival(c, H.next_arrival);
       H.next_arrival++;
     }
+    H.next_arrival_t = H.next_arrival < H.J ? c.t_arrival[H.next_arrival] : __builtin_inf();
   }
   if (lane == 0) publish_scan_inputs(c);
   wave_sync();
@@ -1376,9 +1695,10 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
 // ENV:188-221. `reward` is valid on lane 0 (and uniform).
 SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
   int lane = wave_lane();
+  uint64_t t0 = wave_clock();
   if (lane == 0) {
-    c.sc->f_round_continues = 1;
-    c.sc->events_this_step = 0;
+    g_sc.f_round_continues = 1;
+    g_sc.events_this_step = 0;
     H.last_reward = 0.0;
     if (H.need_reset || H.terminated) {
       H.err = SSS_ERR_NEED_RESET;
@@ -1393,23 +1713,37 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
           commit_remaining_executors(c);
           fulfill_commitments_from_source(c);
           H.curr_source = POOL_NONE;
-          for (int a = 0; a < H.n_active; a++) c.jobs[c.active[a]].selected_mask = 0;
-          c.sc->wall_old = H.wall_time;
-          c.sc->n_old_active = H.n_active;
-          for (int a = 0; a < H.n_active; a++) c.old_active[a] = c.active[a];
-          c.sc->f_round_continues = 0;
+          for (int a = 0; a < H.n_active; a++) (*jobp(c, lds_active(c)[a])).selected_mask = 0;
+          g_sc.wall_old = H.wall_time;
+          g_sc.n_old_active = H.n_active;
+          for (int a = 0; a < H.n_active; a++) lds_old_active(c)[a] = lds_active(c)[a];
+          g_sc.f_round_continues = 0;
         }
       }
       if (H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
     }
   }
   wave_sync();
-  if (wave_ballot(c.sc->f_round_continues || c.hot->h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
+  uint64_t t1 = wave_clock();
+  if (lane == 0) H.prof[1] += t1 - t0;
+  if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
   resume_simulation(c);
+  uint64_t t2 = wave_clock();
+  // reward = -job_time (ENV:208-209); `duration == 0.0` short-circuits to -0.0 (ENV:850-852)
+  if (lane == 0) {
+    g_sc.f_need_jobtime = 0;
+    if (!H.err && H.wall_time - g_sc.wall_old != 0.0) {
+      jobtime_build_set(c);
+      g_sc.f_need_jobtime = 1;
+    }
+  }
+  wave_sync();
+  double job_time = 0.0;
+  if (g_sc.f_need_jobtime) job_time = jobtime_sum(c);
   double reward = 0.0;
   if (lane == 0) {
     if (!H.err) {
-      reward = -compute_jobtime(c);
+      reward = -job_time;
       H.terminated = H.n_completed == H.J;  // ENV:227-229
       if (!H.terminated && !(trk_num_committable(c) > 0 && H.n_sched > 0)) H.err = SSS_ERR_STALLED;  // ENV:212-215
       H.ep_return += reward;
@@ -1419,6 +1753,8 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
       }
     }
     if (H.err) H.need_reset = 1;
+    uint64_t t3 = wave_clock();
+    H.prof[2] += t2 - t1, H.prof[3] += t3 - t2;
   }
   wave_sync();
   return reward;
@@ -1431,49 +1767,41 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
 struct SssKernelArgs {
   SssLayout L;
   SssBuffers B;
-  const SssCfgDev* cfg;
+  SssParams P;
   const SssPackDev* pk;
 };
 
 // reset envs whose mask byte is non-zero (mask == nullptr: all)
 SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const double* time_limits, const uint8_t* mask) {
-  SSS_SHARED SssHot hot;
-  SSS_SHARED SssScratch sc;
   int env = wave_env();
   if (mask && !mask[env]) return;
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   Ctx c;
-  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
-  hot_load(&hot, (const SssHot*)base);
-  wave_sync();
+  ctx_init(c, base, a.L, a.P, a.pk);
+  env_begin(c, base);
   do_reset(c, a.L, seeds[env], time_limits ? time_limits[env] : __builtin_inf());
   write_observation(c, a.L, a.B, env, 0.0);
-  wave_sync();
-  hot_store((SssHot*)base, &hot);
+  env_end(c, base);
 }
 
 // one step() per env; with auto_reset != 0 an env that is terminated at entry starts its next
 // episode instead (seed += seed_stride), like a vector env in "next-step" autoreset mode
 SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
-  SSS_SHARED SssHot hot;
-  SSS_SHARED SssScratch sc;
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   Ctx c;
-  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
-  hot_load(&hot, (const SssHot*)base);
-  wave_sync();
+  ctx_init(c, base, a.L, a.P, a.pk);
+  env_begin(c, base);
   double reward = 0.0;
   // the ballot doubles as the barrier between "all lanes read the header" and lane 0 rewriting it
-  bool start_next_episode = wave_ballot(auto_reset && hot.h.terminated && !hot.h.err) != 0;
+  bool start_next_episode = wave_ballot(auto_reset && g_hot.h.terminated && !g_hot.h.err) != 0;
   if (start_next_episode) {
-    do_reset(c, a.L, hot.h.seed + seed_stride, hot.h.time_limit);
+    do_reset(c, a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
   } else {
     reward = do_step(c, stage_idx[env], num_exec[env]);
   }
   write_observation(c, a.L, a.B, env, reward);
-  wave_sync();
-  hot_store((SssHot*)base, &hot);
+  env_end(c, base);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1484,7 +1812,7 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
 // ------------------------------------------------------------------------------------------
 
 SSS_DEV int obs_num_committable(const Ctx& c) {
-  uint32_t srck = c.hot->h.curr_source;
+  uint32_t srck = g_hot.h.curr_source;
   if (srck == POOL_NONE) return 0;
   int p = pool_index(c, srck);
   return (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
@@ -1495,8 +1823,8 @@ SSS_DEV int obs_num_committable(const Ctx& c) {
 SSS_DEV void policy_fair(Ctx& c, bool dynamic_partition, int& stage_idx, int& num_exec) {
   int lane = wave_lane();
   // shared state is read up front; at least one collective follows before anything returns
-  int A = c.hot->h.n_active;
-  uint32_t srck = c.hot->h.curr_source;
+  int A = g_hot.h.n_active;
+  uint32_t srck = g_hot.h.curr_source;
   int ncommit = obs_num_committable(c);
   int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
   int denom = A > 1 ? A : 1;
@@ -1508,11 +1836,11 @@ SSS_DEV void policy_fair(Ctx& c, bool dynamic_partition, int& stage_idx, int& nu
   for (int ch = 0; ch < n_chunks; ch++) {
     int k = ch * 64 + lane;
     bool valid = k < A;
-    int j = valid ? (int)c.active[k] : 0;
+    int j = valid ? (int)lds_active(c)[k] : 0;
     uint64_t sm = 0, act = 0;
     int sup = 0, gs = 0;
     if (valid) {
-      const SssJob& job = c.jobs[j];
+      const SssJob& job = (*jobp(c, j));
       sm = job.sched_mask, act = job.active_mask, sup = job.supply, gs = job.gs_base;
     }
     // find_stage: first schedulable stage with no active parent, else first schedulable stage
@@ -1565,9 +1893,9 @@ SSS_DEV uint64_t splitmix64(uint64_t x) {
 // hash_policy in tests/golden/make_golden.py. SURVEY 8(d) C2: stage uniform over the schedulable
 // stages, num_exec uniform in [1, num_committable]; `p_none_permille` adds stage_idx = -1 draws.
 SSS_DEV void policy_hash(Ctx& c, int p_none_permille, int& stage_idx, int& num_exec) {
-  uint64_t seed = c.hot->h.seed;
-  uint64_t step = (uint64_t)c.hot->h.ep_steps;
-  int n_sched = c.hot->h.n_sched;
+  uint64_t seed = g_hot.h.seed;
+  uint64_t step = (uint64_t)g_hot.h.ep_steps;
+  int n_sched = g_hot.h.n_sched;
   int ncommit = obs_num_committable(c);
   wave_sync();  // reads above vs. lane 0's writes in the step that follows
   uint64_t h = splitmix64((seed << 32) ^ step), h2 = splitmix64(h), h3 = splitmix64(h2);
@@ -1589,36 +1917,30 @@ SSS_DEV void run_policy(Ctx& c, int policy, int param, int& stage_idx, int& num_
 
 // writes one action per env into stage_idx / num_exec (for sss_step)
 SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_t* stage_idx, int32_t* num_exec) {
-  SSS_SHARED SssHot hot;
-  SSS_SHARED SssScratch sc;
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   Ctx c;
-  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
-  hot_load(&hot, (const SssHot*)base);
-  wave_sync();
+  ctx_init(c, base, a.L, a.P, a.pk);
+  env_begin(c, base);
   int si, ne;
   run_policy(c, policy, param, si, ne);
   if (wave_lane() == 0) stage_idx[env] = si, num_exec[env] = ne;
 }
 
-// n_steps x (policy -> step -> observe) per env in one launch; the env's hot block stays in LDS
-// in between. Every step still writes the full observation, as the reference's step() does.
+// n_steps x (policy -> step -> observe) per env in one launch; the env's hot block and job cache
+// stay in LDS in between. Every step still writes the full observation, as the reference's step() does.
 SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride) {
-  SSS_SHARED SssHot hot;
-  SSS_SHARED SssScratch sc;
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   Ctx c;
-  ctx_init(c, &hot, &sc, base, a.L, a.cfg, a.pk);
-  hot_load(&hot, (const SssHot*)base);
-  wave_sync();
+  ctx_init(c, base, a.L, a.P, a.pk);
+  env_begin(c, base);
   for (int it = 0; it < n_steps; it++) {
-    bool over = wave_ballot(hot.h.terminated || hot.h.need_reset) != 0;
+    bool over = wave_ballot(g_hot.h.terminated || g_hot.h.need_reset) != 0;
     double reward = 0.0;
     if (over) {
-      if (!auto_reset || wave_ballot(hot.h.err != 0) != 0) break;  // failed envs stay failed
-      do_reset(c, a.L, hot.h.seed + seed_stride, hot.h.time_limit);
+      if (!auto_reset || wave_ballot(g_hot.h.err != 0) != 0) break;  // failed envs stay failed
+      do_reset(c, a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
     } else {
       int si, ne;
       run_policy(c, policy, param, si, ne);
@@ -1627,7 +1949,7 @@ SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n
     write_observation(c, a.L, a.B, env, reward);
     wave_sync();
   }
-  hot_store((SssHot*)base, &hot);
+  env_end(c, base);
 }
 
 #undef H

@@ -12,6 +12,7 @@
 #define SSS_DEV_NOINLINE __device__ __noinline__
 #define SSS_KERNEL extern "C" __global__ __launch_bounds__(64)
 #define SSS_SHARED __shared__
+#define SSS_SHARED_DYN(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
 
 SSS_DEV int wave_lane() { return (int)threadIdx.x; }
 SSS_DEV int wave_env() { return (int)blockIdx.x; }
@@ -22,6 +23,11 @@ SSS_DEV void wave_sync() { __syncthreads(); }
 SSS_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
 
 SSS_DEV uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+
+SSS_DEV double wave_bcast_f64(double v, int src) {
+  int lo = __shfl(__double2loint(v), src, 64), hi = __shfl(__double2hiint(v), src, 64);
+  return __hiloint2double(hi, lo);
+}
 
 SSS_DEV uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
@@ -61,6 +67,7 @@ SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
   return x - v;
 }
 
+SSS_DEV uint64_t wave_clock() { return (uint64_t)clock64(); }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 SSS_DEV int popc64(uint64_t x) { return __popcll(x); }
 SSS_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }

@@ -205,7 +205,8 @@ class VecSparkSchedSimEnv:
         return int(self._env_view[i, byte_off: byte_off + 4].cpu().numpy().view(np.int32)[0])
 
     def job_times(self, i: int):
-        """(t_arrival f64[J], t_completed f64[J], completion_order i16[J]) of env i's current episode"""
+        """(t_arrival f64[J], t_completed f64[J], completion_order i16[J], template id i16[J]) of env
+        i's current episode (between launches the HBM copy of every record is current)"""
         d = self.dims
         row = self._env_view[i].cpu().numpy()
         hdr = row[: d.hdr_bytes]
@@ -213,8 +214,9 @@ class VecSparkSchedSimEnv:
         ta = row[d.off_t_arrival: d.off_t_arrival + 8 * J].view(np.float64).copy()
         tc = row[d.off_t_completed: d.off_t_completed + 8 * J].view(np.float64).copy()
         jobs = row[d.off_jobs: d.off_jobs + d.job_rec_bytes * J].reshape(J, d.job_rec_bytes)
-        order = jobs[:, 54:56].copy().view(np.int16).ravel()
-        tmpl = jobs[:, 48:50].copy().view(np.int16).ravel()
+        order = jobs[:, 56:58].copy().view(np.int16).ravel()
+        gs_base = jobs[:, 60:64].copy().view(np.int32).ravel()
+        tmpl = np.searchsorted(workload.pack_section(self._pack, "tmpl_stage_off"), gs_base).astype(np.int16)
         return ta, tc, order, tmpl
 
     def header(self, i: int) -> dict[str, Any]:
@@ -239,6 +241,10 @@ class VecSparkSchedSimEnv:
         for name in ("n_steps", "n_events", "model_bytes"):
             off = HDR_OFF[name]
             tot[name] = int(np.ascontiguousarray(hdr[:, off: off + 8]).view(np.uint64).sum())
+        prof = np.ascontiguousarray(hdr[:, 208:248]).view(np.uint64).sum(axis=0)
+        for k, name in enumerate(("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe")):
+            tot[name] = int(prof[k])
+        tot["n_fast_events"] = int(np.ascontiguousarray(hdr[:, 248:256]).view(np.uint64).sum())
         return tot
 
 

@@ -351,6 +351,15 @@ def serialize_pack(arrs: dict[str, np.ndarray]) -> bytes:
     return bytes(out)
 
 
+def pack_section(pack: bytes, name: str) -> np.ndarray:
+    """numpy view of one section of a serialized pack"""
+    names = [n for n, _ in _SECTIONS]
+    i = names.index(name)
+    head = 8 + 8 * 8
+    off, length = struct.unpack_from("<2q", pack, head + 16 * i)
+    return np.frombuffer(pack, dtype=_SECTIONS[i][1], count=length // np.dtype(_SECTIONS[i][1]).itemsize, offset=off)
+
+
 def build_pack(raw: dict | None = None, seed: int = DEFAULT_SEED) -> bytes:
     if raw is None:
         raw = make_raw_workload(seed)

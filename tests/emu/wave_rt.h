@@ -18,6 +18,7 @@
 #define SSS_DEV_NOINLINE static __attribute__((noinline))
 #define SSS_KERNEL extern "C"
 #define SSS_SHARED static
+#define SSS_SHARED_DYN(name) alignas(16) static uint8_t name[65536]
 
 namespace emu {
 enum Op { OP_SYNC = 1, OP_BALLOT, OP_BCAST, OP_MIN32, OP_MIN64, OP_SUM32, OP_SCAN32 };
@@ -41,6 +42,14 @@ SSS_DEV uint64_t wave_ballot(bool p) {
 SSS_DEV uint32_t wave_bcast_u32(uint32_t v, int src) {
   emu::collective(emu::OP_BCAST, v);
   return (uint32_t)emu::slot(src & 63);
+}
+SSS_DEV double wave_bcast_f64(double v, int src) {
+  uint64_t u;
+  memcpy(&u, &v, 8);
+  emu::collective(emu::OP_BCAST, u);
+  u = emu::slot(src & 63);
+  memcpy(&v, &u, 8);
+  return v;
 }
 SSS_DEV uint32_t wave_min_u32(uint32_t v) {
   emu::collective(emu::OP_MIN32, v);
@@ -66,6 +75,7 @@ SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
   for (int i = 0; i < emu::lane(); i++) s += (uint32_t)emu::slot(i);
   return s;
 }
+SSS_DEV uint64_t wave_clock() { return 0; }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 SSS_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
 SSS_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : -1; }
