@@ -59,7 +59,7 @@ struct sss_handle {
   void* zig_dev;
   void* eff_dev;
   SssParams P;
-  SssPackDev* pk_dev;
+  SssPackDev pk;
 };
 
 static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, SssPackHost* ph, int* J_cap) {
@@ -151,8 +151,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   std::vector<uint8_t> zig(256 * 8 * 3);
   memcpy(zig.data(), ZIG_KE, 2048), memcpy(zig.data() + 2048, ZIG_WE, 2048), memcpy(zig.data() + 4096, ZIG_FE, 2048);
   h->zig_dev = be_alloc(zig.size());
-  h->pk_dev = (SssPackDev*)be_alloc(sizeof(SssPackDev));
-  if (!h->pack_dev || !h->zig_dev || !h->pk_dev) {
+  if (!h->pack_dev || !h->zig_dev) {
     sss_destroy(h);
     return sss_fail(-11, "device allocation failed");
   }
@@ -205,7 +204,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   }
   be_h2d(h->eff_dev, eff.data(), eff.size() * sizeof(int32_t));
   pk.eff = (const int32_t*)h->eff_dev;
-  be_h2d(h->pk_dev, &pk, sizeof(pk));
+  h->pk = pk;
   *out = h;
   return 0;
 }
@@ -223,7 +222,7 @@ extern "C" int sss_bind_buffers(sss_handle* h, const sss_buffers* b) {
 
 static SssKernelArgs sss_args(const sss_handle* h) {
   SssKernelArgs a;
-  a.L = h->L, a.B = h->B, a.P = h->P, a.pk = h->pk_dev;
+  a.L = h->L, a.B = h->B, a.P = h->P, a.pk = h->pk;
   return a;
 }
 
@@ -260,6 +259,6 @@ extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, in
 
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
-  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev), be_free(h->pk_dev);
+  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev);
   delete h;
 }

@@ -82,17 +82,21 @@ struct SssHdr {            // 256 bytes
   uint64_t n_fast;         // events handled by the register fast path
 };
 
+// one pending event per executor at most: 16 bytes, read with a single LDS access.
+// info = kind | stage << 8 | job << 16; t = +inf when the executor has no pending event.
+struct SssEvSlot {
+  double t;
+  uint32_t seq;
+  uint32_t info;
+};
+
 struct SssHot {            // staged HBM <-> LDS as a flat block
   SssHdr h;
   // event slots: one pending event per executor at most (TASK_FINISHED while busy,
   // EXECUTOR_READY while moving); the queue's pop is a wave-wide arg-min over (t, seq)
-  double ev_t[SSS_MAX_EXEC];
-  uint32_t ev_seq[SSS_MAX_EXEC];
+  SssEvSlot ev[SSS_MAX_EXEC];
   uint32_t ex_loc[SSS_MAX_EXEC];       // pool key, POOL_NONE while moving
-  int16_t ev_job[SSS_MAX_EXEC];
   int16_t ex_job[SSS_MAX_EXEC];        // executor.job_id, -1 = None
-  int8_t ev_stage[SSS_MAX_EXEC];
-  uint8_t ev_kind[SSS_MAX_EXEC];
   int8_t ex_task_stage[SSS_MAX_EXEC];  // executor.task.stage_id, -1 = task is None
   uint8_t ex_executing[SSS_MAX_EXEC];
   // commitments: insertion-ordered dict-of-dicts flattened; order within a source = c_seq

@@ -48,14 +48,16 @@ struct alignas(16) SssScratch {
   int16_t fc_num[SSS_MAX_EXEC];
 };
 
-#define SSS_STATIC_LDS_BYTES ((int)(sizeof(SssHot) + sizeof(SssScratch)))
+#define SSS_STATIC_LDS_BYTES ((int)(sizeof(SssHot) + sizeof(SssScratch) + 512))  // + Ctx (g_c), checked below
 
 SSS_SHARED SssHot g_hot;
 SSS_SHARED SssScratch g_sc;
 SSS_SHARED_DYN(g_pool);
 
+// Per-launch context: this env's HBM pointers, the workload-pack pointers and the small
+// parameters. It lives in LDS (not in a struct passed by reference): every function reads what it
+// needs with a ds_read at a fixed address, nothing is spilled to scratch or re-derived per call.
 struct Ctx {
-  // HBM (this env's block of the arena)
   uint16_t* active_g;
   SssJob* jobs;
   double* t_arrival;
@@ -65,24 +67,29 @@ struct Ctx {
   SssPoolHdr* pool_hdr;
   uint8_t* pool_tab;
   double* dur_ring;
-  const SssPackDev* pk;
+  SssPackDev pk;
   SssParams P;
   int E, J_cap, SP;
 };
+SSS_SHARED Ctx g_c;
+static_assert(sizeof(Ctx) <= 512, "SSS_STATIC_LDS_BYTES reserves 512 bytes for Ctx");
 
-SSS_DEV void ctx_init(Ctx& c, uint8_t* env_base, const SssLayout& L, const SssParams& P, const SssPackDev* pk) {
-  c.active_g = (uint16_t*)(env_base + L.off_active);
-  c.jobs = (SssJob*)(env_base + L.off_jobs);
-  c.t_arrival = (double*)(env_base + L.off_t_arrival);
-  c.t_completed = (double*)(env_base + L.off_t_completed);
-  c.stages = (SssStage*)(env_base + L.off_stages);
-  c.durations = (float*)(env_base + L.off_durations);
-  c.pool_hdr = (SssPoolHdr*)(env_base + L.off_pool_hdr);
-  c.pool_tab = env_base + L.off_pool_tab;
-  c.dur_ring = (double*)(env_base + L.off_dur_ring);
-  c.pk = pk;
-  c.P = P;
-  c.E = L.E, c.J_cap = L.J_cap, c.SP = L.SP;
+SSS_DEV void ctx_init(uint8_t* env_base, const SssLayout& L, const SssParams& P, const SssPackDev& pk) {
+  if (wave_lane() == 0) {
+    g_c.active_g = (uint16_t*)(env_base + L.off_active);
+    g_c.jobs = (SssJob*)(env_base + L.off_jobs);
+    g_c.t_arrival = (double*)(env_base + L.off_t_arrival);
+    g_c.t_completed = (double*)(env_base + L.off_t_completed);
+    g_c.stages = (SssStage*)(env_base + L.off_stages);
+    g_c.durations = (float*)(env_base + L.off_durations);
+    g_c.pool_hdr = (SssPoolHdr*)(env_base + L.off_pool_hdr);
+    g_c.pool_tab = env_base + L.off_pool_tab;
+    g_c.dur_ring = (double*)(env_base + L.off_dur_ring);
+    g_c.pk = pk;
+    g_c.P = P;
+    g_c.E = L.E, g_c.J_cap = L.J_cap, g_c.SP = L.SP;
+  }
+  wave_sync();
 }
 
 #define H (g_hot.h)
@@ -97,27 +104,27 @@ SSS_DEV void ctx_init(Ctx& c, uint8_t* env_base, const SssLayout& L, const SssPa
 
 // ---- LDS pool views ----
 #define SLOT_NONE 255
-SSS_DEV uint16_t* lds_active(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_active); }
-SSS_DEV uint8_t* lds_slot_of(const Ctx& c) { return g_pool + c.P.off_slot_of; }
-SSS_DEV uint16_t* lds_keys(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_keys); }
-SSS_DEV uint16_t* lds_jobset(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_jobset); }
-SSS_DEV SssJob* lds_cjobs(const Ctx& c) { return (SssJob*)(g_pool + c.P.off_cjobs); }
-SSS_DEV SssStage* lds_cstages(const Ctx& c) { return (SssStage*)(g_pool + c.P.off_cstages); }
-SSS_DEV float* lds_cdur(const Ctx& c) { return (float*)(g_pool + c.P.off_cdur); }
-SSS_DEV uint16_t* lds_old_active(const Ctx& c) { return (uint16_t*)(g_pool + c.P.off_old_active); }
+SSS_DEV uint16_t* lds_active() { return (uint16_t*)(g_pool + g_c.P.off_active); }
+SSS_DEV uint8_t* lds_slot_of() { return g_pool + g_c.P.off_slot_of; }
+SSS_DEV uint16_t* lds_keys() { return (uint16_t*)(g_pool + g_c.P.off_keys); }
+SSS_DEV uint16_t* lds_jobset() { return (uint16_t*)(g_pool + g_c.P.off_jobset); }
+SSS_DEV SssJob* lds_cjobs() { return (SssJob*)(g_pool + g_c.P.off_cjobs); }
+SSS_DEV SssStage* lds_cstages() { return (SssStage*)(g_pool + g_c.P.off_cstages); }
+SSS_DEV float* lds_cdur() { return (float*)(g_pool + g_c.P.off_cdur); }
+SSS_DEV uint16_t* lds_old_active() { return (uint16_t*)(g_pool + g_c.P.off_old_active); }
 
 // record of job j: its LDS cache slot if it has one, else the HBM copy
-SSS_DEV SssJob* jobp(const Ctx& c, int j) {
-  int s = lds_slot_of(c)[j];
-  return s != SLOT_NONE ? lds_cjobs(c) + s : c.jobs + j;
+SSS_DEV SssJob* jobp(int j) {
+  int s = lds_slot_of()[j];
+  return s != SLOT_NONE ? lds_cjobs() + s : g_c.jobs + j;
 }
-SSS_DEV SssStage* stgp(const Ctx& c, int j, int st) {
-  int s = lds_slot_of(c)[j];
-  return s != SLOT_NONE ? lds_cstages(c) + s * c.SP + st : c.stages + j * c.SP + st;
+SSS_DEV SssStage* stgp(int j, int st) {
+  int s = lds_slot_of()[j];
+  return s != SLOT_NONE ? lds_cstages() + s * g_c.SP + st : g_c.stages + j * g_c.SP + st;
 }
-SSS_DEV float* durp(const Ctx& c, int j, int st) {  // stage.most_recent_duration (observed as f32, ENV:381)
-  int s = lds_slot_of(c)[j];
-  return s != SLOT_NONE ? lds_cdur(c) + s * c.SP + st : c.durations + j * c.SP + st;
+SSS_DEV float* durp(int j, int st) {  // stage.most_recent_duration (observed as f32, ENV:381)
+  int s = lds_slot_of()[j];
+  return s != SLOT_NONE ? lds_cdur() + s * g_c.SP + st : g_c.durations + j * g_c.SP + st;
 }
 
 // pool keys
@@ -125,11 +132,11 @@ SSS_DEV uint32_t key_job_pool(int j) { return (uint32_t)(j + 1) << 8; }
 SSS_DEV uint32_t key_stage_pool(int j, int s) { return ((uint32_t)(j + 1) << 8) | (uint32_t)(s + 1); }
 SSS_DEV int key_job(uint32_t k) { return k == POOL_NONE ? -1 : (int)(k >> 8) - 1; }   // pool_key[0], -1 = None
 SSS_DEV int key_stage(uint32_t k) { return k == POOL_NONE ? -1 : (int)(k & 0xFF) - 1; }  // pool_key[1], -1 = None
-SSS_DEV int pool_index(const Ctx& c, uint32_t k) {
+SSS_DEV int pool_index(uint32_t k) {
   int j = key_job(k), s = key_stage(k);
   if (j < 0) return 0;
   if (s < 0) return 1 + j;
-  return 1 + c.J_cap + j * c.SP + s;
+  return 1 + g_c.J_cap + j * g_c.SP + s;
 }
 SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
 
@@ -353,16 +360,16 @@ SSS_DEV_NOINLINE double fd_exp(double x) {
   return y * 9.33263618503218878990e-302;
 }
 
-SSS_DEV_NOINLINE double rng_standard_exponential(const Ctx& c, SssHdr& h) {
+SSS_DEV_NOINLINE double rng_standard_exponential(SssHdr& h) {
   for (;;) {
     uint64_t ri = rng_next64(h);
     ri >>= 3;
     unsigned idx = (unsigned)(ri & 0xFF);
     ri >>= 8;
-    double x = (double)ri * c.pk->zig_we[idx];
-    if (ri < c.pk->zig_ke[idx]) return x;
+    double x = (double)ri * g_c.pk.zig_we[idx];
+    if (ri < g_c.pk.zig_ke[idx]) return x;
     if (idx == 0) return 7.69711747013104972 - fd_log1p(-rng_random(h));
-    if ((c.pk->zig_fe[idx - 1] - c.pk->zig_fe[idx]) * rng_random(h) + c.pk->zig_fe[idx] < fd_exp(-x)) return x;
+    if ((g_c.pk.zig_fe[idx - 1] - g_c.pk.zig_fe[idx]) * rng_random(h) + g_c.pk.zig_fe[idx] < fd_exp(-x)) return x;
   }
 }
 
@@ -482,68 +489,68 @@ SSS_DEV uint32_t set_pop(SetImg<T>& s) {
   return key;
 }
 
-SSS_DEV SetImg<uint8_t> pool_open(const Ctx& c, uint32_t key) {
-  int p = pool_index(c, key);
-  SssPoolHdr hd = c.pool_hdr[p];
+SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
+  int p = pool_index(key);
+  SssPoolHdr hd = g_c.pool_hdr[p];
   SetImg<uint8_t> s;
-  s.tab = c.pool_tab + (size_t)p * SSS_SET_TABLE;
+  s.tab = g_c.pool_tab + (size_t)p * SSS_SET_TABLE;
   s.mask = hd.mask, s.fill = hd.fill, s.used = hd.used, s.finger = 0;
   return s;
 }
-SSS_DEV void pool_close(const Ctx& c, uint32_t key, const SetImg<uint8_t>& s) {
-  int p = pool_index(c, key);
-  c.pool_hdr[p].mask = (uint16_t)s.mask;
-  c.pool_hdr[p].fill = (uint16_t)s.fill;
-  c.pool_hdr[p].used = (uint16_t)s.used;
+SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
+  int p = pool_index(key);
+  g_c.pool_hdr[p].mask = (uint16_t)s.mask;
+  g_c.pool_hdr[p].fill = (uint16_t)s.fill;
+  g_c.pool_hdr[p].used = (uint16_t)s.used;
 }
-SSS_DEV int pool_size(const Ctx& c, uint32_t key) { return key == POOL_NONE ? 0 : (int)c.pool_hdr[pool_index(c, key)].used; }
-SSS_DEV int pool_commit_from(const Ctx& c, uint32_t key) { return key == POOL_NONE ? 0 : (int)c.pool_hdr[pool_index(c, key)].commit_from; }
+SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
+SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
 
 // ------------------------------------------------------------------------------------------
 // tracker (lane 0)
 // ------------------------------------------------------------------------------------------
 
-SSS_DEV int trk_source_job_id(const Ctx& c) {  // TRK:101-105
+SSS_DEV int trk_source_job_id() {  // TRK:101-105
   uint32_t k = H.curr_source;
   if (k == POOL_NONE || k == POOL_COMMON) return -1;
   return key_job(k);
 }
 
-SSS_DEV void publish_scan_inputs(Ctx& c) {
+SSS_DEV void publish_scan_inputs() {
   g_sc.m_n_active = H.n_active;
-  g_sc.m_src_job = trk_source_job_id(c);
+  g_sc.m_src_job = trk_source_job_id();
 }
 
-SSS_DEV int trk_num_committable(Ctx& c) {  // TRK:107-113
+SSS_DEV int trk_num_committable() {  // TRK:107-113
   uint32_t k = H.curr_source;
   if (k == POOL_NONE) return 0;
-  int p = pool_index(c, k);
-  int n = (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
+  int p = pool_index(k);
+  int n = (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
   CHECK(n >= 0);
   return n;
 }
 
 // executor demand bookkeeping: sat bit of stage (j, s) <=> remaining - (moving_to + commit_to) <= 0 (ENV:566-582)
-SSS_DEV void update_sat(Ctx& c, int j, int s) {
-  SssStage st = (*stgp(c, j, s));
+SSS_DEV void update_sat(int j, int s) {
+  SssStage st = (*stgp(j, s));
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
-  uint64_t m = (*jobp(c, j)).sat_mask;
+  uint64_t m = (*jobp(j)).sat_mask;
   m = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
-  (*jobp(c, j)).sat_mask = m;
+  (*jobp(j)).sat_mask = m;
 }
 
-SSS_DEV void add_supply(Ctx& c, int job, int d) {
+SSS_DEV void add_supply(int job, int d) {
   if (job < 0) {
     H.supply_none += d;
     CHECK(H.supply_none >= 0);
   } else {
-    int v = (int)(*jobp(c, job)).supply + d;
+    int v = (int)(*jobp(job)).supply + d;
     CHECK(v >= 0);
-    (*jobp(c, job)).supply = (int16_t)v;
+    (*jobp(job)).supply = (int16_t)v;
   }
 }
 
-SSS_DEV void trk_add_commitment(Ctx& c, int n, uint32_t dst) {  // TRK:148-157, 226-238
+SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
   uint32_t src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE) return;
@@ -559,19 +566,19 @@ SSS_DEV void trk_add_commitment(Ctx& c, int n, uint32_t dst) {  // TRK:148-157, 
     hot.c_src[i] = src, hot.c_dst[i] = dst, hot.c_n[i] = (int16_t)n, hot.c_seq[i] = H.commit_seq++;
     H.n_commits = i + 1;
   }
-  int ps = pool_index(c, src);
-  c.pool_hdr[ps].commit_from = (int16_t)(c.pool_hdr[ps].commit_from + n);
-  CHECK((int)c.pool_hdr[ps].used >= (int)c.pool_hdr[ps].commit_from);
+  int ps = pool_index(src);
+  g_c.pool_hdr[ps].commit_from = (int16_t)(g_c.pool_hdr[ps].commit_from + n);
+  CHECK((int)g_c.pool_hdr[ps].used >= (int)g_c.pool_hdr[ps].commit_from);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
-    (*stgp(c, dj, ds)).commit_to = (int16_t)((*stgp(c, dj, ds)).commit_to + n);
-    update_sat(c, dj, ds);
+    (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to + n);
+    update_sat(dj, ds);
   }
-  if (dj != key_job(src)) add_supply(c, dj, n);
+  if (dj != key_job(src)) add_supply(dj, n);
 }
 
 // returns the source pool key (TRK:159-176, 240-251)
-SSS_DEV uint32_t trk_remove_commitment(Ctx& c, int e, uint32_t dst) {
+SSS_DEV uint32_t trk_remove_commitment(int e, uint32_t dst) {
   SssHot& hot = g_hot;
   uint32_t src = hot.ex_loc[e];
   CHECK(src != POOL_NONE);
@@ -581,26 +588,26 @@ SSS_DEV uint32_t trk_remove_commitment(Ctx& c, int e, uint32_t dst) {
   CHECK(i < H.n_commits);
   if (i >= H.n_commits) return src;
   hot.c_n[i] = (int16_t)(hot.c_n[i] - 1);
-  int ps = pool_index(c, src);
-  c.pool_hdr[ps].commit_from = (int16_t)(c.pool_hdr[ps].commit_from - 1);
-  CHECK(c.pool_hdr[ps].commit_from >= 0);
+  int ps = pool_index(src);
+  g_c.pool_hdr[ps].commit_from = (int16_t)(g_c.pool_hdr[ps].commit_from - 1);
+  CHECK(g_c.pool_hdr[ps].commit_from >= 0);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
-    (*stgp(c, dj, ds)).commit_to = (int16_t)((*stgp(c, dj, ds)).commit_to - 1);
-    CHECK((*stgp(c, dj, ds)).commit_to >= 0);
-    update_sat(c, dj, ds);
+    (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to - 1);
+    CHECK((*stgp(dj, ds)).commit_to >= 0);
+    update_sat(dj, ds);
   }
   if (hot.c_n[i] == 0) {  // dict.pop(dst): swap-remove, order lives in c_seq
     int last = H.n_commits - 1;
     hot.c_src[i] = hot.c_src[last], hot.c_dst[i] = hot.c_dst[last], hot.c_n[i] = hot.c_n[last], hot.c_seq[i] = hot.c_seq[last];
     H.n_commits = last;
   }
-  if (dj != key_job(src)) add_supply(c, dj, -1);
+  if (dj != key_job(src)) add_supply(dj, -1);
   return src;
 }
 
 // first-inserted live destination of `src`, POOL_NONE if none (TRK:178-183)
-SSS_DEV uint32_t trk_peek_commitment(const Ctx& c, uint32_t src) {
+SSS_DEV uint32_t trk_peek_commitment(uint32_t src) {
   const SssHot& hot = g_hot;
   uint32_t best = 0xFFFFFFFFu, dst = POOL_NONE;
   for (int i = 0; i < H.n_commits; i++)
@@ -608,53 +615,53 @@ SSS_DEV uint32_t trk_peek_commitment(const Ctx& c, uint32_t src) {
   return dst;
 }
 
-SSS_DEV void trk_move_executor_to_pool(Ctx& c, int e, uint32_t new_pool, bool send) {  // TRK:188-222
+SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  // TRK:188-222
   SssHot& hot = g_hot;
   uint32_t old = hot.ex_loc[e];
   if (old != POOL_NONE) {
-    SetImg<uint8_t> s = pool_open(c, old);
+    SetImg<uint8_t> s = pool_open(old);
     bool was = set_remove(s, (uint32_t)e);
     CHECK(was);
-    pool_close(c, old, s);
+    pool_close(old, s);
     hot.ex_loc[e] = POOL_NONE;
   }
   if (!send) {
     hot.ex_loc[e] = new_pool;
-    SetImg<uint8_t> s = pool_open(c, new_pool);
-    set_add(s, (uint32_t)e, lds_keys(c));
-    pool_close(c, new_pool, s);
+    SetImg<uint8_t> s = pool_open(new_pool);
+    set_add(s, (uint32_t)e, lds_keys());
+    pool_close(new_pool, s);
     return;
   }
   int nj = key_job(new_pool), ns = key_stage(new_pool);
   CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
-  (*stgp(c, nj, ns)).moving_to = (int16_t)((*stgp(c, nj, ns)).moving_to + 1);
-  update_sat(c, nj, ns);
+  (*stgp(nj, ns)).moving_to = (int16_t)((*stgp(nj, ns)).moving_to + 1);
+  update_sat(nj, ns);
   int oj = key_job(old);
   CHECK(oj != nj);
-  add_supply(c, nj, 1);
-  if (oj >= 0) add_supply(c, oj, -1);
+  add_supply(nj, 1);
+  if (oj >= 0) add_supply(oj, -1);
 }
 
 // ------------------------------------------------------------------------------------------
 // jobs / stages (lane 0)
 // ------------------------------------------------------------------------------------------
 
-SSS_DEV void job_attach_executor(Ctx& c, int j, int e) {  // JOB:81-84
+SSS_DEV void job_attach_executor(int j, int e) {  // JOB:81-84
   CHECK(g_hot.ex_task_stage[e] < 0);
-  (*jobp(c, j)).local_mask |= bit64(e);
+  (*jobp(j)).local_mask |= bit64(e);
   g_hot.ex_job[e] = (int16_t)j;
 }
-SSS_DEV void job_detach_executor(Ctx& c, int j, int e) {  // JOB:86-89
-  CHECK((*jobp(c, j)).local_mask & bit64(e));
-  (*jobp(c, j)).local_mask &= ~bit64(e);
+SSS_DEV void job_detach_executor(int j, int e) {  // JOB:86-89
+  CHECK((*jobp(j)).local_mask & bit64(e));
+  (*jobp(j)).local_mask &= ~bit64(e);
   g_hot.ex_job[e] = -1;
   g_hot.ex_task_stage[e] = -1;
 }
 SSS_DEV bool stage_completed(const SssStage& st) { return st.remaining == 0 && st.executing == 0; }  // STG:41-43
 
 // JOB:65-73,100-128: stage s of job j completed; returns whether the frontier gained stages
-SSS_DEV bool job_record_stage_completion(Ctx& c, int j, int s) {
-  SssJob& job = (*jobp(c, j));
+SSS_DEV bool job_record_stage_completion(int j, int s) {
+  SssJob& job = (*jobp(j));
   CHECK((job.active_mask & bit64(s)) && (job.frontier_mask & bit64(s)));
   uint64_t active = job.active_mask & ~bit64(s);
   job.active_mask = active;
@@ -662,13 +669,13 @@ SSS_DEV bool job_record_stage_completion(Ctx& c, int j, int s) {
   // completed stages == stages that are no longer active
   uint64_t all = job.n_stages >= 64 ? ~0ull : (bit64(job.n_stages) - 1);
   uint64_t completed = all & ~active;
-  uint64_t children = c.pk->stage_child_mask[job.gs_base + s];
+  uint64_t children = g_c.pk.stage_child_mask[job.gs_base + s];
   uint64_t newm = 0;
   uint64_t cand = children & active;
   while (cand) {
     int ch = ctz64(cand);
     cand &= cand - 1;
-    uint64_t parents = c.pk->stage_parent_mask[job.gs_base + ch];
+    uint64_t parents = g_c.pk.stage_parent_mask[job.gs_base + ch];
     if ((parents & ~completed) == 0) newm |= bit64(ch);
   }
   job.frontier_mask = frontier | newm;
@@ -687,22 +694,9 @@ SSS_DEV int exec_level_value(int i) {
   return (int)((packed >> (8 * i)) & 0xFF);
 }
 SSS_DEV void executor_interval(int n, int& li, int& ri) {
-  if (n <= 5) {
-    li = ri = 0;
-    return;
-  }
-  for (int i = 1; i < 8; i++) {
-    int v = exec_level_value(i);
-    if (n == v) {
-      li = ri = i;
-      return;
-    }
-    if (n < v) {
-      li = i - 1, ri = i;
-      return;
-    }
-  }
-  li = ri = 7;
+  // index of the first level >= n (levels above 80 only matter for n > 80)
+  ri = (n > 5) + (n > 10) + (n > 20) + (n > 40) + (n > 50) + (n > 60) + (n > 80);
+  li = (n <= 5 || n == exec_level_value(ri)) ? ri : ri - 1;
 }
 
 // TPCH:75-106, 216-235. Which list is sampled is a pure function of (stage, executor level, executor
@@ -710,12 +704,12 @@ SSS_DEV void executor_interval(int n, int& li, int& ri) {
 // exception-driven fallback chain (TPCH:88-106; a missing key or an empty list raises before any
 // draw) are resolved once per template on the host into `eff` (sss_host.h: sss_build_eff), so the
 // device does one descriptor load, the draw, and one value load.
-SSS_DEV double task_duration(Ctx& c, int j, int s, int e) {
-  const SssJob* job = jobp(c, j);
+SSS_DEV double task_duration(int j, int s, int e) {
+  const SssJob* job = jobp(j);
   int gs = job->gs_base + s;
   int n_local = popc64(job->local_mask);
-  CHECK(n_local > 0 && n_local <= c.E);
-  if (n_local <= 0 || n_local > c.E) return 0.0;
+  CHECK(n_local > 0 && n_local <= g_c.E);
+  if (n_local <= 0 || n_local > g_c.E) return 0.0;
   int li, ri;
   executor_interval(n_local, li, ri);
   if (li != ri) {
@@ -725,7 +719,7 @@ SSS_DEV double task_duration(Ctx& c, int j, int s, int e) {
   }
   int task_stage = g_hot.ex_task_stage[e];
   int mode = task_stage < 0 ? 0 : (task_stage == s ? 1 : 2);  // idle / same stage id (TPCH:95) / other
-  const int32_t* d = c.pk->eff + (((size_t)gs * 8 + li) * 3 + mode) * 2;
+  const int32_t* d = g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + mode) * 2;
   int off = d[0], lenw = d[1];
   int len = lenw & 0x3FFFFFFF;
   if (len == 0) {
@@ -733,8 +727,8 @@ SSS_DEV double task_duration(Ctx& c, int j, int s, int e) {
     return 0.0;
   }
   uint32_t i = rng_integers(H, (uint32_t)len);
-  double v = (double)c.pk->durations[off + (int)i];
-  if (lenw >> 30) v += c.P.warmup_delay;
+  double v = (double)g_c.pk.durations[off + (int)i];
+  if (lenw >> 30) v += g_c.P.warmup_delay;
   return v;
 }
 
@@ -744,13 +738,13 @@ SSS_DEV double task_duration(Ctx& c, int j, int s, int e) {
 
 // stages of job j that are active, not selected this round and ready (ENV:533-555); `pass`
 // filter (job == source or supply < E, ENV:526-531) applied by the caller
-SSS_DEV uint64_t ready_mask_of_job(const Ctx& c, const SssJob& job, bool first_only) {
+SSS_DEV uint64_t ready_mask_of_job(const SssJob& job, bool first_only) {
   uint64_t cand = job.active_mask & ~job.selected_mask & ~job.sat_mask;
   uint64_t m = 0;
   while (cand) {
     int s = ctz64(cand);
     cand &= cand - 1;
-    uint64_t parents = c.pk->stage_parent_mask[job.gs_base + s];
+    uint64_t parents = g_c.pk.stage_parent_mask[job.gs_base + s];
     if ((parents & ~job.sat_mask) == 0) {
       m |= bit64(s);
       if (first_only) break;
@@ -759,33 +753,33 @@ SSS_DEV uint64_t ready_mask_of_job(const Ctx& c, const SssJob& job, bool first_o
   return m;
 }
 
-SSS_DEV bool job_passes_filter(const Ctx& c, int j, int source_job_id) {
-  return j == source_job_id || (int)(*jobp(c, j)).supply < c.E;
+SSS_DEV bool job_passes_filter(int j, int source_job_id) {
+  return j == source_job_id || (int)(*jobp(j)).supply < g_c.E;
 }
 
 // ENV:821-845 -> (job, stage) or job = -1
-SSS_DEV_NOINLINE void find_backup_stage(Ctx& c, int e, int& out_j, int& out_s) {
+SSS_DEV_NOINLINE void find_backup_stage(int e, int& out_j, int& out_s) {
   out_j = -1, out_s = -1;
   int ejob = g_hot.ex_job[e];
   CHECK(ejob >= 0);
   if (ejob < 0) return;
   // `if not source_job_id` (ENV:521): job id 0 is falsy and gets replaced by the tracker's source
-  int src = ejob <= 0 ? trk_source_job_id(c) : ejob;
-  if (job_passes_filter(c, ejob, src)) {
-    uint64_t m = ready_mask_of_job(c, (*jobp(c, ejob)), true);
+  int src = ejob <= 0 ? trk_source_job_id() : ejob;
+  if (job_passes_filter(ejob, src)) {
+    uint64_t m = ready_mask_of_job((*jobp(ejob)), true);
     if (m) {
       out_j = ejob, out_s = ctz64(m);
       return;
     }
   }
   // other jobs; an empty list is falsy and means "all active jobs" (ENV:518-519)
-  bool ejob_active = (*jobp(c, ejob)).active_mask != 0;
+  bool ejob_active = (*jobp(ejob)).active_mask != 0;
   int n_others = H.n_active - (ejob_active ? 1 : 0);
   for (int a = 0; a < H.n_active; a++) {
-    int j = lds_active(c)[a];
+    int j = lds_active()[a];
     if (n_others > 0 && j == ejob) continue;
-    if (!job_passes_filter(c, j, src)) continue;
-    uint64_t m = ready_mask_of_job(c, (*jobp(c, j)), true);
+    if (!job_passes_filter(j, src)) continue;
+    uint64_t m = ready_mask_of_job((*jobp(j)), true);
     if (m) {
       out_j = j, out_s = ctz64(m);
       return;
@@ -797,63 +791,69 @@ SSS_DEV_NOINLINE void find_backup_stage(Ctx& c, int e, int& out_j, int& out_s) {
 // executor movement (lane 0)
 // ------------------------------------------------------------------------------------------
 
-SSS_DEV void push_event(Ctx& c, int e, double t, int kind, int j, int s) {  // EVQ:34-35
+SSS_DEV uint32_t ev_info(int kind, int j, int s) { return (uint32_t)kind | ((uint32_t)s << 8) | ((uint32_t)j << 16); }
+SSS_DEV int info_kind(uint32_t i) { return (int)(i & 0xFF); }
+SSS_DEV int info_stage(uint32_t i) { return (int)((i >> 8) & 0xFF); }
+SSS_DEV int info_job(uint32_t i) { return (int)(i >> 16); }
+
+SSS_DEV void push_event(int e, double t, int kind, int j, int s) {  // EVQ:34-35
   SssHot& hot = g_hot;
-  CHECK(hot.ev_kind[e] == EV_NONE);
-  hot.ev_t[e] = t, hot.ev_seq[e] = H.counter++, hot.ev_kind[e] = (uint8_t)kind;
-  hot.ev_job[e] = (int16_t)j, hot.ev_stage[e] = (int8_t)s;
+  CHECK((hot.ev[e].info & 0xFF) == EV_NONE);
+  SssEvSlot sl;
+  sl.t = t, sl.seq = H.counter++, sl.info = ev_info(kind, j, s);
+  hot.ev[e] = sl;
 }
 
-SSS_DEV void execute_next_task(Ctx& c, int e, int j, int s) {  // ENV:584-615
-  SssStage& st = (*stgp(c, j, s));
+SSS_DEV void execute_next_task(int e, int j, int s) {  // ENV:584-615
+  SssStage& st = (*stgp(j, s));
   CHECK(st.remaining > 0 && g_hot.ex_job[e] == j && !g_hot.ex_executing[e]);
   st.remaining = (int16_t)(st.remaining - 1);  // STG:53-58
   st.executing = (int16_t)(st.executing + 1);
-  if (st.remaining == 0) (*jobp(c, j)).sat_count = (int16_t)((*jobp(c, j)).sat_count + 1);
-  update_sat(c, j, s);
-  double d = task_duration(c, j, s, e);
+  if (st.remaining == 0) (*jobp(j)).sat_count = (int16_t)((*jobp(j)).sat_count + 1);
+  update_sat(j, s);
+  double d = task_duration(j, s, e);
   g_hot.ex_task_stage[e] = (int8_t)s;
   g_hot.ex_executing[e] = 1;
-  *durp(c, j, s) = (float)d;
-  push_event(c, e, H.wall_time + d, EV_TASK_FINISHED, j, s);
+  *durp(j, s) = (float)d;
+  push_event(e, H.wall_time + d, EV_TASK_FINISHED, j, s);
 }
 
-SSS_DEV void send_executor(Ctx& c, int e, int j, int s) {  // ENV:617-637
+SSS_DEV void send_executor(int e, int j, int s) {  // ENV:617-637
   CHECK(!g_hot.ex_executing[e] && g_hot.ex_job[e] != j);
-  trk_move_executor_to_pool(c, e, key_stage_pool(j, s), true);
+  trk_move_executor_to_pool(e, key_stage_pool(j, s), true);
   int oj = g_hot.ex_job[e];
-  if (oj >= 0) job_detach_executor(c, oj, e);
-  push_event(c, e, H.wall_time + c.P.moving_delay, EV_EXECUTOR_READY, j, s);
+  if (oj >= 0) job_detach_executor(oj, e);
+  push_event(e, H.wall_time + g_c.P.moving_delay, EV_EXECUTOR_READY, j, s);
 }
 
 // ENV:745-782 for an explicit executor list of one
-SSS_DEV void move_idle_executor(Ctx& c, uint32_t src, int e) {
+SSS_DEV void move_idle_executor(uint32_t src, int e) {
   if (src == POOL_NONE) src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
   int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)(*jobp(c, j)).sat_count == (int)(*jobp(c, j)).n_stages;  // JOB:53-55
+  bool is_sat = (int)(*jobp(j)).sat_count == (int)(*jobp(j)).n_stages;  // JOB:53-55
   if (s < 0 && !is_sat) return;
   uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
-  trk_move_executor_to_pool(c, e, dst, false);
-  if (dst == POOL_COMMON) job_detach_executor(c, j, e);
+  trk_move_executor_to_pool(e, dst, false);
+  if (dst == POOL_COMMON) job_detach_executor(j, e);
 }
 
 // set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
-SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(Ctx& c, uint32_t key) {
+SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
   SetImg<uint8_t> out;
   out.tab = g_sc.setB;
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
   out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0;
   if (key == POOL_NONE) return out;
-  SetImg<uint8_t> src = pool_open(c, key);
+  SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
   cp.tab = g_sc.setA;
   for (int i = 0; i < 8; i++) cp.tab[i] = 0;
   cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0;
   if (src.used != 0) {
-    if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys(c));
+    if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys());
     if (cp.mask == src.mask && src.fill == src.used) {
       for (uint32_t i = 0; i <= src.mask; i++) cp.tab[i] = src.tab[i];
     } else {
@@ -866,72 +866,72 @@ SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(Ctx& c, uint32_t key)
   }
   for (uint32_t i = 0; i <= cp.mask; i++) {
     uint32_t en = cp.tab[i];
-    if (en >= 2 && !g_hot.ex_executing[en - 2]) set_add(out, en - 2, lds_keys(c));
+    if (en >= 2 && !g_hot.ex_executing[en - 2]) set_add(out, en - 2, lds_keys());
   }
   return out;
 }
 
 // ENV:745-782 with executor_ids=None: all idle executors of `src`, in set order
-SSS_DEV_NOINLINE void move_idle_executors_all(Ctx& c, uint32_t src) {
+SSS_DEV_NOINLINE void move_idle_executors_all(uint32_t src) {
   if (src == POOL_NONE) src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
-  SetImg<uint8_t> idle = get_idle_source_executors(c, src);
+  SetImg<uint8_t> idle = get_idle_source_executors(src);
   CHECK(idle.used > 0);  // assert executor_ids, "[_move_idle_executors],2"
   if (H.err) return;
   int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)(*jobp(c, j)).sat_count == (int)(*jobp(c, j)).n_stages;
+  bool is_sat = (int)(*jobp(j)).sat_count == (int)(*jobp(j)).n_stages;
   if (s < 0 && !is_sat) return;
   uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
   for (uint32_t i = 0; i <= idle.mask; i++) {  // list(set): ascending slot order
     uint32_t en = idle.tab[i];
     if (en < 2) continue;
     int e = (int)en - 2;
-    trk_move_executor_to_pool(c, e, dst, false);
-    if (dst == POOL_COMMON) job_detach_executor(c, j, e);
+    trk_move_executor_to_pool(e, dst, false);
+    if (dst == POOL_COMMON) job_detach_executor(j, e);
   }
 }
 
-SSS_DEV_NOINLINE void move_executor_to_stage(Ctx& c, int e, int j, int s) {  // ENV:784-819
-  if ((*stgp(c, j, s)).remaining == 0) {
+SSS_DEV_NOINLINE void move_executor_to_stage(int e, int j, int s) {  // ENV:784-819
+  if ((*stgp(j, s)).remaining == 0) {
     // _try_backup_schedule
     int bj, bs;
-    find_backup_stage(c, e, bj, bs);
+    find_backup_stage(e, bj, bs);
     if (bj < 0) {
-      move_idle_executor(c, g_hot.ex_loc[e], e);
+      move_idle_executor(g_hot.ex_loc[e], e);
       return;
     }
     j = bj, s = bs;  // a schedulable stage has demand > 0, hence remaining > 0: no second detour
-    CHECK((*stgp(c, j, s)).remaining > 0);
+    CHECK((*stgp(j, s)).remaining > 0);
     if (H.err) return;
   }
   if (g_hot.ex_job[e] != j) {
-    send_executor(c, e, j, s);
+    send_executor(e, j, s);
     return;
   }
-  if (!((*jobp(c, j)).frontier_mask & bit64(s))) {
+  if (!((*jobp(j)).frontier_mask & bit64(s))) {
     g_hot.ex_task_stage[e] = -1;
-    trk_move_executor_to_pool(c, e, key_job_pool(j), false);
+    trk_move_executor_to_pool(e, key_job_pool(j), false);
     return;
   }
-  trk_move_executor_to_pool(c, e, key_stage_pool(j, s), false);
-  execute_next_task(c, e, j, s);
+  trk_move_executor_to_pool(e, key_stage_pool(j, s), false);
+  execute_next_task(e, j, s);
 }
 
-SSS_DEV void fulfill_commitment(Ctx& c, int e, uint32_t dst) {  // ENV:699-712
-  uint32_t src = trk_remove_commitment(c, e, dst);
+SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
+  uint32_t src = trk_remove_commitment(e, dst);
   if (H.err) return;
   if (dst == POOL_COMMON) {
-    move_idle_executor(c, src, e);
+    move_idle_executor(src, e);
     return;
   }
-  move_executor_to_stage(c, e, key_job(dst), key_stage(dst));
+  move_executor_to_stage(e, key_job(dst), key_stage(dst));
 }
 
-SSS_DEV_NOINLINE void fulfill_commitments_from_source(Ctx& c) {  // ENV:730-743
+SSS_DEV_NOINLINE void fulfill_commitments_from_source() {  // ENV:730-743
   SssHot& hot = g_hot;
   uint32_t src = H.curr_source;
-  SetImg<uint8_t> idle = get_idle_source_executors(c, src);
+  SetImg<uint8_t> idle = get_idle_source_executors(src);
   // snapshot of the source's commitments in insertion order (dict copy, TRK:133-134)
   uint32_t* dsts = g_sc.fc_dst;
   int16_t* nums = g_sc.fc_num;
@@ -951,16 +951,16 @@ SSS_DEV_NOINLINE void fulfill_commitments_from_source(Ctx& c) {  // ENV:730-743
     int num = nums[i];
     while (num && idle.used && !H.err) {
       int e = (int)set_pop(idle);
-      fulfill_commitment(c, e, dsts[i]);
+      fulfill_commitment(e, dsts[i]);
       num--;
     }
   }
   CHECK(idle.used == 0);
 }
 
-SSS_DEV void commit_remaining_executors(Ctx& c) {  // ENV:487-503
-  int n = trk_num_committable(c);
-  if (n > 0) trk_add_commitment(c, n, POOL_COMMON);
+SSS_DEV void commit_remaining_executors() {  // ENV:487-503
+  int n = trk_num_committable();
+  if (n > 0) trk_add_commitment(n, POOL_COMMON);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -968,91 +968,91 @@ SSS_DEV void commit_remaining_executors(Ctx& c) {  // ENV:487-503
 // ------------------------------------------------------------------------------------------
 
 // ---- LDS cache of the active jobs' records (lane 0 flavour) ----
-SSS_DEV void cache_acquire(Ctx& c, int j) {  // on arrival: HBM -> LDS, if a slot is free
+SSS_DEV void cache_acquire(int j) {  // on arrival: HBM -> LDS, if a slot is free
   if (g_sc.free_slots == 0) return;
   int k = ctz64(g_sc.free_slots);
   g_sc.free_slots &= g_sc.free_slots - 1;
-  lds_cjobs(c)[k] = c.jobs[j];
-  for (int s = 0; s < c.SP; s++) {
-    lds_cstages(c)[k * c.SP + s] = c.stages[j * c.SP + s];
-    lds_cdur(c)[k * c.SP + s] = c.durations[j * c.SP + s];
+  lds_cjobs()[k] = g_c.jobs[j];
+  for (int s = 0; s < g_c.SP; s++) {
+    lds_cstages()[k * g_c.SP + s] = g_c.stages[j * g_c.SP + s];
+    lds_cdur()[k * g_c.SP + s] = g_c.durations[j * g_c.SP + s];
   }
-  lds_slot_of(c)[j] = (uint8_t)k;
+  lds_slot_of()[j] = (uint8_t)k;
 }
-SSS_DEV void cache_release(Ctx& c, int j) {  // on completion: LDS -> HBM, slot becomes free
-  int k = lds_slot_of(c)[j];
+SSS_DEV void cache_release(int j) {  // on completion: LDS -> HBM, slot becomes free
+  int k = lds_slot_of()[j];
   if (k == SLOT_NONE) return;
-  c.jobs[j] = lds_cjobs(c)[k];
-  for (int s = 0; s < c.SP; s++) {
-    c.stages[j * c.SP + s] = lds_cstages(c)[k * c.SP + s];
-    c.durations[j * c.SP + s] = lds_cdur(c)[k * c.SP + s];
+  g_c.jobs[j] = lds_cjobs()[k];
+  for (int s = 0; s < g_c.SP; s++) {
+    g_c.stages[j * g_c.SP + s] = lds_cstages()[k * g_c.SP + s];
+    g_c.durations[j * g_c.SP + s] = lds_cdur()[k * g_c.SP + s];
   }
-  lds_slot_of(c)[j] = SLOT_NONE;
+  lds_slot_of()[j] = SLOT_NONE;
   g_sc.free_slots |= bit64(k);
 }
 
-SSS_DEV void handle_job_arrival(Ctx& c, int j) {  // ENV:428-438 (pools were created empty at reset)
-  lds_active(c)[H.n_active] = (uint16_t)j;
+SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created empty at reset)
+  lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
-  cache_acquire(c, j);
-  if (c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
+  cache_acquire(j);
+  if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
 
-SSS_DEV void handle_executor_arrival(Ctx& c, int e, int j, int s) {  // ENV:440-450
-  job_attach_executor(c, j, e);
-  SssStage& st = (*stgp(c, j, s));
+SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
+  job_attach_executor(j, e);
+  SssStage& st = (*stgp(j, s));
   st.moving_to = (int16_t)(st.moving_to - 1);  // TRK:185-187
   CHECK(st.moving_to >= 0);
-  update_sat(c, j, s);
-  trk_move_executor_to_pool(c, e, key_job_pool(j), false);
-  move_executor_to_stage(c, e, j, s);
+  update_sat(j, s);
+  trk_move_executor_to_pool(e, key_job_pool(j), false);
+  move_executor_to_stage(e, j, s);
 }
 
-SSS_DEV_NOINLINE void process_job_completion(Ctx& c, int j) {  // ENV:682-697
-  if (pool_size(c, key_job_pool(j)) > 0) move_idle_executors_all(c, key_job_pool(j));
-  CHECK(pool_size(c, key_job_pool(j)) == 0);
+SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
+  if (pool_size(key_job_pool(j)) > 0) move_idle_executors_all(key_job_pool(j));
+  CHECK(pool_size(key_job_pool(j)) == 0);
   int k;
   for (k = 0; k < H.n_active; k++)
-    if (lds_active(c)[k] == j) break;
+    if (lds_active()[k] == j) break;
   CHECK(k < H.n_active);
   if (k >= H.n_active) return;
-  for (int i = k; i + 1 < H.n_active; i++) lds_active(c)[i] = lds_active(c)[i + 1];
+  for (int i = k; i + 1 < H.n_active; i++) lds_active()[i] = lds_active()[i + 1];
   H.n_active--;
-  (*jobp(c, j)).completion_order = (int16_t)H.n_completed;
+  (*jobp(j)).completion_order = (int16_t)H.n_completed;
   H.n_completed++;
   g_sc.pending_free = j;  // its cache slot is written back once the handler has returned
-  c.t_completed[j] = H.wall_time;
-  double dur = H.wall_time - c.t_arrival[j];
+  g_c.t_completed[j] = H.wall_time;
+  double dur = H.wall_time - g_c.t_arrival[j];
   if (H.dur_n < SSS_DUR_RING) {
-    c.dur_ring[(H.dur_head + H.dur_n) % SSS_DUR_RING] = dur;
+    g_c.dur_ring[(H.dur_head + H.dur_n) % SSS_DUR_RING] = dur;
     H.dur_n++;
   } else {
-    c.dur_ring[H.dur_head] = dur;
+    g_c.dur_ring[H.dur_head] = dur;
     H.dur_head = (H.dur_head + 1) % SSS_DUR_RING;
   }
 }
 
-SSS_DEV_NOINLINE void handle_task_completion(Ctx& c, int e, int j, int s) {  // ENV:452-483
-  SssStage& st = (*stgp(c, j, s));
+SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-483
+  SssStage& st = (*stgp(j, s));
   CHECK(!stage_completed(st));
   st.executing = (int16_t)(st.executing - 1);  // STG:60-62
   g_hot.ex_executing[e] = 0;
   if (st.remaining > 0) {
-    execute_next_task(c, e, j, s);
+    execute_next_task(e, j, s);
     return;
   }
   bool frontier_changed = false;
-  if (stage_completed(st)) frontier_changed = job_record_stage_completion(c, j, s);  // ENV:676-680
-  if ((*jobp(c, j)).active_mask == 0) process_job_completion(c, j);                      // JOB:49-51
+  if (stage_completed(st)) frontier_changed = job_record_stage_completion(j, s);  // ENV:676-680
+  if ((*jobp(j)).active_mask == 0) process_job_completion(j);                      // JOB:49-51
   // _handle_released_executor ENV:639-660
   uint32_t sp = key_stage_pool(j, s);
-  uint32_t dst = trk_peek_commitment(c, sp);
+  uint32_t dst = trk_peek_commitment(sp);
   bool had_commitment = dst != POOL_NONE;
   if (had_commitment)
-    fulfill_commitment(c, e, dst);
+    fulfill_commitment(e, dst);
   else {
     g_hot.ex_task_stage[e] = -1;
-    if (frontier_changed) move_idle_executor(c, sp, e);
+    if (frontier_changed) move_idle_executor(sp, e);
   }
   // _update_executor_source ENV:662-674
   if (frontier_changed)
@@ -1073,18 +1073,16 @@ SSS_DEV_NOINLINE void handle_task_completion(Ctx& c, int e, int j, int s) {  // 
 // would need per event, and lets lane 0 run whole chains of events without any wave-level sync.
 #define POP_EMPTY (-1)
 #define POP_ARRIVAL (-2)
-SSS_DEV int pop_event(Ctx& c) {
+SSS_DEV int pop_event(double next_arrival_t) {
   const SssHot& hot = g_hot;
   double best = __builtin_inf();
   int ex = POP_EMPTY;
   bool tie = false;
-  // 8 independent LDS reads per round, then the compares: the scan is latency-, not issue-bound
-  for (int e0 = 0; e0 < c.E; e0 += 8) {
-    double t[8];
-_Pragma("unroll")
-    for (int k = 0; k < 8; k++) t[k] = hot.ev_t[e0 + k];  // slots >= E hold +inf (SSS_MAX_EXEC is a multiple of 8)
-_Pragma("unroll")
-    for (int k = 0; k < 8; k++) {
+  // 4 independent LDS reads per round, then the compares: the scan is latency-, not issue-bound
+  for (int e0 = 0; e0 < g_c.E; e0 += 4) {
+    double t[4];
+    _Pragma("unroll") for (int k = 0; k < 4; k++) t[k] = hot.ev[e0 + k].t;  // slots >= E hold +inf
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {
       if (t[k] < best) {
         best = t[k], ex = e0 + k, tie = false;
       } else if (t[k] == best && ex >= 0) {
@@ -1094,10 +1092,10 @@ _Pragma("unroll")
   }
   if (tie) {  // equal times: the earlier push wins (EVQ:35)
     uint32_t best_seq = 0xFFFFFFFFu;
-    for (int e = 0; e < c.E; e++)
-      if (hot.ev_t[e] == best && hot.ev_seq[e] < best_seq) best_seq = hot.ev_seq[e], ex = e;
+    for (int e = 0; e < g_c.E; e++)
+      if (hot.ev[e].t == best && hot.ev[e].seq < best_seq) best_seq = hot.ev[e].seq, ex = e;
   }
-  if (hot.h.next_arrival < hot.h.J && hot.h.next_arrival_t <= best) return POP_ARRIVAL;
+  if (next_arrival_t <= best && next_arrival_t < __builtin_inf()) return POP_ARRIVAL;  // +inf: no arrival left
   return ex;
 }
 
@@ -1110,12 +1108,16 @@ struct EvRegs {
   uint64_t n_events;
   uint32_t counter;
   int32_t events_this_step;
+  double next_arrival_t;  // +inf when every job has arrived
+  uint32_t curr_source;
 };
 SSS_DEV void regs_load(EvRegs& r) {
   const SssHdr& h = g_hot.h;
   r.rng_state_hi = h.rng_state_hi, r.rng_state_lo = h.rng_state_lo, r.rng_inc_hi = h.rng_inc_hi, r.rng_inc_lo = h.rng_inc_lo;
   r.rng_has32 = h.rng_has32, r.rng_u32 = h.rng_u32;
   r.wall_time = h.wall_time, r.n_events = h.n_events, r.counter = h.counter, r.events_this_step = g_sc.events_this_step;
+  r.next_arrival_t = h.next_arrival < h.J ? h.next_arrival_t : __builtin_inf();
+  r.curr_source = h.curr_source;
 }
 SSS_DEV void regs_store(const EvRegs& r) {
   SssHdr& h = g_hot.h;
@@ -1129,20 +1131,20 @@ SSS_DEV void regs_store(const EvRegs& r) {
 // stage". executing-- / executing++ cancel, executor.task.stage_id already equals the stage
 // (=> the `rest_wave` mode of task_duration), the event slot keeps its kind/job/stage.
 // Returns false, with nothing modified, when the stage has no remaining task (slow path).
-SSS_DEV bool fast_task_completion(Ctx& c, EvRegs& r, int ex, int j, int s) {
-  int slot = lds_slot_of(c)[j];
+template <bool CACHED>
+SSS_DEV int fast_body(EvRegs& r, int ex, int j, int s, int slot) {
   SssStage* sp;
   SssJob* jp;
   float* dp;
-  if (slot != SLOT_NONE) {
-    sp = lds_cstages(c) + slot * c.SP + s, jp = lds_cjobs(c) + slot, dp = lds_cdur(c) + slot * c.SP + s;
+  if (CACHED) {
+    sp = lds_cstages() + slot * g_c.SP + s, jp = lds_cjobs() + slot, dp = lds_cdur() + slot * g_c.SP + s;
   } else {
-    sp = c.stages + j * c.SP + s, jp = c.jobs + j, dp = c.durations + j * c.SP + s;
+    sp = g_c.stages + j * g_c.SP + s, jp = g_c.jobs + j, dp = g_c.durations + j * g_c.SP + s;
   }
   SssStage st = *sp;
   uint64_t local = jp->local_mask;
   int gs = jp->gs_base + s;
-  if (st.remaining <= 0) return false;
+  if (st.remaining <= 0) return 0;
   st.remaining = (int16_t)(st.remaining - 1);
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
   if (st.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);  // stage just became saturated (ENV:595-597)
@@ -1157,19 +1159,22 @@ SSS_DEV bool fast_task_completion(Ctx& c, EvRegs& r, int ex, int j, int s) {
     int rand_pt = 1 + (int)(rng_random(r) * (right - left));
     if (!((double)rand_pt <= (double)n_local - left)) li = ri;
   }
-  const int32_t* d = c.pk->eff + (((size_t)gs * 8 + li) * 3 + 1) * 2;
-  int off = d[0], lenw = d[1];
+  const int2 d = *(const int2*)(g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + 1) * 2);
+  int off = d.x, lenw = d.y;
   int len = lenw & 0x3FFFFFFF;
-  if (len == 0 || n_local <= 0) {
-    FAIL(n_local <= 0 ? SSS_ERR_INVARIANT : SSS_ERR_NO_DURATION);
-    return true;
-  }
+  if (len == 0 || n_local <= 0) return -1;
   uint32_t i = rng_integers(r, (uint32_t)len);
-  double dur = (double)c.pk->durations[off + (int)i];
+  double dur = (double)g_c.pk.durations[off + (int)i];
   *dp = (float)dur;
-  g_hot.ev_t[ex] = r.wall_time + dur;
-  g_hot.ev_seq[ex] = r.counter++;
-  return true;
+  g_hot.ev[ex].t = r.wall_time + dur;
+  g_hot.ev[ex].seq = r.counter++;
+  return 1;
+}
+
+// 1 = handled, 0 = not a fast-path event (nothing modified), -1 = failed
+SSS_DEV int fast_task_completion(EvRegs& r, int ex, int j, int s) {
+  int slot = lds_slot_of()[j];
+  return slot != SLOT_NONE ? fast_body<true>(r, ex, j, s, slot) : fast_body<false>(r, ex, j, s, slot);
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -1177,7 +1182,7 @@ SSS_DEV bool fast_task_completion(Ctx& c, EvRegs& r, int ex, int j, int s) {
 // Returns len(schedulable_stages); lane 0 stores the per-job masks.
 // n_active / source job come from the mailbox lane 0 filled before the preceding wave_sync
 // (publish_scan_inputs): lane 0 may already be past this function when another lane reads them.
-SSS_DEV int find_schedulable_all(Ctx& c) {
+SSS_DEV int find_schedulable_all() {
   int lane = wave_lane();
   int A = g_sc.m_n_active;
   int src_job = g_sc.m_src_job;
@@ -1187,10 +1192,10 @@ SSS_DEV int find_schedulable_all(Ctx& c) {
     int a = a0 + lane;
     uint32_t cnt = 0;
     if (a < A) {
-      int j = lds_active(c)[a];
-      SssJob* job = jobp(c, j);
+      int j = lds_active()[a];
+      SssJob* job = jobp(j);
       uint64_t m = 0;
-      if (j == src_job || (int)job->supply < c.E) m = ready_mask_of_job(c, *job, false);
+      if (j == src_job || (int)job->supply < g_c.E) m = ready_mask_of_job(*job, false);
       job->sched_mask = m;
       cnt = (uint32_t)popc64(m);
     }
@@ -1200,7 +1205,7 @@ SSS_DEV int find_schedulable_all(Ctx& c) {
 }
 
 // _observe (ENV:345-406) + utils.subgraph (utils.py:5-22) into the env's padded output rows
-SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, int env, double reward) {
+SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env, double reward) {
   int lane = wave_lane();
   uint64_t t_obs0 = wave_clock();
   const SssHdr& h = g_hot.h;
@@ -1213,7 +1218,7 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
   int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
   int src_idx = A;  // ENV:352
   uint64_t lt = bit64(lane) - 1;
-  uint16_t* nbase = lds_keys(c);  // first node row of each active job (scratch shared with the set code)
+  uint16_t* nbase = lds_keys();  // first node row of each active job (scratch shared with the set code)
   // pass 1 - lanes over jobs: dag_ptr (exclusive scan of active-stage counts), exec_supplies
   uint32_t run = 0;
   for (int a0 = 0; a0 < A; a0 += 64) {
@@ -1221,8 +1226,8 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
     uint32_t cnt = 0;
     int j = -1, supply = 0;
     if (a < A) {
-      j = lds_active(c)[a];
-      const SssJob* job = jobp(c, j);
+      j = lds_active()[a];
+      const SssJob* job = jobp(j);
       cnt = (uint32_t)popc64(job->active_mask);
       supply = job->supply;
     }
@@ -1240,21 +1245,21 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
   int base_n = (int)run;
   wave_sync();
   // pass 2 - lanes over (job, stage): node rows
-  int SPn = c.SP;
+  int SPn = g_c.SP;
   for (int i = lane; i < A * SPn; i += 64) {
     int a = i / SPn, st = i - a * SPn;
-    int j = lds_active(c)[a];
-    const SssJob* job = jobp(c, j);
+    int j = lds_active()[a];
+    const SssJob* job = jobp(j);
     uint64_t act = job->active_mask;
     if (st < (int)job->n_stages && (act & bit64(st))) {
       int row = (int)nbase[a] + popc64(act & (bit64(st) - 1));
-      nodes[row * 3 + 0] = (float)stgp(c, j, st)->remaining;
-      nodes[row * 3 + 1] = *durp(c, j, st);
+      nodes[row * 3 + 0] = (float)stgp(j, st)->remaining;
+      nodes[row * 3 + 1] = *durp(j, st);
       nodes[row * 3 + 2] = (job->sched_mask & bit64(st)) ? 1.0f : 0.0f;
     }
   }
   // pass 3 - lanes over (job, template edge): active subgraph, compacted in (job, edge) order
-  int ME = c.P.max_edges;
+  int ME = g_c.P.max_edges;
   int base_e = 0;
   for (int i0 = 0; i0 < A * ME; i0 += 64) {
     int i = i0 + lane;
@@ -1262,11 +1267,11 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
     int eu = 0, ev = 0;
     if (i < A * ME) {
       int a = i / ME, e = i - a * ME;
-      int j = lds_active(c)[a];
-      const SssJob* job = jobp(c, j);
+      int j = lds_active()[a];
+      const SssJob* job = jobp(j);
       if (e < (int)job->n_edges) {
         uint64_t act = job->active_mask;
-        int u = c.pk->edges[2 * (job->edge_off + e)], v = c.pk->edges[2 * (job->edge_off + e) + 1];
+        int u = g_c.pk.edges[2 * (job->edge_off + e)], v = g_c.pk.edges[2 * (job->edge_off + e) + 1];
         keep = (act & bit64(u)) && (act & bit64(v));
         eu = (int)nbase[a] + popc64(act & (bit64(u) - 1));
         ev = (int)nbase[a] + popc64(act & (bit64(v) - 1));
@@ -1286,8 +1291,8 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
     double* of = B.obs_f64 + (size_t)env * SSS_OBS_F64;
     int ncommit = 0;
     if (srck != POOL_NONE) {
-      int p = pool_index(c, srck);
-      ncommit = (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
+      int p = pool_index(srck);
+      ncommit = (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
     }
     oi[OBS_N_NODES] = base_n, oi[OBS_N_EDGES] = base_e, oi[OBS_N_JOBS] = A, oi[OBS_N_SCHED] = h.n_sched;
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
@@ -1306,24 +1311,24 @@ SSS_DEV void write_observation(Ctx& c, const SssLayout& L, const SssBuffers& B, 
 // ---- staging at launch boundaries (all lanes) ----
 // HBM -> LDS: the hot block verbatim, the active-job list, and the records + stage counters of the
 // first n_slots active jobs into the cache. LDS -> HBM at the end of the launch.
-SSS_DEV void env_begin(Ctx& c, const uint8_t* base) {
+SSS_DEV void env_begin(const uint8_t* base) {
   int lane = wave_lane();
   {
     const uint4* s = (const uint4*)base;
     uint4* d = (uint4*)&g_hot;
     for (int i = lane; i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
   }
-  for (int i = lane; i < c.J_cap; i += 64) lds_slot_of(c)[i] = SLOT_NONE;
+  for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   wave_sync();
   int A = g_hot.h.n_active;
-  int nK = A < c.P.n_slots ? A : c.P.n_slots;
+  int nK = A < g_c.P.n_slots ? A : g_c.P.n_slots;
   for (int i = lane; i < A; i += 64) {
-    int j = c.active_g[i];
-    lds_active(c)[i] = (uint16_t)j;
-    if (i < nK) lds_slot_of(c)[j] = (uint8_t)i;
+    int j = g_c.active_g[i];
+    lds_active()[i] = (uint16_t)j;
+    if (i < nK) lds_slot_of()[j] = (uint8_t)i;
   }
   if (lane == 0) {
-    uint64_t all = c.P.n_slots >= 64 ? ~0ull : (bit64(c.P.n_slots) - 1);
+    uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
     g_sc.free_slots = all & ~used;
     g_sc.pending_free = -1;
@@ -1331,39 +1336,39 @@ SSS_DEV void env_begin(Ctx& c, const uint8_t* base) {
   }
   wave_sync();
   // cached records: per slot 8 x u64 of job record, SP x u64 of stage counters, SP/2 x u64 of durations
-  int per = 8 + c.SP + c.SP / 2;
+  int per = 8 + g_c.SP + g_c.SP / 2;
   for (int i = lane; i < nK * per; i += 64) {
     int k = i / per, w = i - k * per;
-    int j = lds_active(c)[k];
+    int j = lds_active()[k];
     if (w < 8)
-      ((uint64_t*)(lds_cjobs(c) + k))[w] = ((const uint64_t*)(c.jobs + j))[w];
-    else if (w < 8 + c.SP)
-      ((uint64_t*)(lds_cstages(c) + k * c.SP))[w - 8] = ((const uint64_t*)(c.stages + j * c.SP))[w - 8];
+      ((uint64_t*)(lds_cjobs() + k))[w] = ((const uint64_t*)(g_c.jobs + j))[w];
+    else if (w < 8 + g_c.SP)
+      ((uint64_t*)(lds_cstages() + k * g_c.SP))[w - 8] = ((const uint64_t*)(g_c.stages + j * g_c.SP))[w - 8];
     else
-      ((uint64_t*)(lds_cdur(c) + k * c.SP))[w - 8 - c.SP] = ((const uint64_t*)(c.durations + j * c.SP))[w - 8 - c.SP];
+      ((uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP];
   }
   wave_sync();
 }
 
-SSS_DEV void env_end(Ctx& c, uint8_t* base) {
+SSS_DEV void env_end(uint8_t* base) {
   int lane = wave_lane();
   wave_sync();
   int A = g_hot.h.n_active;
-  int per = 8 + c.SP + c.SP / 2;
+  int per = 8 + g_c.SP + g_c.SP / 2;
   // every cached job is active (slots are released at completion); lanes over (active job, word)
   for (int i = lane; i < A * per; i += 64) {
     int a = i / per, w = i - a * per;
-    int j = lds_active(c)[a];
-    int k = lds_slot_of(c)[j];
+    int j = lds_active()[a];
+    int k = lds_slot_of()[j];
     if (k == SLOT_NONE) continue;
     if (w < 8)
-      ((uint64_t*)(c.jobs + j))[w] = ((const uint64_t*)(lds_cjobs(c) + k))[w];
-    else if (w < 8 + c.SP)
-      ((uint64_t*)(c.stages + j * c.SP))[w - 8] = ((const uint64_t*)(lds_cstages(c) + k * c.SP))[w - 8];
+      ((uint64_t*)(g_c.jobs + j))[w] = ((const uint64_t*)(lds_cjobs() + k))[w];
+    else if (w < 8 + g_c.SP)
+      ((uint64_t*)(g_c.stages + j * g_c.SP))[w - 8] = ((const uint64_t*)(lds_cstages() + k * g_c.SP))[w - 8];
     else
-      ((uint64_t*)(c.durations + j * c.SP))[w - 8 - c.SP] = ((const uint64_t*)(lds_cdur(c) + k * c.SP))[w - 8 - c.SP];
+      ((uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP];
   }
-  for (int i = lane; i < A; i += 64) c.active_g[i] = lds_active(c)[i];
+  for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
   {
     const uint4* s = (const uint4*)&g_hot;
     uint4* d = (uint4*)base;
@@ -1376,29 +1381,29 @@ SSS_DEV void env_end(Ctx& c, uint8_t* base) {
 // ------------------------------------------------------------------------------------------
 
 // ENV:275-315. Returns false if the action was rejected (state untouched).
-SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
+SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
   // action_space.contains: stage_idx in [-1, n_nodes), num_exec in [1, E] (ENV:85-94, 404)
-  if (stage_idx < -1 || stage_idx >= H.obs_n_nodes || num_exec < 1 || num_exec > c.E) {
+  if (stage_idx < -1 || stage_idx >= H.obs_n_nodes || num_exec < 1 || num_exec > g_c.E) {
     H.err = SSS_ERR_ACTION_SPACE;
     return false;
   }
   if (stage_idx == -1) {
-    commit_remaining_executors(c);
+    commit_remaining_executors();
     return true;
   }
   if (stage_idx >= H.obs_n_sched) {  // KeyError on stage_selection_map (ENV:284)
     H.err = SSS_ERR_STAGE_IDX;
     return false;
   }
-  if (num_exec > trk_num_committable(c)) {
+  if (num_exec > trk_num_committable()) {
     H.err = SSS_ERR_TOO_MANY;
     return false;
   }
   // stage_selection_map[stage_idx]: k-th set bit over the per-job masks in active order
   int k = stage_idx, j = -1, s = -1;
   for (int a = 0; a < H.n_active; a++) {
-    int jj = lds_active(c)[a];
-    uint64_t m = (*jobp(c, jj)).sched_mask;
+    int jj = lds_active()[a];
+    uint64_t m = (*jobp(jj)).sched_mask;
     int n = popc64(m);
     if (k < n) {
       for (int i = 0; i < k; i++) m &= m - 1;
@@ -1409,17 +1414,17 @@ SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
   }
   CHECK(j >= 0);
   if (j < 0) return false;
-  SssStage st = (*stgp(c, j, s));
+  SssStage st = (*stgp(j, s));
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);  // ENV:557-578
   int n = num_exec < demand ? num_exec : demand;
   CHECK(n > 0);
-  trk_add_commitment(c, n, key_stage_pool(j, s));
-  SssJob& job = (*jobp(c, j));
+  trk_add_commitment(n, key_stage_pool(j, s));
+  SssJob& job = (*jobp(j));
   job.selected_mask |= bit64(s);  // ENV:304
   // ENV:307-315: only this job's slice of schedulable_stages is recomputed
   int old_n = popc64(job.sched_mask);
   uint64_t m = 0;
-  if (job_passes_filter(c, j, trk_source_job_id(c))) m = ready_mask_of_job(c, job, false);
+  if (job_passes_filter(j, trk_source_job_id())) m = ready_mask_of_job(job, false);
   job.sched_mask = m;
   H.n_sched += popc64(m) - old_n;
   return true;
@@ -1428,22 +1433,22 @@ SSS_DEV_NOINLINE bool take_action(Ctx& c, int stage_idx, int num_exec) {
 // ENV:847-874. The float sum runs in CPython set(list + list) iteration order: lane 0 builds the
 // set image (jobtime_build_set), then all lanes evaluate one table slot each and the terms are
 // added in slot order (jobtime_sum) - the additions stay sequential, the HBM reads do not.
-SSS_DEV_NOINLINE void jobtime_build_set(Ctx& c) {
+SSS_DEV_NOINLINE void jobtime_build_set() {
   SetImg<uint16_t> all;
-  all.tab = lds_jobset(c);
+  all.tab = lds_jobset();
   for (int i = 0; i < 8; i++) all.tab[i] = 0;
   all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0;
-  for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active(c)[k], lds_keys(c));
-  for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active(c)[k], lds_keys(c));
+  for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active()[k], lds_keys());
+  for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active()[k], lds_keys());
   g_sc.jobset_mask = (int32_t)all.mask;
 }
 
-SSS_DEV double jobtime_sum(Ctx& c) {
+SSS_DEV double jobtime_sum() {
   int lane = wave_lane();
   double wall_old = g_sc.wall_old, wall = g_hot.h.wall_time;
   int mask = g_sc.jobset_mask;
-  double beta = c.P.beta;
-  const uint16_t* tab = lds_jobset(c);
+  double beta = g_c.P.beta;
+  const uint16_t* tab = lds_jobset();
   double job_time = 0.0;
   for (int b = 0; b <= mask; b += 64) {
     uint32_t en = tab[b + lane];  // tables are >= 8 slots; slots beyond the mask are never live
@@ -1451,7 +1456,7 @@ SSS_DEV double jobtime_sum(Ctx& c) {
     double term = 0.0;
     if (live) {
       int j = (int)en - 2;
-      double ta = c.t_arrival[j], tc = c.t_completed[j];
+      double ta = g_c.t_arrival[j], tc = g_c.t_completed[j];
       double start = ta > wall_old ? ta : wall_old;
       double end = tc < wall ? tc : wall;
       if (beta == 0.0)
@@ -1475,7 +1480,7 @@ SSS_DEV double jobtime_sum(Ctx& c) {
 // ------------------------------------------------------------------------------------------
 
 // _resume_simulation (ENV:320-343). Entered and left with LDS in sync.
-SSS_DEV void resume_simulation(Ctx& c) {
+SSS_DEV void resume_simulation() {
   int lane = wave_lane();
   for (;;) {
     if (lane == 0) {
@@ -1486,7 +1491,7 @@ SSS_DEV void resume_simulation(Ctx& c) {
       regs_load(r);
       uint64_t n_fast = 0, t_slow = 0;
       for (;;) {
-        int ex = pop_event(c);
+        int ex = pop_event(r.next_arrival_t);
         if (ex == POP_EMPTY) {
           regs_store(r);
           g_sc.f_done = 1;
@@ -1494,40 +1499,45 @@ SSS_DEV void resume_simulation(Ctx& c) {
         }
         r.n_events++;
         r.events_this_step++;
-        bool fast = false;
-        if (ex >= 0 && g_hot.ev_kind[ex] == EV_TASK_FINISHED) {
-          r.wall_time = g_hot.ev_t[ex];
-          fast = fast_task_completion(c, r, ex, g_hot.ev_job[ex], g_hot.ev_stage[ex]);
+        int fast = 0;
+        if (ex >= 0) {
+          SssEvSlot sl = g_hot.ev[ex];
+          if (info_kind(sl.info) == EV_TASK_FINISHED) {
+            r.wall_time = sl.t;
+            fast = fast_task_completion(r, ex, info_job(sl.info), info_stage(sl.info));
+          }
         }
-        if (fast) {
+        if (fast > 0) {
           // the source stays what it was - None right after a scheduling round - so nothing is
           // committable and the loop continues on registers (ENV:331-332)
           n_fast++;
-          if (H.curr_source == POOL_NONE && !H.err) continue;
+          if (r.curr_source == POOL_NONE) continue;
           regs_store(r);
         } else {
           // everything else goes through the out-of-line handlers on the LDS copy of the state
           regs_store(r);
+          if (fast < 0) FAIL(SSS_ERR_NO_DURATION);
           uint64_t ts0 = wave_clock();
-          if (ex == POP_ARRIVAL) {
+          if (fast < 0) {
+          } else if (ex == POP_ARRIVAL) {
             int job = H.next_arrival;
             H.wall_time = H.next_arrival_t;
             H.next_arrival++;
-            H.next_arrival_t = H.next_arrival < H.J ? c.t_arrival[H.next_arrival] : __builtin_inf();
-            handle_job_arrival(c, job);
+            H.next_arrival_t = H.next_arrival < H.J ? g_c.t_arrival[H.next_arrival] : __builtin_inf();
+            handle_job_arrival(job);
           } else {
             SssHot& hot = g_hot;
-            H.wall_time = hot.ev_t[ex];
-            int kind = hot.ev_kind[ex], job = hot.ev_job[ex], s = hot.ev_stage[ex];
-            hot.ev_kind[ex] = EV_NONE;
-            hot.ev_t[ex] = __builtin_inf();
-            if (kind == EV_TASK_FINISHED)
-              handle_task_completion(c, ex, job, s);
+            SssEvSlot sl = hot.ev[ex];
+            H.wall_time = sl.t;
+            hot.ev[ex].t = __builtin_inf();
+            hot.ev[ex].info = EV_NONE;
+            if (info_kind(sl.info) == EV_TASK_FINISHED)
+              handle_task_completion(ex, info_job(sl.info), info_stage(sl.info));
             else
-              handle_executor_arrival(c, ex, job, s);
+              handle_executor_arrival(ex, info_job(sl.info), info_stage(sl.info));
           }
           if (g_sc.pending_free >= 0) {
-            cache_release(c, g_sc.pending_free);
+            cache_release(g_sc.pending_free);
             g_sc.pending_free = -1;
           }
           t_slow += wave_clock() - ts0;
@@ -1537,9 +1547,9 @@ SSS_DEV void resume_simulation(Ctx& c) {
           g_sc.f_done = 1;
           break;
         }
-        if (trk_num_committable(c) > 0) {
+        if (trk_num_committable() > 0) {
           g_sc.f_scan = 1;
-          publish_scan_inputs(c);
+          publish_scan_inputs();
           break;
         }
         regs_load(r);
@@ -1551,21 +1561,21 @@ SSS_DEV void resume_simulation(Ctx& c) {
     if (g_sc.f_done) {
       // queue exhausted (or failed): schedulable_stages = [] (ENV:324,343)
       if (lane == 0) {
-        for (int a = 0; a < H.n_active; a++) (*jobp(c, lds_active(c)[a])).sched_mask = 0;
+        for (int a = 0; a < H.n_active; a++) (*jobp(lds_active()[a])).sched_mask = 0;
         H.n_sched = 0;
       }
       wave_sync();
       return;
     }
     // f_scan: _find_schedulable_stages() with the whole wave
-    int n = find_schedulable_all(c);
+    int n = find_schedulable_all();
     if (n > 0) {
       if (lane == 0) H.n_sched = n;
       wave_sync();
       return;
     }
     if (lane == 0) {
-      move_idle_executors_all(c, POOL_NONE);  // ENV:340
+      move_idle_executors_all(POOL_NONE);  // ENV:340
       H.curr_source = POOL_NONE;               // ENV:341
     }
     wave_sync();
@@ -1573,14 +1583,14 @@ SSS_DEV void resume_simulation(Ctx& c) {
 }
 
 // episode initialisation: ENV:127-186 + TPCH:54-73,176-206 + TRK:32-71
-SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_limit) {
+SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   int lane = wave_lane();
   SssHot& hot = g_hot;
   // nothing is cached while the records are (re)built in HBM
-  for (int i = lane; i < c.J_cap; i += 64) lds_slot_of(c)[i] = SLOT_NONE;
+  for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   wave_sync();
   if (lane == 0) {
-    g_sc.free_slots = c.P.n_slots >= 64 ? ~0ull : (bit64(c.P.n_slots) - 1);
+    g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     g_sc.pending_free = -1;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
@@ -1599,7 +1609,7 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
     H.seed = seed, H.time_limit = time_limit;
     H.curr_source = POOL_COMMON;
     g_sc.events_this_step = 0;
-    if (!(time_limit < __builtin_inf()) && c.P.cap_cfg <= 0) {
+    if (!(time_limit < __builtin_inf()) && g_c.P.cap_cfg <= 0) {
       H.err = SSS_ERR_NO_LIMIT;  // ENV:137-138
       H.need_reset = 1;
     } else {
@@ -1607,26 +1617,27 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
       // job_sequence TPCH:54-73
       double t = 0.0;
       int J = 0;
-      while (t < time_limit && (c.P.cap_cfg <= 0 || J < c.P.cap_cfg)) {
-        if (J >= c.J_cap) {
+      while (t < time_limit && (g_c.P.cap_cfg <= 0 || J < g_c.P.cap_cfg)) {
+        if (J >= g_c.J_cap) {
           H.err = SSS_ERR_CAPACITY;
           H.need_reset = 1;
           break;
         }
         int q = (int)rng_integers(H, 22);     // TPCH:177
         int size = (int)rng_integers(H, 7);   // TPCH:178
-        (*jobp(c, J)).gs_base = q * 7 + size;  // template id for now; resolved to pack rows below
-        c.t_arrival[J] = t;
+        (*jobp(J)).gs_base = q * 7 + size;  // template id for now; resolved to pack rows below
+        g_c.t_arrival[J] = t;
         J++;
-        t += c.P.mean_interarrival * rng_standard_exponential(c, H);  // TPCH:70
+        t += g_c.P.mean_interarrival * rng_standard_exponential(H);  // TPCH:70
       }
       H.J = J;
     }
   }
   // executors + event slots + commitments
   if (lane < SSS_MAX_EXEC) {
-    hot.ev_t[lane] = __builtin_inf(), hot.ev_seq[lane] = 0, hot.ex_loc[lane] = lane < c.E ? POOL_COMMON : POOL_NONE;
-    hot.ev_job[lane] = -1, hot.ex_job[lane] = -1, hot.ev_stage[lane] = -1, hot.ev_kind[lane] = EV_NONE;
+    hot.ev[lane].t = __builtin_inf(), hot.ev[lane].seq = 0, hot.ev[lane].info = EV_NONE;
+    hot.ex_loc[lane] = lane < g_c.E ? POOL_COMMON : POOL_NONE;
+    hot.ex_job[lane] = -1;
     hot.ex_task_stage[lane] = -1, hot.ex_executing[lane] = 0;
     hot.c_src[lane] = POOL_NONE, hot.c_dst[lane] = POOL_NONE, hot.c_seq[lane] = 0, hot.c_n[lane] = 0;
   }
@@ -1634,66 +1645,66 @@ SSS_DEV void do_reset(Ctx& c, const SssLayout& L, uint64_t seed, double time_lim
   int J = hot.h.J;
   // job records: one lane per job
   for (int j = lane; j < J; j += 64) {
-    SssJob& job = (*jobp(c, j));
+    SssJob& job = (*jobp(j));
     int tmpl = job.gs_base;
-    int gs = c.pk->tmpl_stage_off[tmpl];
-    int ns = c.pk->tmpl_stage_off[tmpl + 1] - gs;
+    int gs = g_c.pk.tmpl_stage_off[tmpl];
+    int ns = g_c.pk.tmpl_stage_off[tmpl + 1] - gs;
     uint64_t frontier = 0;
     for (int s = 0; s < ns; s++)
-      if (c.pk->stage_parent_mask[gs + s] == 0) frontier |= bit64(s);  // JOB:93-111
+      if (g_c.pk.stage_parent_mask[gs + s] == 0) frontier |= bit64(s);  // JOB:93-111
     job.active_mask = ns >= 64 ? ~0ull : (bit64(ns) - 1);
     job.frontier_mask = frontier;
     job.selected_mask = 0, job.sched_mask = 0, job.sat_mask = 0, job.local_mask = 0;
     job.supply = 0, job.sat_count = 0, job.completion_order = -1;
     job.n_stages = (uint8_t)ns;
-    job.n_edges = (uint8_t)(c.pk->tmpl_edge_off[tmpl + 1] - c.pk->tmpl_edge_off[tmpl]);
-    job.edge_off = c.pk->tmpl_edge_off[tmpl];
+    job.n_edges = (uint8_t)(g_c.pk.tmpl_edge_off[tmpl + 1] - g_c.pk.tmpl_edge_off[tmpl]);
+    job.edge_off = g_c.pk.tmpl_edge_off[tmpl];
     job.gs_base = gs;
-    c.t_completed[j] = __builtin_inf();
+    g_c.t_completed[j] = __builtin_inf();
   }
   wave_sync();
   // stage records: lanes over (job, stage)
-  for (int i = lane; i < J * c.SP; i += 64) {
-    int j = i / c.SP, s = i - j * c.SP;
-    const SssJob& job = (*jobp(c, j));
+  for (int i = lane; i < J * g_c.SP; i += 64) {
+    int j = i / g_c.SP, s = i - j * g_c.SP;
+    const SssJob& job = (*jobp(j));
     SssStage st = {0, 0, 0, 0};
     float d = 0.0f;
     if (s < (int)job.n_stages) {
-      st.remaining = (int16_t)c.pk->stage_num_tasks[job.gs_base + s];
-      d = (float)c.pk->stage_rough[job.gs_base + s];
+      st.remaining = (int16_t)g_c.pk.stage_num_tasks[job.gs_base + s];
+      d = (float)g_c.pk.stage_rough[job.gs_base + s];
     }
-    c.stages[i] = st;
-    c.durations[i] = d;
+    g_c.stages[i] = st;
+    g_c.durations[i] = d;
   }
   // pools: every job / stage pool starts as an empty 8-slot set (TRK:73-96)
-  int n_pools = 1 + c.J_cap + J * c.SP;
+  int n_pools = 1 + g_c.J_cap + J * g_c.SP;
   for (int p = lane; p < n_pools; p += 64) {
     SssPoolHdr hd = {7, 0, 0, 0};
-    c.pool_hdr[p] = hd;
-    *(uint64_t*)(c.pool_tab + (size_t)p * SSS_SET_TABLE) = 0ull;
+    g_c.pool_hdr[p] = hd;
+    *(uint64_t*)(g_c.pool_tab + (size_t)p * SSS_SET_TABLE) = 0ull;
   }
   wave_sync();
   if (lane == 0 && !H.err) {
     // common pool = set(range(E)) (TRK:41)
-    SetImg<uint8_t> s = pool_open(c, POOL_COMMON);
-    for (int e = 0; e < c.E; e++) set_add(s, (uint32_t)e, lds_keys(c));
-    pool_close(c, POOL_COMMON, s);
+    SetImg<uint8_t> s = pool_open(POOL_COMMON);
+    for (int e = 0; e < g_c.E; e++) set_add(s, (uint32_t)e, lds_keys());
+    pool_close(POOL_COMMON, s);
     // _load_initial_jobs ENV:260-273
-    while (H.next_arrival < H.J && c.t_arrival[H.next_arrival] <= 0.0) {
-      handle_job_arrival(c, H.next_arrival);
+    while (H.next_arrival < H.J && g_c.t_arrival[H.next_arrival] <= 0.0) {
+      handle_job_arrival(H.next_arrival);
       H.next_arrival++;
     }
-    H.next_arrival_t = H.next_arrival < H.J ? c.t_arrival[H.next_arrival] : __builtin_inf();
+    H.next_arrival_t = H.next_arrival < H.J ? g_c.t_arrival[H.next_arrival] : __builtin_inf();
   }
-  if (lane == 0) publish_scan_inputs(c);
+  if (lane == 0) publish_scan_inputs();
   wave_sync();
-  int n = find_schedulable_all(c);
+  int n = find_schedulable_all();
   if (lane == 0) H.n_sched = n;
   wave_sync();
 }
 
 // ENV:188-221. `reward` is valid on lane 0 (and uniform).
-SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
+SSS_DEV double do_step(int stage_idx, int num_exec) {
   int lane = wave_lane();
   uint64_t t0 = wave_clock();
   if (lane == 0) {
@@ -1704,19 +1715,19 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
       H.err = SSS_ERR_NEED_RESET;
     } else {
       H.err = 0;
-      bool ok = take_action(c, stage_idx, num_exec);
+      bool ok = take_action(stage_idx, num_exec);
       if (ok && !H.err) {
         H.n_steps++;
         H.ep_steps++;
-        if (!(trk_num_committable(c) > 0 && H.n_sched > 0)) {
+        if (!(trk_num_committable() > 0 && H.n_sched > 0)) {
           // commitment round is over (ENV:195-203)
-          commit_remaining_executors(c);
-          fulfill_commitments_from_source(c);
+          commit_remaining_executors();
+          fulfill_commitments_from_source();
           H.curr_source = POOL_NONE;
-          for (int a = 0; a < H.n_active; a++) (*jobp(c, lds_active(c)[a])).selected_mask = 0;
+          for (int a = 0; a < H.n_active; a++) (*jobp(lds_active()[a])).selected_mask = 0;
           g_sc.wall_old = H.wall_time;
           g_sc.n_old_active = H.n_active;
-          for (int a = 0; a < H.n_active; a++) lds_old_active(c)[a] = lds_active(c)[a];
+          for (int a = 0; a < H.n_active; a++) lds_old_active()[a] = lds_active()[a];
           g_sc.f_round_continues = 0;
         }
       }
@@ -1727,25 +1738,25 @@ SSS_DEV double do_step(Ctx& c, int stage_idx, int num_exec) {
   uint64_t t1 = wave_clock();
   if (lane == 0) H.prof[1] += t1 - t0;
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
-  resume_simulation(c);
+  resume_simulation();
   uint64_t t2 = wave_clock();
   // reward = -job_time (ENV:208-209); `duration == 0.0` short-circuits to -0.0 (ENV:850-852)
   if (lane == 0) {
     g_sc.f_need_jobtime = 0;
     if (!H.err && H.wall_time - g_sc.wall_old != 0.0) {
-      jobtime_build_set(c);
+      jobtime_build_set();
       g_sc.f_need_jobtime = 1;
     }
   }
   wave_sync();
   double job_time = 0.0;
-  if (g_sc.f_need_jobtime) job_time = jobtime_sum(c);
+  if (g_sc.f_need_jobtime) job_time = jobtime_sum();
   double reward = 0.0;
   if (lane == 0) {
     if (!H.err) {
       reward = -job_time;
       H.terminated = H.n_completed == H.J;  // ENV:227-229
-      if (!H.terminated && !(trk_num_committable(c) > 0 && H.n_sched > 0)) H.err = SSS_ERR_STALLED;  // ENV:212-215
+      if (!H.terminated && !(trk_num_committable() > 0 && H.n_sched > 0)) H.err = SSS_ERR_STALLED;  // ENV:212-215
       H.ep_return += reward;
       if (H.terminated) {
         H.episodes++;
@@ -1768,7 +1779,7 @@ struct SssKernelArgs {
   SssLayout L;
   SssBuffers B;
   SssParams P;
-  const SssPackDev* pk;
+  SssPackDev pk;
 };
 
 // reset envs whose mask byte is non-zero (mask == nullptr: all)
@@ -1776,12 +1787,11 @@ SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const d
   int env = wave_env();
   if (mask && !mask[env]) return;
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  Ctx c;
-  ctx_init(c, base, a.L, a.P, a.pk);
-  env_begin(c, base);
-  do_reset(c, a.L, seeds[env], time_limits ? time_limits[env] : __builtin_inf());
-  write_observation(c, a.L, a.B, env, 0.0);
-  env_end(c, base);
+  ctx_init(base, a.L, a.P, a.pk);
+  env_begin(base);
+  do_reset(a.L, seeds[env], time_limits ? time_limits[env] : __builtin_inf());
+  write_observation(a.L, a.B, env, 0.0);
+  env_end(base);
 }
 
 // one step() per env; with auto_reset != 0 an env that is terminated at entry starts its next
@@ -1789,19 +1799,18 @@ SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const d
 SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  Ctx c;
-  ctx_init(c, base, a.L, a.P, a.pk);
-  env_begin(c, base);
+  ctx_init(base, a.L, a.P, a.pk);
+  env_begin(base);
   double reward = 0.0;
   // the ballot doubles as the barrier between "all lanes read the header" and lane 0 rewriting it
   bool start_next_episode = wave_ballot(auto_reset && g_hot.h.terminated && !g_hot.h.err) != 0;
   if (start_next_episode) {
-    do_reset(c, a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
+    do_reset(a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
   } else {
-    reward = do_step(c, stage_idx[env], num_exec[env]);
+    reward = do_step(stage_idx[env], num_exec[env]);
   }
-  write_observation(c, a.L, a.B, env, reward);
-  env_end(c, base);
+  write_observation(a.L, a.B, env, reward);
+  env_end(base);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1811,24 +1820,24 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
 // but straight from the env state, so that no observation round trip is needed.
 // ------------------------------------------------------------------------------------------
 
-SSS_DEV int obs_num_committable(const Ctx& c) {
+SSS_DEV int obs_num_committable() {
   uint32_t srck = g_hot.h.curr_source;
   if (srck == POOL_NONE) return 0;
-  int p = pool_index(c, srck);
-  return (int)c.pool_hdr[p].used - (int)c.pool_hdr[p].commit_from;
+  int p = pool_index(srck);
+  return (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
 }
 
 // RoundRobinScheduler.schedule (reference schedulers/heuristics/round_robin.py:14-49 with
 // find_stage / preprocess_obs of heuristics/utils.py:5-37). All lanes; results are uniform.
-SSS_DEV void policy_fair(Ctx& c, bool dynamic_partition, int& stage_idx, int& num_exec) {
+SSS_DEV void policy_fair(bool dynamic_partition, int& stage_idx, int& num_exec) {
   int lane = wave_lane();
   // shared state is read up front; at least one collective follows before anything returns
   int A = g_hot.h.n_active;
   uint32_t srck = g_hot.h.curr_source;
-  int ncommit = obs_num_committable(c);
+  int ncommit = obs_num_committable();
   int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
   int denom = A > 1 ? A : 1;
-  int cap = dynamic_partition ? (c.E + denom - 1) / denom : c.E;  // int(ceil(E / max(1, A)))
+  int cap = dynamic_partition ? (g_c.E + denom - 1) / denom : g_c.E;  // int(ceil(E / max(1, A)))
   int src_rank = -1, first_rank = -1, first_sup = 0;
   uint32_t base = 0;
   int n_chunks = (A + 63) / 64;
@@ -1836,11 +1845,11 @@ SSS_DEV void policy_fair(Ctx& c, bool dynamic_partition, int& stage_idx, int& nu
   for (int ch = 0; ch < n_chunks; ch++) {
     int k = ch * 64 + lane;
     bool valid = k < A;
-    int j = valid ? (int)lds_active(c)[k] : 0;
+    int j = valid ? (int)lds_active()[k] : 0;
     uint64_t sm = 0, act = 0;
     int sup = 0, gs = 0;
     if (valid) {
-      const SssJob& job = (*jobp(c, j));
+      const SssJob& job = (*jobp(j));
       sm = job.sched_mask, act = job.active_mask, sup = job.supply, gs = job.gs_base;
     }
     // find_stage: first schedulable stage with no active parent, else first schedulable stage
@@ -1849,7 +1858,7 @@ SSS_DEV void policy_fair(Ctx& c, bool dynamic_partition, int& stage_idx, int& nu
     while (m) {
       int s = ctz64(m);
       m &= m - 1;
-      if ((c.pk->stage_parent_mask[gs + s] & act) == 0) {
+      if ((g_c.pk.stage_parent_mask[gs + s] & act) == 0) {
         best = s;
         break;
       }
@@ -1892,11 +1901,11 @@ SSS_DEV uint64_t splitmix64(uint64_t x) {
 // the build's counter-based uniform-random policy, keyed (episode seed, step in episode); mirrors
 // hash_policy in tests/golden/make_golden.py. SURVEY 8(d) C2: stage uniform over the schedulable
 // stages, num_exec uniform in [1, num_committable]; `p_none_permille` adds stage_idx = -1 draws.
-SSS_DEV void policy_hash(Ctx& c, int p_none_permille, int& stage_idx, int& num_exec) {
+SSS_DEV void policy_hash(int p_none_permille, int& stage_idx, int& num_exec) {
   uint64_t seed = g_hot.h.seed;
   uint64_t step = (uint64_t)g_hot.h.ep_steps;
   int n_sched = g_hot.h.n_sched;
-  int ncommit = obs_num_committable(c);
+  int ncommit = obs_num_committable();
   wave_sync();  // reads above vs. lane 0's writes in the step that follows
   uint64_t h = splitmix64((seed << 32) ^ step), h2 = splitmix64(h), h3 = splitmix64(h2);
   if (n_sched == 0 || (int)(h3 % 1000) < p_none_permille)
@@ -1908,22 +1917,21 @@ SSS_DEV void policy_hash(Ctx& c, int p_none_permille, int& stage_idx, int& num_e
 
 enum { SSS_POLICY_FAIR = 0, SSS_POLICY_FIFO = 1, SSS_POLICY_HASH = 2 };
 
-SSS_DEV void run_policy(Ctx& c, int policy, int param, int& stage_idx, int& num_exec) {
+SSS_DEV void run_policy(int policy, int param, int& stage_idx, int& num_exec) {
   if (policy == SSS_POLICY_HASH)
-    policy_hash(c, param, stage_idx, num_exec);
+    policy_hash(param, stage_idx, num_exec);
   else
-    policy_fair(c, policy == SSS_POLICY_FAIR, stage_idx, num_exec);
+    policy_fair(policy == SSS_POLICY_FAIR, stage_idx, num_exec);
 }
 
 // writes one action per env into stage_idx / num_exec (for sss_step)
 SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_t* stage_idx, int32_t* num_exec) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  Ctx c;
-  ctx_init(c, base, a.L, a.P, a.pk);
-  env_begin(c, base);
+  ctx_init(base, a.L, a.P, a.pk);
+  env_begin(base);
   int si, ne;
-  run_policy(c, policy, param, si, ne);
+  run_policy(policy, param, si, ne);
   if (wave_lane() == 0) stage_idx[env] = si, num_exec[env] = ne;
 }
 
@@ -1932,24 +1940,23 @@ SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_
 SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  Ctx c;
-  ctx_init(c, base, a.L, a.P, a.pk);
-  env_begin(c, base);
+  ctx_init(base, a.L, a.P, a.pk);
+  env_begin(base);
   for (int it = 0; it < n_steps; it++) {
     bool over = wave_ballot(g_hot.h.terminated || g_hot.h.need_reset) != 0;
     double reward = 0.0;
     if (over) {
       if (!auto_reset || wave_ballot(g_hot.h.err != 0) != 0) break;  // failed envs stay failed
-      do_reset(c, a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
+      do_reset(a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
     } else {
       int si, ne;
-      run_policy(c, policy, param, si, ne);
-      reward = do_step(c, si, ne);
+      run_policy(policy, param, si, ne);
+      reward = do_step(si, ne);
     }
-    write_observation(c, a.L, a.B, env, reward);
+    write_observation(a.L, a.B, env, reward);
     wave_sync();
   }
-  env_end(c, base);
+  env_end(base);
 }
 
 #undef H

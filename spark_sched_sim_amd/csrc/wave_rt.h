@@ -10,7 +10,7 @@
 
 #define SSS_DEV __device__ __forceinline__
 #define SSS_DEV_NOINLINE __device__ __noinline__
-#define SSS_KERNEL extern "C" __global__ __launch_bounds__(64)
+#define SSS_KERNEL extern "C" __global__ __launch_bounds__(64, 4)
 #define SSS_SHARED __shared__
 #define SSS_SHARED_DYN(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
 

@@ -85,3 +85,4 @@ SSS_DEV uint32_t f64_hi32(double x) { return (uint32_t)(f64_bits(x) >> 32); }
 SSS_DEV double f64_with_hi32(double x, uint32_t hi) { return bits_f64((f64_bits(x) & 0xFFFFFFFFull) | ((uint64_t)hi << 32)); }
 
 struct uint4 { uint32_t x, y, z, w; };
+struct int2 { int x, y; };
