@@ -192,7 +192,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
       if (levels[l] == exec_levels[i]) P.lvl_of[i] = (int8_t)l;
   }
   P.max_edges = ph.max_edges_per_job;
-  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, SSS_STATIC_LDS_BYTES)) {
+  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, h->L.E, SSS_STATIC_LDS_BYTES)) {
     sss_destroy(h);
     return sss_fail(-12, "LDS working set does not fit");
   }

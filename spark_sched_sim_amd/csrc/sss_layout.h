@@ -146,9 +146,8 @@ struct SssParams {
   int32_t n_slots;         // LDS cache slots for active jobs (<= 64)
   int32_t jobset_slots;    // capacity of the job-id set image (power of two)
   int32_t pool_bytes;      // dynamic LDS size
-  int32_t off_active, off_old_active, off_slot_of, off_keys, off_jobset, off_cjobs, off_cstages, off_cdur;  // byte offsets in g_pool
+  int32_t off_active, off_old_active, off_slot_of, off_keys, off_jobset, off_cjobs, off_cstages, off_cdur, off_exdesc;  // byte offsets in g_pool
   int32_t max_edges;       // max template edges (flattened edge pass stride)
-  int32_t pad_;
   int8_t lvl_of[8];        // pack level index of executor levels {5,10,20,40,50,60,80,100}, -1 if absent
   double mean_interarrival, moving_delay, warmup_delay, beta;
 };
@@ -181,7 +180,17 @@ static inline int64_t sss_align(int64_t x, int64_t a) { return (x + a - 1) / a *
 #define SSS_LDS_BUDGET 10240  // bytes of LDS per workgroup that keep 16 workgroups (4 waves/SIMD) on a CU
 
 // carve the dynamic LDS pool; returns 0 on success, -1 if even a minimal cache does not fit
-static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int static_bytes) {
+// per-executor cache of the two duration descriptors the executor's stage can need next
+// (executor mode "same stage", one per candidate executor level): keeps the descriptor load out
+// of the event chain. LDS only, rebuilt lazily after every launch.
+struct SssExDesc {
+  int32_t gs;              // pack stage row the entries belong to, -1 = invalid
+  int32_t off[2], lenw[2];
+  int8_t lvl[2];
+  int16_t pad;
+};
+
+static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, int static_bytes) {
   int jobset = J_cap <= 76 ? 128 : (J_cap <= 306 ? 512 : 2048);  // CPython resize thresholds (fill*5 >= mask*3)
   int o = 0;
   P->off_active = o, o += 2 * J_cap;
@@ -190,6 +199,8 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int stat
   o = (o + 1) & ~1;
   P->off_keys = o, o += 2 * (J_cap + 8);
   P->off_jobset = o, o += 2 * jobset;
+  o = (o + 7) & ~7;
+  P->off_exdesc = o, o += (int)sizeof(SssExDesc) * E;
   o = (o + 15) & ~15;
   int per_slot = (int)sizeof(SssJob) + 8 * SP + 4 * SP;
   int budget = SSS_LDS_BUDGET - static_bytes;

@@ -42,6 +42,10 @@ struct alignas(16) SssScratch {
   int32_t events_this_step;
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
   int32_t jobset_mask, f_need_jobtime;
+  // the set image of (old active list + active list) only changes when a job arrives or completes:
+  // versions of the two lists it was built from (valid within one launch)
+  uint32_t active_version, old_version, jobset_old_v, jobset_new_v;
+  int32_t jobset_valid, pad1_;
   uint64_t free_slots;            // bit k set <=> cache slot k is free
   double wall_old;
   uint32_t fc_dst[SSS_MAX_EXEC];  // snapshot of the source's commitments (fulfill_commitments_from_source)
@@ -111,6 +115,7 @@ SSS_DEV uint16_t* lds_jobset() { return (uint16_t*)(g_pool + g_c.P.off_jobset); 
 SSS_DEV SssJob* lds_cjobs() { return (SssJob*)(g_pool + g_c.P.off_cjobs); }
 SSS_DEV SssStage* lds_cstages() { return (SssStage*)(g_pool + g_c.P.off_cstages); }
 SSS_DEV float* lds_cdur() { return (float*)(g_pool + g_c.P.off_cdur); }
+SSS_DEV SssExDesc* lds_exdesc() { return (SssExDesc*)(g_pool + g_c.P.off_exdesc); }
 SSS_DEV uint16_t* lds_old_active() { return (uint16_t*)(g_pool + g_c.P.off_old_active); }
 
 // record of job j: its LDS cache slot if it has one, else the HBM copy
@@ -994,6 +999,7 @@ SSS_DEV void cache_release(int j) {  // on completion: LDS -> HBM, slot becomes 
 SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created empty at reset)
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
+  g_sc.active_version++;
   cache_acquire(j);
   if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
@@ -1021,6 +1027,7 @@ SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
   (*jobp(j)).completion_order = (int16_t)H.n_completed;
   H.n_completed++;
   g_sc.pending_free = j;  // its cache slot is written back once the handler has returned
+  g_sc.active_version++;
   g_c.t_completed[j] = H.wall_time;
   double dur = H.wall_time - g_c.t_arrival[j];
   if (H.dur_n < SSS_DUR_RING) {
@@ -1065,37 +1072,27 @@ SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-
 // wave-parallel phases
 // ------------------------------------------------------------------------------------------
 
-// EventQueue.pop (EVQ:44-49), lane 0. The "heap" is one slot per executor (an executor has at
-// most one pending event; ev_t = +inf when it has none) plus the time-sorted arrival array with a
-// cursor. (t, push counter) keys are unique, so the minimum is the heapq order; arrivals carry the
-// counters 0..J-1 and therefore win ties against executor events. A linear scan of <= 64 LDS
-// slots by one lane costs less than a cross-lane reduction plus the publish/sync round trip it
-// would need per event, and lets lane 0 run whole chains of events without any wave-level sync.
 #define POP_EMPTY (-1)
 #define POP_ARRIVAL (-2)
-SSS_DEV int pop_event(double next_arrival_t) {
-  const SssHot& hot = g_hot;
-  double best = __builtin_inf();
-  int ex = POP_EMPTY;
-  bool tie = false;
-  // 4 independent LDS reads per round, then the compares: the scan is latency-, not issue-bound
-  for (int e0 = 0; e0 < g_c.E; e0 += 4) {
-    double t[4];
-    _Pragma("unroll") for (int k = 0; k < 4; k++) t[k] = hot.ev[e0 + k].t;  // slots >= E hold +inf
-    _Pragma("unroll") for (int k = 0; k < 4; k++) {
-      if (t[k] < best) {
-        best = t[k], ex = e0 + k, tie = false;
-      } else if (t[k] == best && ex >= 0) {
-        tie = true;
-      }
-    }
+// EventQueue.pop (EVQ:44-49) with the whole wave. The "heap" is one slot per executor (an executor
+// has at most one pending event; t = +inf when it has none) plus the time-sorted arrival array
+// with a cursor. (t, push counter) keys are unique, so the minimum is the heapq order; arrivals
+// carry the counters 0..J-1 and therefore win ties against executor events. One lane per
+// executor, lexicographic min over (time, push counter) on the DPP network - no LDS round trips
+// beyond the one read of the slots. All lanes call it; every lane gets the same result.
+SSS_DEV int pop_event_wave(double next_arrival_t) {
+  int lane = wave_lane();
+  SssEvSlot sl = g_hot.ev[lane];
+  double tmin = wave_min_f64_nonneg(sl.t);  // times are >= +0.0; +inf for empty slots
+  bool at_min = sl.t == tmin;
+  uint64_t cand = wave_ballot(at_min);
+  int ex = ctz64(cand);
+  if (cand & (cand - 1)) {  // equal times: the earlier push wins (EVQ:35)
+    uint32_t msq = wave_min_u32(at_min ? sl.seq : 0xFFFFFFFFu);
+    ex = ctz64(wave_ballot(at_min && sl.seq == msq));
   }
-  if (tie) {  // equal times: the earlier push wins (EVQ:35)
-    uint32_t best_seq = 0xFFFFFFFFu;
-    for (int e = 0; e < g_c.E; e++)
-      if (hot.ev[e].t == best && hot.ev[e].seq < best_seq) best_seq = hot.ev[e].seq, ex = e;
-  }
-  if (next_arrival_t <= best && next_arrival_t < __builtin_inf()) return POP_ARRIVAL;  // +inf: no arrival left
+  if (next_arrival_t <= tmin && next_arrival_t < __builtin_inf()) return POP_ARRIVAL;
+  if (!(tmin < __builtin_inf())) return POP_EMPTY;
   return ex;
 }
 
@@ -1144,6 +1141,7 @@ SSS_DEV int fast_body(EvRegs& r, int ex, int j, int s, int slot) {
   SssStage st = *sp;
   uint64_t local = jp->local_mask;
   int gs = jp->gs_base + s;
+  SssExDesc xd = lds_exdesc()[ex];
   if (st.remaining <= 0) return 0;
   st.remaining = (int16_t)(st.remaining - 1);
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
@@ -1154,13 +1152,25 @@ SSS_DEV int fast_body(EvRegs& r, int ex, int j, int s, int slot) {
   int n_local = popc64(local);
   int li, ri;
   executor_interval(n_local, li, ri);
+  int ri_orig = ri;
   if (li != ri) {
     double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
     int rand_pt = 1 + (int)(rng_random(r) * (right - left));
     if (!((double)rand_pt <= (double)n_local - left)) li = ri;
   }
-  const int2 d = *(const int2*)(g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + 1) * 2);
-  int off = d.x, lenw = d.y;
+  // descriptor of (stage, level li, "same stage" mode): from the executor's LDS cache when it
+  // holds it, else one load from the pack (and the cache entry for that candidate is replaced)
+  int off, lenw;
+  int which = li == ri_orig ? 0 : 1;
+  if (xd.gs == gs && xd.lvl[which] == li) {
+    off = xd.off[which], lenw = xd.lenw[which];
+  } else {
+    const int2 d = *(const int2*)(g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + 1) * 2);
+    off = d.x, lenw = d.y;
+    if (xd.gs != gs) xd.lvl[which ^ 1] = -1;
+    xd.gs = gs, xd.off[which] = off, xd.lenw[which] = lenw, xd.lvl[which] = (int8_t)li;
+    lds_exdesc()[ex] = xd;
+  }
   int len = lenw & 0x3FFFFFFF;
   if (len == 0 || n_local <= 0) return -1;
   uint32_t i = rng_integers(r, (uint32_t)len);
@@ -1319,6 +1329,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
     for (int i = lane; i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
   }
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
+  if (lane < g_c.E) lds_exdesc()[lane].gs = -1;
   wave_sync();
   int A = g_hot.h.n_active;
   int nK = A < g_c.P.n_slots ? A : g_c.P.n_slots;
@@ -1333,6 +1344,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
     g_sc.free_slots = all & ~used;
     g_sc.pending_free = -1;
     g_sc.events_this_step = 0;
+    g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
   }
   wave_sync();
   // cached records: per slot 8 x u64 of job record, SP x u64 of stage counters, SP/2 x u64 of durations
@@ -1480,82 +1492,91 @@ SSS_DEV double jobtime_sum() {
 // ------------------------------------------------------------------------------------------
 
 // _resume_simulation (ENV:320-343). Entered and left with LDS in sync.
+// lane 0: one popped event. Returns 0 = keep going, 1 = queue empty / failed, 2 = a scan is needed
+// (committable executors exist). On a non-zero return the LDS header is current.
+SSS_DEV int handle_popped(EvRegs& r, int ex, uint64_t& n_fast, uint64_t& t_slow) {
+  if (ex == POP_EMPTY) {
+    regs_store(r);
+    return 1;
+  }
+  r.n_events++;
+  r.events_this_step++;
+  int fast = 0;
+  if (ex >= 0) {
+    SssEvSlot sl = g_hot.ev[ex];
+    if (info_kind(sl.info) == EV_TASK_FINISHED) {
+      r.wall_time = sl.t;
+      fast = fast_task_completion(r, ex, info_job(sl.info), info_stage(sl.info));
+    }
+  }
+  if (fast > 0) {
+    // the source stays what it was - None right after a scheduling round - so nothing is
+    // committable and the loop continues on registers (ENV:331-332)
+    n_fast++;
+    if (r.curr_source == POOL_NONE) return 0;
+    regs_store(r);
+  } else {
+    // everything else goes through the out-of-line handlers on the LDS copy of the state
+    regs_store(r);
+    if (fast < 0) FAIL(SSS_ERR_NO_DURATION);
+    uint64_t ts0 = wave_clock();
+    if (fast < 0) {
+    } else if (ex == POP_ARRIVAL) {
+      int job = H.next_arrival;
+      H.wall_time = H.next_arrival_t;
+      H.next_arrival++;
+      H.next_arrival_t = H.next_arrival < H.J ? g_c.t_arrival[H.next_arrival] : __builtin_inf();
+      handle_job_arrival(job);
+    } else {
+      SssHot& hot = g_hot;
+      SssEvSlot sl = hot.ev[ex];
+      H.wall_time = sl.t;
+      hot.ev[ex].t = __builtin_inf();
+      hot.ev[ex].info = EV_NONE;
+      if (info_kind(sl.info) == EV_TASK_FINISHED)
+        handle_task_completion(ex, info_job(sl.info), info_stage(sl.info));
+      else
+        handle_executor_arrival(ex, info_job(sl.info), info_stage(sl.info));
+    }
+    if (g_sc.pending_free >= 0) {
+      cache_release(g_sc.pending_free);
+      g_sc.pending_free = -1;
+    }
+    t_slow += wave_clock() - ts0;
+  }
+  // the LDS header is current here
+  if (H.err) return 1;
+  if (trk_num_committable() > 0) {
+    publish_scan_inputs();
+    return 2;
+  }
+  regs_load(r);
+  return 0;
+}
+
 SSS_DEV void resume_simulation() {
   int lane = wave_lane();
   for (;;) {
-    if (lane == 0) {
-      // lane 0 runs events back to back until the wave is needed: a schedulable-stage scan
-      // (committable executors exist), an empty queue, or a failure
-      g_sc.f_done = 0, g_sc.f_scan = 0;
+    // events run back to back until the wave is needed for a schedulable-stage scan, the queue is
+    // empty, or something failed
+    // The pop is a wave reduction, the handler runs on lane 0, and the loop decision travels through
+    // a lane-0 broadcast (no LDS flags, no barrier per event).
+    {
       EvRegs r;
       regs_load(r);
       uint64_t n_fast = 0, t_slow = 0;
-      for (;;) {
-        int ex = pop_event(r.next_arrival_t);
-        if (ex == POP_EMPTY) {
-          regs_store(r);
-          g_sc.f_done = 1;
-          break;
-        }
-        r.n_events++;
-        r.events_this_step++;
-        int fast = 0;
-        if (ex >= 0) {
-          SssEvSlot sl = g_hot.ev[ex];
-          if (info_kind(sl.info) == EV_TASK_FINISHED) {
-            r.wall_time = sl.t;
-            fast = fast_task_completion(r, ex, info_job(sl.info), info_stage(sl.info));
-          }
-        }
-        if (fast > 0) {
-          // the source stays what it was - None right after a scheduling round - so nothing is
-          // committable and the loop continues on registers (ENV:331-332)
-          n_fast++;
-          if (r.curr_source == POOL_NONE) continue;
-          regs_store(r);
-        } else {
-          // everything else goes through the out-of-line handlers on the LDS copy of the state
-          regs_store(r);
-          if (fast < 0) FAIL(SSS_ERR_NO_DURATION);
-          uint64_t ts0 = wave_clock();
-          if (fast < 0) {
-          } else if (ex == POP_ARRIVAL) {
-            int job = H.next_arrival;
-            H.wall_time = H.next_arrival_t;
-            H.next_arrival++;
-            H.next_arrival_t = H.next_arrival < H.J ? g_c.t_arrival[H.next_arrival] : __builtin_inf();
-            handle_job_arrival(job);
-          } else {
-            SssHot& hot = g_hot;
-            SssEvSlot sl = hot.ev[ex];
-            H.wall_time = sl.t;
-            hot.ev[ex].t = __builtin_inf();
-            hot.ev[ex].info = EV_NONE;
-            if (info_kind(sl.info) == EV_TASK_FINISHED)
-              handle_task_completion(ex, info_job(sl.info), info_stage(sl.info));
-            else
-              handle_executor_arrival(ex, info_job(sl.info), info_stage(sl.info));
-          }
-          if (g_sc.pending_free >= 0) {
-            cache_release(g_sc.pending_free);
-            g_sc.pending_free = -1;
-          }
-          t_slow += wave_clock() - ts0;
-        }
-        // the LDS header is current here
-        if (H.err) {
-          g_sc.f_done = 1;
-          break;
-        }
-        if (trk_num_committable() > 0) {
-          g_sc.f_scan = 1;
-          publish_scan_inputs();
-          break;
-        }
-        regs_load(r);
+      int status;
+      do {
+        int ex = pop_event_wave(wave_bcast_f64(r.next_arrival_t, 0));
+        status = 0;
+        if (lane == 0) status = handle_popped(r, ex, n_fast, t_slow);
+        status = (int)wave_bcast_u32((uint32_t)status, 0);
+      } while (status == 0);
+      if (lane == 0) {
+        g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
+        H.n_fast += n_fast;
+        H.prof[0] += t_slow;
       }
-      H.n_fast += n_fast;
-      H.prof[0] += t_slow;
     }
     wave_sync();
     if (g_sc.f_done) {
@@ -1728,6 +1749,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
           g_sc.wall_old = H.wall_time;
           g_sc.n_old_active = H.n_active;
           for (int a = 0; a < H.n_active; a++) lds_old_active()[a] = lds_active()[a];
+          g_sc.old_version = g_sc.active_version;
           g_sc.f_round_continues = 0;
         }
       }
@@ -1744,7 +1766,10 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   if (lane == 0) {
     g_sc.f_need_jobtime = 0;
     if (!H.err && H.wall_time - g_sc.wall_old != 0.0) {
-      jobtime_build_set();
+      if (!(g_sc.jobset_valid && g_sc.jobset_old_v == g_sc.old_version && g_sc.jobset_new_v == g_sc.active_version)) {
+        jobtime_build_set();
+        g_sc.jobset_valid = 1, g_sc.jobset_old_v = g_sc.old_version, g_sc.jobset_new_v = g_sc.active_version;
+      }
       g_sc.f_need_jobtime = 1;
     }
   }

@@ -29,13 +29,45 @@ SSS_DEV double wave_bcast_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// min over the 64 lanes on the DPP network (no LDS traffic): quad swaps, half-row and row mirrors
+// give every lane its 16-lane row minimum; the four row results are combined on the scalar unit.
 SSS_DEV uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-    v = o < v ? o : v;
+  uint32_t o;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  v = o < v ? o : v;
+  uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  a = a < b ? a : b, c = c < d ? c : d;
+  return a < c ? a : c;
+}
+
+// min of non-negative doubles (incl. +inf) over the wave: same DPP pattern on the two halves
+SSS_DEV double wave_min_f64_nonneg(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+#define SSS_DPP_MIN_STEP(ctrl)                                                      \
+  {                                                                                 \
+    int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);           \
+    int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);           \
+    double o = __hiloint2double(ohi, olo), c = __hiloint2double(hi, lo);            \
+    if (o < c) lo = olo, hi = ohi;                                                  \
   }
-  return v;
+  SSS_DPP_MIN_STEP(0xB1)
+  SSS_DPP_MIN_STEP(0x4E)
+  SSS_DPP_MIN_STEP(0x141)
+  SSS_DPP_MIN_STEP(0x140)
+#undef SSS_DPP_MIN_STEP
+  double a = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  double c = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  double d = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  a = a < b ? a : b, c = c < d ? c : d;
+  return a < c ? a : c;
 }
 
 SSS_DEV uint64_t wave_min_u64(uint64_t v) {

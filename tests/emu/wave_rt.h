@@ -63,6 +63,15 @@ SSS_DEV uint64_t wave_min_u64(uint64_t v) {
   for (int i = 0; i < 64; i++) m = emu::slot(i) < m ? emu::slot(i) : m;
   return m;
 }
+SSS_DEV double wave_min_f64_nonneg(double x) {
+  uint64_t u;
+  memcpy(&u, &x, 8);
+  emu::collective(emu::OP_MIN64, u);
+  uint64_t m = ~0ull;  // non-negative doubles order like their bit patterns
+  for (int i = 0; i < 64; i++) m = emu::slot(i) < m ? emu::slot(i) : m;
+  memcpy(&x, &m, 8);
+  return x;
+}
 SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   emu::collective(emu::OP_SUM32, v);
   uint32_t s = 0;
