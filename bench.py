@@ -63,6 +63,22 @@ def cpu_baseline(cfg: dict, policy: str, budget_s: float) -> dict:
             "sample": f"{eps} episodes / {steps} steps of the same config and policy in {dt:.1f} s (C oracle, observation built every step)"}
 
 
+def measured_traffic(kernel: str, config: str, envs: int):
+    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes), recorded under profiles/ by tools/collect_traffic.py for this
+    exact kernel/config; None when no matching measurement is committed."""
+    path = osp.join(ROOT, "profiles", "traffic.json")
+    if not osp.exists(path):
+        return None
+    try:
+        for rec in json.load(open(path)):
+            if rec["kernel"] == kernel and rec["config"] == config and rec["envs"] == envs:
+                return rec["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +89,7 @@ def main() -> None:
     ap.add_argument("--policy", default=None, choices=["hash", "fair"])
     ap.add_argument("--mode", default="step", choices=["step", "fused"])
     ap.add_argument("--fused-chunk", type=int, default=50)
+    ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -102,8 +119,13 @@ def main() -> None:
     env = VecSparkSchedSimEnv(cfg, B, device=dev, pack=workload.default_pack(), auto_reset=True, seed_stride=B * world)
     env.reset(seed=rank * B)  # env i of rank r: seed r*B + i  (placement-invariant global env id)
 
-    def run(n_steps: int, events=None):
-        if args.mode == "step":
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(mode: str, n_steps: int, events=None):
+        if mode == "step":
             for _ in range(n_steps):
                 act = env.policy_actions(policy)
                 if events is not None:
@@ -128,59 +150,68 @@ def main() -> None:
                     env.rollout(policy, n)
                 done += n
 
-    def barrier():
+    def measure(mode: str) -> dict:
+        """W untimed + exactly K timed batched steps in `mode`; all-rank totals on every rank"""
+        run(mode, args.warmup)
+        barrier()
+        c0 = env.counters()
+        events: list = []
+        barrier()
+        t0 = time.perf_counter()
+        run(mode, args.steps, events)
+        barrier()
+        dt = time.perf_counter() - t0
+        c1 = env.counters()
+        kern_ms = sum(a.elapsed_time(b) for a, b in events)
+        tot = torch.tensor([float(c1["n_steps"] - c0["n_steps"]), float(c1["n_events"] - c0["n_events"]),
+                            float(c1["model_bytes"] - c0["model_bytes"]), kern_ms, float(len(events)),
+                            float(c1["n_fast_events"] - c0["n_fast_events"])], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        steps_all, evs_all, bytes_all, kern_ms_all, launches_all, fast_all = tot.cpu().tolist()
+        dt_max = tmax.item()
+        avg_launch_s = (kern_ms_all / launches_all) * 1e-3
+        bytes_per_launch = bytes_all / launches_all
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        kernel = "sss_step_kernel" if mode == "step" else "sss_rollout_kernel"
+        return {
+            "value": steps_all / dt_max,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "events_per_s": evs_all / dt_max,
+            "events_per_step": evs_all / max(1.0, steps_all),
+            "fast_path_event_frac": fast_all / max(1.0, evs_all),
+            "roofline": {
+                "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel, args.config, B),
+                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
+                "kernel_time_frac_of_wall": (kern_ms_all / world) * 1e-3 / dt_max,
+            },
+        }
 
-    run(args.warmup)
-    barrier()
-    c0 = env.counters()
-    events: list = []
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, events)
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = env.counters()
+    primary = measure(args.mode)
+    other_mode = "fused" if args.mode == "step" else "step"
+    secondary = None if args.single_mode else measure(other_mode)
 
-    steps = c1["n_steps"] - c0["n_steps"]
-    evs = c1["n_events"] - c0["n_events"]
-    model_bytes = c1["model_bytes"] - c0["model_bytes"]
-    kern_ms = sum(a.elapsed_time(b) for a, b in events)
-    n_launch = len(events)
-
-    tot = torch.tensor([float(steps), float(evs), float(model_bytes), kern_ms, float(n_launch)], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        # the one exchange of the path: all-gather of per-env episode returns
-        ret = env.header_field("last_ep_return").clone()
-        gathered = [torch.empty_like(ret) for _ in range(world)]
-        dist.all_gather(gathered, ret)
-        mean_return = torch.cat(gathered).mean().item()
+        # the one exchange of the path: all-gather of per-env episode summaries (RCCL)
+        from spark_sched_sim_amd.distributed import all_gather_episode_summaries
+
+        table = all_gather_episode_summaries(env)
+        mean_return = table[:, 0].mean().item()
     else:
         mean_return = env.header_field("last_ep_return").mean().item()
-    tot = tot.cpu().tolist()
-    dt_max = tmax.item()
 
     if rank == 0:
-        steps_all, evs_all, bytes_all, kern_ms_all, launches_all = tot
-        value = steps_all / dt_max
-        # dominant kernel: step (or rollout) kernel. Algorithmic bytes per launch / average launch
-        # duration; per-rank averages are identical in expectation, so use the all-rank sums.
-        avg_launch_s = (kern_ms_all / launches_all) * 1e-3 if launches_all else float("nan")
-        bytes_per_launch = bytes_all / launches_all if launches_all else 0.0
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if launches_all else 0.0
         out = {
             "metric": "env-steps/sec at 4096 batched envs (TPC-H, 10 exec)" if (args.config == "c2" and B == 4096) else f"env-steps/sec at {B} batched envs ({args.config})",
-            "value": value,
+            "value": primary["value"],
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_step": primary["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -189,27 +220,18 @@ def main() -> None:
             "config": {
                 "workload": f"{B} envs/GPU x ({cfg['num_executors']} executors, {cfg['job_arrival_cap']} TPC-H-format jobs, "
                             f"job_arrival_rate {cfg['job_arrival_rate']}/ms, synthetic frozen trace set), on-device '{policy}' policy, "
-                            f"auto-reset, mode={args.mode}",
+                            f"auto-reset, mode={args.mode} ({'sss_policy + sss_step per batched step' if args.mode == 'step' else 'sss_rollout, ' + str(args.fused_chunk) + ' steps per launch'})",
                 "envs_per_gpu": B, "policy": policy, "mode": args.mode, "parallelism": f"env-shard x{world}",
             },
-            "events_per_s": evs_all / dt_max,
-            "events_per_step": evs_all / max(1.0, steps_all),
+            "events_per_s": primary["events_per_s"],
+            "events_per_step": primary["events_per_step"],
+            "fast_path_event_frac": primary["fast_path_event_frac"],
             "mean_last_episode_return": mean_return,
-            "phase_ticks_per_step": {k[6:]: (c1[k] - c0[k]) / max(1, steps) for k in c1 if k.startswith("ticks_")},
-            "fast_event_frac": (c1["n_fast_events"] - c0["n_fast_events"]) / max(1, evs),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "sss_step_kernel" if args.mode == "step" else "sss_rollout_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "kernel_time_frac_of_wall": (kern_ms_all / world) * 1e-3 / dt_max,
-            },
+            "roofline": primary["roofline"],
         }
+        if secondary is not None:
+            # the same K batched steps through the other entry point (same per-step work, same trajectories)
+            out["other_mode"] = dict(secondary, mode=other_mode)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget)
         print(json.dumps(out), flush=True)
