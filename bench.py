@@ -182,6 +182,8 @@ def main() -> None:
             "events_per_s": evs_all / dt_max,
             "events_per_step": evs_all / max(1.0, steps_all),
             "fast_path_event_frac": fast_all / max(1.0, evs_all),
+            # rank-0 shader-clock ticks per real env step spent in each phase (device counters)
+            "phase_ticks_per_step": {k[6:]: (c1[k] - c0[k]) / max(1, c1["n_steps"] - c0["n_steps"]) for k in c1 if k.startswith("ticks_")},
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel, args.config, B),
@@ -226,6 +228,7 @@ def main() -> None:
             "events_per_s": primary["events_per_s"],
             "events_per_step": primary["events_per_step"],
             "fast_path_event_frac": primary["fast_path_event_frac"],
+            "phase_ticks_per_step": primary["phase_ticks_per_step"],
             "mean_last_episode_return": mean_return,
             "roofline": primary["roofline"],
         }
