@@ -25,7 +25,10 @@ def run_policy_episode(name, policy, param, seeds, pack, device="cpu", lib=None,
             hdr = env.header(k)
             if n == n_rec[k] - 1:
                 ok = hdr["terminated"] == 1 and bits(hdr["wall_time"]) == int(g.ep(s, "wall_time")[n]) and hdr["ep_steps"] == n
-                ok = ok and np.isclose(hdr["ep_return"], -g.ep(s, "reward")[1:].view(np.float64).sum() * -1.0)
+                exp_ret = 0.0
+                for rr in g.ep(s, "reward")[1:].view(np.float64).tolist():
+                    exp_ret += rr  # same left-to-right f64 accumulation as the device's ep_return
+                ok = ok and bits(hdr["ep_return"]) == bits(exp_ret)
             else:
                 ok = bits(hdr["wall_time"]) == int(g.ep(s, "wall_time")[n])
             if not ok:
