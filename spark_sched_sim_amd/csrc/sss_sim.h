@@ -1128,20 +1128,36 @@ SSS_DEV void regs_store(const EvRegs& r) {
 // stage". executing-- / executing++ cancel, executor.task.stage_id already equals the stage
 // (=> the `rest_wave` mode of task_duration), the event slot keeps its kind/job/stage.
 // Returns false, with nothing modified, when the stage has no remaining task (slow path).
+// launch constants the fast path needs, fetched from the LDS context once per event loop
+struct FastCtx {
+  uint8_t* slot_of;
+  SssStage* cstages;
+  SssJob* cjobs;
+  float* cdur;
+  SssExDesc* exdesc;
+  const int32_t* eff;
+  const int32_t* durations;
+  int SP;
+};
+SSS_DEV void fastctx_load(FastCtx& f) {
+  f.slot_of = lds_slot_of(), f.cstages = lds_cstages(), f.cjobs = lds_cjobs(), f.cdur = lds_cdur(), f.exdesc = lds_exdesc();
+  f.eff = g_c.pk.eff, f.durations = g_c.pk.durations, f.SP = g_c.SP;
+}
+
 template <bool CACHED>
-SSS_DEV int fast_body(EvRegs& r, int ex, int j, int s, int slot) {
+SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slot) {
   SssStage* sp;
   SssJob* jp;
   float* dp;
   if (CACHED) {
-    sp = lds_cstages() + slot * g_c.SP + s, jp = lds_cjobs() + slot, dp = lds_cdur() + slot * g_c.SP + s;
+    sp = f.cstages + slot * f.SP + s, jp = f.cjobs + slot, dp = f.cdur + slot * f.SP + s;
   } else {
-    sp = g_c.stages + j * g_c.SP + s, jp = g_c.jobs + j, dp = g_c.durations + j * g_c.SP + s;
+    sp = g_c.stages + j * f.SP + s, jp = g_c.jobs + j, dp = g_c.durations + j * f.SP + s;
   }
   SssStage st = *sp;
   uint64_t local = jp->local_mask;
   int gs = jp->gs_base + s;
-  SssExDesc xd = lds_exdesc()[ex];
+  SssExDesc xd = f.exdesc[ex];
   if (st.remaining <= 0) return 0;
   st.remaining = (int16_t)(st.remaining - 1);
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
@@ -1165,16 +1181,16 @@ SSS_DEV int fast_body(EvRegs& r, int ex, int j, int s, int slot) {
   if (xd.gs == gs && xd.lvl[which] == li) {
     off = xd.off[which], lenw = xd.lenw[which];
   } else {
-    const int2 d = *(const int2*)(g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + 1) * 2);
+    const int2 d = *(const int2*)(f.eff + (((size_t)gs * 8 + li) * 3 + 1) * 2);
     off = d.x, lenw = d.y;
     if (xd.gs != gs) xd.lvl[which ^ 1] = -1;
     xd.gs = gs, xd.off[which] = off, xd.lenw[which] = lenw, xd.lvl[which] = (int8_t)li;
-    lds_exdesc()[ex] = xd;
+    f.exdesc[ex] = xd;
   }
   int len = lenw & 0x3FFFFFFF;
   if (len == 0 || n_local <= 0) return -1;
   uint32_t i = rng_integers(r, (uint32_t)len);
-  double dur = (double)g_c.pk.durations[off + (int)i];
+  double dur = (double)f.durations[off + (int)i];
   *dp = (float)dur;
   g_hot.ev[ex].t = r.wall_time + dur;
   g_hot.ev[ex].seq = r.counter++;
@@ -1182,9 +1198,9 @@ SSS_DEV int fast_body(EvRegs& r, int ex, int j, int s, int slot) {
 }
 
 // 1 = handled, 0 = not a fast-path event (nothing modified), -1 = failed
-SSS_DEV int fast_task_completion(EvRegs& r, int ex, int j, int s) {
-  int slot = lds_slot_of()[j];
-  return slot != SLOT_NONE ? fast_body<true>(r, ex, j, s, slot) : fast_body<false>(r, ex, j, s, slot);
+SSS_DEV int fast_task_completion(const FastCtx& f, EvRegs& r, int ex, int j, int s) {
+  int slot = f.slot_of[j];
+  return slot != SLOT_NONE ? fast_body<true>(f, r, ex, j, s, slot) : fast_body<false>(f, r, ex, j, s, slot);
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -1496,7 +1512,7 @@ SSS_DEV double jobtime_sum() {
 // _resume_simulation (ENV:320-343). Entered and left with LDS in sync.
 // lane 0: one popped event. Returns 0 = keep going, 1 = queue empty / failed, 2 = a scan is needed
 // (committable executors exist). On a non-zero return the LDS header is current.
-SSS_DEV int handle_popped(EvRegs& r, int ex, uint64_t& n_fast, uint64_t& t_slow) {
+SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, uint64_t& n_fast, uint64_t& t_slow) {
   if (ex == POP_EMPTY) {
     regs_store(r);
     return 1;
@@ -1508,7 +1524,7 @@ SSS_DEV int handle_popped(EvRegs& r, int ex, uint64_t& n_fast, uint64_t& t_slow)
     SssEvSlot sl = g_hot.ev[ex];
     if (info_kind(sl.info) == EV_TASK_FINISHED) {
       r.wall_time = sl.t;
-      fast = fast_task_completion(r, ex, info_job(sl.info), info_stage(sl.info));
+      fast = fast_task_completion(f, r, ex, info_job(sl.info), info_stage(sl.info));
     }
   }
   if (fast > 0) {
@@ -1566,13 +1582,15 @@ SSS_DEV void resume_simulation() {
     {
       EvRegs r;
       regs_load(r);
+      FastCtx f;
+      fastctx_load(f);
       uint64_t n_fast = 0, t_slow = 0;
       int status;
       do {
-        int ex = pop_event_wave(wave_bcast_f64(r.next_arrival_t, 0));
+        int ex = pop_event_wave(wave_lane0_f64(r.next_arrival_t));
         status = 0;
-        if (lane == 0) status = handle_popped(r, ex, n_fast, t_slow);
-        status = (int)wave_bcast_u32((uint32_t)status, 0);
+        if (lane == 0) status = handle_popped(f, r, ex, n_fast, t_slow);
+        status = (int)wave_lane0_u32((uint32_t)status);
       } while (status == 0);
       if (lane == 0) {
         g_sc.f_done = status == 1, g_sc.f_scan = status == 2;

@@ -22,6 +22,12 @@ SSS_DEV void wave_sync() { __syncthreads(); }
 
 SSS_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
 
+// value of lane 0 on every lane (v_readfirstlane: no LDS round trip); all lanes must be active
+SSS_DEV uint32_t wave_lane0_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+SSS_DEV double wave_lane0_f64(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 SSS_DEV uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 
 SSS_DEV double wave_bcast_f64(double v, int src) {

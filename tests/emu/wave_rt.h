@@ -39,6 +39,10 @@ SSS_DEV uint64_t wave_ballot(bool p) {
   for (int i = 0; i < 64; i++) m |= (emu::slot(i) & 1ull) << i;
   return m;
 }
+SSS_DEV uint32_t wave_bcast_u32(uint32_t v, int src);
+SSS_DEV double wave_bcast_f64(double v, int src);
+SSS_DEV uint32_t wave_lane0_u32(uint32_t v) { return wave_bcast_u32(v, 0); }
+SSS_DEV double wave_lane0_f64(double v) { return wave_bcast_f64(v, 0); }
 SSS_DEV uint32_t wave_bcast_u32(uint32_t v, int src) {
   emu::collective(emu::OP_BCAST, v);
   return (uint32_t)emu::slot(src & 63);
