@@ -59,6 +59,8 @@ SETS = {
     "testyaml_fair": (TESTYAML, "fair", [3, 4], None),
     "bige_hash": (BIGE, "hash", [0, 1, 2], None),
     "c1_fifo": (C1, "fifo", [5, 6], None),
+    # discounted rewards (trainer config, config/decima_tpch.yaml:69 beta=5e-3): np.exp in the reward
+    "c1_fair_beta": (dict(C1, beta=5.0e-3), "fair", [11, 12], None),
 }
 
 

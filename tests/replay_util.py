@@ -10,7 +10,8 @@ from spark_sched_sim_amd import VecSparkSchedSimEnv
 from spark_sched_sim_amd.digest import digest_words
 
 
-def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs_steps: int = 0, max_steps: int | None = None):
+def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs_steps: int = 0, max_steps: int | None = None,
+                  reward_rtol: float = 0.0, rewards_out: list | None = None):
     """one env per seed, all stepped together; returns a list of mismatch descriptions"""
     g = Golden(name)
     seeds = list(seeds)
@@ -62,7 +63,14 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
             exp = tuple(int(g.ep(s, kk)[i]) for kk in ("n_nodes", "n_edges", "n_jobs", "ncommit", "src_idx"))
             ok = got == exp and bits(of[k, 1]) == int(g.ep(s, "wall_time")[i])
             if i > 0:
-                ok = ok and bits(of[k, 0]) == int(g.ep(s, "reward")[i]) and bool(o[6]) == bool(g.ep(s, "terminated")[i]) and int(o[7]) == 0
+                exp_r = float(g.ep(s, "reward")[i: i + 1].view(np.float64)[0])
+                if reward_rtol:  # beta > 0: np.exp in the reference is not bit-reproducible
+                    r_ok = abs(of[k, 0] - exp_r) <= reward_rtol * max(1.0, abs(exp_r))
+                else:
+                    r_ok = bits(of[k, 0]) == bits(exp_r)
+                if rewards_out is not None:
+                    rewards_out.append((s, i, float(of[k, 0])))
+                ok = ok and r_ok and bool(o[6]) == bool(g.ep(s, "terminated")[i]) and int(o[7]) == 0
             n, ne, a = got[0], got[1], got[2]
             if ok:
                 d = (digest_words(nodes[k, :n]), digest_words(el[k, :ne]), digest_words(ptr[k, : a + 1]), digest_words(sup[k, :a]))

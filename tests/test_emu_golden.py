@@ -23,3 +23,22 @@ CASES = [
 def test_kernel_source_matches_reference_under_emulation(name, seeds, max_steps, pack):
     bad = replay_golden(name, seeds, pack, device="cpu", lib=load_emu(), full_obs_steps=10, max_steps=max_steps)
     assert not bad, "\n".join(bad[:10])
+
+
+def test_discounted_rewards_beta(pack):
+    """beta > 0 (reference spark_sched_sim.py:865-872): the reference sums differences of np.exp values,
+    whose last bit is not reproducible, and the subtraction amplifies it - rewards are compared to
+    1e-12 relative, every other field bit-exactly; against the C oracle (same FDLIBM exp, same
+    summation order) the rewards must agree bit-for-bit."""
+    from golden_util import Golden, bits
+    from oracle_binding import OracleEnv
+
+    got: list = []
+    bad = replay_golden("c1_fair_beta", [11], pack, device="cpu", lib=load_emu(), reward_rtol=1e-12, rewards_out=got, max_steps=200)
+    assert not bad, "\n".join(bad[:10])
+    g = Golden("c1_fair_beta")
+    o = OracleEnv(pack, g.cfg)
+    o.reset(11)
+    for s, i, r in got:
+        e, ro, _ = o.step(int(g.ep(11, "stage_idx")[i]), int(g.ep(11, "num_exec")[i]))
+        assert e == 0 and bits(ro) == bits(r), i

@@ -38,3 +38,8 @@ def test_hip_library_is_the_one_loaded():
 def test_hip_matches_reference_golden(name, seeds, max_steps, pack):
     bad = replay_golden(name, seeds, pack, device="cuda:0", full_obs_steps=40, max_steps=max_steps)
     assert not bad, "\n".join(bad[:10])
+
+
+def test_hip_discounted_rewards_beta(pack):
+    bad = replay_golden("c1_fair_beta", [11, 12], pack, device="cuda:0", reward_rtol=1e-12)
+    assert not bad, "\n".join(bad[:10])
