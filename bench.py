@@ -63,6 +63,46 @@ def cpu_baseline(cfg: dict, policy: str, budget_s: float) -> dict:
             "sample": f"{eps} episodes / {steps} steps of the same config and policy in {dt:.1f} s (C oracle, observation built every step)"}
 
 
+_CPU_WORKER = """
+import ctypes as C, json, sys, time
+sys.path[:0] = [{root!r}, {tests!r}]
+from oracle_binding import OracleEnv
+from spark_sched_sim_amd import workload
+cfg, pol, budget, wid = json.loads(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
+env = OracleEnv(workload.default_pack(), cfg)
+steps = eps = 0
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < budget:
+    r = C.c_double()
+    steps += max(0, env.lib.sso_run_episode(env.h, 20000 + 1000 * wid + eps, pol, 10**9, C.byref(r)))
+    eps += 1
+print(json.dumps([steps, time.perf_counter() - t0]))
+"""
+
+
+def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float) -> dict:
+    """the reference's own parallelism model (one process per env, trainers/trainer.py:264-293)
+    with the C oracle: one child process per host core (plain subprocesses that never touch the GPU)"""
+    import subprocess
+
+    n = os.cpu_count() or 1
+    code = _CPU_WORKER.format(root=ROOT, tests=osp.join(ROOT, "tests"))
+    pol = {"fair": 0, "hash": 1}[policy]
+    procs = [subprocess.Popen([sys.executable, "-c", code, json.dumps(cfg), str(pol), str(budget_s), str(w)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for w in range(n)]
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s + 120)
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    steps = sum(r[0] for r in res)
+    dt = max(r[1] for r in res)
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": len(res), "kind": "port",
+            "sample": f"{len(res)} processes x ~{budget_s:.0f} s of whole episodes, same config and policy (C oracle)"}
+
+
 def measured_traffic(kernel: str, config: str, envs: int):
     """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes), recorded under profiles/ by tools/collect_traffic.py for this
@@ -237,6 +277,10 @@ def main() -> None:
             out["other_mode"] = dict(secondary, mode=other_mode)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget)
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(6.0, args.cpu_budget))
+            except Exception as e:  # never let the extra baseline take the bench line down
+                out["cpu_baseline_all_cores"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:
