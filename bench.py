@@ -80,12 +80,28 @@ print(json.dumps([steps, time.perf_counter() - t0]))
 """
 
 
+def usable_cores() -> int:
+    """host cores this process may actually use: affinity mask and cgroup CPU quota included"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float) -> dict:
     """the reference's own parallelism model (one process per env, trainers/trainer.py:264-293)
     with the C oracle: one child process per host core (plain subprocesses that never touch the GPU)"""
     import subprocess
 
-    n = os.cpu_count() or 1
+    n = usable_cores()
     code = _CPU_WORKER.format(root=ROOT, tests=osp.join(ROOT, "tests"))
     pol = {"fair": 0, "hash": 1}[policy]
     procs = [subprocess.Popen([sys.executable, "-c", code, json.dumps(cfg), str(pol), str(budget_s), str(w)],

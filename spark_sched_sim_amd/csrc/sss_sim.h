@@ -1263,8 +1263,8 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     if (is_src) src_idx = a0 + ctz64(is_src);
     if (a < A) {
       nbase[a] = (uint16_t)(run + excl);
-      nt_store(&dag_ptr[a], (int32_t)(run + excl));
-      nt_store(&sup[a], (int32_t)supply);
+      dag_ptr[a] = (int32_t)(run + excl);
+      sup[a] = supply;
     }
     run += tot;
   }
@@ -1279,11 +1279,11 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     uint64_t act = job->active_mask;
     if (st < (int)job->n_stages && (act & bit64(st))) {
       int row = (int)nbase[a] + popc64(act & (bit64(st) - 1));
-      // streaming stores: the observation is written once and read by someone else - keep it out
-      // of the way of the pack tables that live in L2
-      nt_store(&nodes[row * 3 + 0], (float)stgp(j, st)->remaining);
-      nt_store(&nodes[row * 3 + 1], *durp(j, st));
-      nt_store(&nodes[row * 3 + 2], (job->sched_mask & bit64(st)) ? 1.0f : 0.0f);
+      // plain stores: non-temporal ones were measured to double the HBM write traffic (partial
+      // lines are no longer combined in L2) for no gain in time
+      nodes[row * 3 + 0] = (float)stgp(j, st)->remaining;
+      nodes[row * 3 + 1] = *durp(j, st);
+      nodes[row * 3 + 2] = (job->sched_mask & bit64(st)) ? 1.0f : 0.0f;
     }
   }
   // pass 3 - lanes over (job, template edge): active subgraph, compacted in (job, edge) order
@@ -1308,8 +1308,8 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     uint64_t bal = wave_ballot(keep);
     if (keep) {
       int pos = base_e + popc64(bal & lt);
-      nt_store(&el[2 * pos + 0], (int32_t)eu);
-      nt_store(&el[2 * pos + 1], (int32_t)ev);
+      el[2 * pos + 0] = eu;
+      el[2 * pos + 1] = ev;
     }
     base_e += popc64(bal);
   }
