@@ -145,9 +145,14 @@ def main() -> None:
     ap.add_argument("--policy", default=None, choices=["hash", "fair"])
     ap.add_argument("--mode", default="step", choices=["step", "fused"])
     ap.add_argument("--fused-chunk", type=int, default=50)
+    ap.add_argument("--shards", type=int, default=1,
+                    help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
+                         "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
     ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); 'gloo' only for plumbing tests")
+    ap.add_argument("--device-index", type=int, default=None, help="override LOCAL_RANK -> device mapping (plumbing tests on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -160,20 +165,49 @@ def main() -> None:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device_index is None else args.device_index
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
 
     from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
 
     cfg = CONFIGS[args.config]
     policy = args.policy or ("hash" if args.config == "c2" else "fair")
     B = args.envs
-    env = VecSparkSchedSimEnv(cfg, B, device=dev, pack=workload.default_pack(), auto_reset=True, seed_stride=B * world)
-    env.reset(seed=rank * B)  # env i of rank r: seed r*B + i  (placement-invariant global env id)
+    S = max(1, args.shards)
+    assert B % S == 0, "--envs must be divisible by --shards"
+    Bs = B // S
+    pack = workload.default_pack()
+    # env i of shard s of rank r: seed (r*S + s)*Bs + i = its global env id (placement invariant)
+    shards = [VecSparkSchedSimEnv(cfg, Bs, device=dev, pack=pack, auto_reset=True, seed_stride=B * world) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    for k, e in enumerate(shards):
+        e.reset(seed=(rank * S + k) * Bs)
+    torch.cuda.synchronize()
+
+    class _All:  # the rank's whole batch, as the sum of its shards
+        @staticmethod
+        def counters():
+            tot: dict = {}
+            for e in shards:
+                for key, v in e.counters().items():
+                    tot[key] = tot.get(key, 0) + v
+            return tot
+
+        @staticmethod
+        def header_field(name):
+            return torch.cat([e.header_field(name) for e in shards])
+
+        @staticmethod
+        def close():
+            for e in shards:
+                e.close()
+
+    env = _All
 
     def barrier():
         if world > 1:
@@ -181,29 +215,34 @@ def main() -> None:
         torch.cuda.synchronize()
 
     def run(mode: str, n_steps: int, events=None):
+        # every shard issues its own chain of launches on its own stream; chains are independent
         if mode == "step":
             for _ in range(n_steps):
-                act = env.policy_actions(policy)
-                if events is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    env.step_async(act["stage_idx"], act["num_exec"])
-                    e1.record()
-                    events.append((e0, e1))
-                else:
-                    env.step_async(act["stage_idx"], act["num_exec"])
+                for e, st in zip(shards, streams):
+                    with torch.cuda.stream(st):
+                        act = e.policy_actions(policy)
+                        if events is not None:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(st)
+                            e.step_async(act["stage_idx"], act["num_exec"])
+                            e1.record(st)
+                            events.append((e0, e1))
+                        else:
+                            e.step_async(act["stage_idx"], act["num_exec"])
         else:
             done = 0
             while done < n_steps:
                 n = min(args.fused_chunk, n_steps - done)
-                if events is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    env.rollout(policy, n)
-                    e1.record()
-                    events.append((e0, e1))
-                else:
-                    env.rollout(policy, n)
+                for e, st in zip(shards, streams):
+                    with torch.cuda.stream(st):
+                        if events is not None:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(st)
+                            e.rollout(policy, n)
+                            e1.record(st)
+                            events.append((e0, e1))
+                        else:
+                            e.rollout(policy, n)
                 done += n
 
     def measure(mode: str) -> dict:
@@ -235,6 +274,7 @@ def main() -> None:
         return {
             "value": steps_all / dt_max,
             "ms_per_step": dt_max / args.steps * 1e3,
+            "launches_per_step": launches_all / world / args.steps if mode == "step" else launches_all / world / max(1, (args.steps + args.fused_chunk - 1) // args.fused_chunk),
             "events_per_s": evs_all / dt_max,
             "events_per_step": evs_all / max(1.0, steps_all),
             "fast_path_event_frac": fast_all / max(1.0, evs_all),
@@ -280,6 +320,7 @@ def main() -> None:
                             f"job_arrival_rate {cfg['job_arrival_rate']}/ms, synthetic frozen trace set), on-device '{policy}' policy, "
                             f"auto-reset, mode={args.mode} ({'sss_policy + sss_step per batched step' if args.mode == 'step' else 'sss_rollout, ' + str(args.fused_chunk) + ' steps per launch'})",
                 "envs_per_gpu": B, "policy": policy, "mode": args.mode, "parallelism": f"env-shard x{world}",
+                "streams_per_gpu": S,
             },
             "events_per_s": primary["events_per_s"],
             "events_per_step": primary["events_per_step"],
