@@ -93,6 +93,16 @@ SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
+// value of lane `l` (wave-uniform index) on every lane
+SSS_DEV uint32_t wave_readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+SSS_DEV double wave_readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// read-modify-write used when several lanes commit to the same record in one step
+SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { atomicAdd(p, v); }
+SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+
 // exclusive prefix sum over lanes
 SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
   uint32_t x = v;
