@@ -1,0 +1,84 @@
+"""shared by the emulator and GPU Decima tests: replays a decima_*.npz fixture on a batched env
+(one env per recorded seed) and compares every recorded step."""
+import os.path as osp
+
+import numpy as np
+import torch
+
+from spark_sched_sim_amd import VecSparkSchedSimEnv
+from spark_sched_sim_amd.decima import DecimaPolicy, decima_observation
+
+HERE = osp.dirname(osp.abspath(__file__))
+AGENT = dict(embed_dim=16,
+             gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(inplace=True, negative_slope=0.2)),
+             policy_mlp_kwargs=dict(hid_dims=[64, 64], act_cls="Tanh"))
+SCORE_ATOL = 2e-5
+
+
+def check_decima_fixture(name, device, lib, n_steps, levels="auto"):
+    g = np.load(osp.join(HERE, "golden", f"{name}.npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    cfg["num_executors"] = int(cfg["num_executors"])
+    cfg["job_arrival_cap"] = int(cfg["job_arrival_cap"])
+    seeds = [int(s) for s in g["seeds"]]
+    E = cfg["num_executors"]
+    env = VecSparkSchedSimEnv(cfg, len(seeds), device=device, _lib=lib)
+    dev = env.device
+    policy = DecimaPolicy(num_executors=E, **AGENT)
+    policy.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")})
+    policy = policy.to(dev).eval()
+    max_depth = env.dims.stage_stride
+    obs, _ = env.reset(seed=seeds)
+    acts = [g[f"s{s}_actions"] for s in seeds]
+    T = min(n_steps, min(len(a) for a in acts))
+    worst = 0.0
+    for t in range(T):
+        with torch.no_grad():
+            f = decima_observation(obs, E, max_depth, levels=None if levels == "auto" else levels)
+            h = policy.encode(f)
+            ss = policy.stage_scores(f, h)
+            A = f["job_valid"].shape[1]
+            es_all = [policy.exec_scores(f, h, torch.full((len(seeds),), j, dtype=torch.long, device=dev))
+                      for j in range(int(obs["n_jobs"].max()))]
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        for b, s in enumerate(seeds):
+            p = f"s{s}_t{t}_"
+            n = int(obs["n_nodes"][b]); ne = int(obs["n_edges"][b]); a = int(obs["n_jobs"][b])
+            assert n == g[p + "nodes"].shape[0] and a == len(g[p + "dag_ptr"]) - 1, (s, t)
+            assert np.array_equal(f["x"][b, :n].cpu().numpy().view(np.uint32), g[p + "nodes"].view(np.uint32)), (s, t, "features")
+            assert not f["x"][b, n:].any()
+            assert np.array_equal(f["stage_mask"][b, :n].cpu().numpy(), g[p + "stage_mask"]), (s, t)
+            assert not f["stage_mask"][b, n:].any()
+            assert np.array_equal(f["exec_mask"][b, :a].cpu().numpy(), g[p + "exec_mask"]), (s, t)
+            assert np.array_equal(obs["edge_links"][b, :ne].cpu().numpy(), g[p + "edge_links"]), (s, t)
+            em = f["edge_masks"][:, b, :].cpu().numpy()
+            gm = g[p + "edge_masks"]
+            D = gm.shape[0]
+            assert int(f["depth"][b]) == D and bool(f["has_mp"][b]) == (D > 0), (s, t)
+            assert np.array_equal(em[:D, :ne], gm.reshape(D, ne)), (s, t, "edge masks")
+            assert not em[D:].any() and not em[:, ne:].any()
+            # scores
+            sm = g[p + "stage_mask"]
+            got = ss[b, :n].cpu().numpy()
+            assert np.all(np.isneginf(got[~sm]))
+            d = np.abs(got[sm] - g[p + "stage_scores"]).max() if sm.any() else 0.0
+            worst = max(worst, float(d))
+            assert d <= SCORE_ATOL, (s, t, "stage scores", d)
+            cnt = g[p + "exec_counts"]
+            off = np.concatenate([[0], np.cumsum(cnt)])
+            for j in range(a):
+                want = g[p + "exec_scores"][off[j]: off[j + 1]]
+                gj = es_all[j][b].cpu().numpy()
+                fin = np.isfinite(gj)
+                assert int(fin.sum()) == len(want) and np.array_equal(fin, g[p + "exec_mask"][j]), (s, t, j)
+                if len(want):
+                    d = np.abs(gj[fin] - want).max()
+                    worst = max(worst, float(d))
+                    assert d <= SCORE_ATOL, (s, t, j, "exec scores", d)
+        stage = torch.tensor([int(acts[b][t][0]) for b in range(len(seeds))], dtype=torch.int32, device=dev)
+        nexec = torch.tensor([int(acts[b][t][1]) for b in range(len(seeds))], dtype=torch.int32, device=dev)
+        obs, _, term, _, info = env.step({"stage_idx": stage, "num_exec": nexec})
+        env.raise_on_error()
+    env.close()
+    return worst
