@@ -15,7 +15,7 @@ AGENT = dict(embed_dim=16,
 SCORE_ATOL = 2e-5
 
 
-def check_decima_fixture(name, device, lib, n_steps, levels="auto"):
+def check_decima_fixture(name, device, lib, n_steps):
     g = np.load(osp.join(HERE, "golden", f"{name}.npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
     cfg["num_executors"] = int(cfg["num_executors"])
@@ -34,7 +34,7 @@ def check_decima_fixture(name, device, lib, n_steps, levels="auto"):
     worst = 0.0
     for t in range(T):
         with torch.no_grad():
-            f = decima_observation(obs, E, max_depth, levels=None if levels == "auto" else levels)
+            f = decima_observation(obs, E, max_depth, edge_masks=True)
             h = policy.encode(f)
             ss = policy.stage_scores(f, h)
             A = f["job_valid"].shape[1]

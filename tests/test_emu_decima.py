@@ -14,13 +14,6 @@ def test_decima_features_and_scores_match_reference(name, n_steps):
     check_decima_fixture(name, "cpu", load_emu(), n_steps)
 
 
-def test_fixed_level_count_is_equivalent():
-    """levels=<bound> (no device->host sync in the loop) must give the same result as the
-    data-dependent level count: extra levels are empty"""
-    from spark_sched_sim_amd import VecSparkSchedSimEnv  # noqa: F401
-    check_decima_fixture("decima_c1", "cpu", load_emu(), 12, levels=20)
-
-
 def test_sampled_actions_are_always_valid():
     """Decima in the loop: sampled (stage, executor count) pairs drive 6 envs for 150 steps
     without a single rejected action, and the log-probabilities are finite"""

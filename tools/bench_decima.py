@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--levels", type=int, default=-1, help="-1: data-dependent (one sync per step)")
     a = ap.parse_args()
     cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
     env = VecSparkSchedSimEnv(cfg, a.envs, device="cuda:0", auto_reset=True)
@@ -31,18 +30,17 @@ def main():
     policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval()
     gen = torch.Generator(device="cuda:0").manual_seed(1)
     obs, _ = env.reset(seed=0)
-    lv = None if a.levels < 0 else a.levels
     t_pol = 0.0
     for i in range(a.warmup + a.steps):
         if i == a.warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        act, _ = policy.schedule_batch(obs, env.dims.stage_stride, generator=gen, levels=lv)
+        act, _ = policy.schedule_batch(obs, env.dims.stage_stride, generator=gen)
         obs, *_ = env.step(act)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"metric": "env-steps/s with Decima in the loop", "value": a.envs * a.steps / dt, "envs": a.envs,
-                      "ms_per_step": 1e3 * dt / a.steps, "levels": a.levels, "err_envs": int((obs["err"] != 0).sum())}))
+                      "ms_per_step": 1e3 * dt / a.steps, "err_envs": int((obs["err"] != 0).sum())}))
 
 
 if __name__ == "__main__":
