@@ -94,7 +94,11 @@ int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double* time_limit
 /* Replaces SparkSchedSimEnv.step(action) (spark_sched_sim.py:188-221) for all envs:
  * action = {"stage_idx": stage_idx_dev[i], "num_exec": num_exec_dev[i]}. Writes reward, wall_time,
  * terminated, err and the next observation. auto_reset != 0: an env found terminated at entry
- * starts its next episode instead (seed = previous seed + seed_stride), reward 0. */
+ * starts its next episode instead (seed = previous seed + seed_stride), reward 0.
+ * stage_idx_dev[i] == SSS_SKIP_ENV leaves env i completely untouched (state, outputs, counters):
+ * how a rollout collector freezes envs whose episode was truncated by a wrapper
+ * (wrappers/stochastic_time_limit.py:26-31) while the rest of the batch keeps stepping. */
+#define SSS_SKIP_ENV (-2147483647 - 1)
 int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, void* stream);
 
 /* On-device counterparts of the reference's heuristic Scheduler plugins; they fill one action per

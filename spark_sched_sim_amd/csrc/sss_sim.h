@@ -20,6 +20,7 @@
 // No oracle code is used here: this is an independent implementation on different data
 // structures (bit masks, flat slot arrays, fixed-capacity set images); tests compare the two.
 #pragma once
+#include "../../include/sss.h"
 #include "sss_layout.h"
 #include <wave_rt.h>  // csrc/wave_rt.h (gfx950) or tests/emu/wave_rt.h (CPU emulator), chosen by -I order
 
@@ -1843,6 +1844,7 @@ SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const d
 // episode instead (seed += seed_stride), like a vector env in "next-step" autoreset mode
 SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
   int env = wave_env();
+  if (stage_idx[env] == SSS_SKIP_ENV) return;  // wave-uniform: the env is not touched at all
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   ctx_init(base, a.L, a.P, a.pk);
   env_begin(base);

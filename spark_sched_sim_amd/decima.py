@@ -6,9 +6,12 @@ trip: the env's observation tensors are consumed where they are (device, padded 
 
 This is the first "next" row of SURVEY 8(f); the simulator itself does not depend on it.
 
-Layout: everything is padded per env to the env's capacities (N = node_cap, A = job_cap,
-Ed = edge_cap); validity comes from `n_nodes / n_jobs / n_edges`. `DecimaPolicy`'s parameter names
-match the reference's `DecimaScheduler.state_dict()` so its checkpoints load unchanged.
+Layout: `decima_observation` works on the env's own tensors, padded per env to the env's capacities
+(N = node_cap, A = job_cap, Ed = edge_cap; validity from `n_nodes / n_jobs / n_edges`).
+`compact_graph` then drops the padding: a batch of observations becomes ONE flat graph (nodes, jobs
+and edges of all observations back to back, like the reference's `collate_obsns`), which is what
+the GNN runs on and what `GraphArena` stores for training. `DecimaPolicy`'s parameter names match
+the reference's `DecimaScheduler.state_dict()` so its checkpoints load unchanged.
 """
 from __future__ import annotations
 
@@ -112,30 +115,100 @@ def decima_observation(obs, num_executors: int, max_depth: int, num_tasks_scale:
     return out
 
 
+def _excl_cumsum(v: torch.Tensor) -> torch.Tensor:
+    return torch.cumsum(v, 0) - v
+
+
 def compact_graph(f: dict[str, torch.Tensor]) -> dict[str, Any]:
     """the batch as ONE graph over the valid nodes only (what `collate_obsns` / PyG batching does in
-    the reference, decima/utils.py:117-160): flat node features, global node / job ids, flat edge
-    endpoints, and for every DAG layer the list of edges in that layer's mask. Padding never reaches
-    the MLPs. Costs a handful of device->host syncs (sizes of the index lists)."""
+    the reference, decima/utils.py:117-204). Flat tensors, M nodes / J jobs / Ed edges in total:
+    x f32[M,5], node_obs / node_loc / node_job / gen i64[M] (observation, position inside it, global
+    job id, topological generation), stage_mask bool[M], src / dst i64[Ed] (global node ids),
+    edge_obs i64[Ed], job_obs i64[J], job_cap i64[J] (allowed executor counts = 1..cap),
+    job_first i64[J] (global id of the job's first node), n_obs, obs_nodes i64[n_obs],
+    obs_depth i64[n_obs]. Padding never reaches the MLPs. Costs a few device->host syncs (sizes)."""
     x = f["x"]
-    B, N, _ = x.shape
-    A = f["job_valid"].shape[1]
+    B = x.shape[0]
     env_n, loc_n = f["node_valid"].nonzero(as_tuple=True)
-    off = torch.cumsum(f["n_nodes"], 0) - f["n_nodes"]
+    env_j, loc_j = f["job_valid"].nonzero(as_tuple=True)
     env_e, loc_e = f["edge_valid"].nonzero(as_tuple=True)
-    src = off[env_e] + f["edge_src"][env_e, loc_e]
-    dst = off[env_e] + f["edge_dst"][env_e, loc_e]
-    gen = f["gen"][env_n, loc_n]
-    M = env_n.numel()
-    depth = int(gen.max()) if M else 0
-    layers = []
-    for lvl in range(depth):
-        in_m = gen == lvl
-        hit = torch.zeros(M, dtype=torch.int32, device=x.device).index_add_(0, dst, in_m[src].to(torch.int32))
-        in_m = in_m | (hit > 0)
-        layers.append((in_m[src] & in_m[dst]).nonzero(as_tuple=True)[0])
-    return {"x": x[env_n, loc_n], "env": env_n, "loc": loc_n, "job": env_n * A + f["node_job"][env_n, loc_n],
-            "src": src, "dst": dst, "layers": layers, "has_mp": f["has_mp"][env_n], "B": B, "N": N, "A": A}
+    n_nodes = f["n_nodes"]
+    node_off = _excl_cumsum(n_nodes)
+    job_off = _excl_cumsum(f["job_valid"].sum(1))
+    return {"x": x[env_n, loc_n], "node_obs": env_n, "node_loc": loc_n,
+            "node_job": job_off[env_n] + f["node_job"][env_n, loc_n], "gen": f["gen"][env_n, loc_n],
+            "stage_mask": f["stage_mask"][env_n, loc_n],
+            "src": node_off[env_e] + f["edge_src"][env_e, loc_e], "dst": node_off[env_e] + f["edge_dst"][env_e, loc_e],
+            "edge_obs": env_e, "job_obs": env_j, "job_cap": f["commit_caps"][env_j, loc_j],
+            "job_first": node_off[env_j] + f["dag_start"][env_j, loc_j], "n_obs": B,
+            "obs_nodes": n_nodes, "obs_jobs": f["job_valid"].sum(1), "obs_depth": f["depth"]}
+
+
+def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
+    """for every DAG layer l (decima/utils.py:249-267): (ids of the edges whose two ends lie in
+    (generation l) U (its successors) - the reference's `edge_masks[l]` as an index list, ids of the
+    nodes that are the source end of one of them - the nodes the layer updates)"""
+    if "layers" not in g:
+        gen, src, dst = g["gen"], g["src"], g["dst"]
+        M = gen.numel()
+        depth = int(gen.max()) if M else 0
+        layers = []
+        for lvl in range(depth):
+            in_m = gen == lvl
+            hit = torch.zeros(M, dtype=torch.int32, device=gen.device).index_add_(0, dst, in_m[src].to(torch.int32))
+            in_m = in_m | (hit > 0)
+            e = (in_m[src] & in_m[dst]).nonzero(as_tuple=True)[0]
+            recv = torch.zeros(M, dtype=torch.bool, device=gen.device).index_fill_(0, src[e], True).nonzero(as_tuple=True)[0]
+            layers.append((e, recv))
+        g["layers"] = layers
+    return g["layers"]
+
+
+def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, Any]:
+    """the sub-batch made of observations `obs_idx` (i64[k], in that order) of a compact graph,
+    re-labelled - a PPO minibatch out of a `GraphArena`"""
+    dev = g["x"].device
+    n_obs = g["n_obs"]
+    new_of_old = torch.full((n_obs,), -1, dtype=torch.long, device=dev)
+    new_of_old[obs_idx] = torch.arange(obs_idx.numel(), device=dev)
+
+    def pick(owner):  # members of the selected observations, grouped by new observation id (stable)
+        new_owner = new_of_old[owner]
+        keep = (new_owner >= 0).nonzero(as_tuple=True)[0]
+        order = torch.sort(new_owner[keep], stable=True)[1]
+        return keep[order]
+
+    kn, kj, ke = pick(g["node_obs"]), pick(g["job_obs"]), pick(g["edge_obs"])
+    node_new = torch.full((g["x"].shape[0],), -1, dtype=torch.long, device=dev)
+    node_new[kn] = torch.arange(kn.numel(), device=dev)
+    job_new = torch.full((g["job_obs"].numel(),), -1, dtype=torch.long, device=dev)
+    job_new[kj] = torch.arange(kj.numel(), device=dev)
+    return {"x": g["x"][kn], "node_obs": new_of_old[g["node_obs"][kn]], "node_loc": g["node_loc"][kn],
+            "node_job": job_new[g["node_job"][kn]], "gen": g["gen"][kn], "stage_mask": g["stage_mask"][kn],
+            "src": node_new[g["src"][ke]], "dst": node_new[g["dst"][ke]], "edge_obs": new_of_old[g["edge_obs"][ke]],
+            "job_obs": new_of_old[g["job_obs"][kj]], "job_cap": g["job_cap"][kj], "job_first": node_new[g["job_first"][kj]],
+            "n_obs": int(obs_idx.numel()), "obs_nodes": g["obs_nodes"][obs_idx], "obs_jobs": g["obs_jobs"][obs_idx],
+            "obs_depth": g["obs_depth"][obs_idx]}
+
+
+def concat_graphs(gs: list[dict[str, Any]]) -> dict[str, Any]:
+    """observations of several compact graphs back to back (ids shifted)"""
+    out: dict[str, Any] = {}
+    n_off = j_off = o_off = 0
+    parts: dict[str, list] = {k: [] for k in ("x", "node_obs", "node_loc", "node_job", "gen", "stage_mask", "src", "dst",
+                                             "edge_obs", "job_obs", "job_cap", "job_first", "obs_nodes", "obs_jobs", "obs_depth")}
+    for g in gs:
+        shift = {"node_obs": o_off, "edge_obs": o_off, "job_obs": o_off, "node_job": j_off, "src": n_off, "dst": n_off,
+                 "job_first": n_off}
+        for k in parts:
+            parts[k].append(g[k] + shift[k] if k in shift else g[k])
+        n_off += g["x"].shape[0]
+        j_off += g["job_obs"].numel()
+        o_off += g["n_obs"]
+    for k, v in parts.items():
+        out[k] = torch.cat(v)
+    out["n_obs"] = o_off
+    return out
 
 
 def make_mlp(input_dim: int, hid_dims: list[int], output_dim: int, act_cls: str, act_kwargs: dict[str, Any] | None = None) -> nn.Sequential:
@@ -161,26 +234,32 @@ class _NodeEncoder(nn.Module):
         self.mlp_msg = make_mlp(emb, output_dim=emb, **mlp_kwargs)
         self.mlp_update = make_mlp(emb, output_dim=emb, **mlp_kwargs)
 
-    def forward(self, g: dict[str, Any]) -> torch.Tensor:
+    def forward(self, g: dict[str, Any], per_obs_skip: bool) -> torch.Tensor:
         """child -> parent ("reverse flow") message passing one DAG layer at a time, deepest layer
-        first (scheduler.py:192-236). Per layer only the edges of that layer are touched: messages
-        are evaluated per edge (a child with two parents in the layer is evaluated twice - in-degree
-        is small) and the update is evaluated per edge source and written back (duplicates write the
-        same value)."""
+        first (scheduler.py:192-236). Per layer only that layer's edges and receiving nodes are
+        touched: messages are evaluated per edge (a child with two parents in the layer is evaluated
+        twice - in-degree is small), the update once per receiving node.
+
+        A graph with a single DAG layer gets `mlp_prep` only (scheduler.py:196-198, 238-243). The
+        reference applies that test to whatever it is given: one observation when scheduling, the
+        whole collated batch when training. `per_obs_skip` selects the former for every observation
+        of the batch independently (batched inference == the reference's one-at-a-time inference)."""
         x, src, dst = g["x"], g["src"], g["dst"]
         M = x.shape[0]
         h_init = self.mlp_prep(x)
-        if not g["layers"]:
-            return h_init  # every observation is a single layer: mlp_prep only (scheduler.py:238-243)
+        layers = graph_layers(g)
+        if not layers:
+            return h_init
         # nodes that are never the source end of an edge start from update(h_init), the rest from 0
         is_parent = torch.zeros(M, dtype=torch.bool, device=x.device).index_fill_(0, src, True)
         h = torch.where(is_parent[:, None], torch.zeros_like(h_init), self.mlp_update(h_init))
-        for e in reversed(g["layers"]):
-            s_e, d_e = src[e], dst[e]
-            msg = self.mlp_msg(h[d_e])
-            agg = torch.zeros_like(h_init).index_add_(0, s_e, msg)
-            h = h.index_copy(0, s_e, h_init[s_e] + self.mlp_update(agg[s_e]))
-        return torch.where(g["has_mp"][:, None], h, h_init)
+        for e, recv in reversed(layers):
+            msg = self.mlp_msg(h[dst[e]])
+            agg = torch.zeros_like(h_init).index_add_(0, src[e], msg)
+            h = h.index_copy(0, recv, h_init[recv] + self.mlp_update(agg[recv]))
+        if per_obs_skip:
+            h = torch.where((g["obs_depth"] > 0)[g["node_obs"]][:, None], h, h_init)
+        return h
 
 
 class _DagEncoder(nn.Module):
@@ -189,10 +268,9 @@ class _DagEncoder(nn.Module):
         self.mlp = make_mlp(nf + emb, output_dim=emb, **mlp_kwargs)
 
     def forward(self, h_node: torch.Tensor, g: dict[str, Any]) -> torch.Tensor:
-        """per-job sums (scheduler.py:246-262), returned padded f32[B,A,emb] (zeros for padding)"""
+        """per-job sums f32[J,emb] (scheduler.py:246-262)"""
         y = self.mlp(torch.cat([g["x"], h_node], -1))
-        out = torch.zeros((g["B"] * g["A"], y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, g["job"], y)
-        return out.view(g["B"], g["A"], -1)
+        return torch.zeros((g["job_obs"].numel(), y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, g["node_job"], y)
 
 
 class _GlobalEncoder(nn.Module):
@@ -200,8 +278,10 @@ class _GlobalEncoder(nn.Module):
         super().__init__()
         self.mlp = make_mlp(emb, output_dim=emb, **mlp_kwargs)
 
-    def forward(self, h_dag: torch.Tensor, job_valid: torch.Tensor) -> torch.Tensor:
-        return (self.mlp(h_dag) * job_valid[..., None]).sum(1)
+    def forward(self, h_dag: torch.Tensor, g: dict[str, Any]) -> torch.Tensor:
+        """per-observation sums f32[n_obs,emb] (scheduler.py:265-283)"""
+        y = self.mlp(h_dag)
+        return torch.zeros((g["n_obs"], y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, g["job_obs"], y)
 
 
 class _Encoder(nn.Module):
@@ -218,14 +298,29 @@ class _ScoreNet(nn.Module):
         self.mlp_score = make_mlp(input_dim, output_dim=1, **mlp_kwargs)
 
 
+def _segment_log_softmax(scores: torch.Tensor, owner: torch.Tensor, n_seg: int):
+    """(probs clamped like torch.distributions' clamp_probs, their logs) of a softmax taken inside
+    each segment - the reference's `utils.evaluate` (decima/utils.py:26-41)"""
+    mx = torch.full((n_seg,), float("-inf"), dtype=scores.dtype, device=scores.device).scatter_reduce(0, owner, scores.detach(), "amax")
+    ex = (scores - mx[owner]).exp()
+    den = torch.zeros(n_seg, dtype=scores.dtype, device=scores.device).index_add_(0, owner, ex)
+    probs = ex / (den[owner] + 1e-16)
+    eps = torch.finfo(probs.dtype).eps
+    probs = probs.clamp(min=eps, max=1 - eps)
+    return probs, probs.log()
+
+
 class DecimaPolicy(nn.Module):
-    """the reference's Decima architecture (scheduler.py:16-99) with batched-over-envs inference"""
+    """the reference's Decima architecture and trainable-scheduler surface (scheduler.py:16-139),
+    evaluated over a batch of observations at once"""
 
     def __init__(self, num_executors: int, embed_dim: int, gnn_mlp_kwargs: dict[str, Any], policy_mlp_kwargs: dict[str, Any],
-                 state_dict_path: str | None = None, **_unused):
+                 state_dict_path: str | None = None, opt_cls: str | None = None, opt_kwargs: dict[str, Any] | None = None,
+                 max_grad_norm: float | None = None, **_unused):
         super().__init__()
         self.name = "Decima"
         self.num_executors = num_executors
+        self.max_grad_norm = max_grad_norm
         self.encoder = _Encoder(NUM_NODE_FEATURES, embed_dim, gnn_mlp_kwargs)
         self.stage_policy_network = _ScoreNet(NUM_NODE_FEATURES + 3 * embed_dim, policy_mlp_kwargs)
         self.exec_policy_network = _ScoreNet(NUM_DAG_FEATURES + 2 * embed_dim + 1, policy_mlp_kwargs)
@@ -234,58 +329,106 @@ class DecimaPolicy(nn.Module):
                 p.data.zero_()
         if state_dict_path:
             self.load_state_dict(torch.load(state_dict_path, map_location="cpu"))
+        self.optim = getattr(torch.optim, opt_cls)(self.parameters(), **(opt_kwargs or {})) if opt_cls else None
 
-    def encode(self, f: dict[str, torch.Tensor], g: dict[str, Any] | None = None) -> dict[str, Any]:
-        g = g if g is not None else compact_graph(f)
-        h_node = self.encoder.node_encoder(g)
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def encode(self, g: dict[str, Any], per_obs_skip: bool = True) -> dict[str, torch.Tensor]:
+        h_node = self.encoder.node_encoder(g, per_obs_skip)
         h_dag = self.encoder.dag_encoder(h_node, g)
-        h_glob = self.encoder.global_encoder(h_dag, f["job_valid"])
-        return {"node": h_node, "dag": h_dag, "glob": h_glob, "graph": g}
+        h_glob = self.encoder.global_encoder(h_dag, g)
+        return {"node": h_node, "dag": h_dag, "glob": h_glob}
 
-    def stage_scores(self, f: dict[str, torch.Tensor], h: dict[str, Any]) -> torch.Tensor:
-        """f32[B,N]; -inf where the node is not a schedulable stage (scheduler.py:289-318)"""
-        g = h["graph"]
-        h_dag_n = h["dag"].view(g["B"] * g["A"], -1)[g["job"]]
-        inp = torch.cat([g["x"], h["node"], h_dag_n, h["glob"][g["env"]]], -1)
-        s = self.stage_policy_network.mlp_score(inp).squeeze(-1)
-        out = torch.full((g["B"], g["N"]), float("-inf"), dtype=s.dtype, device=s.device)
-        sm = f["stage_mask"][g["env"], g["loc"]]
-        return out.index_put((g["env"][sm], g["loc"][sm]), s[sm])
+    def stage_scores(self, g: dict[str, Any], h: dict[str, torch.Tensor]):
+        """scores of the schedulable stages only (scheduler.py:289-318): (f32[S], global node ids i64[S])"""
+        idx = g["stage_mask"].nonzero(as_tuple=True)[0]
+        inp = torch.cat([g["x"][idx], h["node"][idx], h["dag"][g["node_job"][idx]], h["glob"][g["node_obs"][idx]]], -1)
+        return self.stage_policy_network.mlp_score(inp).squeeze(-1), idx
 
-    def exec_scores(self, f: dict[str, torch.Tensor], h: dict[str, torch.Tensor], job_idx: torch.Tensor) -> torch.Tensor:
-        """f32[B,E]; -inf where the executor count is not allowed for the job (scheduler.py:337-385)"""
-        B, N, _ = f["x"].shape
+    def exec_scores(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
+        """f32[k,E] for jobs `job_gid` (global job ids, i64[k]); entry e scores "e+1 executors"; -inf
+        where that count is not allowed for the job (scheduler.py:337-385)"""
         E = self.num_executors
-        start = f["dag_start"].gather(1, job_idx[:, None]).clamp(max=N - 1)
-        x_dag = f["x"].gather(1, start[..., None].expand(-1, -1, NUM_NODE_FEATURES))[:, 0, :NUM_DAG_FEATURES]
-        h_dag = h["dag"].gather(1, job_idx[:, None, None].expand(-1, -1, h["dag"].shape[-1]))[:, 0]
-        base = torch.cat([x_dag, h_dag, h["glob"]], -1)
+        base = torch.cat([g["x"][g["job_first"][job_gid], :NUM_DAG_FEATURES], h["dag"][job_gid], h["glob"][g["job_obs"][job_gid]]], -1)
         acts = (torch.arange(E, device=base.device) / E).to(base.dtype)
-        inp = torch.cat([base[:, None, :].expand(-1, E, -1), acts[None, :, None].expand(B, -1, -1)], -1)
+        inp = torch.cat([base[:, None, :].expand(-1, E, -1), acts[None, :, None].expand(base.shape[0], -1, -1)], -1)
         s = self.exec_policy_network.mlp_score(inp).squeeze(-1)
-        mask = f["exec_mask"].gather(1, job_idx[:, None, None].expand(-1, -1, E))[:, 0]
+        mask = torch.arange(E, device=base.device)[None, :] < g["job_cap"][job_gid][:, None]
         return torch.where(mask, s, torch.full_like(s, float("-inf")))
 
     @torch.no_grad()
-    def schedule_batch(self, obs, max_depth: int, generator: torch.Generator | None = None):
-        """one action per env: a stage sampled from softmax(stage scores), then an executor count
-        sampled from softmax(exec scores of that stage's job) (scheduler.py:71-99). Returns
-        ({"stage_idx": i32[B], "num_exec": i32[B]}, {"lgprob": f32[B], "job_idx": i64[B]})."""
-        f = decima_observation(obs, self.num_executors, max_depth)
-        h = self.encode(f)
-        ss = self.stage_scores(f, h)
-        any_stage = f["stage_mask"].any(1)
-        ss_safe = torch.where(any_stage[:, None], ss, torch.zeros_like(ss))
-        p = torch.softmax(ss_safe, 1)
+    def act(self, f: dict[str, torch.Tensor], g: dict[str, Any], generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:
+        """samples one Decima action per observation (scheduler.py:71-99): a stage from
+        softmax(stage scores), then an executor count from softmax(exec scores of that stage's job).
+        Returns the reference's action tuple entries `stage_sel` (index among the observation's
+        schedulable stages), `job_idx` (job slot), `exec_sel` (executor count - 1), `lgprob`, and
+        `any_stage` (False where nothing is schedulable; the other entries are then meaningless)."""
+        B, N = f["x"].shape[:2]
+        h = self.encode(g)
+        s, idx = self.stage_scores(g, h)
+        padded = torch.full((B, N), float("-inf"), dtype=s.dtype, device=s.device)
+        padded[g["node_obs"][idx], g["node_loc"][idx]] = s
+        any_stage = torch.isfinite(padded).any(1)
+        p = torch.softmax(torch.where(any_stage[:, None], padded, torch.zeros_like(padded)), 1)
         node = torch.multinomial(p, 1, generator=generator)[:, 0]
-        stage_idx = f["stage_mask"].long().cumsum(1).gather(1, node[:, None])[:, 0] - 1
-        job = f["node_job"].gather(1, node[:, None])[:, 0].clamp(max=f["job_valid"].shape[1] - 1)
-        es = self.exec_scores(f, h, job)
-        any_exec = torch.isfinite(es).any(1)
-        es_safe = torch.where(any_exec[:, None], es, torch.zeros_like(es))
-        pe = torch.softmax(es_safe, 1)
+        stage_sel = f["stage_mask"].long().cumsum(1).gather(1, node[:, None])[:, 0] - 1
+        job_slot = f["node_job"].gather(1, node[:, None])[:, 0].clamp(max=f["job_valid"].shape[1] - 1)
+        has_jobs = g["obs_jobs"] > 0
+        job_gid = (_excl_cumsum(g["obs_jobs"]) + torch.where(has_jobs, job_slot, torch.zeros_like(job_slot)))
+        job_gid = job_gid.clamp(max=max(g["job_obs"].numel() - 1, 0))
+        if g["job_obs"].numel():
+            es = self.exec_scores(g, h, job_gid)
+        else:
+            es = torch.full((B, self.num_executors), float("-inf"), dtype=s.dtype, device=s.device)
+        any_exec = torch.isfinite(es).any(1) & has_jobs
+        pe = torch.softmax(torch.where(any_exec[:, None], es, torch.zeros_like(es)), 1)
         k = torch.multinomial(pe, 1, generator=generator)[:, 0]
         lg = torch.log(p.gather(1, node[:, None])[:, 0]) + torch.log(pe.gather(1, k[:, None])[:, 0])
-        stage_idx = torch.where(any_stage, stage_idx, torch.full_like(stage_idx, -1))
-        return ({"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + k).to(torch.int32)},
-                {"lgprob": lg, "job_idx": job})
+        return {"stage_sel": stage_sel, "job_idx": job_slot, "exec_sel": k, "lgprob": lg, "any_stage": any_stage}
+
+    @torch.no_grad()
+    def schedule_batch(self, obs, max_depth: int, generator: torch.Generator | None = None):
+        """observation transform + `act` for every env of a batched observation. Returns
+        ({"stage_idx": i32[B], "num_exec": i32[B]} for `VecSparkSchedSimEnv.step`, the `act` dict).
+        Envs without a schedulable stage get stage_idx -1."""
+        f = decima_observation(obs, self.num_executors, max_depth)
+        a = self.act(f, compact_graph(f), generator)
+        stage_idx = torch.where(a["any_stage"], a["stage_sel"], torch.full_like(a["stage_sel"], -1))
+        return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}, a
+
+    def evaluate_actions(self, g: dict[str, Any], stage_sel: torch.Tensor, job_idx: torch.Tensor, exec_sel: torch.Tensor):
+        """log-probabilities and normalised entropies of recorded actions under the current
+        parameters, with gradients (scheduler.py:101-139): `stage_sel` = index among the
+        observation's schedulable stages, `job_idx` = job slot inside the observation, `exec_sel` =
+        index among the allowed executor counts. Returns {"lgprobs": f32[n_obs], "entropies": f32[n_obs]}."""
+        n_obs = g["n_obs"]
+        h = self.encode(g, per_obs_skip=False)
+        s, idx = self.stage_scores(g, h)
+        owner = g["node_obs"][idx]
+        p, lp = _segment_log_softmax(s, owner, n_obs)
+        n_acts = torch.zeros(n_obs, dtype=torch.long, device=s.device).index_add_(0, owner, torch.ones_like(owner))
+        stage_lg = lp[_excl_cumsum(n_acts) + stage_sel]
+        stage_ent = -torch.zeros(n_obs, dtype=s.dtype, device=s.device).index_add_(0, owner, lp * p)
+        job_gid = _excl_cumsum(g["obs_jobs"]) + job_idx
+        es = self.exec_scores(g, h, job_gid)
+        allowed = torch.isfinite(es)
+        pe = torch.softmax(es, 1)
+        eps = torch.finfo(pe.dtype).eps
+        pe = torch.where(allowed, pe.clamp(min=eps, max=1 - eps), torch.ones_like(pe))
+        lpe = pe.log()
+        exec_lg = lpe.gather(1, exec_sel[:, None])[:, 0]
+        exec_ent = -(lpe * pe * allowed).sum(1)
+        norm = (self.num_executors * g["obs_nodes"]).to(s.dtype).log()
+        return {"lgprobs": stage_lg + exec_lg, "entropies": (stage_ent + exec_ent) / norm}
+
+    def update_parameters(self, loss: torch.Tensor | None = None) -> None:
+        """scheduler.py (TrainableScheduler) :37-54: backward, clip, optimiser step, zero grads"""
+        assert self.optim
+        if loss is not None and bool(loss != 0):  # the reference tests `if loss:` (scheduler.py:40)
+            loss.backward()
+        if self.max_grad_norm:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), self.max_grad_norm, error_if_nonfinite=True)
+        self.optim.step()
+        self.optim.zero_grad()

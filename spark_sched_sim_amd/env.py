@@ -138,10 +138,7 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
 
     @property
     def job_duration_buff(self) -> list[float]:
-        d = self._vec.dims
-        h = self._vec.header(0)
-        ring = self._vec._env_view[0, d.off_dur_ring: d.off_dur_ring + 8 * 200].cpu().numpy().view(np.float64)
-        return [float(ring[(h["dur_head"] + i) % 200]) for i in range(h["dur_n"])]
+        return self._vec.job_duration_buff(0)
 
     @property
     def avg_job_duration(self) -> float:

@@ -1,0 +1,479 @@
+"""Rollout collection and PPO over the batched env.
+
+The reference trains with one OS process per env: a `RolloutWorker` loop per process
+(reference trainers/rollout_worker.py:118-206), a Pipe gather, then returns / baselines / the CLIP
+loss on the learner (trainers/trainer.py:171-216, trainers/utils/returns_calculator.py:45-76,
+trainers/utils/baselines.py:12-37, trainers/ppo.py:51-138). Here every "worker" is one env of a
+`VecSparkSchedSimEnv`, all envs advance together on the GPU, the recorded observations stay on the
+device as one compact graph (`decima.compact_graph`), and the per-rollout post-processing is a set
+of padded tensor ops. The arithmetic per element follows the reference's; tolerances are in the tests.
+
+Layout of a `Rollouts` record (T = longest rollout of the batch, B = envs): every per-step quantity
+is a [T, B] tensor and `active[t, b]` says whether env b recorded a step at position t (a rollout's
+steps are always a prefix). Observation (t, b) is observation id t*B + b of `graph`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Callable, Sequence
+
+import numpy as np
+import torch
+
+from .decima import compact_graph, concat_graphs, decima_observation, select_observations
+from .wrappers import VecStochasticTimeLimit
+
+SKIP_ENV = -(2 ** 31)  # include/sss.h SSS_SKIP_ENV
+EPS = 1e-8             # trainers/ppo.py:12
+
+
+@dataclass
+class Rollouts:
+    graph: dict[str, Any]
+    active: torch.Tensor        # bool[T,B]
+    t_before: torch.Tensor      # f64[T,B]  wall time (sync) / elapsed time (async) when the action was taken
+    t_after: torch.Tensor       # f64[T,B]  the same clock after the step
+    rewards: torch.Tensor       # f64[T,B]
+    stage_sel: torch.Tensor     # i64[T,B]
+    job_idx: torch.Tensor       # i64[T,B]
+    exec_sel: torch.Tensor      # i64[T,B]
+    lgprobs: torch.Tensor       # f32[T,B]
+    resets: torch.Tensor        # bool[T,B] (async: the env was reset right after this step)
+    stats: dict[str, np.ndarray] = field(default_factory=dict)
+
+    @property
+    def lengths(self) -> torch.Tensor:
+        return self.active.sum(0)
+
+    def rollout(self, b: int) -> dict[str, np.ndarray]:
+        """env b's record in the shape of the reference's `RolloutBuffer` (rollout_worker.py:18-45)"""
+        n = int(self.active[:, b].sum())
+        tb, ta = self.t_before[:n, b].cpu().numpy(), self.t_after[:n, b].cpu().numpy()
+        return {"wall_times": np.concatenate([tb, ta[-1:]]) if n else np.zeros(1),
+                "rewards": self.rewards[:n, b].cpu().numpy(),
+                "actions": torch.stack([self.stage_sel[:n, b], self.job_idx[:n, b], self.exec_sel[:n, b]], 1).cpu().numpy(),
+                "lgprobs": self.lgprobs[:n, b].cpu().numpy(),
+                "resets": self.resets[:n, b].nonzero(as_tuple=True)[0].cpu().numpy()}
+
+    def sample_ids(self) -> torch.Tensor:
+        """observation ids of all recorded steps in the reference's order (rollout-major:
+        `chain(*obsns_list)`, ppo.py:58-62)"""
+        T, B = self.active.shape
+        ids = (torch.arange(T, device=self.active.device)[:, None] * B + torch.arange(B, device=self.active.device)[None, :])
+        return ids.t()[self.active.t()]
+
+    def flat(self, x: torch.Tensor) -> torch.Tensor:
+        """a [T,B] quantity as the flat per-sample vector matching `sample_ids`"""
+        return x.t()[self.active.t()]
+
+
+ActFn = Callable[[Any, dict[str, torch.Tensor], dict[str, Any], torch.Tensor], dict[str, torch.Tensor]]
+
+
+class RolloutCollector:
+    """the reference's `RolloutWorkerSync` / `RolloutWorkerAsync` loops for all envs at once.
+
+    Env b plays worker rank b: seed of its k-th episode = base_seeds[b] + seed_step * k
+    (rollout_worker.py:118-120, trainer.py:264-269), time limit from `StochasticTimeLimit`'s rule.
+    `act_fn(obs, f, g, step_counts)` returns `DecimaPolicy.act`'s dict; the default samples from
+    `policy`. Envs that are done (sync) or have filled their duration (async) are frozen with
+    SSS_SKIP_ENV until the others catch up."""
+
+    def __init__(self, env, mean_time_limit: float, base_seeds: Sequence[int], seed_step: int, num_executors: int,
+                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None):
+        self.env = env
+        self.tl_env = VecStochasticTimeLimit(env, mean_time_limit)
+        self.base_seeds = np.asarray(base_seeds, dtype=np.int64)
+        assert self.base_seeds.shape == (env.num_envs,)
+        self.seed_step = int(seed_step)
+        self.reset_count = np.zeros(env.num_envs, dtype=np.int64)
+        self.step_counts = torch.zeros(env.num_envs, dtype=torch.long)
+        self.E = num_executors
+        self.max_depth = env.dims.stage_stride
+        self.policy = policy
+        self.generator = generator
+        self.act_fn = act_fn or (lambda obs, f, g, n: policy.act(f, g, generator))
+        self._obs = None
+        self._wall = None
+
+    @property
+    def seeds(self) -> np.ndarray:
+        return self.base_seeds + self.seed_step * self.reset_count
+
+    def _reset(self, mask: torch.Tensor | None = None):
+        obs, _ = self.tl_env.reset(seed=[int(s) for s in self.seeds], mask=mask)
+        self.reset_count += 1 if mask is None else mask.cpu().numpy().astype(np.int64)
+        return obs
+
+    def _masked_graph(self, obs, active: torch.Tensor):
+        f = decima_observation(obs, self.E, self.max_depth)
+        keep = active[:, None]
+        for k in ("node_valid", "job_valid", "edge_valid", "stage_mask"):
+            f[k] = f[k] & keep
+        f["n_nodes"] = f["n_nodes"] * active
+        f["depth"] = f["depth"] * active
+        return f, compact_graph(f)
+
+    def _stats(self) -> dict[str, np.ndarray]:
+        """rollout_worker.py:122-130 for every env"""
+        from . import metrics
+        B = self.env.num_envs
+        out = {k: np.zeros(B) for k in ("avg_job_duration", "avg_num_jobs", "num_completed_jobs", "num_job_arrivals")}
+        for b in range(B):
+            h = self.env.header(b)
+            buff = self.env.job_duration_buff(b)
+            with np.errstate(all="ignore"):
+                out["avg_job_duration"][b] = np.mean(buff) * 1e-3 if buff else np.nan
+                out["avg_num_jobs"][b] = metrics.avg_num_jobs(self.env, b)
+            out["num_completed_jobs"][b] = h["n_completed"]
+            out["num_job_arrivals"][b] = h["n_completed"] + h["n_active"]
+        return out
+
+    def _loop(self, asynchronous: bool, duration: float, with_stats: bool) -> Rollouts:
+        env, dev, B = self.env, self.env.device, self.env.num_envs
+        if not asynchronous or self._obs is None:
+            self._obs = self._reset()
+            self._wall = torch.zeros(B, dtype=torch.float64, device=dev)
+        obs, wall = self._obs, self._wall
+        elapsed = torch.zeros(B, dtype=torch.float64, device=dev)
+        active = torch.ones(B, dtype=torch.bool, device=dev)
+        rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
+        while bool(active.any()):
+            f, g = self._masked_graph(obs, active)
+            a = self.act_fn(obs, f, g, self.step_counts)
+            self.step_counts += active.cpu().long()
+            stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
+            num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)
+            obs, rew, term, trunc, info = self.tl_env.step({"stage_idx": stage_idx.contiguous(), "num_exec": num_exec.contiguous()})
+            new_wall = torch.where(active, info["wall_time"], wall)
+            done = (term | trunc) & active
+            rec["g"].append(g)
+            rec["active"].append(active)
+            rec["rewards"].append(torch.where(active, rew, torch.zeros_like(rew)))
+            for k in ("stage_sel", "job_idx", "exec_sel"):
+                rec[k].append(a[k].clone())
+            rec["lgprobs"].append(a["lgprob"].float().clone())
+            if asynchronous:
+                rec["t_before"].append(elapsed)
+                elapsed = torch.where(active, elapsed + (new_wall - wall), elapsed)
+                rec["t_after"].append(elapsed)
+                rec["resets"].append(done)
+                if bool(done.any()):
+                    obs = self._reset(mask=done)
+                    new_wall = torch.where(done, torch.zeros_like(new_wall), new_wall)
+                active = active & (elapsed < duration)
+            else:
+                rec["t_before"].append(wall)
+                rec["t_after"].append(new_wall)
+                rec["resets"].append(torch.zeros_like(done))
+                active = active & ~done
+            wall = new_wall
+        self._obs, self._wall = obs, wall
+        st = lambda k: torch.stack(rec[k]) if rec[k] else torch.zeros((0, B), device=dev)  # noqa: E731
+        return Rollouts(graph=concat_graphs(rec["g"]), active=st("active"), t_before=st("t_before"), t_after=st("t_after"),
+                        rewards=st("rewards"), stage_sel=st("stage_sel"), job_idx=st("job_idx"), exec_sel=st("exec_sel"),
+                        lgprobs=st("lgprobs"), resets=st("resets"), stats=self._stats() if with_stats else {})
+
+    def collect_sync(self, with_stats: bool = True) -> Rollouts:
+        """one full episode per env (rollout_worker.py:133-159)"""
+        return self._loop(False, 0.0, with_stats)
+
+    def collect_async(self, rollout_duration: float, with_stats: bool = True) -> Rollouts:
+        """`rollout_duration` ms of simulated time per env, episodes restarting in place
+        (rollout_worker.py:162-206)"""
+        return self._loop(True, float(rollout_duration), with_stats)
+
+
+# ---- returns (trainers/utils/returns_calculator.py) -----------------------------------------------
+
+def discounted_returns(ro: Rollouts, beta: float) -> torch.Tensor:
+    """R_k = r_k + exp(-beta * 1e-3 * dt_k) * R_{k+1} per rollout (returns_calculator.py:67-76); f64[T,B]"""
+    T, B = ro.active.shape
+    dt = ro.t_after - ro.t_before
+    out = torch.zeros_like(ro.rewards)
+    R = torch.zeros(B, dtype=torch.float64, device=ro.rewards.device)
+    for k in range(T - 1, -1, -1):
+        R = torch.where(ro.active[k], ro.rewards[k] + torch.exp(-beta * 1e-3 * dt[k]) * R, R)
+        out[k] = R
+    return out * ro.active
+
+
+class DifferentialReturns:
+    """average-reward ("differential") returns with the moving estimate of the mean number of
+    concurrent jobs kept in a circular buffer of (dt, reward) rows (returns_calculator.py:6-65, 78-89)"""
+
+    def __init__(self, buff_cap: int):
+        self.cap = int(buff_cap)
+        self.data = np.zeros((self.cap, 2))
+        self.avg_num_jobs: float | None = None
+
+    def _extend(self, new: np.ndarray) -> None:
+        if new.shape[0] > self.cap:
+            new = new[-self.cap:]
+        keep = self.cap - new.shape[0]
+        if keep > 0:
+            self.data[:keep] = self.data[-keep:]
+        self.data[keep:] = new
+
+    def __call__(self, ro: Rollouts) -> torch.Tensor:
+        dt = ro.t_after - ro.t_before
+        rows = np.stack([ro.flat(dt).cpu().numpy(), ro.flat(ro.rewards).cpu().numpy()], 1)
+        self._extend(rows[rows[:, 0] > 0])
+        total_time, rew_sum = self.data.sum(0)
+        self.avg_num_jobs = -rew_sum / total_time
+        T, B = ro.active.shape
+        out = torch.zeros_like(ro.rewards)
+        R = torch.zeros(B, dtype=torch.float64, device=ro.rewards.device)
+        for k in range(T - 1, -1, -1):
+            # R = -(job_time - expected_job_time) + R with job_time = -r (returns_calculator.py:57-60)
+            R = torch.where(ro.active[k], -(-ro.rewards[k] - dt[k] * self.avg_num_jobs) + R, R)
+            out[k] = R
+        return out * ro.active
+
+
+# ---- baselines (trainers/utils/baselines.py) --------------------------------------------------------
+
+def _interp(x: torch.Tensor, xp: torch.Tensor, fp: torch.Tensor, n: torch.Tensor) -> torch.Tensor:
+    """numpy.interp along the last axis for batches: xp rows are non-decreasing with `n` valid
+    entries (the rest padding). Same case analysis as numpy's compiled_interp: clamp outside the
+    range, the LAST knot j with xp[j] <= x, exact hit -> fp[j], else slope * (x - xp[j]) + fp[j]."""
+    Tm = xp.shape[-1]
+    ar = torch.arange(Tm, device=xp.device)
+    xp_s = torch.where(ar < n[..., None], xp, torch.full_like(xp, float("inf")))
+    j = (torch.searchsorted(xp_s, x.contiguous(), right=True) - 1).clamp(min=0)
+    last = (n[..., None] - 1).expand_as(j)
+    j = torch.minimum(j, last)
+    j1 = torch.minimum(j + 1, last)
+    x0, x1, y0, y1 = xp.gather(-1, j), xp.gather(-1, j1), fp.gather(-1, j), fp.gather(-1, j1)
+    slope = (y1 - y0) / (x1 - x0)
+    v = slope * (x - x0) + y0
+    exact = (x == x0) | (j == last) | (x < x0)
+    return torch.where(exact, y0, v)
+
+
+def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, num_rollouts: int) -> torch.Tensor:
+    """for each group of `num_rollouts` consecutive envs (the rollouts of one job sequence) the mean
+    over the group's rollouts of their piecewise-linear value curves, evaluated at each rollout's own
+    step times (baselines.py:12-37; times = `wall_times[:-1]`, trainer.py:206-207). f64[T,B]"""
+    T, B = ro.active.shape
+    assert B == num_sequences * num_rollouts
+    G, R = num_sequences, num_rollouts
+    ts = ro.t_before.t().reshape(G, R, T)
+    ys = values.t().reshape(G, R, T)
+    n = ro.active.sum(0).reshape(G, R)
+    x = ts[:, :, None, :].expand(G, R, R, T)          # query: rollout i's times ...
+    xp = ts[:, None, :, :].expand(G, R, R, T)         # ... on rollout j's curve
+    fp = ys[:, None, :, :].expand(G, R, R, T)
+    nn = n[:, None, :].expand(G, R, R)
+    y_hat = _interp(x.contiguous(), xp.contiguous(), fp.contiguous(), nn.contiguous())
+    acc = torch.zeros((G, R, T), dtype=torch.float64, device=values.device)
+    for j in range(R):
+        acc = acc + y_hat[:, :, j, :]
+    return (acc / R).reshape(B, T).t() * ro.active
+
+
+# ---- PPO (trainers/ppo.py) ----------------------------------------------------------------------------
+
+def ppo_loss(policy, g: dict[str, Any], stage_sel, job_idx, exec_sel, advantages: torch.Tensor, old_lgprobs: torch.Tensor,
+             clip_range: float, entropy_coeff: float):
+    """the CLIP loss of ppo.py:104-138 on one minibatch (a compact graph + per-observation vectors)"""
+    res = policy.evaluate_actions(g, stage_sel, job_idx, exec_sel)
+    advgs = advantages.float()
+    advgs = (advgs - advgs.mean()) / (advgs.std() + EPS)
+    log_ratio = res["lgprobs"] - old_lgprobs
+    ratio = log_ratio.exp()
+    policy_loss = -torch.min(advgs * ratio, advgs * torch.clamp(ratio, 1 - clip_range, 1 + clip_range)).mean()
+    entropy_loss = -res["entropies"].mean()
+    loss = policy_loss + entropy_coeff * entropy_loss
+    with torch.no_grad():
+        approx_kl = ((ratio - 1) - log_ratio).mean()
+    return loss, {"policy_loss": policy_loss.detach(), "entropy_loss": entropy_loss.detach(), "approx_kl_div": approx_kl}
+
+
+class PPO:
+    """the reference's PPO trainer (trainers/ppo.py + the parts of trainers/trainer.py it uses) on
+    the batched env. With `torch.distributed` initialised every rank trains on its own env shard and
+    gradients are averaged across ranks before each optimiser step; the KL early-stop test uses the
+    all-rank mean so that every rank takes the same number of steps."""
+
+    def __init__(self, policy, train_cfg: dict[str, Any], generator: torch.Generator | None = None):
+        self.policy = policy
+        self.entropy_coeff = train_cfg.get("entropy_coeff", 0.0)
+        self.clip_range = train_cfg.get("clip_range", 0.2)
+        self.target_kl = train_cfg.get("target_kl", 0.01)
+        self.num_epochs = train_cfg.get("num_epochs", 10)
+        self.num_batches = train_cfg.get("num_batches", 3)
+        self.num_sequences = int(train_cfg["num_sequences"])
+        self.num_rollouts = int(train_cfg["num_rollouts"])
+        assert ("reward_buff_cap" in train_cfg) ^ ("beta_discount" in train_cfg), \
+            "must provide exactly one of `reward_buff_cap` and `beta_discount` in config"  # trainer.py:63-65
+        self.beta = train_cfg.get("beta_discount")
+        self.diff = DifferentialReturns(train_cfg["reward_buff_cap"]) if "reward_buff_cap" in train_cfg else None
+        self.generator = generator
+
+    def preprocess(self, ro: Rollouts):
+        returns = self.diff(ro) if self.diff is not None else discounted_returns(ro, self.beta)
+        baselines = sequence_baselines(ro, returns, self.num_sequences, self.num_rollouts)
+        return returns, baselines
+
+    def _dist(self):
+        import torch.distributed as dist
+        return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+    def train_on_rollouts(self, ro: Rollouts) -> dict[str, float]:
+        returns, baselines = self.preprocess(ro)
+        ids = ro.sample_ids()
+        advgs = ro.flat(returns - baselines)
+        acts = [ro.flat(ro.stage_sel), ro.flat(ro.job_idx), ro.flat(ro.exec_sel)]
+        old_lg = ro.flat(ro.lgprobs)
+        n = ids.numel()
+        bs = n // self.num_batches + 1
+        dist = self._dist()
+        pol, ent, kls = [], [], []
+        go = True
+        for _ in range(self.num_epochs):
+            if not go:
+                break
+            perm = torch.randperm(n, generator=self.generator, device=ids.device if self.generator is None or self.generator.device.type != "cpu" else "cpu").to(ids.device)
+            # single process: the reference's DataLoader batches (size n // num_batches + 1, ppo.py:66-71).
+            # several ranks: exactly num_batches chunks everywhere, so that the collectives line up
+            chunks = torch.tensor_split(perm, self.num_batches) if dist else [perm[s: s + bs] for s in range(0, n, bs)]
+            for mb in chunks:
+                usable = mb.numel() >= 2  # a single sample has no advantage std (the reference would fail on it)
+                if usable:
+                    g = select_observations(ro.graph, ids[mb])
+                    loss, info = ppo_loss(self.policy, g, acts[0][mb], acts[1][mb], acts[2][mb], advgs[mb], old_lg[mb],
+                                          self.clip_range, self.entropy_coeff)
+                    kl = info["approx_kl_div"]
+                else:
+                    loss, info, kl = None, None, torch.zeros((), device=ids.device)
+                if dist:
+                    stat = torch.stack([kl.float(), torch.ones_like(kl.float()) * usable])
+                    dist.all_reduce(stat)
+                    kl = stat[0] / stat[1].clamp(min=1)
+                elif not usable:
+                    continue
+                kl = float(kl)
+                if usable:
+                    pol.append(float(info["policy_loss"]))
+                    ent.append(float(info["entropy_loss"]))
+                kls.append(kl)
+                if self.target_kl is not None and kl > 1.5 * self.target_kl:
+                    go = False
+                    break
+                if usable:
+                    loss.backward()
+                if dist:
+                    for p in self.policy.parameters():
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                        dist.all_reduce(p.grad)
+                        p.grad /= dist.get_world_size()
+                self.policy.update_parameters(None)
+        return {"policy loss": abs(float(np.mean(pol))), "entropy": abs(float(np.mean(ent))), "approx kl div": abs(float(np.mean(kls)))}
+
+
+class Trainer:
+    """the reference's training loop (trainers/trainer.py:27-168) with the rollout workers replaced
+    by the batched env: per iteration collect `num_sequences x num_rollouts` rollouts (per rank),
+    update the policy, track / checkpoint the best parameters.
+
+    With torch.distributed initialised (one process per GPU) every rank owns `num_sequences` job
+    sequences of its own (base seeds are a function of the global sequence id, so the union over
+    ranks does not depend on the placement), rollouts of one sequence stay on one rank (their
+    baseline needs no traffic), gradients are averaged across ranks and ONE all-gather per
+    iteration moves the per-rollout statistics (trainer.py:113-121's Pipe gather)."""
+
+    def __init__(self, agent_cfg: dict[str, Any], env_cfg: dict[str, Any], train_cfg: dict[str, Any],
+                 device: str | torch.device | None = None, _lib=None):
+        import torch.distributed as dist
+
+        from .decima import DecimaPolicy
+        from .vec_env import VecSparkSchedSimEnv
+
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.seed = int(train_cfg["seed"])
+        torch.manual_seed(self.seed)
+        self.num_iterations = int(train_cfg["num_iterations"])
+        self.num_sequences = int(train_cfg["num_sequences"])
+        self.num_rollouts = int(train_cfg["num_rollouts"])
+        self.rollout_duration = train_cfg.get("rollout_duration")
+        self.checkpointing_freq = int(train_cfg.get("checkpointing_freq", 50))
+        self.artifacts_dir = train_cfg.get("artifacts_dir", "artifacts")
+        self.env_cfg = dict(env_cfg)
+        if "beta_discount" in train_cfg:
+            self.env_cfg["beta"] = train_cfg["beta_discount"]  # trainer.py:70-72
+        assert agent_cfg.get("agent_cls", "DecimaScheduler") == "DecimaScheduler"
+        dev = torch.device(device if device is not None else train_cfg.get("device", "cuda:0"))
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", 0)
+        self.device = dev
+        E = int(self.env_cfg["num_executors"])
+        kw = {k: v for k, v in agent_cfg.items() if k != "agent_cls"}
+        self.policy = DecimaPolicy(num_executors=E, opt_cls=train_cfg["opt_cls"], opt_kwargs=train_cfg.get("opt_kwargs"),
+                                   max_grad_norm=train_cfg.get("max_grad_norm"), **kw).to(dev)
+        B = self.num_sequences * self.num_rollouts
+        sim_cfg = {k: v for k, v in self.env_cfg.items() if k not in ("mean_time_limit", "dataset")}
+        self.env = VecSparkSchedSimEnv(sim_cfg, B, device=dev, _lib=_lib)
+        total_sequences = self.num_sequences * self.world
+        seq_ids = self.rank * self.num_sequences + np.arange(self.num_sequences)
+        base_seeds = np.repeat(self.seed + seq_ids, self.num_rollouts)  # trainer.py:264-266
+        gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
+        gen.manual_seed(self.seed * 1000003 + self.rank)
+        self.collector = RolloutCollector(self.env, self.env_cfg["mean_time_limit"], base_seeds, total_sequences, E,
+                                          policy=self.policy, generator=gen)
+        self.ppo = PPO(self.policy, train_cfg, generator=gen)
+        self.history: list[dict[str, float]] = []
+
+    def _gather_stats(self, stats: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
+        import torch.distributed as dist
+        keys = sorted(stats)
+        local = torch.from_numpy(np.stack([stats[k] for k in keys], 1)).to(self.device)
+        if self.world > 1:
+            out = [torch.empty_like(local) for _ in range(self.world)]
+            dist.all_gather(out, local)
+            local = torch.cat(out, 0)
+        arr = local.cpu().numpy()
+        return {k: arr[:, i] for i, k in enumerate(keys)}
+
+    def train(self, verbose: bool = True) -> list[dict[str, float]]:
+        import json
+        import os
+        import os.path as osp
+        from copy import deepcopy
+
+        ckpt_dir = osp.join(self.artifacts_dir, "checkpoints")
+        if self.rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+        best = None
+        for i in range(self.num_iterations):
+            state_dict = deepcopy(self.policy.state_dict())
+            self.policy.eval()
+            ro = (self.collector.collect_async(self.rollout_duration) if self.rollout_duration else self.collector.collect_sync())
+            self.policy.train()
+            learn = self.ppo.train_on_rollouts(ro)
+            stats = self._gather_stats(ro.stats)
+            with np.errstate(all="ignore"):
+                avg_num_jobs = (self.ppo.diff.avg_num_jobs if self.ppo.diff is not None else None) or float(np.mean(stats["avg_num_jobs"]))
+            if not best or avg_num_jobs < best["avg_num_jobs"]:  # trainer.py:138-142
+                best = {"iteration": i, "avg_num_jobs": float(np.round(avg_num_jobs, 3)), "state_dict": state_dict,
+                        "completed_job_count": int(np.mean(stats["num_completed_jobs"]))}
+            if (i + 1) % self.checkpointing_freq == 0 and self.rank == 0:
+                d = osp.join(ckpt_dir, f"{i + 1}")
+                os.makedirs(d, exist_ok=True)
+                torch.save(best.pop("state_dict"), osp.join(d, "model.pt"))
+                with open(osp.join(d, "state.json"), "w") as fp:
+                    json.dump(best, fp)
+                best = None
+            elif (i + 1) % self.checkpointing_freq == 0:
+                best = None
+            rec = dict(learn, iteration=i, avg_num_jobs=float(avg_num_jobs), samples=int(ro.active.sum()),
+                       episode_length=float(ro.lengths.float().mean()))
+            self.history.append(rec)
+            if verbose and self.rank == 0:
+                print(f"Iteration {i + 1} complete. Avg. # jobs: {avg_num_jobs:.3f}", flush=True)
+        return self.history
+
+    def close(self) -> None:
+        self.env.close()

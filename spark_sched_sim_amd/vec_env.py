@@ -219,6 +219,13 @@ class VecSparkSchedSimEnv:
         tmpl = np.searchsorted(workload.pack_section(self._pack, "tmpl_stage_off"), gs_base).astype(np.int16)
         return ta, tc, order, tmpl
 
+    def job_duration_buff(self, i: int) -> list[float]:
+        """env i's deque of the last 200 completed-job durations, oldest first (spark_sched_sim.py:121, 693-697)"""
+        d = self.dims
+        h = self.header(i)
+        ring = self._env_view[i, d.off_dur_ring: d.off_dur_ring + 8 * 200].cpu().numpy().view(np.float64)
+        return [float(ring[(h["dur_head"] + k) % 200]) for k in range(h["dur_n"])]
+
     def header(self, i: int) -> dict[str, Any]:
         hdr = self._env_view[i, : self.dims.hdr_bytes].cpu().numpy()
         out = {}

@@ -73,7 +73,10 @@ class VecStochasticTimeLimit:
             raise AttributeError(name)
         return getattr(self.env, name)
 
-    def reset(self, *, seed: int | Sequence[int] | None = None, options: dict[str, Any] | None = None):
+    def reset(self, *, seed: int | Sequence[int] | None = None, options: dict[str, Any] | None = None,
+              mask: torch.Tensor | Sequence[bool] | None = None):
+        """`mask` (bool per env): only those envs are reset / get a new limit (rollout collection
+        resets envs one by one as their episodes end, rollout_worker.py:195-199)"""
         B = self.env.num_envs
         if seed is None:
             seeds = [None] * B
@@ -81,15 +84,19 @@ class VecStochasticTimeLimit:
             seeds = [int(seed) + i for i in range(B)]
         else:
             seeds = [int(s) for s in seed]
-        limits = np.empty(B)
+        sel = np.ones(B, dtype=bool) if mask is None else np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask, dtype=bool)
+        limits = self.time_limit.cpu().numpy().copy()
         for i, s in enumerate(seeds):
+            if not sel[i]:
+                continue
             if s:
                 self._rs[i] = np.random.RandomState(s)
             limits[i] = self._rs[i].exponential(self.mean_time_limit)
         self.time_limit = torch.from_numpy(limits).to(self.env.device)
         options = dict(options or {})
         options["time_limit"] = limits
-        return self.env.reset(seed=None if seed is None else seeds, options=options)
+        kw = {} if mask is None else {"mask": torch.from_numpy(sel).to(self.env.device)}
+        return self.env.reset(seed=None if seed is None else seeds, options=options, **kw)
 
     def step(self, actions):
         obs, rew, term, trunc, info = self.env.step(actions)

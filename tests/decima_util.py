@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from spark_sched_sim_amd import VecSparkSchedSimEnv
-from spark_sched_sim_amd.decima import DecimaPolicy, decima_observation
+from spark_sched_sim_amd.decima import DecimaPolicy, compact_graph, decima_observation
 
 HERE = osp.dirname(osp.abspath(__file__))
 AGENT = dict(embed_dim=16,
@@ -35,10 +35,13 @@ def check_decima_fixture(name, device, lib, n_steps):
     for t in range(T):
         with torch.no_grad():
             f = decima_observation(obs, E, max_depth, edge_masks=True)
-            h = policy.encode(f)
-            ss = policy.stage_scores(f, h)
-            A = f["job_valid"].shape[1]
-            es_all = [policy.exec_scores(f, h, torch.full((len(seeds),), j, dtype=torch.long, device=dev))
+            cg = compact_graph(f)
+            h = policy.encode(cg)
+            ss_flat, ss_idx = policy.stage_scores(cg, h)
+            ss = torch.full(f["x"].shape[:2], float("-inf"), device=dev)
+            ss[cg["node_obs"][ss_idx], cg["node_loc"][ss_idx]] = ss_flat
+            job_off = torch.cumsum(obs["n_jobs"].long(), 0) - obs["n_jobs"].long()
+            es_all = [policy.exec_scores(cg, h, job_off + torch.clamp(torch.full_like(job_off, j), max=obs["n_jobs"].long() - 1))
                       for j in range(int(obs["n_jobs"].max()))]
         if dev.type == "cuda":
             torch.cuda.synchronize()

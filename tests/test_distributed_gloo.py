@@ -65,3 +65,44 @@ def test_two_rank_shard_and_all_gather(tmp_path):
     env.close()
     assert torch.equal(gathered, single)
     assert (single[:, 3] == 1).all(), "every env should have finished its episode"
+
+
+# ---- PPO across ranks: every rank trains on its own job sequences, gradients are averaged ---------
+
+TRAIN = dict(trainer_cls="PPO", num_iterations=2, num_sequences=1, num_rollouts=2, seed=7, checkpointing_freq=50,
+             num_epochs=2, num_batches=2, clip_range=0.2, target_kl=None, entropy_coeff=0.04, beta_discount=5.0e-3,
+             opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5)
+ENV = dict(num_executors=5, job_arrival_cap=5, job_arrival_rate=1.0e-4, moving_delay=1500.0, warmup_delay=500.0,
+           mean_time_limit=2.0e5)
+
+
+def _ppo_worker(rank: int, world: int, port: int, out_dir: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    from decima_util import AGENT
+    from emu_util import load_emu
+    from spark_sched_sim_amd.training import Trainer
+
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), ENV, dict(TRAIN, artifacts_dir=os.path.join(out_dir, f"a{rank}")),
+                 device="cpu", _lib=load_emu())
+    seeds = tr.collector.base_seeds.tolist()
+    tr.train(verbose=False)
+    torch.save({"sd": tr.policy.state_dict(), "seeds": seeds, "seed_step": tr.collector.seed_step,
+                "samples": [h["samples"] for h in tr.history]}, os.path.join(out_dir, f"r{rank}.pt"))
+    tr.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ppo_keeps_parameters_in_sync(tmp_path):
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    from emu_util import load_emu
+
+    load_emu()
+    mp.spawn(_ppo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(str(tmp_path / "r0.pt")), torch.load(str(tmp_path / "r1.pt"))
+    # rank r owns global job sequence r: disjoint base seeds, common seed step = total sequences
+    assert r0["seeds"] == [7, 7] and r1["seeds"] == [8, 8] and r0["seed_step"] == r1["seed_step"] == 2
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
