@@ -112,6 +112,49 @@ int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_idx_dev, int
  * semantics are exactly those of sss_policy + sss_step; only the last observation survives. */
 int sss_rollout(sss_handle* h, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream);
 
+/* Decima's view of the current observations, for all envs in one launch: replaces
+ * DecimaObsWrapper.observation (schedulers/decima/env_wrapper.py:69-143), the DAG-layer edge masks
+ * (schedulers/decima/utils.py:238-267) and the PyG batch collation (utils.py:117-204). Reads the
+ * bound observation buffers only. The envs' nodes / jobs / edges are written back to back into flat
+ * arrays at the offsets the caller supplies (exclusive prefix sums of n_nodes / n_jobs / n_edges over
+ * the envs with active != 0); M, J, Ed below are the totals.
+ *   x f32[M,5]             node features [commit cap / E, +-1 source-job flag, supply / E,
+ *                          remaining / num_tasks_scale, remaining * duration / work_scale]
+ *   node_obs/loc/job i64[M] env, row inside the env's observation, flat job id
+ *   sched_rank i64[M]      index among the env's schedulable stages (what stage_idx means), or -1
+ *   gen i32[M]             topological generation inside the active subgraph
+ *   node_recv u32[M]       bit l: the node is the source end of an edge of DAG layer l
+ *   stage_mask u8[M]
+ *   src/dst/edge_obs i64[Ed]  flat node ids of the edge's ends, env
+ *   edge_layers u32[Ed]    bit l: the edge is in the reference's edge_masks[l]
+ *   job_obs/cap/first i64[J]  env, number of allowed executor counts, flat id of the job's first node
+ *   obs_depth i32[num_envs]   number of DAG layers (rows of the reference's edge_masks) per env */
+typedef struct sss_decima_graph {
+  const uint8_t* active_dev; /* u8[num_envs] or NULL (= all) */
+  const int64_t* node_off_dev;
+  const int64_t* job_off_dev;
+  const int64_t* edge_off_dev;
+  float num_tasks_scale; /* 200 in the reference (env_wrapper.py:48) */
+  float work_scale;      /* 1e5 (env_wrapper.py:49) */
+  float* x_dev;
+  int64_t* node_obs_dev;
+  int64_t* node_loc_dev;
+  int64_t* node_job_dev;
+  int64_t* sched_rank_dev;
+  int32_t* gen_dev;
+  uint32_t* node_recv_dev;
+  uint8_t* stage_mask_dev;
+  int64_t* src_dev;
+  int64_t* dst_dev;
+  int64_t* edge_obs_dev;
+  uint32_t* edge_layers_dev;
+  int64_t* job_obs_dev;
+  int64_t* job_cap_dev;
+  int64_t* job_first_dev;
+  int32_t* obs_depth_dev;
+} sss_decima_graph;
+int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

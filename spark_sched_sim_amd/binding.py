@@ -35,6 +35,15 @@ class SssBuffers(C.Structure):
                 ("obs_f64_dev", C.c_void_p)]
 
 
+class SssDecimaGraph(C.Structure):
+    _fields_ = [("active_dev", C.c_void_p), ("node_off_dev", C.c_void_p), ("job_off_dev", C.c_void_p), ("edge_off_dev", C.c_void_p),
+                ("num_tasks_scale", C.c_float), ("work_scale", C.c_float), ("x_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
+                ("node_loc_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("sched_rank_dev", C.c_void_p), ("gen_dev", C.c_void_p),
+                ("node_recv_dev", C.c_void_p), ("stage_mask_dev", C.c_void_p), ("src_dev", C.c_void_p), ("dst_dev", C.c_void_p),
+                ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
+                ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p)]
+
+
 ERROR_NAMES = {
     1: "invalid action: does not belong to the action space",
     2: "invalid action: stage_idx is not a schedulable stage",
@@ -48,7 +57,7 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -73,6 +82,7 @@ class Binding:
         L.sss_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_policy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
+        L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
 

@@ -1,0 +1,123 @@
+// sss_decima.h - the Decima observation transform as ONE kernel over the env's observation buffers
+// (SURVEY 8(f) next-1): DecimaObsWrapper.observation (reference schedulers/decima/env_wrapper.py:69-143),
+// the DAG-layer edge masks of schedulers/decima/utils.py:238-267 and the batch collation of
+// utils.py:117-204, written straight into the flat ("compact graph") arrays the GNN consumes.
+//
+// One wavefront per env. Inputs are the env's own observation rows (nodes, edge_links, dag_ptr,
+// exec_supplies, the scalar block) plus the env's offsets into the flat outputs (exclusive prefix
+// sums of the per-env counts, computed by the caller); nothing of the simulator state is touched,
+// so the kernel is a pure function of the observation. LDS: 12 bytes per node slot
+// (generation, layer-membership bits, receiver bits).
+//
+// Included by sss_hip.hip (gfx950) and tests/emu/emu_backend.cpp (CPU wave emulator) after sss_sim.h.
+#pragma once
+
+struct SssDecimaArgs {
+  const uint8_t* active;  // u8[B] or null
+  const int64_t *node_off, *job_off, *edge_off;
+  float num_tasks_scale, work_scale;
+  float* x;
+  int64_t *node_obs, *node_loc, *node_job, *sched_rank;
+  int32_t* gen;
+  uint32_t* node_recv;
+  uint8_t* stage_mask;
+  int64_t *src, *dst, *edge_obs;
+  uint32_t* edge_layers;
+  int64_t *job_obs, *job_cap, *job_first;
+  int32_t* obs_depth;
+};
+
+SSS_SHARED_DYN(g_dec_lds);
+
+SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDecimaArgs d) {
+  int env = wave_env(), lane = wave_lane();
+  const int32_t* oi = B.obs_i32 + (size_t)env * SSS_OBS_I32;
+  bool on = d.active == nullptr || d.active[env] != 0;
+  int n = on ? oi[OBS_N_NODES] : 0, ne = on ? oi[OBS_N_EDGES] : 0, A = on ? oi[OBS_N_JOBS] : 0;
+  if (n == 0) {  // wave-uniform
+    if (lane == 0) d.obs_depth[env] = 0;
+    return;
+  }
+  int ncommit = oi[OBS_NUM_COMMITTABLE], src_idx = oi[OBS_SOURCE_JOB_IDX];
+  const float* nodes = B.nodes + (size_t)env * L.n_cap * 3;
+  const int32_t* el = B.edge_links + (size_t)env * L.ed_cap * 2;
+  const int32_t* dag_ptr = B.dag_ptr + (size_t)env * (L.J_cap + 1);
+  const int32_t* sup = B.exec_supplies + (size_t)env * L.J_cap;
+  int64_t n0 = d.node_off[env], j0 = d.job_off[env], e0 = d.edge_off[env];
+  int32_t* gen = (int32_t*)g_dec_lds;
+  uint32_t* memb = (uint32_t*)(g_dec_lds + (size_t)4 * L.n_cap);
+  uint32_t* recv = (uint32_t*)(g_dec_lds + (size_t)8 * L.n_cap);
+  for (int i = lane; i < n; i += 64) gen[i] = 0, recv[i] = 0;
+  wave_sync();
+  // topological generations of the active subgraph (nx.topological_generations, utils.py:246-247):
+  // longest-path relaxation over the edge list until nothing moves
+  for (int it = 0; it <= n; it++) {
+    bool moved = false;
+    for (int e = lane; e < ne; e += 64) {
+      int u = el[2 * e], v = el[2 * e + 1];
+      int gu = gen[u] + 1;
+      if (gen[v] < gu) lane_atomic_max_i32(&gen[v], gu), moved = true;
+    }
+    wave_sync();
+    if (!wave_ballot(moved)) break;
+  }
+  // membership bits: bit l of memb[i] <=> node i is in (generation l) U succ(generation l)
+  for (int i = lane; i < n; i += 64) memb[i] = 1u << gen[i];
+  wave_sync();
+  for (int e = lane; e < ne; e += 64) lane_atomic_or_u32(&memb[el[2 * e + 1]], 1u << gen[el[2 * e]]);
+  wave_sync();
+  // edges: global endpoints, the layers whose mask holds the edge (both ends in the layer's node set)
+  for (int e = lane; e < ne; e += 64) {
+    int u = el[2 * e], v = el[2 * e + 1];
+    uint32_t lay = memb[u] & memb[v];
+    d.src[e0 + e] = n0 + u, d.dst[e0 + e] = n0 + v, d.edge_obs[e0 + e] = env;
+    d.edge_layers[e0 + e] = lay;
+    lane_atomic_or_u32(&recv[u], lay);
+  }
+  wave_sync();
+  // jobs: executor cap (env_wrapper.py:72-82), first node
+  for (int a = lane; a < A; a += 64) {
+    int gap = E - sup[a];
+    if (gap < 0) gap = 0;
+    int cap = gap < ncommit ? gap : ncommit;
+    if (a == src_idx) cap = ncommit;
+    d.job_obs[j0 + a] = env, d.job_cap[j0 + a] = cap, d.job_first[j0 + a] = n0 + dag_ptr[a];
+  }
+  // nodes: features (env_wrapper.py:110-143), job, schedulable rank, generation
+  uint32_t run = 0, depth = 0;
+  uint64_t lt = bit64(lane) - 1;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    int i = i0 + lane;
+    bool sched = false;
+    if (i < n) {
+      // job slot of node i: last a with dag_ptr[a] <= i
+      int lo = 0, hi = A;  // invariant: dag_ptr[lo] <= i < dag_ptr[hi]
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (dag_ptr[mid] <= i) lo = mid; else hi = mid;
+      }
+      int a = lo;
+      int supply = sup[a];
+      int gap = E - supply;
+      if (gap < 0) gap = 0;
+      int cap = gap < ncommit ? gap : ncommit;
+      if (a == src_idx) cap = ncommit;
+      float rem = nodes[3 * i], dur = nodes[3 * i + 1];
+      sched = nodes[3 * i + 2] != 0.0f;
+      float* x = d.x + (size_t)(n0 + i) * 5;
+      x[0] = (float)((double)cap / (double)E);
+      x[1] = a == src_idx ? 1.0f : -1.0f;
+      x[2] = (float)((double)supply / (double)E);
+      x[3] = rem / d.num_tasks_scale;
+      x[4] = rem * dur / d.work_scale;
+      d.node_obs[n0 + i] = env, d.node_loc[n0 + i] = i, d.node_job[n0 + i] = j0 + a;
+      d.gen[n0 + i] = gen[i], d.node_recv[n0 + i] = recv[i], d.stage_mask[n0 + i] = sched;
+      if ((uint32_t)gen[i] > depth) depth = (uint32_t)gen[i];
+    }
+    uint64_t bal = wave_ballot(sched);
+    if (i < n) d.sched_rank[n0 + i] = sched ? (int64_t)(run + popc64(bal & lt)) : -1;
+    run += popc64(bal);
+  }
+  depth = ~wave_min_u32(~depth);
+  if (lane == 0) d.obs_depth[env] = (int32_t)depth;
+}

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "sss_sim.h"
+#include "sss_decima.h"
 
 #include <stdint.h>
 #include "zig_tables.inc"
@@ -36,6 +37,11 @@ static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, in
 }
 static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream) {
   hipLaunchKernelGGL(sss_rollout_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, policy, param, n_steps, auto_reset, seed_stride);
+  return (int)hipGetLastError();
+}
+
+static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void* stream) {
+  hipLaunchKernelGGL(sss_decima_graph_kernel, dim3(L.num_envs), dim3(64), (size_t)12 * L.n_cap, (hipStream_t)stream, L, B, E, d);
   return (int)hipGetLastError();
 }
 

@@ -257,6 +257,25 @@ extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, in
   return 0;
 }
 
+extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream) {
+  if (!h || !g) return sss_fail(-1, "NULL argument");
+  if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  if (!g->node_off_dev || !g->job_off_dev || !g->edge_off_dev || !g->x_dev || !g->node_obs_dev || !g->node_loc_dev || !g->node_job_dev ||
+      !g->sched_rank_dev || !g->gen_dev || !g->node_recv_dev || !g->stage_mask_dev || !g->src_dev || !g->dst_dev || !g->edge_obs_dev ||
+      !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev)
+    return sss_fail(-1, "NULL argument");
+  if ((int64_t)12 * h->L.n_cap > 65536) return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
+  SssDecimaArgs d;
+  d.active = g->active_dev, d.node_off = g->node_off_dev, d.job_off = g->job_off_dev, d.edge_off = g->edge_off_dev;
+  d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale;
+  d.x = g->x_dev, d.node_obs = g->node_obs_dev, d.node_loc = g->node_loc_dev, d.node_job = g->node_job_dev, d.sched_rank = g->sched_rank_dev;
+  d.gen = g->gen_dev, d.node_recv = g->node_recv_dev, d.stage_mask = g->stage_mask_dev;
+  d.src = g->src_dev, d.dst = g->dst_dev, d.edge_obs = g->edge_obs_dev, d.edge_layers = g->edge_layers_dev;
+  d.job_obs = g->job_obs_dev, d.job_cap = g->job_cap_dev, d.job_first = g->job_first_dev, d.obs_depth = g->obs_depth_dev;
+  if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
   be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev);

@@ -124,6 +124,7 @@ def compact_graph(f: dict[str, torch.Tensor]) -> dict[str, Any]:
     the reference, decima/utils.py:117-204). Flat tensors, M nodes / J jobs / Ed edges in total:
     x f32[M,5], node_obs / node_loc / node_job / gen i64[M] (observation, position inside it, global
     job id, topological generation), stage_mask bool[M], src / dst i64[Ed] (global node ids),
+    sched_rank i64[M] (index among the observation's schedulable stages, -1 if not schedulable),
     edge_obs i64[Ed], job_obs i64[J], job_cap i64[J] (allowed executor counts = 1..cap),
     job_first i64[J] (global id of the job's first node), n_obs, obs_nodes i64[n_obs],
     obs_depth i64[n_obs]. Padding never reaches the MLPs. Costs a few device->host syncs (sizes)."""
@@ -135,7 +136,9 @@ def compact_graph(f: dict[str, torch.Tensor]) -> dict[str, Any]:
     n_nodes = f["n_nodes"]
     node_off = _excl_cumsum(n_nodes)
     job_off = _excl_cumsum(f["job_valid"].sum(1))
-    return {"x": x[env_n, loc_n], "node_obs": env_n, "node_loc": loc_n,
+    rank = f["stage_mask"].long().cumsum(1) - 1
+    return {"x": x[env_n, loc_n], "node_obs": env_n, "node_loc": loc_n, "n_pad": x.shape[1],
+            "sched_rank": torch.where(f["stage_mask"], rank, torch.full_like(rank, -1))[env_n, loc_n],
             "node_job": job_off[env_n] + f["node_job"][env_n, loc_n], "gen": f["gen"][env_n, loc_n],
             "stage_mask": f["stage_mask"][env_n, loc_n],
             "src": node_off[env_e] + f["edge_src"][env_e, loc_e], "dst": node_off[env_e] + f["edge_dst"][env_e, loc_e],
@@ -148,6 +151,12 @@ def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
     """for every DAG layer l (decima/utils.py:249-267): (ids of the edges whose two ends lie in
     (generation l) U (its successors) - the reference's `edge_masks[l]` as an index list, ids of the
     nodes that are the source end of one of them - the nodes the layer updates)"""
+    if "layers" not in g and "edge_layers" in g:
+        # the graph kernel (include/sss.h sss_decima_graph_build) already marked every edge / node
+        # with the layers it belongs to: one bit test + nonzero per layer
+        depth = int(g["obs_depth"].max()) if g["x"].shape[0] else 0
+        g["layers"] = [(((g["edge_layers"] >> lvl) & 1).nonzero(as_tuple=True)[0], ((g["node_recv"] >> lvl) & 1).nonzero(as_tuple=True)[0])
+                       for lvl in range(depth)]
     if "layers" not in g:
         gen, src, dst = g["gen"], g["src"], g["dst"]
         M = gen.numel()
@@ -185,18 +194,22 @@ def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, A
     job_new[kj] = torch.arange(kj.numel(), device=dev)
     return {"x": g["x"][kn], "node_obs": new_of_old[g["node_obs"][kn]], "node_loc": g["node_loc"][kn],
             "node_job": job_new[g["node_job"][kn]], "gen": g["gen"][kn], "stage_mask": g["stage_mask"][kn],
+            "sched_rank": g["sched_rank"][kn], "n_pad": g["n_pad"],
             "src": node_new[g["src"][ke]], "dst": node_new[g["dst"][ke]], "edge_obs": new_of_old[g["edge_obs"][ke]],
             "job_obs": new_of_old[g["job_obs"][kj]], "job_cap": g["job_cap"][kj], "job_first": node_new[g["job_first"][kj]],
             "n_obs": int(obs_idx.numel()), "obs_nodes": g["obs_nodes"][obs_idx], "obs_jobs": g["obs_jobs"][obs_idx],
-            "obs_depth": g["obs_depth"][obs_idx]}
+            "obs_depth": g["obs_depth"][obs_idx],
+            **({"edge_layers": g["edge_layers"][ke], "node_recv": g["node_recv"][kn]} if "edge_layers" in g else {})}
 
 
 def concat_graphs(gs: list[dict[str, Any]]) -> dict[str, Any]:
     """observations of several compact graphs back to back (ids shifted)"""
     out: dict[str, Any] = {}
     n_off = j_off = o_off = 0
-    parts: dict[str, list] = {k: [] for k in ("x", "node_obs", "node_loc", "node_job", "gen", "stage_mask", "src", "dst",
+    parts: dict[str, list] = {k: [] for k in ("x", "node_obs", "node_loc", "node_job", "gen", "stage_mask", "sched_rank", "src", "dst",
                                              "edge_obs", "job_obs", "job_cap", "job_first", "obs_nodes", "obs_jobs", "obs_depth")}
+    if gs and all("edge_layers" in g for g in gs):
+        parts["edge_layers"], parts["node_recv"] = [], []
     for g in gs:
         shift = {"node_obs": o_off, "edge_obs": o_off, "job_obs": o_off, "node_job": j_off, "src": n_off, "dst": n_off,
                  "job_first": n_off}
@@ -208,6 +221,8 @@ def concat_graphs(gs: list[dict[str, Any]]) -> dict[str, Any]:
     for k, v in parts.items():
         out[k] = torch.cat(v)
     out["n_obs"] = o_off
+    out["n_pad"] = max(g["n_pad"] for g in gs) if gs else 0
+    out["gen"] = out["gen"].long()
     return out
 
 
@@ -359,44 +374,56 @@ class DecimaPolicy(nn.Module):
         return torch.where(mask, s, torch.full_like(s, float("-inf")))
 
     @torch.no_grad()
-    def act(self, f: dict[str, torch.Tensor], g: dict[str, Any], generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:
-        """samples one Decima action per observation (scheduler.py:71-99): a stage from
-        softmax(stage scores), then an executor count from softmax(exec scores of that stage's job).
-        Returns the reference's action tuple entries `stage_sel` (index among the observation's
-        schedulable stages), `job_idx` (job slot), `exec_sel` (executor count - 1), `lgprob`, and
-        `any_stage` (False where nothing is schedulable; the other entries are then meaningless)."""
-        B, N = f["x"].shape[:2]
+    def act(self, g: dict[str, Any], generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:
+        """samples one Decima action per observation of a compact graph (scheduler.py:71-99): a stage
+        from softmax(stage scores), then an executor count from softmax(exec scores of that stage's
+        job). Returns the reference's action tuple entries `stage_sel` (index among the observation's
+        schedulable stages = the env's `stage_idx`), `job_idx` (job slot), `exec_sel` (executor
+        count - 1), `lgprob`, and `any_stage` (False where nothing is schedulable; the other entries
+        are then meaningless)."""
+        B, N = g["n_obs"], g["n_pad"]
+        M, J = g["x"].shape[0], g["job_obs"].numel()
         h = self.encode(g)
         s, idx = self.stage_scores(g, h)
         padded = torch.full((B, N), float("-inf"), dtype=s.dtype, device=s.device)
         padded[g["node_obs"][idx], g["node_loc"][idx]] = s
         any_stage = torch.isfinite(padded).any(1)
         p = torch.softmax(torch.where(any_stage[:, None], padded, torch.zeros_like(padded)), 1)
-        node = torch.multinomial(p, 1, generator=generator)[:, 0]
-        stage_sel = f["stage_mask"].long().cumsum(1).gather(1, node[:, None])[:, 0] - 1
-        job_slot = f["node_job"].gather(1, node[:, None])[:, 0].clamp(max=f["job_valid"].shape[1] - 1)
-        has_jobs = g["obs_jobs"] > 0
-        job_gid = (_excl_cumsum(g["obs_jobs"]) + torch.where(has_jobs, job_slot, torch.zeros_like(job_slot)))
-        job_gid = job_gid.clamp(max=max(g["job_obs"].numel() - 1, 0))
-        if g["job_obs"].numel():
-            es = self.exec_scores(g, h, job_gid)
-        else:
-            es = torch.full((B, self.num_executors), float("-inf"), dtype=s.dtype, device=s.device)
-        any_exec = torch.isfinite(es).any(1) & has_jobs
+        col = torch.multinomial(p, 1, generator=generator)[:, 0]
+        node = (_excl_cumsum(g["obs_nodes"]) + col).clamp(max=max(M - 1, 0))
+        if M == 0:
+            z = torch.zeros(B, dtype=torch.long, device=s.device)
+            return {"stage_sel": z, "job_idx": z, "exec_sel": z, "lgprob": torch.zeros(B, device=s.device), "any_stage": any_stage}
+        stage_sel = g["sched_rank"][node]
+        job_gid = g["node_job"][node]
+        job_slot = job_gid - _excl_cumsum(g["obs_jobs"])
+        es = self.exec_scores(g, h, job_gid.clamp(max=max(J - 1, 0)))
+        any_exec = torch.isfinite(es).any(1) & any_stage
         pe = torch.softmax(torch.where(any_exec[:, None], es, torch.zeros_like(es)), 1)
         k = torch.multinomial(pe, 1, generator=generator)[:, 0]
-        lg = torch.log(p.gather(1, node[:, None])[:, 0]) + torch.log(pe.gather(1, k[:, None])[:, 0])
+        lg = torch.log(p.gather(1, col[:, None])[:, 0]) + torch.log(pe.gather(1, k[:, None])[:, 0])
         return {"stage_sel": stage_sel, "job_idx": job_slot, "exec_sel": k, "lgprob": lg, "any_stage": any_stage}
+
+    @staticmethod
+    def env_actions(a: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        """`act`'s result in the env's action format (DecimaActWrapper.action, env_wrapper.py:33-34);
+        envs without a schedulable stage get stage_idx -1"""
+        stage_idx = torch.where(a["any_stage"], a["stage_sel"], torch.full_like(a["stage_sel"], -1))
+        return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}
+
+    @torch.no_grad()
+    def schedule_env(self, env, generator: torch.Generator | None = None):
+        """Decima in the loop on a `VecSparkSchedSimEnv`: the graph kernel on the env's current
+        observations + `act`. Returns (actions for `env.step`, the `act` dict)."""
+        a = self.act(env.decima_graph(), generator)
+        return self.env_actions(a), a
 
     @torch.no_grad()
     def schedule_batch(self, obs, max_depth: int, generator: torch.Generator | None = None):
-        """observation transform + `act` for every env of a batched observation. Returns
-        ({"stage_idx": i32[B], "num_exec": i32[B]} for `VecSparkSchedSimEnv.step`, the `act` dict).
-        Envs without a schedulable stage get stage_idx -1."""
-        f = decima_observation(obs, self.num_executors, max_depth)
-        a = self.act(f, compact_graph(f), generator)
-        stage_idx = torch.where(a["any_stage"], a["stage_sel"], torch.full_like(a["stage_sel"], -1))
-        return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}, a
+        """the same from a `BatchedObs` alone, with the observation transform done by tensor ops
+        (`decima_observation` + `compact_graph`)"""
+        a = self.act(compact_graph(decima_observation(obs, self.num_executors, max_depth)), generator)
+        return self.env_actions(a), a
 
     def evaluate_actions(self, g: dict[str, Any], stage_sel: torch.Tensor, job_idx: torch.Tensor, exec_sel: torch.Tensor):
         """log-probabilities and normalised entropies of recorded actions under the current

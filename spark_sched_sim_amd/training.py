@@ -20,7 +20,7 @@ from typing import Any, Callable, Sequence
 import numpy as np
 import torch
 
-from .decima import compact_graph, concat_graphs, decima_observation, select_observations
+from .decima import concat_graphs, select_observations
 from .wrappers import VecStochasticTimeLimit
 
 SKIP_ENV = -(2 ** 31)  # include/sss.h SSS_SKIP_ENV
@@ -67,7 +67,7 @@ class Rollouts:
         return x.t()[self.active.t()]
 
 
-ActFn = Callable[[Any, dict[str, torch.Tensor], dict[str, Any], torch.Tensor], dict[str, torch.Tensor]]
+ActFn = Callable[[dict[str, Any], torch.Tensor], dict[str, torch.Tensor]]
 
 
 class RolloutCollector:
@@ -75,8 +75,8 @@ class RolloutCollector:
 
     Env b plays worker rank b: seed of its k-th episode = base_seeds[b] + seed_step * k
     (rollout_worker.py:118-120, trainer.py:264-269), time limit from `StochasticTimeLimit`'s rule.
-    `act_fn(obs, f, g, step_counts)` returns `DecimaPolicy.act`'s dict; the default samples from
-    `policy`. Envs that are done (sync) or have filled their duration (async) are frozen with
+    `act_fn(g, step_counts)` (g = compact graph of the active envs' observations) returns
+    `DecimaPolicy.act`'s dict; the default samples from `policy`. Envs that are done (sync) or have filled their duration (async) are frozen with
     SSS_SKIP_ENV until the others catch up."""
 
     def __init__(self, env, mean_time_limit: float, base_seeds: Sequence[int], seed_step: int, num_executors: int,
@@ -89,10 +89,9 @@ class RolloutCollector:
         self.reset_count = np.zeros(env.num_envs, dtype=np.int64)
         self.step_counts = torch.zeros(env.num_envs, dtype=torch.long)
         self.E = num_executors
-        self.max_depth = env.dims.stage_stride
         self.policy = policy
         self.generator = generator
-        self.act_fn = act_fn or (lambda obs, f, g, n: policy.act(f, g, generator))
+        self.act_fn = act_fn or (lambda g, n: policy.act(g, generator))
         self._obs = None
         self._wall = None
 
@@ -104,15 +103,6 @@ class RolloutCollector:
         obs, _ = self.tl_env.reset(seed=[int(s) for s in self.seeds], mask=mask)
         self.reset_count += 1 if mask is None else mask.cpu().numpy().astype(np.int64)
         return obs
-
-    def _masked_graph(self, obs, active: torch.Tensor):
-        f = decima_observation(obs, self.E, self.max_depth)
-        keep = active[:, None]
-        for k in ("node_valid", "job_valid", "edge_valid", "stage_mask"):
-            f[k] = f[k] & keep
-        f["n_nodes"] = f["n_nodes"] * active
-        f["depth"] = f["depth"] * active
-        return f, compact_graph(f)
 
     def _stats(self) -> dict[str, np.ndarray]:
         """rollout_worker.py:122-130 for every env"""
@@ -139,8 +129,8 @@ class RolloutCollector:
         active = torch.ones(B, dtype=torch.bool, device=dev)
         rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
         while bool(active.any()):
-            f, g = self._masked_graph(obs, active)
-            a = self.act_fn(obs, f, g, self.step_counts)
+            g = self.env.decima_graph(active)
+            a = self.act_fn(g, self.step_counts)
             self.step_counts += active.cpu().long()
             stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
             num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import workload
-from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg
+from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg, SssDecimaGraph
 
 OBS_FIELDS = ("n_nodes", "n_edges", "n_jobs", "n_schedulable", "num_committable_execs", "source_job_idx",
               "terminated", "err")
@@ -167,6 +167,38 @@ class VecSparkSchedSimEnv:
         """n_steps x (policy -> step) per env inside one kernel launch (asynchronous)"""
         self._b.check(self._b.lib.sss_rollout(self._h, POLICY_IDS[policy], int(param), int(n_steps), int(self.auto_reset),
                                               self.seed_stride, self._stream()))
+
+    def decima_graph(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5) -> dict[str, Any]:
+        """the current observations of all envs (or of those with `active[b]` True) as Decima's
+        compact graph - `decima.compact_graph(decima.decima_observation(obs))` produced by ONE kernel
+        (include/sss.h sss_decima_graph_build) instead of ~150 tensor ops, plus per-edge / per-node
+        DAG-layer bits and each schedulable node's `stage_idx`. One device->host sync (totals)."""
+        B, dev = self.num_envs, self.device
+        cnt = self.obs_i32[:, :3].long()  # n_nodes, n_edges, n_jobs
+        act8 = None
+        if active is not None:
+            cnt = cnt * active[:, None]
+            act8 = active.to(torch.uint8).contiguous()
+        off = (torch.cumsum(cnt, 0) - cnt).t().contiguous()
+        M, Ed, J = (int(v) for v in cnt.sum(0).tolist())
+        # buffers hold at least one element so that their pointers are never NULL; `g` gets exact views
+        mk = lambda n, dt, *tail: torch.empty((max(n, 1), *tail), dtype=dt, device=dev)  # noqa: E731
+        buf = {"x": mk(M, torch.float32, 5), "node_obs": mk(M, torch.int64), "node_loc": mk(M, torch.int64), "node_job": mk(M, torch.int64),
+               "sched_rank": mk(M, torch.int64), "gen": mk(M, torch.int32), "node_recv": mk(M, torch.int32), "stage_mask": mk(M, torch.bool),
+               "src": mk(Ed, torch.int64), "dst": mk(Ed, torch.int64), "edge_obs": mk(Ed, torch.int64), "edge_layers": mk(Ed, torch.int32),
+               "job_obs": mk(J, torch.int64), "job_cap": mk(J, torch.int64), "job_first": mk(J, torch.int64), "obs_depth": mk(B, torch.int32)}
+        size = {"x": M, "node_obs": M, "node_loc": M, "node_job": M, "sched_rank": M, "gen": M, "node_recv": M, "stage_mask": M,
+                "src": Ed, "dst": Ed, "edge_obs": Ed, "edge_layers": Ed, "job_obs": J, "job_cap": J, "job_first": J, "obs_depth": B}
+        g = {k: v[: size[k]] for k, v in buf.items()}
+        a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
+                           float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
+                               "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
+                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth")))
+        self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
+        g["n_obs"], g["n_pad"] = B, self.dims.node_cap
+        g["obs_nodes"], g["obs_jobs"] = cnt[:, 0].contiguous(), cnt[:, 2].contiguous()
+        g["_keepalive"] = (off, act8)
+        return g
 
     def raise_on_error(self) -> None:
         """the reference raises from inside step(); the batched env records a per-env code. This

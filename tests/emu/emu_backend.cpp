@@ -13,6 +13,7 @@ void launch(int grid, const std::function<void()>& body);
 }
 
 #include "sss_sim.h"
+#include "sss_decima.h"
 #include "zig_tables.inc"
 
 static int be_set_device(int) { return 0; }
@@ -38,6 +39,11 @@ static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, in
 }
 static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void*) {
   emu::launch(num_envs, [&]() { sss_rollout_kernel(a, policy, param, n_steps, auto_reset, seed_stride); });
+  return 0;
+}
+
+static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void*) {
+  emu::launch(L.num_envs, [&]() { sss_decima_graph_kernel(L, B, E, d); });
   return 0;
 }
 

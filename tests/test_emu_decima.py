@@ -30,7 +30,7 @@ def test_sampled_actions_are_always_valid():
     gen = torch.Generator().manual_seed(11)
     obs, _ = env.reset(seed=100)
     for _ in range(150):
-        act, aux = policy.schedule_batch(obs, env.dims.stage_stride, generator=gen)
+        act, aux = policy.schedule_env(env, generator=gen)
         assert torch.isfinite(aux["lgprob"]).all()
         obs, r, term, trunc, info = env.step(act)
         assert not info["err"].any()

@@ -25,7 +25,7 @@ def test_decima_in_the_loop_256_envs():
     gen = torch.Generator(device="cuda:0").manual_seed(11)
     obs, _ = env.reset(seed=100)
     for _ in range(300):
-        act, aux = policy.schedule_batch(obs, env.dims.stage_stride, generator=gen)
+        act, aux = policy.schedule_env(env, generator=gen)
         obs, r, term, trunc, info = env.step(act)
     torch.cuda.synchronize()
     assert not info["err"].any() and torch.isfinite(aux["lgprob"]).all()

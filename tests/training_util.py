@@ -18,25 +18,29 @@ RETURN_RTOL = 1e-10   # recurrences of up to ~300 exp()-weighted terms over thos
 SCORE_ATOL = 2e-5     # float32 GNN, different summation order
 
 
-def counter_act_fn(obs, f, g, step_counts):
+def counter_act_fn(g, step_counts):
     """the fixture's stand-in for sampling (make_ppo_golden.CounterPolicy), batched"""
-    dev = f["x"].device
-    B = f["x"].shape[0]
-    n_sched = f["stage_mask"].sum(1).cpu().numpy()
+    dev = g["x"].device
+    B = g["n_obs"]
+    n_sched = torch.zeros(B, dtype=torch.long, device=dev).index_add_(0, g["node_obs"], g["stage_mask"].long()).cpu().numpy()
     sel, h2s = np.zeros(B, dtype=np.int64), np.zeros(B, dtype=np.uint64)
     for b in range(B):
         h1 = splitmix64(((1000 + b) << 32) ^ int(step_counts[b]))
         h2s[b] = splitmix64(h1)
         sel[b] = h1 % max(1, int(n_sched[b]))
     stage_sel = torch.from_numpy(sel).to(dev)
-    rank = f["stage_mask"].long().cumsum(1)
-    node = ((rank == (stage_sel[:, None] + 1)) & f["stage_mask"]).long().argmax(1)
-    job = f["node_job"].gather(1, node[:, None])[:, 0].clamp(max=f["job_valid"].shape[1] - 1)
-    n_allowed = f["commit_caps"].gather(1, job[:, None])[:, 0].cpu().numpy()
+    node = (g["sched_rank"] == stage_sel[g["node_obs"]]).nonzero(as_tuple=True)[0]  # one per env that has a stage
+    has = torch.from_numpy(n_sched > 0).to(dev)
+    job_gid = torch.zeros(B, dtype=torch.long, device=dev)
+    job_gid[has] = g["node_job"][node]
+    n_allowed = torch.zeros(B, dtype=torch.long, device=dev)
+    n_allowed[has] = g["job_cap"][job_gid[has]]
+    n_allowed = n_allowed.cpu().numpy()
+    job_off = torch.cumsum(g["obs_jobs"], 0) - g["obs_jobs"]
     ex = np.asarray([int(h2s[b]) % max(1, int(n_allowed[b])) for b in range(B)], dtype=np.int64)
     lg = torch.tensor([-1.0 - 0.001 * ((int(step_counts[b]) + 1) % 7) for b in range(B)], dtype=torch.float32, device=dev)
-    return {"stage_sel": stage_sel, "job_idx": job, "exec_sel": torch.from_numpy(ex).to(dev), "lgprob": lg,
-            "any_stage": torch.from_numpy(n_sched > 0).to(dev)}
+    return {"stage_sel": stage_sel, "job_idx": torch.where(has, job_gid - job_off, torch.zeros_like(job_gid)),
+            "exec_sel": torch.from_numpy(ex).to(dev), "lgprob": lg, "any_stage": has}
 
 
 def load_fixture():

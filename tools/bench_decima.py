@@ -35,7 +35,7 @@ def main():
         if i == a.warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        act, _ = policy.schedule_batch(obs, env.dims.stage_stride, generator=gen)
+        act, _ = policy.schedule_env(env, generator=gen)
         obs, *_ = env.step(act)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""where a Decima-in-the-loop step spends its time: per-section wall time (synchronised) and the
+number of device kernels launched per section"""
+import argparse
+import json
+import os.path as osp
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
+from spark_sched_sim_amd import VecSparkSchedSimEnv  # noqa: E402
+from spark_sched_sim_amd.decima import DecimaPolicy, compact_graph, decima_observation, graph_layers  # noqa: E402
+
+AGENT = dict(embed_dim=16,
+             gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(negative_slope=0.2)),
+             policy_mlp_kwargs=dict(hid_dims=[64, 64], act_cls="Tanh"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=30)
+    a = ap.parse_args()
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, a.envs, device="cuda:0", auto_reset=True)
+    torch.manual_seed(0)
+    policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval()
+    gen = torch.Generator(device="cuda:0").manual_seed(1)
+    obs, _ = env.reset(seed=0)
+    for _ in range(300):  # get into the busy part of the episodes
+        obs, *_ = env.step(env.policy_actions("fair"))
+    sec = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        sec[name] = sec.get(name, 0.0) + time.perf_counter() - t0
+        return r
+
+    with torch.no_grad():
+        for i in range(a.steps + 5):
+            if i == 5:
+                sec.clear()
+            g = timed("graph kernel", lambda: env.decima_graph())
+            timed("layers", lambda: graph_layers(g))
+            act = timed("gnn+sample", lambda: policy.act(g, gen))
+            obs, *_ = timed("env.step", lambda: env.step(policy.env_actions(act)))
+    out = {k: 1e3 * v / a.steps for k, v in sec.items()}
+    out["levels"] = len(g["layers"])
+    out["nodes"] = int(g["x"].shape[0])
+    out["edges"] = int(g["src"].numel())
+    print(json.dumps({"envs": a.envs, "ms_per_step": out}))
+    from torch.profiler import ProfilerActivity, profile
+    with torch.no_grad(), profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for i in range(3):
+            act = policy.act(env.decima_graph(), gen)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+
+
+if __name__ == "__main__":
+    main()
