@@ -155,6 +155,41 @@ typedef struct sss_decima_graph {
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
 
+/* Decima's GNN forward pass for inference (schedulers/decima/scheduler.py:142-385) on a compact graph
+ * written by sss_decima_graph_build: one launch per stage of the pass, each evaluating one whole MLP
+ * per row with its gather / scatter fused in. Supports the published architecture
+ * (config/decima_tpch.yaml:66-78: embed_dim 16, GNN MLPs [32,16] + LeakyReLU, policy MLPs [64,64] +
+ * Tanh). `w_dev` = that stage's MLP parameters packed [W1,b1,W2,b2,W3,b3] (torch.nn.Linear layout).
+ * kind: 0 PREP (n_rows = M: out=h_init[M,16] from x), 1 SINK (h = is_parent ? 0 : update(h_init)),
+ * 2 MSG (rows = edges of a layer: agg[idx1[r]] += msg(h[idx0[r]])), 3 UPD (rows = receiving nodes:
+ * h[n] = h_init[n] + update(agg[n]), n = idx0[r]), 4 DAG (h_dag[node_job[n]] += dag([x,h][n])),
+ * 5 GLOB (rows = jobs: h_glob[job_obs[j]] += glob(h_dag[j])), 6 STAGE (rows = nodes idx0[r]:
+ * out[r] = score), 7 EXEC (rows = (b, c), c < E: out[b*E + c] = score of c+1 executors for job
+ * idx0[b], -inf where c >= job_cap). Accumulators (agg, h_dag, h_glob) must be zeroed by the caller. */
+typedef struct sss_gnn_args {
+  int64_t n_rows;
+  const float* w_dev;
+  float slope;
+  int num_executors;
+  const float* x_dev;
+  const float* h_init_dev;
+  float* h_dev;
+  float* agg_dev;
+  float* h_dag_dev;
+  float* h_glob_dev;
+  float* out_dev;
+  const uint8_t* is_parent_dev;
+  const int32_t* obs_depth_dev; /* SINK, nullable: nodes of observations with depth 0 keep h_init */
+  const int64_t* idx0_dev;
+  const int64_t* idx1_dev;
+  const int64_t* node_job_dev;
+  const int64_t* node_obs_dev;
+  const int64_t* job_obs_dev;
+  const int64_t* job_first_dev;
+  const int64_t* job_cap_dev;
+} sss_gnn_args;
+int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

@@ -44,6 +44,16 @@ class SssDecimaGraph(C.Structure):
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p)]
 
 
+class SssGnnArgs(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("w_dev", C.c_void_p), ("slope", C.c_float), ("num_executors", C.c_int), ("x_dev", C.c_void_p),
+                ("h_init_dev", C.c_void_p), ("h_dev", C.c_void_p), ("agg_dev", C.c_void_p), ("h_dag_dev", C.c_void_p),
+                ("h_glob_dev", C.c_void_p), ("out_dev", C.c_void_p), ("is_parent_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p),
+                ("idx0_dev", C.c_void_p), ("idx1_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
+                ("job_obs_dev", C.c_void_p), ("job_first_dev", C.c_void_p), ("job_cap_dev", C.c_void_p)]
+
+
+GNN_KINDS = {"prep": 0, "sink": 1, "msg": 2, "upd": 3, "dag": 4, "glob": 5, "stage": 6, "exec": 7}
+
 ERROR_NAMES = {
     1: "invalid action: does not belong to the action space",
     2: "invalid action: stage_idx is not a schedulable stage",
@@ -57,7 +67,7 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_decima_graph_build", "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -83,6 +93,7 @@ class Binding:
         L.sss_policy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]
+        L.sss_gnn_launch.argtypes = [C.c_int, C.POINTER(SssGnnArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
 

@@ -6,6 +6,7 @@
 
 #include "sss_sim.h"
 #include "sss_decima.h"
+#include "sss_gnn.h"
 
 #include <stdint.h>
 #include "zig_tables.inc"
@@ -43,6 +44,31 @@ static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, i
 static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void* stream) {
   hipLaunchKernelGGL(sss_decima_graph_kernel, dim3(L.num_envs), dim3(64), (size_t)12 * L.n_cap, (hipStream_t)stream, L, B, E, d);
   return (int)hipGetLastError();
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r < a.n_rows) gnn_row<KIND>(a, r);
+}
+template <int KIND>
+static int gnn_launch_kind(const SssGnnArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  hipLaunchKernelGGL(sss_gnn_kernel<KIND>, dim3((unsigned)((a.n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
+  switch (kind) {
+    case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);
+    case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
+    case GNN_MSG: return gnn_launch_kind<GNN_MSG>(a, stream);
+    case GNN_UPD: return gnn_launch_kind<GNN_UPD>(a, stream);
+    case GNN_DAG: return gnn_launch_kind<GNN_DAG>(a, stream);
+    case GNN_GLOB: return gnn_launch_kind<GNN_GLOB>(a, stream);
+    case GNN_STAGE: return gnn_launch_kind<GNN_STAGE>(a, stream);
+    case GNN_EXEC: return gnn_launch_kind<GNN_EXEC>(a, stream);
+  }
+  return -1;
 }
 
 #include "sss_host.h"

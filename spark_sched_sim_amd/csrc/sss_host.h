@@ -276,6 +276,19 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   return 0;
 }
 
+extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
+  if (!g) return sss_fail(-1, "NULL argument");
+  if (kind < 0 || kind >= GNN_KINDS) return sss_fail(-26, "unknown GNN stage");
+  if (g->n_rows < 0 || !g->w_dev) return sss_fail(-1, "NULL argument");
+  SssGnnArgs a;
+  a.n_rows = g->n_rows, a.w = g->w_dev, a.slope = g->slope, a.E = g->num_executors, a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev;
+  a.agg = g->agg_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev, a.out = g->out_dev, a.is_parent = g->is_parent_dev, a.obs_depth = g->obs_depth_dev;
+  a.idx0 = g->idx0_dev, a.idx1 = g->idx1_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.job_obs = g->job_obs_dev;
+  a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev;
+  if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
   be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev);

@@ -91,6 +91,8 @@ class RolloutCollector:
         self.E = num_executors
         self.policy = policy
         self.generator = generator
+        if policy is not None:
+            policy.bind_kernels(env._b)  # inference on the fused GNN kernels; training stays on autograd
         self.act_fn = act_fn or (lambda g, n: policy.act(g, generator))
         self._obs = None
         self._wall = None

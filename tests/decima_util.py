@@ -36,7 +36,8 @@ def check_decima_fixture(name, device, lib, n_steps):
         with torch.no_grad():
             f = decima_observation(obs, E, max_depth, edge_masks=True)
             cg = compact_graph(f)
-            compare_graphs(env.decima_graph(), cg, f)
+            kg = env.decima_graph()
+            compare_graphs(kg, cg, f)
             h = policy.encode(cg)
             ss_flat, ss_idx = policy.stage_scores(cg, h)
             ss = torch.full(f["x"].shape[:2], float("-inf"), device=dev)
@@ -44,6 +45,20 @@ def check_decima_fixture(name, device, lib, n_steps):
             job_off = torch.cumsum(obs["n_jobs"].long(), 0) - obs["n_jobs"].long()
             es_all = [policy.exec_scores(cg, h, job_off + torch.clamp(torch.full_like(job_off, j), max=obs["n_jobs"].long() - 1))
                       for j in range(int(obs["n_jobs"].max()))]
+            # the fused inference kernels against the tensor-op forward pass
+            policy.bind_kernels(env._b)
+            assert policy._use_kernels()
+            hk = policy._encode_kernels(kg)
+            for k in ("node", "dag", "glob"):
+                assert float((hk[k] - h[k]).abs().max()) <= SCORE_ATOL, (t, k)
+            sk, sk_idx = policy._stage_scores_kernels(kg, hk)
+            assert torch.equal(sk_idx, ss_idx) and float((sk - ss_flat).abs().max()) <= SCORE_ATOL, t
+            for j, es_t in enumerate(es_all):
+                jg = job_off + torch.clamp(torch.full_like(job_off, j), max=obs["n_jobs"].long() - 1)
+                ek = policy._exec_scores_kernels(kg, hk, jg)
+                assert torch.equal(torch.isfinite(ek), torch.isfinite(es_t)), (t, j)
+                fin = torch.isfinite(ek)
+                assert float((ek[fin] - es_t[fin]).abs().max()) <= SCORE_ATOL if fin.any() else True, (t, j)
         if dev.type == "cuda":
             torch.cuda.synchronize()
         for b, s in enumerate(seeds):

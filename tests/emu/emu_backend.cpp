@@ -14,6 +14,8 @@ void launch(int grid, const std::function<void()>& body);
 
 #include "sss_sim.h"
 #include "sss_decima.h"
+#include <math.h>
+#include "sss_gnn.h"
 #include "zig_tables.inc"
 
 static int be_set_device(int) { return 0; }
@@ -45,6 +47,25 @@ static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, i
 static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void*) {
   emu::launch(L.num_envs, [&]() { sss_decima_graph_kernel(L, B, E, d); });
   return 0;
+}
+
+template <int KIND>
+static int gnn_run_kind(const SssGnnArgs& a) {
+  for (int64_t r = 0; r < a.n_rows; r++) gnn_row<KIND>(a, r);
+  return 0;
+}
+static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
+  switch (kind) {
+    case GNN_PREP: return gnn_run_kind<GNN_PREP>(a);
+    case GNN_SINK: return gnn_run_kind<GNN_SINK>(a);
+    case GNN_MSG: return gnn_run_kind<GNN_MSG>(a);
+    case GNN_UPD: return gnn_run_kind<GNN_UPD>(a);
+    case GNN_DAG: return gnn_run_kind<GNN_DAG>(a);
+    case GNN_GLOB: return gnn_run_kind<GNN_GLOB>(a);
+    case GNN_STAGE: return gnn_run_kind<GNN_STAGE>(a);
+    case GNN_EXEC: return gnn_run_kind<GNN_EXEC>(a);
+  }
+  return -1;
 }
 
 #include "sss_host.h"

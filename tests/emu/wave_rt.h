@@ -88,6 +88,7 @@ SSS_DEV double wave_readlane_f64(double v, int l) { return wave_bcast_f64(v, l);
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { *p += v; }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
+SSS_DEV void lane_atomic_add_f32(float* p, float v) { *p += v; }
 SSS_DEV void lane_atomic_max_i32(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
   emu::collective(emu::OP_SCAN32, v);

@@ -28,6 +28,7 @@ def main():
     torch.manual_seed(0)
     policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval()
     gen = torch.Generator(device="cuda:0").manual_seed(1)
+    policy.bind_kernels(env._b)
     obs, _ = env.reset(seed=0)
     for _ in range(300):  # get into the busy part of the episodes
         obs, *_ = env.step(env.policy_actions("fair"))
