@@ -152,6 +152,9 @@ typedef struct sss_decima_graph {
   int64_t* job_cap_dev;
   int64_t* job_first_dev;
   int32_t* obs_depth_dev;
+  int64_t* job_nodes_dev; /* i64[J] number of nodes of the job (they follow job_first back to back) */
+  int64_t* out_start_dev; /* i64[M] flat id of the node's first out-edge; a node's out-edges are contiguous */
+  int32_t* out_deg_dev;   /* i32[M] number of out-edges */
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
 
@@ -160,33 +163,44 @@ int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* strea
  * per row with its gather / scatter fused in. Supports the published architecture
  * (config/decima_tpch.yaml:66-78: embed_dim 16, GNN MLPs [32,16] + LeakyReLU, policy MLPs [64,64] +
  * Tanh). `w_dev` = that stage's MLP parameters packed [W1,b1,W2,b2,W3,b3] (torch.nn.Linear layout).
- * kind: 0 PREP (n_rows = M: out=h_init[M,16] from x), 1 SINK (h = is_parent ? 0 : update(h_init)),
- * 2 MSG (rows = edges of a layer: agg[idx1[r]] += msg(h[idx0[r]])), 3 UPD (rows = receiving nodes:
- * h[n] = h_init[n] + update(agg[n]), n = idx0[r]), 4 DAG (h_dag[node_job[n]] += dag([x,h][n])),
- * 5 GLOB (rows = jobs: h_glob[job_obs[j]] += glob(h_dag[j])), 6 STAGE (rows = nodes idx0[r]:
- * out[r] = score), 7 EXEC (rows = (b, c), c < E: out[b*E + c] = score of c+1 executors for job
- * idx0[b], -inf where c >= job_cap). Accumulators (agg, h_dag, h_glob) must be zeroed by the caller. */
+ * kind: 0 PREP (rows = nodes: out = h_init[M,16] from x), 1 SINK (h = h_init where the node's
+ * observation has depth 0 [obs_depth given], else 0 for nodes with out-edges, else update(h_init)),
+ * 2 LAYER (rows = idx0, -1 = skip: tmp[n] = h_init[n] + update(sum over n's out-edges in DAG layer
+ * `layer` of msg(h[dst])); w = msg, w2 = update), 3 COMMIT (h[n] = tmp[n] for the same rows),
+ * 4 DAGSUM (rows = jobs: h_dag[j] = sum over its nodes of dag([x,h])), 5 GLOBSUM (rows =
+ * observations: h_glob[o] = sum over its jobs of glob(h_dag)), 6 STAGE (rows = idx0, -1 = skip:
+ * out[node_obs*n_pad + node_loc] = score), 7 EXEC (rows = (b, c), c < E: out[b*E + c] = score of c+1
+ * executors for job idx0[b], -inf where c >= job_cap). No atomics, fixed summation order. */
 typedef struct sss_gnn_args {
   int64_t n_rows;
   const float* w_dev;
+  const float* w2_dev;
   float slope;
   int num_executors;
+  int layer;
+  int64_t n_pad;
   const float* x_dev;
   const float* h_init_dev;
   float* h_dev;
-  float* agg_dev;
+  float* tmp_dev;
   float* h_dag_dev;
   float* h_glob_dev;
   float* out_dev;
-  const uint8_t* is_parent_dev;
-  const int32_t* obs_depth_dev; /* SINK, nullable: nodes of observations with depth 0 keep h_init */
+  const int32_t* out_deg_dev;
+  const int32_t* obs_depth_dev; /* SINK, nullable: batch semantics (no per-observation skip) when NULL */
   const int64_t* idx0_dev;
-  const int64_t* idx1_dev;
+  const int64_t* dst_dev;
+  const int64_t* out_start_dev;
+  const uint32_t* edge_layers_dev;
   const int64_t* node_job_dev;
   const int64_t* node_obs_dev;
+  const int64_t* node_loc_dev;
   const int64_t* job_obs_dev;
   const int64_t* job_first_dev;
   const int64_t* job_cap_dev;
+  const int64_t* job_nodes_dev;
+  const int64_t* obs_job_off_dev;
+  const int64_t* obs_jobs_dev;
 } sss_gnn_args;
 int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
 

@@ -41,18 +41,21 @@ class SssDecimaGraph(C.Structure):
                 ("node_loc_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("sched_rank_dev", C.c_void_p), ("gen_dev", C.c_void_p),
                 ("node_recv_dev", C.c_void_p), ("stage_mask_dev", C.c_void_p), ("src_dev", C.c_void_p), ("dst_dev", C.c_void_p),
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
-                ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p)]
+                ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
+                ("out_deg_dev", C.c_void_p)]
 
 
 class SssGnnArgs(C.Structure):
-    _fields_ = [("n_rows", C.c_int64), ("w_dev", C.c_void_p), ("slope", C.c_float), ("num_executors", C.c_int), ("x_dev", C.c_void_p),
-                ("h_init_dev", C.c_void_p), ("h_dev", C.c_void_p), ("agg_dev", C.c_void_p), ("h_dag_dev", C.c_void_p),
-                ("h_glob_dev", C.c_void_p), ("out_dev", C.c_void_p), ("is_parent_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p),
-                ("idx0_dev", C.c_void_p), ("idx1_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
-                ("job_obs_dev", C.c_void_p), ("job_first_dev", C.c_void_p), ("job_cap_dev", C.c_void_p)]
+    _fields_ = [("n_rows", C.c_int64), ("w_dev", C.c_void_p), ("w2_dev", C.c_void_p), ("slope", C.c_float), ("num_executors", C.c_int),
+                ("layer", C.c_int), ("n_pad", C.c_int64), ("x_dev", C.c_void_p), ("h_init_dev", C.c_void_p), ("h_dev", C.c_void_p),
+                ("tmp_dev", C.c_void_p), ("h_dag_dev", C.c_void_p), ("h_glob_dev", C.c_void_p), ("out_dev", C.c_void_p),
+                ("out_deg_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("idx0_dev", C.c_void_p), ("dst_dev", C.c_void_p),
+                ("out_start_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
+                ("node_loc_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_first_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
+                ("job_nodes_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("obs_jobs_dev", C.c_void_p)]
 
 
-GNN_KINDS = {"prep": 0, "sink": 1, "msg": 2, "upd": 3, "dag": 4, "glob": 5, "stage": 6, "exec": 7}
+GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7}
 
 ERROR_NAMES = {
     1: "invalid action: does not belong to the action space",

@@ -6,8 +6,8 @@
 // One wavefront per env. Inputs are the env's own observation rows (nodes, edge_links, dag_ptr,
 // exec_supplies, the scalar block) plus the env's offsets into the flat outputs (exclusive prefix
 // sums of the per-env counts, computed by the caller); nothing of the simulator state is touched,
-// so the kernel is a pure function of the observation. LDS: 12 bytes per node slot
-// (generation, layer-membership bits, receiver bits).
+// so the kernel is a pure function of the observation. LDS: 16 bytes per node slot
+// (generation, layer-membership bits / first out-edge, receiver bits, end of the out-edge range).
 //
 // Included by sss_hip.hip (gfx950) and tests/emu/emu_backend.cpp (CPU wave emulator) after sss_sim.h.
 #pragma once
@@ -23,7 +23,9 @@ struct SssDecimaArgs {
   uint8_t* stage_mask;
   int64_t *src, *dst, *edge_obs;
   uint32_t* edge_layers;
-  int64_t *job_obs, *job_cap, *job_first;
+  int64_t *job_obs, *job_cap, *job_first, *job_nodes;
+  int64_t* out_start;  // i64[M] flat id of the node's first out-edge (edges are ordered by source node)
+  int32_t* out_deg;    // i32[M] number of out-edges
   int32_t* obs_depth;
 };
 
@@ -47,7 +49,8 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   int32_t* gen = (int32_t*)g_dec_lds;
   uint32_t* memb = (uint32_t*)(g_dec_lds + (size_t)4 * L.n_cap);
   uint32_t* recv = (uint32_t*)(g_dec_lds + (size_t)8 * L.n_cap);
-  for (int i = lane; i < n; i += 64) gen[i] = 0, recv[i] = 0;
+  int32_t* oend = (int32_t*)(g_dec_lds + (size_t)12 * L.n_cap);
+  for (int i = lane; i < n; i += 64) gen[i] = 0, recv[i] = 0, oend[i] = 0;
   wave_sync();
   // topological generations of the active subgraph (nx.topological_generations, utils.py:246-247):
   // longest-path relaxation over the edge list until nothing moves
@@ -75,6 +78,18 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
     lane_atomic_or_u32(&recv[u], lay);
   }
   wave_sync();
+  // out-edge range of every node: edge_links is ordered by (job, source, destination)
+  // (spark_sched_sim.py:249-258 + utils.subgraph keep the template's row-major edge order), so a
+  // node's out-edges are contiguous; `memb` is done and becomes the range start
+  int32_t* ostart = (int32_t*)memb;
+  for (int i = lane; i < n; i += 64) ostart[i] = 0;
+  wave_sync();
+  for (int e = lane; e < ne; e += 64) {
+    int u = el[2 * e];
+    if (e == 0 || el[2 * (e - 1)] != u) ostart[u] = e;
+    if (e == ne - 1 || el[2 * (e + 1)] != u) oend[u] = e + 1;
+  }
+  wave_sync();
   // jobs: executor cap (env_wrapper.py:72-82), first node
   for (int a = lane; a < A; a += 64) {
     int gap = E - sup[a];
@@ -82,6 +97,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
     int cap = gap < ncommit ? gap : ncommit;
     if (a == src_idx) cap = ncommit;
     d.job_obs[j0 + a] = env, d.job_cap[j0 + a] = cap, d.job_first[j0 + a] = n0 + dag_ptr[a];
+    d.job_nodes[j0 + a] = dag_ptr[a + 1] - dag_ptr[a];
   }
   // nodes: features (env_wrapper.py:110-143), job, schedulable rank, generation
   uint32_t run = 0, depth = 0;
@@ -112,6 +128,8 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
       x[4] = rem * dur / d.work_scale;
       d.node_obs[n0 + i] = env, d.node_loc[n0 + i] = i, d.node_job[n0 + i] = j0 + a;
       d.gen[n0 + i] = gen[i], d.node_recv[n0 + i] = recv[i], d.stage_mask[n0 + i] = sched;
+      int deg = oend[i] > 0 ? oend[i] - ostart[i] : 0;
+      d.out_start[n0 + i] = e0 + ostart[i], d.out_deg[n0 + i] = deg;
       if ((uint32_t)gen[i] > depth) depth = (uint32_t)gen[i];
     }
     uint64_t bal = wave_ballot(sched);

@@ -42,7 +42,7 @@ static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, i
 }
 
 static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void* stream) {
-  hipLaunchKernelGGL(sss_decima_graph_kernel, dim3(L.num_envs), dim3(64), (size_t)12 * L.n_cap, (hipStream_t)stream, L, B, E, d);
+  hipLaunchKernelGGL(sss_decima_graph_kernel, dim3(L.num_envs), dim3(64), (size_t)16 * L.n_cap, (hipStream_t)stream, L, B, E, d);
   return (int)hipGetLastError();
 }
 
@@ -61,10 +61,10 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
   switch (kind) {
     case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
-    case GNN_MSG: return gnn_launch_kind<GNN_MSG>(a, stream);
-    case GNN_UPD: return gnn_launch_kind<GNN_UPD>(a, stream);
-    case GNN_DAG: return gnn_launch_kind<GNN_DAG>(a, stream);
-    case GNN_GLOB: return gnn_launch_kind<GNN_GLOB>(a, stream);
+    case GNN_LAYER: return gnn_launch_kind<GNN_LAYER>(a, stream);
+    case GNN_COMMIT: return gnn_launch_kind<GNN_COMMIT>(a, stream);
+    case GNN_DAGSUM: return gnn_launch_kind<GNN_DAGSUM>(a, stream);
+    case GNN_GLOBSUM: return gnn_launch_kind<GNN_GLOBSUM>(a, stream);
     case GNN_STAGE: return gnn_launch_kind<GNN_STAGE>(a, stream);
     case GNN_EXEC: return gnn_launch_kind<GNN_EXEC>(a, stream);
   }

@@ -262,9 +262,10 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
   if (!g->node_off_dev || !g->job_off_dev || !g->edge_off_dev || !g->x_dev || !g->node_obs_dev || !g->node_loc_dev || !g->node_job_dev ||
       !g->sched_rank_dev || !g->gen_dev || !g->node_recv_dev || !g->stage_mask_dev || !g->src_dev || !g->dst_dev || !g->edge_obs_dev ||
-      !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev)
+      !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev ||
+      !g->job_nodes_dev || !g->out_start_dev || !g->out_deg_dev)
     return sss_fail(-1, "NULL argument");
-  if ((int64_t)12 * h->L.n_cap > 65536) return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
+  if ((int64_t)16 * h->L.n_cap > 65536) return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
   SssDecimaArgs d;
   d.active = g->active_dev, d.node_off = g->node_off_dev, d.job_off = g->job_off_dev, d.edge_off = g->edge_off_dev;
   d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale;
@@ -272,6 +273,7 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   d.gen = g->gen_dev, d.node_recv = g->node_recv_dev, d.stage_mask = g->stage_mask_dev;
   d.src = g->src_dev, d.dst = g->dst_dev, d.edge_obs = g->edge_obs_dev, d.edge_layers = g->edge_layers_dev;
   d.job_obs = g->job_obs_dev, d.job_cap = g->job_cap_dev, d.job_first = g->job_first_dev, d.obs_depth = g->obs_depth_dev;
+  d.job_nodes = g->job_nodes_dev, d.out_start = g->out_start_dev, d.out_deg = g->out_deg_dev;
   if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));
   return 0;
 }
@@ -281,10 +283,13 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   if (kind < 0 || kind >= GNN_KINDS) return sss_fail(-26, "unknown GNN stage");
   if (g->n_rows < 0 || !g->w_dev) return sss_fail(-1, "NULL argument");
   SssGnnArgs a;
-  a.n_rows = g->n_rows, a.w = g->w_dev, a.slope = g->slope, a.E = g->num_executors, a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev;
-  a.agg = g->agg_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev, a.out = g->out_dev, a.is_parent = g->is_parent_dev, a.obs_depth = g->obs_depth_dev;
-  a.idx0 = g->idx0_dev, a.idx1 = g->idx1_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.job_obs = g->job_obs_dev;
-  a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev;
+  a.n_rows = g->n_rows, a.w = g->w_dev, a.w2 = g->w2_dev, a.slope = g->slope, a.E = g->num_executors, a.layer = g->layer, a.n_pad = g->n_pad;
+  a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev, a.tmp = g->tmp_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev, a.out = g->out_dev;
+  a.out_deg = g->out_deg_dev, a.obs_depth = g->obs_depth_dev, a.idx0 = g->idx0_dev, a.dst = g->dst_dev, a.out_start = g->out_start_dev;
+  a.edge_layers = g->edge_layers_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.node_loc = g->node_loc_dev;
+  a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
+  a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
+  if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
   return 0;
 }

@@ -387,23 +387,29 @@ class DecimaPolicy(nn.Module):
             self._packed = (ver, w, slope)
         return self._packed[1]
 
-    def _launch(self, kind: str, n_rows: int, w: torch.Tensor, **ptrs) -> None:
+    def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, **ptrs) -> None:
+        import ctypes
+
         from .binding import GNN_KINDS, SssGnnArgs
         a = SssGnnArgs()
-        a.n_rows, a.w_dev, a.slope, a.num_executors = int(n_rows), w.data_ptr(), self._packed[2], self.num_executors
+        a.n_rows, a.w_dev, a.slope, a.num_executors, a.layer, a.n_pad = int(n_rows), w.data_ptr(), self._packed[2], self.num_executors, layer, n_pad
         for k, t in ptrs.items():
             setattr(a, k + "_dev", t.data_ptr() if t is not None and t.numel() else None)
         dev = w.device
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        import ctypes
         self._kb.check(self._kb.lib.sss_gnn_launch(GNN_KINDS[kind], ctypes.byref(a), stream))
 
-    def _use_kernels(self) -> bool:
-        if getattr(self, "_kb", None) is None:
-            return False
+    def _use_kernels(self, g: dict[str, Any] | None = None) -> bool:
+        if getattr(self, "_kb", None) is None or (g is not None and "out_start" not in g):
+            return False  # the kernels walk the ranges only the graph kernel (env.decima_graph) provides
         if getattr(self, "_arch_ok", None) is None:
             self._arch_ok = self._kernel_arch_ok()
         return self._arch_ok
+
+    @staticmethod
+    def _index_list(mask: torch.Tensor) -> torch.Tensor:
+        """indices of the set entries, padded with -1 to the mask's length (no device->host sync)"""
+        return torch.nonzero_static(mask, size=mask.numel(), fill_value=-1)[:, 0]
 
     @torch.no_grad()
     def _encode_kernels(self, g: dict[str, Any]) -> dict[str, torch.Tensor]:
@@ -412,37 +418,31 @@ class DecimaPolicy(nn.Module):
         x = g["x"]
         dev = x.device
         M, J, B = x.shape[0], g["job_obs"].numel(), g["n_obs"]
-        layers = graph_layers(g)
-        if "layer_ends" not in g:
-            g["layer_ends"] = [(g["dst"][e], g["src"][e]) for e, _ in layers]
         h_init = torch.empty((M, 16), dtype=torch.float32, device=dev)
         self._launch("prep", M, w["prep"], x=x, out=h_init)
-        if "node_recv" in g:
-            is_parent = (g["node_recv"] != 0).to(torch.uint8)
-        else:
-            is_parent = torch.zeros(M, dtype=torch.uint8, device=dev).index_fill_(0, g["src"], 1)
-        depth = g["obs_depth"].to(torch.int32).contiguous()
         h = torch.empty_like(h_init)
-        self._launch("sink", M, w["update"], h_init=h_init, h=h, is_parent=is_parent, obs_depth=depth, node_obs=g["node_obs"])
-        if layers:
-            agg = torch.empty_like(h_init)
-            for (e, recv), (dst_e, src_e) in zip(reversed(layers), reversed(g["layer_ends"])):
-                agg.zero_()
-                self._launch("msg", e.numel(), w["msg"], h=h, agg=agg, idx0=dst_e, idx1=src_e)
-                self._launch("upd", recv.numel(), w["update"], h_init=h_init, h=h, agg=agg, idx0=recv)
-        h_dag = torch.zeros((J, 16), dtype=torch.float32, device=dev)
-        self._launch("dag", M, w["dag"], x=x, h=h, h_dag=h_dag, node_job=g["node_job"])
-        h_glob = torch.zeros((B, 16), dtype=torch.float32, device=dev)
-        self._launch("glob", J, w["glob"], h_dag=h_dag, h_glob=h_glob, job_obs=g["job_obs"])
+        self._launch("sink", M, w["update"], h_init=h_init, h=h, out_deg=g["out_deg"], obs_depth=g["obs_depth"], node_obs=g["node_obs"])
+        depth = int(g["obs_depth"].max()) if M else 0
+        tmp = torch.empty_like(h_init)
+        for lvl in range(depth - 1, -1, -1):
+            recv = self._index_list((g["node_recv"] >> lvl) & 1)
+            self._launch("layer", M, w["msg"], layer=lvl, w2=w["update"], h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
+                         out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"])
+            self._launch("commit", M, w["msg"], h=h, tmp=tmp, idx0=recv)
+        h_dag = torch.empty((J, 16), dtype=torch.float32, device=dev)
+        self._launch("dagsum", J, w["dag"], x=x, h=h, h_dag=h_dag, job_first=g["job_first"], job_nodes=g["job_nodes"])
+        h_glob = torch.empty((B, 16), dtype=torch.float32, device=dev)
+        self._launch("globsum", B, w["glob"], h_dag=h_dag, h_glob=h_glob, obs_job_off=g["obs_job_off"], obs_jobs=g["obs_jobs"])
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()
-    def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor]):
-        idx = g["stage_mask"].nonzero(as_tuple=True)[0]
-        out = torch.empty(idx.numel(), dtype=torch.float32, device=idx.device)
-        self._launch("stage", idx.numel(), self._packed_weights()["stage"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"], out=out,
-                     idx0=idx, node_job=g["node_job"], node_obs=g["node_obs"])
-        return out, idx
+    def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor]) -> torch.Tensor:
+        """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
+        M = g["x"].shape[0]
+        out = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
+        self._launch("stage", M, self._packed_weights()["stage"], n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"],
+                     out=out, idx0=self._index_list(g["stage_mask"]), node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
+        return out
 
     @torch.no_grad()
     def _exec_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
@@ -485,18 +485,22 @@ class DecimaPolicy(nn.Module):
         are then meaningless)."""
         B, N = g["n_obs"], g["n_pad"]
         M, J = g["x"].shape[0], g["job_obs"].numel()
-        fast = self._use_kernels() and M > 0 and J > 0
-        h = self._encode_kernels(g) if fast else self.encode(g)
-        s, idx = self._stage_scores_kernels(g, h) if fast else self.stage_scores(g, h)
-        padded = torch.full((B, N), float("-inf"), dtype=s.dtype, device=s.device)
-        padded[g["node_obs"][idx], g["node_loc"][idx]] = s
+        fast = self._use_kernels(g) and M > 0 and J > 0
+        if fast:
+            h = self._encode_kernels(g)
+            padded = self._stage_scores_kernels(g, h)
+        else:
+            h = self.encode(g)
+            s, idx = self.stage_scores(g, h)
+            padded = torch.full((B, N), float("-inf"), dtype=s.dtype, device=s.device)
+            padded[g["node_obs"][idx], g["node_loc"][idx]] = s
         any_stage = torch.isfinite(padded).any(1)
         p = torch.softmax(torch.where(any_stage[:, None], padded, torch.zeros_like(padded)), 1)
         col = torch.multinomial(p, 1, generator=generator)[:, 0]
         node = (_excl_cumsum(g["obs_nodes"]) + col).clamp(max=max(M - 1, 0))
         if M == 0:
-            z = torch.zeros(B, dtype=torch.long, device=s.device)
-            return {"stage_sel": z, "job_idx": z, "exec_sel": z, "lgprob": torch.zeros(B, device=s.device), "any_stage": any_stage}
+            z = torch.zeros(B, dtype=torch.long, device=padded.device)
+            return {"stage_sel": z, "job_idx": z, "exec_sel": z, "lgprob": torch.zeros(B, device=padded.device), "any_stage": any_stage}
         stage_sel = g["sched_rank"][node]
         job_gid = g["node_job"][node]
         job_slot = job_gid - _excl_cumsum(g["obs_jobs"])

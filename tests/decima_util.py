@@ -51,8 +51,9 @@ def check_decima_fixture(name, device, lib, n_steps):
             hk = policy._encode_kernels(kg)
             for k in ("node", "dag", "glob"):
                 assert float((hk[k] - h[k]).abs().max()) <= SCORE_ATOL, (t, k)
-            sk, sk_idx = policy._stage_scores_kernels(kg, hk)
-            assert torch.equal(sk_idx, ss_idx) and float((sk - ss_flat).abs().max()) <= SCORE_ATOL, t
+            sk = policy._stage_scores_kernels(kg, hk)
+            assert torch.equal(torch.isfinite(sk), torch.isfinite(ss)), t
+            assert float((sk - ss)[torch.isfinite(ss)].abs().max()) <= SCORE_ATOL, t
             for j, es_t in enumerate(es_all):
                 jg = job_off + torch.clamp(torch.full_like(job_off, j), max=obs["n_jobs"].long() - 1)
                 ek = policy._exec_scores_kernels(kg, hk, jg)
@@ -121,3 +122,10 @@ def compare_graphs(kg, cg, f):
     for (e, r), (ke, kr) in zip(layers, k_layers):
         assert torch.equal(e, ke) and torch.equal(r, kr)
     assert not (kg["edge_layers"] >> len(layers)).any() and not (kg["node_recv"] >> len(layers)).any()
+    # out-edge ranges: every edge lies in its source's range, ranges tile the edge list
+    deg = torch.zeros(kg["x"].shape[0], dtype=torch.long, device=kg["x"].device).index_add_(0, kg["src"], torch.ones_like(kg["src"]))
+    assert torch.equal(kg["out_deg"].long(), deg)
+    e_ids = torch.arange(kg["src"].numel(), device=deg.device)
+    assert bool(((e_ids >= kg["out_start"][kg["src"]]) & (e_ids < kg["out_start"][kg["src"]] + deg[kg["src"]])).all())
+    cnt = torch.zeros(kg["job_obs"].numel(), dtype=torch.long, device=deg.device).index_add_(0, kg["node_job"], torch.ones_like(kg["node_job"]))
+    assert torch.equal(kg["job_nodes"], cnt)

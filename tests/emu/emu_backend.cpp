@@ -58,10 +58,10 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
   switch (kind) {
     case GNN_PREP: return gnn_run_kind<GNN_PREP>(a);
     case GNN_SINK: return gnn_run_kind<GNN_SINK>(a);
-    case GNN_MSG: return gnn_run_kind<GNN_MSG>(a);
-    case GNN_UPD: return gnn_run_kind<GNN_UPD>(a);
-    case GNN_DAG: return gnn_run_kind<GNN_DAG>(a);
-    case GNN_GLOB: return gnn_run_kind<GNN_GLOB>(a);
+    case GNN_LAYER: return gnn_run_kind<GNN_LAYER>(a);
+    case GNN_COMMIT: return gnn_run_kind<GNN_COMMIT>(a);
+    case GNN_DAGSUM: return gnn_run_kind<GNN_DAGSUM>(a);
+    case GNN_GLOBSUM: return gnn_run_kind<GNN_GLOBSUM>(a);
     case GNN_STAGE: return gnn_run_kind<GNN_STAGE>(a);
     case GNN_EXEC: return gnn_run_kind<GNN_EXEC>(a);
   }
