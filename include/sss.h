@@ -162,7 +162,8 @@ int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* strea
  * written by sss_decima_graph_build: one launch per stage of the pass, each evaluating one whole MLP
  * per row with its gather / scatter fused in. Supports the published architecture
  * (config/decima_tpch.yaml:66-78: embed_dim 16, GNN MLPs [32,16] + LeakyReLU, policy MLPs [64,64] +
- * Tanh). `w_dev` = that stage's MLP parameters packed [W1,b1,W2,b2,W3,b3] (torch.nn.Linear layout).
+ * Tanh). `w_dev` = that stage's MLP parameters packed [W1, b1, W2^T, b2, W3, b3] (W1, W3 in torch.nn.Linear's
+ * [out,in] layout, the middle layer transposed to [in,out]).
  * kind: 0 PREP (rows = nodes: out = h_init[M,16] from x), 1 SINK (h = h_init where the node's
  * observation has depth 0 [obs_depth given], else 0 for nodes with out-edges, else update(h_init)),
  * 2 LAYER (rows = idx0, -1 = skip: tmp[n] = h_init[n] + update(sum over n's out-edges in DAG layer

@@ -20,19 +20,26 @@
 //
 // No atomics: a node's out-edges, a job's nodes and an observation's jobs are contiguous ranges of
 // the compact graph (sss_decima.h), so every sum is a short loop inside one thread, in a fixed order.
-// Weights are read through uniform (scalar) loads: every thread of a wave multiplies its own row by
-// the same weight. This is fp32 vector work: the GEMMs are [rows x <=53] x [<=53 x <=64] - far too
+// The parameters of the launch's MLP(s) are staged in LDS once per workgroup and read from there
+// as broadcasts (every thread of a wave multiplies its own row by the same weight; leaving them to
+// scalar loads makes the compiler hoist thousands of loads and spill SGPRs through v_writelane). This is fp32 vector work: the GEMMs are [rows x <=53] x [<=53 x <=64] - far too
 // thin for MFMA tiles to pay, and bf16/fp8 MFMA would not hold the 2e-5 agreement with the reference.
-// Parameters of one MLP are packed [W1 (H1 x IN), b1, W2 (H2 x H1), b2, W3 (OUT x H2), b3], each W
-// row-major exactly as torch.nn.Linear.weight.
+// Parameters of one MLP are packed [W1 (H1 x IN), b1, W2^T (H1 x H2), b2, W3 (OUT x H2), b3]: W1 and
+// W3 row-major exactly as torch.nn.Linear.weight, the middle layer transposed.
 //
 // Included by sss_hip.hip (gfx950) and tests/emu/emu_backend.cpp (rows run in a plain loop there).
 #pragma once
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__clang__)
 #define GNN_UNROLL _Pragma("unroll")
+#define GNN_NO_UNROLL _Pragma("clang loop unroll(disable)")
 #define GNN_FP_CONTRACT _Pragma("clang fp contract(fast)")
+// scheduling fence after every group of output neurons (~64 weights): without it the machine
+// scheduler hoists the weight reads of ALL neurons to the top and spills hundreds of registers
+#define GNN_FENCE(o, in) if ((((o) + 1) * (in)) % 64 < (in)) __builtin_amdgcn_sched_barrier(0)
 #else
+#define GNN_FENCE(o, in)
+#define GNN_NO_UNROLL
 #define GNN_UNROLL
 #define GNN_FP_CONTRACT
 #endif
@@ -69,30 +76,43 @@ SSS_DEV float gnn_act(float v, float slope) {
   return tanhf(v);
 }
 
-template <int IN, int H1, int H2, int OUT, int ACT>
-SSS_DEV void gnn_mlp(const float* __restrict__ w, const float (&x)[IN], float (&y)[OUT], float slope) {
-GNN_FP_CONTRACT
+// One row through Linear-act-Linear-act (`gnn_hidden`) and the last Linear (`gnn_out`). Packed
+// parameters: W1 (H1 x IN, row-major), b1, W2T (H1 x H2: the SECOND layer transposed), b2, W3
+// (OUT x H2), b3. Layer 1 is streamed into layer 2: each hidden-1 neuron is computed and immediately
+// scattered into the H2 accumulators, in a real (not unrolled) loop - both reads are contiguous, and
+// the loop keeps the compiler from hoisting every weight read of the MLP to the top and spilling
+// hundreds of registers. The last layer is linear, so sums of MLP outputs (messages over edges,
+// node summaries over a job, job summaries over an observation) are taken over the hidden-2
+// vectors and pushed through W3 once: sum_k (W3 h2_k + b3) = W3 (sum_k h2_k) + count * b3.
+template <int IN, int H1, int H2, int ACT>
+SSS_DEV void gnn_hidden(const float* __restrict__ w, const float (&x)[IN], float (&h2)[H2], float slope) {
+  GNN_FP_CONTRACT
   const float* W1 = w;
   const float* b1 = W1 + H1 * IN;
-  const float* W2 = b1 + H1;
-  const float* b2 = W2 + H2 * H1;
-  const float* W3 = b2 + H2;
+  const float* W2T = b1 + H1;
+  const float* b2 = W2T + H2 * H1;
+  GNN_UNROLL for (int o = 0; o < H2; o++) h2[o] = b2[o];
+  GNN_NO_UNROLL for (int j = 0; j < H1; j++) {
+    const float* wr = W1 + j * IN;
+    float acc = b1[j];
+    GNN_UNROLL for (int i = 0; i < IN; i++) acc += wr[i] * x[i];
+    float t = gnn_act<ACT>(acc, slope);
+    const float* wc = W2T + j * H2;
+    GNN_UNROLL for (int o = 0; o < H2; o++) h2[o] += wc[o] * t;
+  }
+  GNN_UNROLL for (int o = 0; o < H2; o++) h2[o] = gnn_act<ACT>(h2[o], slope);
+}
+
+// emit(o, b3[o] * bias_count + W3[o,:] . h2) for every output o
+template <int IN, int H1, int H2, int OUT, typename Emit>
+SSS_DEV void gnn_out(const float* __restrict__ w, const float (&h2)[H2], float bias_count, Emit emit) {
+  GNN_FP_CONTRACT
+  const float* W3 = w + H1 * IN + H1 + H2 * H1 + H2;
   const float* b3 = W3 + OUT * H2;
-  float h1[H1], h2[H2];
-  GNN_UNROLL for (int o = 0; o < H1; o++) {
-    float acc = b1[o];
-    GNN_UNROLL for (int i = 0; i < IN; i++) acc += W1[o * IN + i] * x[i];
-    h1[o] = gnn_act<ACT>(acc, slope);
-  }
-  GNN_UNROLL for (int o = 0; o < H2; o++) {
-    float acc = b2[o];
-    GNN_UNROLL for (int i = 0; i < H1; i++) acc += W2[o * H1 + i] * h1[i];
-    h2[o] = gnn_act<ACT>(acc, slope);
-  }
-  GNN_UNROLL for (int o = 0; o < OUT; o++) {
-    float acc = b3[o];
+  GNN_NO_UNROLL for (int o = 0; o < OUT; o++) {
+    float acc = b3[o] * bias_count;
     GNN_UNROLL for (int i = 0; i < H2; i++) acc += W3[o * H2 + i] * h2[i];
-    y[o] = acc;
+    emit(o, acc);
   }
 }
 
@@ -101,81 +121,116 @@ SSS_DEV void gnn_load(const float* p, float* dst) {
   GNN_UNROLL for (int i = 0; i < N; i++) dst[i] = p[i];
 }
 
+// number of packed parameters of the MLP(s) a stage evaluates (LAYER: message MLP then update MLP)
+constexpr int gnn_mlp_params(int in, int h1, int h2, int out) { return h1 * in + h1 + h2 * h1 + h2 + out * h2 + out; }
+constexpr int GNN_W_GNN16 = gnn_mlp_params(16, 32, 16, 16);
 template <int KIND>
-SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r) {
+constexpr int gnn_weight_count() {
+  return KIND == GNN_PREP ? gnn_mlp_params(GNN_NF, 32, 16, 16)
+       : KIND == GNN_DAGSUM ? gnn_mlp_params(GNN_NF + 16, 32, 16, 16)
+       : KIND == GNN_STAGE ? gnn_mlp_params(GNN_NF + 48, 64, 64, 1)
+       : KIND == GNN_EXEC ? gnn_mlp_params(GNN_DF + 33, 64, 64, 1)
+       : KIND == GNN_COMMIT ? 0 : GNN_W_GNN16;
+}
+
+// `w` / `w2`: where this thread reads the parameters from (the gfx950 build stages them in LDS and
+// every lane reads the same address - a broadcast; the emulator reads the argument buffers)
+template <int KIND>
+SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r, const float* w, const float* w2) {
   constexpr int F = GNN_EMB;
   if (KIND == GNN_PREP) {
-    float x[GNN_NF], y[F];
+    float x[GNN_NF], h2[16];
     gnn_load<GNN_NF>(a.x + r * GNN_NF, x);
-    gnn_mlp<GNN_NF, 32, 16, F, 0>(a.w, x, y, a.slope);
-    GNN_UNROLL for (int i = 0; i < F; i++) a.out[r * F + i] = y[i];
+    gnn_hidden<GNN_NF, 32, 16, 0>(w, x, h2, a.slope);
+    gnn_out<GNN_NF, 32, 16, F>(w, h2, 1.0f, [&](int o, float v) { a.out[r * F + o] = v; });
   } else if (KIND == GNN_SINK) {
-    float x[F], y[F];
+    float x[F], h2[16];
     gnn_load<F>(a.h_init + r * F, x);
-    gnn_mlp<F, 32, 16, F, 0>(a.w, x, y, a.slope);
     bool par = a.out_deg[r] != 0;
     bool skip = a.obs_depth != nullptr && a.obs_depth[a.node_obs[r]] == 0;  // single-layer observation: mlp_prep only
-    GNN_UNROLL for (int i = 0; i < F; i++) a.h[r * F + i] = skip ? x[i] : (par ? 0.0f : y[i]);
+    if (skip || par) {
+      GNN_UNROLL for (int i = 0; i < F; i++) a.h[r * F + i] = skip ? x[i] : 0.0f;
+      return;
+    }
+    gnn_hidden<F, 32, 16, 0>(w, x, h2, a.slope);
+    gnn_out<F, 32, 16, F>(w, h2, 1.0f, [&](int o, float v) { a.h[r * F + o] = v; });
   } else if (KIND == GNN_LAYER) {
     int64_t n = a.idx0[r];
     if (n < 0) return;
-    float acc[F], x[F], y[F];
-    GNN_UNROLL for (int i = 0; i < F; i++) acc[i] = 0.0f;
+    float acc[16], x[F], h2[16];
+    GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     int64_t e0 = a.out_start[n];
-    int deg = a.out_deg[n];
+    int deg = a.out_deg[n], used = 0;
     for (int k = 0; k < deg; k++) {
       if (!((a.edge_layers[e0 + k] >> a.layer) & 1u)) continue;
       gnn_load<F>(a.h + a.dst[e0 + k] * F, x);
-      gnn_mlp<F, 32, 16, F, 0>(a.w, x, y, a.slope);
-      GNN_UNROLL for (int i = 0; i < F; i++) acc[i] += y[i];
+      gnn_hidden<F, 32, 16, 0>(w, x, h2, a.slope);
+      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += h2[i];
+      used++;
     }
-    gnn_mlp<F, 32, 16, F, 0>(a.w2, acc, y, a.slope);
-    GNN_UNROLL for (int i = 0; i < F; i++) a.tmp[n * F + i] = a.h_init[n * F + i] + y[i];
+    float agg[F];
+    GNN_UNROLL for (int i = 0; i < F; i++) agg[i] = 0.0f;
+    // the aggregated message = W3 . (sum of hidden vectors) + used * b3; it feeds the update MLP,
+    // whose input must sit in registers: F is small, so this last layer is unrolled
+    {
+      GNN_FP_CONTRACT
+      const float* W3 = w + 32 * F + 32 + 16 * 32 + 16;
+      const float* b3 = W3 + F * 16;
+      GNN_UNROLL for (int o = 0; o < F; o++) {
+        float v = b3[o] * (float)used;
+        GNN_UNROLL for (int i = 0; i < 16; i++) v += W3[o * 16 + i] * acc[i];
+        agg[o] = v;
+        GNN_FENCE(o, 16);
+      }
+    }
+    gnn_hidden<F, 32, 16, 0>(w2, agg, h2, a.slope);
+    gnn_out<F, 32, 16, F>(w2, h2, 1.0f, [&](int o, float v) { a.tmp[n * F + o] = a.h_init[n * F + o] + v; });
   } else if (KIND == GNN_COMMIT) {
     int64_t n = a.idx0[r];
     if (n < 0) return;
     GNN_UNROLL for (int i = 0; i < F; i++) a.h[n * F + i] = a.tmp[n * F + i];
   } else if (KIND == GNN_DAGSUM) {
-    float acc[F], x[GNN_NF + F], y[F];
-    GNN_UNROLL for (int i = 0; i < F; i++) acc[i] = 0.0f;
+    float acc[16], x[GNN_NF + F], h2[16];
+    GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     int64_t n0 = a.job_first[r], cnt = a.job_nodes[r];
     for (int64_t n = n0; n < n0 + cnt; n++) {
       gnn_load<GNN_NF>(a.x + n * GNN_NF, x);
       gnn_load<F>(a.h + n * F, x + GNN_NF);
-      gnn_mlp<GNN_NF + F, 32, 16, F, 0>(a.w, x, y, a.slope);
-      GNN_UNROLL for (int i = 0; i < F; i++) acc[i] += y[i];
+      gnn_hidden<GNN_NF + F, 32, 16, 0>(w, x, h2, a.slope);
+      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += h2[i];
     }
-    GNN_UNROLL for (int i = 0; i < F; i++) a.h_dag[r * F + i] = acc[i];
+    gnn_out<GNN_NF + F, 32, 16, F>(w, acc, (float)cnt, [&](int o, float v) { a.h_dag[r * F + o] = v; });
   } else if (KIND == GNN_GLOBSUM) {
-    float acc[F], x[F], y[F];
-    GNN_UNROLL for (int i = 0; i < F; i++) acc[i] = 0.0f;
+    float acc[16], x[F], h2[16];
+    GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     int64_t j0 = a.obs_job_off[r], cnt = a.obs_jobs[r];
     for (int64_t j = j0; j < j0 + cnt; j++) {
       gnn_load<F>(a.h_dag + j * F, x);
-      gnn_mlp<F, 32, 16, F, 0>(a.w, x, y, a.slope);
-      GNN_UNROLL for (int i = 0; i < F; i++) acc[i] += y[i];
+      gnn_hidden<F, 32, 16, 0>(w, x, h2, a.slope);
+      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += h2[i];
     }
-    GNN_UNROLL for (int i = 0; i < F; i++) a.h_glob[r * F + i] = acc[i];
+    gnn_out<F, 32, 16, F>(w, acc, (float)cnt, [&](int o, float v) { a.h_glob[r * F + o] = v; });
   } else if (KIND == GNN_STAGE) {
     int64_t n = a.idx0[r];
     if (n < 0) return;
-    float x[GNN_NF + 3 * F], y[1];
+    float x[GNN_NF + 3 * F], h2[64];
     gnn_load<GNN_NF>(a.x + n * GNN_NF, x);
     gnn_load<F>(a.h + n * F, x + GNN_NF);
     gnn_load<F>(a.h_dag + a.node_job[n] * F, x + GNN_NF + F);
     gnn_load<F>(a.h_glob + a.node_obs[n] * F, x + GNN_NF + 2 * F);
-    gnn_mlp<GNN_NF + 3 * F, 64, 64, 1, 1>(a.w, x, y, 0.0f);
-    a.out[a.node_obs[n] * a.n_pad + a.node_loc[n]] = y[0];
+    gnn_hidden<GNN_NF + 3 * F, 64, 64, 1>(w, x, h2, 0.0f);
+    gnn_out<GNN_NF + 3 * F, 64, 64, 1>(w, h2, 1.0f, [&](int, float v) { a.out[a.node_obs[n] * a.n_pad + a.node_loc[n]] = v; });
   } else if (KIND == GNN_EXEC) {
     int64_t b = r / a.E;
     int c = (int)(r - b * a.E);
     int64_t j = a.idx0[b];
-    float x[GNN_DF + 2 * F + 1], y[1];
+    float x[GNN_DF + 2 * F + 1], h2[64];
     gnn_load<GNN_DF>(a.x + a.job_first[j] * GNN_NF, x);
     gnn_load<F>(a.h_dag + j * F, x + GNN_DF);
     gnn_load<F>(a.h_glob + a.job_obs[j] * F, x + GNN_DF + F);
     x[GNN_DF + 2 * F] = (float)c / (float)a.E;
-    gnn_mlp<GNN_DF + 2 * F + 1, 64, 64, 1, 1>(a.w, x, y, 0.0f);
-    a.out[r] = c < a.job_cap[j] ? y[0] : -__builtin_inff();
+    gnn_hidden<GNN_DF + 2 * F + 1, 64, 64, 1>(w, x, h2, 0.0f);
+    bool ok = c < a.job_cap[j];
+    gnn_out<GNN_DF + 2 * F + 1, 64, 64, 1>(w, h2, 1.0f, [&](int, float v) { a.out[r] = ok ? v : -__builtin_inff(); });
   }
 }

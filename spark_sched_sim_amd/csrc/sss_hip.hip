@@ -48,8 +48,14 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
 
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
+  constexpr int NW = gnn_weight_count<KIND>();
+  constexpr int NW2 = KIND == GNN_LAYER ? GNN_W_GNN16 : 0;
+  __shared__ __attribute__((aligned(16))) float w_lds[NW + NW2 + 4];
+  for (int i = threadIdx.x; i < NW; i += 256) w_lds[i] = a.w[i];
+  if (NW2) for (int i = threadIdx.x; i < NW2; i += 256) w_lds[NW + i] = a.w2[i];
+  __syncthreads();
   int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r < a.n_rows) gnn_row<KIND>(a, r);
+  if (r < a.n_rows) gnn_row<KIND>(a, r, w_lds, w_lds + NW);
 }
 template <int KIND>
 static int gnn_launch_kind(const SssGnnArgs& a, void* stream) {

@@ -377,8 +377,10 @@ class DecimaPolicy(nn.Module):
     def _packed_weights(self) -> dict[str, torch.Tensor]:
         ver = tuple(p._version for p in self.parameters()) + (str(self.device),)
         if getattr(self, "_packed", None) is None or self._packed[0] != ver:
-            def pack(mlp):
-                return torch.cat([t.detach().reshape(-1).float() for m in mlp if isinstance(m, nn.Linear) for t in (m.weight, m.bias)]).contiguous()
+            def pack(mlp):  # [W1, b1, W2^T, b2, W3, b3] (include/sss.h sss_gnn_launch)
+                lin = [m for m in mlp if isinstance(m, nn.Linear)]
+                parts = [lin[0].weight, lin[0].bias, lin[1].weight.t(), lin[1].bias, lin[2].weight, lin[2].bias]
+                return torch.cat([t.detach().float().contiguous().reshape(-1) for t in parts]).contiguous()
             enc = self.encoder
             w = {"prep": pack(enc.node_encoder.mlp_prep), "msg": pack(enc.node_encoder.mlp_msg), "update": pack(enc.node_encoder.mlp_update),
                  "dag": pack(enc.dag_encoder.mlp), "glob": pack(enc.global_encoder.mlp),

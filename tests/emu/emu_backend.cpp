@@ -51,7 +51,7 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
 
 template <int KIND>
 static int gnn_run_kind(const SssGnnArgs& a) {
-  for (int64_t r = 0; r < a.n_rows; r++) gnn_row<KIND>(a, r);
+  for (int64_t r = 0; r < a.n_rows; r++) gnn_row<KIND>(a, r, a.w, a.w2);
   return 0;
 }
 static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
