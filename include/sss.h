@@ -155,6 +155,7 @@ typedef struct sss_decima_graph {
   int64_t* job_nodes_dev; /* i64[J] number of nodes of the job (they follow job_first back to back) */
   int64_t* out_start_dev; /* i64[M] flat id of the node's first out-edge; a node's out-edges are contiguous */
   int32_t* out_deg_dev;   /* i32[M] number of out-edges */
+  int32_t* layer_recv_dev; /* i32[32], zeroed by the caller: [l] += nodes that are sources of layer-l edges */
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
 
@@ -168,8 +169,9 @@ int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* strea
  * observation has depth 0 [obs_depth given], else 0 for nodes with out-edges, else update(h_init)),
  * 2 LAYER (rows = idx0, -1 = skip: tmp[n] = h_init[n] + update(sum over n's out-edges in DAG layer
  * `layer` of msg(h[dst])); w = msg, w2 = update), 3 COMMIT (h[n] = tmp[n] for the same rows),
- * 4 DAGSUM (rows = jobs: h_dag[j] = sum over its nodes of dag([x,h])), 5 GLOBSUM (rows =
- * observations: h_glob[o] = sum over its jobs of glob(h_dag)), 6 STAGE (rows = idx0, -1 = skip:
+ * 4 DAGSUM (rows = jobs: h_dag[j] = sum over its nodes of dag([x,h]), from the hidden vectors
+ * 8 DAGHID left in tmp[M,16]), 5 GLOBSUM (rows = observations: h_glob[o] = sum over its jobs of
+ * glob(h_dag), from the hidden vectors 9 GLOBHID left in tmp[J,16]), 6 STAGE (rows = idx0, -1 = skip:
  * out[node_obs*n_pad + node_loc] = score), 7 EXEC (rows = (b, c), c < E: out[b*E + c] = score of c+1
  * executors for job idx0[b], -inf where c >= job_cap). No atomics, fixed summation order. */
 typedef struct sss_gnn_args {

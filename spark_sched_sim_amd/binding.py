@@ -42,7 +42,7 @@ class SssDecimaGraph(C.Structure):
                 ("node_recv_dev", C.c_void_p), ("stage_mask_dev", C.c_void_p), ("src_dev", C.c_void_p), ("dst_dev", C.c_void_p),
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
-                ("out_deg_dev", C.c_void_p)]
+                ("out_deg_dev", C.c_void_p), ("layer_recv_dev", C.c_void_p)]
 
 
 class SssGnnArgs(C.Structure):
@@ -55,7 +55,7 @@ class SssGnnArgs(C.Structure):
                 ("job_nodes_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("obs_jobs_dev", C.c_void_p)]
 
 
-GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7}
+GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7, "daghid": 8, "globhid": 9}
 
 ERROR_NAMES = {
     1: "invalid action: does not belong to the action space",

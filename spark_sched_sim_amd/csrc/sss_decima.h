@@ -27,6 +27,7 @@ struct SssDecimaArgs {
   int64_t* out_start;  // i64[M] flat id of the node's first out-edge (edges are ordered by source node)
   int32_t* out_deg;    // i32[M] number of out-edges
   int32_t* obs_depth;
+  int32_t* layer_recv;  // i32[32], zeroed by the caller: [l] += number of receiving nodes of DAG layer l
 };
 
 SSS_SHARED_DYN(g_dec_lds);
@@ -138,4 +139,11 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   }
   depth = ~wave_min_u32(~depth);
   if (lane == 0) d.obs_depth[env] = (int32_t)depth;
+  // batch-wide receiver counts per layer (sizes the per-layer launches of the GNN kernels)
+  for (uint32_t l = 0; l < depth; l++) {
+    uint32_t c = 0;
+    for (int i = lane; i < n; i += 64) c += (recv[i] >> l) & 1u;
+    c = wave_sum_u32(c);
+    if (lane == 0 && c) lane_atomic_add_i32(&d.layer_recv[l], (int32_t)c);
+  }
 }

@@ -11,7 +11,9 @@
 //   LAYER   tmp[r]    = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
 //                       for the layer's receiving nodes r                       (scheduler.py:214-232)
 //   COMMIT  h[r]      = tmp[r]   (a layer reads the previous h everywhere before any node moves)
+//   DAGHID  tmp[n]    = hidden part of dag([x[n], h[n]])
 //   DAGSUM  h_dag[j]  = sum over the job's nodes n of dag([x[n], h[n]])        (scheduler.py:256-262)
+//   GLOBHID tmp[j]    = hidden part of glob(h_dag[j])
 //   GLOBSUM h_glob[o] = sum over the observation's jobs j of glob(h_dag[j])    (scheduler.py:271-283)
 //   STAGE   score[obs(n), loc(n)] = stage([x, h, h_dag[job], h_glob[obs]] of schedulable node n)
 //                                                                                (scheduler.py:296-318)
@@ -44,7 +46,7 @@
 #define GNN_FP_CONTRACT
 #endif
 
-enum { GNN_PREP = 0, GNN_SINK, GNN_LAYER, GNN_COMMIT, GNN_DAGSUM, GNN_GLOBSUM, GNN_STAGE, GNN_EXEC, GNN_KINDS };
+enum { GNN_PREP = 0, GNN_SINK, GNN_LAYER, GNN_COMMIT, GNN_DAGSUM, GNN_GLOBSUM, GNN_STAGE, GNN_EXEC, GNN_DAGHID, GNN_GLOBHID, GNN_KINDS };
 enum { GNN_EMB = 16, GNN_NF = 5, GNN_DF = 3 };
 
 struct SssGnnArgs {
@@ -127,7 +129,7 @@ constexpr int GNN_W_GNN16 = gnn_mlp_params(16, 32, 16, 16);
 template <int KIND>
 constexpr int gnn_weight_count() {
   return KIND == GNN_PREP ? gnn_mlp_params(GNN_NF, 32, 16, 16)
-       : KIND == GNN_DAGSUM ? gnn_mlp_params(GNN_NF + 16, 32, 16, 16)
+       : (KIND == GNN_DAGSUM || KIND == GNN_DAGHID) ? gnn_mlp_params(GNN_NF + 16, 32, 16, 16)
        : KIND == GNN_STAGE ? gnn_mlp_params(GNN_NF + 48, 64, 64, 1)
        : KIND == GNN_EXEC ? gnn_mlp_params(GNN_DF + 33, 64, 64, 1)
        : KIND == GNN_COMMIT ? 0 : GNN_W_GNN16;
@@ -189,25 +191,31 @@ SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r, const float* w, const float
     int64_t n = a.idx0[r];
     if (n < 0) return;
     GNN_UNROLL for (int i = 0; i < F; i++) a.h[n * F + i] = a.tmp[n * F + i];
+  } else if (KIND == GNN_DAGHID) {
+    float x[GNN_NF + F], h2[16];
+    gnn_load<GNN_NF>(a.x + r * GNN_NF, x);
+    gnn_load<F>(a.h + r * F, x + GNN_NF);
+    gnn_hidden<GNN_NF + F, 32, 16, 0>(w, x, h2, a.slope);
+    GNN_UNROLL for (int i = 0; i < 16; i++) a.tmp[r * 16 + i] = h2[i];
   } else if (KIND == GNN_DAGSUM) {
-    float acc[16], x[GNN_NF + F], h2[16];
+    float acc[16];
     GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     int64_t n0 = a.job_first[r], cnt = a.job_nodes[r];
     for (int64_t n = n0; n < n0 + cnt; n++) {
-      gnn_load<GNN_NF>(a.x + n * GNN_NF, x);
-      gnn_load<F>(a.h + n * F, x + GNN_NF);
-      gnn_hidden<GNN_NF + F, 32, 16, 0>(w, x, h2, a.slope);
-      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += h2[i];
+      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += a.tmp[n * 16 + i];
     }
     gnn_out<GNN_NF + F, 32, 16, F>(w, acc, (float)cnt, [&](int o, float v) { a.h_dag[r * F + o] = v; });
+  } else if (KIND == GNN_GLOBHID) {
+    float x[F], h2[16];
+    gnn_load<F>(a.h_dag + r * F, x);
+    gnn_hidden<F, 32, 16, 0>(w, x, h2, a.slope);
+    GNN_UNROLL for (int i = 0; i < 16; i++) a.tmp[r * 16 + i] = h2[i];
   } else if (KIND == GNN_GLOBSUM) {
-    float acc[16], x[F], h2[16];
+    float acc[16];
     GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     int64_t j0 = a.obs_job_off[r], cnt = a.obs_jobs[r];
     for (int64_t j = j0; j < j0 + cnt; j++) {
-      gnn_load<F>(a.h_dag + j * F, x);
-      gnn_hidden<F, 32, 16, 0>(w, x, h2, a.slope);
-      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += h2[i];
+      GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += a.tmp[j * 16 + i];
     }
     gnn_out<F, 32, 16, F>(w, acc, (float)cnt, [&](int o, float v) { a.h_glob[r * F + o] = v; });
   } else if (KIND == GNN_STAGE) {

@@ -73,6 +73,8 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
     case GNN_GLOBSUM: return gnn_launch_kind<GNN_GLOBSUM>(a, stream);
     case GNN_STAGE: return gnn_launch_kind<GNN_STAGE>(a, stream);
     case GNN_EXEC: return gnn_launch_kind<GNN_EXEC>(a, stream);
+    case GNN_DAGHID: return gnn_launch_kind<GNN_DAGHID>(a, stream);
+    case GNN_GLOBHID: return gnn_launch_kind<GNN_GLOBHID>(a, stream);
   }
   return -1;
 }

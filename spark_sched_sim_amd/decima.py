@@ -424,17 +424,22 @@ class DecimaPolicy(nn.Module):
         self._launch("prep", M, w["prep"], x=x, out=h_init)
         h = torch.empty_like(h_init)
         self._launch("sink", M, w["update"], h_init=h_init, h=h, out_deg=g["out_deg"], obs_depth=g["obs_depth"], node_obs=g["node_obs"])
-        depth = int(g["obs_depth"].max()) if M else 0
-        tmp = torch.empty_like(h_init)
+        if "layer_counts" not in g:
+            g["layer_counts"] = g["layer_recv"].tolist()  # the only device->host sync of the pass
+        counts = g["layer_counts"]
+        depth = max((lvl + 1 for lvl, c in enumerate(counts) if c), default=0)
+        tmp = torch.empty((max(M, J), 16), dtype=torch.float32, device=dev)
         for lvl in range(depth - 1, -1, -1):
-            recv = self._index_list((g["node_recv"] >> lvl) & 1)
-            self._launch("layer", M, w["msg"], layer=lvl, w2=w["update"], h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
+            recv = torch.nonzero_static((g["node_recv"] >> lvl) & 1, size=counts[lvl])[:, 0]
+            self._launch("layer", counts[lvl], w["msg"], layer=lvl, w2=w["update"], h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
                          out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"])
-            self._launch("commit", M, w["msg"], h=h, tmp=tmp, idx0=recv)
+            self._launch("commit", counts[lvl], w["msg"], h=h, tmp=tmp, idx0=recv)
         h_dag = torch.empty((J, 16), dtype=torch.float32, device=dev)
-        self._launch("dagsum", J, w["dag"], x=x, h=h, h_dag=h_dag, job_first=g["job_first"], job_nodes=g["job_nodes"])
+        self._launch("daghid", M, w["dag"], x=x, h=h, tmp=tmp)
+        self._launch("dagsum", J, w["dag"], tmp=tmp, h_dag=h_dag, job_first=g["job_first"], job_nodes=g["job_nodes"])
         h_glob = torch.empty((B, 16), dtype=torch.float32, device=dev)
-        self._launch("globsum", B, w["glob"], h_dag=h_dag, h_glob=h_glob, obs_job_off=g["obs_job_off"], obs_jobs=g["obs_jobs"])
+        self._launch("globhid", J, w["glob"], h_dag=h_dag, tmp=tmp)
+        self._launch("globsum", B, w["glob"], tmp=tmp, h_glob=h_glob, obs_job_off=g["obs_job_off"], obs_jobs=g["obs_jobs"])
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()

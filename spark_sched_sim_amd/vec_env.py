@@ -188,15 +188,16 @@ class VecSparkSchedSimEnv:
                "sched_rank": mk(M, torch.int64), "gen": mk(M, torch.int32), "node_recv": mk(M, torch.int32), "stage_mask": mk(M, torch.bool),
                "src": mk(Ed, torch.int64), "dst": mk(Ed, torch.int64), "edge_obs": mk(Ed, torch.int64), "edge_layers": mk(Ed, torch.int32),
                "job_obs": mk(J, torch.int64), "job_cap": mk(J, torch.int64), "job_first": mk(J, torch.int64), "obs_depth": mk(B, torch.int32),
-               "job_nodes": mk(J, torch.int64), "out_start": mk(M, torch.int64), "out_deg": mk(M, torch.int32)}
+               "job_nodes": mk(J, torch.int64), "out_start": mk(M, torch.int64), "out_deg": mk(M, torch.int32),
+               "layer_recv": torch.zeros(32, dtype=torch.int32, device=dev)}
         size = {"x": M, "node_obs": M, "node_loc": M, "node_job": M, "sched_rank": M, "gen": M, "node_recv": M, "stage_mask": M,
                 "src": Ed, "dst": Ed, "edge_obs": Ed, "edge_layers": Ed, "job_obs": J, "job_cap": J, "job_first": J, "obs_depth": B,
-                "job_nodes": J, "out_start": M, "out_deg": M}
+                "job_nodes": J, "out_start": M, "out_deg": M, "layer_recv": 32}
         g = {k: v[: size[k]] for k, v in buf.items()}
         a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
-                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg")))
+                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_recv")))
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
         g["obs_nodes"], g["obs_jobs"] = cnt_t[0], cnt_t[2]

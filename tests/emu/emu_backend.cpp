@@ -64,6 +64,8 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
     case GNN_GLOBSUM: return gnn_run_kind<GNN_GLOBSUM>(a);
     case GNN_STAGE: return gnn_run_kind<GNN_STAGE>(a);
     case GNN_EXEC: return gnn_run_kind<GNN_EXEC>(a);
+    case GNN_DAGHID: return gnn_run_kind<GNN_DAGHID>(a);
+    case GNN_GLOBHID: return gnn_run_kind<GNN_GLOBHID>(a);
   }
   return -1;
 }
