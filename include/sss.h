@@ -155,9 +155,23 @@ typedef struct sss_decima_graph {
   int64_t* job_nodes_dev; /* i64[J] number of nodes of the job (they follow job_first back to back) */
   int64_t* out_start_dev; /* i64[M] flat id of the node's first out-edge; a node's out-edges are contiguous */
   int32_t* out_deg_dev;   /* i32[M] number of out-edges */
-  int32_t* layer_recv_dev; /* i32[32], zeroed by the caller: [l] += nodes that are sources of layer-l edges */
+  int32_t* layer_cnt_dev; /* i32[32][num_envs]: [l][b] = nodes of env b that are sources of layer-l edges */
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
+
+/* The nodes each DAG layer updates, as index lists (what nonzero((node_recv >> l) & 1) returns), for
+ * all layers in one launch: layer l's list starts at recv_dev[layer_base[l]]; env_off_dev = exclusive
+ * prefix sums of layer_cnt along the env axis. */
+typedef struct sss_decima_lists {
+  const int64_t* node_off_dev;
+  const int64_t* obs_nodes_dev;
+  const uint32_t* node_recv_dev;
+  const int64_t* env_off_dev; /* i64[32][num_envs] */
+  int64_t layer_base[32];
+  int64_t* recv_dev;
+  int n_layers;
+} sss_decima_lists;
+int sss_decima_layer_lists(int num_envs, const sss_decima_lists* a, void* stream);
 
 /* Decima's GNN forward pass for inference (schedulers/decima/scheduler.py:142-385) on a compact graph
  * written by sss_decima_graph_build: one launch per stage of the pass, each evaluating one whole MLP

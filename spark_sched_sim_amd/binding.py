@@ -42,7 +42,12 @@ class SssDecimaGraph(C.Structure):
                 ("node_recv_dev", C.c_void_p), ("stage_mask_dev", C.c_void_p), ("src_dev", C.c_void_p), ("dst_dev", C.c_void_p),
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
-                ("out_deg_dev", C.c_void_p), ("layer_recv_dev", C.c_void_p)]
+                ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p)]
+
+
+class SssDecimaLists(C.Structure):
+    _fields_ = [("node_off_dev", C.c_void_p), ("obs_nodes_dev", C.c_void_p), ("node_recv_dev", C.c_void_p), ("env_off_dev", C.c_void_p),
+                ("layer_base", C.c_int64 * 32), ("recv_dev", C.c_void_p), ("n_layers", C.c_int)]
 
 
 class SssGnnArgs(C.Structure):
@@ -70,7 +75,7 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_decima_graph_build", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -96,6 +101,7 @@ class Binding:
         L.sss_policy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]
+        L.sss_decima_layer_lists.argtypes = [C.c_int, C.POINTER(SssDecimaLists), C.c_void_p]
         L.sss_gnn_launch.argtypes = [C.c_int, C.POINTER(SssGnnArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]

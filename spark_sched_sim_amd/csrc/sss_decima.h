@@ -27,7 +27,17 @@ struct SssDecimaArgs {
   int64_t* out_start;  // i64[M] flat id of the node's first out-edge (edges are ordered by source node)
   int32_t* out_deg;    // i32[M] number of out-edges
   int32_t* obs_depth;
-  int32_t* layer_recv;  // i32[32], zeroed by the caller: [l] += number of receiving nodes of DAG layer l
+  int32_t* layer_cnt;   // i32[32][B]: number of receiving nodes of DAG layer l in env b
+};
+
+struct SssDecimaListArgs {
+  const int64_t* node_off;   // i64[B]
+  const int64_t* obs_nodes;  // i64[B] nodes the env contributed (0 for inactive envs)
+  const uint32_t* node_recv; // u32[M]
+  const int64_t* env_off;    // i64[32][B] exclusive prefix sums of layer_cnt along the env axis
+  int64_t layer_base[32];    // start of layer l's list inside recv
+  int64_t* recv;             // i64[sum of all counts]
+  int n_layers;
 };
 
 SSS_SHARED_DYN(g_dec_lds);
@@ -39,6 +49,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   int n = on ? oi[OBS_N_NODES] : 0, ne = on ? oi[OBS_N_EDGES] : 0, A = on ? oi[OBS_N_JOBS] : 0;
   if (n == 0) {  // wave-uniform
     if (lane == 0) d.obs_depth[env] = 0;
+    if (lane < 32) d.layer_cnt[(size_t)lane * L.num_envs + env] = 0;
     return;
   }
   int ncommit = oi[OBS_NUM_COMMITTABLE], src_idx = oi[OBS_SOURCE_JOB_IDX];
@@ -139,11 +150,33 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   }
   depth = ~wave_min_u32(~depth);
   if (lane == 0) d.obs_depth[env] = (int32_t)depth;
-  // batch-wide receiver counts per layer (sizes the per-layer launches of the GNN kernels)
-  for (uint32_t l = 0; l < depth; l++) {
-    uint32_t c = 0;
-    for (int i = lane; i < n; i += 64) c += (recv[i] >> l) & 1u;
-    c = wave_sum_u32(c);
-    if (lane == 0 && c) lane_atomic_add_i32(&d.layer_recv[l], (int32_t)c);
+  // receiving nodes per layer (lane l counts layer l): sizes the per-layer lists / launches
+  uint32_t cnt = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    uint32_t rv = i0 + lane < n ? recv[i0 + lane] : 0u;
+    for (uint32_t l = 0; l < depth; l++) {
+      uint64_t bal = wave_ballot((rv >> l) & 1u);
+      if ((uint32_t)lane == l) cnt += (uint32_t)popc64(bal);
+    }
+  }
+  if (lane < 32) d.layer_cnt[(size_t)lane * L.num_envs + env] = (int32_t)cnt;
+}
+
+// the receiving nodes of every DAG layer as index lists (layer l = recv[layer_base[l] ...), env by
+// env in node order - what torch.nonzero over (node_recv >> l) & 1 would return
+SSS_KERNEL void sss_decima_lists_kernel(int num_envs, SssDecimaListArgs d) {
+  int env = wave_env(), lane = wave_lane();
+  int n = (int)d.obs_nodes[env];
+  if (n == 0) return;
+  int64_t n0 = d.node_off[env];
+  uint64_t lt = bit64(lane) - 1;
+  for (int l = 0; l < d.n_layers; l++) {
+    int64_t pos = d.layer_base[l] + d.env_off[(size_t)l * num_envs + env];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      bool on = i0 + lane < n && ((d.node_recv[n0 + i0 + lane] >> l) & 1u);
+      uint64_t bal = wave_ballot(on);
+      if (on) d.recv[pos + popc64(bal & lt)] = n0 + i0 + lane;
+      pos += popc64(bal);
+    }
   }
 }

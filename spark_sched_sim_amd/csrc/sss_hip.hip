@@ -46,6 +46,11 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
   return (int)hipGetLastError();
 }
 
+static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void* stream) {
+  hipLaunchKernelGGL(sss_decima_lists_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, num_envs, d);
+  return (int)hipGetLastError();
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
   constexpr int NW = gnn_weight_count<KIND>();

@@ -263,7 +263,7 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   if (!g->node_off_dev || !g->job_off_dev || !g->edge_off_dev || !g->x_dev || !g->node_obs_dev || !g->node_loc_dev || !g->node_job_dev ||
       !g->sched_rank_dev || !g->gen_dev || !g->node_recv_dev || !g->stage_mask_dev || !g->src_dev || !g->dst_dev || !g->edge_obs_dev ||
       !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev ||
-      !g->job_nodes_dev || !g->out_start_dev || !g->out_deg_dev || !g->layer_recv_dev)
+      !g->job_nodes_dev || !g->out_start_dev || !g->out_deg_dev || !g->layer_cnt_dev)
     return sss_fail(-1, "NULL argument");
   if ((int64_t)16 * h->L.n_cap > 65536) return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
   SssDecimaArgs d;
@@ -273,8 +273,19 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   d.gen = g->gen_dev, d.node_recv = g->node_recv_dev, d.stage_mask = g->stage_mask_dev;
   d.src = g->src_dev, d.dst = g->dst_dev, d.edge_obs = g->edge_obs_dev, d.edge_layers = g->edge_layers_dev;
   d.job_obs = g->job_obs_dev, d.job_cap = g->job_cap_dev, d.job_first = g->job_first_dev, d.obs_depth = g->obs_depth_dev;
-  d.job_nodes = g->job_nodes_dev, d.out_start = g->out_start_dev, d.out_deg = g->out_deg_dev, d.layer_recv = g->layer_recv_dev;
+  d.job_nodes = g->job_nodes_dev, d.out_start = g->out_start_dev, d.out_deg = g->out_deg_dev, d.layer_cnt = g->layer_cnt_dev;
   if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));
+  return 0;
+}
+
+extern "C" int sss_decima_layer_lists(int num_envs, const sss_decima_lists* g, void* stream) {
+  if (!g || !g->node_off_dev || !g->obs_nodes_dev || !g->node_recv_dev || !g->env_off_dev || !g->recv_dev) return sss_fail(-1, "NULL argument");
+  if (num_envs < 1 || g->n_layers < 0 || g->n_layers > 32) return sss_fail(-27, "bad layer count");
+  SssDecimaListArgs d;
+  d.node_off = g->node_off_dev, d.obs_nodes = g->obs_nodes_dev, d.node_recv = g->node_recv_dev, d.env_off = g->env_off_dev;
+  for (int l = 0; l < 32; l++) d.layer_base[l] = g->layer_base[l];
+  d.recv = g->recv_dev, d.n_layers = g->n_layers;
+  if (int rc = be_launch_decima_lists(num_envs, d, stream)) return sss_fail(-30, std::string("decima lists launch failed: ") + be_error(rc));
   return 0;
 }
 

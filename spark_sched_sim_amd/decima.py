@@ -157,6 +157,7 @@ def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
         depth = int(g["obs_depth"].max()) if g["x"].shape[0] else 0
         g["layers"] = [(((g["edge_layers"] >> lvl) & 1).nonzero(as_tuple=True)[0], ((g["node_recv"] >> lvl) & 1).nonzero(as_tuple=True)[0])
                        for lvl in range(depth)]
+        return g["layers"]
     if "layers" not in g:
         gen, src, dst = g["gen"], g["src"], g["dst"]
         M = gen.numel()
@@ -424,16 +425,14 @@ class DecimaPolicy(nn.Module):
         self._launch("prep", M, w["prep"], x=x, out=h_init)
         h = torch.empty_like(h_init)
         self._launch("sink", M, w["update"], h_init=h_init, h=h, out_deg=g["out_deg"], obs_depth=g["obs_depth"], node_obs=g["node_obs"])
-        if "layer_counts" not in g:
-            g["layer_counts"] = g["layer_recv"].tolist()  # the only device->host sync of the pass
-        counts = g["layer_counts"]
-        depth = max((lvl + 1 for lvl, c in enumerate(counts) if c), default=0)
+        from .vec_env import VecSparkSchedSimEnv
+        lists = VecSparkSchedSimEnv.decima_layer_lists(g)  # the only device->host sync of the pass
         tmp = torch.empty((max(M, J), 16), dtype=torch.float32, device=dev)
-        for lvl in range(depth - 1, -1, -1):
-            recv = torch.nonzero_static((g["node_recv"] >> lvl) & 1, size=counts[lvl])[:, 0]
-            self._launch("layer", counts[lvl], w["msg"], layer=lvl, w2=w["update"], h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
+        for lvl in range(len(lists) - 1, -1, -1):
+            recv = lists[lvl]
+            self._launch("layer", recv.numel(), w["msg"], layer=lvl, w2=w["update"], h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
                          out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"])
-            self._launch("commit", counts[lvl], w["msg"], h=h, tmp=tmp, idx0=recv)
+            self._launch("commit", recv.numel(), w["msg"], h=h, tmp=tmp, idx0=recv)
         h_dag = torch.empty((J, 16), dtype=torch.float32, device=dev)
         self._launch("daghid", M, w["dag"], x=x, h=h, tmp=tmp)
         self._launch("dagsum", J, w["dag"], tmp=tmp, h_dag=h_dag, job_first=g["job_first"], job_nodes=g["job_nodes"])

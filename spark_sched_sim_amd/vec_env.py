@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import workload
-from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg, SssDecimaGraph
+from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg, SssDecimaGraph, SssDecimaLists
 
 OBS_FIELDS = ("n_nodes", "n_edges", "n_jobs", "n_schedulable", "num_committable_execs", "source_job_idx",
               "terminated", "err")
@@ -189,21 +189,45 @@ class VecSparkSchedSimEnv:
                "src": mk(Ed, torch.int64), "dst": mk(Ed, torch.int64), "edge_obs": mk(Ed, torch.int64), "edge_layers": mk(Ed, torch.int32),
                "job_obs": mk(J, torch.int64), "job_cap": mk(J, torch.int64), "job_first": mk(J, torch.int64), "obs_depth": mk(B, torch.int32),
                "job_nodes": mk(J, torch.int64), "out_start": mk(M, torch.int64), "out_deg": mk(M, torch.int32),
-               "layer_recv": torch.zeros(32, dtype=torch.int32, device=dev)}
+               "layer_cnt": torch.empty((32, B), dtype=torch.int32, device=dev)}
         size = {"x": M, "node_obs": M, "node_loc": M, "node_job": M, "sched_rank": M, "gen": M, "node_recv": M, "stage_mask": M,
                 "src": Ed, "dst": Ed, "edge_obs": Ed, "edge_layers": Ed, "job_obs": J, "job_cap": J, "job_first": J, "obs_depth": B,
-                "job_nodes": J, "out_start": M, "out_deg": M, "layer_recv": 32}
+                "job_nodes": J, "out_start": M, "out_deg": M, "layer_cnt": 32}
         g = {k: v[: size[k]] for k, v in buf.items()}
         a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
-                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_recv")))
+                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")))
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
         g["obs_nodes"], g["obs_jobs"] = cnt_t[0], cnt_t[2]
         g["obs_node_off"], g["obs_job_off"] = off[0], off[2]
         g["_keepalive"] = (off, act8)
+        g["_binding"] = self._b
         return g
+
+    @staticmethod
+    def decima_layer_lists(g: dict[str, Any]) -> list[torch.Tensor]:
+        """for every DAG layer of a graph from `decima_graph` the ids of the nodes it updates (one
+        small kernel for all layers; one device->host sync for the list sizes)"""
+        if "recv_lists" not in g:
+            cnt = g["layer_cnt"].long()
+            totals = cnt.sum(1).tolist()
+            n_layers = max((lvl + 1 for lvl, c in enumerate(totals) if c), default=0)
+            base = [0] * 32
+            for lvl in range(1, 32):
+                base[lvl] = base[lvl - 1] + totals[lvl - 1]
+            recv = torch.empty(max(sum(totals), 1), dtype=torch.int64, device=cnt.device)
+            if n_layers:
+                env_off = (torch.cumsum(cnt, 1) - cnt).contiguous()
+                a = SssDecimaLists(g["obs_node_off"].data_ptr(), g["obs_nodes"].data_ptr(), g["node_recv"].data_ptr(), env_off.data_ptr(),
+                                   (C.c_int64 * 32)(*base), recv.data_ptr(), n_layers)
+                dev = cnt.device
+                stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+                b = g["_binding"]
+                b.check(b.lib.sss_decima_layer_lists(g["n_obs"], C.byref(a), stream))
+            g["recv_lists"] = [recv[base[lvl]: base[lvl] + totals[lvl]] for lvl in range(n_layers)]
+        return g["recv_lists"]
 
     def raise_on_error(self) -> None:
         """the reference raises from inside step(); the batched env records a per-env code. This

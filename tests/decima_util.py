@@ -122,6 +122,9 @@ def compare_graphs(kg, cg, f):
     for (e, r), (ke, kr) in zip(layers, k_layers):
         assert torch.equal(e, ke) and torch.equal(r, kr)
     assert not (kg["edge_layers"] >> len(layers)).any() and not (kg["node_recv"] >> len(layers)).any()
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    lists = VecSparkSchedSimEnv.decima_layer_lists(kg)
+    assert len(lists) == len(layers) and all(torch.equal(a, r) for a, (_, r) in zip(lists, layers))
     # out-edge ranges: every edge lies in its source's range, ranges tile the edge list
     deg = torch.zeros(kg["x"].shape[0], dtype=torch.long, device=kg["x"].device).index_add_(0, kg["src"], torch.ones_like(kg["src"]))
     assert torch.equal(kg["out_deg"].long(), deg)

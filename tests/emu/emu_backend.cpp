@@ -49,6 +49,11 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
   return 0;
 }
 
+static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void*) {
+  emu::launch(num_envs, [&]() { sss_decima_lists_kernel(num_envs, d); });
+  return 0;
+}
+
 template <int KIND>
 static int gnn_run_kind(const SssGnnArgs& a) {
   for (int64_t r = 0; r < a.n_rows; r++) gnn_row<KIND>(a, r, a.w, a.w2);
