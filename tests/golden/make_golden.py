@@ -61,6 +61,8 @@ SETS = {
     "c1_fifo": (C1, "fifo", [5, 6], None),
     # discounted rewards (trainer config, config/decima_tpch.yaml:69 beta=5e-3): np.exp in the reward
     "c1_fair_beta": (dict(C1, beta=5.0e-3), "fair", [11, 12], None),
+    # the reference's RandomScheduler plugin (legacy MT19937 RandomState(seed), heuristics/random_scheduler.py)
+    "c1_random": (C1, "random", [7, 8], None),
 }
 
 
@@ -100,6 +102,9 @@ def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls):
         sched = sched_cls(env_cfg["num_executors"], dynamic_partition=True)
     elif policy == "fifo":
         sched = sched_cls(env_cfg["num_executors"], dynamic_partition=False)
+    elif policy == "random":
+        from schedulers.heuristics.random_scheduler import RandomScheduler
+        sched = RandomScheduler(seed=seed)
     else:
         sched = None
     obs, info = env.reset(seed=seed, options=dict(options) if options else None)
