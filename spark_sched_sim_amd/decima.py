@@ -575,3 +575,105 @@ class DecimaPolicy(nn.Module):
             torch.nn.utils.clip_grad_norm_(self.parameters(), self.max_grad_norm, error_if_nonfinite=True)
         self.optim.step()
         self.optim.zero_grad()
+
+
+# ---- the reference's single-env plugin surface ---------------------------------------------------
+
+class DecimaEnvWrapper:
+    """`schedulers/decima/env_wrapper.py:12-34, 37-143` for the single-env facade
+    (`spark_sched_sim_amd.SparkSchedSimEnv`): observations gain Decima's node features, `stage_mask`,
+    `exec_mask` and `edge_masks`; actions `{"stage_idx", "job_idx", "num_exec"}` (num_exec 0-based)
+    are translated back. The transform is the same `decima_observation` that serves the batched env,
+    applied to the facade's one-env device tensors."""
+
+    def __init__(self, env, num_tasks_scale: int = 200, work_scale: float = 1e5):
+        self.env = env
+        self.num_tasks_scale, self.work_scale = num_tasks_scale, work_scale
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    def observation(self, obs: dict) -> dict:
+        from .spaces import GraphInstance
+        vec = self.env.unwrapped._vec
+        f = decima_observation(vec._obs(), vec.num_executors, vec.dims.stage_stride, self.num_tasks_scale, self.work_scale, edge_masks=True)
+        n, ne, a = int(f["n_nodes"][0]), int(f["n_edges"][0]), int(f["job_valid"][0].sum())
+        return {
+            "dag_batch": GraphInstance(f["x"][0, :n].cpu().numpy(), obs["dag_batch"].edges, obs["dag_batch"].edge_links),
+            "dag_ptr": obs["dag_ptr"],
+            "stage_mask": f["stage_mask"][0, :n].cpu().numpy(),
+            "exec_mask": f["exec_mask"][0, :a].cpu().numpy(),
+            "edge_masks": f["edge_masks"][:, 0, :ne].cpu().numpy(),
+        }
+
+    def reset(self, seed=None, options=None):
+        obs, info = self.env.reset(seed=seed, options=options)
+        return self.observation(obs), info
+
+    def step(self, action: dict):
+        obs, rew, term, trunc, info = self.env.step({"stage_idx": action["stage_idx"], "num_exec": 1 + action["num_exec"]})
+        return self.observation(obs), rew, term, trunc, info
+
+    def close(self):
+        return self.env.close()
+
+
+def graph_from_wrapped_obs(obs: dict, device=None) -> dict[str, Any]:
+    """a one-observation compact graph from Decima's (wrapped) observation dict - what
+    `utils.obs_to_pyg` builds for PyG (decima/utils.py:88-115)"""
+    import numpy as np
+    x = torch.as_tensor(np.asarray(obs["dag_batch"].nodes, dtype=np.float32), device=device)
+    M = x.shape[0]
+    ptr = torch.as_tensor(np.asarray(obs["dag_ptr"], dtype=np.int64), device=device)
+    J = ptr.numel() - 1
+    el = torch.as_tensor(np.asarray(obs["dag_batch"].edge_links, dtype=np.int64).reshape(-1, 2), device=device)
+    sm = torch.as_tensor(np.asarray(obs["stage_mask"], dtype=bool), device=device)
+    em_np = np.asarray(obs["edge_masks"], dtype=bool)
+    em = torch.as_tensor(em_np.reshape(em_np.shape[0] if em_np.ndim == 2 else 0, el.shape[0]), device=device)
+    z = torch.zeros(M, dtype=torch.long, device=x.device)
+    node_job = torch.searchsorted(ptr[1:].contiguous(), torch.arange(M, device=x.device), right=True)
+    rank = sm.long().cumsum(0) - 1
+    layers = []
+    for lvl in range(em.shape[0]):
+        e = em[lvl].nonzero(as_tuple=True)[0]
+        layers.append((e, torch.zeros(M, dtype=torch.bool, device=x.device).index_fill_(0, el[e, 0], True).nonzero(as_tuple=True)[0]))
+    caps = torch.as_tensor(np.asarray(obs["exec_mask"], dtype=bool).reshape(J, -1).sum(1), device=x.device)
+    return {"x": x, "node_obs": z, "node_loc": torch.arange(M, device=x.device), "n_pad": max(M, 1), "node_job": node_job,
+            "sched_rank": torch.where(sm, rank, torch.full_like(rank, -1)), "gen": z, "stage_mask": sm, "src": el[:, 0], "dst": el[:, 1],
+            "edge_obs": torch.zeros(el.shape[0], dtype=torch.long, device=x.device), "job_obs": torch.zeros(J, dtype=torch.long, device=x.device),
+            "job_cap": caps, "job_first": ptr[:-1], "n_obs": 1, "obs_nodes": torch.tensor([M], device=x.device),
+            "obs_jobs": torch.tensor([J], device=x.device), "obs_depth": torch.tensor([em.shape[0]], device=x.device), "layers": layers}
+
+
+class DecimaScheduler(DecimaPolicy):
+    """the reference's `DecimaScheduler` plugin (schedulers/decima/scheduler.py:16-99) for the
+    single-env harness (`examples.run_episode`): `schedule(obs)` on one wrapped observation, actions
+    drawn with `random.choices` over the softmax like `utils.sample` (decima/utils.py:19-23)."""
+
+    env_wrapper_cls = DecimaEnvWrapper
+
+    @torch.no_grad()
+    def schedule(self, obs: dict) -> tuple[dict, dict]:
+        import random
+
+        import numpy as np
+
+        def sample(logits: torch.Tensor):
+            pi = torch.softmax(logits, 0).cpu().numpy()
+            idx = random.choices(np.arange(pi.size), pi)[0]
+            return int(idx), np.log(pi[idx])
+
+        g = graph_from_wrapped_obs(obs, self.device)
+        h = self.encode(g)
+        s, idx = self.stage_scores(g, h)
+        stage_idx, stage_lg = sample(s)
+        job_idx = int(g["node_job"][idx[stage_idx]])
+        es = self.exec_scores(g, h, torch.tensor([job_idx], device=s.device))[0]
+        num_exec, exec_lg = sample(es[torch.isfinite(es)])
+        return {"stage_idx": stage_idx, "job_idx": job_idx, "num_exec": num_exec}, {"lgprob": stage_lg + exec_lg}

@@ -116,5 +116,8 @@ def make_scheduler(agent_cfg: dict) -> Scheduler:
     cfg = dict(agent_cfg)
     cls = cfg.pop("agent_cls")
     table = {"RoundRobinScheduler": RoundRobinScheduler, "RandomScheduler": RandomScheduler}
+    if cls == "DecimaScheduler":  # needs torch.nn; imported on demand like the reference's optional agents
+        from .decima import DecimaScheduler
+        table["DecimaScheduler"] = DecimaScheduler
     assert cls in table, f"'{cls}' is not a valid scheduler."
     return table[cls](**cfg)

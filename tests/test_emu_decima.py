@@ -36,3 +36,40 @@ def test_sampled_actions_are_always_valid():
         assert not info["err"].any()
     assert int(env.header_field("n_steps").sum()) == 6 * 150
     env.close()
+
+
+def test_reference_style_decima_episode():
+    """the single-env harness of the reference (examples.py:84-102) with the Decima plugin:
+    env_wrapper_cls(env) + schedule(obs) sampling through `random.choices` under a fixed
+    `random.seed` reproduces the recorded reference episode action for action (scores agree to
+    ~1e-6, so a draw landing that close to a CDF boundary could differ; none does in this episode)"""
+    import os.path as osp
+    import random
+
+    import numpy as np
+    import torch
+
+    from decima_util import AGENT, HERE
+    from golden_util import bits
+    from spark_sched_sim_amd import SparkSchedSimEnv, make_scheduler
+
+    g = np.load(osp.join(HERE, "golden", "decima_episode.npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    cfg["num_executors"], cfg["job_arrival_cap"] = int(cfg["num_executors"]), int(cfg["job_arrival_cap"])
+    sched = make_scheduler(dict(AGENT, agent_cls="DecimaScheduler", num_executors=cfg["num_executors"]))
+    sched.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")})
+    sched.eval()
+    env = sched.env_wrapper_cls(SparkSchedSimEnv(cfg, device="cpu", _lib=load_emu()))
+    random.seed(int(g["py_seed"]))
+    obs, _ = env.reset(seed=int(g["seed"]), options=None)
+    terminated = truncated = False
+    t = 0
+    while not (terminated or truncated):
+        action, info = sched.schedule(obs)
+        assert [action["stage_idx"], action["job_idx"], action["num_exec"]] == g["actions"][t].tolist(), t
+        assert abs(float(info["lgprob"]) - float(g["lgprobs"][t])) < 1e-4, t
+        obs, reward, terminated, truncated, einfo = env.step(action)
+        assert bits(float(reward)) == bits(float(g["rewards"][t])) and bits(float(einfo["wall_time"])) == bits(float(g["wall_times"][t])), t
+        t += 1
+    assert t == len(g["actions"])
+    env.close()
