@@ -469,3 +469,11 @@ class Trainer:
 
     def close(self) -> None:
         self.env.close()
+
+
+def make_trainer(cfg: dict[str, Any], device: str | torch.device | None = None, _lib=None) -> Trainer:
+    """by-name factory like the reference's (trainers/__init__.py:7-13): `cfg` is the parsed YAML
+    with its `trainer` / `agent` / `env` sections"""
+    trainer_cls = cfg["trainer"]["trainer_cls"]
+    assert trainer_cls in ("PPO",), f"'{trainer_cls}' is not a valid trainer."
+    return Trainer(agent_cfg=cfg["agent"], env_cfg=cfg["env"], train_cfg=cfg["trainer"], device=device, _lib=_lib)
