@@ -31,3 +31,45 @@ def test_decima_in_the_loop_256_envs():
     assert not info["err"].any() and torch.isfinite(aux["lgprob"]).all()
     assert int(env.header_field("n_steps").sum()) == 256 * 300
     env.close()
+
+
+def test_simulator_under_decima_actions_matches_oracle(pack):
+    """the step kernel under the action distribution a GNN policy produces (many executors per
+    decision, deep stages first, ...): 64 envs driven by sampled Decima actions for 400 steps;
+    every env's (action -> reward, wall time, termination, observation sizes) chain is replayed
+    through the C oracle and must agree bit for bit"""
+    import numpy as np
+
+    from golden_util import bits
+    from oracle_binding import OracleEnv
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    B, T = 64, 400
+    env = VecSparkSchedSimEnv(cfg, B, device="cuda:0", pack=pack)
+    torch.manual_seed(3)
+    policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval()
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    obs, _ = env.reset(seed=900)
+    rec = []
+    for _ in range(T):
+        act, _ = policy.schedule_env(env, generator=gen)
+        a_s, a_n = act["stage_idx"].cpu().numpy().copy(), act["num_exec"].cpu().numpy().copy()
+        obs, rew, term, trunc, info = env.step(act)
+        rec.append((a_s, a_n, rew.cpu().numpy().copy(), info["wall_time"].cpu().numpy().copy(), term.cpu().numpy().copy(),
+                    obs["n_nodes"].cpu().numpy().copy(), info["err"].cpu().numpy().copy()))
+    for b in range(B):
+        o = OracleEnv(pack, cfg)
+        o.reset(900 + b)
+        for t, (a_s, a_n, rew, wall, term, n_nodes, err) in enumerate(rec):
+            if err[b]:  # the env had already terminated: the batched env reports "reset() required"
+                assert err[b] == 8 and rec[t - 1][4][b]
+                break
+            e, r, done = o.step(int(a_s[b]), int(a_n[b]))
+            assert e == 0, (b, t, e)
+            info = o.info()
+            assert bits(r) == bits(float(rew[b])) and bits(info.wall_time) == bits(float(wall[b])), (b, t)
+            assert done == bool(term[b]) and info.n_nodes == int(n_nodes[b]), (b, t)
+        o.close()
+    env.close()
