@@ -221,6 +221,40 @@ typedef struct sss_gnn_args {
 } sss_gnn_args;
 int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
 
+/* Decima's whole decision for every env in ONE launch (one wavefront per env): observation transform,
+ * GNN encoder, stage and executor-count scores and the two softmax draws of
+ * DecimaScheduler.schedule (schedulers/decima/scheduler.py:71-99) - sss_decima_graph_build +
+ * the sss_gnn_launch sequence + sampling, without the intermediate graph or any host round trip.
+ * w_*_dev: the seven MLPs packed as for sss_gnn_launch. node_scratch_dev: f32[num_envs][node_cap][53],
+ * job_scratch_dev: f32[num_envs][job_cap][32] (work space). Draws are Gumbel-max over a counter-based
+ * uniform stream keyed by (rng_seed, rng_counter, env, candidate): pass a new rng_counter per call.
+ * Outputs per env: stage_idx / num_exec (for sss_step; stage_idx -1 when nothing is schedulable),
+ * Decima's action tuple (stage_sel, job_idx, exec_sel) and its log-probability; optional dense
+ * scores (stage_scores_dev f32[num_envs][node_cap], exec_scores_dev f32[num_envs][E]; -inf = masked). */
+typedef struct sss_decima_policy_args {
+  const uint8_t* active_dev; /* u8[num_envs] or NULL */
+  float num_tasks_scale, work_scale, slope;
+  const float* w_prep_dev;
+  const float* w_msg_dev;
+  const float* w_upd_dev;
+  const float* w_dag_dev;
+  const float* w_glob_dev;
+  const float* w_stage_dev;
+  const float* w_exec_dev;
+  float* node_scratch_dev;
+  float* job_scratch_dev;
+  uint64_t rng_seed, rng_counter;
+  int32_t* stage_idx_dev;
+  int32_t* num_exec_dev;
+  int32_t* stage_sel_dev;
+  int32_t* job_idx_dev;
+  int32_t* exec_sel_dev;
+  float* lgprob_dev;
+  float* stage_scores_dev; /* nullable */
+  float* exec_scores_dev;  /* nullable */
+} sss_decima_policy_args;
+int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* a, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

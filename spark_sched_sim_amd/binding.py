@@ -50,6 +50,15 @@ class SssDecimaLists(C.Structure):
                 ("layer_base", C.c_int64 * 32), ("recv_dev", C.c_void_p), ("n_layers", C.c_int)]
 
 
+class SssDecimaPolicyArgs(C.Structure):
+    _fields_ = [("active_dev", C.c_void_p), ("num_tasks_scale", C.c_float), ("work_scale", C.c_float), ("slope", C.c_float),
+                ("w_prep_dev", C.c_void_p), ("w_msg_dev", C.c_void_p), ("w_upd_dev", C.c_void_p), ("w_dag_dev", C.c_void_p),
+                ("w_glob_dev", C.c_void_p), ("w_stage_dev", C.c_void_p), ("w_exec_dev", C.c_void_p), ("node_scratch_dev", C.c_void_p),
+                ("job_scratch_dev", C.c_void_p), ("rng_seed", C.c_uint64), ("rng_counter", C.c_uint64), ("stage_idx_dev", C.c_void_p),
+                ("num_exec_dev", C.c_void_p), ("stage_sel_dev", C.c_void_p), ("job_idx_dev", C.c_void_p), ("exec_sel_dev", C.c_void_p),
+                ("lgprob_dev", C.c_void_p), ("stage_scores_dev", C.c_void_p), ("exec_scores_dev", C.c_void_p)]
+
+
 class SssGnnArgs(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("w_dev", C.c_void_p), ("w2_dev", C.c_void_p), ("slope", C.c_float), ("num_executors", C.c_int),
                 ("layer", C.c_int), ("n_pad", C.c_int64), ("x_dev", C.c_void_p), ("h_init_dev", C.c_void_p), ("h_dev", C.c_void_p),
@@ -75,7 +84,7 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_decima_policy", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -102,6 +111,7 @@ class Binding:
         L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]
         L.sss_decima_layer_lists.argtypes = [C.c_int, C.POINTER(SssDecimaLists), C.c_void_p]
+        L.sss_decima_policy.argtypes = [C.c_void_p, C.POINTER(SssDecimaPolicyArgs), C.c_void_p]
         L.sss_gnn_launch.argtypes = [C.c_int, C.POINTER(SssGnnArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]

@@ -7,6 +7,7 @@
 #include "sss_sim.h"
 #include "sss_decima.h"
 #include "sss_gnn.h"
+#include "sss_decima_policy.h"
 
 #include <stdint.h>
 #include "zig_tables.inc"
@@ -48,6 +49,11 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
 
 static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void* stream) {
   hipLaunchKernelGGL(sss_decima_lists_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, num_envs, d);
+  return (int)hipGetLastError();
+}
+
+static int be_launch_decima_policy(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaPolicyArgs& d, void* stream) {
+  hipLaunchKernelGGL(sss_decima_policy_kernel, dim3(L.num_envs), dim3(64), (size_t)18 * L.n_cap + 64, (hipStream_t)stream, L, B, E, d);
   return (int)hipGetLastError();
 }
 

@@ -93,6 +93,13 @@ SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
+// sum of a float over the wave (butterfly order; only used where a tolerance applies)
+SSS_DEV float wave_sum_f32(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
 // value of lane `l` (wave-uniform index) on every lane
 SSS_DEV uint32_t wave_readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 SSS_DEV double wave_readlane_f64(double v, int l) {

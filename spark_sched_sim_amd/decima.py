@@ -518,6 +518,46 @@ class DecimaPolicy(nn.Module):
         lg = torch.log(p.gather(1, col[:, None])[:, 0]) + torch.log(pe.gather(1, k[:, None])[:, 0])
         return {"stage_sel": stage_sel, "job_idx": job_slot, "exec_sel": k, "lgprob": lg, "any_stage": any_stage}
 
+    @torch.no_grad()
+    def act_env(self, env, counter: int, seed: int = 0, active: torch.Tensor | None = None, want_scores: bool = False):
+        """Decima's decision for every env of a `VecSparkSchedSimEnv` in ONE kernel launch
+        (include/sss.h sss_decima_policy): transform, GNN, scores and both draws per env inside one
+        wavefront, no intermediate graph, no host sync. Returns (actions for `env.step`, the `act`
+        dict [+ "stage_scores" f32[B,node_cap], "exec_scores" f32[B,E] with `want_scores`]). The draws
+        are a deterministic function of (seed, counter, env): pass a new `counter` every step."""
+        import ctypes
+
+        from .binding import SssDecimaPolicyArgs
+        if getattr(self, "_kb", None) is None:
+            self.bind_kernels(env._b)
+        assert self._use_kernels(), "the fused policy kernel supports the published Decima architecture only"
+        w = self._packed_weights()
+        B, dev, d = env.num_envs, env.device, env.dims
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws["key"] != (B, d.node_cap, d.job_cap, str(dev)):
+            i32 = lambda: torch.empty(B, dtype=torch.int32, device=dev)  # noqa: E731
+            ws = {"key": (B, d.node_cap, d.job_cap, str(dev)),
+                  "node": torch.empty((B, d.node_cap, 53), dtype=torch.float32, device=dev),
+                  "job": torch.empty((B, d.job_cap, 32), dtype=torch.float32, device=dev),
+                  "stage_idx": i32(), "num_exec": i32(), "stage_sel": i32(), "job_idx": i32(), "exec_sel": i32(),
+                  "lgprob": torch.empty(B, dtype=torch.float32, device=dev)}
+            self._ws = ws
+        out = {}
+        if want_scores:
+            out["stage_scores"] = torch.full((B, d.node_cap), float("-inf"), dtype=torch.float32, device=dev)
+            out["exec_scores"] = torch.full((B, self.num_executors), float("-inf"), dtype=torch.float32, device=dev)
+        act8 = active.to(torch.uint8).contiguous() if active is not None else None
+        a = SssDecimaPolicyArgs(act8.data_ptr() if act8 is not None else None, 200.0, 1e5, self._packed[2],
+                                w["prep"].data_ptr(), w["msg"].data_ptr(), w["update"].data_ptr(), w["dag"].data_ptr(), w["glob"].data_ptr(),
+                                w["stage"].data_ptr(), w["exec"].data_ptr(), ws["node"].data_ptr(), ws["job"].data_ptr(),
+                                int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1), ws["stage_idx"].data_ptr(), ws["num_exec"].data_ptr(),
+                                ws["stage_sel"].data_ptr(), ws["job_idx"].data_ptr(), ws["exec_sel"].data_ptr(), ws["lgprob"].data_ptr(),
+                                out["stage_scores"].data_ptr() if want_scores else None, out["exec_scores"].data_ptr() if want_scores else None)
+        self._kb.check(self._kb.lib.sss_decima_policy(env._h, ctypes.byref(a), env._stream()))
+        out.update(stage_sel=ws["stage_sel"].long(), job_idx=ws["job_idx"].long(), exec_sel=ws["exec_sel"].long(), lgprob=ws["lgprob"],
+                   any_stage=ws["stage_idx"] >= 0)
+        return {"stage_idx": ws["stage_idx"], "num_exec": ws["num_exec"]}, out
+
     @staticmethod
     def env_actions(a: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
         """`act`'s result in the env's action format (DecimaActWrapper.action, env_wrapper.py:33-34);
@@ -526,12 +566,17 @@ class DecimaPolicy(nn.Module):
         return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}
 
     @torch.no_grad()
-    def schedule_env(self, env, generator: torch.Generator | None = None):
-        """Decima in the loop on a `VecSparkSchedSimEnv`: the graph kernel on the env's current
-        observations + `act`. Returns (actions for `env.step`, the `act` dict)."""
+    def schedule_env(self, env, generator: torch.Generator | None = None, active: torch.Tensor | None = None):
+        """Decima in the loop on a `VecSparkSchedSimEnv`: one sampled action per env. With the
+        published architecture this is the one-launch policy kernel (`act_env`; its draw counter
+        advances on every call, `generator` only supplies the seed); otherwise the graph kernel +
+        `act`. Returns (actions for `env.step`, the `act` dict)."""
         if getattr(self, "_kb", None) is None:
             self.bind_kernels(env._b)
-        a = self.act(env.decima_graph(), generator)
+        if self._use_kernels():
+            self._calls = getattr(self, "_calls", 0) + 1
+            return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
+        a = self.act(env.decima_graph(active), generator)
         return self.env_actions(a), a
 
     @torch.no_grad()

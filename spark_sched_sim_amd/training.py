@@ -93,7 +93,7 @@ class RolloutCollector:
         self.generator = generator
         if policy is not None:
             policy.bind_kernels(env._b)  # inference on the fused GNN kernels; training stays on autograd
-        self.act_fn = act_fn or (lambda g, n: policy.act(g, generator))
+        self.act_fn = act_fn
         self._obs = None
         self._wall = None
 
@@ -131,8 +131,8 @@ class RolloutCollector:
         active = torch.ones(B, dtype=torch.bool, device=dev)
         rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
         while bool(active.any()):
-            g = self.env.decima_graph(active)
-            a = self.act_fn(g, self.step_counts)
+            g = self.env.decima_graph(active)  # recorded for training
+            a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.schedule_env(self.env, self.generator, active)[1]
             self.step_counts += active.cpu().long()
             stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
             num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)

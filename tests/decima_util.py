@@ -60,6 +60,12 @@ def check_decima_fixture(name, device, lib, n_steps):
                 assert torch.equal(torch.isfinite(ek), torch.isfinite(es_t)), (t, j)
                 fin = torch.isfinite(ek)
                 assert float((ek[fin] - es_t[fin]).abs().max()) <= SCORE_ATOL if fin.any() else True, (t, j)
+            # the one-launch policy kernel: same scores, and a draw that is the Gumbel-max of them
+            acts_k, ak = policy.act_env(env, counter=1000 + t, seed=77, want_scores=True)
+            fin = torch.isfinite(ss)
+            assert torch.equal(torch.isfinite(ak["stage_scores"][:, : ss.shape[1]]), fin), t
+            assert float((ak["stage_scores"][:, : ss.shape[1]] - ss)[fin].abs().max()) <= SCORE_ATOL, t
+            check_policy_draw(ak, acts_k, cg, f, es_all, job_off, 77, 1000 + t)
         if dev.type == "cuda":
             torch.cuda.synchronize()
         for b, s in enumerate(seeds):
@@ -132,3 +138,47 @@ def compare_graphs(kg, cg, f):
     assert bool(((e_ids >= kg["out_start"][kg["src"]]) & (e_ids < kg["out_start"][kg["src"]] + deg[kg["src"]])).all())
     cnt = torch.zeros(kg["job_obs"].numel(), dtype=torch.long, device=deg.device).index_add_(0, kg["node_job"], torch.ones_like(kg["node_job"]))
     assert torch.equal(kg["job_nodes"], cnt)
+
+
+def _gumbel(seed, counter, env, idx, draw):
+    """tests' restatement of dp_gumbel (csrc/sss_decima_policy.h)"""
+    m = (1 << 64) - 1
+    z = (seed ^ ((counter * 0x9E3779B97F4A7C15) & m) ^ ((env & 0xFFFFFFFF) << 32) ^ (draw << 28) ^ idx) & m
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    u = np.float32((np.float32(z >> 40) + np.float32(0.5)) * np.float32(1.0 / 16777216.0))
+    return float(-np.log(-np.log(u)))
+
+
+def check_policy_draw(ak, acts_k, cg, f, es_all, job_off, seed, counter):
+    """the kernel's (stage, executor count) must be the Gumbel-max of its own scores under the
+    documented counter-based stream, and its log-probability the softmax log-probability"""
+    B = f["x"].shape[0]
+    ss = ak["stage_scores"].cpu().numpy()
+    es = ak["exec_scores"].cpu().numpy()
+    sm = f["stage_mask"].cpu().numpy()
+    node_job = f["node_job"].cpu().numpy()
+    for b in range(B):
+        cand = np.flatnonzero(sm[b])
+        if cand.size == 0:
+            assert int(acts_k["stage_idx"][b]) == -1
+            continue
+        keys = np.asarray([ss[b, i] + _gumbel(seed, counter, b, int(i), 0) for i in cand])
+        sel_rank = int(ak["stage_sel"][b])
+        assert keys[sel_rank] >= keys.max() - 1e-4, (b, "stage draw")
+        assert int(acts_k["stage_idx"][b]) == sel_rank
+        job = int(node_job[b, cand[sel_rank]])
+        assert int(ak["job_idx"][b]) == job
+        ok = np.isfinite(es[b])
+        want_es = es_all[job][b].cpu().numpy() if job < len(es_all) else None
+        if want_es is not None:
+            assert np.array_equal(ok, np.isfinite(want_es)) and (np.abs(es[b][ok] - want_es[ok]).max() <= SCORE_ATOL if ok.any() else True), (b, "exec scores")
+        lg = float(ss[b, cand[sel_rank]] - (np.log(np.exp(ss[b, cand] - ss[b, cand].max()).sum()) + ss[b, cand].max()))
+        if ok.any():
+            ek = np.asarray([es[b, c] + _gumbel(seed, counter, b, c, 1) if ok[c] else -np.inf for c in range(es.shape[1])])
+            c_sel = int(ak["exec_sel"][b])
+            assert ek[c_sel] >= ek.max() - 1e-4 and int(acts_k["num_exec"][b]) == c_sel + 1, (b, "exec draw")
+            lg += float(es[b, c_sel] - (np.log(np.exp(es[b][ok] - es[b][ok].max()).sum()) + es[b][ok].max()))
+        assert abs(float(ak["lgprob"][b]) - lg) <= 1e-4, (b, "lgprob", float(ak["lgprob"][b]), lg)

@@ -16,6 +16,7 @@ void launch(int grid, const std::function<void()>& body);
 #include "sss_decima.h"
 #include <math.h>
 #include "sss_gnn.h"
+#include "sss_decima_policy.h"
 #include "zig_tables.inc"
 
 static int be_set_device(int) { return 0; }
@@ -51,6 +52,11 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
 
 static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void*) {
   emu::launch(num_envs, [&]() { sss_decima_lists_kernel(num_envs, d); });
+  return 0;
+}
+
+static int be_launch_decima_policy(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaPolicyArgs& d, void*) {
+  emu::launch(L.num_envs, [&]() { sss_decima_policy_kernel(L, B, E, d); });
   return 0;
 }
 

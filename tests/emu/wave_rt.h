@@ -21,7 +21,7 @@
 #define SSS_SHARED_DYN(name) alignas(16) static uint8_t name[65536]
 
 namespace emu {
-enum Op { OP_SYNC = 1, OP_BALLOT, OP_BCAST, OP_MIN32, OP_MIN64, OP_SUM32, OP_SCAN32 };
+enum Op { OP_SYNC = 1, OP_BALLOT, OP_BCAST, OP_MIN32, OP_MIN64, OP_SUM32, OP_SCAN32, OP_SUMF32 };
 int lane();
 int env();
 // deposits (op, value), yields round-robin, returns once all 64 lanes have deposited; the
@@ -80,6 +80,19 @@ SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   emu::collective(emu::OP_SUM32, v);
   uint32_t s = 0;
   for (int i = 0; i < 64; i++) s += (uint32_t)emu::slot(i);
+  return s;
+}
+SSS_DEV float wave_sum_f32(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  emu::collective(emu::OP_SUMF32, u);
+  float s = 0.0f;
+  for (int i = 0; i < 64; i++) {
+    uint32_t w = (uint32_t)emu::slot(i);
+    float f;
+    memcpy(&f, &w, 4);
+    s += f;
+  }
   return s;
 }
 SSS_DEV uint32_t wave_readlane_u32(uint32_t v, int l) { return wave_bcast_u32(v, l); }

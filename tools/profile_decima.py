@@ -46,19 +46,15 @@ def main():
         for i in range(a.steps + 5):
             if i == 5:
                 sec.clear()
-            g = timed("graph kernel", lambda: env.decima_graph())
-            timed("layers", lambda: graph_layers(g))
-            act = timed("gnn+sample", lambda: policy.act(g, gen))
-            obs, *_ = timed("env.step", lambda: env.step(policy.env_actions(act)))
+            acts, act = timed("policy kernel", lambda: policy.schedule_env(env, gen))
+            obs, *_ = timed("env.step", lambda: env.step(acts))
     out = {k: 1e3 * v / a.steps for k, v in sec.items()}
-    out["levels"] = len(g["layers"])
-    out["nodes"] = int(g["x"].shape[0])
-    out["edges"] = int(g["src"].numel())
+    out["nodes"] = int(obs["n_nodes"].sum())
     print(json.dumps({"envs": a.envs, "ms_per_step": out}))
     from torch.profiler import ProfilerActivity, profile
     with torch.no_grad(), profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         for i in range(3):
-            act = policy.act(env.decima_graph(), gen)
+            policy.schedule_env(env, gen)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
 
