@@ -522,7 +522,8 @@ class DecimaPolicy(nn.Module):
     def act_env(self, env, counter: int, seed: int = 0, active: torch.Tensor | None = None, want_scores: bool = False):
         """Decima's decision for every env of a `VecSparkSchedSimEnv` in ONE kernel launch
         (include/sss.h sss_decima_policy): transform, GNN, scores and both draws per env inside one
-        wavefront, no intermediate graph, no host sync. Returns (actions for `env.step`, the `act`
+        wavefront, no intermediate graph, no host sync. Slower than the row-parallel pipeline at large
+        batches (see `schedule_env`); useful when launches / syncs dominate. Returns (actions for `env.step`, the `act`
         dict [+ "stage_scores" f32[B,node_cap], "exec_scores" f32[B,E] with `want_scores`]). The draws
         are a deterministic function of (seed, counter, env): pass a new `counter` every step."""
         import ctypes
@@ -566,14 +567,17 @@ class DecimaPolicy(nn.Module):
         return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}
 
     @torch.no_grad()
-    def schedule_env(self, env, generator: torch.Generator | None = None, active: torch.Tensor | None = None):
-        """Decima in the loop on a `VecSparkSchedSimEnv`: one sampled action per env. With the
-        published architecture this is the one-launch policy kernel (`act_env`; its draw counter
-        advances on every call, `generator` only supplies the seed); otherwise the graph kernel +
-        `act`. Returns (actions for `env.step`, the `act` dict)."""
+    def schedule_env(self, env, generator: torch.Generator | None = None, active: torch.Tensor | None = None, one_launch: bool = False):
+        """Decima in the loop on a `VecSparkSchedSimEnv`: one sampled action per env. Default: the
+        graph kernel + the row-parallel GNN kernels + `act` (rows of ALL envs share every launch, so
+        the lanes stay full). `one_launch=True` uses the per-env policy kernel (`act_env`; its draw
+        counter advances on every call, `generator` only supplies the seed): no host sync and one
+        launch, but each env's phases run serially inside one wavefront with few active lanes - on
+        one MI355X it is ~6x slower at 4096 envs (profiles/r01_decima.md).
+        Returns (actions for `env.step`, the `act` dict)."""
         if getattr(self, "_kb", None) is None:
             self.bind_kernels(env._b)
-        if self._use_kernels():
+        if one_launch:
             self._calls = getattr(self, "_calls", 0) + 1
             return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
         a = self.act(env.decima_graph(active), generator)

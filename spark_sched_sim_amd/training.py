@@ -132,7 +132,7 @@ class RolloutCollector:
         rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
         while bool(active.any()):
             g = self.env.decima_graph(active)  # recorded for training
-            a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.schedule_env(self.env, self.generator, active)[1]
+            a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.act(g, self.generator)
             self.step_counts += active.cpu().long()
             stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
             num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shards", type=int, default=1, help="split the envs into sub-batches on separate HIP streams (one shard's "
                     "step-kernel tail overlaps the other shards' GNN kernels)")
+    ap.add_argument("--one-launch", action="store_true", help="per-env policy kernel (sss_decima_policy) instead of the row-parallel pipeline")
     a = ap.parse_args()
     cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
     S = max(1, a.shards)
@@ -43,13 +44,13 @@ def main():
             t0 = time.perf_counter()
         for e, st, gen in zip(envs, streams, gens):
             with torch.cuda.stream(st):
-                act, _ = policy.schedule_env(e, generator=gen)
+                act, _ = policy.schedule_env(e, generator=gen, one_launch=a.one_launch)
                 e.step(act)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     err = sum(int((e.obs_i32[:, 7] != 0).sum()) for e in envs)
     print(json.dumps({"metric": "env-steps/s with Decima in the loop", "value": a.envs * a.steps / dt, "envs": a.envs,
-                      "ms_per_step": 1e3 * dt / a.steps, "shards": S, "err_envs": err}))
+                      "ms_per_step": 1e3 * dt / a.steps, "shards": S, "one_launch": a.one_launch, "err_envs": err}))
 
 
 if __name__ == "__main__":

@@ -46,7 +46,7 @@ def main():
         for i in range(a.steps + 5):
             if i == 5:
                 sec.clear()
-            acts, act = timed("policy kernel", lambda: policy.schedule_env(env, gen))
+            acts, act = timed("policy", lambda: policy.schedule_env(env, gen))
             obs, *_ = timed("env.step", lambda: env.step(acts))
     out = {k: 1e3 * v / a.steps for k, v in sec.items()}
     out["nodes"] = int(obs["n_nodes"].sum())
