@@ -255,6 +255,33 @@ typedef struct sss_decima_policy_args {
 } sss_decima_policy_args;
 int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* a, void* stream);
 
+/* The two softmax draws of DecimaScheduler.schedule (schedulers/decima/scheduler.py:80-99) for the
+ * sss_gnn_launch pipeline, one wavefront per observation, same Gumbel-max stream as sss_decima_policy.
+ * which = 0: stage draw from stage_scores_dev (f32[n_obs][n_pad], -inf = masked) -> job_gid_dev (the
+ * idx0 of the EXEC launch), stage_idx / stage_sel / job_idx, lgprob, any_stage. which = 1: executor
+ * count draw from exec_scores_dev (f32[n_obs][E]) -> num_exec / exec_sel, lgprob += . */
+typedef struct sss_decima_sample_args {
+  int64_t n_pad;
+  int num_executors;
+  uint64_t rng_seed, rng_counter;
+  const float* stage_scores_dev;
+  const float* exec_scores_dev;
+  const int64_t* obs_nodes_dev;
+  const int64_t* obs_node_off_dev;
+  const int64_t* obs_job_off_dev;
+  const int64_t* sched_rank_dev;
+  const int64_t* node_job_dev;
+  int64_t* job_gid_dev;
+  int32_t* stage_idx_dev;
+  int32_t* num_exec_dev;
+  int64_t* stage_sel_dev;
+  int64_t* job_idx_dev;
+  int64_t* exec_sel_dev;
+  float* lgprob_dev;
+  uint8_t* any_stage_dev;
+} sss_decima_sample_args;
+int sss_decima_sample(int n_obs, int which, const sss_decima_sample_args* a, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

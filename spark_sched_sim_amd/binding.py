@@ -59,6 +59,15 @@ class SssDecimaPolicyArgs(C.Structure):
                 ("lgprob_dev", C.c_void_p), ("stage_scores_dev", C.c_void_p), ("exec_scores_dev", C.c_void_p)]
 
 
+class SssDecimaSampleArgs(C.Structure):
+    _fields_ = [("n_pad", C.c_int64), ("num_executors", C.c_int), ("rng_seed", C.c_uint64), ("rng_counter", C.c_uint64),
+                ("stage_scores_dev", C.c_void_p), ("exec_scores_dev", C.c_void_p), ("obs_nodes_dev", C.c_void_p),
+                ("obs_node_off_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("sched_rank_dev", C.c_void_p),
+                ("node_job_dev", C.c_void_p), ("job_gid_dev", C.c_void_p), ("stage_idx_dev", C.c_void_p), ("num_exec_dev", C.c_void_p),
+                ("stage_sel_dev", C.c_void_p), ("job_idx_dev", C.c_void_p), ("exec_sel_dev", C.c_void_p), ("lgprob_dev", C.c_void_p),
+                ("any_stage_dev", C.c_void_p)]
+
+
 class SssGnnArgs(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("w_dev", C.c_void_p), ("w2_dev", C.c_void_p), ("slope", C.c_float), ("num_executors", C.c_int),
                 ("layer", C.c_int), ("n_pad", C.c_int64), ("x_dev", C.c_void_p), ("h_init_dev", C.c_void_p), ("h_dev", C.c_void_p),
@@ -84,7 +93,7 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_decima_policy", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -112,6 +121,7 @@ class Binding:
         L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]
         L.sss_decima_layer_lists.argtypes = [C.c_int, C.POINTER(SssDecimaLists), C.c_void_p]
         L.sss_decima_policy.argtypes = [C.c_void_p, C.POINTER(SssDecimaPolicyArgs), C.c_void_p]
+        L.sss_decima_sample.argtypes = [C.c_int, C.c_int, C.POINTER(SssDecimaSampleArgs), C.c_void_p]
         L.sss_gnn_launch.argtypes = [C.c_int, C.POINTER(SssGnnArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]

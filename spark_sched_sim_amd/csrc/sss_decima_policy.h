@@ -316,3 +316,79 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
 SSS_KERNEL void sss_decima_policy_kernel(SssLayout L, SssBuffers B, int E, SssDecimaPolicyArgs d) {
   decima_policy_wave(L, B, E, d, wave_env());
 }
+
+// ---- the two softmax draws of DecimaScheduler.schedule for the row-parallel pipeline ------------
+// (scheduler.py:80-99): one wavefront per observation; `first` = the stage draw from the padded
+// stage scores (sss_gnn_launch STAGE), `second` = the executor-count draw from the scores of the
+// chosen stage's job (sss_gnn_launch EXEC). Same Gumbel-max stream as decima_policy_wave.
+struct SssDecimaSampleArgs {
+  int64_t n_pad;
+  int E;
+  uint64_t rng_seed, rng_counter;
+  const float* stage_scores;   // f32[B][n_pad]
+  const float* exec_scores;    // f32[B][E] (second draw)
+  const int64_t *obs_nodes, *obs_node_off, *obs_job_off;
+  const int64_t *sched_rank, *node_job;  // flat [M]
+  int64_t* job_gid;            // i64[B]: flat job id of the chosen stage (0 when nothing is schedulable)
+  int32_t *stage_idx, *num_exec;
+  int64_t *stage_sel, *job_idx, *exec_sel;
+  float* lgprob;
+  uint8_t* any_stage;
+};
+
+SSS_KERNEL void sss_decima_sample_stage_kernel(SssDecimaSampleArgs d) {
+  int env = wave_env(), lane = wave_lane();
+  int n = (int)d.obs_nodes[env];
+  const float* row = d.stage_scores + (size_t)env * d.n_pad;
+  float best_key = -__builtin_inff(), best_score = 0.0f, m_run = -__builtin_inff(), s_run = 0.0f;
+  uint32_t best_i = 0x7FFFFFFFu;
+  for (int i = lane; i < n; i += 64) {
+    float sc = row[i];
+    if (sc == -__builtin_inff()) continue;
+    float key = sc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)i, 0);
+    if (key > best_key) best_key = key, best_i = (uint32_t)i, best_score = sc;
+    float m_new = sc > m_run ? sc : m_run;
+    s_run = s_run * expf(m_run - m_new) + expf(sc - m_new);
+    m_run = m_new;
+  }
+  float kmax, M, sel_score;
+  uint32_t sel, dummy_i;
+  dp_wave_argmax(best_key, best_i, kmax, sel);
+  bool any_stage = wave_ballot(best_i != 0x7FFFFFFFu) != 0;
+  if (!any_stage) {  // wave-uniform
+    if (lane == 0) {
+      d.any_stage[env] = 0, d.job_gid[env] = 0, d.stage_idx[env] = -1, d.stage_sel[env] = 0, d.job_idx[env] = 0, d.lgprob[env] = 0.0f;
+    }
+    return;
+  }
+  dp_wave_argmax(m_run, 0, M, dummy_i);
+  float S = wave_sum_f32(m_run == -__builtin_inff() ? 0.0f : s_run * expf(m_run - M));
+  dp_wave_argmax(best_i == sel ? best_score : -__builtin_inff(), 0, sel_score, dummy_i);
+  if (lane == 0) {
+    int64_t flat = d.obs_node_off[env] + sel;
+    int64_t jg = d.node_job[flat];
+    d.any_stage[env] = 1, d.job_gid[env] = jg;
+    d.stage_idx[env] = (int32_t)d.sched_rank[flat], d.stage_sel[env] = d.sched_rank[flat], d.job_idx[env] = jg - d.obs_job_off[env];
+    d.lgprob[env] = sel_score - M - logf(S);
+  }
+}
+
+SSS_KERNEL void sss_decima_sample_exec_kernel(SssDecimaSampleArgs d) {
+  int env = wave_env(), lane = wave_lane();
+  bool live = d.any_stage[env] != 0;
+  float esc = live && lane < d.E ? d.exec_scores[(size_t)env * d.E + lane] : -__builtin_inff();
+  bool ok = esc != -__builtin_inff();
+  float ekey = ok ? esc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)lane, 1) : -__builtin_inff();
+  float kmax, EM, esel;
+  uint32_t csel, dummy_i;
+  dp_wave_argmax(ekey, (uint32_t)lane, kmax, csel);
+  bool any_exec = wave_ballot(ok) != 0;
+  dp_wave_argmax(esc, 0, EM, dummy_i);
+  float ES = wave_sum_f32(ok ? expf(esc - EM) : 0.0f);
+  dp_wave_argmax(ok && (uint32_t)lane == csel ? esc : -__builtin_inff(), 0, esel, dummy_i);
+  if (lane == 0) {
+    if (!any_exec) csel = 0;
+    d.exec_sel[env] = csel, d.num_exec[env] = (int32_t)csel + 1;
+    if (any_exec) d.lgprob[env] += esel - EM - logf(ES);
+  }
+}

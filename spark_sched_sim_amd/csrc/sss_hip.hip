@@ -57,6 +57,12 @@ static int be_launch_decima_policy(const SssLayout& L, const SssBuffers& B, int 
   return (int)hipGetLastError();
 }
 
+static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleArgs& d, void* stream) {
+  if (which == 0) hipLaunchKernelGGL(sss_decima_sample_stage_kernel, dim3(n_obs), dim3(64), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(sss_decima_sample_exec_kernel, dim3(n_obs), dim3(64), 0, (hipStream_t)stream, d);
+  return (int)hipGetLastError();
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
   constexpr int NW = gnn_weight_count<KIND>();

@@ -308,6 +308,19 @@ extern "C" int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* g,
   return 0;
 }
 
+extern "C" int sss_decima_sample(int n_obs, int which, const sss_decima_sample_args* g, void* stream) {
+  if (!g || n_obs < 1 || (which != 0 && which != 1)) return sss_fail(-1, "bad argument");
+  if (g->num_executors < 1 || g->num_executors > 64) return sss_fail(-28, "num_executors must be 1..64");
+  SssDecimaSampleArgs d;
+  d.n_pad = g->n_pad, d.E = g->num_executors, d.rng_seed = g->rng_seed, d.rng_counter = g->rng_counter;
+  d.stage_scores = g->stage_scores_dev, d.exec_scores = g->exec_scores_dev, d.obs_nodes = g->obs_nodes_dev, d.obs_node_off = g->obs_node_off_dev;
+  d.obs_job_off = g->obs_job_off_dev, d.sched_rank = g->sched_rank_dev, d.node_job = g->node_job_dev, d.job_gid = g->job_gid_dev;
+  d.stage_idx = g->stage_idx_dev, d.num_exec = g->num_exec_dev, d.stage_sel = g->stage_sel_dev, d.job_idx = g->job_idx_dev;
+  d.exec_sel = g->exec_sel_dev, d.lgprob = g->lgprob_dev, d.any_stage = g->any_stage_dev;
+  if (int rc = be_launch_decima_sample(n_obs, which, d, stream)) return sss_fail(-30, std::string("decima sample launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   if (!g) return sss_fail(-1, "NULL argument");
   if (kind < 0 || kind >= GNN_KINDS) return sss_fail(-26, "unknown GNN stage");

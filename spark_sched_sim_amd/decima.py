@@ -451,6 +451,40 @@ class DecimaPolicy(nn.Module):
         return out
 
     @torch.no_grad()
+    def _sample_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], padded: torch.Tensor, generator: torch.Generator | None,
+                        scores_out: dict | None = None) -> dict[str, torch.Tensor]:
+        """both draws on the device (include/sss.h sss_decima_sample): stage draw -> executor scores
+        of the chosen stage's job -> executor-count draw; Gumbel-max over a counter-based stream
+        (seed = the generator's, counter = number of calls so far)"""
+        import ctypes
+
+        from .binding import SssDecimaSampleArgs
+        B, E, dev = g["n_obs"], self.num_executors, padded.device
+        self._calls = getattr(self, "_calls", 0) + 1
+        i64 = lambda: torch.empty(B, dtype=torch.int64, device=dev)  # noqa: E731
+        out = {"stage_sel": i64(), "job_idx": i64(), "exec_sel": i64(), "lgprob": torch.empty(B, dtype=torch.float32, device=dev),
+               "any_stage": torch.empty(B, dtype=torch.bool, device=dev)}
+        job_gid = i64()
+        stage_idx = torch.empty(B, dtype=torch.int32, device=dev)
+        num_exec = torch.empty(B, dtype=torch.int32, device=dev)
+        es = torch.empty((B, E), dtype=torch.float32, device=dev)
+        a = SssDecimaSampleArgs(g["n_pad"], E, (generator.initial_seed() if generator is not None else 0) & (2 ** 64 - 1), self._calls,
+                                padded.data_ptr(), es.data_ptr(), g["obs_nodes"].data_ptr(), g["obs_node_off"].data_ptr(),
+                                g["obs_job_off"].data_ptr(), g["sched_rank"].data_ptr(), g["node_job"].data_ptr(), job_gid.data_ptr(),
+                                stage_idx.data_ptr(), num_exec.data_ptr(), out["stage_sel"].data_ptr(), out["job_idx"].data_ptr(),
+                                out["exec_sel"].data_ptr(), out["lgprob"].data_ptr(), out["any_stage"].data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
+        self._launch("exec", B * E, self._packed_weights()["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
+                     idx0=job_gid, job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
+        self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
+        out["env_stage_idx"], out["env_num_exec"] = stage_idx, num_exec
+        out["rng"] = (a.rng_seed, a.rng_counter)
+        if scores_out is not None:
+            scores_out["stage_scores"], scores_out["exec_scores"] = padded, es
+        return out
+
+    @torch.no_grad()
     def _exec_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
         k, E = job_gid.numel(), self.num_executors
         out = torch.empty((k, E), dtype=torch.float32, device=job_gid.device)
@@ -495,6 +529,7 @@ class DecimaPolicy(nn.Module):
         if fast:
             h = self._encode_kernels(g)
             padded = self._stage_scores_kernels(g, h)
+            return self._sample_kernels(g, h, padded, generator)
         else:
             h = self.encode(g)
             s, idx = self.stage_scores(g, h)
@@ -563,6 +598,8 @@ class DecimaPolicy(nn.Module):
     def env_actions(a: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
         """`act`'s result in the env's action format (DecimaActWrapper.action, env_wrapper.py:33-34);
         envs without a schedulable stage get stage_idx -1"""
+        if "env_stage_idx" in a:  # written by the sampling kernels
+            return {"stage_idx": a["env_stage_idx"], "num_exec": a["env_num_exec"]}
         stage_idx = torch.where(a["any_stage"], a["stage_sel"], torch.full_like(a["stage_sel"], -1))
         return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}
 

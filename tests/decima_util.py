@@ -60,6 +60,10 @@ def check_decima_fixture(name, device, lib, n_steps):
                 assert torch.equal(torch.isfinite(ek), torch.isfinite(es_t)), (t, j)
                 fin = torch.isfinite(ek)
                 assert float((ek[fin] - es_t[fin]).abs().max()) <= SCORE_ATOL if fin.any() else True, (t, j)
+            # the pipeline's sampling kernels: draws are the Gumbel-max of the pipeline's own scores
+            sc = {}
+            ap = policy._sample_kernels(kg, hk, sk, torch.Generator().manual_seed(123), scores_out=sc)
+            check_policy_draw({**ap, **sc}, policy.env_actions(ap), cg, f, es_all, job_off, *ap["rng"])
             # the one-launch policy kernel: same scores, and a draw that is the Gumbel-max of them
             acts_k, ak = policy.act_env(env, counter=1000 + t, seed=77, want_scores=True)
             fin = torch.isfinite(ss)

@@ -60,6 +60,12 @@ static int be_launch_decima_policy(const SssLayout& L, const SssBuffers& B, int 
   return 0;
 }
 
+static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleArgs& d, void*) {
+  if (which == 0) emu::launch(n_obs, [&]() { sss_decima_sample_stage_kernel(d); });
+  else emu::launch(n_obs, [&]() { sss_decima_sample_exec_kernel(d); });
+  return 0;
+}
+
 template <int KIND>
 static int gnn_run_kind(const SssGnnArgs& a) {
   for (int64_t r = 0; r < a.n_rows; r++) gnn_row<KIND>(a, r, a.w, a.w2);
