@@ -78,6 +78,18 @@ SSS_DEV float gnn_act(float v, float slope) {
   return tanhf(v);
 }
 
+// bias + w . x with four independent accumulators (the serial FMA chain is what a lone wave waits on)
+template <int N>
+SSS_DEV float gnn_dot(const float* __restrict__ w, const float (&x)[N], float bias) {
+  GNN_FP_CONTRACT
+  float a0 = bias, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  GNN_UNROLL for (int i = 0; i + 3 < N; i += 4) {
+    a0 += w[i] * x[i], a1 += w[i + 1] * x[i + 1], a2 += w[i + 2] * x[i + 2], a3 += w[i + 3] * x[i + 3];
+  }
+  GNN_UNROLL for (int i = N & ~3; i < N; i++) a0 += w[i] * x[i];
+  return (a0 + a1) + (a2 + a3);
+}
+
 // One row through Linear-act-Linear-act (`gnn_hidden`) and the last Linear (`gnn_out`). Packed
 // parameters: W1 (H1 x IN, row-major), b1, W2T (H1 x H2: the SECOND layer transposed), b2, W3
 // (OUT x H2), b3. Layer 1 is streamed into layer 2: each hidden-1 neuron is computed and immediately
@@ -96,9 +108,7 @@ SSS_DEV void gnn_hidden(const float* __restrict__ w, const float (&x)[IN], float
   GNN_UNROLL for (int o = 0; o < H2; o++) h2[o] = b2[o];
   GNN_NO_UNROLL for (int j = 0; j < H1; j++) {
     const float* wr = W1 + j * IN;
-    float acc = b1[j];
-    GNN_UNROLL for (int i = 0; i < IN; i++) acc += wr[i] * x[i];
-    float t = gnn_act<ACT>(acc, slope);
+    float t = gnn_act<ACT>(gnn_dot<IN>(wr, x, b1[j]), slope);
     const float* wc = W2T + j * H2;
     GNN_UNROLL for (int o = 0; o < H2; o++) h2[o] += wc[o] * t;
   }
@@ -112,9 +122,7 @@ SSS_DEV void gnn_out(const float* __restrict__ w, const float (&h2)[H2], float b
   const float* W3 = w + H1 * IN + H1 + H2 * H1 + H2;
   const float* b3 = W3 + OUT * H2;
   GNN_NO_UNROLL for (int o = 0; o < OUT; o++) {
-    float acc = b3[o] * bias_count;
-    GNN_UNROLL for (int i = 0; i < H2; i++) acc += W3[o * H2 + i] * h2[i];
-    emit(o, acc);
+    emit(o, gnn_dot<H2>(W3 + o * H2, h2, b3[o] * bias_count));
   }
 }
 
