@@ -59,3 +59,18 @@ def test_train(tmp_path):
     tr.train(verbose=False)
     assert tr.history[0]["samples"] > 0
     tr.close()
+
+
+def test_trainer_async_rollouts(tmp_path):
+    """`rollout_duration` in the trainer config selects the asynchronous collection mode
+    (trainer.py:60, rollout_worker.py:162-206): fixed simulated time per iteration, episodes
+    restarting in place, env state carried over between iterations"""
+    from decima_util import AGENT
+    from spark_sched_sim_amd.training import Trainer
+
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), ENV, dict(TRAIN, artifacts_dir=str(tmp_path), rollout_duration=1.0e5),
+                 device="cpu", _lib=load_emu())
+    hist = tr.train(verbose=False)
+    assert len(hist) == 2 and all(h["samples"] > 0 for h in hist)
+    assert int(tr.collector.reset_count.min()) >= 1
+    tr.close()
