@@ -1327,7 +1327,9 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
     oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
     of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
+#ifndef SSS_EVPROF
     g_hot.h.prof[4] += wave_clock() - t_obs0;
+#endif
     g_hot.h.obs_n_nodes = base_n;
     g_hot.h.obs_n_sched = h.n_sched;
     g_hot.h.last_reward = reward;
@@ -1587,12 +1589,28 @@ SSS_DEV void resume_simulation() {
       fastctx_load(f);
       uint64_t n_fast = 0, t_slow = 0;
       int status;
+#ifdef SSS_EVPROF
+      uint64_t tp_pop = 0, tp_handle = 0, tp_loop0 = wave_clock();
+#endif
       do {
+#ifdef SSS_EVPROF
+        uint64_t c0 = wave_clock();
+#endif
         int ex = pop_event_wave(wave_lane0_f64(r.next_arrival_t));
+#ifdef SSS_EVPROF
+        uint64_t c1 = wave_clock();
+#endif
         status = 0;
         if (lane == 0) status = handle_popped(f, r, ex, n_fast, t_slow);
+#ifdef SSS_EVPROF
+        uint64_t c2 = wave_clock();
+        tp_pop += c1 - c0, tp_handle += c2 - c1;
+#endif
         status = (int)wave_lane0_u32((uint32_t)status);
       } while (status == 0);
+#ifdef SSS_EVPROF
+      if (lane == 0) H.prof[1] += tp_pop, H.prof[3] += tp_handle, H.prof[4] += wave_clock() - tp_loop0;
+#endif
       if (lane == 0) {
         g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
         H.n_fast += n_fast;
@@ -1779,7 +1797,9 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   }
   wave_sync();
   uint64_t t1 = wave_clock();
+#ifndef SSS_EVPROF
   if (lane == 0) H.prof[1] += t1 - t0;
+#endif
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
   resume_simulation();
   uint64_t t2 = wave_clock();
@@ -1811,7 +1831,11 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     }
     if (H.err) H.need_reset = 1;
     uint64_t t3 = wave_clock();
+#ifndef SSS_EVPROF
     H.prof[2] += t2 - t1, H.prof[3] += t3 - t2;
+#else
+    H.prof[2] += t2 - t1;
+#endif
   }
   wave_sync();
   return reward;
