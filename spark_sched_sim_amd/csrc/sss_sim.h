@@ -1191,7 +1191,11 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   int len = lenw & 0x3FFFFFFF;
   if (len == 0 || n_local <= 0) return -1;
   uint32_t i = rng_integers(r, (uint32_t)len);
+#ifdef SSS_EXPERIMENT_NO_GATHER  // timing experiment only (wrong durations): what the L2 gather costs
+  double dur = (double)(100 + ((off + (int)i) & 1023));
+#else
   double dur = (double)f.durations[off + (int)i];
+#endif
   *dp = (float)dur;
   g_hot.ev[ex].t = r.wall_time + dur;
   g_hot.ev[ex].seq = r.counter++;
