@@ -1155,11 +1155,17 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   } else {
     sp = g_c.stages + j * f.SP + s, jp = g_c.jobs + j, dp = g_c.durations + j * f.SP + s;
   }
+#ifdef SSS_EVPROF2
+  uint64_t q0 = wave_clock();
+#endif
   SssStage st = *sp;
   uint64_t local = jp->local_mask;
   int gs = jp->gs_base + s;
   SssExDesc xd = f.exdesc[ex];
   if (st.remaining <= 0) return 0;
+#ifdef SSS_EVPROF2
+  uint64_t q1 = wave_clock();
+#endif
   st.remaining = (int16_t)(st.remaining - 1);
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
   if (st.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);  // stage just became saturated (ENV:595-597)
@@ -1190,7 +1196,13 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   }
   int len = lenw & 0x3FFFFFFF;
   if (len == 0 || n_local <= 0) return -1;
+#ifdef SSS_EVPROF2
+  uint64_t q2 = wave_clock();
+#endif
   uint32_t i = rng_integers(r, (uint32_t)len);
+#ifdef SSS_EVPROF2
+  uint64_t q3 = wave_clock();
+#endif
 #ifdef SSS_EXPERIMENT_NO_GATHER  // timing experiment only (wrong durations): what the L2 gather costs
   double dur = (double)(100 + ((off + (int)i) & 1023));
 #else
@@ -1199,6 +1211,10 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   *dp = (float)dur;
   g_hot.ev[ex].t = r.wall_time + dur;
   g_hot.ev[ex].seq = r.counter++;
+#ifdef SSS_EVPROF2
+  uint64_t q4 = wave_clock();
+  g_hot.h.prof[0] += q1 - q0, g_hot.h.prof[1] += q2 - q1, g_hot.h.prof[2] += q3 - q2, g_hot.h.prof[3] += q4 - q3;
+#endif
   return 1;
 }
 
@@ -1331,7 +1347,7 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
     oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
     of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
-#ifndef SSS_EVPROF
+#if !defined(SSS_EVPROF) && !defined(SSS_EVPROF2)
     g_hot.h.prof[4] += wave_clock() - t_obs0;
 #endif
     g_hot.h.obs_n_nodes = base_n;
@@ -1618,7 +1634,9 @@ SSS_DEV void resume_simulation() {
       if (lane == 0) {
         g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
         H.n_fast += n_fast;
+#ifndef SSS_EVPROF2
         H.prof[0] += t_slow;
+#endif
       }
     }
     wave_sync();
@@ -1801,7 +1819,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   }
   wave_sync();
   uint64_t t1 = wave_clock();
-#ifndef SSS_EVPROF
+#if !defined(SSS_EVPROF) && !defined(SSS_EVPROF2)
   if (lane == 0) H.prof[1] += t1 - t0;
 #endif
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
@@ -1835,7 +1853,8 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     }
     if (H.err) H.need_reset = 1;
     uint64_t t3 = wave_clock();
-#ifndef SSS_EVPROF
+#if defined(SSS_EVPROF2)
+#elif !defined(SSS_EVPROF)
     H.prof[2] += t2 - t1, H.prof[3] += t3 - t2;
 #else
     H.prof[2] += t2 - t1;
