@@ -525,16 +525,14 @@ class DecimaPolicy(nn.Module):
         are then meaningless)."""
         B, N = g["n_obs"], g["n_pad"]
         M, J = g["x"].shape[0], g["job_obs"].numel()
-        fast = self._use_kernels(g) and M > 0 and J > 0
-        if fast:
+        if self._use_kernels(g) and M > 0 and J > 0:
             h = self._encode_kernels(g)
-            padded = self._stage_scores_kernels(g, h)
-            return self._sample_kernels(g, h, padded, generator)
-        else:
-            h = self.encode(g)
-            s, idx = self.stage_scores(g, h)
-            padded = torch.full((B, N), float("-inf"), dtype=s.dtype, device=s.device)
-            padded[g["node_obs"][idx], g["node_loc"][idx]] = s
+            return self._sample_kernels(g, h, self._stage_scores_kernels(g, h), generator)
+        # tensor-op path (other architectures, graphs built without the graph kernel)
+        h = self.encode(g)
+        s, idx = self.stage_scores(g, h)
+        padded = torch.full((B, N), float("-inf"), dtype=s.dtype, device=s.device)
+        padded[g["node_obs"][idx], g["node_loc"][idx]] = s
         any_stage = torch.isfinite(padded).any(1)
         p = torch.softmax(torch.where(any_stage[:, None], padded, torch.zeros_like(padded)), 1)
         col = torch.multinomial(p, 1, generator=generator)[:, 0]
@@ -545,8 +543,7 @@ class DecimaPolicy(nn.Module):
         stage_sel = g["sched_rank"][node]
         job_gid = g["node_job"][node]
         job_slot = job_gid - _excl_cumsum(g["obs_jobs"])
-        job_sel = job_gid.clamp(min=0, max=max(J - 1, 0))
-        es = self._exec_scores_kernels(g, h, job_sel) if fast else self.exec_scores(g, h, job_sel)
+        es = self.exec_scores(g, h, job_gid.clamp(min=0, max=max(J - 1, 0)))
         any_exec = torch.isfinite(es).any(1) & any_stage
         pe = torch.softmax(torch.where(any_exec[:, None], es, torch.zeros_like(es)), 1)
         k = torch.multinomial(pe, 1, generator=generator)[:, 0]
