@@ -80,7 +80,15 @@ class RolloutCollector:
     SSS_SKIP_ENV until the others catch up."""
 
     def __init__(self, env, mean_time_limit: float, base_seeds: Sequence[int], seed_step: int, num_executors: int,
-                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None):
+                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None, on_env_error: str = "raise"):
+        """on_env_error: what to do when an env reports an error from `step` - in practice the
+        reference's `[step]` assertion (spark_sched_sim.py:212-215), which valid Decima actions can
+        trigger (tests/golden/stall_case.json). "raise" = the reference's behaviour (the worker
+        aborts, the trainer stops, rollout_worker.py:110-112 / trainer.py:117-124); "truncate" = the
+        rollout ends before the failing step and training goes on (`env_errors` counts them)."""
+        assert on_env_error in ("raise", "truncate")
+        self.on_env_error = on_env_error
+        self.env_errors = 0
         self.env = env
         self.tl_env = VecStochasticTimeLimit(env, mean_time_limit)
         self.base_seeds = np.asarray(base_seeds, dtype=np.int64)
@@ -96,6 +104,7 @@ class RolloutCollector:
         self.act_fn = act_fn
         self._obs = None
         self._wall = None
+        self._pending_reset = None
 
     @property
     def seeds(self) -> np.ndarray:
@@ -127,6 +136,10 @@ class RolloutCollector:
             self._obs = self._reset()
             self._wall = torch.zeros(B, dtype=torch.float64, device=dev)
         obs, wall = self._obs, self._wall
+        if asynchronous and self._pending_reset is not None:
+            obs = self._reset(mask=self._pending_reset)
+            wall = torch.where(self._pending_reset, torch.zeros_like(wall), wall)
+        self._pending_reset = None
         elapsed = torch.zeros(B, dtype=torch.float64, device=dev)
         active = torch.ones(B, dtype=torch.bool, device=dev)
         rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
@@ -137,6 +150,26 @@ class RolloutCollector:
             stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
             num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)
             obs, rew, term, trunc, info = self.tl_env.step({"stage_idx": stage_idx.contiguous(), "num_exec": num_exec.contiguous()})
+            bad = (info["err"] != 0) & active
+            if bool(bad.any()):
+                self.env_errors += int(bad.sum())
+                if self.on_env_error == "raise":
+                    from .binding import ERROR_NAMES
+                    b = int(bad.nonzero()[0])
+                    code = int(info["err"][b])
+                    err = RuntimeError(f"env {b} (seed {int(self.seeds[b] - self.seed_step)}), rollout step {len(rec['g'])}: "
+                                       f"{ERROR_NAMES.get(code, code)}; action stage_idx={int(stage_idx[b])} num_exec={int(num_exec[b])}")
+                    # what a bug report needs: the env's seed, time limit and action history
+                    err.case = {"seed": int(self.seeds[b] - self.seed_step), "time_limit": float(self.tl_env.time_limit[b]), "code": code,
+                                "stage_idx": [int(x[b]) for x in rec["stage_sel"]] + [int(stage_idx[b])],
+                                "num_exec": [int(x[b]) + 1 for x in rec["exec_sel"]] + [int(num_exec[b])]}
+                    raise err
+                # truncate: the failing step is not recorded and the env sits out the rest of this
+                # collection (async: it starts its next episode at the next collection)
+                active = active & ~bad
+                self._pending_reset = bad if self._pending_reset is None else (self._pending_reset | bad)
+                if not bool(active.any()):
+                    break
             new_wall = torch.where(active, info["wall_time"], wall)
             done = (term | trunc) & active
             rec["g"].append(g)
@@ -233,7 +266,7 @@ def _interp(x: torch.Tensor, xp: torch.Tensor, fp: torch.Tensor, n: torch.Tensor
     ar = torch.arange(Tm, device=xp.device)
     xp_s = torch.where(ar < n[..., None], xp, torch.full_like(xp, float("inf")))
     j = (torch.searchsorted(xp_s, x.contiguous(), right=True) - 1).clamp(min=0)
-    last = (n[..., None] - 1).expand_as(j)
+    last = (n[..., None] - 1).clamp(min=0).expand_as(j)
     j = torch.minimum(j, last)
     j1 = torch.minimum(j + 1, last)
     x0, x1, y0, y1 = xp.gather(-1, j), xp.gather(-1, j1), fp.gather(-1, j), fp.gather(-1, j1)
@@ -259,9 +292,16 @@ def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, n
     nn = n[:, None, :].expand(G, R, R)
     y_hat = _interp(x.contiguous(), xp.contiguous(), fp.contiguous(), nn.contiguous())
     acc = torch.zeros((G, R, T), dtype=torch.float64, device=values.device)
+    if bool((n > 0).all()):
+        for j in range(R):
+            acc = acc + y_hat[:, :, j, :]
+        return (acc / R).reshape(B, T).t() * ro.active
+    # some rollout recorded nothing (its env failed on its first step, on_env_error="truncate"):
+    # it has no curve and is left out of its group's mean
+    has = (n > 0).to(torch.float64)
     for j in range(R):
-        acc = acc + y_hat[:, :, j, :]
-    return (acc / R).reshape(B, T).t() * ro.active
+        acc = acc + y_hat[:, :, j, :] * has[:, None, j, None]
+    return (acc / has.sum(1).clamp(min=1)[:, None, None]).reshape(B, T).t() * ro.active
 
 
 # ---- PPO (trainers/ppo.py) ----------------------------------------------------------------------------
@@ -414,7 +454,7 @@ class Trainer:
         gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
         gen.manual_seed(self.seed * 1000003 + self.rank)
         self.collector = RolloutCollector(self.env, self.env_cfg["mean_time_limit"], base_seeds, total_sequences, E,
-                                          policy=self.policy, generator=gen)
+                                          policy=self.policy, generator=gen, on_env_error=train_cfg.get("on_env_error", "raise"))
         self.ppo = PPO(self.policy, train_cfg, generator=gen)
         self.history: list[dict[str, float]] = []
 
@@ -460,7 +500,7 @@ class Trainer:
                 best = None
             elif (i + 1) % self.checkpointing_freq == 0:
                 best = None
-            rec = dict(learn, iteration=i, avg_num_jobs=float(avg_num_jobs), samples=int(ro.active.sum()),
+            rec = dict(learn, iteration=i, avg_num_jobs=float(avg_num_jobs), samples=int(ro.active.sum()), env_errors=self.collector.env_errors,
                        episode_length=float(ro.lengths.float().mean()))
             self.history.append(rec)
             if verbose and self.rank == 0:

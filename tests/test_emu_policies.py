@@ -114,3 +114,38 @@ def test_auto_reset_continues_with_strided_seeds(fused, pack):
         assert na == nb and torch.equal(a.nodes[k, :na, :2], b.nodes[k, :nb, :2]), k
     a.close()
     b.close()
+
+
+def test_valid_action_sequence_that_stalls_the_reference(pack):
+    """tests/golden/stall_case.json: a sequence of VALID (stage, executor count) actions - sampled by
+    a Decima policy during PPO - after which the reference env raises AssertionError('[step]')
+    (spark_sched_sim.py:212-215): no committable executors, no schedulable stage, events left.
+    The oracle and the kernel must fail at the same step with the same code, and agree bit for bit
+    on every step before it."""
+    import json
+    import os.path as osp
+
+    import torch
+
+    from golden_util import GOLDEN_DIR, bits
+    from oracle_binding import OracleEnv
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+
+    c = json.load(open(osp.join(GOLDEN_DIR, "stall_case.json")))
+    cfg = {k: v for k, v in c["env_cfg"].items() if k != "mean_time_limit"}
+    env = VecSparkSchedSimEnv(cfg, 1, device="cpu", pack=pack, _lib=load_emu())
+    env.reset(seed=[c["seed"]], options={"time_limit": c["time_limit"]})
+    o = OracleEnv(pack, cfg)
+    o.reset(c["seed"], c["time_limit"])
+    for t, (s, n) in enumerate(zip(c["stage_idx"], c["num_exec"])):
+        _, rew, term, _, info = env.step({"stage_idx": torch.tensor([s], dtype=torch.int32), "num_exec": torch.tensor([n], dtype=torch.int32)})
+        e, r, done = o.step(s, n)
+        assert int(info["err"][0]) == e, t
+        if e:
+            assert (t, e) == (c["error_step"], 5)
+            break
+        assert bits(float(rew[0])) == bits(r) and bits(float(info["wall_time"][0])) == bits(o.info().wall_time) and not done, t
+    else:
+        raise AssertionError("the sequence did not stall")
+    env.close()
+    o.close()

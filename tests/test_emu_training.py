@@ -74,3 +74,44 @@ def test_trainer_async_rollouts(tmp_path):
     assert len(hist) == 2 and all(h["samples"] > 0 for h in hist)
     assert int(tr.collector.reset_count.min()) >= 1
     tr.close()
+
+
+def test_collector_truncates_a_rollout_whose_env_stalls(pack=None):
+    """on_env_error="truncate": tests/golden/stall_case.json (valid actions, the reference raises
+    AssertionError('[step]') at step 110) replayed through the collector: the rollout keeps its 110
+    good steps, the failing one is not recorded, the other env is unaffected; "raise" raises."""
+    import json
+    import os.path as osp
+
+    import pytest
+    import torch
+
+    from golden_util import GOLDEN_DIR
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.training import RolloutCollector, discounted_returns, sequence_baselines
+
+    c = json.load(open(osp.join(GOLDEN_DIR, "stall_case.json")))
+    cfg = {k: v for k, v in c["env_cfg"].items() if k != "mean_time_limit"}
+
+    def replay(g, counts):  # env 0 replays the recorded actions, env 1 always takes (stage 0, 1 executor)
+        t = int(counts[0]) if int(counts[0]) < len(c["stage_idx"]) else len(c["stage_idx"]) - 1
+        z = torch.zeros(2, dtype=torch.long)
+        return {"stage_sel": torch.tensor([c["stage_idx"][t], 0]), "job_idx": z, "exec_sel": torch.tensor([c["num_exec"][t] - 1, 0]),
+                "lgprob": torch.zeros(2), "any_stage": torch.ones(2, dtype=torch.bool)}
+
+    for mode in ("truncate", "raise"):
+        env = VecSparkSchedSimEnv(cfg, 2, device="cpu", _lib=load_emu())
+        col = RolloutCollector(env, c["env_cfg"]["mean_time_limit"], [c["seed"], c["seed"]], 1, 10, act_fn=replay, on_env_error=mode)
+        # same seed => same sampled time limit as the recorded episode (StochasticTimeLimit's rule)
+        if mode == "raise":
+            with pytest.raises(RuntimeError, match="simulation stalled") as ei:
+                col.collect_sync(with_stats=False)
+            assert ei.value.case["stage_idx"] == c["stage_idx"] and ei.value.case["seed"] == c["seed"]
+        else:
+            ro = col.collect_sync(with_stats=False)
+            assert float(col.tl_env.time_limit[0]) == c["time_limit"]
+            assert int(ro.lengths[0]) == c["error_step"] and col.env_errors == 1 and int(ro.lengths[1]) > 0
+            ret = discounted_returns(ro, cfg["beta"])
+            base = sequence_baselines(ro, ret, 1, 2)
+            assert torch.isfinite(ret).all() and torch.isfinite(base).all()
+        env.close()
