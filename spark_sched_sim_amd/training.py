@@ -117,18 +117,7 @@ class RolloutCollector:
 
     def _stats(self) -> dict[str, np.ndarray]:
         """rollout_worker.py:122-130 for every env"""
-        from . import metrics
-        B = self.env.num_envs
-        out = {k: np.zeros(B) for k in ("avg_job_duration", "avg_num_jobs", "num_completed_jobs", "num_job_arrivals")}
-        for b in range(B):
-            h = self.env.header(b)
-            buff = self.env.job_duration_buff(b)
-            with np.errstate(all="ignore"):
-                out["avg_job_duration"][b] = np.mean(buff) * 1e-3 if buff else np.nan
-                out["avg_num_jobs"][b] = metrics.avg_num_jobs(self.env, b)
-            out["num_completed_jobs"][b] = h["n_completed"]
-            out["num_job_arrivals"][b] = h["n_completed"] + h["n_active"]
-        return out
+        return {k: v.cpu().numpy() for k, v in self.env.rollout_stats().items()}
 
     def _loop(self, asynchronous: bool, duration: float, with_stats: bool) -> Rollouts:
         env, dev, B = self.env, self.env.device, self.env.num_envs

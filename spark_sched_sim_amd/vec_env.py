@@ -302,6 +302,27 @@ class VecSparkSchedSimEnv:
         n = np.dtype(w).itemsize
         return self._env_view[:, off: off + n].view(tw).squeeze(1)
 
+    def rollout_stats(self) -> dict[str, torch.Tensor]:
+        """what the reference's rollout workers report per env (rollout_worker.py:122-130:
+        `avg_job_duration` [s, over the last <=200 completed jobs, nan if none], `avg_num_jobs`
+        (metrics.py:16-18), `num_completed_jobs`, `num_job_arrivals`) for ALL envs as f64[B] device
+        tensors - no per-env host round trips"""
+        d, B = self.dims, self.num_envs
+        J = d.job_cap
+        f64 = lambda off, n: self._env_view[:, off: off + 8 * n].view(torch.float64)  # noqa: E731
+        ta, tc = f64(d.off_t_arrival, J), f64(d.off_t_completed, J)
+        wall = self.header_field("wall_time")
+        arrived = torch.arange(J, device=self.device)[None, :] < self.header_field("next_arrival")[:, None]
+        dur = torch.where(arrived, torch.minimum(tc, wall[:, None]) - ta, torch.zeros_like(ta))
+        n_ring = self.header_field("dur_n").to(torch.float64)
+        ring = f64(d.off_dur_ring, 200)
+        head = self.header_field("dur_head").long()
+        k = (torch.arange(200, device=self.device)[None, :] - head[:, None]) % 200  # position of slot in deque order
+        ring_sum = torch.where(k < n_ring[:, None], ring, torch.zeros_like(ring)).sum(1)
+        done, act = self.header_field("n_completed").to(torch.float64), self.header_field("n_active").to(torch.float64)
+        return {"avg_job_duration": ring_sum / n_ring * 1e-3, "avg_num_jobs": dur.sum(1) / wall, "num_completed_jobs": done,
+                "num_job_arrivals": done + act}
+
     def counters(self) -> dict[str, int]:
         """lifetime totals over all envs: real step() calls, events popped, SURVEY 8(d) model bytes"""
         hdr = self._env_view[:, : self.dims.hdr_bytes].cpu().numpy()
