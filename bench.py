@@ -135,6 +135,34 @@ def measured_traffic(kernel: str, config: str, envs: int):
     return None
 
 
+def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int = 20) -> dict:
+    """extra, not the headline: the same B envs with a sampled Decima action (GNN policy, random-init
+    weights of the published architecture) for every env on every step - graph kernel, GNN kernels,
+    sampling kernels, sss_step (spark_sched_sim_amd/decima.py)"""
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    agent = dict(embed_dim=16, gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(negative_slope=0.2)),
+                 policy_mlp_kwargs=dict(hid_dims=[64, 64], act_cls="Tanh"))
+    env = VecSparkSchedSimEnv(cfg, B, device=dev, pack=pack, auto_reset=True)
+    torch.manual_seed(0)
+    policy = DecimaPolicy(num_executors=cfg["num_executors"], **agent).to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(1)
+    env.reset(seed=0)
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        act, _ = policy.schedule_env(env, generator=gen)
+        env.step(act)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err = int((env.obs_i32[:, 7] != 0).sum())
+    env.close()
+    return {"value": B * steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "envs_in_error_state": err,
+            "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +173,7 @@ def main() -> None:
     ap.add_argument("--policy", default=None, choices=["hash", "fair"])
     ap.add_argument("--mode", default="step", choices=["step", "fused"])
     ap.add_argument("--fused-chunk", type=int, default=50)
+    ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
     ap.add_argument("--shards", type=int, default=1,
                     help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
                          "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
@@ -338,6 +367,11 @@ def main() -> None:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(6.0, args.cpu_budget))
             except Exception as e:  # never let the extra baseline take the bench line down
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        if world == 1 and not args.no_decima and args.config == "c2":
+            try:  # SURVEY 8(f) next-1 on the same env sizing; never let it take the bench line down
+                out["decima_in_loop"] = decima_in_loop(cfg, B, dev, pack)
+            except Exception as e:
+                out["decima_in_loop"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:
