@@ -139,6 +139,8 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
     """extra, not the headline: the same B envs with a sampled Decima action (GNN policy, random-init
     weights of the published architecture) for every env on every step - graph kernel, GNN kernels,
     sampling kernels, sss_step (spark_sched_sim_amd/decima.py)"""
+    import torch
+
     from spark_sched_sim_amd import VecSparkSchedSimEnv
     from spark_sched_sim_amd.decima import DecimaPolicy
 
