@@ -73,3 +73,32 @@ def test_simulator_under_decima_actions_matches_oracle(pack):
             assert done == bool(term[b]) and info.n_nodes == int(n_nodes[b]), (b, t)
         o.close()
     env.close()
+
+
+def test_graph_kernel_at_c3_sizing_matches_tensor_ops():
+    """node capacity 3600 (200 jobs x 18 stage slots): 57.6 KB of LDS per workgroup in the graph
+    kernel; its output must still equal the tensor-op construction, and the kernel forward the
+    tensor-op forward, on busy mid-episode observations"""
+    from decima_util import compare_graphs
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy, compact_graph, decima_observation
+
+    cfg = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 32, device="cuda:0")
+    torch.manual_seed(5)
+    policy = DecimaPolicy(num_executors=50, **AGENT).to("cuda:0").eval().bind_kernels(env._b)
+    obs, _ = env.reset(seed=77)
+    for chunk in range(4):
+        env.rollout("fair", 700)
+        obs = env._obs()
+        f = decima_observation(obs, 50, env.dims.stage_stride, edge_masks=True)
+        cg = compact_graph(f)
+        kg = env.decima_graph()
+        compare_graphs(kg, cg, f)
+        with torch.no_grad():
+            h = policy.encode(cg)
+            hk = policy._encode_kernels(kg)
+            for k in ("node", "dag", "glob"):
+                assert float((hk[k] - h[k]).abs().max()) <= 5e-5, (chunk, k)
+    assert int(obs["n_nodes"].max()) > 40
+    env.close()
