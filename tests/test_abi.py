@@ -78,3 +78,30 @@ def test_workload_pack_is_frozen(pack):
     assert workload.pack_digest(pack) == Golden("c1_fair").pack_sha256
     arrs = workload.build_pack_arrays(workload.make_raw_workload())
     assert arrs["tmpl_stage_off"].size == 155 and int(np.diff(arrs["tmpl_stage_off"]).max()) <= 64
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """every struct of include/sss.h against its ctypes mirror in binding.py: same size and the same
+    offset for every field (compiled from the header with gcc, as a C caller would see it)"""
+    from spark_sched_sim_amd import binding as B
+
+    pairs = {"sss_cfg": B.SssCfg, "sss_dims": B.SssDims, "sss_buffers": B.SssBuffers, "sss_decima_graph": B.SssDecimaGraph,
+             "sss_decima_lists": B.SssDecimaLists, "sss_decima_policy_args": B.SssDecimaPolicyArgs,
+             "sss_decima_sample_args": B.SssDecimaSampleArgs, "sss_gnn_args": B.SssGnnArgs}
+    header = open(osp.join(ROOT, "include", "sss.h")).read()
+    assert set(re.findall(r"}\s*(sss_[a-z_]+);", header)) == set(pairs), "a struct of the header has no ctypes mirror (or vice versa)"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{osp.join(ROOT, "include", "sss.h")}"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, *_ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
