@@ -797,16 +797,26 @@ SSS_DEV_NOINLINE void find_backup_stage(int e, int& out_j, int& out_s) {
 // executor movement (lane 0)
 // ------------------------------------------------------------------------------------------
 
-SSS_DEV uint32_t ev_info(int kind, int j, int s) { return (uint32_t)kind | ((uint32_t)s << 8) | ((uint32_t)j << 16); }
+// event word: kind (bits 0-7) | stage (8-13) | LDS slot of the job, valid within a launch, 127 = none
+// (14-20) | job (21-31). The slot rides along so that the handler of a popped TASK_FINISHED does not
+// have to look it up (one dependent LDS round trip less per event); env_begin fills it for the events
+// that are pending when a launch starts, env_end clears it so that the HBM image does not depend on
+// how slots were handed out.
+#define INFO_SLOT_NONE 127u
+SSS_DEV uint32_t ev_info(int kind, int j, int s, uint32_t slot) {
+  return (uint32_t)kind | ((uint32_t)s << 8) | ((slot > 63u ? INFO_SLOT_NONE : slot) << 14) | ((uint32_t)j << 21);
+}
 SSS_DEV int info_kind(uint32_t i) { return (int)(i & 0xFF); }
-SSS_DEV int info_stage(uint32_t i) { return (int)((i >> 8) & 0xFF); }
-SSS_DEV int info_job(uint32_t i) { return (int)(i >> 16); }
+SSS_DEV int info_stage(uint32_t i) { return (int)((i >> 8) & 0x3F); }
+SSS_DEV uint32_t info_slot(uint32_t i) { return (i >> 14) & 0x7F; }
+SSS_DEV int info_job(uint32_t i) { return (int)(i >> 21); }
+SSS_DEV uint32_t info_with_slot(uint32_t i, uint32_t slot) { return (i & ~(0x7Fu << 14)) | ((slot > 63u ? INFO_SLOT_NONE : slot) << 14); }
 
 SSS_DEV void push_event(int e, double t, int kind, int j, int s) {  // EVQ:34-35
   SssHot& hot = g_hot;
   CHECK((hot.ev[e].info & 0xFF) == EV_NONE);
   SssEvSlot sl;
-  sl.t = t, sl.seq = H.counter++, sl.info = ev_info(kind, j, s);
+  sl.t = t, sl.seq = H.counter++, sl.info = ev_info(kind, j, s, lds_slot_of()[j]);
   hot.ev[e] = sl;
 }
 
@@ -1081,7 +1091,7 @@ SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-
 // carry the counters 0..J-1 and therefore win ties against executor events. One lane per
 // executor, lexicographic min over (time, push counter) on the DPP network - no LDS round trips
 // beyond the one read of the slots. All lanes call it; every lane gets the same result.
-SSS_DEV int pop_event_wave(double next_arrival_t) {
+SSS_DEV int pop_event_wave(double next_arrival_t, double& t_win, uint32_t& info_win) {
   int lane = wave_lane();
   SssEvSlot sl = g_hot.ev[lane];
   double tmin = wave_min_f64_nonneg(sl.t);  // times are >= +0.0; +inf for empty slots
@@ -1094,6 +1104,8 @@ SSS_DEV int pop_event_wave(double next_arrival_t) {
   }
   if (next_arrival_t <= tmin && next_arrival_t < __builtin_inf()) return POP_ARRIVAL;
   if (!(tmin < __builtin_inf())) return POP_EMPTY;
+  t_win = tmin;                                // the winner's time is the minimum itself
+  info_win = wave_readlane_u32(sl.info, ex);   // its event word straight from the winner's register
   return ex;
 }
 
@@ -1219,9 +1231,8 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
 }
 
 // 1 = handled, 0 = not a fast-path event (nothing modified), -1 = failed
-SSS_DEV int fast_task_completion(const FastCtx& f, EvRegs& r, int ex, int j, int s) {
-  int slot = f.slot_of[j];
-  return slot != SLOT_NONE ? fast_body<true>(f, r, ex, j, s, slot) : fast_body<false>(f, r, ex, j, s, slot);
+SSS_DEV int fast_task_completion(const FastCtx& f, EvRegs& r, int ex, int j, int s, uint32_t slot) {
+  return slot != INFO_SLOT_NONE ? fast_body<true>(f, r, ex, j, s, (int)slot) : fast_body<false>(f, r, ex, j, s, SLOT_NONE);
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -1400,6 +1411,11 @@ SSS_DEV void env_begin(const uint8_t* base) {
     else
       ((uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP];
   }
+  // pending events learn the slot their job got for this launch
+  if (lane < g_c.E) {
+    uint32_t info = g_hot.ev[lane].info;
+    if (info_kind(info) != EV_NONE) g_hot.ev[lane].info = info_with_slot(info, lds_slot_of()[info_job(info)]);
+  }
   wave_sync();
 }
 
@@ -1422,6 +1438,11 @@ SSS_DEV void env_end(uint8_t* base) {
       ((uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP];
   }
   for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
+  if (lane < g_c.E) {  // the HBM image of an event does not name an LDS slot
+    uint32_t info = g_hot.ev[lane].info;
+    if (info_kind(info) != EV_NONE) g_hot.ev[lane].info = info_with_slot(info, INFO_SLOT_NONE);
+  }
+  wave_sync();
   {
     const uint4* s = (const uint4*)&g_hot;
     uint4* d = (uint4*)base;
@@ -1535,7 +1556,7 @@ SSS_DEV double jobtime_sum() {
 // _resume_simulation (ENV:320-343). Entered and left with LDS in sync.
 // lane 0: one popped event. Returns 0 = keep going, 1 = queue empty / failed, 2 = a scan is needed
 // (committable executors exist). On a non-zero return the LDS header is current.
-SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, uint64_t& n_fast, uint64_t& t_slow) {
+SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, double t_win, uint32_t info_win, uint64_t& n_fast, uint64_t& t_slow) {
   if (ex == POP_EMPTY) {
     regs_store(r);
     return 1;
@@ -1543,12 +1564,9 @@ SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, uint64_t& n_fast,
   r.n_events++;
   r.events_this_step++;
   int fast = 0;
-  if (ex >= 0) {
-    SssEvSlot sl = g_hot.ev[ex];
-    if (info_kind(sl.info) == EV_TASK_FINISHED) {
-      r.wall_time = sl.t;
-      fast = fast_task_completion(f, r, ex, info_job(sl.info), info_stage(sl.info));
-    }
+  if (ex >= 0 && info_kind(info_win) == EV_TASK_FINISHED) {
+    r.wall_time = t_win;
+    fast = fast_task_completion(f, r, ex, info_job(info_win), info_stage(info_win), info_slot(info_win));
   }
   if (fast > 0) {
     // the source stays what it was - None right after a scheduling round - so nothing is
@@ -1616,12 +1634,14 @@ SSS_DEV void resume_simulation() {
 #ifdef SSS_EVPROF
         uint64_t c0 = wave_clock();
 #endif
-        int ex = pop_event_wave(wave_lane0_f64(r.next_arrival_t));
+        double t_win = 0.0;
+        uint32_t info_win = 0;
+        int ex = pop_event_wave(wave_lane0_f64(r.next_arrival_t), t_win, info_win);
 #ifdef SSS_EVPROF
         uint64_t c1 = wave_clock();
 #endif
         status = 0;
-        if (lane == 0) status = handle_popped(f, r, ex, n_fast, t_slow);
+        if (lane == 0) status = handle_popped(f, r, ex, t_win, info_win, n_fast, t_slow);
 #ifdef SSS_EVPROF
         uint64_t c2 = wave_clock();
         tp_pop += c1 - c0, tp_handle += c2 - c1;
