@@ -1094,7 +1094,8 @@ SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-
 SSS_DEV int pop_event_wave(double next_arrival_t, double& t_win, uint32_t& info_win) {
   int lane = wave_lane();
   SssEvSlot sl = g_hot.ev[lane];
-  double tmin = wave_min_f64_nonneg(sl.t);  // times are >= +0.0; +inf for empty slots
+  // times are >= +0.0; +inf for empty slots and for the lanes beyond the executors
+  double tmin = g_c.E <= 16 ? wave_min_f64_nonneg_row0(sl.t) : wave_min_f64_nonneg(sl.t);
   bool at_min = sl.t == tmin;
   uint64_t cand = wave_ballot(at_min);
   int ex = ctz64(cand);

@@ -76,6 +76,25 @@ SSS_DEV double wave_min_f64_nonneg(double x) {
   return a < c ? a : c;
 }
 
+// the same when only lanes 0..15 can hold anything below +inf (<= 16 executors): the first 16-lane
+// row's minimum is the answer, the cross-row combine is skipped
+SSS_DEV double wave_min_f64_nonneg_row0(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+#define SSS_DPP_MIN_STEP(ctrl)                                                      \
+  {                                                                                 \
+    int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);           \
+    int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);           \
+    double o = __hiloint2double(ohi, olo), c = __hiloint2double(hi, lo);            \
+    if (o < c) lo = olo, hi = ohi;                                                  \
+  }
+  SSS_DPP_MIN_STEP(0xB1)
+  SSS_DPP_MIN_STEP(0x4E)
+  SSS_DPP_MIN_STEP(0x141)
+  SSS_DPP_MIN_STEP(0x140)
+#undef SSS_DPP_MIN_STEP
+  return __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+}
+
 SSS_DEV uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {

@@ -76,6 +76,11 @@ SSS_DEV double wave_min_f64_nonneg(double x) {
   memcpy(&x, &m, 8);
   return x;
 }
+SSS_DEV double wave_min_f64_nonneg_row0(double x) {  // lanes 16..63 must hold +inf (checked)
+  double m = wave_min_f64_nonneg(emu::lane() < 16 ? x : __builtin_inf());
+  if (emu::lane() >= 16 && x != __builtin_inf()) __builtin_trap();
+  return m;
+}
 SSS_DEV uint32_t wave_sum_u32(uint32_t v) {
   emu::collective(emu::OP_SUM32, v);
   uint32_t s = 0;
