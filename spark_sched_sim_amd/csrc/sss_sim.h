@@ -1182,7 +1182,7 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   st.remaining = (int16_t)(st.remaining - 1);
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
   if (st.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);  // stage just became saturated (ENV:595-597)
-  if (demand <= 0) jp->sat_mask |= bit64(s);
+  if (demand <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));  // fire-and-forget: nothing below waits for the old mask
   *sp = st;
   // task_duration, executor mode 1 ("same stage")
   int n_local = popc64(local);
