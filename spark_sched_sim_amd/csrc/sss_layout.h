@@ -15,7 +15,10 @@
 #define SSS_MAX_JOBS 1024     // job ids are 16 bit; job-id set scratch lives in LDS (sss_sim.h)
 #define SSS_JOBSET_SLOTS 2048  // CPython table for <= 1228 distinct small ints
 #define SSS_MAX_LEVELS 16
-#define SSS_SET_TABLE 256     // bytes per pool-set image (max CPython table for <= 64 small ints)
+#define SSS_SET_TABLE 256     // bytes of a set image holding <= 63 small ints at any resize (CPython grows to > 4 * used)
+// bytes per executor-pool image: a pool that holds all 64 executors when its fill (keys + dummies)
+// crosses 3/5 of a 128-slot table is rebuilt into 512 slots (set_table_resize(used * 4 = 256))
+#define sss_pool_table_bytes(E) ((E) >= 64 ? 2 * SSS_SET_TABLE : SSS_SET_TABLE)
 #define SSS_DUR_RING 200      // deque(maxlen=200), reference spark_sched_sim.py:83
 #define SSS_OBS_I32 8
 #define SSS_OBS_F64 2
@@ -234,7 +237,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->off_stages = o, o = sss_align(o + 8 * (int64_t)J_cap * SP, 64);
   L->off_durations = o, o = sss_align(o + 4 * (int64_t)J_cap * SP, 64);
   L->off_pool_hdr = o, o = sss_align(o + 8 * (int64_t)L->n_pools, 64);
-  L->off_pool_tab = o, o += (int64_t)SSS_SET_TABLE * L->n_pools;
+  L->off_pool_tab = o, o += (int64_t)sss_pool_table_bytes(E) * L->n_pools;
   L->off_dur_ring = o, o += 8 * SSS_DUR_RING;
   L->off_old_active = o, o += 2 * (int64_t)J_cap;
   L->env_stride = sss_align(o, 256);

@@ -102,10 +102,21 @@ SSS_DEV void ctx_init(uint8_t* env_base, const SssLayout& L, const SssParams& P,
   do {                             \
     if (H.err == 0) H.err = (code); \
   } while (0)
+#ifdef SSS_CHECK_TRACE  // emulator debugging: say which invariant broke
+#include <stdio.h>
+#define CHECK(cond)                                                                     \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      if (H.err == 0) fprintf(stderr, "[CHECK] line %d: %s\n", __LINE__, #cond);         \
+      FAIL(SSS_ERR_INVARIANT);                                                          \
+    }                                                                                   \
+  } while (0)
+#else
 #define CHECK(cond)                          \
   do {                                       \
     if (!(cond)) FAIL(SSS_ERR_INVARIANT);     \
   } while (0)
+#endif
 
 // ---- LDS pool views ----
 #define SLOT_NONE 255
@@ -499,7 +510,7 @@ SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
   int p = pool_index(key);
   SssPoolHdr hd = g_c.pool_hdr[p];
   SetImg<uint8_t> s;
-  s.tab = g_c.pool_tab + (size_t)p * SSS_SET_TABLE;
+  s.tab = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E);
   s.mask = hd.mask, s.fill = hd.fill, s.used = hd.used, s.finger = 0;
   return s;
 }
@@ -1784,7 +1795,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   for (int p = lane; p < n_pools; p += 64) {
     SssPoolHdr hd = {7, 0, 0, 0};
     g_c.pool_hdr[p] = hd;
-    *(uint64_t*)(g_c.pool_tab + (size_t)p * SSS_SET_TABLE) = 0ull;
+    *(uint64_t*)(g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E)) = 0ull;
   }
   wave_sync();
   if (lane == 0 && !H.err) {

@@ -149,3 +149,29 @@ def test_valid_action_sequence_that_stalls_the_reference(pack):
         raise AssertionError("the sequence did not stall")
     env.close()
     o.close()
+
+
+@pytest.mark.parametrize("seed,steps", [(15883, 60), (15875, 110)])
+def test_sixty_four_executors_pool_set_growth(seed, steps, pack):
+    """num_executors = 64 (one lane per executor: the build's limit). A pool that holds all 64
+    executors while dummies push its fill over 3/5 of 128 slots is rebuilt by CPython into a
+    512-slot table (set_table_resize(used * 4)); the image must have room for it. These seeds hit
+    that within ~20 / ~70 steps under the FIFO policy; kernel and oracle must agree bit for bit."""
+    from golden_util import bits
+    from oracle_binding import OracleEnv
+
+    cfg = dict(num_executors=64, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 1, device="cpu", pack=pack, _lib=load_emu())
+    env.reset(seed=[seed])
+    o = OracleEnv(pack, cfg)
+    o.reset(seed)
+    for t in range(steps):
+        a = env.policy_actions("fifo")
+        s, n = int(a["stage_idx"][0]), int(a["num_exec"][0])
+        _, rew, term, _, info = env.step(a)
+        e, r, done = o.step(s, n)
+        assert int(info["err"][0]) == 0 and e == 0, t
+        assert bits(float(rew[0])) == bits(r) and bits(float(info["wall_time"][0])) == bits(o.info().wall_time), t
+        assert np.array_equal(env.obs_view(0)["dag_batch"].nodes, o.obs()[1]), t
+    env.close()
+    o.close()

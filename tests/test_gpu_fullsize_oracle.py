@@ -41,7 +41,12 @@ def oracle_episodes(pack, cfg, policy_id, seeds, threads=16):
     return [res[s] for s in seeds]
 
 
-@pytest.mark.parametrize("cfg,policy,policy_id,B,max_steps", [(C2, "hash", 1, 4096, 1600), (C3, "fair", 0, 4096, 9000)])
+E64 = dict(num_executors=64, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0)  # the lane limit
+BURST = dict(num_executors=20, job_arrival_cap=120, job_arrival_rate=4.0e-4, moving_delay=500.0, warmup_delay=100.0)  # ~100 jobs active at once
+
+
+@pytest.mark.parametrize("cfg,policy,policy_id,B,max_steps", [(C2, "hash", 1, 4096, 1600), (C3, "fair", 0, 4096, 9000),
+                                                              (E64, "fair", 0, 2048, 9000), (BURST, "fair", 0, 1024, 9000)])
 def test_full_batch_episode_summaries_match_oracle(cfg, policy, policy_id, B, max_steps, pack):
     from spark_sched_sim_amd import VecSparkSchedSimEnv
 
