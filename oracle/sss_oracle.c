@@ -1169,7 +1169,12 @@ static uint64_t splitmix64(uint64_t x) {
 }
 
 int64_t sso_run_episode(sss_oracle *o, uint64_t seed, int policy, int64_t max_steps, double *sum_reward) {
-  if (sso_reset(o, seed, INFINITY)) return -1;
+  return sso_run_episode_tl(o, seed, INFINITY, policy, max_steps, sum_reward);
+}
+
+/* the same with reset(options={"time_limit": ...}) (ENV:127-186: the limit bounds the arrival sequence) */
+int64_t sso_run_episode_tl(sss_oracle *o, uint64_t seed, double time_limit, int policy, int64_t max_steps, double *sum_reward) {
+  if (sso_reset(o, seed, time_limit)) return -1;
   int64_t steps = 0;
   double acc = 0;
   /* the observation is materialised every step, as the reference does (ENV:193,221) */

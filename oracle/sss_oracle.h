@@ -53,6 +53,7 @@ void sso_job_times(const sss_oracle *o, double *t_arrival, double *t_completed, 
 int sso_active_jobs(const sss_oracle *o, int32_t *out);
 int sso_duration_buffer(const sss_oracle *o, double *out);
 int64_t sso_run_episode(sss_oracle *o, uint64_t seed, int policy, int64_t max_steps, double *sum_reward);
+int64_t sso_run_episode_tl(sss_oracle *o, uint64_t seed, double time_limit, int policy, int64_t max_steps, double *sum_reward);
 
 #ifdef __cplusplus
 }

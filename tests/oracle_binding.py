@@ -53,6 +53,8 @@ def load_oracle(variant: str = "") -> C.CDLL:
     lib.sso_step_count.restype = C.c_int64
     lib.sso_run_episode.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.POINTER(C.c_double)]
     lib.sso_run_episode.restype = C.c_int64
+    lib.sso_run_episode_tl.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_int64, C.POINTER(C.c_double)]
+    lib.sso_run_episode_tl.restype = C.c_int64
     _LIBS[variant] = lib
     return lib
 

@@ -19,13 +19,13 @@ C2 = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_
 C3 = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
 
 
-def oracle_episodes(pack, cfg, policy_id, seeds, threads=16):
+def oracle_episodes(pack, cfg, policy_id, seeds, threads=16, time_limit=float("inf")):
     def work(chunk):
         env = OracleEnv(pack, cfg)
         out = []
         for s in chunk:
             r = C.c_double()
-            n = env.lib.sso_run_episode(env.h, int(s), policy_id, 10**9, C.byref(r))  # releases the GIL
+            n = env.lib.sso_run_episode_tl(env.h, int(s), time_limit, policy_id, 10**9, C.byref(r))  # releases the GIL
             info = SsoObsInfo()
             env.lib.sso_obs_sizes(env.h, C.byref(info))
             out.append((int(n), r.value, info.wall_time, info.num_jobs))
