@@ -174,6 +174,15 @@ class VecSparkSchedSimEnv:
         (include/sss.h sss_decima_graph_build) instead of ~150 tensor ops, plus per-edge / per-node
         DAG-layer bits and each schedulable node's `stage_idx`. One device->host sync (totals)."""
         B, dev = self.num_envs, self.device
+        if 16 * self.dims.node_cap > 65536:
+            # the kernel's per-node LDS working set does not fit: same graph from tensor ops on the device
+            from .decima import compact_graph, decima_observation
+            f = decima_observation(self._obs(), self.num_executors, self.dims.stage_stride, int(num_tasks_scale), work_scale)
+            if active is not None:
+                for k in ("node_valid", "job_valid", "edge_valid", "stage_mask"):
+                    f[k] = f[k] & active[:, None]
+                f["n_nodes"], f["depth"] = f["n_nodes"] * active, f["depth"] * active
+            return compact_graph(f)
         cnt = self.obs_i32[:, :3].long()  # n_nodes, n_edges, n_jobs
         act8 = None
         if active is not None:

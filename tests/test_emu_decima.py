@@ -73,3 +73,28 @@ def test_reference_style_decima_episode():
         t += 1
     assert t == len(g["actions"])
     env.close()
+
+
+def test_large_node_capacity_falls_back_to_tensor_op_graph():
+    """job capacity 300 -> 5400 node slots: beyond the graph kernel's LDS working set; the same
+    compact graph then comes from tensor ops and the policy runs its tensor-op forward"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=8, job_arrival_cap=300, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 3, device="cpu", _lib=load_emu())
+    assert 16 * env.dims.node_cap > 65536
+    torch.manual_seed(1)
+    policy = DecimaPolicy(num_executors=8, **AGENT).eval()
+    gen = torch.Generator().manual_seed(2)
+    env.reset(seed=5)
+    for _ in range(25):
+        act, aux = policy.schedule_env(env, generator=gen)
+        obs, r, term, trunc, info = env.step(act)
+        assert not info["err"].any() and torch.isfinite(aux["lgprob"]).all()
+    g = env.decima_graph(active=torch.tensor([True, False, True]))
+    assert "out_start" not in g and int(g["obs_nodes"][1]) == 0 and int(g["obs_nodes"][0]) > 0
+    env.close()
