@@ -102,3 +102,38 @@ def test_graph_kernel_at_c3_sizing_matches_tensor_ops():
                 assert float((hk[k] - h[k]).abs().max()) <= 5e-5, (chunk, k)
     assert int(obs["n_nodes"].max()) > 40
     env.close()
+
+
+@pytest.mark.parametrize("E,J,rate", [(1, 6, 1.0e-4), (2, 12, 1.0e-4), (17, 40, 1.0e-4), (64, 60, 2.0e-4)])
+def test_decima_pipeline_at_executor_count_extremes(E, J, rate):
+    """1, 2, 17 and 64 executors: 64 envs stepped by sampled Decima actions for 150 steps without a
+    rejected action (only the reference's own `[step]` stall may appear), the kernel forward equal
+    to the tensor-op forward, and the one-launch policy kernel consistent with the pipeline's scores"""
+    from decima_util import SCORE_ATOL
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy, compact_graph, decima_observation
+
+    cfg = dict(num_executors=E, job_arrival_cap=J, job_arrival_rate=rate, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 64, device="cuda:0", auto_reset=True)
+    torch.manual_seed(E)
+    policy = DecimaPolicy(num_executors=E, **AGENT).to("cuda:0").eval().bind_kernels(env._b)
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    obs, _ = env.reset(seed=400)
+    for t in range(150):
+        if t % 50 == 10:
+            kg = env.decima_graph()
+            cg = compact_graph(decima_observation(obs, E, env.dims.stage_stride))
+            with torch.no_grad():
+                h, hk = policy.encode(cg), policy._encode_kernels(kg)
+            for k in ("node", "dag", "glob"):
+                assert float((hk[k] - h[k]).abs().max()) <= 5e-5, (t, k)
+            sk = policy._stage_scores_kernels(kg, hk)
+            _, one = policy.act_env(env, counter=t, seed=9, want_scores=True)
+            fin = torch.isfinite(sk)
+            assert torch.equal(torch.isfinite(one["stage_scores"]), fin) and float((one["stage_scores"] - sk)[fin].abs().max()) <= SCORE_ATOL
+        act, aux = policy.schedule_env(env, generator=gen)
+        obs, r, term, trunc, info = env.step(act)
+        live = info["err"] == 0
+        assert bool(((info["err"] == 0) | (info["err"] == 5) | (info["err"] == 8)).all()), torch.unique(info["err"])
+        assert torch.isfinite(aux["lgprob"][live]).all()
+    env.close()
