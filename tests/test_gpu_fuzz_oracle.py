@@ -32,6 +32,9 @@ CASES = [
     ("time_limit_only", dict(num_executors=10, job_arrival_cap=None, max_jobs=400, job_arrival_rate=4.0e-5, moving_delay=2000.0,
                              warmup_delay=1000.0), "fair", 3.0e6),
     ("discounted", _cfg(10, 30, 4.0e-5, beta=5.0e-3), "fair", None),
+    ("thousand_jobs", _cfg(40, 1000, 2.0e-3, md=200.0), "fair", None),   # the build's job-capacity limit
+    ("tiny_time_limit", dict(num_executors=5, job_arrival_cap=None, max_jobs=50, job_arrival_rate=1.0e-4, moving_delay=2000.0,
+                             warmup_delay=1000.0), "fair", 5.0e3),        # mostly single-job episodes
 ]
 
 
@@ -67,4 +70,19 @@ def test_config_sweep_matches_oracle(name, cfg, policy, time_limit, pack):
             assert abs(ret[i] - want[1]) <= 1e-12 * abs(want[1]), (name, i)
         else:
             assert bits(ret[i]) == bits(want[1]), (name, i, ret[i], want[1])
+    env.close()
+
+
+def test_more_arrivals_than_max_jobs_is_reported(pack):
+    """job_arrival_cap=None with a time limit: the arena holds `max_jobs` jobs; an episode whose
+    Poisson sequence is longer fails loudly with code 10 instead of writing past the arena"""
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+
+    cfg = dict(num_executors=5, job_arrival_cap=None, max_jobs=8, job_arrival_rate=1.0e-3, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 32, device="cuda:0", pack=pack)
+    env.reset(seed=1, options={"time_limit": 1.0e5})   # ~100 arrivals expected, 8 fit
+    err = env.obs_i32[:, 7].cpu().numpy()
+    assert (err == 10).all(), np.unique(err)
+    with pytest.raises(ValueError, match="max_jobs"):
+        env.raise_on_error()
     env.close()
