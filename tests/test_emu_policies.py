@@ -175,3 +175,38 @@ def test_sixty_four_executors_pool_set_growth(seed, steps, pack):
         assert np.array_equal(env.obs_view(0)["dag_batch"].nodes, o.obs()[1]), t
     env.close()
     o.close()
+
+
+@pytest.mark.parametrize("name,cfg,policy,pid", [
+    ("one_executor", dict(num_executors=1, job_arrival_cap=4, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0),
+    ("zero_delays", dict(num_executors=6, job_arrival_cap=10, job_arrival_rate=1.0e-4, moving_delay=0.0, warmup_delay=0.0), "hash", 1),
+    ("all_at_once", dict(num_executors=7, job_arrival_cap=12, job_arrival_rate=1.0e-1, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0),
+])
+def test_small_config_sweep_matches_oracle_episodes(name, cfg, policy, pid, pack):
+    """the CPU-suite slice of tests/test_gpu_fuzz_oracle.py: whole episodes of a few unusual
+    configurations under the emulator, episode summaries equal to the oracle's"""
+    import ctypes as C
+
+    from golden_util import bits
+    from oracle_binding import OracleEnv, SsoObsInfo
+
+    B, base = 3, 900
+    env = VecSparkSchedSimEnv(cfg, B, device="cpu", pack=pack, _lib=load_emu())
+    env.reset(seed=base)
+    for _ in range(60):
+        env.rollout(policy, 100)
+        if bool(((env.header_field("terminated") != 0) | (env.obs_i32[:, 7] != 0)).all()):
+            break
+    for i in range(B):
+        o = OracleEnv(pack, cfg)
+        r = C.c_double()
+        n = o.lib.sso_run_episode(o.h, base + i, pid, 10 ** 9, C.byref(r))
+        info = SsoObsInfo()
+        o.lib.sso_obs_sizes(o.h, C.byref(info))
+        if int(env.obs_i32[i, 7]) == 5:
+            assert n == -105, (name, i)
+        else:
+            got = (int(env.header_field("ep_steps")[i]), bits(float(env.header_field("ep_return")[i])), bits(float(env.header_field("wall_time")[i])))
+            assert got == (n, bits(r.value), bits(info.wall_time)), (name, i)
+        o.close()
+    env.close()
