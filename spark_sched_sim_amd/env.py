@@ -45,6 +45,8 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
         self.beta: float = env_cfg.get("beta", 0)
         self.job_arrival_cap = env_cfg.get("job_arrival_cap")
         self.render_mode = None
+        from .spaces import make_action_space
+        self.action_space = make_action_space(self.num_executors)
         self._vec = VecSparkSchedSimEnv(env_cfg, 1, device=device, _lib=_lib)
         self._act_s = torch.zeros(1, dtype=torch.int32, device=self._vec.device)
         self._act_n = torch.ones(1, dtype=torch.int32, device=self._vec.device)
@@ -58,7 +60,7 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
         self._vec.reset(seed=None if seed is None else [seed], options=options)
         self._raise()
         self.job_arrival_cap = self._vec.header(0)["J"]  # reference overwrites it (spark_sched_sim.py:156)
-        return self._vec.obs_view(0), self.info
+        return self._observe(), self.info
 
     def step(self, action: dict):
         if not isinstance(action, dict) or set(action.keys()) != {"stage_idx", "num_exec"}:
@@ -72,7 +74,12 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
         self._raise()
         o = self._vec.obs_i32[0].cpu().numpy()
         reward = self._vec.obs_f64[0, 0].item()
-        return self._vec.obs_view(0), reward, bool(o[6]), False, self.info
+        return self._observe(), reward, bool(o[6]), False, self.info
+
+    def _observe(self) -> dict:
+        obs = self._vec.obs_view(0)
+        self.action_space["stage_idx"].n = len(obs["dag_batch"].nodes) + 1  # spark_sched_sim.py:403-404
+        return obs
 
     def close(self) -> None:
         self._vec.close()

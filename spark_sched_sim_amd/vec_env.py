@@ -82,6 +82,11 @@ class VecSparkSchedSimEnv:
         self._act_stage = torch.zeros(B, dtype=torch.int32, device=dev)
         self._act_nexec = torch.ones(B, dtype=torch.int32, device=dev)
         self._closed = False
+        # gymnasium.vector.VectorEnv attributes; the per-env action space is the reference's at
+        # construction (its stage_idx bound follows each observation: valid range is [-1, n_nodes[i]))
+        from .spaces import make_action_space
+        self.single_action_space = make_action_space(self.num_executors)
+        self.action_space = self.single_action_space
 
     # ---- plumbing ---------------------------------------------------------------------
 

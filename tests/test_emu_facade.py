@@ -61,3 +61,19 @@ def test_invalid_actions_raise_like_the_reference():
         SparkSchedSimEnv(dict(g.cfg, job_arrival_cap=None, max_jobs=16), device="cpu", _lib=load_emu()).reset(seed=0)
     env.close()
     env2.close()
+
+
+def test_action_space_follows_the_observation():
+    """spark_sched_sim.py:85-94, 403-404: Dict(stage_idx: Discrete(n_nodes + 1, start=-1),
+    num_exec: Discrete(E, start=1)); contains() is what step() validates against"""
+    g = Golden("tiny_hash")
+    env = SparkSchedSimEnv(g.cfg, device="cpu", _lib=load_emu())
+    assert env.action_space["stage_idx"].n == 1 and env.action_space["num_exec"].n == g.cfg["num_executors"]
+    obs, _ = env.reset(seed=0)
+    n = len(obs["dag_batch"].nodes)
+    sp = env.action_space
+    assert sp["stage_idx"].n == n + 1 and sp["stage_idx"].start == -1
+    assert sp.contains({"stage_idx": -1, "num_exec": 1}) and sp.contains({"stage_idx": n - 1, "num_exec": g.cfg["num_executors"]})
+    assert not sp.contains({"stage_idx": n, "num_exec": 1}) and not sp.contains({"stage_idx": 0, "num_exec": 0})
+    assert not sp.contains({"stage_idx": 0, "num_exec": 1, "job_idx": 0})
+    env.close()
