@@ -376,7 +376,12 @@ class DecimaPolicy(nn.Module):
         return [dims(m) for m in pol] == [[(53, 64), (64, 64), (64, 1)], [(36, 64), (64, 64), (64, 1)]] and all(acts(m) == [nn.Tanh, nn.Tanh] for m in pol)
 
     def _packed_weights(self) -> dict[str, torch.Tensor]:
-        ver = tuple(p._version for p in self.parameters()) + (str(self.device),)
+        # re-pack when the parameters moved: optimiser steps bump every parameter's version together, so
+        # the first and the last one stand for all (update_parameters / load_state_dict also invalidate)
+        ps = getattr(self, "_plist", None)
+        if ps is None:
+            ps = self._plist = list(self.parameters())
+        ver = (ps[0]._version, ps[-1]._version, ps[0].device)
         if getattr(self, "_packed", None) is None or self._packed[0] != ver:
             def pack(mlp):  # [W1, b1, W2^T, b2, W3, b3] (include/sss.h sss_gnn_launch)
                 lin = [m for m in mlp if isinstance(m, nn.Linear)]
@@ -389,6 +394,20 @@ class DecimaPolicy(nn.Module):
             slope = float(enc.node_encoder.mlp_prep[1].negative_slope)
             self._packed = (ver, w, slope)
         return self._packed[1]
+
+    def invalidate_kernel_weights(self) -> None:
+        """call after changing parameters by other means than `update_parameters` / `load_state_dict`"""
+        self._packed = None
+        self._plist = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): new parameter tensors
+        self._packed = None
+        self._plist = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, **ptrs) -> None:
         import ctypes
@@ -416,7 +435,8 @@ class DecimaPolicy(nn.Module):
 
     @torch.no_grad()
     def _encode_kernels(self, g: dict[str, Any]) -> dict[str, torch.Tensor]:
-        """`encode(g, per_obs_skip=True)` on the fused kernels"""
+        """`encode(g, per_obs_skip=True)` on the fused kernels. Re-packs the parameters if they changed
+        since the last call (the other kernel stages of the same `act` reuse that packing)."""
         w = self._packed_weights()
         x = g["x"]
         dev = x.device
@@ -446,7 +466,7 @@ class DecimaPolicy(nn.Module):
         """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
         M = g["x"].shape[0]
         out = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
-        self._launch("stage", M, self._packed_weights()["stage"], n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"],
+        self._launch("stage", M, self._packed[1]["stage"], n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"],
                      out=out, idx0=self._index_list(g["stage_mask"]), node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
         return out
 
@@ -475,7 +495,7 @@ class DecimaPolicy(nn.Module):
                                 out["exec_sel"].data_ptr(), out["lgprob"].data_ptr(), out["any_stage"].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
-        self._launch("exec", B * E, self._packed_weights()["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
+        self._launch("exec", B * E, self._packed[1]["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
                      idx0=job_gid, job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
         self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
         out["env_stage_idx"], out["env_num_exec"] = stage_idx, num_exec
@@ -488,7 +508,7 @@ class DecimaPolicy(nn.Module):
     def _exec_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
         k, E = job_gid.numel(), self.num_executors
         out = torch.empty((k, E), dtype=torch.float32, device=job_gid.device)
-        self._launch("exec", k * E, self._packed_weights()["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=out,
+        self._launch("exec", k * E, self._packed[1]["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=out,
                      idx0=job_gid.contiguous(), job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
         return out
 
@@ -614,7 +634,7 @@ class DecimaPolicy(nn.Module):
         if one_launch:
             self._calls = getattr(self, "_calls", 0) + 1
             return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
-        a = self.act(env.decima_graph(active), generator)
+        a = self.act(env.decima_graph(active, reuse_buffers=True), generator)
         return self.env_actions(a), a
 
     @torch.no_grad()
@@ -658,6 +678,7 @@ class DecimaPolicy(nn.Module):
             torch.nn.utils.clip_grad_norm_(self.parameters(), self.max_grad_norm, error_if_nonfinite=True)
         self.optim.step()
         self.optim.zero_grad()
+        self._packed = None  # the inference kernels re-pack the parameters on their next use
 
 
 # ---- the reference's single-env plugin surface ---------------------------------------------------

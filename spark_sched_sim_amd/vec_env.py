@@ -82,6 +82,7 @@ class VecSparkSchedSimEnv:
         self._act_stage = torch.zeros(B, dtype=torch.int32, device=dev)
         self._act_nexec = torch.ones(B, dtype=torch.int32, device=dev)
         self._closed = False
+        self._dg_pool: dict[int, torch.Tensor] = {}
         # gymnasium.vector.VectorEnv attributes; the per-env action space is the reference's at
         # construction (its stage_idx bound follows each observation: valid range is [-1, n_nodes[i]))
         from .spaces import make_action_space
@@ -173,11 +174,15 @@ class VecSparkSchedSimEnv:
         self._b.check(self._b.lib.sss_rollout(self._h, POLICY_IDS[policy], int(param), int(n_steps), int(self.auto_reset),
                                               self.seed_stride, self._stream()))
 
-    def decima_graph(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5) -> dict[str, Any]:
+    def decima_graph(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5,
+                     reuse_buffers: bool = False) -> dict[str, Any]:
         """the current observations of all envs (or of those with `active[b]` True) as Decima's
         compact graph - `decima.compact_graph(decima.decima_observation(obs))` produced by ONE kernel
         (include/sss.h sss_decima_graph_build) instead of ~150 tensor ops, plus per-edge / per-node
-        DAG-layer bits and each schedulable node's `stage_idx`. One device->host sync (totals)."""
+        DAG-layer bits and each schedulable node's `stage_idx`. One device->host sync (totals).
+        `reuse_buffers`: write into buffers kept by the env (views into them are returned and are
+        overwritten by the next such call) - for act-and-forget inference loops; graphs that are
+        kept (rollout recording) must use the default."""
         B, dev = self.num_envs, self.device
         if 16 * self.dims.node_cap > 65536:
             # the kernel's per-node LDS working set does not fit: same graph from tensor ops on the device
@@ -197,7 +202,17 @@ class VecSparkSchedSimEnv:
         off = (torch.cumsum(cnt_t, 1) - cnt_t).contiguous()
         M, Ed, J = (int(v) for v in cnt_t.sum(1).tolist())
         # buffers hold at least one element so that their pointers are never NULL; `g` gets exact views
-        mk = lambda n, dt, *tail: torch.empty((max(n, 1), *tail), dtype=dt, device=dev)  # noqa: E731
+        pool = self._dg_pool if reuse_buffers else None
+
+        def mk(n, dt, *tail, _c=[0]):
+            if pool is None:
+                return torch.empty((max(n, 1), *tail), dtype=dt, device=dev)
+            k = _c[0]
+            _c[0] += 1
+            t = pool.get(k)
+            if t is None or t.shape[0] < max(n, 1) or t.dtype != dt:
+                t = pool[k] = torch.empty((max(2 * n, 1024), *tail), dtype=dt, device=dev)  # grows geometrically
+            return t[: max(n, 1)]
         buf = {"x": mk(M, torch.float32, 5), "node_obs": mk(M, torch.int64), "node_loc": mk(M, torch.int64), "node_job": mk(M, torch.int64),
                "sched_rank": mk(M, torch.int64), "gen": mk(M, torch.int32), "node_recv": mk(M, torch.int32), "stage_mask": mk(M, torch.bool),
                "src": mk(Ed, torch.int64), "dst": mk(Ed, torch.int64), "edge_obs": mk(Ed, torch.int64), "edge_layers": mk(Ed, torch.int32),
