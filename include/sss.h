@@ -252,6 +252,7 @@ typedef struct sss_decima_policy_args {
   float* lgprob_dev;
   float* stage_scores_dev; /* nullable */
   float* exec_scores_dev;  /* nullable */
+  uint64_t* prof_dev;      /* nullable: u64[num_envs][8] shader cycles per phase + depth + node count */
 } sss_decima_policy_args;
 int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* a, void* stream);
 

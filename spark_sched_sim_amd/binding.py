@@ -56,7 +56,7 @@ class SssDecimaPolicyArgs(C.Structure):
                 ("w_glob_dev", C.c_void_p), ("w_stage_dev", C.c_void_p), ("w_exec_dev", C.c_void_p), ("node_scratch_dev", C.c_void_p),
                 ("job_scratch_dev", C.c_void_p), ("rng_seed", C.c_uint64), ("rng_counter", C.c_uint64), ("stage_idx_dev", C.c_void_p),
                 ("num_exec_dev", C.c_void_p), ("stage_sel_dev", C.c_void_p), ("job_idx_dev", C.c_void_p), ("exec_sel_dev", C.c_void_p),
-                ("lgprob_dev", C.c_void_p), ("stage_scores_dev", C.c_void_p), ("exec_scores_dev", C.c_void_p)]
+                ("lgprob_dev", C.c_void_p), ("stage_scores_dev", C.c_void_p), ("exec_scores_dev", C.c_void_p), ("prof_dev", C.c_void_p)]
 
 
 class SssDecimaSampleArgs(C.Structure):

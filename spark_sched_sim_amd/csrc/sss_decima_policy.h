@@ -9,14 +9,18 @@
 // schedulable stages, executor counts); phases are separated by wave_sync. Per-node vectors
 // (features, h_init, h, scratch) live in a per-env slab of global memory that stays in L2; the DAG
 // analysis (generations, layer membership bits, out-edge ranges, node->job) lives in LDS,
-// 18 bytes per node slot. The MLPs are the row functions of sss_gnn.h; their parameters are read
-// straight from the argument buffers (wave-uniform addresses).
+// 18 bytes per node slot. The MLPs are the row functions of sss_gnn.h. The gfx950 build packs up to
+// four envs (wavefronts) into one workgroup that first stages all seven MLPs' parameters (83 KB)
+// in LDS - one workgroup per CU, every weight read a broadcast LDS read; phases of one env are
+// separated by wavefront-local fences, never by workgroup barriers (envs differ in depth).
 //
 // Sampling: Gumbel-max with a counter-based uniform stream keyed by (seed, counter, env, candidate)
 // - the reference samples with Python's unseeded `random.choices` (utils.py:19-23), i.e. any exact
 // softmax sampler is faithful; this one needs no prefix sums and is reproducible.
 #pragma once
 
+enum { DP_W_PREP = 0, DP_W_MSG = 992, DP_W_UPD = 2336, DP_W_DAG = 3680, DP_W_GLOB = 5184, DP_W_STAGE = 6528, DP_W_EXEC = 14212,
+       DP_W_TOTAL = 20808 };  // float offsets of the packed MLPs inside the staged block (sizes: gnn_mlp_params, 16-byte aligned starts)
 enum { DP_X = 0, DP_HINIT = 5, DP_H = 21, DP_TMP = 37, DP_NODE_FLOATS = 53, DP_JOB_FLOATS = 32 };
 
 struct SssDecimaPolicyArgs {
@@ -31,6 +35,7 @@ struct SssDecimaPolicyArgs {
   float* lgprob;
   float* stage_scores;  // nullable: f32[B][n_cap], -inf where not schedulable
   float* exec_scores;   // nullable: f32[B][E], -inf where not allowed
+  uint64_t* prof;       // nullable: u64[B][8] shader cycles per phase (analysis, prep, layers, summaries, stage, exec)
 };
 
 SSS_SHARED_DYN(g_dp_lds);
@@ -59,9 +64,9 @@ SSS_DEV float dp_gumbel(uint64_t seed, uint64_t counter, int env, uint32_t idx, 
   return -logf(-logf(u));
 }
 
-SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaPolicyArgs& d, int env) {
+SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaPolicyArgs& d, int env, uint8_t* lds) {
   constexpr int F = GNN_EMB;
-  int lane = wave_lane();
+  int lane = wave_lane() & 63;  // several envs (wavefronts) may share a workgroup
   const int32_t* oi = B.obs_i32 + (size_t)env * SSS_OBS_I32;
   bool on = d.active == nullptr || d.active[env] != 0;
   int n = on ? oi[OBS_N_NODES] : 0, ne = on ? oi[OBS_N_EDGES] : 0, A = on ? oi[OBS_N_JOBS] : 0;
@@ -78,17 +83,19 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
   const int32_t* sup = B.exec_supplies + (size_t)env * L.J_cap;
   float* NS = d.node_scratch + (size_t)env * L.n_cap * DP_NODE_FLOATS;
   float* JS = d.job_scratch + (size_t)env * L.J_cap * DP_JOB_FLOATS;
-  int32_t* gen = (int32_t*)g_dp_lds;
-  uint32_t* memb = (uint32_t*)(g_dp_lds + (size_t)4 * L.n_cap);
-  uint32_t* recv = (uint32_t*)(g_dp_lds + (size_t)8 * L.n_cap);
-  uint16_t* ostart = (uint16_t*)(g_dp_lds + (size_t)12 * L.n_cap);
-  uint16_t* oend = (uint16_t*)(g_dp_lds + (size_t)14 * L.n_cap);
-  uint16_t* njob = (uint16_t*)(g_dp_lds + (size_t)16 * L.n_cap);
-  float* hglob = (float*)(g_dp_lds + (size_t)18 * L.n_cap);  // 16 floats (+ pad)
+  int32_t* gen = (int32_t*)lds;
+  uint32_t* memb = (uint32_t*)(lds + (size_t)4 * L.n_cap);
+  uint32_t* recv = (uint32_t*)(lds + (size_t)8 * L.n_cap);
+  uint16_t* ostart = (uint16_t*)(lds + (size_t)12 * L.n_cap);
+  uint16_t* oend = (uint16_t*)(lds + (size_t)14 * L.n_cap);
+  uint16_t* njob = (uint16_t*)(lds + (size_t)16 * L.n_cap);
+  uint16_t* list = (uint16_t*)(lds + (size_t)18 * L.n_cap);  // compacted row ids of the current phase
+  float* hglob = (float*)(lds + (size_t)20 * L.n_cap);    // 16 floats (L.n_cap is even)
 
+  uint64_t pc0 = wave_clock();
   // ---- DAG analysis (as in sss_decima_graph_kernel) -------------------------------------------
   for (int i = lane; i < n; i += 64) gen[i] = 0, recv[i] = 0, ostart[i] = 0, oend[i] = 0;
-  wave_sync();
+  wave_sync_local();
   for (int it = 0; it <= n; it++) {
     bool moved = false;
     for (int e = lane; e < ne; e += 64) {
@@ -96,7 +103,7 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
       int gu = gen[u] + 1;
       if (gen[v] < gu) lane_atomic_max_i32(&gen[v], gu), moved = true;
     }
-    wave_sync();
+    wave_sync_local();
     if (!wave_ballot(moved)) break;
   }
   uint32_t depth = 0;
@@ -111,17 +118,18 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
     njob[i] = (uint16_t)lo;
   }
   depth = ~wave_min_u32(~depth);
-  wave_sync();
+  wave_sync_local();
   for (int e = lane; e < ne; e += 64) lane_atomic_or_u32(&memb[el[2 * e + 1]], 1u << gen[el[2 * e]]);
-  wave_sync();
+  wave_sync_local();
   for (int e = lane; e < ne; e += 64) {
     int u = el[2 * e], v = el[2 * e + 1];
     lane_atomic_or_u32(&recv[u], memb[u] & memb[v]);
     if (e == 0 || el[2 * (e - 1)] != u) ostart[u] = (uint16_t)e;
     if (e == ne - 1 || el[2 * (e + 1)] != u) oend[u] = (uint16_t)(e + 1);
   }
-  wave_sync();
+  wave_sync_local();
 
+  uint64_t pc1 = wave_clock();
   // ---- node features, h_init, starting h (scheduler.py:200-209) ----------------------------------
   for (int i = lane; i < n; i += 64) {
     int a = njob[i];
@@ -151,12 +159,25 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
       gnn_out<F, 32, 16, F>(d.w_upd, h2, 1.0f, [&](int o, float v) { row[DP_H + o] = v; });
     }
   }
-  wave_sync();
+  wave_sync_local();
 
+  uint64_t pc2 = wave_clock();
   // ---- message passing, deepest DAG layer first (scheduler.py:211-236) ---------------------------
+  uint64_t lt = bit64(lane) - 1;
   for (int l = (int)depth - 1; l >= 0; l--) {
-    for (int i = lane; i < n; i += 64) {
-      if (!((recv[i] >> l) & 1u)) continue;
+    // the layer's receiving nodes, compacted: the heavy body then runs on full lanes instead of once
+    // per 64-node round that happens to contain a receiver
+    int cnt = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      int i = i0 + lane;
+      bool on = i < n && ((recv[i] >> l) & 1u);
+      uint64_t bal = wave_ballot(on);
+      if (on) list[cnt + popc64(bal & lt)] = (uint16_t)i;
+      cnt += popc64(bal);
+    }
+    wave_sync_local();
+    for (int k = lane; k < cnt; k += 64) {
+      int i = list[k];
       float acc[16], x[F], h2[16];
       GNN_UNROLL for (int k = 0; k < 16; k++) acc[k] = 0.0f;
       int used = 0;
@@ -183,15 +204,15 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
       float* row = NS + (size_t)i * DP_NODE_FLOATS;
       gnn_out<F, 32, 16, F>(d.w_upd, h2, 1.0f, [&](int o, float v) { row[DP_TMP + o] = row[DP_HINIT + o] + v; });
     }
-    wave_sync();
-    for (int i = lane; i < n; i += 64) {
-      if (!((recv[i] >> l) & 1u)) continue;
-      float* row = NS + (size_t)i * DP_NODE_FLOATS;
+    wave_sync_local();
+    for (int k = lane; k < cnt; k += 64) {
+      float* row = NS + (size_t)list[k] * DP_NODE_FLOATS;
       for (int o = 0; o < F; o++) row[DP_H + o] = row[DP_TMP + o];
     }
-    wave_sync();
+    wave_sync_local();
   }
 
+  uint64_t pc3 = wave_clock();
   // ---- job summaries and the global summary (scheduler.py:246-283) -------------------------------
   for (int i = lane; i < n; i += 64) {
     float* row = NS + (size_t)i * DP_NODE_FLOATS;
@@ -201,7 +222,7 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
     gnn_hidden<GNN_NF + F, 32, 16, 0>(d.w_dag, x, h2, d.slope);
     GNN_UNROLL for (int k = 0; k < 16; k++) row[DP_TMP + k] = h2[k];
   }
-  wave_sync();
+  wave_sync_local();
   for (int a = lane; a < A; a += 64) {
     float acc[16], x[F], h2[16];
     GNN_UNROLL for (int k = 0; k < 16; k++) acc[k] = 0.0f;
@@ -216,7 +237,7 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
     gnn_hidden<F, 32, 16, 0>(d.w_glob, x, h2, d.slope);
     GNN_UNROLL for (int k = 0; k < 16; k++) jr[16 + k] = h2[k];
   }
-  wave_sync();
+  wave_sync_local();
   {
     float acc[16];
     GNN_UNROLL for (int k = 0; k < 16; k++) acc[k] = 0.0f;
@@ -226,21 +247,32 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
     }
     gnn_out<F, 32, 16, F>(d.w_glob, acc, (float)A, [&](int o, float v) { if (lane == 0) hglob[o] = v; });
   }
-  wave_sync();
+  wave_sync_local();
 
+  uint64_t pc4 = wave_clock();
   // ---- stage scores + first draw (scheduler.py:80-84, 296-318) -----------------------------------
   float best_key = -__builtin_inff(), best_score = 0.0f, m_run = -__builtin_inff(), s_run = 0.0f;
   uint32_t best_i = 0x7FFFFFFFu;
-  for (int i = lane; i < n; i += 64) {
-    bool sched = nodes[3 * i + 2] != 0.0f;
-    float sc = -__builtin_inff();
-    if (sched) {
+  int n_sched = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    int i = i0 + lane;
+    bool on = i < n && nodes[3 * i + 2] != 0.0f;
+    uint64_t bal = wave_ballot(on);
+    if (on) list[n_sched + popc64(bal & (bit64(lane) - 1))] = (uint16_t)i;
+    n_sched += popc64(bal);
+    if (d.stage_scores && i < n && !on) d.stage_scores[(size_t)env * L.n_cap + i] = -__builtin_inff();
+  }
+  wave_sync_local();
+  for (int k = lane; k < n_sched; k += 64) {
+    int i = list[k];
+    float sc;
+    {
       const float* row = NS + (size_t)i * DP_NODE_FLOATS;
       float x[GNN_NF + 3 * F], h2[64];
       gnn_load<GNN_NF>(row + DP_X, x);
       gnn_load<F>(row + DP_H, x + GNN_NF);
       gnn_load<F>(JS + (size_t)njob[i] * DP_JOB_FLOATS, x + GNN_NF + F);
-      GNN_UNROLL for (int k = 0; k < F; k++) x[GNN_NF + 2 * F + k] = hglob[k];
+      GNN_UNROLL for (int q = 0; q < F; q++) x[GNN_NF + 2 * F + q] = hglob[q];
       gnn_hidden<GNN_NF + 3 * F, 64, 64, 1>(d.w_stage, x, h2, 0.0f);
       gnn_out<GNN_NF + 3 * F, 64, 64, 1>(d.w_stage, h2, 1.0f, [&](int, float v) { sc = v; });
       float key = sc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)i, 0);
@@ -271,6 +303,7 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
   for (int i = lane; i < (int)sel; i += 64) rank += nodes[3 * i + 2] != 0.0f;
   rank = wave_sum_u32(rank);
 
+  uint64_t pc5 = wave_clock();
   // ---- executor-count scores of the chosen stage's job + second draw (scheduler.py:90-91, 337-385)
   int a_sel = njob[sel];
   int cap;
@@ -310,11 +343,16 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
     d.stage_idx[env] = (int32_t)rank, d.num_exec[env] = (int32_t)csel + 1;
     d.stage_sel[env] = (int32_t)rank, d.job_idx[env] = a_sel, d.exec_sel[env] = (int32_t)csel;
     d.lgprob[env] = lg_stage + (any_exec ? esel - EM - logf(ES) : 0.0f);
+    if (d.prof) {
+      uint64_t pc6 = wave_clock();
+      uint64_t* pr = d.prof + (size_t)env * 8;
+      pr[0] = pc1 - pc0, pr[1] = pc2 - pc1, pr[2] = pc3 - pc2, pr[3] = pc4 - pc3, pr[4] = pc5 - pc4, pr[5] = pc6 - pc5, pr[6] = depth, pr[7] = (uint64_t)n;
+    }
   }
 }
 
 SSS_KERNEL void sss_decima_policy_kernel(SssLayout L, SssBuffers B, int E, SssDecimaPolicyArgs d) {
-  decima_policy_wave(L, B, E, d, wave_env());
+  decima_policy_wave(L, B, E, d, wave_env(), g_dp_lds);
 }
 
 // ---- the two softmax draws of DecimaScheduler.schedule for the row-parallel pipeline ------------

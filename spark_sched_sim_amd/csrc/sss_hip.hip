@@ -52,8 +52,38 @@ static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void
   return (int)hipGetLastError();
 }
 
+// up to four envs per workgroup behind one staged copy of the parameters (sss_decima_policy.h)
+extern "C" __global__ __launch_bounds__(256) void sss_decima_policy_mw_kernel(SssLayout L, SssBuffers B, int E, SssDecimaPolicyArgs d,
+                                                                              int envs_per_wg, int lds_per_env) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dp_lds[];
+  float* wl = (float*)dp_lds;
+  const float* src[7] = {d.w_prep, d.w_msg, d.w_upd, d.w_dag, d.w_glob, d.w_stage, d.w_exec};
+  const int off[7] = {DP_W_PREP, DP_W_MSG, DP_W_UPD, DP_W_DAG, DP_W_GLOB, DP_W_STAGE, DP_W_EXEC};
+  const int len[7] = {992, 1344, 1344, 1504, 1344, 7681, 6593};  // gnn_mlp_params of the seven MLPs
+  for (int m = 0; m < 7; m++)
+    for (int i = threadIdx.x; i < len[m]; i += blockDim.x) wl[off[m] + i] = src[m][i];
+  __syncthreads();
+  int wave = threadIdx.x >> 6;
+  int env = blockIdx.x * envs_per_wg + wave;
+  if (env >= L.num_envs) return;
+  d.w_prep = wl + DP_W_PREP, d.w_msg = wl + DP_W_MSG, d.w_upd = wl + DP_W_UPD, d.w_dag = wl + DP_W_DAG, d.w_glob = wl + DP_W_GLOB;
+  d.w_stage = wl + DP_W_STAGE, d.w_exec = wl + DP_W_EXEC;
+  decima_policy_wave(L, B, E, d, env, dp_lds + ((DP_W_TOTAL * 4 + 63) & ~63) + (size_t)wave * lds_per_env);
+}
+
 static int be_launch_decima_policy(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaPolicyArgs& d, void* stream) {
-  hipLaunchKernelGGL(sss_decima_policy_kernel, dim3(L.num_envs), dim3(64), (size_t)18 * L.n_cap + 64, (hipStream_t)stream, L, B, E, d);
+  const int w_bytes = (DP_W_TOTAL * 4 + 63) & ~63;
+  const int per_env = (20 * L.n_cap + 64 + 63) & ~63;
+  int k = (160 * 1024 - w_bytes) / per_env;
+  if (k < 1) return -1;
+  if (k > 4) k = 4;
+  size_t lds = (size_t)w_bytes + (size_t)k * per_env;
+  static size_t granted = 0;
+  if (lds > granted) {  // more than the default 64 KB of dynamic LDS has to be asked for
+    if (hipFuncSetAttribute((const void*)sss_decima_policy_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    granted = lds;
+  }
+  hipLaunchKernelGGL(sss_decima_policy_mw_kernel, dim3((L.num_envs + k - 1) / k), dim3(64 * k), lds, (hipStream_t)stream, L, B, E, d, k, per_env);
   return (int)hipGetLastError();
 }
 

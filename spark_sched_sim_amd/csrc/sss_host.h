@@ -296,14 +296,15 @@ extern "C" int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* g,
       !g->node_scratch_dev || !g->job_scratch_dev || !g->stage_idx_dev || !g->num_exec_dev || !g->stage_sel_dev || !g->job_idx_dev ||
       !g->exec_sel_dev || !g->lgprob_dev)
     return sss_fail(-1, "NULL argument");
-  if ((int64_t)18 * h->L.n_cap + 64 > 65536 || h->L.n_cap > 65535) return sss_fail(-25, "node capacity too large for the Decima policy kernel's LDS working set");
+  if ((int64_t)20 * h->L.n_cap + 64 > 65536 || h->L.n_cap > 65535) return sss_fail(-25, "node capacity too large for the Decima policy kernel's LDS working set");
+  if (h->cfg.num_executors > 64) return sss_fail(-28, "num_executors must be <= 64");
   SssDecimaPolicyArgs d;
   d.active = g->active_dev, d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale, d.slope = g->slope;
   d.w_prep = g->w_prep_dev, d.w_msg = g->w_msg_dev, d.w_upd = g->w_upd_dev, d.w_dag = g->w_dag_dev, d.w_glob = g->w_glob_dev;
   d.w_stage = g->w_stage_dev, d.w_exec = g->w_exec_dev, d.node_scratch = g->node_scratch_dev, d.job_scratch = g->job_scratch_dev;
   d.rng_seed = g->rng_seed, d.rng_counter = g->rng_counter, d.stage_idx = g->stage_idx_dev, d.num_exec = g->num_exec_dev;
   d.stage_sel = g->stage_sel_dev, d.job_idx = g->job_idx_dev, d.exec_sel = g->exec_sel_dev, d.lgprob = g->lgprob_dev;
-  d.stage_scores = g->stage_scores_dev, d.exec_scores = g->exec_scores_dev;
+  d.stage_scores = g->stage_scores_dev, d.exec_scores = g->exec_scores_dev, d.prof = g->prof_dev;
   if (int rc = be_launch_decima_policy(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima policy launch failed: ") + be_error(rc));
   return 0;
 }

@@ -20,6 +20,14 @@ SSS_DEV int wave_env() { return (int)blockIdx.x; }
 // workgroup == one wave: s_barrier is free, what matters is the LDS/global fence
 SSS_DEV void wave_sync() { __syncthreads(); }
 
+// ordering point inside ONE wavefront of a larger workgroup: earlier LDS / global writes of any lane
+// are visible to every lane afterwards; no workgroup barrier (other wavefronts are not involved)
+SSS_DEV void wave_sync_local() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 SSS_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
 
 // value of lane 0 on every lane (v_readfirstlane: no LDS round trip); all lanes must be active

@@ -571,7 +571,8 @@ class DecimaPolicy(nn.Module):
         return {"stage_sel": stage_sel, "job_idx": job_slot, "exec_sel": k, "lgprob": lg, "any_stage": any_stage}
 
     @torch.no_grad()
-    def act_env(self, env, counter: int, seed: int = 0, active: torch.Tensor | None = None, want_scores: bool = False):
+    def act_env(self, env, counter: int, seed: int = 0, active: torch.Tensor | None = None, want_scores: bool = False,
+                want_prof: bool = False):
         """Decima's decision for every env of a `VecSparkSchedSimEnv` in ONE kernel launch
         (include/sss.h sss_decima_policy): transform, GNN, scores and both draws per env inside one
         wavefront, no intermediate graph, no host sync. Slower than the row-parallel pipeline at large
@@ -605,7 +606,11 @@ class DecimaPolicy(nn.Module):
                                 w["stage"].data_ptr(), w["exec"].data_ptr(), ws["node"].data_ptr(), ws["job"].data_ptr(),
                                 int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1), ws["stage_idx"].data_ptr(), ws["num_exec"].data_ptr(),
                                 ws["stage_sel"].data_ptr(), ws["job_idx"].data_ptr(), ws["exec_sel"].data_ptr(), ws["lgprob"].data_ptr(),
-                                out["stage_scores"].data_ptr() if want_scores else None, out["exec_scores"].data_ptr() if want_scores else None)
+                                out["stage_scores"].data_ptr() if want_scores else None, out["exec_scores"].data_ptr() if want_scores else None,
+                                None)
+        if want_prof:  # shader cycles per phase: analysis, prep, layers, summaries, stage, exec; then depth, nodes
+            out["prof"] = torch.zeros((B, 8), dtype=torch.int64, device=dev)
+            a.prof_dev = out["prof"].data_ptr()
         self._kb.check(self._kb.lib.sss_decima_policy(env._h, ctypes.byref(a), env._stream()))
         out.update(stage_sel=ws["stage_sel"].long(), job_idx=ws["job_idx"].long(), exec_sel=ws["exec_sel"].long(), lgprob=ws["lgprob"],
                    any_stage=ws["stage_idx"] >= 0)

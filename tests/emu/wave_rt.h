@@ -33,6 +33,7 @@ uint64_t slot(int lane);
 SSS_DEV int wave_lane() { return emu::lane(); }
 SSS_DEV int wave_env() { return emu::env(); }
 SSS_DEV void wave_sync() { emu::collective(emu::OP_SYNC, 0); }
+SSS_DEV void wave_sync_local() { emu::collective(emu::OP_SYNC, 0); }
 SSS_DEV uint64_t wave_ballot(bool p) {
   emu::collective(emu::OP_BALLOT, p ? 1 : 0);
   uint64_t m = 0;
