@@ -631,8 +631,8 @@ class DecimaPolicy(nn.Module):
         graph kernel + the row-parallel GNN kernels + `act` (rows of ALL envs share every launch, so
         the lanes stay full). `one_launch=True` uses the per-env policy kernel (`act_env`; its draw
         counter advances on every call, `generator` only supplies the seed): no host sync and one
-        launch, but each env's phases run serially inside one wavefront with few active lanes - on
-        one MI355X it is ~6x slower at 4096 envs (profiles/r01_decima.md).
+        launch, but each env's phases run serially inside one wavefront - on one MI355X it ties the
+        pipeline up to ~1024 envs and is 2x slower at 4096 (profiles/r01_decima.md).
         Returns (actions for `env.step`, the `act` dict)."""
         if getattr(self, "_kb", None) is None:
             self.bind_kernels(env._b)
