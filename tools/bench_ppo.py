@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--jobs", type=int, default=200)
     ap.add_argument("--mean-time-limit", type=float, default=2.0e7)
     ap.add_argument("--rollout-duration", type=float, default=0.0)
+    ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--device-index", type=int, default=None)
     a = ap.parse_args()
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=a.sequences, num_rollouts=a.rollouts, seed=42,
                  checkpointing_freq=10 ** 9, num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04,
@@ -35,7 +37,14 @@ def main():
         train["rollout_duration"] = a.rollout_duration
     env = dict(num_executors=a.executors, job_arrival_cap=a.jobs, job_arrival_rate=4.0e-5, moving_delay=2000.0,
                warmup_delay=1000.0, mean_time_limit=a.mean_time_limit)  # config/decima_tpch.yaml:80-86
-    tr = Trainer(AGENT, env, train, device="cuda:0")
+    import os
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    dev = f"cuda:{local if a.device_index is None else a.device_index}"
+    torch.cuda.set_device(dev)
+    if world > 1:  # BASELINE config 5: `torch.distributed.run --nproc-per-node 8 tools/bench_ppo.py --sequences 256 --rollouts 4`
+        import torch.distributed as dist
+        dist.init_process_group(a.dist_backend)
+    tr = Trainer(AGENT, env, train, device=dev)
     out = []
     for it in range(a.iterations):
         torch.cuda.synchronize()
@@ -49,10 +58,14 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         n = int(ro.active.sum())
-        out.append({"iteration": it, "envs": a.sequences * a.rollouts, "samples": n, "longest_rollout": int(ro.active.shape[0]),
+        out.append({"iteration": it, "n_gpus": world, "envs_per_gpu": a.sequences * a.rollouts, "envs": a.sequences * a.rollouts, "samples": n, "longest_rollout": int(ro.active.shape[0]),
                     "collect_s": t1 - t0, "train_s": t2 - t1, "collect_env_steps_per_s": n / (t1 - t0),
                     "graph_nodes": int(ro.graph["x"].shape[0]), **learn})
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
