@@ -1838,12 +1838,10 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
           commit_remaining_executors();
           fulfill_commitments_from_source();
           H.curr_source = POOL_NONE;
-          for (int a = 0; a < H.n_active; a++) (*jobp(lds_active()[a])).selected_mask = 0;
           g_sc.wall_old = H.wall_time;
           g_sc.n_old_active = H.n_active;
-          for (int a = 0; a < H.n_active; a++) lds_old_active()[a] = lds_active()[a];
           g_sc.old_version = g_sc.active_version;
-          g_sc.f_round_continues = 0;
+          g_sc.f_round_continues = 0;  // selected_stages.clear() and the old-active snapshot follow, lanes over jobs
         }
       }
       if (H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
@@ -1855,6 +1853,12 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   if (lane == 0) H.prof[1] += t1 - t0;
 #endif
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
+  for (int a = lane; a < g_hot.h.n_active; a += 64) {  // ENV:203 selected_stages.clear(); active jobs at the round's end
+    int j = lds_active()[a];
+    (*jobp(j)).selected_mask = 0;
+    lds_old_active()[a] = (uint16_t)j;
+  }
+  wave_sync();
   resume_simulation();
   uint64_t t2 = wave_clock();
   // reward = -job_time (ENV:208-209); `duration == 0.0` short-circuits to -0.0 (ENV:850-852)
