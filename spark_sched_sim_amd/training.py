@@ -516,3 +516,33 @@ def make_trainer(cfg: dict[str, Any], device: str | torch.device | None = None, 
     trainer_cls = cfg["trainer"]["trainer_cls"]
     assert trainer_cls in ("PPO",), f"'{trainer_cls}' is not a valid trainer."
     return Trainer(agent_cfg=cfg["agent"], env_cfg=cfg["env"], train_cfg=cfg["trainer"], device=device, _lib=_lib)
+
+
+def main(argv=None) -> None:
+    """the reference's train.py / cfg_loader.py: `python -m spark_sched_sim_amd.training -f config.yaml`
+    (the reference's YAML files, e.g. config/decima_tpch.yaml, are accepted unchanged; under
+    torch.distributed.run every rank trains on its own job sequences)"""
+    import os
+    from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
+
+    import yaml
+
+    parser = ArgumentParser(description=main.__doc__, formatter_class=ArgumentDefaultsHelpFormatter)
+    parser.add_argument("-f", "--file", dest="filename", help="experiment definition file", metavar="FILE", required=True)
+    args = parser.parse_args(argv)
+    with open(args.filename, "r") as stream:
+        cfg = yaml.safe_load(stream)
+    device = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+        device = f"cuda:{local}"
+    tr = make_trainer(cfg, device=device)
+    tr.train()
+    tr.close()
+
+
+if __name__ == "__main__":
+    main()

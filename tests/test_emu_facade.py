@@ -77,3 +77,14 @@ def test_action_space_follows_the_observation():
     assert not sp.contains({"stage_idx": n, "num_exec": 1}) and not sp.contains({"stage_idx": 0, "num_exec": 0})
     assert not sp.contains({"stage_idx": 0, "num_exec": 1, "job_idx": 0})
     env.close()
+
+
+def test_examples_run_episode_reproduces_the_reference_metric(capsys):
+    """the reference's examples.py on this build: fair scheduler, ENV_CFG, seed 1234 -> the same
+    average job duration the recorded reference episode has"""
+    from spark_sched_sim_amd import examples
+
+    g = Golden("c1_fair")
+    got = examples.fair_example(device="cpu", _lib=load_emu())
+    assert bits(got) == bits(np.mean(g.ep(1234, "job_durations")) * 1e-3)
+    assert "Average job duration" in capsys.readouterr().out
