@@ -291,12 +291,13 @@ def main() -> None:
         kern_ms = sum(a.elapsed_time(b) for a, b in events)
         tot = torch.tensor([float(c1["n_steps"] - c0["n_steps"]), float(c1["n_events"] - c0["n_events"]),
                             float(c1["model_bytes"] - c0["model_bytes"]), kern_ms, float(len(events)),
-                            float(c1["n_fast_events"] - c0["n_fast_events"])], dtype=torch.float64, device=dev)
+                            float(c1["n_fast_events"] - c0["n_fast_events"]), float(c1["n_batched_events"] - c0["n_batched_events"]),
+                            float(c1["n_rounds"] - c0["n_rounds"])], dtype=torch.float64, device=dev)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        steps_all, evs_all, bytes_all, kern_ms_all, launches_all, fast_all = tot.cpu().tolist()
+        steps_all, evs_all, bytes_all, kern_ms_all, launches_all, fast_all, batched_all, rounds_all = tot.cpu().tolist()
         dt_max = tmax.item()
         avg_launch_s = (kern_ms_all / launches_all) * 1e-3
         bytes_per_launch = bytes_all / launches_all
@@ -309,6 +310,9 @@ def main() -> None:
             "events_per_s": evs_all / dt_max,
             "events_per_step": evs_all / max(1.0, steps_all),
             "fast_path_event_frac": fast_all / max(1.0, evs_all),
+            # share of all events handled by lane-parallel batches, and events per batch round
+            "batched_event_frac": batched_all / max(1.0, evs_all),
+            "events_per_batch": batched_all / max(1.0, rounds_all),
             # rank-0 shader-clock ticks per real env step spent in each phase (device counters)
             "phase_ticks_per_step": {k[6:]: (c1[k] - c0[k]) / max(1, c1["n_steps"] - c0["n_steps"]) for k in c1 if k.startswith("ticks_")},
             "roofline": {

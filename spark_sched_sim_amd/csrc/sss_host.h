@@ -58,6 +58,7 @@ struct sss_handle {
   void* pack_dev;
   void* zig_dev;
   void* eff_dev;
+  void* jump_dev;
   SssParams P;
   SssPackDev pk;
 };
@@ -85,11 +86,16 @@ static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes,
 //   mode 2  new to the stage:     first_wave, else fresh_durations
 // A wave "fails" when the level key is missing (KeyError) or its list is empty (ValueError from
 // Generator.choice before any draw); len 0 in the result = the exception would escape.
-static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost& ph, const int8_t lvl_of[8]) {
+// Each entry also carries a lower bound of any duration the list can yield (its minimum, plus the
+// whole milliseconds of warmup_delay where that is added): the batched event path (sss_sim.h,
+// batch_fast_events) uses it to bound the time of events that do not exist yet.
+static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost& ph, const int8_t lvl_of[8], double warmup_delay) {
   const uint32_t* keymask = (const uint32_t*)(pack + ph.sec_off[7]);
   const int32_t* maxlvl = (const int32_t*)(pack + ph.sec_off[8]);
   const int32_t* desc = (const int32_t*)(pack + ph.sec_off[10]);
-  std::vector<int32_t> eff((size_t)ph.total_stages * 8 * 3 * 2, 0);
+  const int32_t* durations = (const int32_t*)(pack + ph.sec_off[11]);
+  int warm_floor = warmup_delay > 0 ? (warmup_delay < 1e9 ? (int)floor(warmup_delay) : 1000000000) : 0;
+  std::vector<int32_t> eff((size_t)ph.total_stages * 8 * 3 * 4, 0);
   for (int gs = 0; gs < ph.total_stages; gs++)
     for (int i = 0; i < 8; i++) {
       int lvl = lvl_of[i];
@@ -97,13 +103,17 @@ static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost
       auto d = [&](int wave, int k) { return desc[((gs * 3 + wave) * ph.L + lvl) * 2 + k]; };
       static const int chain[3][3] = {{0, 1, -1}, {2, 1, 0}, {1, 0, -1}};
       for (int mode = 0; mode < 3; mode++) {
-        int32_t* out = &eff[(((size_t)gs * 8 + i) * 3 + mode) * 2];
+        int32_t* out = &eff[(((size_t)gs * 8 + i) * 3 + mode) * 4];
         for (int k = 0; k < 3; k++) {
           int wave = chain[mode][k];
           if (wave < 0) break;
           if (d(wave, 1) > 0) {
+            bool warm = mode == 0 && k == 1;
             out[0] = d(wave, 0);
-            out[1] = d(wave, 1) | ((mode == 0 && k == 1) ? (1 << 30) : 0);
+            out[1] = d(wave, 1) | (warm ? (1 << 30) : 0);
+            int mn = durations[d(wave, 0)];
+            for (int q = 1; q < d(wave, 1); q++) mn = durations[d(wave, 0) + q] < mn ? durations[d(wave, 0) + q] : mn;
+            out[2] = (mn < 0 ? 0 : mn) + (warm ? warm_floor : 0);
             break;
           }
         }
@@ -133,6 +143,28 @@ extern "C" int sss_query_dims(const sss_cfg* cfg, const void* pack, size_t pack_
   return 0;
 }
 
+// PCG64 jump-ahead table (numpy's pcg64: 128-bit LCG, multiplier 0x2360ED051FC65DA44385DF649FCCF645):
+// state_{n+k} = A_k * state_n + C_k * inc (mod 2^128) for k = -64..64, rows (A_hi, A_lo, C_hi, C_lo).
+// With it the 64 lanes of a wave produce the next 64 raw outputs of an env's stream at once
+// (sss_sim.h, rng_refill) - the stream itself is exactly numpy's.
+static std::vector<uint64_t> sss_build_pcg_jump() {
+  typedef unsigned __int128 u128;
+  const u128 a = ((u128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+  u128 ainv = a;  // a * a == 1 (mod 8); each Newton step doubles the number of correct low bits
+  for (int i = 0; i < 7; i++) ainv *= 2 - a * ainv;
+  std::vector<uint64_t> t(129 * 4);
+  auto put = [&](int k, u128 A, u128 C) {
+    uint64_t* r = &t[(size_t)(k + 64) * 4];
+    r[0] = (uint64_t)(A >> 64), r[1] = (uint64_t)A, r[2] = (uint64_t)(C >> 64), r[3] = (uint64_t)C;
+  };
+  u128 A = 1, C = 0;
+  put(0, A, C);
+  for (int k = 1; k <= 64; k++) A = a * A, C = a * C + 1, put(k, A, C);
+  A = 1, C = 0;
+  for (int k = 1; k <= 64; k++) A = ainv * A, C = ainv * (C - 1), put(-k, A, C);  // state_{n-1} = ainv * (state_n - inc)
+  return t;
+}
+
 extern "C" const char* sss_last_error(void) { return g_sss_err.c_str(); }
 
 extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, int device, sss_handle** out) {
@@ -155,8 +187,10 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
     sss_destroy(h);
     return sss_fail(-11, "device allocation failed");
   }
-  be_h2d(h->pack_dev, pack, pack_bytes);
-  be_h2d(h->zig_dev, zig.data(), zig.size());
+  if (be_h2d(h->pack_dev, pack, pack_bytes) || be_h2d(h->zig_dev, zig.data(), zig.size())) {
+    sss_destroy(h);
+    return sss_fail(-13, "copying the workload pack to the device failed");
+  }
 
   SssPackDev pk;
   memset(&pk, 0, sizeof(pk));
@@ -196,14 +230,24 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
     sss_destroy(h);
     return sss_fail(-12, "LDS working set does not fit");
   }
-  std::vector<int32_t> eff = sss_build_eff((const uint8_t*)pack, ph, P.lvl_of);
+  std::vector<int32_t> eff = sss_build_eff((const uint8_t*)pack, ph, P.lvl_of, cfg->warmup_delay);
   h->eff_dev = be_alloc(eff.size() * sizeof(int32_t));
   if (!h->eff_dev) {
     sss_destroy(h);
     return sss_fail(-11, "device allocation failed");
   }
-  be_h2d(h->eff_dev, eff.data(), eff.size() * sizeof(int32_t));
+  std::vector<uint64_t> jump = sss_build_pcg_jump();
+  h->jump_dev = be_alloc(jump.size() * sizeof(uint64_t));
+  if (!h->jump_dev) {
+    sss_destroy(h);
+    return sss_fail(-11, "device allocation failed");
+  }
+  if (be_h2d(h->eff_dev, eff.data(), eff.size() * sizeof(int32_t)) || be_h2d(h->jump_dev, jump.data(), jump.size() * sizeof(uint64_t))) {
+    sss_destroy(h);
+    return sss_fail(-13, "copying the duration descriptors to the device failed");
+  }
   pk.eff = (const int32_t*)h->eff_dev;
+  pk.pcg_jump = (const uint64_t*)h->jump_dev;
   h->pk = pk;
   *out = h;
   return 0;
@@ -340,6 +384,6 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
 
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
-  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev);
+  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev), be_free(h->jump_dev);
   delete h;
 }

@@ -48,7 +48,7 @@ enum { EV_NONE = 0, EV_TASK_FINISHED = 2, EV_EXECUTOR_READY = 3 };
 #define POOL_NONE 0xFFFFFFFFu
 #define POOL_COMMON 0u
 
-struct SssHdr {            // 256 bytes
+struct SssHdr {            // 288 bytes
   uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
   uint32_t rng_has32, rng_u32;
   double wall_time;
@@ -82,7 +82,10 @@ struct SssHdr {            // 256 bytes
   int32_t last_ep_steps;
   double next_arrival_t;   // t_arrival[next_arrival] (+inf when exhausted): keeps the pop off HBM
   uint64_t prof[5];        // shader-clock ticks spent in: slow-path event handlers, action+fulfil, event loop, reward, observe
-  uint64_t n_fast;         // events handled by the register fast path
+  uint64_t n_fast;         // TASK_FINISHED events that took the "stage has more tasks" path (batched or one at a time)
+  uint64_t n_batched;      // ... of which handled by the lane-parallel batch path
+  uint64_t n_rounds;       // batch rounds that committed at least one event
+  uint64_t pad_[2];
 };
 
 // one pending event per executor at most: 16 bytes, read with a single LDS access.
@@ -150,6 +153,7 @@ struct SssParams {
   int32_t jobset_slots;    // capacity of the job-id set image (power of two)
   int32_t pool_bytes;      // dynamic LDS size
   int32_t off_active, off_old_active, off_slot_of, off_keys, off_jobset, off_cjobs, off_cstages, off_cdur, off_exdesc;  // byte offsets in g_pool
+  int32_t off_slot_job, off_slot_ref;
   int32_t max_edges;       // max template edges (flattened edge pass stride)
   int8_t lvl_of[8];        // pack level index of executor levels {5,10,20,40,50,60,80,100}, -1 if absent
   double mean_interarrival, moving_delay, warmup_delay, beta;
@@ -165,7 +169,8 @@ struct SssPackDev {
   const int32_t *stage_max_first_lvl, *edges, *desc, *durations;
   const uint64_t* zig_ke;
   const double *zig_we, *zig_fe;
-  const int32_t* eff;  // [total_stages][8 executor levels][3 modes][2] = (offset, len | warmup << 30)
+  const int32_t* eff;  // [total_stages][8 executor levels][3 modes][4] = (offset, len | warmup << 30, min duration of the list, 0)
+  const uint64_t* pcg_jump;  // [129][4]: PCG64 jump-ahead by k = -64..64 steps: state' = A * state + C * inc, rows (A_hi, A_lo, C_hi, C_lo)
 };
 
 struct SssBuffers {        // raw device pointers of torch-allocated tensors
@@ -186,11 +191,13 @@ static inline int64_t sss_align(int64_t x, int64_t a) { return (x + a - 1) / a *
 // per-executor cache of the two duration descriptors the executor's stage can need next
 // (executor mode "same stage", one per candidate executor level): keeps the descriptor load out
 // of the event chain. LDS only, rebuilt lazily after every launch.
-struct SssExDesc {
+struct SssExDesc {          // 32 bytes, two 16-byte LDS accesses
   int32_t gs;              // pack stage row the entries belong to, -1 = invalid
-  int32_t off[2], lenw[2];
-  int8_t lvl[2];
+  int8_t li, ri;           // the two candidate executor levels (equal when the level interval is closed)
   int16_t pad;
+  int32_t off_l, lenw_l;   // list of (stage, level li, "same stage" mode)
+  int32_t dmin_l, dmin_r;  // lower bounds of a duration drawn from either list
+  int32_t off_r, lenw_r;   // ... level ri
 };
 
 static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, int static_bytes) {
@@ -199,10 +206,12 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   P->off_active = o, o += 2 * J_cap;
   P->off_old_active = o, o += 2 * J_cap;
   P->off_slot_of = o, o += J_cap;
+  P->off_slot_ref = o, o += 64;
   o = (o + 1) & ~1;
+  P->off_slot_job = o, o += 2 * 64;
   P->off_keys = o, o += 2 * (J_cap + 8);
   P->off_jobset = o, o += 2 * jobset;
-  o = (o + 7) & ~7;
+  o = (o + 15) & ~15;
   P->off_exdesc = o, o += (int)sizeof(SssExDesc) * E;
   o = (o + 15) & ~15;
   int per_slot = (int)sizeof(SssJob) + 8 * SP + 4 * SP;
@@ -244,7 +253,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->state_bytes = L->env_stride * num_envs;
 }
 
-static_assert(sizeof(SssHdr) == 256, "SssHdr must be 256 bytes");
+static_assert(sizeof(SssHdr) == 288, "SssHdr must be 288 bytes");
 static_assert(sizeof(SssHot) % 16 == 0, "SssHot is copied with 16-byte accesses");
 static_assert(sizeof(SssJob) == 64, "SssJob must be one 64-byte line");
 static_assert(sizeof(SssStage) == 8 && sizeof(SssPoolHdr) == 8, "packed records");

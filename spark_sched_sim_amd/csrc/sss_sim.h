@@ -34,6 +34,11 @@
 // active-job list, the job -> cache-slot map, the LDS cache of the ACTIVE jobs' records and stage
 // counters (what the event chain touches on every event), and scratch for set images.
 struct alignas(16) SssScratch {
+  // the next raw outputs of the env's PCG64 stream, produced 64 at a time by the whole wave
+  // (rng_refill); rng_pos of them are consumed; rng_pos == 64: none buffered, the header holds the
+  // generator's state as numpy would have it
+  uint64_t rng_buf[64];
+  int32_t rng_pos, pad0_[3];
   uint8_t setA[SSS_SET_TABLE];
   uint8_t setB[SSS_SET_TABLE];
   // flags lane 0 publishes for the uniform control flow
@@ -42,6 +47,7 @@ struct alignas(16) SssScratch {
   int32_t n_old_active;
   int32_t events_this_step;
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
+  int32_t pinned_job;             // job of the event being handled: its cache slot is not given away
   int32_t jobset_mask, f_need_jobtime;
   // the set image of (old active list + active list) only changes when a job arrives or completes:
   // versions of the two lists it was built from (valid within one launch)
@@ -118,6 +124,13 @@ SSS_DEV void ctx_init(uint8_t* env_base, const SssLayout& L, const SssParams& P,
   } while (0)
 #endif
 
+#ifdef SSS_BATCH_STATS  // emulator-only census of why rounds end (tests/emu, never in the product build)
+extern "C" { extern long long sss_batch_stats[32]; }
+#define STAT(i, v) ((void)(wave_lane() == 0 ? (sss_batch_stats[i] += (v)) : 0))
+#else
+#define STAT(i, v) ((void)0)
+#endif
+
 // ---- LDS pool views ----
 #define SLOT_NONE 255
 SSS_DEV uint16_t* lds_active() { return (uint16_t*)(g_pool + g_c.P.off_active); }
@@ -129,6 +142,8 @@ SSS_DEV SssStage* lds_cstages() { return (SssStage*)(g_pool + g_c.P.off_cstages)
 SSS_DEV float* lds_cdur() { return (float*)(g_pool + g_c.P.off_cdur); }
 SSS_DEV SssExDesc* lds_exdesc() { return (SssExDesc*)(g_pool + g_c.P.off_exdesc); }
 SSS_DEV uint16_t* lds_old_active() { return (uint16_t*)(g_pool + g_c.P.off_old_active); }
+SSS_DEV uint16_t* lds_slot_job() { return (uint16_t*)(g_pool + g_c.P.off_slot_job); }  // job held by a cache slot
+SSS_DEV uint8_t* lds_slot_ref() { return g_pool + g_c.P.off_slot_ref; }                // pending events that name the slot
 
 // record of job j: its LDS cache slot if it has one, else the HBM copy
 SSS_DEV SssJob* jobp(int j) {
@@ -167,8 +182,7 @@ SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
 #define PCG_MH 0x2360ED051FC65DA4ull
 #define PCG_ML 0x4385DF649FCCF645ull
 
-template <class S>
-SSS_DEV void rng_step(S& h) {
+SSS_DEV void rng_step(SssHdr& h) {
   uint64_t lo = h.rng_state_lo, hi = h.rng_state_hi;
   uint64_t plo = lo * PCG_ML;
   uint64_t phi = mul64hi(lo, PCG_ML) + hi * PCG_ML + lo * PCG_MH;
@@ -177,39 +191,88 @@ SSS_DEV void rng_step(S& h) {
   h.rng_state_lo = rlo, h.rng_state_hi = rhi;
 }
 
-template <class S>
-SSS_DEV uint64_t rng_next64(S& h) {
-  rng_step(h);
-  uint64_t x = h.rng_state_hi ^ h.rng_state_lo;
-  unsigned rot = (unsigned)(h.rng_state_hi >> 58);
+SSS_DEV uint64_t pcg_output(uint64_t hi, uint64_t lo) {  // XSL-RR 128/64
+  uint64_t x = hi ^ lo;
+  unsigned rot = (unsigned)(hi >> 58);
   return (x >> rot) | (x << ((64 - rot) & 63));
 }
 
-template <class S>
-SSS_DEV uint32_t rng_next32(S& h) {
+// (a_hi:a_lo) * (b_hi:b_lo) mod 2^128
+SSS_DEV void mul128(uint64_t a_hi, uint64_t a_lo, uint64_t b_hi, uint64_t b_lo, uint64_t& r_hi, uint64_t& r_lo) {
+  r_lo = a_lo * b_lo;
+  r_hi = mul64hi(a_lo, b_lo) + a_lo * b_hi + a_hi * b_lo;
+}
+
+// the generator's state k steps away (k in [-64, 64]) from (s_hi:s_lo): A_k * state + C_k * inc
+SSS_DEV void pcg_jump(int k, uint64_t s_hi, uint64_t s_lo, uint64_t inc_hi, uint64_t inc_lo, uint64_t& r_hi, uint64_t& r_lo) {
+  const uint64_t* row = g_c.pk.pcg_jump + (size_t)(k + 64) * 4;
+  uint64_t a_hi, a_lo, c_hi, c_lo;
+  mul128(row[0], row[1], s_hi, s_lo, a_hi, a_lo);
+  mul128(row[2], row[3], inc_hi, inc_lo, c_hi, c_lo);
+  r_lo = a_lo + c_lo;
+  r_hi = a_hi + c_hi + (r_lo < a_lo ? 1ull : 0ull);
+}
+
+// All lanes: the next 64 raw outputs of the stream into g_sc.rng_buf, one per lane. While outputs
+// are buffered the header holds the state BEHIND the last buffered output; lane l produces the
+// output (rng_pos + l + 1 - 64) steps from there, so unconsumed outputs are simply produced again.
+SSS_DEV void rng_refill() {
+  int lane = wave_lane();
+  int p = g_sc.rng_pos;
+  uint64_t s_hi, s_lo;
+  pcg_jump(p + lane + 1 - 64, g_hot.h.rng_state_hi, g_hot.h.rng_state_lo, g_hot.h.rng_inc_hi, g_hot.h.rng_inc_lo, s_hi, s_lo);
+  wave_sync();  // every lane has read the old state
+  g_sc.rng_buf[lane] = pcg_output(s_hi, s_lo);
+  if (lane == 63) g_hot.h.rng_state_hi = s_hi, g_hot.h.rng_state_lo = s_lo, g_sc.rng_pos = 0;
+  wave_sync();
+}
+
+// lane 0: the header's state becomes the state numpy's generator would have now (HBM image)
+SSS_DEV void rng_canonicalize() {
+  int p = g_sc.rng_pos;
+  if (p < 64) {
+    uint64_t s_hi, s_lo;
+    pcg_jump(p - 64, g_hot.h.rng_state_hi, g_hot.h.rng_state_lo, g_hot.h.rng_inc_hi, g_hot.h.rng_inc_lo, s_hi, s_lo);
+    g_hot.h.rng_state_hi = s_hi, g_hot.h.rng_state_lo = s_lo;
+    g_sc.rng_pos = 64;
+  }
+}
+
+// lane 0: one raw output - from the buffer while it lasts, else by stepping the generator
+SSS_DEV uint64_t rng_next64() {
+  int p = g_sc.rng_pos;
+  if (p < 64) {
+    g_sc.rng_pos = p + 1;
+    return g_sc.rng_buf[p];
+  }
+  rng_step(g_hot.h);
+  return pcg_output(g_hot.h.rng_state_hi, g_hot.h.rng_state_lo);
+}
+
+SSS_DEV uint32_t rng_next32() {
+  SssHdr& h = g_hot.h;
   if (h.rng_has32) {
     h.rng_has32 = 0;
     return h.rng_u32;
   }
-  uint64_t n = rng_next64(h);
+  uint64_t n = rng_next64();
   h.rng_has32 = 1;
   h.rng_u32 = (uint32_t)(n >> 32);
   return (uint32_t)n;
 }
 
-template <class S>
-SSS_DEV double rng_random(S& h) { return (double)(rng_next64(h) >> 11) * (1.0 / 9007199254740992.0); }
+SSS_DEV double u64_to_unit(uint64_t x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+SSS_DEV double rng_random() { return u64_to_unit(rng_next64()); }
 
-template <class S>
-SSS_DEV uint32_t rng_integers(S& h, uint32_t n) {
+SSS_DEV uint32_t rng_integers(uint32_t n) {
   uint32_t rng = n - 1;
   if (rng == 0) return 0;
-  uint64_t m = (uint64_t)rng_next32(h) * n;
+  uint64_t m = (uint64_t)rng_next32() * n;
   uint32_t leftover = (uint32_t)m;
   if (leftover < n) {
     uint32_t threshold = (0xFFFFFFFFu - rng) % n;
     while (leftover < threshold) {
-      m = (uint64_t)rng_next32(h) * n;
+      m = (uint64_t)rng_next32() * n;
       leftover = (uint32_t)m;
     }
   }
@@ -377,16 +440,16 @@ SSS_DEV_NOINLINE double fd_exp(double x) {
   return y * 9.33263618503218878990e-302;
 }
 
-SSS_DEV_NOINLINE double rng_standard_exponential(SssHdr& h) {
+SSS_DEV_NOINLINE double rng_standard_exponential() {
   for (;;) {
-    uint64_t ri = rng_next64(h);
+    uint64_t ri = rng_next64();
     ri >>= 3;
     unsigned idx = (unsigned)(ri & 0xFF);
     ri >>= 8;
     double x = (double)ri * g_c.pk.zig_we[idx];
     if (ri < g_c.pk.zig_ke[idx]) return x;
-    if (idx == 0) return 7.69711747013104972 - fd_log1p(-rng_random(h));
-    if ((g_c.pk.zig_fe[idx - 1] - g_c.pk.zig_fe[idx]) * rng_random(h) + g_c.pk.zig_fe[idx] < fd_exp(-x)) return x;
+    if (idx == 0) return 7.69711747013104972 - fd_log1p(-rng_random());
+    if ((g_c.pk.zig_fe[idx - 1] - g_c.pk.zig_fe[idx]) * rng_random() + g_c.pk.zig_fe[idx] < fd_exp(-x)) return x;
   }
 }
 
@@ -731,19 +794,19 @@ SSS_DEV double task_duration(int j, int s, int e) {
   executor_interval(n_local, li, ri);
   if (li != ri) {
     double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
-    int rand_pt = 1 + (int)(rng_random(H) * (right - left));
+    int rand_pt = 1 + (int)(rng_random() * (right - left));
     if (!((double)rand_pt <= (double)n_local - left)) li = ri;
   }
   int task_stage = g_hot.ex_task_stage[e];
   int mode = task_stage < 0 ? 0 : (task_stage == s ? 1 : 2);  // idle / same stage id (TPCH:95) / other
-  const int32_t* d = g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + mode) * 2;
+  const int32_t* d = g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + mode) * 4;
   int off = d[0], lenw = d[1];
   int len = lenw & 0x3FFFFFFF;
   if (len == 0) {
     FAIL(SSS_ERR_NO_DURATION);
     return 0.0;
   }
-  uint32_t i = rng_integers(H, (uint32_t)len);
+  uint32_t i = rng_integers((uint32_t)len);
   double v = (double)g_c.pk.durations[off + (int)i];
   if (lenw >> 30) v += g_c.P.warmup_delay;
   return v;
@@ -823,11 +886,14 @@ SSS_DEV uint32_t info_slot(uint32_t i) { return (i >> 14) & 0x7F; }
 SSS_DEV int info_job(uint32_t i) { return (int)(i >> 21); }
 SSS_DEV uint32_t info_with_slot(uint32_t i, uint32_t slot) { return (i & ~(0x7Fu << 14)) | ((slot > 63u ? INFO_SLOT_NONE : slot) << 14); }
 
+SSS_DEV int cache_acquire(int j);
 SSS_DEV void push_event(int e, double t, int kind, int j, int s) {  // EVQ:34-35
   SssHot& hot = g_hot;
   CHECK((hot.ev[e].info & 0xFF) == EV_NONE);
+  int slot = cache_acquire(j);  // a job with a pending event holds a cache slot (if there is one to have)
+  if (slot != SLOT_NONE) lds_slot_ref()[slot]++;
   SssEvSlot sl;
-  sl.t = t, sl.seq = H.counter++, sl.info = ev_info(kind, j, s, lds_slot_of()[j]);
+  sl.t = t, sl.seq = H.counter++, sl.info = ev_info(kind, j, s, (uint32_t)slot);
   hot.ev[e] = sl;
 }
 
@@ -994,19 +1060,14 @@ SSS_DEV void commit_remaining_executors() {  // ENV:487-503
 // event handlers (lane 0)
 // ------------------------------------------------------------------------------------------
 
-// ---- LDS cache of the active jobs' records (lane 0 flavour) ----
-SSS_DEV void cache_acquire(int j) {  // on arrival: HBM -> LDS, if a slot is free
-  if (g_sc.free_slots == 0) return;
-  int k = ctz64(g_sc.free_slots);
-  g_sc.free_slots &= g_sc.free_slots - 1;
-  lds_cjobs()[k] = g_c.jobs[j];
-  for (int s = 0; s < g_c.SP; s++) {
-    lds_cstages()[k * g_c.SP + s] = g_c.stages[j * g_c.SP + s];
-    lds_cdur()[k * g_c.SP + s] = g_c.durations[j * g_c.SP + s];
-  }
-  lds_slot_of()[j] = (uint8_t)k;
-}
-SSS_DEV void cache_release(int j) {  // on completion: LDS -> HBM, slot becomes free
+// ---- LDS cache of job records (lane 0 flavour) ----
+// A slot holds one job's record, stage counters and recent durations. Slots go to the jobs the
+// event chain works on: a job gets one when an event is pushed for it (push_event) and keeps it at
+// least while events that name it are pending (lds_slot_ref) - so with n_slots >= num_executors every
+// pending event finds its job in LDS. Everything else reaches a job through jobp / stgp / durp, which
+// fall back to the HBM copy. Slots are written back when their job completes, when they are handed
+// to another job, and at the end of the launch.
+SSS_DEV void cache_release(int j) {  // LDS -> HBM, slot becomes free
   int k = lds_slot_of()[j];
   if (k == SLOT_NONE) return;
   g_c.jobs[j] = lds_cjobs()[k];
@@ -1017,12 +1078,37 @@ SSS_DEV void cache_release(int j) {  // on completion: LDS -> HBM, slot becomes 
   lds_slot_of()[j] = SLOT_NONE;
   g_sc.free_slots |= bit64(k);
 }
+SSS_DEV int cache_acquire(int j) {  // HBM -> LDS if the job has no slot yet; returns its slot or SLOT_NONE
+  int k = lds_slot_of()[j];
+  if (k != SLOT_NONE) return k;
+  if (g_sc.free_slots == 0) {
+    // hand over the slot of a job no pending event names (never the job whose event is being handled)
+    int victim = -1;
+    for (int q = 0; q < g_c.P.n_slots; q++)
+      if (lds_slot_ref()[q] == 0 && (int)lds_slot_job()[q] != g_sc.pinned_job) {
+        victim = q;
+        break;
+      }
+    if (victim < 0) return SLOT_NONE;
+    cache_release((int)lds_slot_job()[victim]);
+  }
+  k = ctz64(g_sc.free_slots);
+  g_sc.free_slots &= g_sc.free_slots - 1;
+  lds_cjobs()[k] = g_c.jobs[j];
+  for (int s = 0; s < g_c.SP; s++) {
+    lds_cstages()[k * g_c.SP + s] = g_c.stages[j * g_c.SP + s];
+    lds_cdur()[k * g_c.SP + s] = g_c.durations[j * g_c.SP + s];
+  }
+  lds_slot_of()[j] = (uint8_t)k;
+  lds_slot_job()[k] = (uint16_t)j;
+  lds_slot_ref()[k] = 0;
+  return k;
+}
 
 SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created empty at reset)
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
   g_sc.active_version++;
-  cache_acquire(j);
   if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
 
@@ -1121,39 +1207,7 @@ SSS_DEV int pop_event_wave(double next_arrival_t, double& t_win, uint32_t& info_
   return ex;
 }
 
-// Registers of the lane-0 event loop: the header fields every event touches. Loaded when the loop
-// is entered, written back when it is left or before any out-of-line (slow path) handler runs.
-struct EvRegs {
-  uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
-  uint32_t rng_has32, rng_u32;
-  double wall_time;
-  uint64_t n_events;
-  uint32_t counter;
-  int32_t events_this_step;
-  double next_arrival_t;  // +inf when every job has arrived
-  uint32_t curr_source;
-};
-SSS_DEV void regs_load(EvRegs& r) {
-  const SssHdr& h = g_hot.h;
-  r.rng_state_hi = h.rng_state_hi, r.rng_state_lo = h.rng_state_lo, r.rng_inc_hi = h.rng_inc_hi, r.rng_inc_lo = h.rng_inc_lo;
-  r.rng_has32 = h.rng_has32, r.rng_u32 = h.rng_u32;
-  r.wall_time = h.wall_time, r.n_events = h.n_events, r.counter = h.counter, r.events_this_step = g_sc.events_this_step;
-  r.next_arrival_t = h.next_arrival < h.J ? h.next_arrival_t : __builtin_inf();
-  r.curr_source = h.curr_source;
-}
-SSS_DEV void regs_store(const EvRegs& r) {
-  SssHdr& h = g_hot.h;
-  h.rng_state_hi = r.rng_state_hi, h.rng_state_lo = r.rng_state_lo;
-  h.rng_has32 = r.rng_has32, h.rng_u32 = r.rng_u32;
-  h.wall_time = r.wall_time, h.n_events = r.n_events, h.counter = r.counter, g_sc.events_this_step = r.events_this_step;
-}
-
-// The common event (97-99 % of all events are TASK_FINISHED, most of them with tasks left in the
-// stage): ENV:452-467 + ENV:584-615 + TPCH:75-106 fused for "same executor continues on the same
-// stage". executing-- / executing++ cancel, executor.task.stage_id already equals the stage
-// (=> the `rest_wave` mode of task_duration), the event slot keeps its kind/job/stage.
-// Returns false, with nothing modified, when the stage has no remaining task (slow path).
-// launch constants the fast path needs, fetched from the LDS context once per event loop
+// launch constants the event loop needs, fetched from the LDS context once per loop
 struct FastCtx {
   uint8_t* slot_of;
   SssStage* cstages;
@@ -1162,15 +1216,34 @@ struct FastCtx {
   SssExDesc* exdesc;
   const int32_t* eff;
   const int32_t* durations;
-  int SP;
+  int SP, E;
 };
 SSS_DEV void fastctx_load(FastCtx& f) {
   f.slot_of = lds_slot_of(), f.cstages = lds_cstages(), f.cjobs = lds_cjobs(), f.cdur = lds_cdur(), f.exdesc = lds_exdesc();
-  f.eff = g_c.pk.eff, f.durations = g_c.pk.durations, f.SP = g_c.SP;
+  f.eff = g_c.pk.eff, f.durations = g_c.pk.durations, f.SP = g_c.SP, f.E = g_c.E;
 }
 
+#define LENW_LEN 0x3FFFFFFF
+
+// the duration lists an executor that stays on pack stage `gs` can draw from next ("same stage"
+// mode of TPCH:75-106): one per candidate executor level (li == ri when the interval is closed)
+SSS_DEV void exdesc_fetch(const FastCtx& f, SssExDesc& xd, int gs, int li, int ri) {
+  const int4 a = *(const int4*)(f.eff + (((size_t)gs * 8 + li) * 3 + 1) * 4);
+  int4 b = a;
+  if (ri != li) b = *(const int4*)(f.eff + (((size_t)gs * 8 + ri) * 3 + 1) * 4);
+  xd.gs = gs, xd.li = (int8_t)li, xd.ri = (int8_t)ri, xd.pad = 0;
+  xd.off_l = a.x, xd.lenw_l = a.y, xd.dmin_l = a.z;
+  xd.off_r = b.x, xd.lenw_r = b.y, xd.dmin_r = b.z;
+}
+
+// The common event (97-99 % of all events are TASK_FINISHED, most of them with tasks left in the
+// stage): ENV:452-467 + ENV:584-615 + TPCH:75-106 fused for "same executor continues on the same
+// stage". executing-- / executing++ cancel, executor.task.stage_id already equals the stage
+// (=> the `rest_wave` mode of task_duration), the event slot keeps its kind/job/stage.
+// One event, lane 0 (the lane-parallel version is batch_fast_events below).
+// Returns 1 = handled, 0 = the stage has no remaining task (nothing modified: slow path), -1 = failed.
 template <bool CACHED>
-SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slot) {
+SSS_DEV int fast_body(const FastCtx& f, int ex, double t_ev, int j, int s, int slot) {
   SssStage* sp;
   SssJob* jp;
   float* dp;
@@ -1179,17 +1252,12 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   } else {
     sp = g_c.stages + j * f.SP + s, jp = g_c.jobs + j, dp = g_c.durations + j * f.SP + s;
   }
-#ifdef SSS_EVPROF2
-  uint64_t q0 = wave_clock();
-#endif
   SssStage st = *sp;
   uint64_t local = jp->local_mask;
   int gs = jp->gs_base + s;
   SssExDesc xd = f.exdesc[ex];
   if (st.remaining <= 0) return 0;
-#ifdef SSS_EVPROF2
-  uint64_t q1 = wave_clock();
-#endif
+  g_hot.h.wall_time = t_ev;
   st.remaining = (int16_t)(st.remaining - 1);
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
   if (st.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);  // stage just became saturated (ENV:595-597)
@@ -1199,52 +1267,190 @@ SSS_DEV int fast_body(const FastCtx& f, EvRegs& r, int ex, int j, int s, int slo
   int n_local = popc64(local);
   int li, ri;
   executor_interval(n_local, li, ri);
-  int ri_orig = ri;
-  if (li != ri) {
-    double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
-    int rand_pt = 1 + (int)(rng_random(r) * (right - left));
-    if (!((double)rand_pt <= (double)n_local - left)) li = ri;
-  }
-  // descriptor of (stage, level li, "same stage" mode): from the executor's LDS cache when it
-  // holds it, else one load from the pack (and the cache entry for that candidate is replaced)
-  int off, lenw;
-  int which = li == ri_orig ? 0 : 1;
-  if (xd.gs == gs && xd.lvl[which] == li) {
-    off = xd.off[which], lenw = xd.lenw[which];
-  } else {
-    const int2 d = *(const int2*)(f.eff + (((size_t)gs * 8 + li) * 3 + 1) * 2);
-    off = d.x, lenw = d.y;
-    if (xd.gs != gs) xd.lvl[which ^ 1] = -1;
-    xd.gs = gs, xd.off[which] = off, xd.lenw[which] = lenw, xd.lvl[which] = (int8_t)li;
+  if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) {
+    exdesc_fetch(f, xd, gs, li, ri);
     f.exdesc[ex] = xd;
   }
-  int len = lenw & 0x3FFFFFFF;
+  int lvl = li;
+  if (li != ri) {
+    double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+    int rand_pt = 1 + (int)(rng_random() * (right - left));
+    if (!((double)rand_pt <= (double)n_local - left)) lvl = ri;
+  }
+  int off = lvl == li ? xd.off_l : xd.off_r, lenw = lvl == li ? xd.lenw_l : xd.lenw_r;
+  int len = lenw & LENW_LEN;
   if (len == 0 || n_local <= 0) return -1;
-#ifdef SSS_EVPROF2
-  uint64_t q2 = wave_clock();
-#endif
-  uint32_t i = rng_integers(r, (uint32_t)len);
-#ifdef SSS_EVPROF2
-  uint64_t q3 = wave_clock();
-#endif
-#ifdef SSS_EXPERIMENT_NO_GATHER  // timing experiment only (wrong durations): what the L2 gather costs
-  double dur = (double)(100 + ((off + (int)i) & 1023));
-#else
+  uint32_t i = rng_integers((uint32_t)len);
   double dur = (double)f.durations[off + (int)i];
-#endif
   *dp = (float)dur;
-  g_hot.ev[ex].t = r.wall_time + dur;
-  g_hot.ev[ex].seq = r.counter++;
-#ifdef SSS_EVPROF2
-  uint64_t q4 = wave_clock();
-  g_hot.h.prof[0] += q1 - q0, g_hot.h.prof[1] += q2 - q1, g_hot.h.prof[2] += q3 - q2, g_hot.h.prof[3] += q4 - q3;
-#endif
+  g_hot.ev[ex].t = t_ev + dur;
+  g_hot.ev[ex].seq = g_hot.h.counter++;
   return 1;
 }
 
-// 1 = handled, 0 = not a fast-path event (nothing modified), -1 = failed
-SSS_DEV int fast_task_completion(const FastCtx& f, EvRegs& r, int ex, int j, int s, uint32_t slot) {
-  return slot != INFO_SLOT_NONE ? fast_body<true>(f, r, ex, j, s, (int)slot) : fast_body<false>(f, r, ex, j, s, SLOT_NONE);
+SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, int s, uint32_t slot) {
+  return slot != INFO_SLOT_NONE ? fast_body<true>(f, ex, t_ev, j, s, (int)slot) : fast_body<false>(f, ex, t_ev, j, s, SLOT_NONE);
+}
+
+// ------------------------------------------------------------------------------------------
+// Lane-parallel event batches (all lanes). While nothing is committable the event loop only pops
+// and handles (ENV:326-332), and a TASK_FINISHED whose stage still has tasks touches nothing but
+// its own executor, its stage's counters and the shared random stream. Such events do not have to
+// run one by one: with one lane per executor,
+//   * every pending event that can take that path computes a LOWER BOUND of the time of the event it
+//     will push (its own time + the minimum of the duration lists it can draw from, SssExDesc::dmin);
+//     M = min over those bounds, over the times of all pending events that need the general handlers,
+//     and the next job arrival. Every pending fast event with t < M is popped before anything else
+//     can happen - in time order, and the events they push all land at >= M. That set is the batch;
+//   * the batch members rank themselves by time (a loop over the members with v_readlane: members
+//     are few); the rank gives each member its push counter and - because the number of raw
+//     generator outputs each event consumes is known beforehand (one for random() when its executor
+//     level interval is open, then one 32-bit half for the bounded integer, TPCH:208-235, numpy's
+//     buffered 32-bit path) - its position in the env's random stream, which the wave has produced
+//     ahead of time (rng_refill);
+//   * members of one stage decrement its task counter together; the last of them in time order
+//     leaves its duration as the stage's most recent one (ENV:604).
+// Anything unusual - equal times inside the batch, a stage that would run out of tasks mid-batch,
+// a draw that needs Lemire's rejection test, duration lists with one or no entry - shortens the
+// batch or leaves the round to the one-event-at-a-time path, which is always correct.
+// Returns the number of events handled (0: none, nothing modified).
+// ------------------------------------------------------------------------------------------
+SSS_DEV int batch_fast_events(const FastCtx& f) {
+  const int lane = wave_lane();
+  // ---- everything that is read from shared state is read before the first collective ----
+  const SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
+  const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  const int pos = g_sc.rng_pos;
+  const double next_arr = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
+  const uint32_t info = sl.info;
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info);
+  bool cand = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
+  SssStage st = {0, 0, 0, 0};
+  SssExDesc xd;
+  xd.gs = -1, xd.li = xd.ri = 0, xd.pad = 0, xd.off_l = xd.off_r = 0, xd.lenw_l = xd.lenw_r = 0, xd.dmin_l = xd.dmin_r = 0;
+  int n_local = 0, li = 0, ri = 0, len_l = 0, len_r = 0;
+  if (cand) {
+    st = f.cstages[slot * f.SP + s];
+    const SssJob* jp = f.cjobs + slot;
+    const uint64_t local = jp->local_mask;
+    const int gs = jp->gs_base + s;
+    n_local = popc64(local);
+    executor_interval(n_local, li, ri);
+    xd = f.exdesc[lane];
+    if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) {
+      exdesc_fetch(f, xd, gs, li, ri);
+      f.exdesc[lane] = xd;  // an entry is only ever used with its own executor's events
+    }
+    len_l = xd.lenw_l & LENW_LEN, len_r = xd.lenw_r & LENW_LEN;
+    // lists with one entry draw nothing, empty ones fail (TPCH:88-106): both go one at a time
+    cand = st.remaining > 0 && n_local > 0 && len_l > 1 && len_r > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
+  }
+  const bool open = li != ri;
+  const int dmin = xd.dmin_l < xd.dmin_r ? xd.dmin_l : xd.dmin_r;
+  const double key = cand ? sl.t + (double)dmin : sl.t;
+  double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
+  if (next_arr < M) M = next_arr;  // an arrival wins ties against executor events (EVQ:35, counters 0..J-1)
+  bool V = cand && sl.t < M;
+  uint64_t vm = wave_ballot(V);
+#ifdef SSS_BATCH_STATS
+  {
+    uint64_t cm = wave_ballot(cand), tfm = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED), pend = wave_ballot(sl.t < __builtin_inf());
+    uint64_t unc = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot == INFO_SLOT_NONE);
+    uint64_t l1 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining > 0 && (len_l <= 1 || len_r <= 1));
+    uint64_t r0 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining <= 0);
+    STAT(0, 1), STAT(1, popc64(pend)), STAT(2, popc64(tfm)), STAT(3, popc64(cm)), STAT(4, popc64(vm)), STAT(5, vm == 0);
+    STAT(6, popc64(unc)), STAT(7, popc64(l1)), STAT(8, popc64(r0));
+    // is the head of the queue a candidate at all?
+    double tmin = wave_min_f64_nonneg(sl.t);
+    uint64_t head = wave_ballot(sl.t == tmin);
+    STAT(9, (head & cm) != 0), STAT(10, next_arr <= tmin);
+    STAT(11, (head & unc) != 0), STAT(12, (head & l1) != 0), STAT(13, (head & r0) != 0), STAT(14, (head & ~tfm) != 0);
+  }
+#endif
+  if (vm == 0) return 0;
+  uint32_t nmax = (uint32_t)(64 - pos) >> 1;  // two raw outputs per event at most
+  const uint32_t tag = (info & ~0xFFu) | (open ? 0x80u : 0u);  // (job, slot, stage) | draws random()
+  uint32_t rank, R, cb, ct;
+  for (;;) {
+    // rank = members before this one in time, R = how many of those draw random(),
+    // cb / ct = members of the same stage before this one / in total
+    uint32_t le = 0;
+    rank = 0, R = 0, cb = 0, ct = 0;
+    for (uint64_t m = vm; m; m &= m - 1) {
+      const int k = ctz64(m);
+      const double tk = wave_readlane_f64(sl.t, k);
+      const uint32_t gk = wave_readlane_u32(tag, k);
+      const bool lt = tk < sl.t, same = ((gk ^ tag) >> 8) == 0;
+      rank += lt ? 1u : 0u;
+      le += tk <= sl.t ? 1u : 0u;
+      R += (lt && (gk & 0x80u)) ? 1u : 0u;
+      cb += (lt && same) ? 1u : 0u;
+      ct += same ? 1u : 0u;
+    }
+    if (wave_ballot(V && le != rank + 1) != 0) { STAT(15, 1); return 0; }  // equal times: the push counters decide (EVQ:35), one at a time
+    // the stage has fewer tasks left than events before this one, or more events than buffered randomness
+    const bool over = V && (cb >= (uint32_t)st.remaining || rank >= nmax);
+    if (wave_ballot(over) == 0) break;
+    STAT(16, 1);
+    const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
+    V = V && rank < rcut;
+    vm = wave_ballot(V);
+    if (vm == 0) return 0;
+  }
+  const uint32_t n = (uint32_t)popc64(vm);
+  // ---- the members' draws ----
+  const uint32_t Fr = h0 ? rank >> 1 : (rank + 1) >> 1;  // raw outputs taken by the 32-bit draws of the members before
+  const bool fresh = ((h0 + rank) & 1u) == 0;           // this member's 32-bit draw takes a new raw output (low half)
+  const uint32_t P = R + Fr;
+  int lvl = li;
+  uint64_t x32 = 0;
+  uint32_t u32 = 0;
+  if (V) {
+    if (open) {  // TPCH:222-229
+      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
+      if (!((double)rand_pt <= (double)n_local - left)) lvl = ri;
+    }
+    if (fresh) {
+      x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
+      u32 = (uint32_t)x32;
+    } else if (rank == 0) {
+      u32 = u32_0;  // the half numpy kept from before the batch
+    } else {
+      u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);  // the half the member before left behind
+    }
+  }
+  const int off = lvl == li ? xd.off_l : xd.off_r;
+  const uint32_t len = (uint32_t)(lvl == li ? len_l : len_r);
+  const uint64_t mm = (uint64_t)u32 * len;
+  if (wave_ballot(V && (uint32_t)mm < len) != 0) { STAT(17, 1); return 0; }  // Lemire's rejection test is needed: one at a time
+  // ---- commit: nothing was modified before this point ----
+  if (V) {
+    const double dur = (double)f.durations[off + (int)(mm >> 32)];
+    g_hot.ev[lane].t = sl.t + dur;
+    g_hot.ev[lane].seq = counter0 + rank;
+    if (cb + 1 == ct) {  // the stage's last event of the batch (STG:53-58, ENV:595-597,604)
+      SssJob* jp = f.cjobs + slot;
+      st.remaining = (int16_t)(st.remaining - (int)ct);
+      f.cstages[slot * f.SP + s] = st;
+      f.cdur[slot * f.SP + s] = (float)dur;
+      if (st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
+      if ((int)st.remaining - ((int)st.moving_to + (int)st.commit_to) <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));
+    }
+    if (rank == n - 1) {  // the last event of the batch leaves the header behind
+      SssHdr& h = g_hot.h;
+      h.wall_time = sl.t;
+      h.counter = counter0 + n;
+      h.n_events += n, h.n_fast += n, h.n_batched += n, h.n_rounds++;
+      g_sc.events_this_step += (int32_t)n;
+      g_sc.rng_pos = pos + (int)P + (open ? 1 : 0) + (fresh ? 1 : 0);
+      h.rng_has32 = fresh ? 1u : 0u;
+      if (fresh) h.rng_u32 = (uint32_t)(x32 >> 32);
+    }
+  }
+  wave_sync();
+  return (int)n;
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -1370,9 +1576,7 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
     oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
     of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
-#if !defined(SSS_EVPROF) && !defined(SSS_EVPROF2)
     g_hot.h.prof[4] += wave_clock() - t_obs0;
-#endif
     g_hot.h.obs_n_nodes = base_n;
     g_hot.h.obs_n_sched = h.n_sched;
     g_hot.h.last_reward = reward;
@@ -1394,28 +1598,43 @@ SSS_DEV void env_begin(const uint8_t* base) {
   }
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   if (lane < g_c.E) lds_exdesc()[lane].gs = -1;
+  lds_slot_ref()[lane] = 0;
   wave_sync();
   int A = g_hot.h.n_active;
-  int nK = A < g_c.P.n_slots ? A : g_c.P.n_slots;
-  for (int i = lane; i < A; i += 64) {
-    int j = g_c.active_g[i];
-    lds_active()[i] = (uint16_t)j;
-    if (i < nK) lds_slot_of()[j] = (uint8_t)i;
-  }
+  for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
   if (lane == 0) {
+    // the jobs of the pending events get the cache slots (first come, first served); the events learn
+    // the slot their job got for this launch
+    int nK = 0;
+    for (int e = 0; e < g_c.E; e++) {
+      uint32_t info = g_hot.ev[e].info;
+      if (info_kind(info) == EV_NONE) continue;
+      int j = info_job(info);
+      int k = lds_slot_of()[j];
+      if (k == SLOT_NONE && nK < g_c.P.n_slots) {
+        k = nK++;
+        lds_slot_of()[j] = (uint8_t)k;
+        lds_slot_job()[k] = (uint16_t)j;
+      }
+      if (k != SLOT_NONE) lds_slot_ref()[k]++;
+      g_hot.ev[e].info = info_with_slot(info, (uint32_t)k);
+    }
     uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
     g_sc.free_slots = all & ~used;
-    g_sc.pending_free = -1;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1;
     g_sc.events_this_step = 0;
     g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
+    g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
   }
   wave_sync();
   // cached records: per slot 8 x u64 of job record, SP x u64 of stage counters, SP/2 x u64 of durations
+  uint64_t occ = ~g_sc.free_slots & (g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1));
+  int nK = popc64(occ);  // slots 0 .. nK-1
   int per = 8 + g_c.SP + g_c.SP / 2;
   for (int i = lane; i < nK * per; i += 64) {
     int k = i / per, w = i - k * per;
-    int j = lds_active()[k];
+    int j = lds_slot_job()[k];
     if (w < 8)
       ((uint64_t*)(lds_cjobs() + k))[w] = ((const uint64_t*)(g_c.jobs + j))[w];
     else if (w < 8 + g_c.SP)
@@ -1423,25 +1642,21 @@ SSS_DEV void env_begin(const uint8_t* base) {
     else
       ((uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP];
   }
-  // pending events learn the slot their job got for this launch
-  if (lane < g_c.E) {
-    uint32_t info = g_hot.ev[lane].info;
-    if (info_kind(info) != EV_NONE) g_hot.ev[lane].info = info_with_slot(info, lds_slot_of()[info_job(info)]);
-  }
   wave_sync();
 }
 
 SSS_DEV void env_end(uint8_t* base) {
   int lane = wave_lane();
   wave_sync();
+  if (lane == 0) rng_canonicalize();  // the HBM image never depends on what was buffered
   int A = g_hot.h.n_active;
   int per = 8 + g_c.SP + g_c.SP / 2;
-  // every cached job is active (slots are released at completion); lanes over (active job, word)
-  for (int i = lane; i < A * per; i += 64) {
-    int a = i / per, w = i - a * per;
-    int j = lds_active()[a];
-    int k = lds_slot_of()[j];
-    if (k == SLOT_NONE) continue;
+  uint64_t occ = ~g_sc.free_slots & (g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1));
+  // lanes over (slot, word); free slots are skipped
+  for (int i = lane; i < g_c.P.n_slots * per; i += 64) {
+    int k = i / per, w = i - k * per;
+    if (!(occ & bit64(k))) continue;
+    int j = lds_slot_job()[k];
     if (w < 8)
       ((uint64_t*)(g_c.jobs + j))[w] = ((const uint64_t*)(lds_cjobs() + k))[w];
     else if (w < 8 + g_c.SP)
@@ -1567,28 +1782,21 @@ SSS_DEV double jobtime_sum() {
 
 // _resume_simulation (ENV:320-343). Entered and left with LDS in sync.
 // lane 0: one popped event. Returns 0 = keep going, 1 = queue empty / failed, 2 = a scan is needed
-// (committable executors exist). On a non-zero return the LDS header is current.
-SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, double t_win, uint32_t info_win, uint64_t& n_fast, uint64_t& t_slow) {
-  if (ex == POP_EMPTY) {
-    regs_store(r);
-    return 1;
-  }
-  r.n_events++;
-  r.events_this_step++;
+// (committable executors exist).
+SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_win, uint64_t& t_slow) {
+  if (ex == POP_EMPTY) return 1;
+  H.n_events++;
+  g_sc.events_this_step++;
   int fast = 0;
-  if (ex >= 0 && info_kind(info_win) == EV_TASK_FINISHED) {
-    r.wall_time = t_win;
-    fast = fast_task_completion(f, r, ex, info_job(info_win), info_stage(info_win), info_slot(info_win));
-  }
+  if (ex >= 0 && info_kind(info_win) == EV_TASK_FINISHED)
+    fast = fast_task_completion(f, ex, t_win, info_job(info_win), info_stage(info_win), info_slot(info_win));
   if (fast > 0) {
     // the source stays what it was - None right after a scheduling round - so nothing is
-    // committable and the loop continues on registers (ENV:331-332)
-    n_fast++;
-    if (r.curr_source == POOL_NONE) return 0;
-    regs_store(r);
+    // committable and the loop continues (ENV:331-332)
+    H.n_fast++;
+    if (H.curr_source == POOL_NONE) return 0;
   } else {
-    // everything else goes through the out-of-line handlers on the LDS copy of the state
-    regs_store(r);
+    // everything else goes through the out-of-line handlers
     if (fast < 0) FAIL(SSS_ERR_NO_DURATION);
     uint64_t ts0 = wave_clock();
     if (fast < 0) {
@@ -1604,10 +1812,13 @@ SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, double t_win, uin
       H.wall_time = sl.t;
       hot.ev[ex].t = __builtin_inf();
       hot.ev[ex].info = EV_NONE;
+      if (info_slot(sl.info) != INFO_SLOT_NONE) lds_slot_ref()[info_slot(sl.info)]--;
+      g_sc.pinned_job = info_job(sl.info);
       if (info_kind(sl.info) == EV_TASK_FINISHED)
         handle_task_completion(ex, info_job(sl.info), info_stage(sl.info));
       else
         handle_executor_arrival(ex, info_job(sl.info), info_stage(sl.info));
+      g_sc.pinned_job = -1;
     }
     if (g_sc.pending_free >= 0) {
       cache_release(g_sc.pending_free);
@@ -1615,61 +1826,43 @@ SSS_DEV int handle_popped(const FastCtx& f, EvRegs& r, int ex, double t_win, uin
     }
     t_slow += wave_clock() - ts0;
   }
-  // the LDS header is current here
   if (H.err) return 1;
   if (trk_num_committable() > 0) {
     publish_scan_inputs();
     return 2;
   }
-  regs_load(r);
   return 0;
 }
 
 SSS_DEV void resume_simulation() {
   int lane = wave_lane();
+  FastCtx f;
+  fastctx_load(f);
+  // raw generator outputs the event loop wants to find buffered at the top of a round: two per
+  // event of a batch (batches are cut to what is there, so this only has to be "enough")
+  const int rng_need = 2 * (f.E < 20 ? f.E : 20);
   for (;;) {
-    // events run back to back until the wave is needed for a schedulable-stage scan, the queue is
-    // empty, or something failed
-    // The pop is a wave reduction, the handler runs on lane 0, and the loop decision travels through
-    // a lane-0 broadcast (no LDS flags, no barrier per event).
-    {
-      EvRegs r;
-      regs_load(r);
-      FastCtx f;
-      fastctx_load(f);
-      uint64_t n_fast = 0, t_slow = 0;
-      int status;
-#ifdef SSS_EVPROF
-      uint64_t tp_pop = 0, tp_handle = 0, tp_loop0 = wave_clock();
-#endif
-      do {
-#ifdef SSS_EVPROF
-        uint64_t c0 = wave_clock();
-#endif
-        double t_win = 0.0;
-        uint32_t info_win = 0;
-        int ex = pop_event_wave(wave_lane0_f64(r.next_arrival_t), t_win, info_win);
-#ifdef SSS_EVPROF
-        uint64_t c1 = wave_clock();
-#endif
-        status = 0;
-        if (lane == 0) status = handle_popped(f, r, ex, t_win, info_win, n_fast, t_slow);
-#ifdef SSS_EVPROF
-        uint64_t c2 = wave_clock();
-        tp_pop += c1 - c0, tp_handle += c2 - c1;
-#endif
-        status = (int)wave_lane0_u32((uint32_t)status);
-      } while (status == 0);
-#ifdef SSS_EVPROF
-      if (lane == 0) H.prof[1] += tp_pop, H.prof[3] += tp_handle, H.prof[4] += wave_clock() - tp_loop0;
-#endif
-      if (lane == 0) {
-        g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
-        H.n_fast += n_fast;
-#ifndef SSS_EVPROF2
-        H.prof[0] += t_slow;
-#endif
-      }
+    // events run until the wave is needed for a schedulable-stage scan, the queue is empty, or
+    // something failed. A round = one lane-parallel batch of "task finished, stage has more tasks"
+    // events if the head of the queue allows one (batch_fast_events), else one event popped by a
+    // wave reduction and handled on lane 0; the loop decision travels through a lane-0 broadcast
+    // (no LDS flags, no barrier per event).
+    uint64_t t_slow = 0;
+    int status;
+    do {
+      status = 0;
+      if (64 - g_sc.rng_pos < rng_need) rng_refill();
+      if (batch_fast_events(f) > 0) continue;
+      double t_win = 0.0;
+      uint32_t info_win = 0;
+      double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
+      int ex = pop_event_wave(next_arrival_t, t_win, info_win);
+      if (lane == 0) status = handle_popped(f, ex, t_win, info_win, t_slow);
+      status = (int)wave_lane0_u32((uint32_t)status);
+    } while (status == 0);
+    if (lane == 0) {
+      g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
+      H.prof[0] += t_slow;
     }
     wave_sync();
     if (g_sc.f_done) {
@@ -1702,21 +1895,22 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   SssHot& hot = g_hot;
   // nothing is cached while the records are (re)built in HBM
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
+  lds_slot_ref()[lane] = 0;
   wave_sync();
   if (lane == 0) {
     g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    g_sc.pending_free = -1;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
     int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
     double last_ep_return = H.last_ep_return, last_ep_wall = H.last_ep_wall;
     uint64_t prof[5];
     for (int i = 0; i < 5; i++) prof[i] = H.prof[i];
-    uint64_t n_fast_keep = H.n_fast;
+    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds;
     SssHdr z = {};
     H = z;
     for (int i = 0; i < 5; i++) H.prof[i] = prof[i];
-    H.n_fast = n_fast_keep;
+    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep;
     H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
     H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
@@ -1728,6 +1922,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
       H.need_reset = 1;
     } else {
       rng_seed(H, seed);
+      g_sc.rng_pos = 64;  // nothing buffered: the header holds the generator's state itself
       // job_sequence TPCH:54-73
       double t = 0.0;
       int J = 0;
@@ -1737,12 +1932,12 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
           H.need_reset = 1;
           break;
         }
-        int q = (int)rng_integers(H, 22);     // TPCH:177
-        int size = (int)rng_integers(H, 7);   // TPCH:178
+        int q = (int)rng_integers(22);     // TPCH:177
+        int size = (int)rng_integers(7);   // TPCH:178
         (*jobp(J)).gs_base = q * 7 + size;  // template id for now; resolved to pack rows below
         g_c.t_arrival[J] = t;
         J++;
-        t += g_c.P.mean_interarrival * rng_standard_exponential(H);  // TPCH:70
+        t += g_c.P.mean_interarrival * rng_standard_exponential();  // TPCH:70
       }
       H.J = J;
     }
@@ -1849,9 +2044,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   }
   wave_sync();
   uint64_t t1 = wave_clock();
-#if !defined(SSS_EVPROF) && !defined(SSS_EVPROF2)
   if (lane == 0) H.prof[1] += t1 - t0;
-#endif
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
   for (int a = lane; a < g_hot.h.n_active; a += 64) {  // ENV:203 selected_stages.clear(); active jobs at the round's end
     int j = lds_active()[a];
@@ -1889,12 +2082,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     }
     if (H.err) H.need_reset = 1;
     uint64_t t3 = wave_clock();
-#if defined(SSS_EVPROF2)
-#elif !defined(SSS_EVPROF)
     H.prof[2] += t2 - t1, H.prof[3] += t3 - t2;
-#else
-    H.prof[2] += t2 - t1;
-#endif
   }
   wave_sync();
   return reward;

@@ -137,6 +137,7 @@ SSS_DEV double wave_readlane_f64(double v, int l) {
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { atomicAdd(p, v); }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+SSS_DEV void lane_atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 SSS_DEV void lane_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }  // global_atomic_add_f32
 SSS_DEV void lane_atomic_max_i32(int32_t* p, int32_t v) { atomicMax(p, v); }
 

@@ -359,23 +359,27 @@ class VecSparkSchedSimEnv:
         for name in ("n_steps", "n_events", "model_bytes"):
             off = HDR_OFF[name]
             tot[name] = int(np.ascontiguousarray(hdr[:, off: off + 8]).view(np.uint64).sum())
-        prof = np.ascontiguousarray(hdr[:, 208:248]).view(np.uint64).sum(axis=0)
+        prof = np.ascontiguousarray(hdr[:, HDR_PROF: HDR_PROF + 40]).view(np.uint64).sum(axis=0)
         for k, name in enumerate(("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe")):
             tot[name] = int(prof[k])
-        tot["n_fast_events"] = int(np.ascontiguousarray(hdr[:, 248:256]).view(np.uint64).sum())
+        for name in ("n_fast", "n_batched", "n_rounds"):
+            off = HDR_OFF[name]
+            tot[name + "_events" if name != "n_rounds" else name] = int(np.ascontiguousarray(hdr[:, off: off + 8]).view(np.uint64).sum())
         return tot
 
 
-# byte offsets inside SssHdr (csrc/sss_layout.h); checked by tests/test_layout.py
+# byte offsets inside SssHdr (csrc/sss_layout.h); pinned by tests/test_abi.py against the header compiled with gcc
+HDR_PROF = 208  # uint64 prof[5]: shader-clock ticks in slow-path handlers, action + fulfil, event loop, reward, observe
 HDR_OFF = {"wall_time": 40, "time_limit": 48, "seed": 56, "n_steps": 64, "n_events": 72, "model_bytes": 80,
            "counter": 88, "next_arrival": 92, "J": 96, "n_active": 100, "n_completed": 104, "curr_source": 108,
            "n_sched": 112, "terminated": 136, "err": 140, "need_reset": 144, "dur_head": 148, "dur_n": 152,
            "episodes": 156, "last_reward": 160, "ep_return": 168, "last_ep_return": 176, "last_ep_wall": 184,
-           "ep_steps": 192, "last_ep_steps": 196}
+           "ep_steps": 192, "last_ep_steps": 196, "next_arrival_t": 200, "n_fast": 248, "n_batched": 256, "n_rounds": 264}
 HDR_W = {"wall_time": np.float64, "time_limit": np.float64, "seed": np.uint64, "n_steps": np.uint64,
          "n_events": np.uint64, "model_bytes": np.uint64, "counter": np.uint32, "next_arrival": np.int32,
          "J": np.int32, "n_active": np.int32, "n_completed": np.int32, "curr_source": np.uint32,
          "n_sched": np.int32, "terminated": np.int32, "err": np.int32, "need_reset": np.int32,
          "dur_head": np.int32, "dur_n": np.int32, "episodes": np.int32, "last_reward": np.float64,
          "ep_return": np.float64, "last_ep_return": np.float64, "last_ep_wall": np.float64,
-         "ep_steps": np.int32, "last_ep_steps": np.int32}
+         "ep_steps": np.int32, "last_ep_steps": np.int32, "next_arrival_t": np.float64, "n_fast": np.uint64,
+         "n_batched": np.uint64, "n_rounds": np.uint64}

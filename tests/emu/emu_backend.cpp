@@ -12,6 +12,9 @@ namespace emu {
 void launch(int grid, const std::function<void()>& body);
 }
 
+#ifdef SSS_BATCH_STATS
+extern "C" { long long sss_batch_stats[32]; }
+#endif
 #include "sss_sim.h"
 #include "sss_decima.h"
 #include <math.h>

@@ -107,6 +107,7 @@ SSS_DEV double wave_readlane_f64(double v, int l) { return wave_bcast_f64(v, l);
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { *p += v; }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
+SSS_DEV void lane_atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
 SSS_DEV void lane_atomic_add_f32(float* p, float v) { *p += v; }
 SSS_DEV void lane_atomic_max_i32(int32_t* p, int32_t v) { if (*p < v) *p = v; }
 SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
@@ -128,3 +129,4 @@ SSS_DEV double f64_with_hi32(double x, uint32_t hi) { return bits_f64((f64_bits(
 
 struct uint4 { uint32_t x, y, z, w; };
 struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };

@@ -58,16 +58,18 @@ def test_no_cpu_fallback():
 
 def test_header_offsets_match_layout(tmp_path):
     """vec_env.HDR_OFF mirrors struct SssHdr (csrc/sss_layout.h)"""
-    from spark_sched_sim_amd.vec_env import HDR_OFF
+    from spark_sched_sim_amd.vec_env import HDR_OFF, HDR_PROF
 
     src = tmp_path / "off.cpp"
-    fields = " ".join(f'P({k})' for k in HDR_OFF)
+    fields = " ".join(f'P({k})' for k in HDR_OFF) + ' P(prof) printf("sizeof %zu\\n", sizeof(SssHdr));'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sss_layout.h"\nint main(){\n'
                    '#define P(f) printf("%s %zu\\n", #f, offsetof(SssHdr, f));\n' + fields + "\nreturn 0;}\n")
     exe = tmp_path / "off"
     subprocess.run(["g++", "-I", osp.join(ROOT, "spark_sched_sim_amd", "csrc"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
     got = {l.split()[0]: int(l.split()[1]) for l in out.splitlines()}
+    assert got.pop("prof") == HDR_PROF  # the profiling counters VecSparkSchedSimEnv.counters() reads
+    assert got.pop("sizeof") == 288
     assert got == HDR_OFF
 
 
