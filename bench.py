@@ -360,6 +360,8 @@ def main() -> None:
             "events_per_s": primary["events_per_s"],
             "events_per_step": primary["events_per_step"],
             "fast_path_event_frac": primary["fast_path_event_frac"],
+            "batched_event_frac": primary["batched_event_frac"],
+            "events_per_batch": primary["events_per_batch"],
             "phase_ticks_per_step": primary["phase_ticks_per_step"],
             "mean_last_episode_return": mean_return,
             "roofline": primary["roofline"],

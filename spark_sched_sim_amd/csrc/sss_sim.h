@@ -1289,6 +1289,8 @@ SSS_DEV int fast_body(const FastCtx& f, int ex, double t_ev, int j, int s, int s
 }
 
 SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, int s, uint32_t slot) {
+  // an event pushed while its job had no slot does not name one; the job may have got one since
+  if (slot == INFO_SLOT_NONE && f.slot_of[j] != SLOT_NONE) slot = f.slot_of[j];
   return slot != INFO_SLOT_NONE ? fast_body<true>(f, ex, t_ev, j, s, (int)slot) : fast_body<false>(f, ex, t_ev, j, s, SLOT_NONE);
 }
 
@@ -1316,6 +1318,9 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
 SSS_DEV int batch_fast_events(const FastCtx& f) {
+#ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
+  return 0;
+#endif
   const int lane = wave_lane();
   // ---- everything that is read from shared state is read before the first collective ----
   const SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
@@ -1446,7 +1451,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f) {
       g_sc.events_this_step += (int32_t)n;
       g_sc.rng_pos = pos + (int)P + (open ? 1 : 0) + (fresh ? 1 : 0);
       h.rng_has32 = fresh ? 1u : 0u;
-      if (fresh) h.rng_u32 = (uint32_t)(x32 >> 32);
+      h.rng_u32 = fresh ? (uint32_t)(x32 >> 32) : u32;  // the half numpy keeps / the one just used up, as the one-event path leaves it
     }
   }
   wave_sync();
