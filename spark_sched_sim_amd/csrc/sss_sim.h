@@ -104,12 +104,19 @@ SSS_DEV void ctx_init(uint8_t* env_base, const SssLayout& L, const SssParams& P,
 }
 
 #define H (g_hot.h)
+#ifdef SSS_CHECK_TRACE  // emulator debugging: say which invariant broke
+#include <stdio.h>
+#define FAIL(code)                                                                          \
+  do {                                                                                      \
+    if (H.err == 0) fprintf(stderr, "[FAIL] line %d: code %d\n", __LINE__, (int)(code)), H.err = (code); \
+  } while (0)
+#else
 #define FAIL(code)                 \
   do {                             \
     if (H.err == 0) H.err = (code); \
   } while (0)
-#ifdef SSS_CHECK_TRACE  // emulator debugging: say which invariant broke
-#include <stdio.h>
+#endif
+#ifdef SSS_CHECK_TRACE
 #define CHECK(cond)                                                                     \
   do {                                                                                  \
     if (!(cond)) {                                                                      \
@@ -1279,6 +1286,11 @@ SSS_DEV int fast_body(const FastCtx& f, int ex, double t_ev, int j, int s, int s
   }
   int off = lvl == li ? xd.off_l : xd.off_r, lenw = lvl == li ? xd.lenw_l : xd.lenw_r;
   int len = lenw & LENW_LEN;
+#ifdef SSS_CHECK_TRACE
+  if (len == 0 || n_local <= 0)
+    fprintf(stderr, "[fast_body] CACHED=%d ex=%d j=%d s=%d slot=%d len=%d n_local=%d gs=%d li=%d ri=%d slot_of=%d ex_job=%d\n", (int)CACHED, ex, j, s, slot, len,
+            n_local, gs, li, ri, (int)f.slot_of[j], (int)g_hot.ex_job[ex]);
+#endif
   if (len == 0 || n_local <= 0) return -1;
   uint32_t i = rng_integers((uint32_t)len);
   double dur = (double)f.durations[off + (int)i];
@@ -1826,7 +1838,10 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
       g_sc.pinned_job = -1;
     }
     if (g_sc.pending_free >= 0) {
-      cache_release(g_sc.pending_free);
+      // a completed job gives its slot back right away - unless an executor is still on its way to
+      // it (its EXECUTOR_READY names the slot); then the slot is handed on later like any other
+      int k = lds_slot_of()[g_sc.pending_free];
+      if (k != SLOT_NONE && lds_slot_ref()[k] == 0) cache_release(g_sc.pending_free);
       g_sc.pending_free = -1;
     }
     t_slow += wave_clock() - ts0;

@@ -91,3 +91,9 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
 }
 
 #include "sss_host.h"
+
+// test-only export: the PCG64 jump-ahead table the host uploads (tests/test_emu_event_batches.py)
+extern "C" void sss_test_pcg_jump_table(uint64_t* out) {
+  std::vector<uint64_t> t = sss_build_pcg_jump();
+  memcpy(out, t.data(), t.size() * sizeof(uint64_t));
+}

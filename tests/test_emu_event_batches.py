@@ -1,0 +1,100 @@
+"""The lane-parallel event batches of the event loop (csrc/sss_sim.h batch_fast_events) and the
+pre-generated PCG64 stream they draw from (rng_refill), under the CPU wave emulator.
+
+* whole episodes in long launches (the job cache is only rebuilt at launch boundaries, so slots are
+  handed from job to job inside a launch) against the C oracle, env by env, bit for bit;
+* the same kernel source compiled with every event going one at a time (-DSSS_NO_BATCH) must leave
+  byte-identical env state after every launch;
+* the batch path is really taken (device counters);
+* the jump-ahead table against numpy's own PCG64.advance().
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from emu_util import load_emu
+from golden_util import bits
+from oracle_binding import OracleEnv, SsoObsInfo
+from spark_sched_sim_amd import VecSparkSchedSimEnv
+
+C2 = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+E64 = dict(num_executors=64, job_arrival_cap=30, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+E20 = dict(num_executors=20, job_arrival_cap=40, job_arrival_rate=2.0e-4, moving_delay=500.0, warmup_delay=100.0)
+
+
+def oracle_summary(pack, cfg, policy_id, seed):
+    env = OracleEnv(pack, cfg)
+    r = C.c_double()
+    n = env.lib.sso_run_episode(env.h, int(seed), policy_id, 10**9, C.byref(r))
+    info = SsoObsInfo()
+    env.lib.sso_obs_sizes(env.h, C.byref(info))
+    out = (int(n), bits(r.value), bits(info.wall_time), int(env.lib.sso_event_count(env.h)))
+    env.close()
+    return out
+
+
+# 31133 / 31158: seeds on which a completed job's cache slot was once handed on while an executor
+# was still travelling to that job (found by the 4096-env GPU test, reproduced here)
+@pytest.mark.parametrize("cfg,policy,policy_id,seeds,chunk", [
+    (C2, "hash", 1, [31133, 31158, 7], 200),
+    (C2, "fair", 0, [3, 4], 500),
+    (E64, "hash", 1, [0, 1], 150),
+    (E20, "fair", 0, [11], 300),
+])
+def test_long_launches_match_oracle(cfg, policy, policy_id, seeds, chunk, pack):
+    env = VecSparkSchedSimEnv(cfg, len(seeds), device="cpu", pack=pack, _lib=load_emu())
+    env.reset(seed=seeds)
+    for _ in range(40):
+        env.rollout(policy, chunk)
+        if all(env.header(k)["terminated"] or env.header(k)["err"] for k in range(len(seeds))):
+            break
+    for k, s in enumerate(seeds):
+        h = env.header(k)
+        assert h["err"] == 0 and h["terminated"] == 1, (s, h["err"], h["ep_steps"])
+        exp = oracle_summary(pack, cfg, policy_id, s)
+        assert (h["last_ep_steps"], bits(h["last_ep_return"]), bits(h["last_ep_wall"]), h["n_events"]) == exp, (s, h, exp)
+    c = env.counters()
+    assert c["n_batched_events"] > 0.5 * c["n_fast_events"] > 0  # the batch path did the bulk of the work
+    assert c["n_batched_events"] >= 2 * c["n_rounds"] > 0 or cfg is E64
+    env.close()
+
+
+@pytest.mark.parametrize("cfg,policy,seeds,chunk,n_launches", [(C2, "hash", [5, 31133], 37, 12), (E64, "fair", [2], 61, 8)])
+def test_batches_equal_one_event_at_a_time(cfg, policy, seeds, chunk, n_launches, pack):
+    """the batch path is an optimisation of the one-at-a-time path, nothing else: same env bytes"""
+    envs = [VecSparkSchedSimEnv(cfg, len(seeds), device="cpu", pack=pack, _lib=load_emu(v)) for v in ("", "_nobatch")]
+    for e in envs:
+        e.reset(seed=seeds)
+    skip = slice(256, 272)  # SssHdr::n_batched, n_rounds: the only fields that may differ
+    for it in range(n_launches):
+        for e in envs:
+            e.rollout(policy, chunk)
+        a, b = (e._env_view.numpy().copy() for e in envs)
+        a[:, skip] = 0
+        b[:, skip] = 0
+        assert np.array_equal(a, b), f"launch {it}: env state differs"
+        for name in ("nodes", "edge_links", "dag_ptr", "exec_supplies", "obs_i32", "obs_f64"):
+            assert np.array_equal(getattr(envs[0], name).numpy(), getattr(envs[1], name).numpy()), (it, name)
+    assert envs[0].counters()["n_batched_events"] > 0 and envs[1].counters()["n_batched_events"] == 0
+    for e in envs:
+        e.close()
+
+
+def test_jump_table_is_numpys_advance():
+    """sss_host.h sss_build_pcg_jump through its test export: state_{n+k} = A_k * state_n + C_k * inc"""
+    lib = load_emu()
+    tab = (C.c_uint64 * (129 * 4))()
+    lib.sss_test_pcg_jump_table(tab)
+    t = np.frombuffer(tab, dtype=np.uint64).reshape(129, 4)
+    bg = np.random.PCG64(12345)
+    st = bg.state["state"]
+    s0, inc = int(st["state"]), int(st["inc"])
+    mask = (1 << 128) - 1
+    for k in (-64, -63, -17, -1, 0, 1, 2, 31, 63, 64):
+        row = [int(x) for x in t[k + 64]]
+        A, Cc = (row[0] << 64) | row[1], (row[2] << 64) | row[3]
+        got = (A * s0 + Cc * inc) & mask
+        ref = np.random.PCG64(12345)
+        ref.advance(k % (1 << 128))
+        assert got == int(ref.state["state"]["state"]), k
