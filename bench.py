@@ -181,6 +181,7 @@ def main() -> None:
                          "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
     ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--evprof", action="store_true", help="library built with -DSSS_EVPROF (tools/evprof.sh): report ticks per event-loop round segment")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); 'gloo' only for plumbing tests")
     ap.add_argument("--device-index", type=int, default=None, help="override LOCAL_RANK -> device mapping (plumbing tests on one GPU)")
@@ -323,7 +324,18 @@ def main() -> None:
             },
         }
 
+    ev0 = env.counters() if args.evprof else None
     primary = measure(args.mode)
+    evprof = None
+    if args.evprof:
+        ev1 = env.counters()
+        dd = {k: ev1[k] - ev0[k] for k in ev1}
+        rounds = max(1, dd["evprof_rounds"])
+        evprof = {"rounds_per_step": rounds / max(1, dd["n_steps"]), "batch_rounds_per_step": dd["n_rounds"] / max(1, dd["n_steps"]),
+                  "ticks_per_round": {"batch_classify_or_early_exit": dd["ticks_slow_events"] / rounds, "batch_member_loop": dd["ticks_action"] / rounds,
+                                      "batch_draw_commit": dd["ticks_events"] / rounds, "single_pop": dd["ticks_reward"] / rounds,
+                                      "single_handler": dd["ticks_observe"] / rounds, "rng_refill": dd["evprof_refill"] / rounds},
+                  "ticks_per_step_total": sum(dd[k] for k in ("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe", "evprof_refill")) / max(1, dd["n_steps"])}
     other_mode = "fused" if args.mode == "step" else "step"
     secondary = None if args.single_mode else measure(other_mode)
 
@@ -366,6 +378,8 @@ def main() -> None:
             "mean_last_episode_return": mean_return,
             "roofline": primary["roofline"],
         }
+        if evprof is not None:
+            out["evprof"] = evprof
         if secondary is not None:
             # the same K batched steps through the other entry point (same per-step work, same trajectories)
             out["other_mode"] = dict(secondary, mode=other_mode)

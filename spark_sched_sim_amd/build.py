@@ -13,8 +13,17 @@ import sys
 
 CSRC = osp.join(osp.dirname(osp.abspath(__file__)), "csrc")
 ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
-SOURCES = ["sss_hip.hip", "sss_sim.h", "sss_host.h", "sss_layout.h", "wave_rt.h", "zig_tables.inc",
-           osp.join(ROOT, "include", "sss.h")]
+
+
+def sources() -> list[str]:
+    """everything the library is compiled from: every source / header / table under csrc/ plus the C ABI header"""
+    import glob
+    out = [osp.join(ROOT, "include", "sss.h")]
+    for pat in ("*.hip", "*.h", "*.inc"):
+        out += sorted(glob.glob(osp.join(CSRC, pat)))
+    return out
+
+
 OUT = osp.join(CSRC, "libsss_hip.so")
 
 # -ffp-contract=off: f64 event times / rewards must round exactly as the reference's do (no FMA fusion)
@@ -33,7 +42,7 @@ def needs_build() -> bool:
     if not osp.exists(OUT):
         return True
     t = osp.getmtime(OUT)
-    return any(osp.getmtime(s if osp.isabs(s) else osp.join(CSRC, s)) > t for s in SOURCES)
+    return any(osp.getmtime(s) > t for s in sources())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

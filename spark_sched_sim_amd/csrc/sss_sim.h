@@ -48,6 +48,7 @@ struct alignas(16) SssScratch {
   int32_t events_this_step;
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
   int32_t pinned_job;             // job of the event being handled: its cache slot is not given away
+  int32_t pc_next;                // pool cache: next line to be replaced
   int32_t jobset_mask, f_need_jobtime;
   // the set image of (old active list + active list) only changes when a job arrives or completes:
   // versions of the two lists it was built from (valid within one launch)
@@ -470,6 +471,8 @@ template <typename T>
 struct SetImg {
   T* tab;
   uint32_t mask, fill, used, finger;
+  uint32_t cap;  // slots available at `tab`; a resize beyond it continues in `big` (pool images cached in LDS)
+  T* big;
 };
 
 template <typename T>
@@ -499,6 +502,7 @@ SSS_DEV void set_resize(SetImg<T>& s, uint32_t minused, uint16_t* keys) {
     uint32_t e = s.tab[i];
     if (e >= 2) keys[n++] = (uint16_t)(e - 2);
   }
+  if (newsize > s.cap) s.tab = s.big, s.cap = 0xFFFFFFFFu;  // the live keys are in `keys`: nothing to copy
   for (uint32_t i = 0; i < newsize; i++) s.tab[i] = 0;
   for (uint32_t i = 0; i < n; i++) set_insert_clean(s.tab, newsize - 1, keys[i]);
   s.mask = newsize - 1;
@@ -576,22 +580,93 @@ SSS_DEV uint32_t set_pop(SetImg<T>& s) {
   return key;
 }
 
-SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
+// ---- LDS cache of executor-pool images ----
+// The pools the event chain and the commitment rounds work on (the source pool, the job / stage
+// pools executors sit in) are a handful at any time, but every access used to be a dependent HBM
+// round trip on lane 0. n_pc lines, fully associative (the keys are compared four at a time),
+// replaced round robin, written back when replaced and at the end of the launch. A line holds the
+// pool's header and its table while that has at most 32 slots; larger tables stay in HBM.
+#define PC_DIRTY 1u
+#define PC_BIG 2u
+SSS_DEV uint32_t* lds_pc_keys() { return (uint32_t*)(g_pool + g_c.P.off_pc_keys); }
+SSS_DEV SssPoolLine* lds_pc_lines() { return (SssPoolLine*)(g_pool + g_c.P.off_pc_lines); }
+SSS_DEV uint8_t* pool_home_table(int p) { return g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E); }
+
+SSS_DEV int pc_find(uint32_t key) {  // any lane, read-only
+  const uint32_t* k = lds_pc_keys();
+  for (int i = 0; i < g_c.P.n_pc; i += 4) {
+    const uint4 q = *(const uint4*)(k + i);
+    if (q.x == key) return i;
+    if (q.y == key) return i + 1;
+    if (q.z == key) return i + 2;
+    if (q.w == key) return i + 3;
+  }
+  return -1;
+}
+SSS_DEV void pc_writeback(int i) {  // line -> HBM copy
+  SssPoolLine* ln = lds_pc_lines() + i;
+  int p = pool_index(lds_pc_keys()[i]);
+  g_c.pool_hdr[p] = ln->hdr;
+  if (!(ln->flags & PC_BIG)) {
+    uint64_t* home = (uint64_t*)pool_home_table(p);
+    for (uint32_t w = 0; w < ((uint32_t)ln->hdr.mask + 1) / 8; w++) home[w] = ((const uint64_t*)ln->tab)[w];
+  }
+  ln->flags &= ~PC_DIRTY;
+}
+SSS_DEV int pc_load(uint32_t key) {  // lane 0: the pool's line, fetched from HBM if it has none
+  int i = pc_find(key);
+  if (i >= 0) return i;
+  i = g_sc.pc_next;
+  g_sc.pc_next = (i + 1) & (g_c.P.n_pc - 1);
+  SssPoolLine* ln = lds_pc_lines() + i;
+  if (lds_pc_keys()[i] != POOL_NONE && (ln->flags & PC_DIRTY)) pc_writeback(i);
   int p = pool_index(key);
   SssPoolHdr hd = g_c.pool_hdr[p];
+  ln->hdr = hd;
+  if (hd.mask < SSS_PC_INLINE) {
+    const uint64_t* home = (const uint64_t*)pool_home_table(p);
+    for (uint32_t w = 0; w < ((uint32_t)hd.mask + 1) / 8; w++) ((uint64_t*)ln->tab)[w] = home[w];
+    ln->flags = 0;
+  } else
+    ln->flags = PC_BIG;
+  lds_pc_keys()[i] = key;
+  return i;
+}
+// header of a pool, read-only, any lane (the line if there is one, else the HBM copy)
+SSS_DEV SssPoolHdr pool_hdr_get(uint32_t key) {
+  int i = pc_find(key);
+  return i >= 0 ? lds_pc_lines()[i].hdr : g_c.pool_hdr[pool_index(key)];
+}
+// lane 0: header to modify
+SSS_DEV SssPoolHdr* pool_hdr_mut(uint32_t key) {
+  SssPoolLine* ln = lds_pc_lines() + pc_load(key);
+  ln->flags |= PC_DIRTY;
+  return &ln->hdr;
+}
+
+SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
+  SssPoolLine* ln = lds_pc_lines() + pc_load(key);
   SetImg<uint8_t> s;
-  s.tab = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E);
-  s.mask = hd.mask, s.fill = hd.fill, s.used = hd.used, s.finger = 0;
+  s.big = pool_home_table(pool_index(key));
+  if (ln->flags & PC_BIG)
+    s.tab = s.big, s.cap = 0xFFFFFFFFu;
+  else
+    s.tab = ln->tab, s.cap = SSS_PC_INLINE;
+  s.mask = ln->hdr.mask, s.fill = ln->hdr.fill, s.used = ln->hdr.used, s.finger = 0;
   return s;
 }
+// nothing may have been opened since the matching pool_open (the line is still there)
 SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
-  int p = pool_index(key);
-  g_c.pool_hdr[p].mask = (uint16_t)s.mask;
-  g_c.pool_hdr[p].fill = (uint16_t)s.fill;
-  g_c.pool_hdr[p].used = (uint16_t)s.used;
+  SssPoolLine* ln = lds_pc_lines() + pc_find(key);
+  ln->hdr.mask = (uint16_t)s.mask, ln->hdr.fill = (uint16_t)s.fill, ln->hdr.used = (uint16_t)s.used;
+  if (s.tab == s.big && s.mask < SSS_PC_INLINE) {  // shrunk back below the inline size: the table moves into the line
+    for (uint32_t w = 0; w < (s.mask + 1) / 8; w++) ((uint64_t*)ln->tab)[w] = ((const uint64_t*)s.big)[w];
+    ln->flags = PC_DIRTY;
+  } else
+    ln->flags = PC_DIRTY | (s.tab == s.big ? PC_BIG : 0u);
 }
-SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
-SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
+SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)pool_hdr_get(key).used; }
+SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)pool_hdr_get(key).commit_from; }
 
 // ------------------------------------------------------------------------------------------
 // tracker (lane 0)
@@ -611,8 +686,8 @@ SSS_DEV void publish_scan_inputs() {
 SSS_DEV int trk_num_committable() {  // TRK:107-113
   uint32_t k = H.curr_source;
   if (k == POOL_NONE) return 0;
-  int p = pool_index(k);
-  int n = (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
+  const SssPoolHdr hd = lds_pc_lines()[pc_load(k)].hdr;
+  int n = (int)hd.used - (int)hd.commit_from;
   CHECK(n >= 0);
   return n;
 }
@@ -653,9 +728,9 @@ SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
     hot.c_src[i] = src, hot.c_dst[i] = dst, hot.c_n[i] = (int16_t)n, hot.c_seq[i] = H.commit_seq++;
     H.n_commits = i + 1;
   }
-  int ps = pool_index(src);
-  g_c.pool_hdr[ps].commit_from = (int16_t)(g_c.pool_hdr[ps].commit_from + n);
-  CHECK((int)g_c.pool_hdr[ps].used >= (int)g_c.pool_hdr[ps].commit_from);
+  SssPoolHdr* ph = pool_hdr_mut(src);
+  ph->commit_from = (int16_t)(ph->commit_from + n);
+  CHECK((int)ph->used >= (int)ph->commit_from);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
     (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to + n);
@@ -675,9 +750,9 @@ SSS_DEV uint32_t trk_remove_commitment(int e, uint32_t dst) {
   CHECK(i < H.n_commits);
   if (i >= H.n_commits) return src;
   hot.c_n[i] = (int16_t)(hot.c_n[i] - 1);
-  int ps = pool_index(src);
-  g_c.pool_hdr[ps].commit_from = (int16_t)(g_c.pool_hdr[ps].commit_from - 1);
-  CHECK(g_c.pool_hdr[ps].commit_from >= 0);
+  SssPoolHdr* ph = pool_hdr_mut(src);
+  ph->commit_from = (int16_t)(ph->commit_from - 1);
+  CHECK(ph->commit_from >= 0);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
     (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to - 1);
@@ -702,7 +777,20 @@ SSS_DEV uint32_t trk_peek_commitment(uint32_t src) {
   return dst;
 }
 
-SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  // TRK:188-222
+#ifdef SSS_EVPROF2
+#define EVP2_BEGIN uint64_t evp2_t0 = wave_clock()
+#define EVP2_END(i) g_hot.h.pad_[i] += wave_clock() - evp2_t0
+#else
+#define EVP2_BEGIN ((void)0)
+#define EVP2_END(i) ((void)0)
+#endif
+SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send);
+SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {
+  EVP2_BEGIN;
+  trk_move_executor_to_pool_(e, new_pool, send);
+  EVP2_END(0);
+}
+SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send) {  // TRK:188-222
   SssHot& hot = g_hot;
   uint32_t old = hot.ex_loc[e];
   if (old != POOL_NONE) {
@@ -940,18 +1028,25 @@ SSS_DEV void move_idle_executor(uint32_t src, int e) {
 }
 
 // set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
+SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key);
 SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
+  EVP2_BEGIN;
+  SetImg<uint8_t> r = get_idle_source_executors_(key);
+  EVP2_END(1);
+  return r;
+}
+SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
   SetImg<uint8_t> out;
   out.tab = g_sc.setB;
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
-  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0;
+  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0, out.cap = 0xFFFFFFFFu, out.big = nullptr;
   if (key == POOL_NONE) return out;
   SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
   cp.tab = g_sc.setA;
   for (int i = 0; i < 8; i++) cp.tab[i] = 0;
-  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0;
+  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0, cp.cap = 0xFFFFFFFFu, cp.big = nullptr;
   if (src.used != 0) {
     if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys());
     if (cp.mask == src.mask && src.fill == src.used) {
@@ -1116,7 +1211,7 @@ SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created emp
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
   g_sc.active_version++;
-  if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
+  if (pool_size(POOL_COMMON) > 0) H.curr_source = POOL_COMMON;
 }
 
 SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
@@ -1232,6 +1327,31 @@ SSS_DEV void fastctx_load(FastCtx& f) {
 
 #define LENW_LEN 0x3FFFFFFF
 
+// -DSSS_EVPROF (tools/evprof.sh): shader-clock ticks of the segments of an event-loop round, kept in
+// the header's profiling slots instead of the per-phase totals (timing builds only)
+#ifdef SSS_EVPROF
+struct EvProf {
+  uint64_t t[8];
+  uint64_t last;
+};
+#define EVP_DECL EvProf evp = {{0, 0, 0, 0, 0, 0, 0, 0}, wave_clock()}
+#define EVP_ARG , EvProf& evp
+#define EVP_PASS , evp
+#define EVP_MARK(i)                  \
+  do {                               \
+    uint64_t now_ = wave_clock();    \
+    evp.t[i] += now_ - evp.last;     \
+    evp.last = now_;                 \
+  } while (0)
+#define EVP_COUNT(i) (evp.t[i]++)
+#else
+#define EVP_DECL
+#define EVP_ARG
+#define EVP_PASS
+#define EVP_MARK(i) ((void)0)
+#define EVP_COUNT(i) ((void)0)
+#endif
+
 // the duration lists an executor that stays on pack stage `gs` can draw from next ("same stage"
 // mode of TPCH:75-106): one per candidate executor level (li == ri when the interval is closed)
 SSS_DEV void exdesc_fetch(const FastCtx& f, SssExDesc& xd, int gs, int li, int ri) {
@@ -1316,20 +1436,20 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 //     M = min over those bounds, over the times of all pending events that need the general handlers,
 //     and the next job arrival. Every pending fast event with t < M is popped before anything else
 //     can happen - in time order, and the events they push all land at >= M. That set is the batch;
-//   * the batch members rank themselves by time (a loop over the members with v_readlane: members
-//     are few); the rank gives each member its push counter and - because the number of raw
+//   * the batch members rank themselves by (time, push counter) - heapq's order, EVQ:35 - in a loop
+//     over the members with v_readlane (members are few); the rank gives each member its push counter and - because the number of raw
 //     generator outputs each event consumes is known beforehand (one for random() when its executor
 //     level interval is open, then one 32-bit half for the bounded integer, TPCH:208-235, numpy's
 //     buffered 32-bit path) - its position in the env's random stream, which the wave has produced
 //     ahead of time (rng_refill);
 //   * members of one stage decrement its task counter together; the last of them in time order
 //     leaves its duration as the stage's most recent one (ENV:604).
-// Anything unusual - equal times inside the batch, a stage that would run out of tasks mid-batch,
-// a draw that needs Lemire's rejection test, duration lists with one or no entry - shortens the
-// batch or leaves the round to the one-event-at-a-time path, which is always correct.
+// Anything unusual - a stage that would run out of tasks mid-batch, a draw that needs Lemire's
+// rejection test, duration lists with one or no entry - shortens the batch or leaves the round to the
+// one-event-at-a-time path, which is always correct.
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
-SSS_DEV int batch_fast_events(const FastCtx& f) {
+SSS_DEV int batch_fast_events(const FastCtx& f EVP_ARG) {
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
 #endif
@@ -1370,6 +1490,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f) {
   if (next_arr < M) M = next_arr;  // an arrival wins ties against executor events (EVQ:35, counters 0..J-1)
   bool V = cand && sl.t < M;
   uint64_t vm = wave_ballot(V);
+  EVP_MARK(0);
 #ifdef SSS_BATCH_STATS
   {
     uint64_t cm = wave_ballot(cand), tfm = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED), pend = wave_ballot(sl.t < __builtin_inf());
@@ -1388,24 +1509,22 @@ SSS_DEV int batch_fast_events(const FastCtx& f) {
   if (vm == 0) return 0;
   uint32_t nmax = (uint32_t)(64 - pos) >> 1;  // two raw outputs per event at most
   const uint32_t tag = (info & ~0xFFu) | (open ? 0x80u : 0u);  // (job, slot, stage) | draws random()
-  uint32_t rank, R, cb, ct;
-  for (;;) {
-    // rank = members before this one in time, R = how many of those draw random(),
-    // cb / ct = members of the same stage before this one / in total
-    uint32_t le = 0;
+  uint32_t rank = 0, R = 0, cb = 0, ct = 1;
+  while (vm & (vm - 1)) {  // a batch of one needs no ranking
+    // rank = members before this one in (time, push counter) order (EVQ:35: keys are unique),
+    // R = how many of those draw random(), cb / ct = members of the same stage before this one / in total
     rank = 0, R = 0, cb = 0, ct = 0;
     for (uint64_t m = vm; m; m &= m - 1) {
       const int k = ctz64(m);
       const double tk = wave_readlane_f64(sl.t, k);
+      const uint32_t qk = wave_readlane_u32(sl.seq, k);
       const uint32_t gk = wave_readlane_u32(tag, k);
-      const bool lt = tk < sl.t, same = ((gk ^ tag) >> 8) == 0;
+      const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq), same = ((gk ^ tag) >> 8) == 0;
       rank += lt ? 1u : 0u;
-      le += tk <= sl.t ? 1u : 0u;
       R += (lt && (gk & 0x80u)) ? 1u : 0u;
       cb += (lt && same) ? 1u : 0u;
       ct += same ? 1u : 0u;
     }
-    if (wave_ballot(V && le != rank + 1) != 0) { STAT(15, 1); return 0; }  // equal times: the push counters decide (EVQ:35), one at a time
     // the stage has fewer tasks left than events before this one, or more events than buffered randomness
     const bool over = V && (cb >= (uint32_t)st.remaining || rank >= nmax);
     if (wave_ballot(over) == 0) break;
@@ -1414,8 +1533,11 @@ SSS_DEV int batch_fast_events(const FastCtx& f) {
     V = V && rank < rcut;
     vm = wave_ballot(V);
     if (vm == 0) return 0;
+    if (!(vm & (vm - 1))) rank = 0, R = 0, cb = 0, ct = 1;
   }
   const uint32_t n = (uint32_t)popc64(vm);
+  STAT(18 + (n < 13 ? n : 13), 1);
+  EVP_MARK(1);
   // ---- the members' draws ----
   const uint32_t Fr = h0 ? rank >> 1 : (rank + 1) >> 1;  // raw outputs taken by the 32-bit draws of the members before
   const bool fresh = ((h0 + rank) & 1u) == 0;           // this member's 32-bit draw takes a new raw output (low half)
@@ -1467,6 +1589,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f) {
     }
   }
   wave_sync();
+  EVP_MARK(2);
   return (int)n;
 }
 
@@ -1586,14 +1709,16 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     double* of = B.obs_f64 + (size_t)env * SSS_OBS_F64;
     int ncommit = 0;
     if (srck != POOL_NONE) {
-      int p = pool_index(srck);
-      ncommit = (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
+      const SssPoolHdr hd = pool_hdr_get(srck);
+      ncommit = (int)hd.used - (int)hd.commit_from;
     }
     oi[OBS_N_NODES] = base_n, oi[OBS_N_EDGES] = base_e, oi[OBS_N_JOBS] = A, oi[OBS_N_SCHED] = h.n_sched;
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
     oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
     of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
+#ifndef SSS_EVPROF
     g_hot.h.prof[4] += wave_clock() - t_obs0;
+#endif
     g_hot.h.obs_n_nodes = base_n;
     g_hot.h.obs_n_sched = h.n_sched;
     g_hot.h.last_reward = reward;
@@ -1616,6 +1741,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   if (lane < g_c.E) lds_exdesc()[lane].gs = -1;
   lds_slot_ref()[lane] = 0;
+  if (lane < g_c.P.n_pc) lds_pc_keys()[lane] = POOL_NONE;
   wave_sync();
   int A = g_hot.h.n_active;
   for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
@@ -1639,7 +1765,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
     uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
     g_sc.free_slots = all & ~used;
-    g_sc.pending_free = -1, g_sc.pinned_job = -1;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.pc_next = 0;
     g_sc.events_this_step = 0;
     g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
     g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
@@ -1682,6 +1808,7 @@ SSS_DEV void env_end(uint8_t* base) {
       ((uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP];
   }
   for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
+  if (lane < g_c.P.n_pc && lds_pc_keys()[lane] != POOL_NONE && (lds_pc_lines()[lane].flags & PC_DIRTY)) pc_writeback(lane);
   if (lane < g_c.E) {  // the HBM image of an event does not name an LDS slot
     uint32_t info = g_hot.ev[lane].info;
     if (info_kind(info) != EV_NONE) g_hot.ev[lane].info = info_with_slot(info, INFO_SLOT_NONE);
@@ -1755,7 +1882,7 @@ SSS_DEV_NOINLINE void jobtime_build_set() {
   SetImg<uint16_t> all;
   all.tab = lds_jobset();
   for (int i = 0; i < 8; i++) all.tab[i] = 0;
-  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0;
+  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0, all.cap = 0xFFFFFFFFu, all.big = nullptr;
   for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active()[k], lds_keys());
   for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active()[k], lds_keys());
   g_sc.jobset_mask = (int32_t)all.mask;
@@ -1869,20 +1996,35 @@ SSS_DEV void resume_simulation() {
     // (no LDS flags, no barrier per event).
     uint64_t t_slow = 0;
     int status;
+    EVP_DECL;
     do {
       status = 0;
-      if (64 - g_sc.rng_pos < rng_need) rng_refill();
-      if (batch_fast_events(f) > 0) continue;
+      if (64 - g_sc.rng_pos < rng_need) {
+        rng_refill();
+        EVP_MARK(5);
+      }
+      EVP_COUNT(6);
+      if (batch_fast_events(f EVP_PASS) > 0) continue;
+      EVP_MARK(0);  // a round the batch path left early is charged to its first segment
       double t_win = 0.0;
       uint32_t info_win = 0;
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
+      EVP_MARK(3);
       if (lane == 0) status = handle_popped(f, ex, t_win, info_win, t_slow);
       status = (int)wave_lane0_u32((uint32_t)status);
+      EVP_MARK(4);
     } while (status == 0);
     if (lane == 0) {
       g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
+#ifdef SSS_EVPROF
+      for (int i = 0; i < 5; i++) H.prof[i] += evp.t[i];
+#ifndef SSS_EVPROF2
+      H.pad_[0] += evp.t[5], H.pad_[1] += evp.t[6];
+#endif
+#else
       H.prof[0] += t_slow;
+#endif
     }
     wave_sync();
     if (g_sc.f_done) {
@@ -1916,21 +2058,22 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   // nothing is cached while the records are (re)built in HBM
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   lds_slot_ref()[lane] = 0;
+  if (lane < g_c.P.n_pc) lds_pc_keys()[lane] = POOL_NONE;  // the pools are rebuilt in HBM below
   wave_sync();
   if (lane == 0) {
     g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    g_sc.pending_free = -1, g_sc.pinned_job = -1;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.pc_next = 0;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
     int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
     double last_ep_return = H.last_ep_return, last_ep_wall = H.last_ep_wall;
     uint64_t prof[5];
     for (int i = 0; i < 5; i++) prof[i] = H.prof[i];
-    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds;
+    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds, pad0_keep = H.pad_[0], pad1_keep = H.pad_[1];
     SssHdr z = {};
     H = z;
     for (int i = 0; i < 5; i++) H.prof[i] = prof[i];
-    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep;
+    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep, H.pad_[0] = pad0_keep, H.pad_[1] = pad1_keep;
     H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
     H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
@@ -2064,7 +2207,9 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   }
   wave_sync();
   uint64_t t1 = wave_clock();
+#ifndef SSS_EVPROF
   if (lane == 0) H.prof[1] += t1 - t0;
+#endif
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
   for (int a = lane; a < g_hot.h.n_active; a += 64) {  // ENV:203 selected_stages.clear(); active jobs at the round's end
     int j = lds_active()[a];
@@ -2102,7 +2247,9 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     }
     if (H.err) H.need_reset = 1;
     uint64_t t3 = wave_clock();
+#ifndef SSS_EVPROF
     H.prof[2] += t2 - t1, H.prof[3] += t3 - t2;
+#endif
   }
   wave_sync();
   return reward;
@@ -2161,8 +2308,8 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
 SSS_DEV int obs_num_committable() {
   uint32_t srck = g_hot.h.curr_source;
   if (srck == POOL_NONE) return 0;
-  int p = pool_index(srck);
-  return (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
+  const SssPoolHdr hd = pool_hdr_get(srck);
+  return (int)hd.used - (int)hd.commit_from;
 }
 
 // RoundRobinScheduler.schedule (reference schedulers/heuristics/round_robin.py:14-49 with

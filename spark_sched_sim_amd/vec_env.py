@@ -362,6 +362,8 @@ class VecSparkSchedSimEnv:
         prof = np.ascontiguousarray(hdr[:, HDR_PROF: HDR_PROF + 40]).view(np.uint64).sum(axis=0)
         for k, name in enumerate(("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe")):
             tot[name] = int(prof[k])
+        pad = np.ascontiguousarray(hdr[:, 272:288]).view(np.uint64).sum(axis=0)  # only written by -DSSS_EVPROF builds
+        tot["evprof_refill"], tot["evprof_rounds"] = int(pad[0]), int(pad[1])
         for name in ("n_fast", "n_batched", "n_rounds"):
             off = HDR_OFF[name]
             tot[name + "_events" if name != "n_rounds" else name] = int(np.ascontiguousarray(hdr[:, off: off + 8]).view(np.uint64).sum())

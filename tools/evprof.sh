@@ -1,12 +1,14 @@
 #!/bin/bash
-# GPU box: per-event cycle breakdown of the event loop (see profiles/r01_bench.md). Builds the library
-# with -DSSS_EVPROF (phase counters re-purposed: action = pop, reward = handler, observe = whole loop);
-# a second build adds -DSSS_EXPERIMENT_NO_GATHER (durations not read from the table: WRONG results,
-# timing only) to size the L2 gather inside the fast-path handler.
+# GPU box: where an event-loop round's time goes. Builds the library with -DSSS_EVPROF (the header's
+# phase counters are re-purposed: slow_events = batch part 1 (loads, classification, window min, ballot; also
+# the whole of a round the batch path left early), action = batch member loop, events = batch draws +
+# commit, reward = one-event pop, observe = one-event handler; pad0 = generator refills; pad1 = rounds),
+# runs the fused bench and prints ticks per round. The regular library is rebuilt afterwards.
 set -e
-cd $GRAFT_REPO_ROOT
-for extra in "" "-DSSS_EXPERIMENT_NO_GATHER"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DSSS_EVPROF $extra -I spark_sched_sim_amd/csrc -o spark_sched_sim_amd/csrc/libsss_hip.so spark_sched_sim_amd/csrc/sss_hip.hip
-  python bench.py --steps 400 --warmup 50 --no-cpu-baseline --single-mode --mode fused 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('fused [$extra]', d['value'], d['phase_ticks_per_step'], d['events_per_step'], d['fast_path_event_frac'])"
+cd "$(dirname "$0")/.."
+for cfg in c2 c3; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function -DSSS_EVPROF "$@" -I spark_sched_sim_amd/csrc -o spark_sched_sim_amd/csrc/libsss_hip.so spark_sched_sim_amd/csrc/sss_hip.hip
+  python bench.py --config $cfg --steps 400 --warmup 100 --no-cpu-baseline --no-decima --single-mode --mode fused --evprof 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); p=d['evprof']; print('$cfg fused', round(d['value']/1e6,2), 'M steps/s; events/step', round(d['events_per_step'],1), 'batched', round(d['batched_event_frac'],2), 'x', round(d['events_per_batch'],2)); print(json.dumps(p))"
 done
+python -m spark_sched_sim_amd.build --force > /dev/null
