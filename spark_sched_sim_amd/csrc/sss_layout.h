@@ -138,15 +138,6 @@ struct SssPoolHdr {        // 8 bytes: CPython set header + outgoing commitment 
   int16_t commit_from;
 };
 
-// one line of the LDS pool cache: the pool's header and, for tables of up to 32 slots, its table
-#define SSS_PC_INLINE 32
-struct SssPoolLine {       // 48 bytes
-  SssPoolHdr hdr;
-  uint8_t tab[SSS_PC_INLINE];
-  uint32_t flags;          // bit 0: differs from the HBM copy; bit 1: the table is larger than 32 slots and lives in HBM
-  uint32_t pad;
-};
-
 // per-env byte offsets, filled on the host by sss_compute_layout
 struct SssLayout {
   int32_t num_envs, E, J_cap, SP, L, n_pools, n_cap, ed_cap, max_edges_per_job;
@@ -163,7 +154,6 @@ struct SssParams {
   int32_t pool_bytes;      // dynamic LDS size
   int32_t off_active, off_old_active, off_slot_of, off_keys, off_jobset, off_cjobs, off_cstages, off_cdur, off_exdesc;  // byte offsets in g_pool
   int32_t off_slot_job, off_slot_ref;
-  int32_t off_pc_keys, off_pc_lines, n_pc;  // LDS cache of executor-pool images (sss_sim.h, pc_*): n_pc lines, a power of two
   int32_t max_edges;       // max template edges (flattened edge pass stride)
   int8_t lvl_of[8];        // pack level index of executor levels {5,10,20,40,50,60,80,100}, -1 if absent
   double mean_interarrival, moving_delay, warmup_delay, beta;
@@ -222,9 +212,6 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   P->off_keys = o, o += 2 * (J_cap + 8);
   P->off_jobset = o, o += 2 * jobset;
   o = (o + 15) & ~15;
-  P->n_pc = E <= 16 ? 16 : 32;
-  P->off_pc_keys = o, o += 4 * P->n_pc;
-  P->off_pc_lines = o, o += (int)sizeof(SssPoolLine) * P->n_pc;
   P->off_exdesc = o, o += (int)sizeof(SssExDesc) * E;
   o = (o + 15) & ~15;
   int per_slot = (int)sizeof(SssJob) + 8 * SP + 4 * SP;

@@ -48,7 +48,6 @@ struct alignas(16) SssScratch {
   int32_t events_this_step;
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
   int32_t pinned_job;             // job of the event being handled: its cache slot is not given away
-  int32_t pc_next;                // pool cache: next line to be replaced
   int32_t jobset_mask, f_need_jobtime;
   // the set image of (old active list + active list) only changes when a job arrives or completes:
   // versions of the two lists it was built from (valid within one launch)
@@ -471,8 +470,6 @@ template <typename T>
 struct SetImg {
   T* tab;
   uint32_t mask, fill, used, finger;
-  uint32_t cap;  // slots available at `tab`; a resize beyond it continues in `big` (pool images cached in LDS)
-  T* big;
 };
 
 template <typename T>
@@ -502,7 +499,6 @@ SSS_DEV void set_resize(SetImg<T>& s, uint32_t minused, uint16_t* keys) {
     uint32_t e = s.tab[i];
     if (e >= 2) keys[n++] = (uint16_t)(e - 2);
   }
-  if (newsize > s.cap) s.tab = s.big, s.cap = 0xFFFFFFFFu;  // the live keys are in `keys`: nothing to copy
   for (uint32_t i = 0; i < newsize; i++) s.tab[i] = 0;
   for (uint32_t i = 0; i < n; i++) set_insert_clean(s.tab, newsize - 1, keys[i]);
   s.mask = newsize - 1;
@@ -580,93 +576,22 @@ SSS_DEV uint32_t set_pop(SetImg<T>& s) {
   return key;
 }
 
-// ---- LDS cache of executor-pool images ----
-// The pools the event chain and the commitment rounds work on (the source pool, the job / stage
-// pools executors sit in) are a handful at any time, but every access used to be a dependent HBM
-// round trip on lane 0. n_pc lines, fully associative (the keys are compared four at a time),
-// replaced round robin, written back when replaced and at the end of the launch. A line holds the
-// pool's header and its table while that has at most 32 slots; larger tables stay in HBM.
-#define PC_DIRTY 1u
-#define PC_BIG 2u
-SSS_DEV uint32_t* lds_pc_keys() { return (uint32_t*)(g_pool + g_c.P.off_pc_keys); }
-SSS_DEV SssPoolLine* lds_pc_lines() { return (SssPoolLine*)(g_pool + g_c.P.off_pc_lines); }
-SSS_DEV uint8_t* pool_home_table(int p) { return g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E); }
-
-SSS_DEV int pc_find(uint32_t key) {  // any lane, read-only
-  const uint32_t* k = lds_pc_keys();
-  for (int i = 0; i < g_c.P.n_pc; i += 4) {
-    const uint4 q = *(const uint4*)(k + i);
-    if (q.x == key) return i;
-    if (q.y == key) return i + 1;
-    if (q.z == key) return i + 2;
-    if (q.w == key) return i + 3;
-  }
-  return -1;
-}
-SSS_DEV void pc_writeback(int i) {  // line -> HBM copy
-  SssPoolLine* ln = lds_pc_lines() + i;
-  int p = pool_index(lds_pc_keys()[i]);
-  g_c.pool_hdr[p] = ln->hdr;
-  if (!(ln->flags & PC_BIG)) {
-    uint64_t* home = (uint64_t*)pool_home_table(p);
-    for (uint32_t w = 0; w < ((uint32_t)ln->hdr.mask + 1) / 8; w++) home[w] = ((const uint64_t*)ln->tab)[w];
-  }
-  ln->flags &= ~PC_DIRTY;
-}
-SSS_DEV int pc_load(uint32_t key) {  // lane 0: the pool's line, fetched from HBM if it has none
-  int i = pc_find(key);
-  if (i >= 0) return i;
-  i = g_sc.pc_next;
-  g_sc.pc_next = (i + 1) & (g_c.P.n_pc - 1);
-  SssPoolLine* ln = lds_pc_lines() + i;
-  if (lds_pc_keys()[i] != POOL_NONE && (ln->flags & PC_DIRTY)) pc_writeback(i);
+SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
   int p = pool_index(key);
   SssPoolHdr hd = g_c.pool_hdr[p];
-  ln->hdr = hd;
-  if (hd.mask < SSS_PC_INLINE) {
-    const uint64_t* home = (const uint64_t*)pool_home_table(p);
-    for (uint32_t w = 0; w < ((uint32_t)hd.mask + 1) / 8; w++) ((uint64_t*)ln->tab)[w] = home[w];
-    ln->flags = 0;
-  } else
-    ln->flags = PC_BIG;
-  lds_pc_keys()[i] = key;
-  return i;
-}
-// header of a pool, read-only, any lane (the line if there is one, else the HBM copy)
-SSS_DEV SssPoolHdr pool_hdr_get(uint32_t key) {
-  int i = pc_find(key);
-  return i >= 0 ? lds_pc_lines()[i].hdr : g_c.pool_hdr[pool_index(key)];
-}
-// lane 0: header to modify
-SSS_DEV SssPoolHdr* pool_hdr_mut(uint32_t key) {
-  SssPoolLine* ln = lds_pc_lines() + pc_load(key);
-  ln->flags |= PC_DIRTY;
-  return &ln->hdr;
-}
-
-SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
-  SssPoolLine* ln = lds_pc_lines() + pc_load(key);
   SetImg<uint8_t> s;
-  s.big = pool_home_table(pool_index(key));
-  if (ln->flags & PC_BIG)
-    s.tab = s.big, s.cap = 0xFFFFFFFFu;
-  else
-    s.tab = ln->tab, s.cap = SSS_PC_INLINE;
-  s.mask = ln->hdr.mask, s.fill = ln->hdr.fill, s.used = ln->hdr.used, s.finger = 0;
+  s.tab = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E);
+  s.mask = hd.mask, s.fill = hd.fill, s.used = hd.used, s.finger = 0;
   return s;
 }
-// nothing may have been opened since the matching pool_open (the line is still there)
 SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
-  SssPoolLine* ln = lds_pc_lines() + pc_find(key);
-  ln->hdr.mask = (uint16_t)s.mask, ln->hdr.fill = (uint16_t)s.fill, ln->hdr.used = (uint16_t)s.used;
-  if (s.tab == s.big && s.mask < SSS_PC_INLINE) {  // shrunk back below the inline size: the table moves into the line
-    for (uint32_t w = 0; w < (s.mask + 1) / 8; w++) ((uint64_t*)ln->tab)[w] = ((const uint64_t*)s.big)[w];
-    ln->flags = PC_DIRTY;
-  } else
-    ln->flags = PC_DIRTY | (s.tab == s.big ? PC_BIG : 0u);
+  int p = pool_index(key);
+  g_c.pool_hdr[p].mask = (uint16_t)s.mask;
+  g_c.pool_hdr[p].fill = (uint16_t)s.fill;
+  g_c.pool_hdr[p].used = (uint16_t)s.used;
 }
-SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)pool_hdr_get(key).used; }
-SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)pool_hdr_get(key).commit_from; }
+SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
+SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
 
 // ------------------------------------------------------------------------------------------
 // tracker (lane 0)
@@ -686,8 +611,8 @@ SSS_DEV void publish_scan_inputs() {
 SSS_DEV int trk_num_committable() {  // TRK:107-113
   uint32_t k = H.curr_source;
   if (k == POOL_NONE) return 0;
-  const SssPoolHdr hd = lds_pc_lines()[pc_load(k)].hdr;
-  int n = (int)hd.used - (int)hd.commit_from;
+  int p = pool_index(k);
+  int n = (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
   CHECK(n >= 0);
   return n;
 }
@@ -728,9 +653,9 @@ SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
     hot.c_src[i] = src, hot.c_dst[i] = dst, hot.c_n[i] = (int16_t)n, hot.c_seq[i] = H.commit_seq++;
     H.n_commits = i + 1;
   }
-  SssPoolHdr* ph = pool_hdr_mut(src);
-  ph->commit_from = (int16_t)(ph->commit_from + n);
-  CHECK((int)ph->used >= (int)ph->commit_from);
+  int ps = pool_index(src);
+  g_c.pool_hdr[ps].commit_from = (int16_t)(g_c.pool_hdr[ps].commit_from + n);
+  CHECK((int)g_c.pool_hdr[ps].used >= (int)g_c.pool_hdr[ps].commit_from);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
     (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to + n);
@@ -750,9 +675,9 @@ SSS_DEV uint32_t trk_remove_commitment(int e, uint32_t dst) {
   CHECK(i < H.n_commits);
   if (i >= H.n_commits) return src;
   hot.c_n[i] = (int16_t)(hot.c_n[i] - 1);
-  SssPoolHdr* ph = pool_hdr_mut(src);
-  ph->commit_from = (int16_t)(ph->commit_from - 1);
-  CHECK(ph->commit_from >= 0);
+  int ps = pool_index(src);
+  g_c.pool_hdr[ps].commit_from = (int16_t)(g_c.pool_hdr[ps].commit_from - 1);
+  CHECK(g_c.pool_hdr[ps].commit_from >= 0);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
     (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to - 1);
@@ -1039,14 +964,14 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
   SetImg<uint8_t> out;
   out.tab = g_sc.setB;
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
-  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0, out.cap = 0xFFFFFFFFu, out.big = nullptr;
+  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0;
   if (key == POOL_NONE) return out;
   SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
   cp.tab = g_sc.setA;
   for (int i = 0; i < 8; i++) cp.tab[i] = 0;
-  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0, cp.cap = 0xFFFFFFFFu, cp.big = nullptr;
+  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0;
   if (src.used != 0) {
     if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys());
     if (cp.mask == src.mask && src.fill == src.used) {
@@ -1211,7 +1136,7 @@ SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created emp
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
   g_sc.active_version++;
-  if (pool_size(POOL_COMMON) > 0) H.curr_source = POOL_COMMON;
+  if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
 
 SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
@@ -1709,8 +1634,8 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     double* of = B.obs_f64 + (size_t)env * SSS_OBS_F64;
     int ncommit = 0;
     if (srck != POOL_NONE) {
-      const SssPoolHdr hd = pool_hdr_get(srck);
-      ncommit = (int)hd.used - (int)hd.commit_from;
+      int p = pool_index(srck);
+      ncommit = (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
     }
     oi[OBS_N_NODES] = base_n, oi[OBS_N_EDGES] = base_e, oi[OBS_N_JOBS] = A, oi[OBS_N_SCHED] = h.n_sched;
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
@@ -1741,7 +1666,6 @@ SSS_DEV void env_begin(const uint8_t* base) {
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   if (lane < g_c.E) lds_exdesc()[lane].gs = -1;
   lds_slot_ref()[lane] = 0;
-  if (lane < g_c.P.n_pc) lds_pc_keys()[lane] = POOL_NONE;
   wave_sync();
   int A = g_hot.h.n_active;
   for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
@@ -1765,7 +1689,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
     uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
     g_sc.free_slots = all & ~used;
-    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.pc_next = 0;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1;
     g_sc.events_this_step = 0;
     g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
     g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
@@ -1808,7 +1732,6 @@ SSS_DEV void env_end(uint8_t* base) {
       ((uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP];
   }
   for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
-  if (lane < g_c.P.n_pc && lds_pc_keys()[lane] != POOL_NONE && (lds_pc_lines()[lane].flags & PC_DIRTY)) pc_writeback(lane);
   if (lane < g_c.E) {  // the HBM image of an event does not name an LDS slot
     uint32_t info = g_hot.ev[lane].info;
     if (info_kind(info) != EV_NONE) g_hot.ev[lane].info = info_with_slot(info, INFO_SLOT_NONE);
@@ -1882,7 +1805,7 @@ SSS_DEV_NOINLINE void jobtime_build_set() {
   SetImg<uint16_t> all;
   all.tab = lds_jobset();
   for (int i = 0; i < 8; i++) all.tab[i] = 0;
-  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0, all.cap = 0xFFFFFFFFu, all.big = nullptr;
+  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0;
   for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active()[k], lds_keys());
   for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active()[k], lds_keys());
   g_sc.jobset_mask = (int32_t)all.mask;
@@ -2058,11 +1981,10 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   // nothing is cached while the records are (re)built in HBM
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   lds_slot_ref()[lane] = 0;
-  if (lane < g_c.P.n_pc) lds_pc_keys()[lane] = POOL_NONE;  // the pools are rebuilt in HBM below
   wave_sync();
   if (lane == 0) {
     g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.pc_next = 0;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
     int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
@@ -2308,8 +2230,8 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
 SSS_DEV int obs_num_committable() {
   uint32_t srck = g_hot.h.curr_source;
   if (srck == POOL_NONE) return 0;
-  const SssPoolHdr hd = pool_hdr_get(srck);
-  return (int)hd.used - (int)hd.commit_from;
+  int p = pool_index(srck);
+  return (int)g_c.pool_hdr[p].used - (int)g_c.pool_hdr[p].commit_from;
 }
 
 // RoundRobinScheduler.schedule (reference schedulers/heuristics/round_robin.py:14-49 with
