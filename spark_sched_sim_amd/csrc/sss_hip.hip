@@ -127,3 +127,11 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
 }
 
 #include "sss_host.h"
+
+#ifdef SSS_EVPROF3  // timing builds only (tools/debug/evprof3.sh): reads and clears the scoped profiler's table
+extern "C" int sss_debug_prof(unsigned long long* out64) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  static const unsigned long long zeros[64] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
+}
+#endif

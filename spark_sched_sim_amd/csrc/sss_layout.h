@@ -133,9 +133,10 @@ struct SssStage {          // 8 bytes
   int16_t remaining, executing, commit_to, moving_to;
 };
 
-struct SssPoolHdr {        // 8 bytes: CPython set header + outgoing commitment count
+struct SssPoolHdr {        // 16 bytes: CPython set header + outgoing commitment count + the table while it has 8 slots
   uint16_t mask, fill, used;
   int16_t commit_from;
+  uint8_t tab8[8];         // the table image when mask == 7 (nearly every pool); larger tables live in the pool's slot of the overflow area
 };
 
 // per-env byte offsets, filled on the host by sss_compute_layout
@@ -181,6 +182,14 @@ struct SssBuffers {        // raw device pointers of torch-allocated tensors
   int32_t* exec_supplies;  // i32[B][J_cap]
   int32_t* obs_i32;        // i32[B][SSS_OBS_I32]
   double* obs_f64;         // f64[B][SSS_OBS_F64]
+};
+
+// the first argument of every simulator kernel (sss_sim.h reads it back from the kernel-argument segment)
+struct SssKernelArgs {
+  SssLayout L;
+  SssBuffers B;
+  SssParams P;
+  SssPackDev pk;
 };
 
 static inline int64_t sss_align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -245,7 +254,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->off_t_completed = o, o += 8 * (int64_t)J_cap;
   L->off_stages = o, o = sss_align(o + 8 * (int64_t)J_cap * SP, 64);
   L->off_durations = o, o = sss_align(o + 4 * (int64_t)J_cap * SP, 64);
-  L->off_pool_hdr = o, o = sss_align(o + 8 * (int64_t)L->n_pools, 64);
+  L->off_pool_hdr = o, o = sss_align(o + (int64_t)sizeof(SssPoolHdr) * L->n_pools, 64);
   L->off_pool_tab = o, o += (int64_t)sss_pool_table_bytes(E) * L->n_pools;
   L->off_dur_ring = o, o += 8 * SSS_DUR_RING;
   L->off_old_active = o, o += 2 * (int64_t)J_cap;
@@ -256,4 +265,4 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
 static_assert(sizeof(SssHdr) == 288, "SssHdr must be 288 bytes");
 static_assert(sizeof(SssHot) % 16 == 0, "SssHot is copied with 16-byte accesses");
 static_assert(sizeof(SssJob) == 64, "SssJob must be one 64-byte line");
-static_assert(sizeof(SssStage) == 8 && sizeof(SssPoolHdr) == 8, "packed records");
+static_assert(sizeof(SssStage) == 8 && sizeof(SssPoolHdr) == 16, "packed records");

@@ -34,6 +34,8 @@
 // active-job list, the job -> cache-slot map, the LDS cache of the ACTIVE jobs' records and stage
 // counters (what the event chain touches on every event), and scratch for set images.
 struct alignas(16) SssScratch {
+  uint8_t pool8[8];  // the 8-slot table of the pool that is open (pool_open / pool_close)
+  uint8_t pad8_[8];
   // the next raw outputs of the env's PCG64 stream, produced 64 at a time by the whole wave
   // (rng_refill); rng_pos of them are consumed; rng_pos == 64: none buffered, the header holds the
   // generator's state as numpy would have it
@@ -59,15 +61,18 @@ struct alignas(16) SssScratch {
   int16_t fc_num[SSS_MAX_EXEC];
 };
 
-#define SSS_STATIC_LDS_BYTES ((int)(sizeof(SssHot) + sizeof(SssScratch) + 512))  // + Ctx (g_c), checked below
+#define SSS_STATIC_LDS_BYTES ((int)(sizeof(SssHot) + sizeof(SssScratch)))
 
 SSS_SHARED SssHot g_hot;
 SSS_SHARED SssScratch g_sc;
 SSS_SHARED_DYN(g_pool);
 
-// Per-launch context: this env's HBM pointers, the workload-pack pointers and the small
-// parameters. It lives in LDS (not in a struct passed by reference): every function reads what it
-// needs with a ds_read at a fixed address, nothing is spilled to scratch or re-derived per call.
+// Per-launch context: this env's HBM pointers, the workload-pack pointers and the small parameters.
+// All of it is a function of the kernel arguments (every simulator kernel takes SssKernelArgs first)
+// and the workgroup id, so any function - inlined or not - reads what it needs from the
+// kernel-argument segment: scalar loads the compiler knows to be invariant (they are merged and
+// hoisted freely, cost no LDS round trip and no LDS space) plus a little scalar arithmetic.
+// `g_c.x` builds the view and uses one member; everything unused folds away.
 struct Ctx {
   uint16_t* active_g;
   SssJob* jobs;
@@ -82,26 +87,28 @@ struct Ctx {
   SssParams P;
   int E, J_cap, SP;
 };
-SSS_SHARED Ctx g_c;
-static_assert(sizeof(Ctx) <= 512, "SSS_STATIC_LDS_BYTES reserves 512 bytes for Ctx");
-
-SSS_DEV void ctx_init(uint8_t* env_base, const SssLayout& L, const SssParams& P, const SssPackDev& pk) {
-  if (wave_lane() == 0) {
-    g_c.active_g = (uint16_t*)(env_base + L.off_active);
-    g_c.jobs = (SssJob*)(env_base + L.off_jobs);
-    g_c.t_arrival = (double*)(env_base + L.off_t_arrival);
-    g_c.t_completed = (double*)(env_base + L.off_t_completed);
-    g_c.stages = (SssStage*)(env_base + L.off_stages);
-    g_c.durations = (float*)(env_base + L.off_durations);
-    g_c.pool_hdr = (SssPoolHdr*)(env_base + L.off_pool_hdr);
-    g_c.pool_tab = env_base + L.off_pool_tab;
-    g_c.dur_ring = (double*)(env_base + L.off_dur_ring);
-    g_c.pk = pk;
-    g_c.P = P;
-    g_c.E = L.E, g_c.J_cap = L.J_cap, g_c.SP = L.SP;
-  }
-  wave_sync();
+SSS_DEV Ctx ctx_make() {
+  const SssKernelArgs* a = (const SssKernelArgs*)SSS_KERNARG_PTR();
+  uint8_t* env_base = (uint8_t*)a->B.state + (size_t)wave_env() * (size_t)a->L.env_stride;
+  Ctx c;
+  c.active_g = (uint16_t*)(env_base + a->L.off_active);
+  c.jobs = (SssJob*)(env_base + a->L.off_jobs);
+  c.t_arrival = (double*)(env_base + a->L.off_t_arrival);
+  c.t_completed = (double*)(env_base + a->L.off_t_completed);
+  c.stages = (SssStage*)(env_base + a->L.off_stages);
+  c.durations = (float*)(env_base + a->L.off_durations);
+  c.pool_hdr = (SssPoolHdr*)(env_base + a->L.off_pool_hdr);
+  c.pool_tab = env_base + a->L.off_pool_tab;
+  c.dur_ring = (double*)(env_base + a->L.off_dur_ring);
+  c.pk = a->pk;
+  c.P = a->P;
+  c.E = a->L.E, c.J_cap = a->L.J_cap, c.SP = a->L.SP;
+  return c;
 }
+#define g_c (ctx_make())
+
+SSS_DEV void prof3_clear();
+SSS_DEV void ctx_init() { prof3_clear(); }
 
 #define H (g_hot.h)
 #ifdef SSS_CHECK_TRACE  // emulator debugging: say which invariant broke
@@ -136,6 +143,31 @@ extern "C" { extern long long sss_batch_stats[32]; }
 #define STAT(i, v) ((void)(wave_lane() == 0 ? (sss_batch_stats[i] += (v)) : 0))
 #else
 #define STAT(i, v) ((void)0)
+#endif
+
+// -DSSS_EVPROF3 (tools/debug/evprof3.sh): inclusive shader-clock ticks and call counts of the lane-0
+// procedures, in a device-global table read back through sss_debug_prof (timing builds only)
+#ifdef SSS_EVPROF3
+__device__ unsigned long long g_prof3[64];
+SSS_SHARED unsigned long long g_prof3_lds[64];  // per-wave totals, added to the table once per launch (prof3_flush)
+struct Prof3Scope {
+  int id;
+  uint64_t t0;
+  __device__ Prof3Scope(int i) : id(i), t0(wave_clock()) {}
+  __device__ ~Prof3Scope() {
+    if (wave_lane() == 0) g_prof3_lds[2 * id] += wave_clock() - t0, g_prof3_lds[2 * id + 1] += 1;
+  }
+};
+#define PROF3(id) Prof3Scope prof3_scope_##id(id)
+SSS_DEV void prof3_clear() { g_prof3_lds[wave_lane()] = 0; }
+SSS_DEV void prof3_flush() {
+  wave_sync();
+  if (g_prof3_lds[wave_lane()]) atomicAdd(&g_prof3[wave_lane()], g_prof3_lds[wave_lane()]);
+}
+#else
+SSS_DEV void prof3_clear() {}
+SSS_DEV void prof3_flush() {}
+#define PROF3(id) ((void)0)
 #endif
 
 // ---- LDS pool views ----
@@ -470,6 +502,10 @@ template <typename T>
 struct SetImg {
   T* tab;
   uint32_t mask, fill, used, finger;
+  uint32_t cap;  // slots available at `tab`; a resize beyond it continues in `big` (pool images: 8 inline slots, then the overflow area)
+  T* big;
+  T* small;      // where an 8-slot table goes (pool images), or nullptr
+  uint32_t aux;  // pool images: the record's outgoing commitment count, carried from pool_open to pool_close
 };
 
 template <typename T>
@@ -499,6 +535,10 @@ SSS_DEV void set_resize(SetImg<T>& s, uint32_t minused, uint16_t* keys) {
     uint32_t e = s.tab[i];
     if (e >= 2) keys[n++] = (uint16_t)(e - 2);
   }
+  if (newsize > s.cap)
+    s.tab = s.big, s.cap = 0xFFFFFFFFu;  // the live keys are in `keys`: nothing to copy
+  else if (newsize <= 8 && s.small)
+    s.tab = s.small, s.cap = 8;          // a pool image that fits its record again
   for (uint32_t i = 0; i < newsize; i++) s.tab[i] = 0;
   for (uint32_t i = 0; i < n; i++) set_insert_clean(s.tab, newsize - 1, keys[i]);
   s.mask = newsize - 1;
@@ -576,19 +616,33 @@ SSS_DEV uint32_t set_pop(SetImg<T>& s) {
   return key;
 }
 
+// A pool's record is 16 bytes: the set header, the outgoing commitment count and - while the table
+// has 8 slots, which is nearly always - the table itself. pool_open fetches the record with one
+// access and works on the table in LDS scratch; pool_close stores the record with one access.
+// Tables that have grown live in the pool's slot of the overflow area (g_c.pool_tab).
 SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
   int p = pool_index(key);
-  SssPoolHdr hd = g_c.pool_hdr[p];
+  const uint4 rec = *(const uint4*)(g_c.pool_hdr + p);  // mask | fill << 16, used | commit_from << 16, tab8[0..3], tab8[4..7]
   SetImg<uint8_t> s;
-  s.tab = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E);
-  s.mask = hd.mask, s.fill = hd.fill, s.used = hd.used, s.finger = 0;
+  s.mask = rec.x & 0xFFFFu, s.fill = rec.x >> 16, s.used = rec.y & 0xFFFFu, s.finger = 0, s.aux = rec.y >> 16;
+  s.big = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E);
+  s.small = g_sc.pool8;
+  if (s.mask == 7) {
+    *(uint2*)g_sc.pool8 = mk_u2(rec.z, rec.w);
+    s.tab = g_sc.pool8, s.cap = 8;
+  } else
+    s.tab = s.big, s.cap = 0xFFFFFFFFu;
   return s;
 }
+// nothing else may have been opened in between (one scratch table), no commitment of the pool changed
 SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
-  int p = pool_index(key);
-  g_c.pool_hdr[p].mask = (uint16_t)s.mask;
-  g_c.pool_hdr[p].fill = (uint16_t)s.fill;
-  g_c.pool_hdr[p].used = (uint16_t)s.used;
+  SssPoolHdr* hd = g_c.pool_hdr + pool_index(key);
+  const uint32_t w0 = s.mask | (s.fill << 16), w1 = (s.used & 0xFFFFu) | (s.aux << 16);
+  if (s.mask == 7) {
+    const uint2 t = *(const uint2*)g_sc.pool8;
+    *(uint4*)hd = mk_u4(w0, w1, t.x, t.y);
+  } else
+    *(uint2*)hd = mk_u2(w0, w1);
 }
 SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
 SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
@@ -638,6 +692,7 @@ SSS_DEV void add_supply(int job, int d) {
 }
 
 SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
+  PROF3(1);
   uint32_t src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE) return;
@@ -666,6 +721,7 @@ SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
 
 // returns the source pool key (TRK:159-176, 240-251)
 SSS_DEV uint32_t trk_remove_commitment(int e, uint32_t dst) {
+  PROF3(2);
   SssHot& hot = g_hot;
   uint32_t src = hot.ex_loc[e];
   CHECK(src != POOL_NONE);
@@ -715,22 +771,99 @@ SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {
   trk_move_executor_to_pool_(e, new_pool, send);
   EVP2_END(0);
 }
+// ---- 8-slot set images held in a register (mask == 7: LINEAR_PROBES never applies, i + 9 > mask) ----
+SSS_DEV uint32_t t8_get(uint64_t t, uint32_t i) { return (uint32_t)(t >> (8 * i)) & 0xFFu; }
+SSS_DEV uint64_t t8_set(uint64_t t, uint32_t i, uint32_t v) { return (t & ~(0xFFull << (8 * i))) | ((uint64_t)v << (8 * i)); }
+SSS_DEV bool set8_remove(uint64_t& t, uint32_t& used, uint32_t key) {  // set_remove
+  uint32_t i = key & 7, perturb = key;
+  for (;;) {
+    uint32_t e = t8_get(t, i);
+    if (e == 0) return false;
+    if (e == key + 2) {
+      t = t8_set(t, i, 1);
+      used--;
+      return true;
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & 7;
+  }
+}
+// set_add; returns true when the table has to be resized afterwards (fill * 5 >= mask * 3)
+SSS_DEV bool set8_add(uint64_t& t, uint32_t& fill, uint32_t& used, uint32_t key) {
+  uint32_t i = key & 7, perturb = key;
+  int freeslot = -1;
+  for (;;) {
+    uint32_t e = t8_get(t, i);
+    if (e == 0) break;
+    if (e == key + 2) return false;
+    if (e == 1) freeslot = (int)i;
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & 7;
+  }
+  if (freeslot >= 0) {
+    used++;
+    t = t8_set(t, (uint32_t)freeslot, key + 2);
+    return false;
+  }
+  fill++, used++;
+  t = t8_set(t, i, key + 2);
+  return fill * 5 >= 7 * 3;
+}
+
 SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send) {  // TRK:188-222
+  PROF3(3);
   SssHot& hot = g_hot;
   uint32_t old = hot.ex_loc[e];
-  if (old != POOL_NONE) {
-    SetImg<uint8_t> s = pool_open(old);
-    bool was = set_remove(s, (uint32_t)e);
-    CHECK(was);
-    pool_close(old, s);
-    hot.ex_loc[e] = POOL_NONE;
-  }
-  if (!send) {
-    hot.ex_loc[e] = new_pool;
-    SetImg<uint8_t> s = pool_open(new_pool);
-    set_add(s, (uint32_t)e, lds_keys());
-    pool_close(new_pool, s);
-    return;
+  const bool has_old = old != POOL_NONE, has_new = !send;
+  const bool same = has_old && has_new && old == new_pool;
+  // both records are fetched up front (one round trip); 8-slot images are worked on in registers
+  SssPoolHdr* ho = g_c.pool_hdr + (has_old ? pool_index(old) : 0);
+  SssPoolHdr* hn = g_c.pool_hdr + (has_new ? pool_index(new_pool) : 0);
+  uint4 ro = mk_u4(7u, 0u, 0u, 0u), rn = ro;
+  if (has_old) ro = *(const uint4*)ho;
+  if (has_new && !same) rn = *(const uint4*)hn;
+  if ((ro.x & 0xFFFFu) == 7 && (rn.x & 0xFFFFu) == 7) {
+    if (has_old) {
+      uint64_t t = (uint64_t)ro.z | ((uint64_t)ro.w << 32);
+      uint32_t used = ro.y & 0xFFFFu;
+      bool was = set8_remove(t, used, (uint32_t)e);
+      CHECK(was);
+      ro.y = (ro.y & 0xFFFF0000u) | used, ro.z = (uint32_t)t, ro.w = (uint32_t)(t >> 32);
+      if (!same) *(uint4*)ho = ro;
+      hot.ex_loc[e] = POOL_NONE;
+    }
+    if (has_new) {
+      if (same) rn = ro;
+      hot.ex_loc[e] = new_pool;
+      uint64_t t = (uint64_t)rn.z | ((uint64_t)rn.w << 32);
+      uint32_t fill = rn.x >> 16, used = rn.y & 0xFFFFu;
+      if (set8_add(t, fill, used, (uint32_t)e)) {
+        // set_table_resize(used * 4): through the scratch table, the result may have more than 8 slots
+        SetImg<uint8_t> s;
+        *(uint2*)g_sc.pool8 = mk_u2((uint32_t)t, (uint32_t)(t >> 32));
+        s.tab = g_sc.pool8, s.cap = 8, s.small = g_sc.pool8, s.big = g_c.pool_tab + (size_t)pool_index(new_pool) * sss_pool_table_bytes(g_c.E);
+        s.mask = 7, s.fill = fill, s.used = used, s.finger = 0, s.aux = rn.y >> 16;
+        set_resize(s, s.used * 4, lds_keys());
+        pool_close(new_pool, s);
+      } else
+        *(uint4*)hn = mk_u4(7u | (fill << 16), (rn.y & 0xFFFF0000u) | used, (uint32_t)t, (uint32_t)(t >> 32));
+      return;
+    }
+  } else {
+    if (has_old) {
+      SetImg<uint8_t> s = pool_open(old);
+      bool was = set_remove(s, (uint32_t)e);
+      CHECK(was);
+      pool_close(old, s);
+      hot.ex_loc[e] = POOL_NONE;
+    }
+    if (has_new) {
+      hot.ex_loc[e] = new_pool;
+      SetImg<uint8_t> s = pool_open(new_pool);
+      set_add(s, (uint32_t)e, lds_keys());
+      pool_close(new_pool, s);
+      return;
+    }
   }
   int nj = key_job(new_pool), ns = key_stage(new_pool);
   CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
@@ -761,6 +894,7 @@ SSS_DEV bool stage_completed(const SssStage& st) { return st.remaining == 0 && s
 
 // JOB:65-73,100-128: stage s of job j completed; returns whether the frontier gained stages
 SSS_DEV bool job_record_stage_completion(int j, int s) {
+  PROF3(4);
   SssJob& job = (*jobp(j));
   CHECK((job.active_mask & bit64(s)) && (job.frontier_mask & bit64(s)));
   uint64_t active = job.active_mask & ~bit64(s);
@@ -805,6 +939,7 @@ SSS_DEV void executor_interval(int n, int& li, int& ri) {
 // draw) are resolved once per template on the host into `eff` (sss_host.h: sss_build_eff), so the
 // device does one descriptor load, the draw, and one value load.
 SSS_DEV double task_duration(int j, int s, int e) {
+  PROF3(5);
   const SssJob* job = jobp(j);
   int gs = job->gs_base + s;
   int n_local = popc64(job->local_mask);
@@ -859,6 +994,7 @@ SSS_DEV bool job_passes_filter(int j, int source_job_id) {
 
 // ENV:821-845 -> (job, stage) or job = -1
 SSS_DEV_NOINLINE void find_backup_stage(int e, int& out_j, int& out_s) {
+  PROF3(6);
   out_j = -1, out_s = -1;
   int ejob = g_hot.ex_job[e];
   CHECK(ejob >= 0);
@@ -918,6 +1054,7 @@ SSS_DEV void push_event(int e, double t, int kind, int j, int s) {  // EVQ:34-35
 }
 
 SSS_DEV void execute_next_task(int e, int j, int s) {  // ENV:584-615
+  PROF3(7);
   SssStage& st = (*stgp(j, s));
   CHECK(st.remaining > 0 && g_hot.ex_job[e] == j && !g_hot.ex_executing[e]);
   st.remaining = (int16_t)(st.remaining - 1);  // STG:53-58
@@ -932,6 +1069,7 @@ SSS_DEV void execute_next_task(int e, int j, int s) {  // ENV:584-615
 }
 
 SSS_DEV void send_executor(int e, int j, int s) {  // ENV:617-637
+  PROF3(8);
   CHECK(!g_hot.ex_executing[e] && g_hot.ex_job[e] != j);
   trk_move_executor_to_pool(e, key_stage_pool(j, s), true);
   int oj = g_hot.ex_job[e];
@@ -961,17 +1099,18 @@ SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
   return r;
 }
 SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
+  PROF3(9);
   SetImg<uint8_t> out;
   out.tab = g_sc.setB;
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
-  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0;
+  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0, out.cap = 0xFFFFFFFFu, out.big = nullptr, out.small = nullptr;
   if (key == POOL_NONE) return out;
   SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
   cp.tab = g_sc.setA;
   for (int i = 0; i < 8; i++) cp.tab[i] = 0;
-  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0;
+  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0, cp.cap = 0xFFFFFFFFu, cp.big = nullptr, cp.small = nullptr;
   if (src.used != 0) {
     if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys());
     if (cp.mask == src.mask && src.fill == src.used) {
@@ -993,6 +1132,7 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
 
 // ENV:745-782 with executor_ids=None: all idle executors of `src`, in set order
 SSS_DEV_NOINLINE void move_idle_executors_all(uint32_t src) {
+  PROF3(10);
   if (src == POOL_NONE) src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
@@ -1013,6 +1153,7 @@ SSS_DEV_NOINLINE void move_idle_executors_all(uint32_t src) {
 }
 
 SSS_DEV_NOINLINE void move_executor_to_stage(int e, int j, int s) {  // ENV:784-819
+  PROF3(11);
   if ((*stgp(j, s)).remaining == 0) {
     // _try_backup_schedule
     int bj, bs;
@@ -1039,6 +1180,9 @@ SSS_DEV_NOINLINE void move_executor_to_stage(int e, int j, int s) {  // ENV:784-
 }
 
 SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
+  // the executor is about to work for (or travel to) the destination's job, whose records then get
+  // a cache slot anyway (push_event): taking it now turns the scattered HBM accesses below into LDS ones
+  if (dst != POOL_COMMON) cache_acquire(key_job(dst));
   uint32_t src = trk_remove_commitment(e, dst);
   if (H.err) return;
   if (dst == POOL_COMMON) {
@@ -1049,6 +1193,7 @@ SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
 }
 
 SSS_DEV_NOINLINE void fulfill_commitments_from_source() {  // ENV:730-743
+  PROF3(12);
   SssHot& hot = g_hot;
   uint32_t src = H.curr_source;
   SetImg<uint8_t> idle = get_idle_source_executors(src);
@@ -1095,6 +1240,7 @@ SSS_DEV void commit_remaining_executors() {  // ENV:487-503
 // fall back to the HBM copy. Slots are written back when their job completes, when they are handed
 // to another job, and at the end of the launch.
 SSS_DEV void cache_release(int j) {  // LDS -> HBM, slot becomes free
+  PROF3(20);
   int k = lds_slot_of()[j];
   if (k == SLOT_NONE) return;
   g_c.jobs[j] = lds_cjobs()[k];
@@ -1106,6 +1252,7 @@ SSS_DEV void cache_release(int j) {  // LDS -> HBM, slot becomes free
   g_sc.free_slots |= bit64(k);
 }
 SSS_DEV int cache_acquire(int j) {  // HBM -> LDS if the job has no slot yet; returns its slot or SLOT_NONE
+  PROF3(19);
   int k = lds_slot_of()[j];
   if (k != SLOT_NONE) return k;
   if (g_sc.free_slots == 0) {
@@ -1133,6 +1280,7 @@ SSS_DEV int cache_acquire(int j) {  // HBM -> LDS if the job has no slot yet; re
 }
 
 SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created empty at reset)
+  PROF3(13);
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
   g_sc.active_version++;
@@ -1140,6 +1288,7 @@ SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created emp
 }
 
 SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
+  PROF3(14);
   job_attach_executor(j, e);
   SssStage& st = (*stgp(j, s));
   st.moving_to = (int16_t)(st.moving_to - 1);  // TRK:185-187
@@ -1150,6 +1299,7 @@ SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
 }
 
 SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
+  PROF3(15);
   if (pool_size(key_job_pool(j)) > 0) move_idle_executors_all(key_job_pool(j));
   CHECK(pool_size(key_job_pool(j)) == 0);
   int k;
@@ -1175,6 +1325,7 @@ SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
 }
 
 SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-483
+  PROF3(16);
   SssStage& st = (*stgp(j, s));
   CHECK(!stage_completed(st));
   st.executing = (int16_t)(st.executing - 1);  // STG:60-62
@@ -1375,6 +1526,7 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
 SSS_DEV int batch_fast_events(const FastCtx& f EVP_ARG) {
+  PROF3(30);
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
 #endif
@@ -1524,6 +1676,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f EVP_ARG) {
 // n_active / source job come from the mailbox lane 0 filled before the preceding wave_sync
 // (publish_scan_inputs): lane 0 may already be past this function when another lane reads them.
 SSS_DEV int find_schedulable_all() {
+  PROF3(21);
   int lane = wave_lane();
   int A = g_sc.m_n_active;
   int src_job = g_sc.m_src_job;
@@ -1547,6 +1700,7 @@ SSS_DEV int find_schedulable_all() {
 
 // _observe (ENV:345-406) + utils.subgraph (utils.py:5-22) into the env's padded output rows
 SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env, double reward) {
+  PROF3(22);
   int lane = wave_lane();
   uint64_t t_obs0 = wave_clock();
   const SssHdr& h = g_hot.h;
@@ -1657,6 +1811,7 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
 // HBM -> LDS: the hot block verbatim, the active-job list, and the records + stage counters of the
 // first n_slots active jobs into the cache. LDS -> HBM at the end of the launch.
 SSS_DEV void env_begin(const uint8_t* base) {
+  PROF3(23);
   int lane = wave_lane();
   {
     const uint4* s = (const uint4*)base;
@@ -1713,6 +1868,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
 }
 
 SSS_DEV void env_end(uint8_t* base) {
+  PROF3(24);
   int lane = wave_lane();
   wave_sync();
   if (lane == 0) rng_canonicalize();  // the HBM image never depends on what was buffered
@@ -1750,6 +1906,7 @@ SSS_DEV void env_end(uint8_t* base) {
 
 // ENV:275-315. Returns false if the action was rejected (state untouched).
 SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
+  PROF3(17);
   // action_space.contains: stage_idx in [-1, n_nodes), num_exec in [1, E] (ENV:85-94, 404)
   if (stage_idx < -1 || stage_idx >= H.obs_n_nodes || num_exec < 1 || num_exec > g_c.E) {
     H.err = SSS_ERR_ACTION_SPACE;
@@ -1802,16 +1959,18 @@ SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
 // set image (jobtime_build_set), then all lanes evaluate one table slot each and the terms are
 // added in slot order (jobtime_sum) - the additions stay sequential, the HBM reads do not.
 SSS_DEV_NOINLINE void jobtime_build_set() {
+  PROF3(18);
   SetImg<uint16_t> all;
   all.tab = lds_jobset();
   for (int i = 0; i < 8; i++) all.tab[i] = 0;
-  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0;
+  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0, all.cap = 0xFFFFFFFFu, all.big = nullptr, all.small = nullptr;
   for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active()[k], lds_keys());
   for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active()[k], lds_keys());
   g_sc.jobset_mask = (int32_t)all.mask;
 }
 
 SSS_DEV double jobtime_sum() {
+  PROF3(25);
   int lane = wave_lane();
   double wall_old = g_sc.wall_old, wall = g_hot.h.wall_time;
   int mask = g_sc.jobset_mask;
@@ -1851,6 +2010,7 @@ SSS_DEV double jobtime_sum() {
 // lane 0: one popped event. Returns 0 = keep going, 1 = queue empty / failed, 2 = a scan is needed
 // (committable executors exist).
 SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_win, uint64_t& t_slow) {
+  PROF3(31);
   if (ex == POP_EMPTY) return 1;
   H.n_events++;
   g_sc.events_this_step++;
@@ -1905,6 +2065,7 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
 }
 
 SSS_DEV void resume_simulation() {
+  PROF3(26);
   int lane = wave_lane();
   FastCtx f;
   fastctx_load(f);
@@ -1976,6 +2137,7 @@ SSS_DEV void resume_simulation() {
 
 // episode initialisation: ENV:127-186 + TPCH:54-73,176-206 + TRK:32-71
 SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
+  PROF3(27);
   int lane = wave_lane();
   SssHot& hot = g_hot;
   // nothing is cached while the records are (re)built in HBM
@@ -2073,9 +2235,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   // pools: every job / stage pool starts as an empty 8-slot set (TRK:73-96)
   int n_pools = 1 + g_c.J_cap + J * g_c.SP;
   for (int p = lane; p < n_pools; p += 64) {
-    SssPoolHdr hd = {7, 0, 0, 0};
-    g_c.pool_hdr[p] = hd;
-    *(uint64_t*)(g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E)) = 0ull;
+    *(uint4*)(g_c.pool_hdr + p) = mk_u4(7u, 0u, 0u, 0u);  // mask 7, fill 0, used 0, no commitments, empty 8-slot table
   }
   wave_sync();
   if (lane == 0 && !H.err) {
@@ -2099,6 +2259,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
 
 // ENV:188-221. `reward` is valid on lane 0 (and uniform).
 SSS_DEV double do_step(int stage_idx, int num_exec) {
+  PROF3(28);
   int lane = wave_lane();
   uint64_t t0 = wave_clock();
   if (lane == 0) {
@@ -2181,19 +2342,12 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
 // kernels
 // ------------------------------------------------------------------------------------------
 
-struct SssKernelArgs {
-  SssLayout L;
-  SssBuffers B;
-  SssParams P;
-  SssPackDev pk;
-};
-
 // reset envs whose mask byte is non-zero (mask == nullptr: all)
 SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const double* time_limits, const uint8_t* mask) {
   int env = wave_env();
   if (mask && !mask[env]) return;
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  ctx_init(base, a.L, a.P, a.pk);
+  ctx_init();
   env_begin(base);
   do_reset(a.L, seeds[env], time_limits ? time_limits[env] : __builtin_inf());
   write_observation(a.L, a.B, env, 0.0);
@@ -2206,7 +2360,7 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
   int env = wave_env();
   if (stage_idx[env] == SSS_SKIP_ENV) return;  // wave-uniform: the env is not touched at all
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  ctx_init(base, a.L, a.P, a.pk);
+  ctx_init();
   env_begin(base);
   double reward = 0.0;
   // the ballot doubles as the barrier between "all lanes read the header" and lane 0 rewriting it
@@ -2218,6 +2372,7 @@ SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const
   }
   write_observation(a.L, a.B, env, reward);
   env_end(base);
+  prof3_flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2325,6 +2480,7 @@ SSS_DEV void policy_hash(int p_none_permille, int& stage_idx, int& num_exec) {
 enum { SSS_POLICY_FAIR = 0, SSS_POLICY_FIFO = 1, SSS_POLICY_HASH = 2 };
 
 SSS_DEV void run_policy(int policy, int param, int& stage_idx, int& num_exec) {
+  PROF3(29);
   if (policy == SSS_POLICY_HASH)
     policy_hash(param, stage_idx, num_exec);
   else
@@ -2335,7 +2491,7 @@ SSS_DEV void run_policy(int policy, int param, int& stage_idx, int& num_exec) {
 SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_t* stage_idx, int32_t* num_exec) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  ctx_init(base, a.L, a.P, a.pk);
+  ctx_init();
   env_begin(base);
   int si, ne;
   run_policy(policy, param, si, ne);
@@ -2347,7 +2503,7 @@ SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_
 SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
-  ctx_init(base, a.L, a.P, a.pk);
+  ctx_init();
   env_begin(base);
   for (int it = 0; it < n_steps; it++) {
     bool over = wave_ballot(g_hot.h.terminated || g_hot.h.need_reset) != 0;
@@ -2364,6 +2520,7 @@ SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n
     wave_sync();
   }
   env_end(base);
+  prof3_flush();
 }
 
 #undef H

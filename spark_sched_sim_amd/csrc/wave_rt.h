@@ -9,10 +9,15 @@
 #include <stdint.h>
 
 #define SSS_DEV __device__ __forceinline__
-#define SSS_DEV_NOINLINE __device__ __noinline__
+// everything is inlined into the kernels: the kernel-argument segment pointer (SSS_KERNARG_PTR) is null in callees
+#define SSS_DEV_NOINLINE __device__ __forceinline__
 #define SSS_KERNEL extern "C" __global__ __launch_bounds__(64, 4)
 #define SSS_SHARED __shared__
 #define SSS_SHARED_DYN(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
+
+// the kernel-argument segment of the running kernel (constant address space: scalar, invariant loads);
+// usable from any device function
+#define SSS_KERNARG_PTR() ((const void*)__builtin_amdgcn_kernarg_segment_ptr())
 
 SSS_DEV int wave_lane() { return (int)threadIdx.x; }
 SSS_DEV int wave_env() { return (int)blockIdx.x; }
@@ -153,6 +158,8 @@ SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
   return x - v;
 }
 
+SSS_DEV uint2 mk_u2(uint32_t x, uint32_t y) { return make_uint2(x, y); }
+SSS_DEV uint4 mk_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return make_uint4(x, y, z, w); }
 SSS_DEV uint64_t wave_clock() { return (uint64_t)clock64(); }
 template <class T>
 SSS_DEV void nt_store(T* p, T v) { __builtin_nontemporal_store(v, p); }

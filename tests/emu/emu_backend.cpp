@@ -31,19 +31,23 @@ static int be_h2d(void* dst, const void* src, size_t n) {
   return 0;
 }
 static int be_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* seeds, const double* tl, const uint8_t* mask, void*) {
+  emu::g_kernargs = &a;
   emu::launch(num_envs, [&]() { sss_reset_kernel(a, seeds, tl, mask); });
   return 0;
 }
 static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride, void*) {
+  emu::g_kernargs = &a;
   emu::launch(num_envs, [&]() { sss_step_kernel(a, stage_idx, num_exec, auto_reset, seed_stride); });
   return 0;
 }
 
 static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, int param, int32_t* stage_idx, int32_t* num_exec, void*) {
+  emu::g_kernargs = &a;
   emu::launch(num_envs, [&]() { sss_policy_kernel(a, policy, param, stage_idx, num_exec); });
   return 0;
 }
 static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void*) {
+  emu::g_kernargs = &a;
   emu::launch(num_envs, [&]() { sss_rollout_kernel(a, policy, param, n_steps, auto_reset, seed_stride); });
   return 0;
 }

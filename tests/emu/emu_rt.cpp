@@ -40,6 +40,7 @@ emu_switch:
 
 namespace emu {
 
+const void* g_kernargs = nullptr;
 static const int W = 64;
 static const size_t STACK = 512 * 1024;
 

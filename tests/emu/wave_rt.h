@@ -30,6 +30,9 @@ void collective(int op, uint64_t value);
 uint64_t slot(int lane);
 }  // namespace emu
 
+namespace emu { extern const void* g_kernargs; }  // set by the launch wrappers (emu_backend.cpp)
+#define SSS_KERNARG_PTR() (emu::g_kernargs)
+
 SSS_DEV int wave_lane() { return emu::lane(); }
 SSS_DEV int wave_env() { return emu::env(); }
 SSS_DEV void wave_sync() { emu::collective(emu::OP_SYNC, 0); }
@@ -130,3 +133,7 @@ SSS_DEV double f64_with_hi32(double x, uint32_t hi) { return bits_f64((f64_bits(
 struct uint4 { uint32_t x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+SSS_DEV uint2 mk_u2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+SSS_DEV uint4 mk_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+

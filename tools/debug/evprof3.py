@@ -1,0 +1,41 @@
+"""debug: scoped profile of the lane-0 procedures (library built with -DSSS_EVPROF3 by evprof3.sh)"""
+import ctypes as C, sys, os.path as osp
+ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
+sys.path[:0] = [ROOT]
+import torch
+from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
+from spark_sched_sim_amd.binding import load_library
+NAMES = {1: "trk_add_commitment", 2: "trk_remove_commitment", 3: "trk_move_executor_to_pool", 4: "job_record_stage_completion", 5: "task_duration",
+         6: "find_backup_stage", 7: "execute_next_task", 8: "send_executor", 9: "get_idle_source_executors", 10: "move_idle_executors_all",
+         11: "move_executor_to_stage", 12: "fulfill_commitments_from_source", 13: "handle_job_arrival", 14: "handle_executor_arrival",
+         15: "process_job_completion", 16: "handle_task_completion", 17: "take_action", 18: "jobtime_build_set", 19: "cache_acquire", 20: "cache_release",
+         21: "find_schedulable_all", 22: "write_observation", 23: "env_begin", 24: "env_end", 25: "jobtime_sum", 26: "resume_simulation", 27: "do_reset",
+         28: "do_step", 29: "run_policy", 30: "batch_fast_events", 31: "handle_popped"}
+CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
+       "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
+lib = load_library()
+buf = (C.c_ulonglong * 64)()
+mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
+for name in sys.argv[1].split(","):
+    cfg, pol = CFG[name]
+    env = VecSparkSchedSimEnv(cfg, 4096, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
+    env.reset(seed=0)
+    env.rollout(pol, 600)
+    torch.cuda.synchronize()
+    lib.sss_debug_prof(buf)
+    c0 = env.counters()
+    if mode == "fused":
+        for _ in range(6):
+            env.rollout(pol, 50)
+    else:
+        for _ in range(300):
+            env.step(env.policy_actions(pol))
+    torch.cuda.synchronize()
+    lib.sss_debug_prof(buf)
+    c1 = env.counters()
+    steps = c1["n_steps"] - c0["n_steps"]; evs = c1["n_events"] - c0["n_events"]
+    print(f"== {name} {mode}: {steps} steps, {evs/steps:.1f} events/step; per STEP: ticks (calls, ticks/call)")
+    rows = [(buf[2 * i] / steps, buf[2 * i + 1] / steps, NAMES[i]) for i in NAMES if buf[2 * i + 1]]
+    for t, n, nm in sorted(rows, reverse=True):
+        print(f"  {nm:34s} {t:10.0f}  ({n:7.3f} calls, {t / max(n, 1e-9):9.0f} each)")
+    env.close()
