@@ -1525,16 +1525,16 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 // one-event-at-a-time path, which is always correct.
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
-SSS_DEV int batch_fast_events(const FastCtx& f EVP_ARG) {
+SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need EVP_ARG) {
   PROF3(30);
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
 #endif
   const int lane = wave_lane();
   // ---- everything that is read from shared state is read before the first collective ----
-  const SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
-  const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
-  const int pos = g_sc.rng_pos;
+  SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
+  uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  int pos = g_sc.rng_pos;
   const double next_arr = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
   const uint32_t info = sl.info;
   const uint32_t slot = info_slot(info);
@@ -1558,116 +1558,139 @@ SSS_DEV int batch_fast_events(const FastCtx& f EVP_ARG) {
     }
     len_l = xd.lenw_l & LENW_LEN, len_r = xd.lenw_r & LENW_LEN;
     // lists with one entry draw nothing, empty ones fail (TPCH:88-106): both go one at a time
-    cand = st.remaining > 0 && n_local > 0 && len_l > 1 && len_r > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
+    cand = n_local > 0 && len_l > 1 && len_r > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
   }
+  // what stays true for this executor's event from batch to batch as long as only batches run: its
+  // stage, the job's local executors, hence the candidate lists and their bound
+  const bool fast_kind = cand;
   const bool open = li != ri;
-  const int dmin = xd.dmin_l < xd.dmin_r ? xd.dmin_l : xd.dmin_r;
-  const double key = cand ? sl.t + (double)dmin : sl.t;
-  double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
-  if (next_arr < M) M = next_arr;  // an arrival wins ties against executor events (EVQ:35, counters 0..J-1)
-  bool V = cand && sl.t < M;
-  uint64_t vm = wave_ballot(V);
-  EVP_MARK(0);
-#ifdef SSS_BATCH_STATS
-  {
-    uint64_t cm = wave_ballot(cand), tfm = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED), pend = wave_ballot(sl.t < __builtin_inf());
-    uint64_t unc = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot == INFO_SLOT_NONE);
-    uint64_t l1 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining > 0 && (len_l <= 1 || len_r <= 1));
-    uint64_t r0 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining <= 0);
-    STAT(0, 1), STAT(1, popc64(pend)), STAT(2, popc64(tfm)), STAT(3, popc64(cm)), STAT(4, popc64(vm)), STAT(5, vm == 0);
-    STAT(6, popc64(unc)), STAT(7, popc64(l1)), STAT(8, popc64(r0));
-    // is the head of the queue a candidate at all?
-    double tmin = wave_min_f64_nonneg(sl.t);
-    uint64_t head = wave_ballot(sl.t == tmin);
-    STAT(9, (head & cm) != 0), STAT(10, next_arr <= tmin);
-    STAT(11, (head & unc) != 0), STAT(12, (head & l1) != 0), STAT(13, (head & r0) != 0), STAT(14, (head & ~tfm) != 0);
-  }
-#endif
-  if (vm == 0) return 0;
-  uint32_t nmax = (uint32_t)(64 - pos) >> 1;  // two raw outputs per event at most
+  const double dmin = (double)(xd.dmin_l < xd.dmin_r ? xd.dmin_l : xd.dmin_r);
+  const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
   const uint32_t tag = (info & ~0xFFu) | (open ? 0x80u : 0u);  // (job, slot, stage) | draws random()
-  uint32_t rank = 0, R = 0, cb = 0, ct = 1;
-  while (vm & (vm - 1)) {  // a batch of one needs no ranking
-    // rank = members before this one in (time, push counter) order (EVQ:35: keys are unique),
-    // R = how many of those draw random(), cb / ct = members of the same stage before this one / in total
-    rank = 0, R = 0, cb = 0, ct = 0;
-    for (uint64_t m = vm; m; m &= m - 1) {
-      const int k = ctz64(m);
-      const double tk = wave_readlane_f64(sl.t, k);
-      const uint32_t qk = wave_readlane_u32(sl.seq, k);
-      const uint32_t gk = wave_readlane_u32(tag, k);
-      const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq), same = ((gk ^ tag) >> 8) == 0;
-      rank += lt ? 1u : 0u;
-      R += (lt && (gk & 0x80u)) ? 1u : 0u;
-      cb += (lt && same) ? 1u : 0u;
-      ct += same ? 1u : 0u;
+  int total = 0;
+  // ---- batch after batch, state in registers; only the stage counters are re-read (other lanes change them) ----
+  for (;;) {
+    cand = fast_kind && st.remaining > 0;
+    const double key = cand ? sl.t + dmin : sl.t;
+    double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
+    if (next_arr < M) M = next_arr;  // an arrival wins ties against executor events (EVQ:35, counters 0..J-1)
+    bool V = cand && sl.t < M;
+    uint64_t vm = wave_ballot(V);
+    EVP_MARK(0);
+#ifdef SSS_BATCH_STATS
+    {
+      uint64_t cm = wave_ballot(cand), tfm = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED), pend = wave_ballot(sl.t < __builtin_inf());
+      uint64_t unc = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot == INFO_SLOT_NONE);
+      uint64_t l1 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining > 0 && (len_l <= 1 || len_r <= 1));
+      uint64_t r0 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining <= 0);
+      STAT(0, 1), STAT(1, popc64(pend)), STAT(2, popc64(tfm)), STAT(3, popc64(cm)), STAT(4, popc64(vm)), STAT(5, vm == 0);
+      STAT(6, popc64(unc)), STAT(7, popc64(l1)), STAT(8, popc64(r0));
+      double tmin = wave_min_f64_nonneg(sl.t);  // is the head of the queue a candidate at all?
+      uint64_t head = wave_ballot(sl.t == tmin);
+      STAT(9, (head & cm) != 0), STAT(10, next_arr <= tmin);
+      STAT(11, (head & unc) != 0), STAT(12, (head & l1) != 0), STAT(13, (head & r0) != 0), STAT(14, (head & ~tfm) != 0);
     }
-    // the stage has fewer tasks left than events before this one, or more events than buffered randomness
-    const bool over = V && (cb >= (uint32_t)st.remaining || rank >= nmax);
-    if (wave_ballot(over) == 0) break;
-    STAT(16, 1);
-    const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
-    V = V && rank < rcut;
-    vm = wave_ballot(V);
-    if (vm == 0) return 0;
-    if (!(vm & (vm - 1))) rank = 0, R = 0, cb = 0, ct = 1;
+#endif
+    if (vm == 0) return total;
+    const uint32_t nmax = (uint32_t)(64 - pos) >> 1;  // two raw outputs per event at most
+    uint32_t rank = 0, R = 0, cb = 0, ct = 1;
+    while (vm & (vm - 1)) {  // a batch of one needs no ranking
+      // rank = members before this one in (time, push counter) order (EVQ:35: keys are unique),
+      // R = how many of those draw random(), cb / ct = members of the same stage before this one / in total
+      rank = 0, R = 0, cb = 0, ct = 0;
+      for (uint64_t m = vm; m; m &= m - 1) {
+        const int k = ctz64(m);
+        const double tk = wave_readlane_f64(sl.t, k);
+        const uint32_t qk = wave_readlane_u32(sl.seq, k);
+        const uint32_t gk = wave_readlane_u32(tag, k);
+        const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq), same = ((gk ^ tag) >> 8) == 0;
+        rank += lt ? 1u : 0u;
+        R += (lt && (gk & 0x80u)) ? 1u : 0u;
+        cb += (lt && same) ? 1u : 0u;
+        ct += same ? 1u : 0u;
+      }
+      // the stage has fewer tasks left than events before this one, or more events than buffered randomness
+      const bool over = V && (cb >= (uint32_t)st.remaining || rank >= nmax);
+      if (wave_ballot(over) == 0) break;
+      STAT(16, 1);
+      const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
+      V = V && rank < rcut;
+      vm = wave_ballot(V);
+      if (vm == 0) return total;
+      if (!(vm & (vm - 1))) rank = 0, R = 0, cb = 0, ct = 1;
+    }
+    const uint32_t n = (uint32_t)popc64(vm);
+    STAT(18 + (n < 13 ? n : 13), 1);
+    EVP_MARK(1);
+    // ---- the members' draws ----
+    const uint32_t Fr = h0 ? rank >> 1 : (rank + 1) >> 1;  // raw outputs taken by the 32-bit draws of the members before
+    const bool fresh = ((h0 + rank) & 1u) == 0;           // this member's 32-bit draw takes a new raw output (low half)
+    const uint32_t P = R + Fr;
+    int lvl = li;
+    uint64_t x32 = 0;
+    uint32_t u32 = 0;
+    if (V) {
+      if (open) {  // TPCH:222-229
+        const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
+        if (!((double)rand_pt <= (double)n_local - left)) lvl = ri;
+      }
+      if (fresh) {
+        x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
+        u32 = (uint32_t)x32;
+      } else if (rank == 0) {
+        u32 = u32_0;  // the half numpy kept from before the batch
+      } else {
+        u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);  // the half the member before left behind
+      }
+    }
+    const int off = lvl == li ? xd.off_l : xd.off_r;
+    const uint32_t len = (uint32_t)(lvl == li ? len_l : len_r);
+    const uint64_t mm = (uint64_t)u32 * len;
+    if (wave_ballot(V && (uint32_t)mm < len) != 0) {  // Lemire's rejection test is needed: one at a time
+      STAT(17, 1);
+      return total;
+    }
+    // ---- commit: nothing of this batch was modified before this point ----
+    const uint64_t lastm = wave_ballot(V && rank == n - 1);  // the batch's last event: its lane leaves the header behind
+    const uint32_t consumed = P + (open ? 1u : 0u) + (fresh ? 1u : 0u);
+    const uint32_t u32_after = fresh ? (uint32_t)(x32 >> 32) : u32;  // the half numpy keeps / the one just used up
+    if (V) {
+      const double dur = (double)f.durations[off + (int)(mm >> 32)];
+      const uint32_t seq_new = counter0 + rank;
+      if (rank == n - 1) {
+        SssHdr& h = g_hot.h;
+        h.wall_time = sl.t;
+        h.counter = counter0 + n;
+        h.n_events += n, h.n_fast += n, h.n_batched += n, h.n_rounds++;
+        g_sc.events_this_step += (int32_t)n;
+        g_sc.rng_pos = pos + (int)consumed;
+        h.rng_has32 = fresh ? 1u : 0u;
+        h.rng_u32 = u32_after;
+      }
+      sl.t = sl.t + dur, sl.seq = seq_new;
+      g_hot.ev[lane].t = sl.t;
+      g_hot.ev[lane].seq = seq_new;
+      if (cb + 1 == ct) {  // the stage's last event of the batch (STG:53-58, ENV:595-597,604)
+        SssJob* jp = f.cjobs + slot;
+        st.remaining = (int16_t)(st.remaining - (int)ct);
+        f.cstages[slot * f.SP + s] = st;
+        f.cdur[slot * f.SP + s] = (float)dur;
+        if (st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
+        if ((int)st.remaining - ((int)st.moving_to + (int)st.commit_to) <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));
+      }
+    }
+    total += (int)n;
+    // the header fields the next batch starts from, on every lane (from the last event's lane)
+    const int ll = ctz64(lastm);
+    counter0 += n;
+    pos += (int)wave_readlane_u32(consumed, ll);
+    h0 = wave_readlane_u32(fresh ? 1u : 0u, ll);
+    u32_0 = wave_readlane_u32(u32_after, ll);
+    wave_sync();
+    EVP_MARK(2);
+    if (64 - pos < rng_need) return total;  // the caller refills the generator's buffer
+    if (fast_kind) st = f.cstages[slot * f.SP + s];  // other events of the stage may have taken tasks
   }
-  const uint32_t n = (uint32_t)popc64(vm);
-  STAT(18 + (n < 13 ? n : 13), 1);
-  EVP_MARK(1);
-  // ---- the members' draws ----
-  const uint32_t Fr = h0 ? rank >> 1 : (rank + 1) >> 1;  // raw outputs taken by the 32-bit draws of the members before
-  const bool fresh = ((h0 + rank) & 1u) == 0;           // this member's 32-bit draw takes a new raw output (low half)
-  const uint32_t P = R + Fr;
-  int lvl = li;
-  uint64_t x32 = 0;
-  uint32_t u32 = 0;
-  if (V) {
-    if (open) {  // TPCH:222-229
-      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
-      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
-      if (!((double)rand_pt <= (double)n_local - left)) lvl = ri;
-    }
-    if (fresh) {
-      x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
-      u32 = (uint32_t)x32;
-    } else if (rank == 0) {
-      u32 = u32_0;  // the half numpy kept from before the batch
-    } else {
-      u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);  // the half the member before left behind
-    }
-  }
-  const int off = lvl == li ? xd.off_l : xd.off_r;
-  const uint32_t len = (uint32_t)(lvl == li ? len_l : len_r);
-  const uint64_t mm = (uint64_t)u32 * len;
-  if (wave_ballot(V && (uint32_t)mm < len) != 0) { STAT(17, 1); return 0; }  // Lemire's rejection test is needed: one at a time
-  // ---- commit: nothing was modified before this point ----
-  if (V) {
-    const double dur = (double)f.durations[off + (int)(mm >> 32)];
-    g_hot.ev[lane].t = sl.t + dur;
-    g_hot.ev[lane].seq = counter0 + rank;
-    if (cb + 1 == ct) {  // the stage's last event of the batch (STG:53-58, ENV:595-597,604)
-      SssJob* jp = f.cjobs + slot;
-      st.remaining = (int16_t)(st.remaining - (int)ct);
-      f.cstages[slot * f.SP + s] = st;
-      f.cdur[slot * f.SP + s] = (float)dur;
-      if (st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
-      if ((int)st.remaining - ((int)st.moving_to + (int)st.commit_to) <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));
-    }
-    if (rank == n - 1) {  // the last event of the batch leaves the header behind
-      SssHdr& h = g_hot.h;
-      h.wall_time = sl.t;
-      h.counter = counter0 + n;
-      h.n_events += n, h.n_fast += n, h.n_batched += n, h.n_rounds++;
-      g_sc.events_this_step += (int32_t)n;
-      g_sc.rng_pos = pos + (int)P + (open ? 1 : 0) + (fresh ? 1 : 0);
-      h.rng_has32 = fresh ? 1u : 0u;
-      h.rng_u32 = fresh ? (uint32_t)(x32 >> 32) : u32;  // the half numpy keeps / the one just used up, as the one-event path leaves it
-    }
-  }
-  wave_sync();
-  EVP_MARK(2);
-  return (int)n;
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -2088,7 +2111,7 @@ SSS_DEV void resume_simulation() {
         EVP_MARK(5);
       }
       EVP_COUNT(6);
-      if (batch_fast_events(f EVP_PASS) > 0) continue;
+      if (batch_fast_events(f, rng_need EVP_PASS) > 0) continue;
       EVP_MARK(0);  // a round the batch path left early is charged to its first segment
       double t_win = 0.0;
       uint32_t info_win = 0;
