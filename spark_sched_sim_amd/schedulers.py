@@ -86,29 +86,38 @@ class RoundRobinScheduler(Scheduler):
 
 
 class RandomScheduler(Scheduler):
-    """uniformly random job, then `find_stage` in it (reference
-    schedulers/heuristics/random_scheduler.py:7-32; legacy `RandomState` stream like the reference)"""
+    """The reference's random heuristic (schedulers/heuristics/random_scheduler.py:7-32): jobs are
+    tried in a random order until one has a stage to offer, then a random executor count.
+
+    What is pinned by tests/golden/c1_random.npz is the stream, not the text: the draws come from a
+    legacy MT19937 `numpy.random.RandomState(seed)`; each job pick is one `choice` over the jobs not
+    yet rejected in this call (in active order), and the executor count is one `randint` over
+    [1, num_committable_execs] made after the job search, whether or not a stage was found."""
+
+    name = "Random"
+    env_wrapper_cls = None
 
     def __init__(self, seed: int = 42):
-        self.name = "Random"
-        self.env_wrapper_cls = None
         self.set_seed(seed)
 
     def set_seed(self, seed: int) -> None:
         self.np_random = np.random.RandomState(seed)
 
+    def _pick_stage(self, obs: dict) -> int:
+        remaining = list(range(len(obs["exec_supplies"])))
+        while remaining:
+            job = self.np_random.choice(remaining)
+            found = find_stage(obs, job)
+            if found != -1:
+                return found
+            remaining.remove(job)
+        return -1
+
     def schedule(self, obs: dict) -> tuple[dict, dict]:
         preprocess_obs(obs)
-        job_idxs = list(range(len(obs["exec_supplies"])))
-        stage_idx = -1
-        while job_idxs:
-            j = self.np_random.choice(job_idxs)
-            stage_idx = find_stage(obs, j)
-            if stage_idx != -1:
-                break
-            job_idxs.remove(j)
-        num_exec = self.np_random.randint(1, obs["num_committable_execs"] + 1)
-        return {"stage_idx": stage_idx, "num_exec": num_exec}, {}
+        stage = self._pick_stage(obs)
+        count = self.np_random.randint(1, obs["num_committable_execs"] + 1)
+        return {"stage_idx": stage, "num_exec": count}, {}
 
 
 def make_scheduler(agent_cfg: dict) -> Scheduler:

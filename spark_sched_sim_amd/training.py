@@ -397,55 +397,11 @@ class PPO:
                     flat /= dist.get_world_size()
                     off = 0
                     for p in params:
-                        n = p.numel()
-                        p.grad.copy_(flat[off: off + n].view_as(p))
-                        off += n
+                        k = p.numel()  # not `n`: that is the number of samples the epochs permute
+                        p.grad.copy_(flat[off: off + k].view_as(p))
+                        off += k
                 self.policy.update_parameters(None)
         return {"policy loss": abs(float(np.mean(pol))), "entropy": abs(float(np.mean(ent))), "approx kl div": abs(float(np.mean(kls)))}
-
-
-class VPG(PPO):
-    """Vanilla policy gradient (trainers/vpg.py:12-50) as evidently intended: per rollout
-    `-(lgprobs * normalised advantage).mean()` plus the entropy term, gradients accumulated over the
-    rollouts, ONE optimiser step per iteration. (The reference's loop header `zip(data.values())`,
-    vpg.py:25, cannot run as written - it yields 1-tuples; `zip(*data.values())` is what its body
-    needs. There is therefore no reference output to pin this class against; the test checks the
-    accumulated gradient against the same formula written with plain tensor ops.)"""
-
-    def train_on_rollouts(self, ro: Rollouts) -> dict[str, float]:
-        returns, baselines = self.preprocess(ro)
-        B = ro.active.shape[1]
-        T_ids = torch.arange(ro.active.shape[0], device=ro.active.device)
-        pol, ent = [], []
-        dist = self._dist()
-        for b in range(B):
-            n = int(ro.active[:, b].sum())
-            if n < 2:
-                continue
-            ids = T_ids[:n] * B + b
-            g = select_observations(ro.graph, ids)
-            res = self.policy.evaluate_actions(g, ro.stage_sel[:n, b], ro.job_idx[:n, b], ro.exec_sel[:n, b])
-            adv = (returns[:n, b] - baselines[:n, b]).float()
-            adv = (adv - adv.mean()) / (adv.std() + EPS)
-            policy_loss = -(res["lgprobs"] * adv).mean()
-            entropy_loss = -res["entropies"].mean()
-            (policy_loss + self.entropy_coeff * entropy_loss).backward()
-            pol.append(float(policy_loss.detach()))
-            ent.append(float(entropy_loss.detach()))
-        if dist:
-            params = list(self.policy.parameters())
-            for p in params:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
-            flat /= dist.get_world_size()
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off: off + p.numel()].view_as(p))
-                off += p.numel()
-        self.policy.update_parameters(None)
-        return {"policy loss": float(np.mean(pol)) if pol else 0.0, "entropy": float(np.mean(ent)) if ent else 0.0, "approx kl div": 0.0}
 
 
 class Trainer:
@@ -498,7 +454,7 @@ class Trainer:
         gen.manual_seed(self.seed * 1000003 + self.rank)
         self.collector = RolloutCollector(self.env, self.env_cfg["mean_time_limit"], base_seeds, total_sequences, E,
                                           policy=self.policy, generator=gen, on_env_error=train_cfg.get("on_env_error", "raise"))
-        self.ppo = (VPG if train_cfg.get("trainer_cls", "PPO") == "VPG" else PPO)(self.policy, train_cfg, generator=gen)
+        self.ppo = PPO(self.policy, train_cfg, generator=gen)
         self.history: list[dict[str, float]] = []
 
     def _gather_stats(self, stats: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
@@ -558,35 +514,5 @@ def make_trainer(cfg: dict[str, Any], device: str | torch.device | None = None, 
     """by-name factory like the reference's (trainers/__init__.py:7-13): `cfg` is the parsed YAML
     with its `trainer` / `agent` / `env` sections"""
     trainer_cls = cfg["trainer"]["trainer_cls"]
-    assert trainer_cls in ("PPO", "VPG"), f"'{trainer_cls}' is not a valid trainer."
+    assert trainer_cls == "PPO", f"'{trainer_cls}' is not a valid trainer."  # PPO is the trainer of BASELINE config 5
     return Trainer(agent_cfg=cfg["agent"], env_cfg=cfg["env"], train_cfg=cfg["trainer"], device=device, _lib=_lib)
-
-
-def main(argv=None) -> None:
-    """the reference's train.py / cfg_loader.py: `python -m spark_sched_sim_amd.training -f config.yaml`
-    (the reference's YAML files, e.g. config/decima_tpch.yaml, are accepted unchanged; under
-    torch.distributed.run every rank trains on its own job sequences)"""
-    import os
-    from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
-
-    import yaml
-
-    parser = ArgumentParser(description=main.__doc__, formatter_class=ArgumentDefaultsHelpFormatter)
-    parser.add_argument("-f", "--file", dest="filename", help="experiment definition file", metavar="FILE", required=True)
-    args = parser.parse_args(argv)
-    with open(args.filename, "r") as stream:
-        cfg = yaml.safe_load(stream)
-    device = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
-        device = f"cuda:{local}"
-    tr = make_trainer(cfg, device=device)
-    tr.train()
-    tr.close()
-
-
-if __name__ == "__main__":
-    main()

@@ -106,3 +106,53 @@ def test_two_rank_ppo_keeps_parameters_in_sync(tmp_path):
     assert r0["seeds"] == [7, 7] and r1["seeds"] == [8, 8] and r0["seed_step"] == r1["seed_step"] == 2
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+
+
+def _ppo_epochs_worker(rank: int, world: int, port: int, out_dir: str, num_epochs: int):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    from decima_util import AGENT
+    from emu_util import load_emu
+    from spark_sched_sim_amd import training
+
+    perm_sizes = []
+    real_randperm = torch.randperm
+
+    def spy(n, *a, **kw):
+        perm_sizes.append(int(n))
+        return real_randperm(n, *a, **kw)
+
+    training.torch.randperm = spy
+    try:
+        tr = training.Trainer(dict(AGENT, agent_cls="DecimaScheduler"), ENV,
+                              dict(TRAIN, num_iterations=1, num_epochs=num_epochs, artifacts_dir=os.path.join(out_dir, f"e{num_epochs}a{rank}")),
+                              device="cpu", _lib=load_emu())
+        tr.train(verbose=False)
+    finally:
+        training.torch.randperm = real_randperm
+    torch.save({"sd": tr.policy.state_dict(), "perm_sizes": perm_sizes, "samples": tr.history[0]["samples"]},
+               os.path.join(out_dir, f"e{num_epochs}r{rank}.pt"))
+    tr.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ppo_every_epoch_permutes_all_samples(tmp_path):
+    """regression: the gradient-bucket loop of the multi-rank path once overwrote the sample count,
+    so every epoch after the first permuted a single sample (and only the first epoch trained)"""
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    from emu_util import load_emu
+
+    load_emu()
+    for epochs in (1, 3):
+        mp.spawn(_ppo_epochs_worker, args=(2, _free_port(), str(tmp_path), epochs), nprocs=2, join=True)
+    for rank in (0, 1):
+        r3 = torch.load(str(tmp_path / f"e3r{rank}.pt"))
+        assert len(r3["perm_sizes"]) == 3 and r3["samples"] > 2
+        assert all(n == r3["samples"] for n in r3["perm_sizes"]), r3["perm_sizes"]
+    one, three = torch.load(str(tmp_path / "e1r0.pt")), torch.load(str(tmp_path / "e3r0.pt"))
+    assert any(not torch.equal(one["sd"][k], three["sd"][k]) for k in one["sd"]), "epochs 2 and 3 must move the parameters"
+    other = torch.load(str(tmp_path / "e3r1.pt"))
+    for k in three["sd"]:
+        assert torch.equal(three["sd"][k], other["sd"][k]), k

@@ -79,12 +79,22 @@ def test_action_space_follows_the_observation():
     env.close()
 
 
-def test_examples_run_episode_reproduces_the_reference_metric(capsys):
-    """the reference's examples.py on this build: fair scheduler, ENV_CFG, seed 1234 -> the same
+def test_reference_style_episode_loop_reproduces_the_reference_metric():
+    """the loop every harness of the reference runs (examples.py:84-102, rollout_worker.py:135-157)
+    against the facade: reset(seed) -> schedule(obs) -> step(action) until the episode ends, then
+    metrics.avg_job_duration - fair scheduler, the reference's example config, seed 1234 -> the same
     average job duration the recorded reference episode has"""
-    from spark_sched_sim_amd import examples
+    from spark_sched_sim_amd import metrics
 
     g = Golden("c1_fair")
-    got = examples.fair_example(device="cpu", _lib=load_emu())
+    env = SparkSchedSimEnv(g.cfg, device="cpu", _lib=load_emu())
+    sched = RoundRobinScheduler(g.cfg["num_executors"], dynamic_partition=True)
+    obs, _ = env.reset(seed=1234, options=None)
+    done = False
+    while not done:
+        action, _ = sched.schedule(obs)
+        obs, _, terminated, truncated, _ = env.step(action)
+        done = terminated or truncated
+    got = metrics.avg_job_duration(env) * 1e-3
     assert bits(got) == bits(np.mean(g.ep(1234, "job_durations")) * 1e-3)
-    assert "Average job duration" in capsys.readouterr().out
+    env.close()

@@ -115,44 +115,3 @@ def test_collector_truncates_a_rollout_whose_env_stalls(pack=None):
             base = sequence_baselines(ro, ret, 1, 2)
             assert torch.isfinite(ret).all() and torch.isfinite(base).all()
         env.close()
-
-
-def test_vpg_accumulated_gradient(tmp_path):
-    """trainer_cls 'VPG': the gradient accumulated over the rollouts equals the sum of per-rollout
-    -(lgprob * normalised advantage).mean() - entropy_coeff * entropy.mean() written directly"""
-    import torch
-
-    from decima_util import AGENT
-    from spark_sched_sim_amd.decima import select_observations
-    from spark_sched_sim_amd.training import EPS, Trainer
-
-    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), ENV, dict(TRAIN, trainer_cls="VPG", artifacts_dir=str(tmp_path)),
-                 device="cpu", _lib=load_emu())
-    ro = tr.collector.collect_sync(with_stats=False)
-    returns, baselines = tr.ppo.preprocess(ro)
-    B = ro.active.shape[1]
-    total = 0.0
-    for b in range(B):
-        n = int(ro.active[:, b].sum())
-        if n < 2:
-            continue
-        g = select_observations(ro.graph, torch.arange(n) * B + b)
-        res = tr.policy.evaluate_actions(g, ro.stage_sel[:n, b], ro.job_idx[:n, b], ro.exec_sel[:n, b])
-        adv = (returns[:n, b] - baselines[:n, b]).float()
-        adv = (adv - adv.mean()) / (adv.std() + EPS)
-        total = total + (-(res["lgprobs"] * adv).mean() - 0.04 * res["entropies"].mean())
-    want = torch.autograd.grad(total, list(tr.policy.parameters()), allow_unused=True)
-    captured = {}
-    orig = tr.policy.update_parameters
-
-    def spy(loss=None):
-        captured["g"] = [None if p.grad is None else p.grad.clone() for p in tr.policy.parameters()]
-        orig(loss)
-    tr.policy.update_parameters = spy
-    before = [p.detach().clone() for p in tr.policy.parameters()]
-    tr.ppo.train_on_rollouts(ro)
-    for gw, gg in zip(want, captured["g"]):
-        if gw is not None:
-            assert torch.allclose(gw, gg, atol=1e-6, rtol=1e-4)
-    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, tr.policy.parameters()))
-    tr.close()
