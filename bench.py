@@ -2,7 +2,7 @@
 """Throughput benchmark of the hot path: env-steps/s of the batched Spark-scheduling simulator.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs B] [--config c2|c3] [--policy hash|fair]
-                    [--mode step|fused] [--no-cpu-baseline]
+                    [--mode step|fused] [--no-cpu-baseline] [--no-c3] [--no-decima]
 
 A "step" is ONE batched step of all envs of a rank: on-device policy kernel + step kernel
 (`--mode step`, the drop-in boundary: sss_policy + sss_step per step), or one iteration of the
@@ -10,13 +10,21 @@ fused rollout kernel (`--mode fused`, sss_rollout: identical per-step work, poli
 observe, without leaving the kernel). Envs auto-reset (next-step mode); only real step() calls are
 counted (the device counts them), so `value` = real env steps of all ranks / max-over-ranks time.
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): envs are sharded, B per rank, no
-data-path collective; one RCCL all-gather of per-env episode returns after the timed region
-(the stand-in for the reference's Pipe gather, trainers/trainer.py:113-121). Weak scaling.
+Before anything is timed every env is rolled to its steady state with fused launches (episodes of
+different seeds have different lengths, so after a few episodes the envs of a batch sit at all
+phases of their episodes); `--warmup W` untimed steps in the measured mode follow.
+
+Multi-GPU (`--gpus N`): with no torch.distributed environment bench.py starts its own N ranks
+(fresh processes, one per GPU, 127.0.0.1 rendezvous); under `torch.distributed.run` it is one of
+them. Envs are sharded, B per rank, no data-path collective; one RCCL all-gather of per-env episode
+returns after the timed region (the stand-in for the reference's Pipe gather,
+trainers/trainer.py:113-121). Weak scaling.
 
 Prints ONE JSON line on rank 0 (see the driver contract) including `roofline` (SURVEY 8(d) model
-bytes of the dominant kernel / its HIP-event-measured duration / 8 TB/s) and `cpu_baseline`
-(the C oracle, oracle/sss_oracle.c, timed on this box's host on a bounded sample).
+bytes of the dominant kernel / its HIP-event-measured duration / 8 TB/s), `cpu_baseline` (the C
+oracle, oracle/sss_oracle.c, timed on this box's host on a bounded sample), `step_tail` (how much
+of a step launch is the wait for its slowest env) and, at N = 1, a `c3` record with the same
+measurements on BASELINE config 3 (4096 envs, 50 executors, 200 jobs, fair policy).
 """
 from __future__ import annotations
 
@@ -35,6 +43,8 @@ CONFIGS = {
     "c2": dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
     "c3": dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
 }
+DEFAULT_POLICY = {"c2": "hash", "c3": "fair"}
+PREROLL_STEPS = {"c2": 1500, "c3": 6000}  # a few episodes each (about 600 / 4000 steps long)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -119,17 +129,20 @@ def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float) -> dict:
             "sample": f"{len(res)} processes x ~{budget_s:.0f} s of whole episodes, same config and policy (C oracle)"}
 
 
-def measured_traffic(kernel: str, config: str, envs: int):
+def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float):
     """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes), recorded under profiles/ by tools/collect_traffic.py for this
-    exact kernel/config; None when no matching measurement is committed."""
+    exact kernel/config - and this regime: the record carries the events per step it was measured
+    at, and it is only reported next to a run within 15 % of that. None otherwise."""
     path = osp.join(ROOT, "profiles", "traffic.json")
     if not osp.exists(path):
         return None
     try:
         for rec in json.load(open(path)):
             if rec["kernel"] == kernel and rec["config"] == config and rec["envs"] == envs:
-                return rec["hbm_bytes_per_launch"]
+                ref = rec.get("events_per_step")
+                if ref and abs(events_per_step - ref) <= 0.15 * ref:
+                    return rec["hbm_bytes_per_launch"]
     except Exception:
         return None
     return None
@@ -165,94 +178,62 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
             "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--config", default="c2", choices=list(CONFIGS))
-    ap.add_argument("--policy", default=None, choices=["hash", "fair"])
-    ap.add_argument("--mode", default="step", choices=["step", "fused"])
-    ap.add_argument("--fused-chunk", type=int, default=50)
-    ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
-    ap.add_argument("--shards", type=int, default=1,
-                    help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
-                         "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
-    ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--evprof", action="store_true", help="library built with -DSSS_EVPROF (tools/evprof.sh): report ticks per event-loop round segment")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); 'gloo' only for plumbing tests")
-    ap.add_argument("--device-index", type=int, default=None, help="override LOCAL_RANK -> device mapping (plumbing tests on one GPU)")
-    args = ap.parse_args()
+class Bench:
+    """one rank's share of one configuration: B envs (optionally in sub-batches on their own streams)"""
 
-    import torch
+    def __init__(self, args, config: str, policy: str, B: int, dev, rank: int, world: int):
+        import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
-    dev_index = local_rank if args.device_index is None else args.device_index
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
+        from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
 
-        dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
-
-    from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
-
-    cfg = CONFIGS[args.config]
-    policy = args.policy or ("hash" if args.config == "c2" else "fair")
-    B = args.envs
-    S = max(1, args.shards)
-    assert B % S == 0, "--envs must be divisible by --shards"
-    Bs = B // S
-    pack = workload.default_pack()
-    # env i of shard s of rank r: seed (r*S + s)*Bs + i = its global env id (placement invariant)
-    shards = [VecSparkSchedSimEnv(cfg, Bs, device=dev, pack=pack, auto_reset=True, seed_stride=B * world) for _ in range(S)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
-    for k, e in enumerate(shards):
-        e.reset(seed=(rank * S + k) * Bs)
-    torch.cuda.synchronize()
-
-    class _All:  # the rank's whole batch, as the sum of its shards
-        @staticmethod
-        def counters():
-            tot: dict = {}
-            for e in shards:
-                for key, v in e.counters().items():
-                    tot[key] = tot.get(key, 0) + v
-            return tot
-
-        @staticmethod
-        def header_field(name):
-            return torch.cat([e.header_field(name) for e in shards])
-
-        @staticmethod
-        def close():
-            for e in shards:
-                e.close()
-
-    env = _All
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+        self.torch, self.args, self.config, self.policy, self.B, self.dev, self.rank, self.world = torch, args, config, policy, B, dev, rank, world
+        self.cfg = CONFIGS[config]
+        S = max(1, args.shards)
+        assert B % S == 0, "--envs must be divisible by --shards"
+        Bs = B // S
+        self.pack = workload.default_pack()
+        # env i of shard s of rank r: seed (r*S + s)*Bs + i = its global env id (placement invariant)
+        self.shards = [VecSparkSchedSimEnv(self.cfg, Bs, device=dev, pack=self.pack, auto_reset=True, seed_stride=B * world) for _ in range(S)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+        for k, e in enumerate(self.shards):
+            e.reset(seed=(rank * S + k) * Bs)
+        # steady state: every env a few episodes in, all phases of an episode present in the batch
+        left = PREROLL_STEPS[config] if args.preroll is None else args.preroll
+        while left > 0:
+            n = min(500, left)
+            for e in self.shards:
+                e.rollout(policy, n)
+            left -= n
         torch.cuda.synchronize()
 
-    def run(mode: str, n_steps: int, events=None):
+    def counters(self) -> dict:
+        tot: dict = {}
+        for e in self.shards:
+            for key, v in e.counters().items():
+                tot[key] = tot.get(key, 0) + v
+        return tot
+
+    def header_field(self, name):
+        return self.torch.cat([e.header_field(name) for e in self.shards])
+
+    def close(self):
+        for e in self.shards:
+            e.close()
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, mode: str, n_steps: int, events=None):
         # every shard issues its own chain of launches on its own stream; chains are independent
+        torch, args = self.torch, self.args
         if mode == "step":
             for _ in range(n_steps):
-                for e, st in zip(shards, streams):
+                for e, st in zip(self.shards, self.streams):
                     with torch.cuda.stream(st):
-                        act = e.policy_actions(policy)
+                        act = e.policy_actions(self.policy)
                         if events is not None:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record(st)
@@ -265,37 +246,39 @@ def main() -> None:
             done = 0
             while done < n_steps:
                 n = min(args.fused_chunk, n_steps - done)
-                for e, st in zip(shards, streams):
+                for e, st in zip(self.shards, self.streams):
                     with torch.cuda.stream(st):
                         if events is not None:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record(st)
-                            e.rollout(policy, n)
+                            e.rollout(self.policy, n)
                             e1.record(st)
                             events.append((e0, e1))
                         else:
-                            e.rollout(policy, n)
+                            e.rollout(self.policy, n)
                 done += n
 
-    def measure(mode: str) -> dict:
+    def measure(self, mode: str, steps: int, warmup: int) -> dict:
         """W untimed + exactly K timed batched steps in `mode`; all-rank totals on every rank"""
-        run(mode, args.warmup)
-        barrier()
-        c0 = env.counters()
+        torch, args = self.torch, self.args
+        self.run(mode, warmup)
+        self.barrier()
+        c0 = self.counters()
         events: list = []
-        barrier()
+        self.barrier()
         t0 = time.perf_counter()
-        run(mode, args.steps, events)
-        barrier()
+        self.run(mode, steps, events)
+        self.barrier()
         dt = time.perf_counter() - t0
-        c1 = env.counters()
+        c1 = self.counters()
         kern_ms = sum(a.elapsed_time(b) for a, b in events)
         tot = torch.tensor([float(c1["n_steps"] - c0["n_steps"]), float(c1["n_events"] - c0["n_events"]),
                             float(c1["model_bytes"] - c0["model_bytes"]), kern_ms, float(len(events)),
                             float(c1["n_fast_events"] - c0["n_fast_events"]), float(c1["n_batched_events"] - c0["n_batched_events"]),
-                            float(c1["n_rounds"] - c0["n_rounds"])], dtype=torch.float64, device=dev)
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+                            float(c1["n_rounds"] - c0["n_rounds"])], dtype=torch.float64, device=self.dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         steps_all, evs_all, bytes_all, kern_ms_all, launches_all, fast_all, batched_all, rounds_all = tot.cpu().tolist()
@@ -304,12 +287,13 @@ def main() -> None:
         bytes_per_launch = bytes_all / launches_all
         achieved = bytes_per_launch / avg_launch_s / 1e9
         kernel = "sss_step_kernel" if mode == "step" else "sss_rollout_kernel"
+        evps = evs_all / max(1.0, steps_all)
         return {
             "value": steps_all / dt_max,
-            "ms_per_step": dt_max / args.steps * 1e3,
-            "launches_per_step": launches_all / world / args.steps if mode == "step" else launches_all / world / max(1, (args.steps + args.fused_chunk - 1) // args.fused_chunk),
+            "ms_per_step": dt_max / steps * 1e3,
+            "launches_per_step": launches_all / self.world / steps if mode == "step" else launches_all / self.world / max(1, (steps + args.fused_chunk - 1) // args.fused_chunk),
             "events_per_s": evs_all / dt_max,
-            "events_per_step": evs_all / max(1.0, steps_all),
+            "events_per_step": evps,
             "fast_path_event_frac": fast_all / max(1.0, evs_all),
             # share of all events handled by lane-parallel batches, and events per batch round
             "batched_event_frac": batched_all / max(1.0, evs_all),
@@ -318,17 +302,108 @@ def main() -> None:
             "phase_ticks_per_step": {k[6:]: (c1[k] - c0[k]) / max(1, c1["n_steps"] - c0["n_steps"]) for k in c1 if k.startswith("ticks_")},
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel, args.config, B),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel, self.config, self.B, evps),
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
-                "kernel_time_frac_of_wall": (kern_ms_all / world) * 1e-3 / dt_max,
+                "kernel_time_frac_of_wall": (kern_ms_all / self.world) * 1e-3 / dt_max,
             },
         }
 
-    ev0 = env.counters() if args.evprof else None
-    primary = measure(args.mode)
+    def step_tail(self, launches: int = 24) -> dict:
+        """why a step launch lasts as long as it does: per-env shader ticks of single launches (device
+        counters read before and after each; outside the timed region). A launch ends with its
+        slowest env: `slowest / mean` env ticks is the share of the launch spent waiting for it."""
+        import numpy as np
+
+        from spark_sched_sim_amd.vec_env import HDR_OFF, HDR_PROF
+
+        torch, e = self.torch, self.shards[0]
+
+        def snap():
+            h = e._env_view[:, : e.dims.hdr_bytes].cpu().numpy()
+            prof = np.ascontiguousarray(h[:, HDR_PROF: HDR_PROF + 40]).view(np.uint64).astype(np.int64)
+            ev = np.ascontiguousarray(h[:, HDR_OFF["n_events"]: HDR_OFF["n_events"] + 8]).view(np.uint64).ravel().astype(np.int64)
+            return prof[:, 1:].sum(1), ev  # action + events + reward + observe ticks (slow-path ticks are inside events)
+
+        slow, mean, p99, evs, ms = [], [], [], [], []
+        for _ in range(launches):
+            t_a, ev_a = snap()
+            act = e.policy_actions(self.policy)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e.step_async(act["stage_idx"], act["num_exec"])
+            e1.record()
+            torch.cuda.synchronize()
+            t_b, ev_b = snap()
+            d = t_b - t_a
+            k = int(np.argmax(d))
+            slow.append(float(d[k])), mean.append(float(d.mean())), p99.append(float(np.sort(d)[-max(1, len(d) // 100)]))
+            evs.append(int(ev_b[k] - ev_a[k])), ms.append(e0.elapsed_time(e1))
+        return {"launches": launches, "slowest_env_ticks": float(np.mean(slow)), "mean_env_ticks": float(np.mean(mean)), "p99_env_ticks": float(np.mean(p99)),
+                "slowest_over_mean": float(np.mean(slow) / max(1.0, np.mean(mean))), "slowest_env_events": float(np.mean(evs)),
+                "launch_ms": float(np.mean(ms)), "what": "per-env shader ticks of single step launches; a launch ends with its slowest env"}
+
+
+def run_ranks_myself(args) -> int:
+    """--gpus N without a torch.distributed environment: N fresh rank processes (nothing here has touched the GPU)"""
+    from spark_sched_sim_amd.distributed import launch_ranks
+
+    return launch_ranks(args.gpus, [osp.abspath(__file__)] + sys.argv[1:])
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--config", default="c2", choices=list(CONFIGS))
+    ap.add_argument("--policy", default=None, choices=["hash", "fair"])
+    ap.add_argument("--mode", default="step", choices=["step", "fused"])
+    ap.add_argument("--fused-chunk", type=int, default=50)
+    ap.add_argument("--preroll", type=int, default=None, help="fused steps every env runs before anything is timed (default: a few episodes)")
+    ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE config 3 record (N=1, --config c2 only)")
+    ap.add_argument("--shards", type=int, default=1,
+                    help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
+                         "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
+    ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--evprof", action="store_true", help="library built with -DSSS_EVPROF (tools/evprof.sh): report ticks per event-loop round segment")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); 'gloo' only for plumbing tests")
+    ap.add_argument("--device-index", type=int, default=None, help="override LOCAL_RANK -> device mapping (plumbing tests on one GPU)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(run_ranks_myself(args))
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
+    dev_index = local_rank if args.device_index is None else args.device_index
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(args.dist_backend)  # "nccl" is RCCL on ROCm
+
+    policy = args.policy or DEFAULT_POLICY[args.config]
+    B = args.envs
+    bench = Bench(args, args.config, policy, B, dev, rank, world)
+    cfg = bench.cfg
+
+    ev0 = bench.counters() if args.evprof else None
+    primary = bench.measure(args.mode, args.steps, args.warmup)
     evprof = None
     if args.evprof:
-        ev1 = env.counters()
+        ev1 = bench.counters()
         dd = {k: ev1[k] - ev0[k] for k in ev1}
         rounds = max(1, dd["evprof_rounds"])
         evprof = {"rounds_per_step": rounds / max(1, dd["n_steps"]), "batch_rounds_per_step": dd["n_rounds"] / max(1, dd["n_steps"]),
@@ -337,18 +412,28 @@ def main() -> None:
                                       "single_handler": dd["ticks_observe"] / rounds, "rng_refill": dd["evprof_refill"] / rounds},
                   "ticks_per_step_total": sum(dd[k] for k in ("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe", "evprof_refill")) / max(1, dd["n_steps"])}
     other_mode = "fused" if args.mode == "step" else "step"
-    secondary = None if args.single_mode else measure(other_mode)
+    secondary = None if args.single_mode else bench.measure(other_mode, args.steps, args.warmup)
+    tail = bench.step_tail() if (world == 1 and args.shards == 1 and not args.evprof) else None
 
     if world > 1:
         # the one exchange of the path: all-gather of per-env episode summaries (RCCL)
         from spark_sched_sim_amd.distributed import all_gather_episode_summaries
 
-        table = all_gather_episode_summaries(env)
+        table = torch.cat([all_gather_episode_summaries(e) for e in bench.shards])
         mean_return = table[:, 0].mean().item()
+        ranks_seen = int(table.shape[0] // B)
     else:
-        mean_return = env.header_field("last_ep_return").mean().item()
+        mean_return = bench.header_field("last_ep_return").mean().item()
+        ranks_seen = 1
+    # every env has finished at least one episode before the timed region: the measured regime is the steady state
+    if (args.preroll is None or args.preroll >= PREROLL_STEPS[args.config]) and mean_return == 0.0:
+        raise SystemExit("bench.py: the envs are not in their steady state (no finished episode)")
 
+    out = None
     if rank == 0:
+        workload = (f"{B} envs/GPU x ({cfg['num_executors']} executors, {cfg['job_arrival_cap']} TPC-H-format jobs, job_arrival_rate {cfg['job_arrival_rate']}/ms, "
+                    f"synthetic frozen trace set), on-device '{policy}' policy, auto-reset, steady state (every env several episodes in), "
+                    f"mode={args.mode} ({'sss_policy + sss_step per batched step' if args.mode == 'step' else 'sss_rollout, ' + str(args.fused_chunk) + ' steps per launch'})")
         out = {
             "metric": "env-steps/sec at 4096 batched envs (TPC-H, 10 exec)" if (args.config == "c2" and B == 4096) else f"env-steps/sec at {B} batched envs ({args.config})",
             "value": primary["value"],
@@ -362,13 +447,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "int64+f64",
             "data": "synthetic",
-            "config": {
-                "workload": f"{B} envs/GPU x ({cfg['num_executors']} executors, {cfg['job_arrival_cap']} TPC-H-format jobs, "
-                            f"job_arrival_rate {cfg['job_arrival_rate']}/ms, synthetic frozen trace set), on-device '{policy}' policy, "
-                            f"auto-reset, mode={args.mode} ({'sss_policy + sss_step per batched step' if args.mode == 'step' else 'sss_rollout, ' + str(args.fused_chunk) + ' steps per launch'})",
-                "envs_per_gpu": B, "policy": policy, "mode": args.mode, "parallelism": f"env-shard x{world}",
-                "streams_per_gpu": S,
-            },
+            "config": {"workload": workload, "envs_per_gpu": B, "policy": policy, "mode": args.mode,
+                       "parallelism": f"env-shard x{world}", "streams_per_gpu": max(1, args.shards), "ranks_seen_by_all_gather": ranks_seen},
             "events_per_s": primary["events_per_s"],
             "events_per_step": primary["events_per_step"],
             "fast_path_event_frac": primary["fast_path_event_frac"],
@@ -380,6 +460,8 @@ def main() -> None:
         }
         if evprof is not None:
             out["evprof"] = evprof
+        if tail is not None:
+            out["step_tail"] = tail
         if secondary is not None:
             # the same K batched steps through the other entry point (same per-step work, same trajectories)
             out["other_mode"] = dict(secondary, mode=other_mode)
@@ -389,14 +471,37 @@ def main() -> None:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(6.0, args.cpu_budget))
             except Exception as e:  # never let the extra baseline take the bench line down
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
+    pack = bench.pack
+    bench.close()
+
+    # BASELINE config 3 next to the headline (N = 1): same measurements, its own roofline and CPU baseline
+    if world == 1 and args.config == "c2" and not args.no_c3 and not args.evprof and args.shards == 1:
+        try:
+            b3 = Bench(args, "c3", DEFAULT_POLICY["c3"], B, dev, rank, world)
+            k3, w3 = max(10, min(args.steps, 300)), max(5, min(args.warmup, 50))
+            r3 = b3.measure("step", k3, w3)
+            f3 = b3.measure("fused", k3, w3)
+            rec = {"what": f"BASELINE config 3: {B} envs x (50 executors, 200 jobs), fair policy, steady state; {k3} timed batched steps after {w3} warm-up steps",
+                   "value": r3["value"], "unit": "env-steps/s", "ms_per_step": r3["ms_per_step"], "events_per_step": r3["events_per_step"],
+                   "fast_path_event_frac": r3["fast_path_event_frac"], "batched_event_frac": r3["batched_event_frac"], "events_per_batch": r3["events_per_batch"],
+                   "phase_ticks_per_step": r3["phase_ticks_per_step"], "roofline": r3["roofline"], "step_tail": b3.step_tail(12),
+                   "other_mode": dict(f3, mode="fused"), "mean_last_episode_return": b3.header_field("last_ep_return").mean().item()}
+            b3.close()
+            if not args.no_cpu_baseline:
+                rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(6.0, args.cpu_budget))
+                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(6.0, args.cpu_budget))
+            out["c3"] = rec
+        except Exception as e:
+            out["c3"] = {"error": repr(e)}
+    if rank == 0:
         if world == 1 and not args.no_decima and args.config == "c2":
             try:  # SURVEY 8(f) next-1 on the same env sizing; never let it take the bench line down
                 out["decima_in_loop"] = decima_in_loop(cfg, B, dev, pack)
             except Exception as e:
                 out["decima_in_loop"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    env.close()
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -10,6 +10,11 @@ on how envs are placed on GPUs.
 """
 from __future__ import annotations
 
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -40,3 +45,29 @@ def all_gather_episode_summaries(env, group=None) -> torch.Tensor:
     out = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, local, group=group)
     return torch.cat(out, dim=0)
+
+
+def launch_ranks(world_size: int, argv: list[str], port: int | None = None, env: dict | None = None) -> int:
+    """Starts `world_size` fresh Python processes running `argv` (script + arguments), one rank per
+    GPU, with the torch.distributed environment set (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR =
+    127.0.0.1, MASTER_PORT) - the stand-in for the reference's own worker start-up
+    (trainers/trainer.py:264-293 spawns its rollout processes itself). The caller must not have
+    touched the GPU: every rank is a new process, nothing is exec'ed over an initialised one.
+    Rank 0 inherits stdout (it prints the result), the other ranks' stdout goes to stderr.
+    Returns the first non-zero exit code, else 0."""
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    procs = []
+    for rank in range(world_size):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), LOCAL_WORLD_SIZE=str(world_size),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=None if rank == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        r = p.wait()
+        rc = rc or r
+    return rc

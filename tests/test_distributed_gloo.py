@@ -156,3 +156,53 @@ def test_two_rank_ppo_every_epoch_permutes_all_samples(tmp_path):
     other = torch.load(str(tmp_path / "e3r1.pt"))
     for k in three["sd"]:
         assert torch.equal(three["sd"][k], other["sd"][k]), k
+
+
+# ---- self-starting ranks (bench.py --gpus N with no outer launcher) ----------------------------------
+
+_RANK_SCRIPT = """
+import json, os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([float(os.environ["RANK"]) + 10.0 * float(os.environ["LOCAL_RANK"])])
+out = [torch.zeros(1) for _ in range(dist.get_world_size())]
+dist.all_gather(out, t)
+if dist.get_rank() == 0:
+    print(json.dumps({"world": dist.get_world_size(), "gathered": [float(x) for x in out], "master": os.environ["MASTER_ADDR"]}), flush=True)
+else:
+    print("not the result line", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_launch_ranks_starts_one_fresh_process_per_rank(tmp_path, capfd):
+    """spark_sched_sim_amd.distributed.launch_ranks: what bench.py / tools/bench_*.py use when they are
+    asked for N > 1 GPUs outside torch.distributed.run (reference: the trainer starts its own workers,
+    trainers/trainer.py:264-293)"""
+    import json
+
+    sys.path[:0] = [os.path.dirname(HERE)]
+    from spark_sched_sim_amd.distributed import launch_ranks
+
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    assert launch_ranks(2, [str(script)]) == 0
+    out, err = capfd.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # gloo's own chatter aside
+    assert len(lines) == 1, lines  # only rank 0 owns stdout
+    rec = json.loads(lines[0])
+    assert rec == {"world": 2, "gathered": [0.0, 11.0], "master": "127.0.0.1"}
+    assert "not the result line" in err
+
+
+def test_bench_starts_its_own_ranks(capfd):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns two ranks; here (no GPU)
+    each of them stops at the "needs an AMD GPU" check - after the rank environment was set up"""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present: the two ranks ran the bench")
+    assert r.stderr.count("bench.py needs an AMD GPU") == 2, r.stderr[-2000:]

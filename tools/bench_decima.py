@@ -3,9 +3,10 @@
 sampling every action on the device. Not the headline metric (bench.py is); prints one JSON line.
 
 One GPU: `python tools/bench_decima.py --envs 4096`. Several GPUs (config 4 = 8192 envs on 8 GPUs):
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_decima.py
---envs 1024` - `--envs` is per rank, envs are sharded by global id, there is no per-step traffic; the
-timed region is bracketed by barriers and the slowest rank's time is used."""
+`python tools/bench_decima.py --gpus 8 --envs 1024` starts its own ranks (or run it under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1`) - `--envs` is per
+rank, envs are sharded by global id, there is no per-step traffic; the timed region is bracketed by
+barriers and the slowest rank's time is used."""
 import argparse
 import json
 import os
@@ -26,6 +27,7 @@ AGENT = dict(embed_dim=16,
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
@@ -35,6 +37,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--device-index", type=int, default=None)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # start the ranks ourselves (nothing has touched the GPU yet)
+        from spark_sched_sim_amd.distributed import launch_ranks
+        raise SystemExit(launch_ranks(a.gpus, [osp.abspath(__file__)] + sys.argv[1:]))
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     dev = f"cuda:{local if a.device_index is None else a.device_index}"
     torch.cuda.set_device(dev)

@@ -20,6 +20,7 @@ AGENT = dict(agent_cls="DecimaScheduler", embed_dim=16,
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
     ap.add_argument("--sequences", type=int, default=256)
     ap.add_argument("--rollouts", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=2)
@@ -30,6 +31,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--device-index", type=int, default=None)
     a = ap.parse_args()
+    import os
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # BASELINE config 5: `python tools/bench_ppo.py --gpus 8 --sequences 256 --rollouts 4`
+        from spark_sched_sim_amd.distributed import launch_ranks
+        raise SystemExit(launch_ranks(a.gpus, [osp.abspath(__file__)] + sys.argv[1:]))
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=a.sequences, num_rollouts=a.rollouts, seed=42,
                  checkpointing_freq=10 ** 9, num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04,
                  beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo")

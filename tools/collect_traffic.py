@@ -58,7 +58,10 @@ def main():
     for config, envs in (("c2", 4096), ("c3", 4096)):
         for mode, kernel in (("step", "sss_step_kernel"), ("fused", "sss_rollout_kernel")):
             cmd = ["python3", "bench.py", "--config", config, "--envs", str(envs), "--mode", mode, "--single-mode",
-                   "--no-cpu-baseline", "--steps", "200", "--warmup", "50"]
+                   "--no-cpu-baseline", "--no-decima", "--no-c3", "--steps", "200", "--warmup", "50"]
+            # the regime the counters are collected in (steady state: bench.py pre-rolls every env), from an unprofiled run
+            line = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT).stdout.strip().splitlines()[-1]
+            ref = json.loads(line)
             per = {}
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals = pmc_run(counter, f"{config}_{mode}", cmd)
@@ -69,6 +72,7 @@ def main():
                          "fetch_size_kib_raw": per["FETCH_SIZE"], "write_size_kib_raw": per["WRITE_SIZE"],
                          "calibration": {"fetch_factor": f_fetch, "write_factor": f_write,
                                          "how": "256 MiB torch copy_ kernel in the same rocprofv3 setup"},
+                         "events_per_step": ref["events_per_step"], "algorithmic_bytes_per_launch": ref["roofline"]["bytes_per_launch"],
                          "hbm_bytes_per_launch": hbm})
             print(recs[-1], flush=True)
     json.dump(recs, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
