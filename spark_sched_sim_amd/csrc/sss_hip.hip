@@ -13,6 +13,22 @@
 #include "zig_tables.inc"
 
 static int be_set_device(int device) { return (int)hipSetDevice(device); }
+// launches of a handle go to the handle's device whatever the caller's current device is, and leave
+// the caller's current device as it was
+struct BeDeviceGuard {
+  int prev = -1, dev;
+  explicit BeDeviceGuard(int device) : dev(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~BeDeviceGuard() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+static int be_current_device() {
+  int d = 0;
+  return hipGetDevice(&d) == hipSuccess ? d : 0;
+}
 static const char* be_error(int rc) { return hipGetErrorString((hipError_t)rc); }
 static void* be_alloc(size_t n) {
   void* p = nullptr;
@@ -78,10 +94,11 @@ static int be_launch_decima_policy(const SssLayout& L, const SssBuffers& B, int 
   if (k < 1) return -1;
   if (k > 4) k = 4;
   size_t lds = (size_t)w_bytes + (size_t)k * per_env;
-  static size_t granted = 0;
-  if (lds > granted) {  // more than the default 64 KB of dynamic LDS has to be asked for
+  static size_t granted[64] = {0};  // per device: the attribute belongs to the device's copy of the kernel
+  size_t& g = granted[be_current_device() & 63];
+  if (lds > g) {  // more than the default 64 KB of dynamic LDS has to be asked for
     if (hipFuncSetAttribute((const void*)sss_decima_policy_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-    granted = lds;
+    g = lds;
   }
   hipLaunchKernelGGL(sss_decima_policy_mw_kernel, dim3((L.num_envs + k - 1) / k), dim3(64 * k), lds, (hipStream_t)stream, L, B, E, d, k, per_env);
   return (int)hipGetLastError();

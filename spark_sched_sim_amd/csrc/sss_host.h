@@ -172,6 +172,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   int J_cap;
   if (int rc = sss_validate(cfg, pack, pack_bytes, num_envs, &ph, &J_cap)) return rc;
   if (!out) return sss_fail(-1, "out is NULL");
+  BeDeviceGuard guard(device);  // allocations and uploads on the env's device; the caller's current device is restored
   if (int rc = be_set_device(device)) return sss_fail(-10, "cannot select device " + std::to_string(device) + ": " + be_error(rc));
   sss_handle* h = new sss_handle();
   h->cfg = *cfg, h->ph = ph, h->device = device, h->bound = false;
@@ -273,6 +274,7 @@ static SssKernelArgs sss_args(const sss_handle* h) {
 extern "C" int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double* time_limits_dev, const uint8_t* mask_dev, void* stream) {
   if (!h || !seeds_dev) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  BeDeviceGuard guard(h->device);
   if (int rc = be_launch_reset(sss_args(h), h->L.num_envs, seeds_dev, time_limits_dev, mask_dev, stream)) return sss_fail(-30, std::string("reset launch failed: ") + be_error(rc));
   return 0;
 }
@@ -280,6 +282,7 @@ extern "C" int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double*
 extern "C" int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, void* stream) {
   if (!h || !stage_idx_dev || !num_exec_dev) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  BeDeviceGuard guard(h->device);
   if (int rc = be_launch_step(sss_args(h), h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("step launch failed: ") + be_error(rc));
   return 0;
 }
@@ -287,6 +290,7 @@ extern "C" int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32
 extern "C" int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_idx_dev, int32_t* num_exec_dev, void* stream) {
   if (!h || !stage_idx_dev || !num_exec_dev) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  BeDeviceGuard guard(h->device);
   if (policy < 0 || policy > 2) return sss_fail(-23, "unknown policy");
   if (int rc = be_launch_policy(sss_args(h), h->L.num_envs, policy, param, stage_idx_dev, num_exec_dev, stream)) return sss_fail(-30, std::string("policy launch failed: ") + be_error(rc));
   return 0;
@@ -295,6 +299,7 @@ extern "C" int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_i
 extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream) {
   if (!h) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  BeDeviceGuard guard(h->device);
   if (policy < 0 || policy > 2) return sss_fail(-23, "unknown policy");
   if (n_steps < 0) return sss_fail(-24, "n_steps must be >= 0");
   if (int rc = be_launch_rollout(sss_args(h), h->L.num_envs, policy, param, n_steps, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("rollout launch failed: ") + be_error(rc));
@@ -304,6 +309,7 @@ extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, in
 extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream) {
   if (!h || !g) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  BeDeviceGuard guard(h->device);
   if (!g->node_off_dev || !g->job_off_dev || !g->edge_off_dev || !g->x_dev || !g->node_obs_dev || !g->node_loc_dev || !g->node_job_dev ||
       !g->sched_rank_dev || !g->gen_dev || !g->node_recv_dev || !g->stage_mask_dev || !g->src_dev || !g->dst_dev || !g->edge_obs_dev ||
       !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev ||
@@ -336,6 +342,7 @@ extern "C" int sss_decima_layer_lists(int num_envs, const sss_decima_lists* g, v
 extern "C" int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* g, void* stream) {
   if (!h || !g) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  BeDeviceGuard guard(h->device);
   if (!g->w_prep_dev || !g->w_msg_dev || !g->w_upd_dev || !g->w_dag_dev || !g->w_glob_dev || !g->w_stage_dev || !g->w_exec_dev ||
       !g->node_scratch_dev || !g->job_scratch_dev || !g->stage_idx_dev || !g->num_exec_dev || !g->stage_sel_dev || !g->job_idx_dev ||
       !g->exec_sel_dev || !g->lgprob_dev)
@@ -384,6 +391,7 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
 
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
+  BeDeviceGuard guard(h->device);
   be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev), be_free(h->jump_dev);
   delete h;
 }

@@ -45,8 +45,9 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
         self.beta: float = env_cfg.get("beta", 0)
         self.job_arrival_cap = env_cfg.get("job_arrival_cap")
         self.render_mode = None
-        from .spaces import make_action_space
+        from .spaces import make_action_space, make_observation_space
         self.action_space = make_action_space(self.num_executors)
+        self.observation_space = make_observation_space(self.num_executors)
         self._vec = VecSparkSchedSimEnv(env_cfg, 1, device=device, _lib=_lib)
         self._act_s = torch.zeros(1, dtype=torch.int32, device=self._vec.device)
         self._act_n = torch.ones(1, dtype=torch.int32, device=self._vec.device)
@@ -60,6 +61,7 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
         self._vec.reset(seed=None if seed is None else [seed], options=options)
         self._raise()
         self.job_arrival_cap = self._vec.header(0)["J"]  # reference overwrites it (spark_sched_sim.py:156)
+        self.observation_space["source_job_idx"].n = self.job_arrival_cap + 1  # :157
         return self._observe(), self.info
 
     def step(self, action: dict):
@@ -79,6 +81,7 @@ class SparkSchedSimEnv(_Base):  # type: ignore[misc]
     def _observe(self) -> dict:
         obs = self._vec.obs_view(0)
         self.action_space["stage_idx"].n = len(obs["dag_batch"].nodes) + 1  # spark_sched_sim.py:403-404
+        self.observation_space["dag_ptr"].feature_space.n = len(obs["dag_batch"].nodes) + 1
         return obs
 
     def close(self) -> None:

@@ -85,9 +85,13 @@ class VecSparkSchedSimEnv:
         self._dg_pool: dict[int, torch.Tensor] = {}
         # gymnasium.vector.VectorEnv attributes; the per-env action space is the reference's at
         # construction (its stage_idx bound follows each observation: valid range is [-1, n_nodes[i]))
-        from .spaces import make_action_space
+        from .spaces import make_action_space, make_observation_space
         self.single_action_space = make_action_space(self.num_executors)
         self.action_space = self.single_action_space
+        # per-env observation space of the reference (its two episode-dependent bounds are those of the env at
+        # construction here; the per-env views of the facade keep them current, env.py)
+        self.single_observation_space = make_observation_space(self.num_executors, NUM_NODE_FEATURES)
+        self.observation_space = self.single_observation_space
 
     # ---- plumbing ---------------------------------------------------------------------
 
@@ -151,13 +155,19 @@ class VecSparkSchedSimEnv:
     def step(self, actions):
         """reference `step(action)` (spark_sched_sim.py:188-221), batched.
         `actions`: {"stage_idx": i32[B], "num_exec": i32[B]} (tensors on the env's device).
-        Returns (obs, reward f64[B], terminated bool[B], truncated bool[B], info)."""
+        Returns (obs, reward f64[B], terminated bool[B], truncated bool[B], info).
+
+        Aliasing contract: `obs` holds VIEWS of the env's observation buffers - the next step / reset
+        overwrites them in place (zero-copy hand-off to a policy on the device). The small per-env
+        vectors a loop typically keeps across steps - reward, terminated, info["wall_time"],
+        info["err"] - are copies. `step_async` + the buffers themselves is the copy-free path."""
         if set(actions.keys()) != {"stage_idx", "num_exec"}:
             raise ValueError("invalid action: does not belong to the action space")  # Dict.contains
         self.step_async(actions["stage_idx"], actions["num_exec"])
         obs = self._obs()
-        terminated = obs["terminated"] != 0
-        return obs, self.obs_f64[:, 0], terminated, torch.zeros_like(terminated), {"wall_time": self.obs_f64[:, 1], "err": obs["err"]}
+        small = torch.cat([self.obs_f64, self.obs_i32[:, 6:8].to(torch.float64)], dim=1)  # ONE copy: reward, wall_time, terminated, err
+        terminated = small[:, 2] != 0
+        return obs, small[:, 0], terminated, torch.zeros_like(terminated), {"wall_time": small[:, 1], "err": small[:, 3].to(torch.int32)}
 
     # ---- on-device policies and fused rollouts ---------------------------------------------
 

@@ -23,6 +23,9 @@ extern "C" { long long sss_batch_stats[32]; }
 #include "zig_tables.inc"
 
 static int be_set_device(int) { return 0; }
+struct BeDeviceGuard {
+  explicit BeDeviceGuard(int) {}
+};
 static const char* be_error(int) { return "emulator"; }
 static void* be_alloc(size_t n) { return calloc(1, n ? n : 1); }
 static void be_free(void* p) { free(p); }

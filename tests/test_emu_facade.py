@@ -98,3 +98,42 @@ def test_reference_style_episode_loop_reproduces_the_reference_metric():
     got = metrics.avg_job_duration(env) * 1e-3
     assert bits(got) == bits(np.mean(g.ep(1234, "job_durations")) * 1e-3)
     env.close()
+
+
+def test_observation_space_follows_the_episode():
+    """spark_sched_sim.py:96-125: the observation space of the reference, with the two bounds that move
+    (`dag_ptr` after every observation, :403)"""
+    g = Golden("tiny_hash")
+    env = SparkSchedSimEnv(g.cfg, device="cpu", _lib=load_emu())
+    sp = env.observation_space
+    assert set(sp.keys()) == {"dag_batch", "dag_ptr", "num_committable_execs", "source_job_idx", "exec_supplies"}
+    assert sp["num_committable_execs"].n == g.cfg["num_executors"] + 1 and sp["exec_supplies"].feature_space.n == 2 * g.cfg["num_executors"]
+    obs, _ = env.reset(seed=0)
+    n = len(obs["dag_batch"].nodes)
+    assert sp["dag_ptr"].feature_space.n == n + 1
+    assert sp["dag_batch"].contains(obs["dag_batch"]) and sp["dag_ptr"].contains(obs["dag_ptr"])
+    assert sp["num_committable_execs"].contains(obs["num_committable_execs"]) and sp["exec_supplies"].contains(obs["exec_supplies"])
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    vec = VecSparkSchedSimEnv(g.cfg, 2, device="cpu", _lib=load_emu())
+    assert set(vec.single_observation_space.keys()) == set(sp.keys()) and vec.single_action_space["num_exec"].n == g.cfg["num_executors"]
+    vec.close()
+    env.close()
+
+
+def test_step_returns_copies_of_the_small_vectors():
+    """rewards / flags kept across steps must not change under the caller's feet (the observation tensors are views, by contract)"""
+    import torch
+
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+
+    g = Golden("tiny_hash")
+    vec = VecSparkSchedSimEnv(g.cfg, 3, device="cpu", _lib=load_emu())
+    vec.reset(seed=0)
+    kept = []
+    for _ in range(12):
+        _, rew, term, _, info = vec.step(vec.policy_actions("fair"))
+        kept.append((rew, rew.clone(), info["wall_time"], info["wall_time"].clone()))
+    for rew, rew0, wt, wt0 in kept:
+        assert torch.equal(rew, rew0) and torch.equal(wt, wt0)
+    assert any(float(k[2].max()) > 0 for k in kept)
+    vec.close()
