@@ -1,0 +1,73 @@
+"""-m gpu: one rank's share of BASELINE configs 4 and 5 (8192 envs on 8 GPUs = 1024 envs per GPU).
+
+* config 4: 1024 envs with the Decima GNN policy sampling every action on the device; 32 of the
+  envs are replayed through the C oracle, action by action, bit for bit;
+* config 5: one PPO iteration shaped like the reference's config/decima_tpch.yaml (50 executors,
+  200 jobs, 4 rollouts per job sequence, 3 epochs x 10 batches, target KL 0.01) with 1024 envs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from decima_util import AGENT
+from golden_util import bits
+
+pytestmark = pytest.mark.gpu
+
+C2 = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+
+
+def test_config4_rank_share_decima_in_loop_with_oracle_sample(pack):
+    from oracle_binding import OracleEnv
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    B, T, base = 1024, 160, 4000
+    env = VecSparkSchedSimEnv(C2, B, device="cuda:0", pack=pack)
+    torch.manual_seed(3)
+    policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval()
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    env.reset(seed=base)
+    sample = np.linspace(0, B - 1, 32).astype(int)
+    acts, rews, walls, terms, errs = [], [], [], [], []
+    for _ in range(T):
+        act, aux = policy.schedule_env(env, generator=gen)
+        acts.append((act["stage_idx"][sample].cpu().numpy().copy(), act["num_exec"][sample].cpu().numpy().copy()))
+        _, r, term, _, info = env.step(act)
+        rews.append(r[sample].cpu().numpy()), walls.append(info["wall_time"][sample].cpu().numpy())
+        terms.append(term[sample].cpu().numpy()), errs.append(info["err"][sample].cpu().numpy())
+    assert torch.isfinite(aux["lgprob"]).all()
+    assert int(env.header_field("n_steps").sum()) > B * T // 2
+    for col, k in enumerate(sample):
+        o = OracleEnv(pack, C2)
+        assert o.reset(base + int(k)) == 0
+        for t in range(T):
+            if errs[t][col]:  # the reference's "[step]" stall or a finished episode: the oracle must agree, then the env is dead
+                e, _, _ = o.step(int(acts[t][0][col]), int(acts[t][1][col]))
+                assert e == int(errs[t][col]), (k, t, e, errs[t][col])
+                break
+            e, r, term = o.step(int(acts[t][0][col]), int(acts[t][1][col]))
+            assert e == 0 and bits(r) == bits(rews[t][col]) and bits(o.info().wall_time) == bits(walls[t][col]) and term == bool(terms[t][col]), (k, t)
+            if term:
+                break
+        o.close()
+    env.close()
+
+
+def test_config5_rank_share_one_ppo_iteration(tmp_path):
+    from spark_sched_sim_amd.training import Trainer
+
+    # config/decima_tpch.yaml: trainer 3 epochs x 10 batches, clip 0.2, target KL 0.01, entropy 0.04, beta 5e-3, Adam 3e-4,
+    # max grad norm 0.5; env 50 executors, 200 jobs, 4e-5 arrivals/ms, mean time limit 2e7 ms; 4 rollouts per sequence
+    train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=256, num_rollouts=4, seed=42, checkpointing_freq=10 ** 9,
+                 num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3,
+                 opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir=str(tmp_path), rollout_duration=6.0e4, on_env_error="truncate")
+    env = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), env, train, device="cuda:0")
+    assert tr.env.num_envs == 1024
+    before = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    hist = tr.train(verbose=False)
+    assert len(hist) == 1 and hist[0]["samples"] > 1024
+    assert all(np.isfinite(hist[0][k]) for k in ("policy loss", "entropy", "approx kl div"))
+    assert any(not torch.equal(before[k], v) for k, v in tr.policy.state_dict().items())
+    tr.close()
