@@ -506,7 +506,29 @@ struct SetImg {
   T* big;
   T* small;      // where an 8-slot table goes (pool images), or nullptr
   uint32_t aux;  // pool images: the record's outgoing commitment count, carried from pool_open to pool_close
+  bool wide;     // `tab` is in HBM: probe groups are fetched whole (ProbeGroup)
 };
+
+// One probe group of a byte table (entries i .. i + probes, at most 10) fetched with two accesses
+// instead of up to ten dependent ones; used for tables in HBM (`wide`), whose accesses may be unaligned.
+struct ProbeGroup {
+  uint64_t lo;
+  uint32_t hi;
+};
+SSS_DEV uint32_t probe_group_at(const ProbeGroup& g, uint32_t p) { return p < 8 ? (uint32_t)(g.lo >> (8 * p)) & 0xFFu : (g.hi >> (8 * (p - 8))) & 0xFFu; }
+template <typename T>
+SSS_DEV ProbeGroup probe_group_load(const T* tab, uint32_t i, uint32_t probes) {
+  ProbeGroup g;
+  g.lo = 0, g.hi = 0;
+  if (probes) {
+    uint16_t h;
+    __builtin_memcpy(&g.lo, (const uint8_t*)tab + i, 8);
+    __builtin_memcpy(&h, (const uint8_t*)tab + i + 8, 2);
+    g.hi = h;
+  } else
+    g.lo = ((const uint8_t*)tab)[i];
+  return g;
+}
 
 template <typename T>
 SSS_DEV void set_insert_clean(T* tab, uint32_t mask, uint32_t key) {
@@ -536,9 +558,9 @@ SSS_DEV void set_resize(SetImg<T>& s, uint32_t minused, uint16_t* keys) {
     if (e >= 2) keys[n++] = (uint16_t)(e - 2);
   }
   if (newsize > s.cap)
-    s.tab = s.big, s.cap = 0xFFFFFFFFu;  // the live keys are in `keys`: nothing to copy
+    s.tab = s.big, s.cap = 0xFFFFFFFFu, s.wide = true;  // the live keys are in `keys`: nothing to copy
   else if (newsize <= 8 && s.small)
-    s.tab = s.small, s.cap = 8;          // a pool image that fits its record again
+    s.tab = s.small, s.cap = 8, s.wide = false;         // a pool image that fits its record again
   for (uint32_t i = 0; i < newsize; i++) s.tab[i] = 0;
   for (uint32_t i = 0; i < n; i++) set_insert_clean(s.tab, newsize - 1, keys[i]);
   s.mask = newsize - 1;
@@ -555,8 +577,10 @@ SSS_DEV void set_add(SetImg<T>& s, uint32_t key, uint16_t* keys) {
   for (;;) {
     uint32_t probes = (i + 9 <= mask) ? 9 : 0;
     bool found = false;
+    ProbeGroup g;
+    if (sizeof(T) == 1 && s.wide) g = probe_group_load(s.tab, i, probes);
     for (uint32_t p = 0; p <= probes; p++) {
-      uint32_t e = s.tab[i + p];
+      uint32_t e = (sizeof(T) == 1 && s.wide) ? probe_group_at(g, p) : (uint32_t)s.tab[i + p];
       if (e == 0) {
         idx = i + p;
         found = true;
@@ -588,8 +612,10 @@ SSS_DEV bool set_remove(SetImg<T>& s, uint32_t key) {
   uint32_t perturb = key;
   for (;;) {
     uint32_t probes = (i + 9 <= mask) ? 9 : 0;
+    ProbeGroup g;
+    if (sizeof(T) == 1 && s.wide) g = probe_group_load(s.tab, i, probes);
     for (uint32_t p = 0; p <= probes; p++) {
-      uint32_t e = s.tab[i + p];
+      uint32_t e = (sizeof(T) == 1 && s.wide) ? probe_group_at(g, p) : (uint32_t)s.tab[i + p];
       if (e == 0) return false;
       if (e == key + 2) {
         s.tab[i + p] = 1;
@@ -629,9 +655,9 @@ SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
   s.small = g_sc.pool8;
   if (s.mask == 7) {
     *(uint2*)g_sc.pool8 = mk_u2(rec.z, rec.w);
-    s.tab = g_sc.pool8, s.cap = 8;
+    s.tab = g_sc.pool8, s.cap = 8, s.wide = false;
   } else
-    s.tab = s.big, s.cap = 0xFFFFFFFFu;
+    s.tab = s.big, s.cap = 0xFFFFFFFFu, s.wide = true;
   return s;
 }
 // nothing else may have been opened in between (one scratch table), no commitment of the pool changed
@@ -842,7 +868,7 @@ SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send) {  
         SetImg<uint8_t> s;
         *(uint2*)g_sc.pool8 = mk_u2((uint32_t)t, (uint32_t)(t >> 32));
         s.tab = g_sc.pool8, s.cap = 8, s.small = g_sc.pool8, s.big = g_c.pool_tab + (size_t)pool_index(new_pool) * sss_pool_table_bytes(g_c.E);
-        s.mask = 7, s.fill = fill, s.used = used, s.finger = 0, s.aux = rn.y >> 16;
+        s.mask = 7, s.fill = fill, s.used = used, s.finger = 0, s.aux = rn.y >> 16, s.wide = false;
         set_resize(s, s.used * 4, lds_keys());
         pool_close(new_pool, s);
       } else
@@ -1103,18 +1129,30 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
   SetImg<uint8_t> out;
   out.tab = g_sc.setB;
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
-  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0, out.cap = 0xFFFFFFFFu, out.big = nullptr, out.small = nullptr;
+  out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0, out.cap = 0xFFFFFFFFu, out.big = nullptr, out.small = nullptr, out.wide = false;
   if (key == POOL_NONE) return out;
   SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
   cp.tab = g_sc.setA;
   for (int i = 0; i < 8; i++) cp.tab[i] = 0;
-  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0, cp.cap = 0xFFFFFFFFu, cp.big = nullptr, cp.small = nullptr;
+  cp.mask = 7, cp.fill = 0, cp.used = 0, cp.finger = 0, cp.cap = 0xFFFFFFFFu, cp.big = nullptr, cp.small = nullptr, cp.wide = false;
   if (src.used != 0) {
     if ((cp.fill + src.used) * 5 >= cp.mask * 3) set_resize(cp, (cp.used + src.used) * 2, lds_keys());
     if (cp.mask == src.mask && src.fill == src.used) {
-      for (uint32_t i = 0; i <= src.mask; i++) cp.tab[i] = src.tab[i];
+      if (src.wide)  // tables beyond the record's 8 slots have 16 slots or more: 16 bytes at a time
+        for (uint32_t w = 0; w < (src.mask + 1) / 16; w++) ((uint4*)cp.tab)[w] = ((const uint4*)src.tab)[w];
+      else
+        for (uint32_t i = 0; i <= src.mask; i++) cp.tab[i] = src.tab[i];
+    } else if (src.wide) {
+      for (uint32_t w = 0; w < (src.mask + 1) / 16; w++) {
+        const uint4 q = ((const uint4*)src.tab)[w];
+        const uint32_t word[4] = {q.x, q.y, q.z, q.w};
+        for (int b = 0; b < 16; b++) {
+          uint32_t en = (word[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+          if (en >= 2) set_insert_clean(cp.tab, cp.mask, en - 2);
+        }
+      }
     } else {
       for (uint32_t i = 0; i <= src.mask; i++) {
         uint32_t en = src.tab[i];
@@ -1136,12 +1174,19 @@ SSS_DEV_NOINLINE void move_idle_executors_all(uint32_t src) {
   if (src == POOL_NONE) src = H.curr_source;
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
+  int j = key_job(src), s = key_stage(src);
+  bool is_sat = (int)(*jobp(j)).sat_count == (int)(*jobp(j)).n_stages;
+  if (s < 0 && !is_sat) {
+    // nothing moves (ENV:766-769) - but the reference has built the idle list by then and asserts that it
+    // is not empty ("[_move_idle_executors],2"): the pool's idle members are the executors located in it
+    bool any_idle = false;
+    for (int e = 0; e < g_c.E; e++) any_idle = any_idle || (g_hot.ex_loc[e] == src && !g_hot.ex_executing[e]);
+    CHECK(any_idle);
+    return;
+  }
   SetImg<uint8_t> idle = get_idle_source_executors(src);
   CHECK(idle.used > 0);  // assert executor_ids, "[_move_idle_executors],2"
   if (H.err) return;
-  int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)(*jobp(j)).sat_count == (int)(*jobp(j)).n_stages;
-  if (s < 0 && !is_sat) return;
   uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
   for (uint32_t i = 0; i <= idle.mask; i++) {  // list(set): ascending slot order
     uint32_t en = idle.tab[i];
@@ -1986,7 +2031,7 @@ SSS_DEV_NOINLINE void jobtime_build_set() {
   SetImg<uint16_t> all;
   all.tab = lds_jobset();
   for (int i = 0; i < 8; i++) all.tab[i] = 0;
-  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0, all.cap = 0xFFFFFFFFu, all.big = nullptr, all.small = nullptr;
+  all.mask = 7, all.fill = 0, all.used = 0, all.finger = 0, all.cap = 0xFFFFFFFFu, all.big = nullptr, all.small = nullptr, all.wide = false;
   for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active()[k], lds_keys());
   for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active()[k], lds_keys());
   g_sc.jobset_mask = (int32_t)all.mask;
