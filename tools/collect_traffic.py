@@ -31,11 +31,14 @@ def pmc_run(counter: str, tag: str, cmd: list[str]) -> dict[str, list[float]]:
     d = os.path.join(OUT, f"traffic_{tag}_{counter}")
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--"] + cmd,
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
-    vals: dict[str, list[float]] = {}
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
-                vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                rows.append((int(row.get("Dispatch_Id", len(rows))), row["Kernel_Name"], float(row["Counter_Value"])))
+    vals: dict[str, list[float]] = {}
+    for _, name, v in sorted(rows):  # launch order: the timed launches are the last ones of a bench run
+        vals.setdefault(name, []).append(v)
     return vals
 
 
@@ -66,6 +69,10 @@ def main():
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals = pmc_run(counter, f"{config}_{mode}", cmd)
                 v = vals.get(kernel, [])
+                if mode == "fused":  # only the timed launches (200 steps in chunks of 50); the pre-roll launches are longer
+                    v = v[-4:]
+                else:
+                    v = v[-200:]
                 per[counter] = sum(v) / len(v) if v else float("nan")
             hbm = (per["FETCH_SIZE"] * f_fetch + per["WRITE_SIZE"] * f_write) * 1024.0
             recs.append({"kernel": kernel, "config": config, "envs": envs, "mode": mode,
