@@ -50,6 +50,11 @@ struct alignas(16) SssScratch {
   int32_t events_this_step;
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
   int32_t pinned_job;             // job of the event being handled: its cache slot is not given away
+  // the idle executors of pool `idle_key`, found with one ballot right before a lane-0 section that asks for
+  // them (publish_idle_mask); consumed by the next get_idle_source_executors, valid for nothing else
+  uint32_t idle_key;
+  int32_t idle_valid;
+  uint64_t idle_mask;
   int32_t jobset_mask, f_need_jobtime;
   // the set image of (old active list + active list) only changes when a job arrives or completes:
   // versions of the two lists it was built from (valid within one launch)
@@ -139,7 +144,7 @@ SSS_DEV void ctx_init() { prof3_clear(); }
 #endif
 
 #ifdef SSS_BATCH_STATS  // emulator-only census of why rounds end (tests/emu, never in the product build)
-extern "C" { extern long long sss_batch_stats[32]; }
+extern "C" { extern long long sss_batch_stats[64]; }
 #define STAT(i, v) ((void)(wave_lane() == 0 ? (sss_batch_stats[i] += (v)) : 0))
 #else
 #define STAT(i, v) ((void)0)
@@ -1117,6 +1122,13 @@ SSS_DEV void move_idle_executor(uint32_t src, int e) {
 }
 
 // set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
+// all lanes: which executors sit idle in the source pool (a pool's members are the executors located in it)
+SSS_DEV void publish_idle_mask() {
+  int lane = wave_lane();
+  uint32_t key = g_hot.h.curr_source;
+  uint64_t m = wave_ballot(lane < g_c.E && key != POOL_NONE && g_hot.ex_loc[lane] == key && !g_hot.ex_executing[lane]);
+  if (lane == 0) g_sc.idle_key = key, g_sc.idle_mask = m, g_sc.idle_valid = 1;
+}
 SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key);
 SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
   EVP2_BEGIN;
@@ -1131,6 +1143,20 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
   for (int i = 0; i < 8; i++) out.tab[i] = 0;
   out.mask = 7, out.fill = 0, out.used = 0, out.finger = 0, out.cap = 0xFFFFFFFFu, out.big = nullptr, out.small = nullptr, out.wide = false;
   if (key == POOL_NONE) return out;
+  if (g_sc.idle_valid && g_sc.idle_key == key) {
+    // at most one idle executor: the set built from the pool's copy is {e} whatever the iteration order
+    // (one add into a fresh 8-slot table) - the usual case when executors are released one at a time
+    uint64_t m = g_sc.idle_mask;
+    g_sc.idle_valid = 0;
+    if ((m & (m - 1)) == 0) {
+      if (m) {
+        int e = ctz64(m);
+        out.tab[e & 7] = (uint8_t)(e + 2);
+        out.fill = out.used = 1;
+      }
+      return out;
+    }
+  }
   SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
   SetImg<uint8_t> cp;
@@ -1257,14 +1283,28 @@ SSS_DEV_NOINLINE void fulfill_commitments_from_source() {  // ENV:730-743
     dsts[n] = hot.c_dst[bi], nums[n] = hot.c_n[bi], n++;
     last_seq = best, first = false;
   }
+#ifdef SSS_BATCH_STATS
+  int st_m = 0, st_send = 0, st_local = 0, st_common = 0;
+#endif
   for (int i = 0; i < n && !H.err; i++) {
     int num = nums[i];
     while (num && idle.used && !H.err) {
       int e = (int)set_pop(idle);
+#ifdef SSS_BATCH_STATS
+      st_m++;
+      if (dsts[i] == POOL_COMMON) st_common++;
+      else if (g_hot.ex_job[e] != key_job(dsts[i])) st_send++;
+      else st_local++;
+#endif
       fulfill_commitment(e, dsts[i]);
       num--;
     }
   }
+#ifdef SSS_BATCH_STATS
+  sss_batch_stats[40] += 1, sss_batch_stats[41] += st_m, sss_batch_stats[42] += st_send, sss_batch_stats[43] += st_local, sss_batch_stats[44] += st_common;
+  if (st_m >= 8) sss_batch_stats[45] += 1, sss_batch_stats[46] += st_m, sss_batch_stats[47] += (st_send == st_m), sss_batch_stats[48] += (st_send == st_m) ? st_m : 0, sss_batch_stats[49] += (src == POOL_COMMON);
+  if (st_m >= 8 && st_send != st_m) sss_batch_stats[50] += st_send, sss_batch_stats[51] += st_local, sss_batch_stats[52] += st_common;
+#endif
   CHECK(idle.used == 0);
 }
 
@@ -1912,7 +1952,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
     uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
     g_sc.free_slots = all & ~used;
-    g_sc.pending_free = -1, g_sc.pinned_job = -1;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0;
     g_sc.events_this_step = 0;
     g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
     g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
@@ -2195,9 +2235,11 @@ SSS_DEV void resume_simulation() {
       wave_sync();
       return;
     }
+    publish_idle_mask();
     if (lane == 0) {
       move_idle_executors_all(POOL_NONE);  // ENV:340
       H.curr_source = POOL_NONE;               // ENV:341
+      g_sc.idle_valid = 0;
     }
     wave_sync();
   }
@@ -2214,7 +2256,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   wave_sync();
   if (lane == 0) {
     g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    g_sc.pending_free = -1, g_sc.pinned_job = -1;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
     int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
@@ -2330,6 +2372,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   PROF3(28);
   int lane = wave_lane();
   uint64_t t0 = wave_clock();
+  publish_idle_mask();  // for fulfill_commitments_from_source, should the round end with this action (nothing below moves an executor before it)
   if (lane == 0) {
     g_sc.f_round_continues = 1;
     g_sc.events_this_step = 0;
@@ -2355,6 +2398,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
       }
       if (H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
     }
+    g_sc.idle_valid = 0;
   }
   wave_sync();
   uint64_t t1 = wave_clock();
