@@ -64,6 +64,12 @@ struct alignas(16) SssScratch {
   double wall_old;
   uint32_t fc_dst[SSS_MAX_EXEC];  // snapshot of the source's commitments (fulfill_commitments_from_source)
   int16_t fc_num[SSS_MAX_EXEC];
+  // the executors that fulfil them, in the order the reference pops them (fulfil_build_list): executor,
+  // index of its commitment in the snapshot, and what became of it in a lane-parallel chunk
+  uint8_t fi_e[SSS_MAX_EXEC], fi_k[SSS_MAX_EXEC], fi_type[SSS_MAX_EXEC];
+  int32_t fi_m, fi_m_par, f_fulfil;
+  uint64_t fi_detach;             // executors a chunk detaches from the source's job
+  uint32_t fi_rng_pos, fi_rng_has32, fi_rng_u32, fi_pad;
 };
 
 #define SSS_STATIC_LDS_BYTES ((int)(sizeof(SssHot) + sizeof(SssScratch)))
@@ -176,6 +182,7 @@ SSS_DEV void prof3_flush() {}
 #endif
 
 // ---- LDS pool views ----
+#define LENW_LEN 0x3FFFFFFF  // list length in a duration descriptor (bit 30: warmup_delay is added)
 #define SLOT_NONE 255
 SSS_DEV uint16_t* lds_active() { return (uint16_t*)(g_pool + g_c.P.off_active); }
 SSS_DEV uint8_t* lds_slot_of() { return g_pool + g_c.P.off_slot_of; }
@@ -673,7 +680,7 @@ SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
     const uint2 t = *(const uint2*)g_sc.pool8;
     *(uint4*)hd = mk_u4(w0, w1, t.x, t.y);
   } else
-    *(uint2*)hd = mk_u2(w0, w1);
+    *(uint4*)hd = mk_u4(w0, w1, 0u, 0u);  // the table lives in the overflow area; the inline bytes are kept clean
 }
 SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
 SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
@@ -1263,12 +1270,14 @@ SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
   move_executor_to_stage(e, key_job(dst), key_stage(dst));
 }
 
-SSS_DEV_NOINLINE void fulfill_commitments_from_source() {  // ENV:730-743
+// ENV:730-743, first half (lane 0): the source's commitments in insertion order (dict copy, TRK:133-134) and the idle
+// executors that will fulfil them, in set.pop() order. What each pop yields does not depend on the
+// fulfilments, so the list is complete before the first executor moves.
+SSS_DEV_NOINLINE void fulfil_build_list() {
   PROF3(12);
   SssHot& hot = g_hot;
   uint32_t src = H.curr_source;
   SetImg<uint8_t> idle = get_idle_source_executors(src);
-  // snapshot of the source's commitments in insertion order (dict copy, TRK:133-134)
   uint32_t* dsts = g_sc.fc_dst;
   int16_t* nums = g_sc.fc_num;
   int n = 0;
@@ -1283,29 +1292,327 @@ SSS_DEV_NOINLINE void fulfill_commitments_from_source() {  // ENV:730-743
     dsts[n] = hot.c_dst[bi], nums[n] = hot.c_n[bi], n++;
     last_seq = best, first = false;
   }
-#ifdef SSS_BATCH_STATS
-  int st_m = 0, st_send = 0, st_local = 0, st_common = 0;
-#endif
-  for (int i = 0; i < n && !H.err; i++) {
+  int m = 0, m_par = -1;
+  for (int i = 0; i < n; i++) {
     int num = nums[i];
-    while (num && idle.used && !H.err) {
-      int e = (int)set_pop(idle);
-#ifdef SSS_BATCH_STATS
-      st_m++;
-      if (dsts[i] == POOL_COMMON) st_common++;
-      else if (g_hot.ex_job[e] != key_job(dsts[i])) st_send++;
-      else st_local++;
-#endif
-      fulfill_commitment(e, dsts[i]);
+    if (dsts[i] == POOL_COMMON && m_par < 0) m_par = m;  // the common pool is committed to last (ENV:196): a suffix
+    while (num && idle.used) {
+      g_sc.fi_e[m] = (uint8_t)set_pop(idle), g_sc.fi_k[m] = (uint8_t)i, m++;
       num--;
     }
   }
-#ifdef SSS_BATCH_STATS
-  sss_batch_stats[40] += 1, sss_batch_stats[41] += st_m, sss_batch_stats[42] += st_send, sss_batch_stats[43] += st_local, sss_batch_stats[44] += st_common;
-  if (st_m >= 8) sss_batch_stats[45] += 1, sss_batch_stats[46] += st_m, sss_batch_stats[47] += (st_send == st_m), sss_batch_stats[48] += (st_send == st_m) ? st_m : 0, sss_batch_stats[49] += (src == POOL_COMMON);
-  if (st_m >= 8 && st_send != st_m) sss_batch_stats[50] += st_send, sss_batch_stats[51] += st_local, sss_batch_stats[52] += st_common;
-#endif
+  g_sc.fi_m = m, g_sc.fi_m_par = m_par < 0 ? m : m_par;
   CHECK(idle.used == 0);
+}
+
+// ENV:730-743, second half, one executor at a time (lane 0): items [from, fi_m) of the list
+SSS_DEV_NOINLINE void fulfil_serial_range(int from, int to) {
+  for (int i = from; i < to && !H.err; i++) fulfill_commitment((int)g_sc.fi_e[i], g_sc.fc_dst[g_sc.fi_k[i]]);
+}
+SSS_DEV void fulfil_serial(int from) { fulfil_serial_range(from, g_sc.fi_m); }
+
+// marks key's slot of a byte table in HBM as a dummy (the table half of set_remove); any lane
+SSS_DEV bool table_mark_dummy(uint8_t* tab, uint32_t mask, uint32_t key) {
+  uint32_t i = key & mask, perturb = key;
+  for (;;) {
+    uint32_t probes = (i + 9 <= mask) ? 9 : 0;
+    ProbeGroup g = probe_group_load(tab, i, probes);
+    for (uint32_t p = 0; p <= probes; p++) {
+      uint32_t en = probe_group_at(g, p);
+      if (en == 0) return false;
+      if (en == key + 2) {
+        tab[i + p] = 1;
+        return true;
+      }
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+
+enum { FI_SEND = 1, FI_EXEC = 2, FI_PARK = 3 };
+
+// ------------------------------------------------------------------------------------------
+// Lane-parallel fulfilment (all lanes): items [c0, c0 + n) of the list, one lane each, n <= 24.
+// An executor committed to a stage is either SENT there (it belongs to another job or to none:
+// ENV:617-637, an EXECUTOR_READY event after moving_delay) or it already works for the stage's job:
+// then it moves into the stage's pool and STARTS a task if the stage is in the frontier
+// (ENV:584-615: a duration draw and a TASK_FINISHED event), else it is PARKED in the job's pool
+// (ENV:808-813, no event). What one fulfilment needs from the
+// ones before it is little, and computable from ballots because the lanes ARE the order:
+//   * the push counter of its event = counter + the number of event-pushing items before it;
+//   * the stage's task counters = initial - the tasks started by the items of the same commitment
+//     before it (items of one commitment are consecutive);
+//   * the job's number of local executors seen by a duration draw = initial - the executors sent away
+//     before it (they are detached from the source's job, JOB:86-89);
+//   * its position in the random stream = the raw outputs consumed by the draws before it, known
+//     without their values (one for random() when the executor-level interval is open, one 32-bit
+//     half for the bounded integer - as in batch_fast_events).
+// Removals from the source pool commute (a removal leaves a dummy, probe chains do not change);
+// additions to a stage's pool are made in item order by lane 0, with one open / close per pool.
+// Returns n when the chunk was fulfilled. When it holds anything else (a stage short of tasks -> backup
+// scheduling, the source pool as destination, an executor parked in the pool it is in, duration lists
+// with one or no entry, a draw that needs Lemire's rejection test) nothing is modified and the
+// return value is the index (< n) of the first item that cannot go this way; [that item, serial_end)
+// - the rest of its commitment - is for the one-at-a-time path, the items before it for a shorter chunk.
+// ------------------------------------------------------------------------------------------
+SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
+  const int lane = wave_lane();
+  const bool active = lane < n;
+  const int idx = c0 + (active ? lane : 0);
+  // ---- reads ----
+  const uint32_t src = g_hot.h.curr_source;
+  const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  const int pos = g_sc.rng_pos;
+  const double wall = g_hot.h.wall_time;
+  const int e = g_sc.fi_e[idx], k = g_sc.fi_k[idx];
+  const uint32_t dst = g_sc.fc_dst[k];
+  const int j = key_job(dst), s = key_stage(dst);
+  const int exj = g_hot.ex_job[e], exts = g_hot.ex_task_stage[e];
+  const int src_job = key_job(src);
+  SssStage* sp = stgp(j, s);
+  SssJob* jp = jobp(j);
+  SssStage st = *sp;
+  const uint64_t local = jp->local_mask;
+  const int gs = jp->gs_base + s;
+  const bool in_frontier = (jp->frontier_mask & bit64(s)) != 0;
+  const int slot = lds_slot_of()[j];
+  const SssPoolHdr src_hdr = g_c.pool_hdr[pool_index(src)];
+  const int type = exj != j ? FI_SEND : (in_frontier ? FI_EXEC : FI_PARK);
+  bool bad = active && (dst == src || s < 0 || g_hot.ex_executing[e] || g_hot.ex_loc[e] != src || (type == FI_PARK && src == key_job_pool(j)) ||
+                        (exj >= 0 && exj != src_job) || (type == FI_SEND && j == src_job));
+  const uint64_t below = bit64(lane) - 1;
+  const uint64_t m_act = wave_ballot(active);
+  const uint64_t m_exec = wave_ballot(active && type == FI_EXEC), m_park = wave_ballot(active && type == FI_PARK);
+  const uint64_t m_send = m_act & ~m_exec & ~m_park, m_event = m_act & ~m_park;
+  const uint64_t m_send_att = wave_ballot(active && type == FI_SEND && exj >= 0);
+  // the items of this lane's commitment (consecutive lanes)
+  uint64_t run = 0;
+  for (uint64_t rem = m_act; rem;) {
+    const int l = ctz64(rem);
+    const uint32_t kk = wave_readlane_u32((uint32_t)k, l);
+    const uint64_t mk = wave_ballot(active && (uint32_t)k == kk);
+    if ((uint32_t)k == kk) run = mk;
+    rem &= ~mk;
+  }
+  const int n_run = popc64(run), n_exec_run = popc64(run & m_exec), n_send_run = popc64(run & m_send), n_park_run = n_run - n_exec_run - n_send_run;
+  // a stage without remaining tasks sends the executor to a backup stage (ENV:784-797): one at a time
+  bad = bad || (active && ((int)st.remaining < n_exec_run + ((n_send_run || n_park_run) ? 1 : 0) || (int)st.commit_to < n_run));
+  // the duration draw of a task start (TPCH:75-106, 216-235)
+  int n_local = 0, li = 0, ri = 0;
+  int4 da = mk_i4(0, 0, 0, 0), db = da;
+  bool open = false;
+  if (active && type == FI_EXEC && !bad) {
+    n_local = popc64(local) - popc64(m_send_att & below);
+    if (n_local <= 0 || n_local > g_c.E)
+      bad = true;
+    else {
+      executor_interval(n_local, li, ri);
+      open = li != ri;
+      const int mode = exts < 0 ? 0 : (exts == s ? 1 : 2);
+      const int32_t* eff = g_c.pk.eff;
+      da = *(const int4*)(eff + (((size_t)gs * 8 + li) * 3 + mode) * 4);
+      db = open ? *(const int4*)(eff + (((size_t)gs * 8 + ri) * 3 + mode) * 4) : da;
+      bad = (da.y & LENW_LEN) <= 1 || (db.y & LENW_LEN) <= 1;
+    }
+  }
+  const uint64_t m_open = wave_ballot(active && type == FI_EXEC && open);
+#ifdef SSS_BATCH_STATS
+  {
+    uint64_t b1 = wave_ballot(active && type == FI_PARK && src == key_job_pool(j)), b2 = wave_ballot(active && dst == src);
+    uint64_t b3 = wave_ballot(active && ((int)st.remaining < n_exec_run + (n_send_run ? 1 : 0))), b4 = wave_ballot(active && (int)st.commit_to < n_run);
+    uint64_t b5 = wave_ballot(active && type == FI_EXEC && ((da.y & LENW_LEN) <= 1 || (db.y & LENW_LEN) <= 1));
+    uint64_t b6 = wave_ballot(active && (g_hot.ex_executing[e] || g_hot.ex_loc[e] != src || (exj >= 0 && exj != src_job) || (type == FI_SEND && j == src_job)));
+    STAT(57, b1 != 0), STAT(58, b2 != 0), STAT(59, b3 != 0), STAT(60, b4 != 0), STAT(61, b5 != 0), STAT(62, b6 != 0);
+  }
+#endif
+  {
+    const uint64_t m_bad = wave_ballot(bad);
+    if (m_bad != 0 || 2 * popc64(m_exec) > 64 - pos) {
+      const int fb = m_bad ? ctz64(m_bad) : 0;
+      const uint32_t rlo = wave_readlane_u32((uint32_t)run, fb), rhi = wave_readlane_u32((uint32_t)(run >> 32), fb);
+      const uint64_t r = ((uint64_t)rhi << 32) | rlo;
+      serial_end = c0 + (r ? 64 - __builtin_clzll(r) : fb + 1);
+      return fb;
+    }
+  }
+  const uint32_t rank = (uint32_t)popc64(m_exec & below), R = (uint32_t)popc64(m_open & below);
+  const uint32_t Fr = h0 ? rank >> 1 : (rank + 1) >> 1;
+  const bool fresh = ((h0 + rank) & 1u) == 0;
+  const uint32_t P = R + Fr;
+  int4 dd = da;
+  uint64_t x32 = 0;
+  uint32_t u32 = 0;
+  const bool is_exec = active && type == FI_EXEC;
+  if (is_exec) {
+    if (open) {
+      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
+      if (!((double)rand_pt <= (double)n_local - left)) dd = db;
+    }
+    if (fresh) {
+      x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
+      u32 = (uint32_t)x32;
+    } else if (rank == 0) {
+      u32 = u32_0;
+    } else {
+      u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);
+    }
+  }
+  const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
+  const uint64_t mm = (uint64_t)u32 * len;
+  {
+    const uint64_t m_rej = wave_ballot(is_exec && (uint32_t)mm < len);
+    if (m_rej != 0) {
+      serial_end = c0 + ctz64(m_rej) + 1;
+      return ctz64(m_rej);
+    }
+  }
+  // ---- commit ----
+  const bool big_src = src_hdr.mask != 7;
+  if (active) {
+    double t = wall + g_c.P.moving_delay;
+    double dur = 0.0;
+    if (is_exec) {
+      dur = (double)g_c.pk.durations[dd.x + (int)(mm >> 32)];
+      if (dd.y >> 30) dur += g_c.P.warmup_delay;
+      t = wall + dur;
+    }
+    if (type != FI_PARK) {
+      SssEvSlot sl;
+      sl.t = t, sl.seq = counter0 + (uint32_t)popc64(m_event & below), sl.info = ev_info(is_exec ? EV_TASK_FINISHED : EV_EXECUTOR_READY, j, s, (uint32_t)slot);
+      g_hot.ev[e] = sl;
+    }
+    if (type == FI_PARK) {
+      g_hot.ex_loc[e] = key_job_pool(j), g_hot.ex_task_stage[e] = -1;  // ENV:808-813
+    } else if (is_exec) {
+      g_hot.ex_loc[e] = dst, g_hot.ex_task_stage[e] = (int8_t)s, g_hot.ex_executing[e] = 1;
+      if ((run & m_exec & ~(below | bit64(lane))) == 0) *durp(j, s) = (float)dur;  // the commitment's last task start: most recent duration (ENV:604)
+      if ((m_exec & ~(below | bit64(lane))) == 0) {  // the chunk's last draw leaves the generator behind
+        g_sc.fi_rng_pos = (uint32_t)pos + P + (open ? 1u : 0u) + (fresh ? 1u : 0u);
+        g_sc.fi_rng_has32 = fresh ? 1u : 0u, g_sc.fi_rng_u32 = fresh ? (uint32_t)(x32 >> 32) : u32;
+      }
+    } else {
+      g_hot.ex_loc[e] = POOL_NONE;
+      if (exj >= 0) {
+        g_hot.ex_job[e] = -1, g_hot.ex_task_stage[e] = -1;  // JOB:86-89
+        lane_atomic_or_u64(&g_sc.fi_detach, bit64(e));
+      }
+    }
+    g_sc.fi_type[idx] = (uint8_t)type;
+    if ((run & ~(below | bit64(lane))) == 0) {  // last item of its commitment: the stage's counters (TRK:159-176,188-222; STG:53-58)
+      st.remaining = (int16_t)(st.remaining - n_exec_run), st.executing = (int16_t)(st.executing + n_exec_run);
+      st.commit_to = (int16_t)(st.commit_to - n_run), st.moving_to = (int16_t)(st.moving_to + n_send_run);
+      *sp = st;
+      if (n_exec_run && st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
+      // executor demand = remaining - (moving_to + commit_to) is what it was unless executors were parked
+      // (their commitments are gone, they did not reach the stage): then the saturation bit is re-derived
+      if (n_park_run) {
+        if ((int)st.remaining - ((int)st.moving_to + (int)st.commit_to) <= 0)
+          lane_atomic_or_u64(&jp->sat_mask, bit64(s));
+        else
+          lane_atomic_and_u64(&jp->sat_mask, ~bit64(s));
+      }
+    }
+    if (big_src) {
+      bool was = table_mark_dummy(g_c.pool_tab + (size_t)pool_index(src) * sss_pool_table_bytes(g_c.E), src_hdr.mask, (uint32_t)e);
+      CHECK(was);
+    }
+  }
+  wave_sync();
+  if (lane == 0) {
+    // the source pool's record: n executors and n commitments fewer
+    {
+      SetImg<uint8_t> sset = pool_open(src);
+      if (!big_src) {
+        for (int i = c0; i < c0 + n; i++) {
+          bool was = set_remove(sset, (uint32_t)g_sc.fi_e[i]);
+          CHECK(was);
+        }
+      } else
+        sset.used -= (uint32_t)n;
+      sset.aux -= (uint32_t)n;
+      pool_close(src, sset);
+    }
+    // executors sent away leave the source's job (JOB:86-89, TRK:218-221)
+    if (src_job >= 0) {
+      const int n_send_all = popc64(m_send);
+      if (n_send_all) add_supply(src_job, -n_send_all);
+      if (g_sc.fi_detach) (*jobp(src_job)).local_mask &= ~g_sc.fi_detach;
+    }
+    g_sc.fi_detach = 0;
+    // stage pools receive their executors in item order; commitments are settled; events name their jobs' slots
+    for (int i = c0; i < c0 + n;) {
+      const int kk = g_sc.fi_k[i];
+      const uint32_t d = g_sc.fc_dst[kk];
+      int i1 = i, n_ex = 0, n_pk = 0;
+      while (i1 < c0 + n && g_sc.fi_k[i1] == kk) n_ex += g_sc.fi_type[i1] == FI_EXEC, n_pk += g_sc.fi_type[i1] == FI_PARK, i1++;
+      if (n_ex || n_pk) {  // the items of one commitment are all of one kind: into the stage's pool, or into its job's pool
+        const uint32_t into = n_ex ? d : key_job_pool(key_job(d));
+        SetImg<uint8_t> dset = pool_open(into);
+        for (int q = i; q < i1; q++) set_add(dset, (uint32_t)g_sc.fi_e[q], lds_keys());
+        pool_close(into, dset);
+      }
+      int ci;
+      for (ci = 0; ci < H.n_commits; ci++)
+        if (g_hot.c_src[ci] == src && g_hot.c_dst[ci] == d) break;
+      CHECK(ci < H.n_commits);
+      if (ci < H.n_commits) {
+        g_hot.c_n[ci] = (int16_t)(g_hot.c_n[ci] - (i1 - i));
+        if (g_hot.c_n[ci] == 0) {
+          int last = H.n_commits - 1;
+          g_hot.c_src[ci] = g_hot.c_src[last], g_hot.c_dst[ci] = g_hot.c_dst[last], g_hot.c_n[ci] = g_hot.c_n[last], g_hot.c_seq[ci] = g_hot.c_seq[last];
+          H.n_commits = last;
+        }
+      }
+      const int sl = lds_slot_of()[key_job(d)];
+      if (sl != SLOT_NONE && !n_pk) lds_slot_ref()[sl] = (uint8_t)(lds_slot_ref()[sl] + (i1 - i));
+      i = i1;
+    }
+    H.counter = counter0 + (uint32_t)popc64(m_event);
+    if (m_exec) g_sc.rng_pos = (int32_t)g_sc.fi_rng_pos, H.rng_has32 = g_sc.fi_rng_has32, H.rng_u32 = g_sc.fi_rng_u32;
+  }
+  wave_sync();
+  return n;
+}
+
+// ENV:730-743, second half (all lanes): lane-parallel chunks while the list allows, the rest one at a time
+SSS_DEV void fulfil_run() {
+  const int m = g_sc.fi_m, m_par = g_sc.fi_m_par;
+  int done = 0;
+#ifndef SSS_NO_BATCH
+  while (done < m_par) {
+    if (64 - g_sc.rng_pos < 48) rng_refill();
+    int n = m_par - done < 24 ? m_par - done : 24;
+    // the jobs the chunk's events will name get their cache slots first (as push_event would see to)
+    if (wave_lane() == 0)
+      for (int i = done; i < done + n; i++) cache_acquire(key_job(g_sc.fc_dst[g_sc.fi_k[i]]));
+    wave_sync();
+    int serial_end = 0;
+    int got = fulfil_chunk(done, n, serial_end);
+    if (got < n) {
+      STAT(54, 1);
+      if (got > 0) {  // the items before the first one that needs the general path
+        int dummy = 0;
+        int again = fulfil_chunk(done, got, dummy);
+        if (again < got) break;  // (cannot happen: the prefix passed every test a moment ago)
+        STAT(53, 1), STAT(55, got);
+        done += got;
+      }
+      if (wave_lane() == 0) fulfil_serial_range(done, serial_end);
+      wave_sync();
+      if (wave_ballot(g_hot.h.err != 0) != 0) break;
+      done = serial_end;
+      continue;
+    }
+    STAT(53, 1), STAT(55, n);
+    done += n;
+  }
+#endif
+  STAT(56, m - done);
+  (void)m_par;
+  if (wave_lane() == 0 && done < m) fulfil_serial(done);
+  wave_sync();
 }
 
 SSS_DEV void commit_remaining_executors() {  // ENV:487-503
@@ -1486,7 +1793,6 @@ SSS_DEV void fastctx_load(FastCtx& f) {
   f.eff = g_c.pk.eff, f.durations = g_c.pk.durations, f.SP = g_c.SP, f.E = g_c.E;
 }
 
-#define LENW_LEN 0x3FFFFFFF
 
 // -DSSS_EVPROF (tools/evprof.sh): shader-clock ticks of the segments of an event-loop round, kept in
 // the header's profiling slots instead of the per-phase totals (timing builds only)
@@ -1952,7 +2258,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
     uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
     uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
     g_sc.free_slots = all & ~used;
-    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
     g_sc.events_this_step = 0;
     g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
     g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
@@ -2256,7 +2562,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   wave_sync();
   if (lane == 0) {
     g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0;
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
     // lifetime counters and the duration deque survive resets (ENV:83)
     uint64_t n_steps = H.n_steps, n_events = H.n_events, model_bytes = H.model_bytes;
     int dur_head = H.dur_head, dur_n = H.dur_n, episodes = H.episodes, last_ep_steps = H.last_ep_steps;
@@ -2372,9 +2678,9 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   PROF3(28);
   int lane = wave_lane();
   uint64_t t0 = wave_clock();
-  publish_idle_mask();  // for fulfill_commitments_from_source, should the round end with this action (nothing below moves an executor before it)
+  publish_idle_mask();  // for fulfil_build_list, should the round end with this action (nothing below moves an executor before it)
   if (lane == 0) {
-    g_sc.f_round_continues = 1;
+    g_sc.f_round_continues = 1, g_sc.f_fulfil = 0;
     g_sc.events_this_step = 0;
     H.last_reward = 0.0;
     if (H.need_reset || H.terminated) {
@@ -2388,18 +2694,25 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
         if (!(trk_num_committable() > 0 && H.n_sched > 0)) {
           // commitment round is over (ENV:195-203)
           commit_remaining_executors();
-          fulfill_commitments_from_source();
-          H.curr_source = POOL_NONE;
-          g_sc.wall_old = H.wall_time;
-          g_sc.n_old_active = H.n_active;
-          g_sc.old_version = g_sc.active_version;
-          g_sc.f_round_continues = 0;  // selected_stages.clear() and the old-active snapshot follow, lanes over jobs
+          fulfil_build_list();
+          g_sc.f_fulfil = 1;
         }
       }
-      if (H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
     }
     g_sc.idle_valid = 0;
   }
+  wave_sync();
+  if (g_sc.f_fulfil) {
+    fulfil_run();
+    if (lane == 0) {
+      H.curr_source = POOL_NONE;
+      g_sc.wall_old = H.wall_time;
+      g_sc.n_old_active = H.n_active;
+      g_sc.old_version = g_sc.active_version;
+      g_sc.f_round_continues = 0;  // selected_stages.clear() and the old-active snapshot follow, lanes over jobs
+    }
+  }
+  if (lane == 0 && H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
   wave_sync();
   uint64_t t1 = wave_clock();
 #ifndef SSS_EVPROF

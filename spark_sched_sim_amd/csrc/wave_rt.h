@@ -141,6 +141,7 @@ SSS_DEV double wave_readlane_f64(double v, int l) {
 // read-modify-write used when several lanes commit to the same record in one step
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { atomicAdd(p, v); }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+SSS_DEV void lane_atomic_and_u64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 SSS_DEV void lane_atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 SSS_DEV void lane_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }  // global_atomic_add_f32
@@ -158,6 +159,7 @@ SSS_DEV uint32_t wave_scan_excl_u32(uint32_t v) {
   return x - v;
 }
 
+SSS_DEV int4 mk_i4(int x, int y, int z, int w) { return make_int4(x, y, z, w); }
 SSS_DEV uint2 mk_u2(uint32_t x, uint32_t y) { return make_uint2(x, y); }
 SSS_DEV uint4 mk_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return make_uint4(x, y, z, w); }
 SSS_DEV uint64_t wave_clock() { return (uint64_t)clock64(); }

@@ -109,6 +109,7 @@ SSS_DEV double wave_readlane_f64(double v, int l) { return wave_bcast_f64(v, l);
 // fibers run one at a time between collectives: plain read-modify-write is atomic enough
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { *p += v; }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
+SSS_DEV void lane_atomic_and_u64(uint64_t* p, uint64_t v) { *p &= v; }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 SSS_DEV void lane_atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
 SSS_DEV void lane_atomic_add_f32(float* p, float v) { *p += v; }
@@ -134,6 +135,7 @@ struct uint4 { uint32_t x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+SSS_DEV int4 mk_i4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 SSS_DEV uint2 mk_u2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 SSS_DEV uint4 mk_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 
