@@ -640,6 +640,25 @@ SSS_DEV bool set_remove(SetImg<T>& s, uint32_t key) {
   }
 }
 
+// marks key's slot of a byte table in HBM as a dummy (the table half of set_remove); any lane
+SSS_DEV bool table_mark_dummy(uint8_t* tab, uint32_t mask, uint32_t key) {
+  uint32_t i = key & mask, perturb = key;
+  for (;;) {
+    uint32_t probes = (i + 9 <= mask) ? 9 : 0;
+    ProbeGroup g = probe_group_load(tab, i, probes);
+    for (uint32_t p = 0; p <= probes; p++) {
+      uint32_t en = probe_group_at(g, p);
+      if (en == 0) return false;
+      if (en == key + 2) {
+        tab[i + p] = 1;
+        return true;
+      }
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+
 template <typename T>
 SSS_DEV uint32_t set_pop(SetImg<T>& s) {
   uint32_t i = s.finger & s.mask;
@@ -854,54 +873,50 @@ SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send) {  
   uint32_t old = hot.ex_loc[e];
   const bool has_old = old != POOL_NONE, has_new = !send;
   const bool same = has_old && has_new && old == new_pool;
-  // both records are fetched up front (one round trip); 8-slot images are worked on in registers
+  // both records are fetched up front (one round trip); 8-slot images are worked on in registers, larger
+  // ones in their table in the overflow area, with the header taken from the record already fetched
   SssPoolHdr* ho = g_c.pool_hdr + (has_old ? pool_index(old) : 0);
   SssPoolHdr* hn = g_c.pool_hdr + (has_new ? pool_index(new_pool) : 0);
   uint4 ro = mk_u4(7u, 0u, 0u, 0u), rn = ro;
   if (has_old) ro = *(const uint4*)ho;
   if (has_new && !same) rn = *(const uint4*)hn;
-  if ((ro.x & 0xFFFFu) == 7 && (rn.x & 0xFFFFu) == 7) {
-    if (has_old) {
+  if (has_old) {
+    if ((ro.x & 0xFFFFu) == 7) {
       uint64_t t = (uint64_t)ro.z | ((uint64_t)ro.w << 32);
       uint32_t used = ro.y & 0xFFFFu;
       bool was = set8_remove(t, used, (uint32_t)e);
       CHECK(was);
       ro.y = (ro.y & 0xFFFF0000u) | used, ro.z = (uint32_t)t, ro.w = (uint32_t)(t >> 32);
-      if (!same) *(uint4*)ho = ro;
-      hot.ex_loc[e] = POOL_NONE;
+    } else {
+      bool was = table_mark_dummy(g_c.pool_tab + (size_t)pool_index(old) * sss_pool_table_bytes(g_c.E), ro.x & 0xFFFFu, (uint32_t)e);
+      CHECK(was);
+      ro.y = (ro.y & 0xFFFF0000u) | (((ro.y & 0xFFFFu) - 1u) & 0xFFFFu);  // used--
     }
-    if (has_new) {
-      if (same) rn = ro;
-      hot.ex_loc[e] = new_pool;
+    if (!same) *(uint4*)ho = ro;
+    hot.ex_loc[e] = POOL_NONE;
+  }
+  if (has_new) {
+    if (same) rn = ro;
+    hot.ex_loc[e] = new_pool;
+    SetImg<uint8_t> s;
+    s.small = g_sc.pool8, s.big = g_c.pool_tab + (size_t)pool_index(new_pool) * sss_pool_table_bytes(g_c.E);
+    s.mask = rn.x & 0xFFFFu, s.fill = rn.x >> 16, s.used = rn.y & 0xFFFFu, s.finger = 0, s.aux = rn.y >> 16;
+    if (s.mask == 7) {
       uint64_t t = (uint64_t)rn.z | ((uint64_t)rn.w << 32);
-      uint32_t fill = rn.x >> 16, used = rn.y & 0xFFFFu;
-      if (set8_add(t, fill, used, (uint32_t)e)) {
+      if (set8_add(t, s.fill, s.used, (uint32_t)e)) {
         // set_table_resize(used * 4): through the scratch table, the result may have more than 8 slots
-        SetImg<uint8_t> s;
         *(uint2*)g_sc.pool8 = mk_u2((uint32_t)t, (uint32_t)(t >> 32));
-        s.tab = g_sc.pool8, s.cap = 8, s.small = g_sc.pool8, s.big = g_c.pool_tab + (size_t)pool_index(new_pool) * sss_pool_table_bytes(g_c.E);
-        s.mask = 7, s.fill = fill, s.used = used, s.finger = 0, s.aux = rn.y >> 16, s.wide = false;
+        s.tab = g_sc.pool8, s.cap = 8, s.wide = false;
         set_resize(s, s.used * 4, lds_keys());
         pool_close(new_pool, s);
       } else
-        *(uint4*)hn = mk_u4(7u | (fill << 16), (rn.y & 0xFFFF0000u) | used, (uint32_t)t, (uint32_t)(t >> 32));
-      return;
-    }
-  } else {
-    if (has_old) {
-      SetImg<uint8_t> s = pool_open(old);
-      bool was = set_remove(s, (uint32_t)e);
-      CHECK(was);
-      pool_close(old, s);
-      hot.ex_loc[e] = POOL_NONE;
-    }
-    if (has_new) {
-      hot.ex_loc[e] = new_pool;
-      SetImg<uint8_t> s = pool_open(new_pool);
+        *(uint4*)hn = mk_u4(7u | (s.fill << 16), (rn.y & 0xFFFF0000u) | s.used, (uint32_t)t, (uint32_t)(t >> 32));
+    } else {
+      s.tab = s.big, s.cap = 0xFFFFFFFFu, s.wide = true;
       set_add(s, (uint32_t)e, lds_keys());
       pool_close(new_pool, s);
-      return;
     }
+    return;
   }
   int nj = key_job(new_pool), ns = key_stage(new_pool);
   CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
@@ -1310,25 +1325,6 @@ SSS_DEV_NOINLINE void fulfil_serial_range(int from, int to) {
   for (int i = from; i < to && !H.err; i++) fulfill_commitment((int)g_sc.fi_e[i], g_sc.fc_dst[g_sc.fi_k[i]]);
 }
 SSS_DEV void fulfil_serial(int from) { fulfil_serial_range(from, g_sc.fi_m); }
-
-// marks key's slot of a byte table in HBM as a dummy (the table half of set_remove); any lane
-SSS_DEV bool table_mark_dummy(uint8_t* tab, uint32_t mask, uint32_t key) {
-  uint32_t i = key & mask, perturb = key;
-  for (;;) {
-    uint32_t probes = (i + 9 <= mask) ? 9 : 0;
-    ProbeGroup g = probe_group_load(tab, i, probes);
-    for (uint32_t p = 0; p <= probes; p++) {
-      uint32_t en = probe_group_at(g, p);
-      if (en == 0) return false;
-      if (en == key + 2) {
-        tab[i + p] = 1;
-        return true;
-      }
-    }
-    perturb >>= 5;
-    i = (i * 5 + 1 + perturb) & mask;
-  }
-}
 
 enum { FI_SEND = 1, FI_EXEC = 2, FI_PARK = 3 };
 
@@ -1932,11 +1928,20 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need EVP_ARG) {
   const int s = info_stage(info);
   bool cand = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
   SssStage st = {0, 0, 0, 0};
+  if (cand) st = f.cstages[slot * f.SP + s];
+  {
+    // no batch unless the head of the queue is such an event with tasks left in its stage (anything else
+    // bounds the window from below): found out before the executors' duration lists are looked at
+    const bool c1 = cand && st.remaining > 0;
+    const double kq = c1 ? __builtin_inf() : sl.t;
+    const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
+    const double t_stop = next_arr < t_other ? next_arr : t_other;
+    if (wave_ballot(c1 && sl.t < t_stop) == 0) return 0;
+  }
   SssExDesc xd;
   xd.gs = -1, xd.li = xd.ri = 0, xd.pad = 0, xd.off_l = xd.off_r = 0, xd.lenw_l = xd.lenw_r = 0, xd.dmin_l = xd.dmin_r = 0;
   int n_local = 0, li = 0, ri = 0, len_l = 0, len_r = 0;
   if (cand) {
-    st = f.cstages[slot * f.SP + s];
     const SssJob* jp = f.cjobs + slot;
     const uint64_t local = jp->local_mask;
     const int gs = jp->gs_base + s;
@@ -2502,7 +2507,9 @@ SSS_DEV void resume_simulation() {
         EVP_MARK(5);
       }
       EVP_COUNT(6);
-      if (batch_fast_events(f, rng_need EVP_PASS) > 0) continue;
+      // zero or more batches; when they end, the head of the queue is an event for the general path
+      // (or the generator's buffer ran low: then one event goes the one-at-a-time way, which is always right)
+      batch_fast_events(f, rng_need EVP_PASS);
       EVP_MARK(0);  // a round the batch path left early is charged to its first segment
       double t_win = 0.0;
       uint32_t info_win = 0;
