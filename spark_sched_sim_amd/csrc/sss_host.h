@@ -59,6 +59,7 @@ struct sss_handle {
   void* zig_dev;
   void* eff_dev;
   void* jump_dev;
+  void* common_dev;
   SssParams P;
   SssPackDev pk;
 };
@@ -165,6 +166,49 @@ static std::vector<uint64_t> sss_build_pcg_jump() {
   return t;
 }
 
+// The common executor pool right after reset is set(range(E)) (executor_tracker.py:41): the image CPython 3.10
+// builds by adding 0, 1, .., E-1 to an empty set (set_add_entry / set_table_resize for keys with hash(k) == k:
+// LINEAR_PROBES 9, PERTURB_SHIFT 5, resize at fill * 5 >= mask * 3 to the first power of two > 4 * used).
+// No removals are involved, so there are no dummies. Layout: the 16-byte pool record (mask | fill << 16,
+// used, 8 inline slots), then the table when it has more than 8 slots. Slot bytes: 0 = empty, key + 2.
+static std::vector<uint8_t> sss_build_common_pool(int E) {
+  std::vector<uint8_t> tab(8, 0);
+  uint32_t mask = 7, fill = 0;
+  auto insert_clean = [](std::vector<uint8_t>& t, uint32_t m, uint32_t key) {
+    uint32_t perturb = key, i = key & m;
+    for (;;) {
+      uint32_t probes = (i + 9 <= m) ? 9 : 0;
+      for (uint32_t p = 0; p <= probes; p++)
+        if (t[i + p] == 0) {
+          t[i + p] = (uint8_t)(key + 2);
+          return;
+        }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & m;
+    }
+  };
+  for (uint32_t key = 0; key < (uint32_t)E; key++) {
+    insert_clean(tab, mask, key);  // keys are distinct and nothing was removed: an add is a clean insert
+    fill++;
+    if (fill * 5 >= mask * 3) {
+      uint32_t newsize = 8;
+      while (newsize <= fill * 4) newsize <<= 1;
+      std::vector<uint8_t> nt(newsize, 0);
+      for (uint32_t i = 0; i <= mask; i++)
+        if (tab[i] >= 2) insert_clean(nt, newsize - 1, tab[i] - 2u);
+      tab.swap(nt), mask = newsize - 1;
+    }
+  }
+  std::vector<uint8_t> out(16 + (mask == 7 ? 0 : mask + 1), 0);
+  uint32_t w0 = mask | (fill << 16), w1 = fill;  // used == fill; no outgoing commitments
+  memcpy(&out[0], &w0, 4), memcpy(&out[4], &w1, 4);
+  if (mask == 7)
+    memcpy(&out[8], tab.data(), 8);
+  else
+    memcpy(&out[16], tab.data(), mask + 1);
+  return out;
+}
+
 extern "C" const char* sss_last_error(void) { return g_sss_err.c_str(); }
 
 extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, int device, sss_handle** out) {
@@ -247,8 +291,15 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
     sss_destroy(h);
     return sss_fail(-13, "copying the duration descriptors to the device failed");
   }
+  std::vector<uint8_t> common = sss_build_common_pool(cfg->num_executors);
+  h->common_dev = be_alloc(common.size());
+  if (!h->common_dev || be_h2d(h->common_dev, common.data(), common.size())) {
+    sss_destroy(h);
+    return sss_fail(-11, "device allocation failed");
+  }
   pk.eff = (const int32_t*)h->eff_dev;
   pk.pcg_jump = (const uint64_t*)h->jump_dev;
+  pk.common_pool = (const uint8_t*)h->common_dev;
   h->pk = pk;
   *out = h;
   return 0;
@@ -392,6 +443,6 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
   BeDeviceGuard guard(h->device);
-  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev), be_free(h->jump_dev);
+  be_free(h->pack_dev), be_free(h->zig_dev), be_free(h->eff_dev), be_free(h->jump_dev), be_free(h->common_dev);
   delete h;
 }

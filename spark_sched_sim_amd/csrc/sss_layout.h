@@ -171,6 +171,7 @@ struct SssPackDev {
   const uint64_t* zig_ke;
   const double *zig_we, *zig_fe;
   const int32_t* eff;  // [total_stages][8 executor levels][3 modes][4] = (offset, len | warmup << 30, min duration of the list, 0)
+  const uint8_t* common_pool;  // the common pool right after reset, set(range(E)): its 16-byte record, then (tables beyond 8 slots) the table
   const uint64_t* pcg_jump;  // [129][4]: PCG64 jump-ahead by k = -64..64 steps: state' = A * state + C * inc, rows (A_hi, A_lo, C_hi, C_lo)
 };
 

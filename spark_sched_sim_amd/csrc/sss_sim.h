@@ -69,6 +69,8 @@ struct alignas(16) SssScratch {
   uint8_t fi_e[SSS_MAX_EXEC], fi_k[SSS_MAX_EXEC], fi_type[SSS_MAX_EXEC];
   int32_t fi_m, fi_m_par, f_fulfil;
   uint64_t fi_detach;             // executors a chunk detaches from the source's job
+  double reset_t;                 // do_reset: arrival time of the next job while the job sequence is drawn in chunks
+  int32_t reset_more, reset_pad;
   uint32_t fi_rng_pos, fi_rng_has32, fi_rng_u32, fi_pad;
 };
 
@@ -2587,19 +2589,35 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     H.seed = seed, H.time_limit = time_limit;
     H.curr_source = POOL_COMMON;
     g_sc.events_this_step = 0;
+    g_sc.reset_more = 0;
     if (!(time_limit < __builtin_inf()) && g_c.P.cap_cfg <= 0) {
       H.err = SSS_ERR_NO_LIMIT;  // ENV:137-138
       H.need_reset = 1;
     } else {
       rng_seed(H, seed);
       g_sc.rng_pos = 64;  // nothing buffered: the header holds the generator's state itself
-      // job_sequence TPCH:54-73
-      double t = 0.0;
-      int J = 0;
-      while (t < time_limit && (g_c.P.cap_cfg <= 0 || J < g_c.P.cap_cfg)) {
+      H.J = 0;
+      g_sc.reset_t = 0.0, g_sc.reset_more = 1;
+    }
+  }
+  wave_sync();
+  // job_sequence TPCH:54-73: lane 0 draws job after job from raw outputs the wave produces 64 at a time
+  // (a job takes two of them unless the exponential leaves the ziggurat's fast path)
+  while (g_sc.reset_more) {
+    rng_refill();
+    if (lane == 0) {
+      double t = g_sc.reset_t;
+      int J = H.J;
+      bool more = true;
+      while (g_sc.rng_pos <= 56) {
+        if (!(t < time_limit && (g_c.P.cap_cfg <= 0 || J < g_c.P.cap_cfg))) {
+          more = false;
+          break;
+        }
         if (J >= g_c.J_cap) {
           H.err = SSS_ERR_CAPACITY;
           H.need_reset = 1;
+          more = false;
           break;
         }
         int q = (int)rng_integers(22);     // TPCH:177
@@ -2609,8 +2627,9 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
         J++;
         t += g_c.P.mean_interarrival * rng_standard_exponential();  // TPCH:70
       }
-      H.J = J;
+      H.J = J, g_sc.reset_t = t, g_sc.reset_more = more ? 1 : 0;
     }
+    wave_sync();
   }
   // executors + event slots + commitments
   if (lane < SSS_MAX_EXEC) {
@@ -2655,17 +2674,19 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     g_c.stages[i] = st;
     g_c.durations[i] = d;
   }
-  // pools: every job / stage pool starts as an empty 8-slot set (TRK:73-96)
+  // pools: every job / stage pool starts as an empty 8-slot set (TRK:73-96); the common pool as
+  // set(range(E)) (TRK:41), whose image the host has built once (sss_host.h: sss_build_common_pool)
   int n_pools = 1 + g_c.J_cap + J * g_c.SP;
   for (int p = lane; p < n_pools; p += 64) {
-    *(uint4*)(g_c.pool_hdr + p) = mk_u4(7u, 0u, 0u, 0u);  // mask 7, fill 0, used 0, no commitments, empty 8-slot table
+    *(uint4*)(g_c.pool_hdr + p) = p == 0 ? ((const uint4*)g_c.pk.common_pool)[0] : mk_u4(7u, 0u, 0u, 0u);  // mask 7, fill 0, used 0, no commitments, empty 8-slot table
+  }
+  {
+    const uint32_t cmask = ((const uint32_t*)g_c.pk.common_pool)[0] & 0xFFFFu;
+    if (cmask != 7)
+      for (uint32_t w = (uint32_t)lane; w < (cmask + 1) / 16; w += 64) ((uint4*)g_c.pool_tab)[w] = ((const uint4*)g_c.pk.common_pool)[1 + w];
   }
   wave_sync();
   if (lane == 0 && !H.err) {
-    // common pool = set(range(E)) (TRK:41)
-    SetImg<uint8_t> s = pool_open(POOL_COMMON);
-    for (int e = 0; e < g_c.E; e++) set_add(s, (uint32_t)e, lds_keys());
-    pool_close(POOL_COMMON, s);
     // _load_initial_jobs ENV:260-273
     while (H.next_arrival < H.J && g_c.t_arrival[H.next_arrival] <= 0.0) {
       handle_job_arrival(H.next_arrival);
