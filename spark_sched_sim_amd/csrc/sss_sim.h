@@ -68,6 +68,9 @@ struct alignas(16) SssScratch {
   // index of its commitment in the snapshot, and what became of it in a lane-parallel chunk
   uint8_t fi_e[SSS_MAX_EXEC], fi_k[SSS_MAX_EXEC], fi_type[SSS_MAX_EXEC];
   int32_t fi_m, fi_m_par, f_fulfil;
+  uint32_t rl_old[SSS_MAX_EXEC];  // batch_released_events: the members' old pools and commitment entries, by rank
+  uint8_t rl_idx[SSS_MAX_EXEC];
+  uint32_t rl_seq[SSS_MAX_EXEC];
   uint64_t fi_detach;             // executors a chunk detaches from the source's job
   double reset_t;                 // do_reset: arrival time of the next job while the job sequence is drawn in chunks
   int32_t reset_more, reset_pad;
@@ -1724,6 +1727,23 @@ SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-
     execute_next_task(e, j, s);
     return;
   }
+#ifdef SSS_BATCH_STATS
+  {
+    // census: what kind of "no task left in the stage" event is this?
+    uint32_t spk = key_stage_pool(j, s);
+    uint32_t d0 = trk_peek_commitment(spk);
+    bool completes = stage_completed(st);
+    int cat = 0;  // 0 no commitment, 1 to common, 2 other job (send), 3 same job not in frontier (park), 4 same job start task
+    if (d0 != POOL_NONE) {
+      if (d0 == POOL_COMMON) cat = 1;
+      else if (key_job(d0) != j) cat = 2;
+      else cat = ((*jobp(j)).frontier_mask & bit64(key_stage(d0))) ? 4 : 3;
+    }
+    sss_batch_stats[24 + cat] += 1;
+    if (completes) sss_batch_stats[29] += 1;
+    if (cat == 4 && !completes) sss_batch_stats[30] += 1;
+  }
+#endif
   bool frontier_changed = false;
   if (stage_completed(st)) frontier_changed = job_record_stage_completion(j, s);  // ENV:676-680
   if ((*jobp(j)).active_mask == 0) process_job_completion(j);                      // JOB:49-51
@@ -2089,6 +2109,252 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need EVP_ARG) {
     if (64 - pos < rng_need) return total;  // the caller refills the generator's buffer
     if (fast_kind) st = f.cstages[slot * f.SP + s];  // other events of the stage may have taken tasks
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Batches of RELEASED executors (all lanes). The other frequent event while nothing is committable:
+// TASK_FINISHED on a stage with no task left to start (ENV:468-483) whose pool holds a commitment to
+// another stage of the same job (the policy lined the executor's next stage up): the executor leaves
+// its stage's pool, the commitment is settled, and it either starts a task on the new stage
+// (in the frontier: ENV:584-615, a duration draw and a new TASK_FINISHED event) or is parked in the
+// job's pool (not yet in the frontier: ENV:808-813, no event). The source stays what it is
+// (ENV:662-674), nothing becomes committable, the loop goes on. Same construction as
+// batch_fast_events: a window below every event that needs the general handlers and below every event
+// a member can push; members ranked by (time, push counter); draws and push counters by rank; counters
+// of stages and pools by counts. Left to the one-event path: the event that completes its stage
+// (frontier changes), pools without or with exhausted commitments, commitments to other jobs or to the
+// common pool, destination stages short of tasks (backup scheduling), jobs without a cache slot.
+// Returns the number of events handled (0: none, nothing modified).
+// ------------------------------------------------------------------------------------------
+SSS_DEV int batch_released_events(const FastCtx& f) {
+#ifdef SSS_NO_BATCH
+  return 0;
+#endif
+  const int lane = wave_lane();
+  // ---- reads ----
+  const SssEvSlot sl = g_hot.ev[lane];
+  const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  const int pos = g_sc.rng_pos;
+  const int n_commits = g_hot.h.n_commits;
+  const double next_arr = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
+  const uint32_t info = sl.info;
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info), j = info_job(info);
+  const bool tfc = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
+  SssStage st_old = {0, 0, 0, 0};
+  if (tfc) st_old = f.cstages[slot * f.SP + s];
+  // an executor whose departure does not complete its stage (that one changes the frontier: general path).
+  // With a source pool set, an executor entering or leaving it could make executors committable (ENV:331-338):
+  // batches only while there is none, which is the normal state between scheduling rounds
+  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.h.curr_source == POOL_NONE;
+  {
+    const double kq = cand ? __builtin_inf() : sl.t;
+    const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
+    const double t_stop = next_arr < t_other ? next_arr : t_other;
+    if (wave_ballot(cand && sl.t < t_stop) == 0) return 0;
+  }
+  // the commitment its pool would serve first (TRK:178-183: the first-inserted one of that source)
+  const uint32_t sp = key_stage_pool(j, s);
+  int c_idx = -1, c_cnt = 0;
+  uint32_t dst = POOL_NONE, c_best = 0xFFFFFFFFu;
+  for (int i = 0; i < n_commits; i++) {
+    const uint32_t cs = g_hot.c_src[i], cq = g_hot.c_seq[i];
+    if (cand && cs == sp && cq < c_best) c_best = cq, c_idx = i, dst = g_hot.c_dst[i], c_cnt = g_hot.c_n[i];
+  }
+  const int s2 = key_stage(dst);
+  cand = cand && c_idx >= 0 && dst != POOL_COMMON && key_job(dst) == j && s2 >= 0 && s2 != s;
+  SssStage st_new = {0, 0, 0, 0};
+  bool exec = false, open = false;
+  int n_local = 0, li = 0, ri = 0;
+  int4 da = mk_i4(0, 0, 0, 0), db = da;
+  if (cand) {
+    const SssJob* jp = f.cjobs + slot;
+    st_new = f.cstages[slot * f.SP + s2];
+    exec = (jp->frontier_mask & bit64(s2)) != 0;
+    cand = st_new.remaining > 0 && g_hot.ex_job[lane] == j;
+    if (cand && exec) {  // TPCH:75-106: the executor's last task was on another stage of the job ("first wave" of the new one)
+      n_local = popc64(jp->local_mask);
+      executor_interval(n_local, li, ri);
+      open = li != ri;
+      const int gs2 = jp->gs_base + s2;
+      da = *(const int4*)(f.eff + (((size_t)gs2 * 8 + li) * 3 + 2) * 4);
+      db = open ? *(const int4*)(f.eff + (((size_t)gs2 * 8 + ri) * 3 + 2) * 4) : da;
+      cand = n_local > 0 && (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
+    }
+  }
+  const double dmin = (double)(da.z < db.z ? da.z : db.z);
+  const double key = cand ? (exec ? sl.t + dmin : __builtin_inf()) : sl.t;  // a parked executor pushes nothing
+  double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
+  if (next_arr < M) M = next_arr;
+  bool V = cand && sl.t < M;
+  uint64_t vm = wave_ballot(V);
+  if (vm == 0) return 0;
+  const uint32_t nmax = (uint32_t)(64 - pos) >> 1;
+  const uint32_t tag_old = (slot << 8) | (uint32_t)s, tag_new = (slot << 8) | (uint32_t)s2 | (exec ? 0x10000u : 0u) | (open ? 0x20000u : 0u);
+  // rank among all members / among the task starters, starters before with an open level interval,
+  // members before that leave the same stage, starters before on the same new stage, members with the same new stage
+  uint32_t rank, rank_x, R, cb_old, cb_take, ct_take, ct_old;
+  for (;;) {
+    rank = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take = 0, ct_old = 0;
+    for (uint64_t m = vm; m; m &= m - 1) {
+      const int k = ctz64(m);
+      const double tk = wave_readlane_f64(sl.t, k);
+      const uint32_t qk = wave_readlane_u32(sl.seq, k);
+      const uint32_t ok = wave_readlane_u32(tag_old, k), nk = wave_readlane_u32(tag_new, k);
+      const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq);
+      const bool xk = (nk & 0x10000u) != 0, same_new = ((nk ^ tag_new) & 0xFFFFu) == 0, same_old = ok == tag_old;
+      rank += lt ? 1u : 0u;
+      rank_x += (lt && xk) ? 1u : 0u;
+      R += (lt && (nk & 0x20000u)) ? 1u : 0u;
+      cb_old += (lt && same_old) ? 1u : 0u;
+      ct_old += same_old ? 1u : 0u;
+      cb_take += (lt && xk && same_new) ? 1u : 0u;
+      ct_take += (xk && same_new) ? 1u : 0u;
+    }
+    // completes its stage / the commitment is used up / the new stage runs dry / not enough buffered randomness
+    const bool over = V && ((int)cb_old + 2 > (int)st_old.executing || (int)cb_old >= c_cnt || (exec && (int)cb_take >= (int)st_new.remaining) || rank_x >= nmax);
+    if (wave_ballot(over) == 0) break;
+    const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
+    V = V && rank < rcut;
+    vm = wave_ballot(V);
+    if (vm == 0) return 0;
+  }
+  const uint32_t n = (uint32_t)popc64(vm);
+  const uint64_t xm = wave_ballot(V && exec);
+  const uint32_t n_x = (uint32_t)popc64(xm);
+  // ---- the task starters' draws ----
+  const uint32_t Fr = h0 ? rank_x >> 1 : (rank_x + 1) >> 1;
+  const bool fresh = ((h0 + rank_x) & 1u) == 0;
+  const uint32_t P = R + Fr;
+  const bool vx = V && exec;
+  int4 dd = da;
+  uint64_t x32 = 0;
+  uint32_t u32 = 0;
+  if (vx) {
+    if (open) {
+      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
+      if (!((double)rand_pt <= (double)n_local - left)) dd = db;
+    }
+    if (fresh) {
+      x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
+      u32 = (uint32_t)x32;
+    } else if (rank_x == 0) {
+      u32 = u32_0;
+    } else {
+      u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);
+    }
+  }
+  const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
+  const uint64_t mm = (uint64_t)u32 * len;
+  if (wave_ballot(vx && (uint32_t)mm < len) != 0) return 0;
+  // ---- commit ----
+  if (V) {
+    SssJob* jp = f.cjobs + slot;
+    uint32_t* w_old = (uint32_t*)(f.cstages + slot * f.SP + s);
+    uint32_t* w_new = (uint32_t*)(f.cstages + slot * f.SP + s2);
+    lane_atomic_add_u32(w_old, 0u - (1u << 16));  // executing-- (STG:60-62)
+    lane_atomic_add_u32(w_new + 1, 0u - 1u);      // commitments to the new stage: one fewer (TRK:159-176)
+    g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = exec ? FI_EXEC : FI_PARK;
+    g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best, g_sc.fc_dst[rank] = exec ? dst : key_job_pool(j);
+    if (exec) {
+      double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
+      if (dd.y >> 30) dur += g_c.P.warmup_delay;
+      lane_atomic_add_u32(w_new, (1u << 16) - 1u);  // remaining--, executing++ (STG:53-58)
+      g_hot.ev[lane].t = sl.t + dur;
+      g_hot.ev[lane].seq = counter0 + rank_x;
+      g_hot.ev[lane].info = ev_info(EV_TASK_FINISHED, j, s2, slot);
+      g_hot.ex_task_stage[lane] = (int8_t)s2, g_hot.ex_loc[lane] = dst;
+      if (cb_take + 1 == ct_take) {  // the new stage's last starter of the batch
+        f.cdur[slot * f.SP + s2] = (float)dur;
+        if ((int)st_new.remaining - (int)ct_take == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
+      }
+    } else {
+      g_hot.ev[lane].t = __builtin_inf();
+      g_hot.ev[lane].info = EV_NONE;
+      g_hot.ex_executing[lane] = 0, g_hot.ex_task_stage[lane] = -1, g_hot.ex_loc[lane] = key_job_pool(j);
+    }
+    if (rank == n - 1) {
+      SssHdr& h = g_hot.h;
+      h.wall_time = sl.t;
+      h.counter = counter0 + n_x;
+      h.n_events += n, h.n_batched += n, h.n_rounds++;
+      g_sc.events_this_step += (int32_t)n;
+    }
+    if (vx && rank_x == n_x - 1) {
+      g_sc.rng_pos = pos + (int)P + (open ? 1 : 0) + (fresh ? 1 : 0);
+      g_hot.h.rng_has32 = fresh ? 1u : 0u;
+      g_hot.h.rng_u32 = fresh ? (uint32_t)(x32 >> 32) : u32;
+    }
+  }
+  wave_sync();
+  if (lane == 0) {
+    // pools, commitments, slot references, saturation bits of stages that lost commitments without gaining an executor
+    uint64_t done = 0;
+    for (uint32_t r = 0; r < n; r++) {
+      // commitment of member r (in rank order, so that entries disappear in the order the one-event path removes them)
+      const uint32_t okey = g_sc.rl_old[r];
+      int ci = g_sc.rl_idx[r];
+      if (!(ci < H.n_commits && g_hot.c_src[ci] == okey && g_hot.c_seq[ci] == g_sc.rl_seq[r])) {  // entries have moved (swap-remove)
+        ci = -1;
+        for (int i = 0; i < H.n_commits; i++)
+          if (g_hot.c_src[i] == okey && g_hot.c_seq[i] == g_sc.rl_seq[r]) ci = i;
+      }
+      CHECK(ci >= 0);
+      if (ci >= 0) {
+        g_hot.c_n[ci] = (int16_t)(g_hot.c_n[ci] - 1);
+        if (g_hot.c_n[ci] == 0) {
+          int last = H.n_commits - 1;
+          g_hot.c_src[ci] = g_hot.c_src[last], g_hot.c_dst[ci] = g_hot.c_dst[last], g_hot.c_n[ci] = g_hot.c_n[last], g_hot.c_seq[ci] = g_hot.c_seq[last];
+          H.n_commits = last;
+        }
+      }
+      if (g_sc.fi_type[r] == FI_PARK) {  // its event is gone: one reference to the job's cache slot fewer
+        const int ks = lds_slot_of()[key_job(okey)];
+        if (ks != SLOT_NONE) lds_slot_ref()[ks]--;
+      }
+    }
+    for (uint32_t r = 0; r < n; r++) {
+      if (done & bit64(r)) continue;
+      // everybody who leaves this pool: one open / close (removals commute)
+      const uint32_t okey = g_sc.rl_old[r];
+      SetImg<uint8_t> so = pool_open(okey);
+      uint32_t cnt = 0;
+      for (uint32_t q = r; q < n; q++)
+        if (g_sc.rl_old[q] == okey) {
+          bool was = set_remove(so, (uint32_t)g_sc.fi_e[q]);
+          CHECK(was);
+          done |= bit64(q), cnt++;
+        }
+      so.aux -= cnt;  // the pool's outgoing commitments
+      pool_close(okey, so);
+    }
+    done = 0;
+    for (uint32_t r = 0; r < n; r++) {
+      if (done & bit64(r)) continue;
+      // everybody who enters this pool, in event order
+      const uint32_t nkey = g_sc.fc_dst[r];
+      SetImg<uint8_t> sn = pool_open(nkey);
+      for (uint32_t q = r; q < n; q++)
+        if (g_sc.fc_dst[q] == nkey) {
+          set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
+          done |= bit64(q);
+        }
+      pool_close(nkey, sn);
+    }
+  }
+  wave_sync();
+  // saturation bits (ENV:566-582): a parked executor's commitment is gone and it did not reach the stage
+  if (V && !exec) {
+    const SssStage t2 = f.cstages[slot * f.SP + s2];
+    SssJob* jp = f.cjobs + slot;
+    if ((int)t2.remaining - ((int)t2.moving_to + (int)t2.commit_to) <= 0)
+      lane_atomic_or_u64(&jp->sat_mask, bit64(s2));
+    else
+      lane_atomic_and_u64(&jp->sat_mask, ~bit64(s2));
+  }
+  wave_sync();
+  return (int)n;
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -2513,6 +2779,7 @@ SSS_DEV void resume_simulation() {
       // (or the generator's buffer ran low: then one event goes the one-at-a-time way, which is always right)
       batch_fast_events(f, rng_need EVP_PASS);
       EVP_MARK(0);  // a round the batch path left early is charged to its first segment
+      if (64 - g_sc.rng_pos >= rng_need && batch_released_events(f) > 0) continue;
       double t_win = 0.0;
       uint32_t info_win = 0;
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
