@@ -1673,7 +1673,6 @@ SSS_DEV int cache_acquire(int j) {  // HBM -> LDS if the job has no slot yet; re
 }
 
 SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created empty at reset)
-  PROF3(13);
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
   g_sc.active_version++;
@@ -2113,23 +2112,79 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need EVP_ARG) {
 
 // ------------------------------------------------------------------------------------------
 // Batches of RELEASED executors (all lanes). The other frequent event while nothing is committable:
-// TASK_FINISHED on a stage with no task left to start (ENV:468-483) whose pool holds a commitment to
-// another stage of the same job (the policy lined the executor's next stage up): the executor leaves
-// its stage's pool, the commitment is settled, and it either starts a task on the new stage
-// (in the frontier: ENV:584-615, a duration draw and a new TASK_FINISHED event) or is parked in the
-// job's pool (not yet in the frontier: ENV:808-813, no event). The source stays what it is
-// (ENV:662-674), nothing becomes committable, the loop goes on. Same construction as
-// batch_fast_events: a window below every event that needs the general handlers and below every event
-// a member can push; members ranked by (time, push counter); draws and push counters by rank; counters
-// of stages and pools by counts. Left to the one-event path: the event that completes its stage
-// (frontier changes), pools without or with exhausted commitments, commitments to other jobs or to the
-// common pool, destination stages short of tasks (backup scheduling), jobs without a cache slot.
+// TASK_FINISHED on a stage with no task left to start (ENV:468-483) whose pool holds a commitment
+// (the policy lined the executor's next stop up). The executor leaves its stage's pool, the commitment
+// is settled (TRK:159-176) and, by destination (ENV:699-712, 784-819, 745-782):
+//   START   another stage of its job, in the frontier: it moves into that stage's pool and starts a task
+//           (a duration draw, a new TASK_FINISHED event);
+//   PARK    another stage of its job, not yet in the frontier: it waits in the job's pool (no event);
+//   SEND    a stage of another job: it is detached from its job and travels (EXECUTOR_READY after moving_delay);
+//   IDLE    the common pool: it goes to the job's pool, or - the job being saturated - is detached into the
+//           common pool (no event).
+// The source stays what it is (ENV:662-674), nothing becomes committable, the loop goes on. Same
+// construction as batch_fast_events: a window below every event that needs the general handlers and
+// below every event a member can push; members ranked by (time, push counter); draws and push counters
+// by rank; counters of stages and pools by counts. Left to the one-event path: the event that completes
+// its stage (frontier changes), pools without or with exhausted commitments, destination stages short
+// of tasks (backup scheduling), jobs without a cache slot, and members whose outcome would depend on
+// an earlier member of the same job (a start after a detachment: the job's executor count enters the
+// draw; an idle executor after a start: the job's saturation decides where it goes).
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
+// One lane per pool (batch_released_events): every member of ranks [0, n) that leaves pool `okey` is taken out
+// of it - one fetch and one store of the pool's record; removals commute - and the pool's outgoing
+// commitments shrink by as many.
+SSS_DEV void pool_leave_many(uint32_t okey, uint32_t n) {
+  SssPoolHdr* hd = g_c.pool_hdr + pool_index(okey);
+  uint4 rec = *(const uint4*)hd;
+  const uint32_t mask = rec.x & 0xFFFFu;
+  uint32_t used = rec.y & 0xFFFFu, aux = rec.y >> 16;
+  uint64_t t = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+  for (uint32_t q = 0; q < n; q++) {
+    if (g_sc.rl_old[q] != okey) continue;
+    bool was;
+    if (mask == 7)
+      was = set8_remove(t, used, (uint32_t)g_sc.fi_e[q]);
+    else {
+      was = table_mark_dummy(g_c.pool_tab + (size_t)pool_index(okey) * sss_pool_table_bytes(g_c.E), mask, (uint32_t)g_sc.fi_e[q]);
+      used--;
+    }
+    CHECK(was);
+    aux--;
+  }
+  *(uint4*)hd = mk_u4(rec.x, (used & 0xFFFFu) | (aux << 16), mask == 7 ? (uint32_t)t : 0u, mask == 7 ? (uint32_t)(t >> 32) : 0u);
+}
+// ... and every member that enters pool `nkey` is added, in rank order. Returns false, with nothing done, when
+// the additions could make the table grow (that needs the scratch lists of the one-pool-at-a-time path).
+SSS_DEV bool pool_enter_many(uint32_t nkey, uint32_t n) {
+  SssPoolHdr* hd = g_c.pool_hdr + pool_index(nkey);
+  const uint4 rec = *(const uint4*)hd;
+  SetImg<uint8_t> sn;
+  sn.mask = rec.x & 0xFFFFu, sn.fill = rec.x >> 16, sn.used = rec.y & 0xFFFFu, sn.finger = 0, sn.aux = rec.y >> 16;
+  uint32_t cnt = 0;
+  for (uint32_t q = 0; q < n; q++) cnt += g_sc.fc_dst[q] == nkey ? 1u : 0u;
+  if ((sn.fill + cnt) * 5 >= sn.mask * 3) return false;
+  if (sn.mask == 7) {
+    uint64_t t = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+    for (uint32_t q = 0; q < n; q++)
+      if (g_sc.fc_dst[q] == nkey) set8_add(t, sn.fill, sn.used, (uint32_t)g_sc.fi_e[q]);
+    *(uint4*)hd = mk_u4(7u | (sn.fill << 16), (sn.used & 0xFFFFu) | (sn.aux << 16), (uint32_t)t, (uint32_t)(t >> 32));
+  } else {
+    sn.big = g_c.pool_tab + (size_t)pool_index(nkey) * sss_pool_table_bytes(g_c.E), sn.small = nullptr;
+    sn.tab = sn.big, sn.cap = 0xFFFFFFFFu, sn.wide = true;
+    for (uint32_t q = 0; q < n; q++)
+      if (g_sc.fc_dst[q] == nkey) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());  // no growth (checked above): the scratch list is not touched
+    *(uint4*)hd = mk_u4(sn.mask | (sn.fill << 16), (sn.used & 0xFFFFu) | (sn.aux << 16), 0u, 0u);
+  }
+  return true;
+}
+
+enum { RL_START = 0, RL_PARK = 1, RL_SEND = 2, RL_IDLE_JOB = 3, RL_IDLE_COMMON = 4 };
 SSS_DEV int batch_released_events(const FastCtx& f) {
 #ifdef SSS_NO_BATCH
   return 0;
 #endif
+  PROF3(0);
   const int lane = wave_lane();
   // ---- reads ----
   const SssEvSlot sl = g_hot.ev[lane];
@@ -2146,12 +2201,13 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   // an executor whose departure does not complete its stage (that one changes the frontier: general path).
   // With a source pool set, an executor entering or leaving it could make executors committable (ENV:331-338):
   // batches only while there is none, which is the normal state between scheduling rounds
-  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.h.curr_source == POOL_NONE;
+  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.h.curr_source == POOL_NONE && g_hot.ex_job[lane] == j;
   {
     const double kq = cand ? __builtin_inf() : sl.t;
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
-    if (wave_ballot(cand && sl.t < t_stop) == 0) return 0;
+    const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
+    if ((pre & (pre - 1)) == 0) return 0;  // none, or a single one: the one-event path is as fast
   }
   // the commitment its pool would serve first (TRK:178-183: the first-inserted one of that source)
   const uint32_t sp = key_stage_pool(j, s);
@@ -2161,58 +2217,76 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     const uint32_t cs = g_hot.c_src[i], cq = g_hot.c_seq[i];
     if (cand && cs == sp && cq < c_best) c_best = cq, c_idx = i, dst = g_hot.c_dst[i], c_cnt = g_hot.c_n[i];
   }
-  const int s2 = key_stage(dst);
-  cand = cand && c_idx >= 0 && dst != POOL_COMMON && key_job(dst) == j && s2 >= 0 && s2 != s;
+  cand = cand && c_idx >= 0 && dst != sp;
+  const int j2 = key_job(dst), s2 = key_stage(dst);
+  int type = RL_START;
   SssStage st_new = {0, 0, 0, 0};
-  bool exec = false, open = false;
+  SssStage* sp_new = nullptr;
+  bool open = false;
   int n_local = 0, li = 0, ri = 0;
   int4 da = mk_i4(0, 0, 0, 0), db = da;
   if (cand) {
     const SssJob* jp = f.cjobs + slot;
-    st_new = f.cstages[slot * f.SP + s2];
-    exec = (jp->frontier_mask & bit64(s2)) != 0;
-    cand = st_new.remaining > 0 && g_hot.ex_job[lane] == j;
-    if (cand && exec) {  // TPCH:75-106: the executor's last task was on another stage of the job ("first wave" of the new one)
-      n_local = popc64(jp->local_mask);
-      executor_interval(n_local, li, ri);
-      open = li != ri;
-      const int gs2 = jp->gs_base + s2;
-      da = *(const int4*)(f.eff + (((size_t)gs2 * 8 + li) * 3 + 2) * 4);
-      db = open ? *(const int4*)(f.eff + (((size_t)gs2 * 8 + ri) * 3 + 2) * 4) : da;
-      cand = n_local > 0 && (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
+    if (dst == POOL_COMMON) {
+      type = (int)jp->sat_count == (int)jp->n_stages ? RL_IDLE_COMMON : RL_IDLE_JOB;  // JOB:53-55
+    } else if (s2 < 0) {
+      cand = false;  // (commitments name stages or the common pool)
+    } else {
+      sp_new = j2 == j ? f.cstages + slot * f.SP + s2 : stgp(j2, s2);
+      st_new = *sp_new;
+      cand = st_new.remaining > 0;  // else: backup scheduling (ENV:784-797)
+      type = j2 != j ? RL_SEND : ((jp->frontier_mask & bit64(s2)) ? RL_START : RL_PARK);
+      if (cand && type == RL_START) {  // TPCH:75-106: the executor's last task was on another stage of the job
+        n_local = popc64(jp->local_mask);
+        executor_interval(n_local, li, ri);
+        open = li != ri;
+        const int gs2 = jp->gs_base + s2;
+        da = *(const int4*)(f.eff + (((size_t)gs2 * 8 + li) * 3 + 2) * 4);
+        db = open ? *(const int4*)(f.eff + (((size_t)gs2 * 8 + ri) * 3 + 2) * 4) : da;
+        cand = n_local > 0 && (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
+      }
     }
   }
-  const double dmin = (double)(da.z < db.z ? da.z : db.z);
-  const double key = cand ? (exec ? sl.t + dmin : __builtin_inf()) : sl.t;  // a parked executor pushes nothing
+  const bool start = type == RL_START, pusher = type == RL_START || type == RL_SEND, detach = type == RL_SEND || type == RL_IDLE_COMMON;
+  const bool idle = type == RL_IDLE_JOB || type == RL_IDLE_COMMON;
+  // when the event a member pushes can come at the earliest
+  const double push_lb = start ? (double)(da.z < db.z ? da.z : db.z) : (type == RL_SEND ? g_c.P.moving_delay : __builtin_inf());
+  const double key = cand ? sl.t + push_lb : sl.t;
   double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
   uint64_t vm = wave_ballot(V);
   if (vm == 0) return 0;
   const uint32_t nmax = (uint32_t)(64 - pos) >> 1;
-  const uint32_t tag_old = (slot << 8) | (uint32_t)s, tag_new = (slot << 8) | (uint32_t)s2 | (exec ? 0x10000u : 0u) | (open ? 0x20000u : 0u);
-  // rank among all members / among the task starters, starters before with an open level interval,
-  // members before that leave the same stage, starters before on the same new stage, members with the same new stage
-  uint32_t rank, rank_x, R, cb_old, cb_take, ct_take, ct_old;
+  const uint32_t tag_old = (slot << 8) | (uint32_t)s;
+  const uint32_t tag_new = (idle ? 0x1FFFFu : (((uint32_t)j2 << 6) | (uint32_t)s2)) | (start ? 0x20000u : 0u) | (open ? 0x40000u : 0u) |
+                           (detach ? 0x80000u : 0u) | (pusher ? 0x100000u : 0u);
+  // rank among all members / among the pushers / among the starters; starters before with an open level
+  // interval; members before that leave the same stage; starters before on the same new stage; members of
+  // the same job before that detach from it / start a task
+  uint32_t rank, rank_p, rank_x, R, cb_old, cb_take, ct_take, det_job, start_job;
   for (;;) {
-    rank = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take = 0, ct_old = 0;
+    rank = 0, rank_p = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take = 0, det_job = 0, start_job = 0;
     for (uint64_t m = vm; m; m &= m - 1) {
       const int k = ctz64(m);
       const double tk = wave_readlane_f64(sl.t, k);
       const uint32_t qk = wave_readlane_u32(sl.seq, k);
       const uint32_t ok = wave_readlane_u32(tag_old, k), nk = wave_readlane_u32(tag_new, k);
       const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq);
-      const bool xk = (nk & 0x10000u) != 0, same_new = ((nk ^ tag_new) & 0xFFFFu) == 0, same_old = ok == tag_old;
+      const bool xk = (nk & 0x20000u) != 0, same_new = ((nk ^ tag_new) & 0x1FFFFu) == 0, same_old = ok == tag_old, same_job = ((ok ^ tag_old) >> 8) == 0;
       rank += lt ? 1u : 0u;
+      rank_p += (lt && (nk & 0x100000u)) ? 1u : 0u;
       rank_x += (lt && xk) ? 1u : 0u;
-      R += (lt && (nk & 0x20000u)) ? 1u : 0u;
+      R += (lt && (nk & 0x40000u)) ? 1u : 0u;
       cb_old += (lt && same_old) ? 1u : 0u;
-      ct_old += same_old ? 1u : 0u;
       cb_take += (lt && xk && same_new) ? 1u : 0u;
       ct_take += (xk && same_new) ? 1u : 0u;
+      det_job += (lt && same_job && (nk & 0x80000u)) ? 1u : 0u;
+      start_job += (lt && same_job && xk) ? 1u : 0u;
     }
-    // completes its stage / the commitment is used up / the new stage runs dry / not enough buffered randomness
-    const bool over = V && ((int)cb_old + 2 > (int)st_old.executing || (int)cb_old >= c_cnt || (exec && (int)cb_take >= (int)st_new.remaining) || rank_x >= nmax);
+    // completes its stage / the commitment is used up / the new stage runs dry / depends on an earlier member of its job / randomness
+    const bool over = V && ((int)cb_old + 2 > (int)st_old.executing || (int)cb_old >= c_cnt || (!idle && (int)cb_take >= (int)st_new.remaining) ||
+                            (start && det_job > 0) || (idle && start_job > 0) || rank_x >= nmax);
     if (wave_ballot(over) == 0) break;
     const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
     V = V && rank < rcut;
@@ -2220,13 +2294,13 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     if (vm == 0) return 0;
   }
   const uint32_t n = (uint32_t)popc64(vm);
-  const uint64_t xm = wave_ballot(V && exec);
-  const uint32_t n_x = (uint32_t)popc64(xm);
-  // ---- the task starters' draws ----
+  const uint32_t n_x = (uint32_t)popc64(wave_ballot(V && start)), n_p = (uint32_t)popc64(wave_ballot(V && pusher));
+  const uint32_t n_idle = (uint32_t)popc64(wave_ballot(V && idle));
+  // ---- the starters' draws ----
   const uint32_t Fr = h0 ? rank_x >> 1 : (rank_x + 1) >> 1;
   const bool fresh = ((h0 + rank_x) & 1u) == 0;
   const uint32_t P = R + Fr;
-  const bool vx = V && exec;
+  const bool vx = V && start;
   int4 dd = da;
   uint64_t x32 = 0;
   uint32_t u32 = 0;
@@ -2251,34 +2325,49 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   // ---- commit ----
   if (V) {
     SssJob* jp = f.cjobs + slot;
-    uint32_t* w_old = (uint32_t*)(f.cstages + slot * f.SP + s);
-    uint32_t* w_new = (uint32_t*)(f.cstages + slot * f.SP + s2);
-    lane_atomic_add_u32(w_old, 0u - (1u << 16));  // executing-- (STG:60-62)
-    lane_atomic_add_u32(w_new + 1, 0u - 1u);      // commitments to the new stage: one fewer (TRK:159-176)
-    g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = exec ? FI_EXEC : FI_PARK;
-    g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best, g_sc.fc_dst[rank] = exec ? dst : key_job_pool(j);
-    if (exec) {
+    lane_atomic_add_u32((uint32_t*)(f.cstages + slot * f.SP + s), 0u - (1u << 16));  // executing-- (STG:60-62)
+    g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = (uint8_t)type;
+    g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best;
+    g_sc.fc_dst[rank] = start ? dst : (type == RL_SEND ? POOL_NONE : (type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j)));  // the pool it enters
+    if (start) {
       double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
       if (dd.y >> 30) dur += g_c.P.warmup_delay;
-      lane_atomic_add_u32(w_new, (1u << 16) - 1u);  // remaining--, executing++ (STG:53-58)
+      lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - 1u);          // commitments to the new stage: one fewer (TRK:159-176)
+      lane_atomic_add_u32((uint32_t*)sp_new, (1u << 16) - 1u);      // remaining--, executing++ (STG:53-58)
       g_hot.ev[lane].t = sl.t + dur;
-      g_hot.ev[lane].seq = counter0 + rank_x;
+      g_hot.ev[lane].seq = counter0 + rank_p;
       g_hot.ev[lane].info = ev_info(EV_TASK_FINISHED, j, s2, slot);
       g_hot.ex_task_stage[lane] = (int8_t)s2, g_hot.ex_loc[lane] = dst;
       if (cb_take + 1 == ct_take) {  // the new stage's last starter of the batch
         f.cdur[slot * f.SP + s2] = (float)dur;
         if ((int)st_new.remaining - (int)ct_take == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
       }
+    } else if (type == RL_SEND) {
+      lane_atomic_add_u32((uint32_t*)sp_new + 1, 0xFFFFu);           // commit_to--, moving_to++ (the borrow of the low half is the carry into the high one)
+      g_hot.ev[lane].t = sl.t + g_c.P.moving_delay;
+      g_hot.ev[lane].seq = counter0 + rank_p;
+      g_hot.ev[lane].info = ev_info(EV_EXECUTOR_READY, j2, s2, (uint32_t)lds_slot_of()[j2]);
+      g_hot.ex_executing[lane] = 0, g_hot.ex_loc[lane] = POOL_NONE;
+      lane_atomic_add_u32((uint32_t*)&jp->supply, 0u - 1u);          // the old job's executor count (TRK:218-221)
     } else {
+      if (type == RL_PARK) {
+        lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - 1u);
+        g_hot.ex_task_stage[lane] = -1;  // ENV:808-813
+      }
       g_hot.ev[lane].t = __builtin_inf();
       g_hot.ev[lane].info = EV_NONE;
-      g_hot.ex_executing[lane] = 0, g_hot.ex_task_stage[lane] = -1, g_hot.ex_loc[lane] = key_job_pool(j);
+      g_hot.ex_executing[lane] = 0, g_hot.ex_loc[lane] = type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j);
+    }
+    if (detach) {  // JOB:86-89
+      lane_atomic_and_u64(&jp->local_mask, ~bit64(lane));
+      g_hot.ex_job[lane] = -1, g_hot.ex_task_stage[lane] = -1;
     }
     if (rank == n - 1) {
       SssHdr& h = g_hot.h;
       h.wall_time = sl.t;
-      h.counter = counter0 + n_x;
+      h.counter = counter0 + n_p;
       h.n_events += n, h.n_batched += n, h.n_rounds++;
+      h.supply_none -= (int32_t)n_idle;  // TRK:159-176: a commitment to the common pool counted as its supply
       g_sc.events_this_step += (int32_t)n;
     }
     if (vx && rank_x == n_x - 1) {
@@ -2288,11 +2377,10 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     }
   }
   wave_sync();
+  PROF3(13);
   if (lane == 0) {
-    // pools, commitments, slot references, saturation bits of stages that lost commitments without gaining an executor
-    uint64_t done = 0;
+    // commitments (in rank order, so that entries disappear in the order the one-event path removes them) and slot references
     for (uint32_t r = 0; r < n; r++) {
-      // commitment of member r (in rank order, so that entries disappear in the order the one-event path removes them)
       const uint32_t okey = g_sc.rl_old[r];
       int ci = g_sc.rl_idx[r];
       if (!(ci < H.n_commits && g_hot.c_src[ci] == okey && g_hot.c_seq[ci] == g_sc.rl_seq[r])) {  // entries have moved (swap-remove)
@@ -2309,43 +2397,48 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
           H.n_commits = last;
         }
       }
-      if (g_sc.fi_type[r] == FI_PARK) {  // its event is gone: one reference to the job's cache slot fewer
+      if (g_sc.fi_type[r] != RL_START) {  // its event is gone, or names another job: one reference to the old job's cache slot fewer
         const int ks = lds_slot_of()[key_job(okey)];
         if (ks != SLOT_NONE) lds_slot_ref()[ks]--;
+        if (g_sc.fi_type[r] == RL_SEND) {
+          const uint32_t ns = info_slot(g_hot.ev[g_sc.fi_e[r]].info);
+          if (ns != INFO_SLOT_NONE) lds_slot_ref()[ns]++;
+        }
       }
     }
-    for (uint32_t r = 0; r < n; r++) {
-      if (done & bit64(r)) continue;
-      // everybody who leaves this pool: one open / close (removals commute)
-      const uint32_t okey = g_sc.rl_old[r];
-      SetImg<uint8_t> so = pool_open(okey);
-      uint32_t cnt = 0;
-      for (uint32_t q = r; q < n; q++)
-        if (g_sc.rl_old[q] == okey) {
-          bool was = set_remove(so, (uint32_t)g_sc.fi_e[q]);
-          CHECK(was);
-          done |= bit64(q), cnt++;
-        }
-      so.aux -= cnt;  // the pool's outgoing commitments
-      pool_close(okey, so);
-    }
-    done = 0;
-    for (uint32_t r = 0; r < n; r++) {
-      if (done & bit64(r)) continue;
-      // everybody who enters this pool, in event order
-      const uint32_t nkey = g_sc.fc_dst[r];
-      SetImg<uint8_t> sn = pool_open(nkey);
-      for (uint32_t q = r; q < n; q++)
-        if (g_sc.fc_dst[q] == nkey) {
-          set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
-          done |= bit64(q);
-        }
-      pool_close(nkey, sn);
+  }
+  // pools: one lane per pool, all pools at once. A member speaks for the pool it leaves / enters if no
+  // member before it (in rank) shares that pool.
+  bool deferred = false;
+  if (V) {
+    if (cb_old == 0) pool_leave_many(sp, n);
+    const uint32_t nkey = g_sc.fc_dst[rank];
+    bool lead = nkey != POOL_NONE;
+    for (uint32_t q = 0; q < rank; q++) lead = lead && g_sc.fc_dst[q] != nkey;
+    if (lead) deferred = !pool_enter_many(nkey, n);
+  }
+  uint64_t dm = wave_ballot(deferred);
+  STAT(31, 1), STAT(32, popc64(dm)), STAT(33, n);
+  if (dm) {  // tables that have to grow: one pool at a time with the general code
+    wave_sync();
+    if (lane == 0) {
+      while (dm) {
+        const int l = ctz64(dm);
+        dm &= dm - 1;
+        // lane l's member: find its rank (the executor is the lane) and its pool
+        uint32_t nkey = POOL_NONE;
+        for (uint32_t q = 0; q < n; q++)
+          if (g_sc.fi_e[q] == (uint8_t)l) nkey = g_sc.fc_dst[q];
+        SetImg<uint8_t> sn = pool_open(nkey);
+        for (uint32_t q = 0; q < n; q++)
+          if (g_sc.fc_dst[q] == nkey) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
+        pool_close(nkey, sn);
+      }
     }
   }
   wave_sync();
   // saturation bits (ENV:566-582): a parked executor's commitment is gone and it did not reach the stage
-  if (V && !exec) {
+  if (V && type == RL_PARK) {
     const SssStage t2 = f.cstages[slot * f.SP + s2];
     SssJob* jp = f.cjobs + slot;
     if ((int)t2.remaining - ((int)t2.moving_to + (int)t2.commit_to) <= 0)

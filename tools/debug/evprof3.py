@@ -5,9 +5,9 @@ sys.path[:0] = [ROOT]
 import torch
 from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
 from spark_sched_sim_amd.binding import load_library
-NAMES = {1: "trk_add_commitment", 2: "trk_remove_commitment", 3: "trk_move_executor_to_pool", 4: "job_record_stage_completion", 5: "task_duration",
+NAMES = {0: "batch_released_events", 1: "trk_add_commitment", 2: "trk_remove_commitment", 3: "trk_move_executor_to_pool", 4: "job_record_stage_completion", 5: "task_duration",
          6: "find_backup_stage", 7: "execute_next_task", 8: "send_executor", 9: "get_idle_source_executors", 10: "move_idle_executors_all",
-         11: "move_executor_to_stage", 12: "fulfill_commitments_from_source", 13: "handle_job_arrival", 14: "handle_executor_arrival",
+         11: "move_executor_to_stage", 12: "fulfill_commitments_from_source", 13: "batch_released_events: commit + lane-0 tail", 14: "handle_executor_arrival",
          15: "process_job_completion", 16: "handle_task_completion", 17: "take_action", 18: "jobtime_build_set", 19: "cache_acquire", 20: "cache_release",
          21: "find_schedulable_all", 22: "write_observation", 23: "env_begin", 24: "env_end", 25: "jobtime_sum", 26: "resume_simulation", 27: "do_reset",
          28: "do_step", 29: "run_policy", 30: "batch_fast_events", 31: "handle_popped"}
