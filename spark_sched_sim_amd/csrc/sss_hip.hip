@@ -151,4 +151,7 @@ extern "C" int sss_debug_prof(unsigned long long* out64) {
   static const unsigned long long zeros[64] = {0};
   return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
 }
+extern "C" int sss_debug_prof_min(unsigned long long min_step_ticks) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3_min), &min_step_ticks, sizeof(min_step_ticks)) == hipSuccess ? 0 : -1;
+}
 #endif

@@ -120,6 +120,17 @@ static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost
         }
       }
     }
+  // fourth word of the idle-executor entries: the bound over ALL executor levels of the stage - for an executor
+  // whose job's executor count is not known yet when the bound is needed (batch_arrival_events)
+  for (int gs = 0; gs < ph.total_stages; gs++) {
+    int32_t lb = 0x7FFFFFFF;
+    for (int i = 0; i < 8; i++) {
+      const int32_t* e = &eff[(((size_t)gs * 8 + i) * 3 + 0) * 4];
+      if ((e[1] & 0x3FFFFFFF) > 0 && e[2] < lb) lb = e[2];
+    }
+    if (lb == 0x7FFFFFFF) lb = 0;
+    for (int i = 0; i < 8; i++) eff[(((size_t)gs * 8 + i) * 3 + 0) * 4 + 3] = lb;
+  }
   return eff;
 }
 

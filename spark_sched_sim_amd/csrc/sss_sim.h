@@ -165,6 +165,7 @@ extern "C" { extern long long sss_batch_stats[64]; }
 // procedures, in a device-global table read back through sss_debug_prof (timing builds only)
 #ifdef SSS_EVPROF3
 __device__ unsigned long long g_prof3[64];
+__device__ unsigned long long g_prof3_min;  // only launches whose do_step took at least this long are recorded (tail census)
 SSS_SHARED unsigned long long g_prof3_lds[64];  // per-wave totals, added to the table once per launch (prof3_flush)
 struct Prof3Scope {
   int id;
@@ -178,6 +179,7 @@ struct Prof3Scope {
 SSS_DEV void prof3_clear() { g_prof3_lds[wave_lane()] = 0; }
 SSS_DEV void prof3_flush() {
   wave_sync();
+  if (g_prof3_lds[2 * 28] < g_prof3_min) return;
   if (g_prof3_lds[wave_lane()]) atomicAdd(&g_prof3[wave_lane()], g_prof3_lds[wave_lane()]);
 }
 #else
@@ -1633,7 +1635,6 @@ SSS_DEV void commit_remaining_executors() {  // ENV:487-503
 // fall back to the HBM copy. Slots are written back when their job completes, when they are handed
 // to another job, and at the end of the launch.
 SSS_DEV void cache_release(int j) {  // LDS -> HBM, slot becomes free
-  PROF3(20);
   int k = lds_slot_of()[j];
   if (k == SLOT_NONE) return;
   g_c.jobs[j] = lds_cjobs()[k];
@@ -1933,7 +1934,7 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 // one-event-at-a-time path, which is always correct.
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
-SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need EVP_ARG) {
+SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EVP_ARG) {
   PROF3(30);
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
@@ -1950,7 +1951,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need EVP_ARG) {
   bool cand = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
   SssStage st = {0, 0, 0, 0};
   if (cand) st = f.cstages[slot * f.SP + s];
-  {
+  if (!head_known) {
     // no batch unless the head of the queue is such an event with tasks left in its stage (anything else
     // bounds the window from below): found out before the executors' duration lists are looked at
     const bool c1 = cand && st.remaining > 0;
@@ -2199,9 +2200,10 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   SssStage st_old = {0, 0, 0, 0};
   if (tfc) st_old = f.cstages[slot * f.SP + s];
   // an executor whose departure does not complete its stage (that one changes the frontier: general path).
-  // With a source pool set, an executor entering or leaving it could make executors committable (ENV:331-338):
-  // batches only while there is none, which is the normal state between scheduling rounds
-  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.h.curr_source == POOL_NONE && g_hot.ex_job[lane] == j;
+  // With a source pool set, an executor entering it would become committable (ENV:331-338, TRK:107-113): such a
+  // member goes the general way (below). Leaving the source takes one of its commitments along: no change.
+  const uint32_t source = g_hot.h.curr_source;
+  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.ex_job[lane] == j;
   {
     const double kq = cand ? __builtin_inf() : sl.t;
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
@@ -2249,6 +2251,9 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   }
   const bool start = type == RL_START, pusher = type == RL_START || type == RL_SEND, detach = type == RL_SEND || type == RL_IDLE_COMMON;
   const bool idle = type == RL_IDLE_JOB || type == RL_IDLE_COMMON;
+  // the pool the member enters
+  const uint32_t enters = start ? dst : (type == RL_SEND ? POOL_NONE : (type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j)));
+  cand = cand && (source == POOL_NONE || enters != source);
   // when the event a member pushes can come at the earliest
   const double push_lb = start ? (double)(da.z < db.z ? da.z : db.z) : (type == RL_SEND ? g_c.P.moving_delay : __builtin_inf());
   const double key = cand ? sl.t + push_lb : sl.t;
@@ -2328,7 +2333,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     lane_atomic_add_u32((uint32_t*)(f.cstages + slot * f.SP + s), 0u - (1u << 16));  // executing-- (STG:60-62)
     g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = (uint8_t)type;
     g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best;
-    g_sc.fc_dst[rank] = start ? dst : (type == RL_SEND ? POOL_NONE : (type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j)));  // the pool it enters
+    g_sc.fc_dst[rank] = enters;
     if (start) {
       double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
       if (dd.y >> 30) dur += g_c.P.warmup_delay;
@@ -2445,6 +2450,265 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
       lane_atomic_or_u64(&jp->sat_mask, bit64(s2));
     else
       lane_atomic_and_u64(&jp->sat_mask, ~bit64(s2));
+  }
+  wave_sync();
+  return (int)n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Batches of ARRIVING executors (all lanes). Executors sent to a job in one fulfilment arrive together
+// (same moving_delay, ENV:617-637), and while no source is set their EXECUTOR_READY events (ENV:440-450)
+// do not interact beyond the counters of their job and stage: the executor is attached to the job
+// (JOB:81-84), passes through the job's pool (TRK:188-222) and
+//   START   its stage is in the frontier and has a task left: it enters the stage's pool and starts one
+//           (an idle executor's draw, TPCH:75-106 - the job's executor count includes every member that
+//           arrived before it; a new TASK_FINISHED event);
+//   PARK    its stage is not in the frontier yet: it waits in the job's pool (ENV:808-813, no event).
+// A stage that has run out of tasks (backup scheduling, ENV:784-797) ends the batch. Same construction as
+// the other batches: window below everything that is not a member and below what members can push, members
+// ranked by (time, push counter), draws and counters by rank, one lane per pool for the set images.
+// Returns the number of events handled (0: none, nothing modified).
+// ------------------------------------------------------------------------------------------
+enum { AR_START = 0, AR_PARK = 1 };
+// One lane per job: every member of that job enters the job's pool and leaves it again (START) or is taken out
+// and put back by the move to the pool it is already in (PARK, TRK:188-222 with old == new), in rank order.
+// Returns false, with nothing done, unless the image has 8 slots and stays that way.
+SSS_DEV bool pool_pass_many(uint32_t jkey, uint32_t n) {
+  SssPoolHdr* hd = g_c.pool_hdr + pool_index(jkey);
+  const uint4 rec = *(const uint4*)hd;
+  if ((rec.x & 0xFFFFu) != 7) return false;
+  uint32_t fill = rec.x >> 16, used = rec.y & 0xFFFFu;
+  uint64_t t = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+  for (uint32_t q = 0; q < n; q++) {
+    if (g_sc.rl_old[q] != jkey) continue;
+    const uint32_t e = g_sc.fi_e[q];
+    if (set8_add(t, fill, used, e)) {
+      // set_table_resize(used * 4): 8 slots again while the executor is alone in the pool - rebuilt
+      // without the dummies, i.e. the one key in its home slot
+      if (used >= 2) return false;
+      t = (uint64_t)(e + 2) << (8 * (e & 7)), fill = used = 1;
+    }
+    bool was = set8_remove(t, used, e);
+    CHECK(was);
+    if (g_sc.fi_type[q] == AR_PARK) set8_add(t, fill, used, e);  // lands on a dummy: no growth
+  }
+  *(uint4*)hd = mk_u4(7u | (fill << 16), (used & 0xFFFFu) | (rec.y & 0xFFFF0000u), (uint32_t)t, (uint32_t)(t >> 32));
+  return true;
+}
+
+SSS_DEV int batch_arrival_events(const FastCtx& f) {
+#ifdef SSS_NO_BATCH
+  return 0;
+#endif
+  PROF3(20);
+  const int lane = wave_lane();
+  // ---- reads ----
+  const SssEvSlot sl = g_hot.ev[lane];
+  const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  const int pos = g_sc.rng_pos;
+  const double next_arr = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
+  const uint32_t info = sl.info;
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info), j = info_job(info);
+  const uint32_t source = g_hot.h.curr_source;
+  bool cand = lane < f.E && info_kind(info) == EV_EXECUTOR_READY && slot != INFO_SLOT_NONE;
+  {
+    const double kq = cand ? __builtin_inf() : sl.t;
+    const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
+    const double t_stop = next_arr < t_other ? next_arr : t_other;
+    const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
+    if ((pre & (pre - 1)) == 0) return 0;  // none, or a single one: the one-event path is as fast
+  }
+  SssStage st = {0, 0, 0, 0};
+  const SssJob* jpc = f.cjobs + (cand ? slot : 0);
+  int gs = 0, n_base = 0, type = AR_START;
+  double push_lb = __builtin_inf();
+  if (cand) {
+    st = f.cstages[slot * f.SP + s];
+    gs = jpc->gs_base + s;
+    n_base = popc64(jpc->local_mask);
+    type = (jpc->frontier_mask & bit64(s)) ? AR_START : AR_PARK;
+    // with a source pool set, an executor that stays in it would become committable (ENV:331-338): general path
+    cand = st.remaining > 0 && st.moving_to > 0 && (source == POOL_NONE || source != (type == AR_START ? key_stage_pool(j, s) : key_job_pool(j)));
+    if (type == AR_START) push_lb = (double)f.eff[(((size_t)gs * 8 + 0) * 3 + 0) * 4 + 3];
+  }
+  const bool start = type == AR_START;
+  const double key = cand ? sl.t + push_lb : sl.t;
+  double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
+  if (next_arr < M) M = next_arr;
+  bool V = cand && sl.t < M;
+  uint64_t vm = wave_ballot(V);
+  if ((vm & (vm - 1)) == 0) return 0;
+  // who comes before this member, who shares its job / its stage
+  uint64_t before = 0, same_job = 0, same_stage = 0;
+  for (uint64_t m = vm; m; m &= m - 1) {
+    const int k = ctz64(m);
+    const double tk = wave_readlane_f64(sl.t, k);
+    const uint32_t qk = wave_readlane_u32(sl.seq, k);
+    const uint32_t ik = wave_readlane_u32(info, k);
+    const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq);
+    before |= lt ? bit64(k) : 0ull;
+    same_job |= info_job(ik) == j ? bit64(k) : 0ull;
+    same_stage |= ((ik ^ info) >> 8) == 0 ? bit64(k) : 0ull;
+  }
+  // the executor count of the job when this member draws (JOB:81-84: every member before it has been attached)
+  const int n_local = n_base + popc64(before & same_job) + 1;
+  int li = 0, ri = 0;
+  executor_interval(n_local, li, ri);
+  const bool open = li != ri;
+  int4 da = mk_i4(0, 0, 0, 0), db = da;
+  bool drawable = true;
+  if (V && start) {
+    da = *(const int4*)(f.eff + (((size_t)gs * 8 + li) * 3 + 0) * 4);
+    db = open ? *(const int4*)(f.eff + (((size_t)gs * 8 + ri) * 3 + 0) * 4) : da;
+    drawable = n_local <= f.E && (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
+  }
+  const uint32_t nmax = (uint32_t)(64 - pos) >> 1;
+  const uint64_t startm0 = wave_ballot(V && start);
+  {
+    // the stage runs dry before this member (backup scheduling) / a list that draws nothing or fails / randomness
+    const uint32_t takes_before = (uint32_t)popc64(before & same_stage & startm0);
+    const bool over = V && ((start && ((int)takes_before >= (int)st.remaining || !drawable || (uint32_t)popc64(before & startm0) >= nmax)) ||
+                            popc64(before & same_stage) >= (int)st.moving_to);
+    const uint64_t om = wave_ballot(over);
+    if (om) {
+      // everything from the first such member on stays for the one-event path
+      const uint32_t rcut = wave_min_u32(over ? (uint32_t)popc64(before & vm) : 0xFFFFFFFFu);
+      V = V && (uint32_t)popc64(before & vm) < rcut;
+      vm = wave_ballot(V);
+      if ((vm & (vm - 1)) == 0) return 0;
+    }
+  }
+  before &= vm;
+  const uint64_t startm = wave_ballot(V && start), openm = wave_ballot(V && start && open);
+  const uint32_t n = (uint32_t)popc64(vm), n_x = (uint32_t)popc64(startm);
+  const uint32_t rank = (uint32_t)popc64(before), rank_x = (uint32_t)popc64(before & startm), R = (uint32_t)popc64(before & openm);
+  const uint32_t cb_take = (uint32_t)popc64(before & same_stage & startm), ct_take = (uint32_t)popc64(vm & same_stage & startm);
+  const uint32_t cb_stage = (uint32_t)popc64(before & same_stage), ct_stage = (uint32_t)popc64(vm & same_stage);
+  // ---- the starters' draws ----
+  const uint32_t Fr = h0 ? rank_x >> 1 : (rank_x + 1) >> 1;
+  const bool fresh = ((h0 + rank_x) & 1u) == 0;
+  const uint32_t P = R + Fr;
+  const bool vx = V && start;
+  int4 dd = da;
+  uint64_t x32 = 0;
+  uint32_t u32 = 0;
+  if (vx) {
+    if (open) {
+      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
+      if (!((double)rand_pt <= (double)n_local - left)) dd = db;
+    }
+    if (fresh) {
+      x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
+      u32 = (uint32_t)x32;
+    } else if (rank_x == 0) {
+      u32 = u32_0;
+    } else {
+      u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);
+    }
+  }
+  const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
+  const uint64_t mm = (uint64_t)u32 * len;
+  if (wave_ballot(vx && (uint32_t)mm < len) != 0) return 0;
+  // ---- commit ----
+  const uint32_t jkey = key_job_pool(j), skey = key_stage_pool(j, s);
+  if (V) {
+    SssJob* jp = f.cjobs + slot;
+    SssStage* stp = f.cstages + slot * f.SP + s;
+    lane_atomic_or_u64(&jp->local_mask, bit64(lane));  // JOB:81-84
+    g_hot.ex_job[lane] = (int16_t)j;
+    lane_atomic_add_u32((uint32_t*)stp + 1, 0u - (1u << 16));  // moving_to-- (TRK:185-187)
+    g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = (uint8_t)type;
+    g_sc.rl_old[rank] = jkey;
+    g_sc.fc_dst[rank] = start ? skey : POOL_NONE;  // the pool it enters after the job's
+    if (start) {
+      double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
+      if (dd.y >> 30) dur += g_c.P.warmup_delay;
+      lane_atomic_add_u32((uint32_t*)stp, (1u << 16) - 1u);  // remaining--, executing++ (STG:53-58)
+      g_hot.ev[lane].t = sl.t + dur;
+      g_hot.ev[lane].seq = counter0 + rank_x;
+      g_hot.ev[lane].info = ev_info(EV_TASK_FINISHED, j, s, slot);
+      g_hot.ex_task_stage[lane] = (int8_t)s, g_hot.ex_executing[lane] = 1, g_hot.ex_loc[lane] = skey;
+      if (cb_take + 1 == ct_take) {  // the stage's last starter of the batch
+        f.cdur[slot * f.SP + s] = (float)dur;
+        if ((int)st.remaining - (int)ct_take == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
+      }
+    } else {
+      g_hot.ev[lane].t = __builtin_inf();
+      g_hot.ev[lane].info = EV_NONE;
+      g_hot.ex_task_stage[lane] = -1, g_hot.ex_loc[lane] = jkey;
+    }
+    if (rank == n - 1) {
+      SssHdr& h = g_hot.h;
+      h.wall_time = sl.t;
+      h.counter = counter0 + n_x;
+      h.n_events += n, h.n_batched += n, h.n_rounds++;
+      g_sc.events_this_step += (int32_t)n;
+    }
+    if (vx && rank_x == n_x - 1) {
+      g_sc.rng_pos = pos + (int)P + (open ? 1 : 0) + (fresh ? 1 : 0);
+      g_hot.h.rng_has32 = fresh ? 1u : 0u;
+      g_hot.h.rng_u32 = fresh ? (uint32_t)(x32 >> 32) : u32;
+    }
+  }
+  wave_sync();
+  // pools: one lane per pool. The first member of a job speaks for the job's pool, the first starter of a
+  // stage for the stage's
+  bool def_job = false, def_stage = false;
+  if (V) {
+    if ((before & same_job) == 0) def_job = !pool_pass_many(jkey, n);
+    if (start && cb_take == 0) def_stage = !pool_enter_many(skey, n);
+  }
+  if (n != n_x && lane == 0) {
+    // a parked executor's event is gone: one reference to the job's cache slot fewer (a starter's new event names it again)
+    for (uint32_t q = 0; q < n; q++)
+      if (g_sc.fi_type[q] == AR_PARK) lds_slot_ref()[lds_slot_of()[key_job(g_sc.rl_old[q])]]--;
+  }
+  uint64_t dj = wave_ballot(def_job), ds = wave_ballot(def_stage);
+  STAT(34, 1), STAT(35, n), STAT(36, popc64(dj)), STAT(37, popc64(ds)), STAT(38, n - n_x);
+  if (dj | ds) {  // tables with more than 8 slots, or about to grow: one pool at a time with the general code
+    wave_sync();
+    if (lane == 0) {
+      while (dj) {
+        const int l = ctz64(dj);
+        dj &= dj - 1;
+        uint32_t key = POOL_NONE;
+        for (uint32_t q = 0; q < n; q++)
+          if (g_sc.fi_e[q] == (uint8_t)l) key = g_sc.rl_old[q];
+        SetImg<uint8_t> sj = pool_open(key);
+        for (uint32_t q = 0; q < n; q++) {
+          if (g_sc.rl_old[q] != key) continue;
+          set_add(sj, (uint32_t)g_sc.fi_e[q], lds_keys());
+          bool was = set_remove(sj, (uint32_t)g_sc.fi_e[q]);
+          CHECK(was);
+          if (g_sc.fi_type[q] == AR_PARK) set_add(sj, (uint32_t)g_sc.fi_e[q], lds_keys());
+        }
+        pool_close(key, sj);
+      }
+      while (ds) {
+        const int l = ctz64(ds);
+        ds &= ds - 1;
+        uint32_t key = POOL_NONE;
+        for (uint32_t q = 0; q < n; q++)
+          if (g_sc.fi_e[q] == (uint8_t)l) key = g_sc.fc_dst[q];
+        SetImg<uint8_t> sn = pool_open(key);
+        for (uint32_t q = 0; q < n; q++)
+          if (g_sc.fc_dst[q] == key) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
+        pool_close(key, sn);
+      }
+    }
+  }
+  wave_sync();
+  // saturation bit of the stage (ENV:566-582), by its last member: arrivals that start a task leave the
+  // demand what it was, parked ones raise it
+  if (V && cb_stage + 1 == ct_stage) {
+    const SssStage t2 = f.cstages[slot * f.SP + s];
+    SssJob* jp = f.cjobs + slot;
+    if ((int)t2.remaining - ((int)t2.moving_to + (int)t2.commit_to) <= 0)
+      lane_atomic_or_u64(&jp->sat_mask, bit64(s));
+    else
+      lane_atomic_and_u64(&jp->sat_mask, ~bit64(s));
   }
   wave_sync();
   return (int)n;
@@ -2821,10 +3085,15 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
       hot.ev[ex].info = EV_NONE;
       if (info_slot(sl.info) != INFO_SLOT_NONE) lds_slot_ref()[info_slot(sl.info)]--;
       g_sc.pinned_job = info_job(sl.info);
-      if (info_kind(sl.info) == EV_TASK_FINISHED)
+      if (info_kind(sl.info) == EV_TASK_FINISHED) {
+        STAT(43, 1), STAT(44, H.curr_source != POOL_NONE), STAT(45, info_slot(sl.info) == INFO_SLOT_NONE);
         handle_task_completion(ex, info_job(sl.info), info_stage(sl.info));
-      else
+      }
+      else {
+        STAT(39, 1), STAT(40, H.curr_source != POOL_NONE), STAT(41, info_slot(sl.info) == INFO_SLOT_NONE);
+        STAT(42, (*stgp(info_job(sl.info), info_stage(sl.info))).remaining == 0);
         handle_executor_arrival(ex, info_job(sl.info), info_stage(sl.info));
+      }
       g_sc.pinned_job = -1;
     }
     if (g_sc.pending_free >= 0) {
@@ -2868,16 +3137,28 @@ SSS_DEV void resume_simulation() {
         EVP_MARK(5);
       }
       EVP_COUNT(6);
-      // zero or more batches; when they end, the head of the queue is an event for the general path
-      // (or the generator's buffer ran low: then one event goes the one-at-a-time way, which is always right)
-      batch_fast_events(f, rng_need EVP_PASS);
-      EVP_MARK(0);  // a round the batch path left early is charged to its first segment
-      if (64 - g_sc.rng_pos >= rng_need && batch_released_events(f) > 0) continue;
+      // the head of the queue decides what kind of round this is
       double t_win = 0.0;
       uint32_t info_win = 0;
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
       EVP_MARK(3);
+      if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {
+        int handled = 0;
+        if (info_kind(info_win) == EV_TASK_FINISHED) {
+          // tasks left in its stage: zero or more batches of such events; when they end, the head of the queue
+          // is something else (or the generator's buffer ran low). None left: a batch of released executors
+          if (f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0)
+            handled = batch_fast_events(f, rng_need, true EVP_PASS);
+          else if (64 - g_sc.rng_pos >= rng_need)
+            handled = batch_released_events(f);
+        } else if (64 - g_sc.rng_pos >= rng_need) {
+          handled = batch_arrival_events(f);
+        }
+        EVP_MARK(0);  // a round the batch path left early is charged to its first segment
+        if (handled > 0) continue;
+        // nothing was touched: the popped event goes the one-at-a-time way, which is always right
+      }
       if (lane == 0) status = handle_popped(f, ex, t_win, info_win, t_slow);
       status = (int)wave_lane0_u32((uint32_t)status);
       EVP_MARK(4);

@@ -8,7 +8,7 @@ from spark_sched_sim_amd.binding import load_library
 NAMES = {0: "batch_released_events", 1: "trk_add_commitment", 2: "trk_remove_commitment", 3: "trk_move_executor_to_pool", 4: "job_record_stage_completion", 5: "task_duration",
          6: "find_backup_stage", 7: "execute_next_task", 8: "send_executor", 9: "get_idle_source_executors", 10: "move_idle_executors_all",
          11: "move_executor_to_stage", 12: "fulfill_commitments_from_source", 13: "batch_released_events: commit + lane-0 tail", 14: "handle_executor_arrival",
-         15: "process_job_completion", 16: "handle_task_completion", 17: "take_action", 18: "jobtime_build_set", 19: "cache_acquire", 20: "cache_release",
+         15: "process_job_completion", 16: "handle_task_completion", 17: "take_action", 18: "jobtime_build_set", 19: "cache_acquire", 20: "batch_arrival_events",
          21: "find_schedulable_all", 22: "write_observation", 23: "env_begin", 24: "env_end", 25: "jobtime_sum", 26: "resume_simulation", 27: "do_reset",
          28: "do_step", 29: "run_policy", 30: "batch_fast_events", 31: "handle_popped"}
 CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
@@ -16,6 +16,9 @@ CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5
 lib = load_library()
 buf = (C.c_ulonglong * 64)()
 mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
+# third argument: only record step launches of envs whose do_step took at least that many ticks (the tail of step mode)
+min_ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+lib.sss_debug_prof_min.argtypes = [C.c_ulonglong]
 for name in sys.argv[1].split(","):
     cfg, pol = CFG[name]
     env = VecSparkSchedSimEnv(cfg, 4096, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
@@ -23,6 +26,7 @@ for name in sys.argv[1].split(","):
     env.rollout(pol, 600)
     torch.cuda.synchronize()
     lib.sss_debug_prof(buf)
+    lib.sss_debug_prof_min(min_ticks)
     c0 = env.counters()
     if mode == "fused":
         for _ in range(6):
@@ -33,7 +37,10 @@ for name in sys.argv[1].split(","):
     torch.cuda.synchronize()
     lib.sss_debug_prof(buf)
     c1 = env.counters()
+    lib.sss_debug_prof_min(0)
     steps = c1["n_steps"] - c0["n_steps"]; evs = c1["n_events"] - c0["n_events"]
+    if min_ticks:
+        steps = buf[2 * 28 + 1]  # per recorded (slow) step
     print(f"== {name} {mode}: {steps} steps, {evs/steps:.1f} events/step; per STEP: ticks (calls, ticks/call)")
     rows = [(buf[2 * i] / steps, buf[2 * i + 1] / steps, NAMES[i]) for i in NAMES if buf[2 * i + 1]]
     for t, n, nm in sorted(rows, reverse=True):

@@ -12,4 +12,8 @@ for f in sys.argv[1:]:
     print(f)
     line(d["config"]["mode"], d)
     if "other_mode" in d: line(d["other_mode"]["mode"], d["other_mode"])
+    if "c3" in d:
+        line("c3 " + d["c3"].get("mode", "step"), d["c3"])
+        if "other_mode" in d["c3"]: line("c3 " + d["c3"]["other_mode"]["mode"], d["c3"]["other_mode"])
+        if "step_tail" in d["c3"]: print("   c3 tail", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d["c3"]["step_tail"].items() if k != "what"})
     if "cpu_baseline" in d: print("   cpu 1 core %.2fM, all cores %.2fM (%s)" % (d["cpu_baseline"]["value"]/1e6, d.get("cpu_baseline_all_cores", {}).get("value", 0)/1e6, d.get("cpu_baseline_all_cores", {}).get("cores")))
