@@ -2132,6 +2132,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
 // draw; an idle executor after a start: the job's saturation decides where it goes).
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
+#define RL_NO_COMMITMENT 0xFFu  // rl_idx of a member whose pool holds no commitment
 // One lane per pool (batch_released_events): every member of ranks [0, n) that leaves pool `okey` is taken out
 // of it - one fetch and one store of the pool's record; removals commute - and the pool's outgoing
 // commitments shrink by as many.
@@ -2151,7 +2152,7 @@ SSS_DEV void pool_leave_many(uint32_t okey, uint32_t n) {
       used--;
     }
     CHECK(was);
-    aux--;
+    if (g_sc.rl_idx[q] != RL_NO_COMMITMENT) aux--;
   }
   *(uint4*)hd = mk_u4(rec.x, (used & 0xFFFFu) | (aux << 16), mask == 7 ? (uint32_t)t : 0u, mask == 7 ? (uint32_t)(t >> 32) : 0u);
 }
@@ -2180,7 +2181,22 @@ SSS_DEV bool pool_enter_many(uint32_t nkey, uint32_t n) {
   return true;
 }
 
-enum { RL_START = 0, RL_PARK = 1, RL_SEND = 2, RL_IDLE_JOB = 3, RL_IDLE_COMMON = 4 };
+enum { RL_START = 0, RL_PARK = 1, RL_SEND = 2, RL_IDLE_JOB = 3, RL_IDLE_COMMON = 4, RL_FREE_JOB = 5, RL_FREE_COMMON = 6 };
+// all lanes: is there a schedulable stage whatever the source (ENV:505-555 without the source job's exemption) -
+// an active job below the executor cap (ENV:526-531) with a ready, unsaturated, unselected stage?
+SSS_DEV bool any_schedulable_without_source() {
+  const int lane = wave_lane();
+  const int A = g_hot.h.n_active;
+  bool any = false;
+  for (int a0 = 0; a0 < A; a0 += 64) {
+    const int a = a0 + lane;
+    if (a < A) {
+      const SssJob* job = jobp(lds_active()[a]);
+      if ((int)job->supply < g_c.E && ready_mask_of_job(*job, true) != 0) any = true;
+    }
+  }
+  return wave_ballot(any) != 0;
+}
 SSS_DEV int batch_released_events(const FastCtx& f) {
 #ifdef SSS_NO_BATCH
   return 0;
@@ -2219,7 +2235,12 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     const uint32_t cs = g_hot.c_src[i], cq = g_hot.c_seq[i];
     if (cand && cs == sp && cq < c_best) c_best = cq, c_idx = i, dst = g_hot.c_dst[i], c_cnt = g_hot.c_n[i];
   }
-  cand = cand && c_idx >= 0 && dst != sp;
+  // no commitment: the executor has nowhere to go (ENV:655-659). It becomes the source (ENV:662-674), and if nothing
+  // is schedulable then - which the members' own jobs (below) and one scan of the others (further below) establish,
+  // and which stays so while only such executors and idled ones are processed - it is moved to its job's pool or,
+  // the job being saturated, to the common pool, and the source is cleared (ENV:331-341, 745-782)
+  const bool freed = cand && c_idx < 0;
+  cand = cand && (freed || dst != sp);
   const int j2 = key_job(dst), s2 = key_stage(dst);
   int type = RL_START;
   SssStage st_new = {0, 0, 0, 0};
@@ -2229,7 +2250,10 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   int4 da = mk_i4(0, 0, 0, 0), db = da;
   if (cand) {
     const SssJob* jp = f.cjobs + slot;
-    if (dst == POOL_COMMON) {
+    if (freed) {
+      type = (int)jp->sat_count == (int)jp->n_stages ? RL_FREE_COMMON : RL_FREE_JOB;
+      cand = ready_mask_of_job(*jp, true) == 0;  // its own job passes the filter as the source's job (ENV:526-531)
+    } else if (dst == POOL_COMMON) {
       type = (int)jp->sat_count == (int)jp->n_stages ? RL_IDLE_COMMON : RL_IDLE_JOB;  // JOB:53-55
     } else if (s2 < 0) {
       cand = false;  // (commitments name stages or the common pool)
@@ -2249,11 +2273,19 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
       }
     }
   }
-  const bool start = type == RL_START, pusher = type == RL_START || type == RL_SEND, detach = type == RL_SEND || type == RL_IDLE_COMMON;
-  const bool idle = type == RL_IDLE_JOB || type == RL_IDLE_COMMON;
+  if (wave_ballot(cand && freed) != 0) {
+    // executors idling in a stage's pool would move along with a freed one (ENV:714-728): there are none between events
+    const bool idle_in_stage = lane < f.E && !g_hot.ex_executing[lane] && g_hot.ex_loc[lane] != POOL_NONE && g_hot.ex_loc[lane] != POOL_COMMON &&
+                               key_stage(g_hot.ex_loc[lane]) >= 0;
+    if (wave_ballot(idle_in_stage) != 0 || any_schedulable_without_source()) cand = cand && !freed;
+  }
+  const bool start = type == RL_START, pusher = type == RL_START || type == RL_SEND;
+  const bool detach = type == RL_SEND || type == RL_IDLE_COMMON || type == RL_FREE_COMMON;
+  const bool idle = type == RL_IDLE_JOB || type == RL_IDLE_COMMON;        // settles a commitment to the common pool
+  const bool rests = idle || type == RL_FREE_JOB || type == RL_FREE_COMMON;  // ends up waiting in the job's / the common pool
   // the pool the member enters
-  const uint32_t enters = start ? dst : (type == RL_SEND ? POOL_NONE : (type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j)));
-  cand = cand && (source == POOL_NONE || enters != source);
+  const uint32_t enters = start ? dst : (type == RL_SEND ? POOL_NONE : ((type == RL_IDLE_COMMON || type == RL_FREE_COMMON) ? POOL_COMMON : key_job_pool(j)));
+  cand = cand && (freed || source == POOL_NONE || enters != source);
   // when the event a member pushes can come at the earliest
   const double push_lb = start ? (double)(da.z < db.z ? da.z : db.z) : (type == RL_SEND ? g_c.P.moving_delay : __builtin_inf());
   const double key = cand ? sl.t + push_lb : sl.t;
@@ -2264,14 +2296,14 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   if (vm == 0) return 0;
   const uint32_t nmax = (uint32_t)(64 - pos) >> 1;
   const uint32_t tag_old = (slot << 8) | (uint32_t)s;
-  const uint32_t tag_new = (idle ? 0x1FFFFu : (((uint32_t)j2 << 6) | (uint32_t)s2)) | (start ? 0x20000u : 0u) | (open ? 0x40000u : 0u) |
-                           (detach ? 0x80000u : 0u) | (pusher ? 0x100000u : 0u);
+  const uint32_t tag_new = (rests ? 0x1FFFFu : (((uint32_t)j2 << 6) | (uint32_t)s2)) | (start ? 0x20000u : 0u) | (open ? 0x40000u : 0u) |
+                           (detach ? 0x80000u : 0u) | (pusher ? 0x100000u : 0u) | (type == RL_PARK ? 0x200000u : 0u);
   // rank among all members / among the pushers / among the starters; starters before with an open level
   // interval; members before that leave the same stage; starters before on the same new stage; members of
   // the same job before that detach from it / start a task
-  uint32_t rank, rank_p, rank_x, R, cb_old, cb_take, ct_take, det_job, start_job;
+  uint32_t rank, rank_p, rank_x, R, cb_old, cb_take, ct_take, det_job, start_job, stir;
   for (;;) {
-    rank = 0, rank_p = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take = 0, det_job = 0, start_job = 0;
+    rank = 0, rank_p = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take = 0, det_job = 0, start_job = 0, stir = 0;
     for (uint64_t m = vm; m; m &= m - 1) {
       const int k = ctz64(m);
       const double tk = wave_readlane_f64(sl.t, k);
@@ -2288,10 +2320,11 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
       ct_take += (xk && same_new) ? 1u : 0u;
       det_job += (lt && same_job && (nk & 0x80000u)) ? 1u : 0u;
       start_job += (lt && same_job && xk) ? 1u : 0u;
+      stir += (lt && (nk & 0x300000u)) ? 1u : 0u;  // members before that change a stage's demand or a job's executor count
     }
     // completes its stage / the commitment is used up / the new stage runs dry / depends on an earlier member of its job / randomness
-    const bool over = V && ((int)cb_old + 2 > (int)st_old.executing || (int)cb_old >= c_cnt || (!idle && (int)cb_take >= (int)st_new.remaining) ||
-                            (start && det_job > 0) || (idle && start_job > 0) || rank_x >= nmax);
+    const bool over = V && ((int)cb_old + 2 > (int)st_old.executing || (!freed && (int)cb_old >= c_cnt) || (!rests && (int)cb_take >= (int)st_new.remaining) ||
+                            (start && det_job > 0) || (rests && start_job > 0) || (freed && stir > 0) || rank_x >= nmax);
     if (wave_ballot(over) == 0) break;
     const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
     V = V && rank < rcut;
@@ -2301,6 +2334,9 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   const uint32_t n = (uint32_t)popc64(vm);
   const uint32_t n_x = (uint32_t)popc64(wave_ballot(V && start)), n_p = (uint32_t)popc64(wave_ballot(V && pusher));
   const uint32_t n_idle = (uint32_t)popc64(wave_ballot(V && idle));
+  const uint64_t freed_m = wave_ballot(V && freed);
+  const bool any_freed = freed_m != 0;
+  STAT(46, popc64(freed_m));
   // ---- the starters' draws ----
   const uint32_t Fr = h0 ? rank_x >> 1 : (rank_x + 1) >> 1;
   const bool fresh = ((h0 + rank_x) & 1u) == 0;
@@ -2332,7 +2368,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     SssJob* jp = f.cjobs + slot;
     lane_atomic_add_u32((uint32_t*)(f.cstages + slot * f.SP + s), 0u - (1u << 16));  // executing-- (STG:60-62)
     g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = (uint8_t)type;
-    g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best;
+    g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = freed ? (uint8_t)RL_NO_COMMITMENT : (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best;
     g_sc.fc_dst[rank] = enters;
     if (start) {
       double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
@@ -2361,7 +2397,8 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
       }
       g_hot.ev[lane].t = __builtin_inf();
       g_hot.ev[lane].info = EV_NONE;
-      g_hot.ex_executing[lane] = 0, g_hot.ex_loc[lane] = type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j);
+      if (freed) g_hot.ex_task_stage[lane] = -1;  // executor.task = None (ENV:655-656)
+      g_hot.ex_executing[lane] = 0, g_hot.ex_loc[lane] = enters;
     }
     if (detach) {  // JOB:86-89
       lane_atomic_and_u64(&jp->local_mask, ~bit64(lane));
@@ -2374,6 +2411,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
       h.n_events += n, h.n_batched += n, h.n_rounds++;
       h.supply_none -= (int32_t)n_idle;  // TRK:159-176: a commitment to the common pool counted as its supply
       g_sc.events_this_step += (int32_t)n;
+      if (any_freed) h.curr_source = POOL_NONE, g_sc.idle_valid = 0;  // ENV:341, after whichever freed executor came last
     }
     if (vx && rank_x == n_x - 1) {
       g_sc.rng_pos = pos + (int)P + (open ? 1 : 0) + (fresh ? 1 : 0);
@@ -2388,6 +2426,11 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     for (uint32_t r = 0; r < n; r++) {
       const uint32_t okey = g_sc.rl_old[r];
       int ci = g_sc.rl_idx[r];
+      if (ci == (int)RL_NO_COMMITMENT) {
+        const int ks = lds_slot_of()[key_job(okey)];
+        if (ks != SLOT_NONE) lds_slot_ref()[ks]--;
+        continue;
+      }
       if (!(ci < H.n_commits && g_hot.c_src[ci] == okey && g_hot.c_seq[ci] == g_sc.rl_seq[r])) {  // entries have moved (swap-remove)
         ci = -1;
         for (int i = 0; i < H.n_commits; i++)
@@ -2439,6 +2482,14 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
           if (g_sc.fc_dst[q] == nkey) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
         pool_close(nkey, sn);
       }
+    }
+  }
+  if (any_freed) {
+    // every scan that found nothing left schedulable_stages empty (ENV:333, 505-540)
+    const int A = g_hot.h.n_active;
+    for (int a = lane; a < A; a += 64) {
+      SssJob* job = jobp(lds_active()[a]);
+      if (job->sched_mask) job->sched_mask = 0;
     }
   }
   wave_sync();
