@@ -526,6 +526,7 @@ struct SetImg {
   T* small;      // where an 8-slot table goes (pool images), or nullptr
   uint32_t aux;  // pool images: the record's outgoing commitment count, carried from pool_open to pool_close
   bool wide;     // `tab` is in HBM: probe groups are fetched whole (ProbeGroup)
+  bool big_wide; // ... and so is `big` (only read when a resize moves the table there)
 };
 
 // One probe group of a byte table (entries i .. i + probes, at most 10) fetched with two accesses
@@ -577,7 +578,7 @@ SSS_DEV void set_resize(SetImg<T>& s, uint32_t minused, uint16_t* keys) {
     if (e >= 2) keys[n++] = (uint16_t)(e - 2);
   }
   if (newsize > s.cap)
-    s.tab = s.big, s.cap = 0xFFFFFFFFu, s.wide = true;  // the live keys are in `keys`: nothing to copy
+    s.tab = s.big, s.cap = 0xFFFFFFFFu, s.wide = s.big_wide;  // the live keys are in `keys`: nothing to copy
   else if (newsize <= 8 && s.small)
     s.tab = s.small, s.cap = 8, s.wide = false;         // a pool image that fits its record again
   for (uint32_t i = 0; i < newsize; i++) s.tab[i] = 0;
@@ -689,7 +690,7 @@ SSS_DEV SetImg<uint8_t> pool_open(uint32_t key) {
   const uint4 rec = *(const uint4*)(g_c.pool_hdr + p);  // mask | fill << 16, used | commit_from << 16, tab8[0..3], tab8[4..7]
   SetImg<uint8_t> s;
   s.mask = rec.x & 0xFFFFu, s.fill = rec.x >> 16, s.used = rec.y & 0xFFFFu, s.finger = 0, s.aux = rec.y >> 16;
-  s.big = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E);
+  s.big = g_c.pool_tab + (size_t)p * sss_pool_table_bytes(g_c.E), s.big_wide = true;
   s.small = g_sc.pool8;
   if (s.mask == 7) {
     *(uint2*)g_sc.pool8 = mk_u2(rec.z, rec.w);
@@ -707,6 +708,37 @@ SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
     *(uint4*)hd = mk_u4(w0, w1, t.x, t.y);
   } else
     *(uint4*)hd = mk_u4(w0, w1, 0u, 0u);  // the table lives in the overflow area; the inline bytes are kept clean
+}
+// The same with the whole wave, for a run of operations on one pool (the event batches): the pool's table comes
+// into LDS with one access per lane whatever its size, lane 0 works on it there - dependent LDS accesses
+// instead of dependent HBM ones - and it goes back the same way. pool_stage_in (all lanes) .. lane-0 section
+// on the image it returns .. wave_sync .. pool_stage_out (all lanes). The staging area is setA + setB.
+SSS_DEV uint8_t* pool_table_hbm(uint32_t key) { return g_c.pool_tab + (size_t)pool_index(key) * sss_pool_table_bytes(g_c.E); }
+SSS_DEV SetImg<uint8_t> pool_stage_in(uint32_t key) {
+  const int lane = wave_lane();
+  const uint4 rec = *(const uint4*)(g_c.pool_hdr + pool_index(key));
+  const uint32_t bytes = sss_pool_table_bytes(g_c.E);
+  static_assert(2 * SSS_SET_TABLE <= 64 * 8, "one 8-byte access per lane moves a whole table");
+  if ((uint32_t)lane * 8 < bytes) ((uint2*)g_sc.setA)[lane] = ((const uint2*)pool_table_hbm(key))[lane];
+  SetImg<uint8_t> s;
+  s.mask = rec.x & 0xFFFFu, s.fill = rec.x >> 16, s.used = rec.y & 0xFFFFu, s.finger = 0, s.aux = rec.y >> 16;
+  s.big = g_sc.setA, s.big_wide = false, s.small = g_sc.pool8;
+  if (s.mask == 7) {
+    if (lane == 0) *(uint2*)g_sc.pool8 = mk_u2(rec.z, rec.w);
+    s.tab = g_sc.pool8, s.cap = 8, s.wide = false;
+  } else
+    s.tab = g_sc.setA, s.cap = bytes, s.wide = false;
+  wave_sync();
+  return s;
+}
+// `s`: lane 0's image after its operations (the other lanes' copies are stale)
+SSS_DEV void pool_stage_out(uint32_t key, const SetImg<uint8_t>& s) {
+  const int lane = wave_lane();
+  // the whole area goes back, not just the slots in use: the HBM copy then is byte for byte what the
+  // one-operation-at-a-time code would have left (it works in place), dead slots included
+  if ((uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E)) ((uint2*)pool_table_hbm(key))[lane] = ((const uint2*)g_sc.setA)[lane];
+  if (lane == 0) pool_close(key, s);
+  wave_sync();
 }
 SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
 SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
@@ -906,7 +938,7 @@ SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send) {  
     if (same) rn = ro;
     hot.ex_loc[e] = new_pool;
     SetImg<uint8_t> s;
-    s.small = g_sc.pool8, s.big = g_c.pool_tab + (size_t)pool_index(new_pool) * sss_pool_table_bytes(g_c.E);
+    s.small = g_sc.pool8, s.big = g_c.pool_tab + (size_t)pool_index(new_pool) * sss_pool_table_bytes(g_c.E), s.big_wide = true;
     s.mask = rn.x & 0xFFFFu, s.fill = rn.x >> 16, s.used = rn.y & 0xFFFFu, s.finger = 0, s.aux = rn.y >> 16;
     if (s.mask == 7) {
       uint64_t t = (uint64_t)rn.z | ((uint64_t)rn.w << 32);
@@ -2136,6 +2168,13 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
 // One lane per pool (batch_released_events): every member of ranks [0, n) that leaves pool `okey` is taken out
 // of it - one fetch and one store of the pool's record; removals commute - and the pool's outgoing
 // commitments shrink by as many.
+// every member's own lane, for pools with more than 8 slots: removals commute and touch one slot each
+SSS_DEV void pool_leave_table(uint32_t okey, uint32_t e) {
+  const uint32_t mask = g_c.pool_hdr[pool_index(okey)].mask;
+  if (mask == 7) return;
+  bool was = table_mark_dummy(pool_table_hbm(okey), mask, e);
+  CHECK(was);
+}
 SSS_DEV void pool_leave_many(uint32_t okey, uint32_t n) {
   SssPoolHdr* hd = g_c.pool_hdr + pool_index(okey);
   uint4 rec = *(const uint4*)hd;
@@ -2144,41 +2183,61 @@ SSS_DEV void pool_leave_many(uint32_t okey, uint32_t n) {
   uint64_t t = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
   for (uint32_t q = 0; q < n; q++) {
     if (g_sc.rl_old[q] != okey) continue;
-    bool was;
-    if (mask == 7)
-      was = set8_remove(t, used, (uint32_t)g_sc.fi_e[q]);
-    else {
-      was = table_mark_dummy(g_c.pool_tab + (size_t)pool_index(okey) * sss_pool_table_bytes(g_c.E), mask, (uint32_t)g_sc.fi_e[q]);
-      used--;
-    }
-    CHECK(was);
+    if (mask == 7) {
+      bool was = set8_remove(t, used, (uint32_t)g_sc.fi_e[q]);
+      CHECK(was);
+    } else
+      used--;  // the member's own lane has marked its slot of the table (pool_leave_table)
     if (g_sc.rl_idx[q] != RL_NO_COMMITMENT) aux--;
   }
   *(uint4*)hd = mk_u4(rec.x, (used & 0xFFFFu) | (aux << 16), mask == 7 ? (uint32_t)t : 0u, mask == 7 ? (uint32_t)(t >> 32) : 0u);
 }
-// ... and every member that enters pool `nkey` is added, in rank order. Returns false, with nothing done, when
-// the additions could make the table grow (that needs the scratch lists of the one-pool-at-a-time path).
+// ... and every member that enters pool `nkey` is added, in rank order. Returns false, with nothing done, unless
+// the image has 8 slots and keeps them (larger tables and growth go through the LDS staging area, pools_staged).
 SSS_DEV bool pool_enter_many(uint32_t nkey, uint32_t n) {
   SssPoolHdr* hd = g_c.pool_hdr + pool_index(nkey);
   const uint4 rec = *(const uint4*)hd;
-  SetImg<uint8_t> sn;
-  sn.mask = rec.x & 0xFFFFu, sn.fill = rec.x >> 16, sn.used = rec.y & 0xFFFFu, sn.finger = 0, sn.aux = rec.y >> 16;
+  if ((rec.x & 0xFFFFu) != 7) return false;
+  uint32_t fill = rec.x >> 16, used = rec.y & 0xFFFFu;
   uint32_t cnt = 0;
   for (uint32_t q = 0; q < n; q++) cnt += g_sc.fc_dst[q] == nkey ? 1u : 0u;
-  if ((sn.fill + cnt) * 5 >= sn.mask * 3) return false;
-  if (sn.mask == 7) {
-    uint64_t t = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
-    for (uint32_t q = 0; q < n; q++)
-      if (g_sc.fc_dst[q] == nkey) set8_add(t, sn.fill, sn.used, (uint32_t)g_sc.fi_e[q]);
-    *(uint4*)hd = mk_u4(7u | (sn.fill << 16), (sn.used & 0xFFFFu) | (sn.aux << 16), (uint32_t)t, (uint32_t)(t >> 32));
-  } else {
-    sn.big = g_c.pool_tab + (size_t)pool_index(nkey) * sss_pool_table_bytes(g_c.E), sn.small = nullptr;
-    sn.tab = sn.big, sn.cap = 0xFFFFFFFFu, sn.wide = true;
-    for (uint32_t q = 0; q < n; q++)
-      if (g_sc.fc_dst[q] == nkey) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());  // no growth (checked above): the scratch list is not touched
-    *(uint4*)hd = mk_u4(sn.mask | (sn.fill << 16), (sn.used & 0xFFFFu) | (sn.aux << 16), 0u, 0u);
-  }
+  if ((fill + cnt) * 5 >= 7 * 3) return false;
+  uint64_t t = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+  for (uint32_t q = 0; q < n; q++)
+    if (g_sc.fc_dst[q] == nkey) set8_add(t, fill, used, (uint32_t)g_sc.fi_e[q]);
+  *(uint4*)hd = mk_u4(7u | (fill << 16), (used & 0xFFFFu) | (rec.y & 0xFFFF0000u), (uint32_t)t, (uint32_t)(t >> 32));
   return true;
+}
+// All lanes: the pools the lanes of `dm` speak for, one at a time through the LDS staging area. ENTER: the members
+// whose fc_dst is the pool are added in rank order. PASS (arriving executors, their job's pool, rl_old): each
+// enters and leaves again, or - parked - is taken out and put back by the move to the pool it is already in.
+enum { STAGED_ENTER = 0, STAGED_PASS = 1 };
+template <int MODE>
+SSS_DEV void pools_staged(uint64_t dm, uint32_t n) {
+  const int lane = wave_lane();
+  while (dm) {
+    const int l = ctz64(dm);
+    dm &= dm - 1;
+    uint32_t key = POOL_NONE;
+    for (uint32_t q = 0; q < n; q++)
+      if (g_sc.fi_e[q] == (uint8_t)l) key = MODE == STAGED_ENTER ? g_sc.fc_dst[q] : g_sc.rl_old[q];
+    SetImg<uint8_t> sn = pool_stage_in(key);
+    if (lane == 0) {
+      for (uint32_t q = 0; q < n; q++) {
+        const uint32_t e = g_sc.fi_e[q];
+        if (MODE == STAGED_ENTER) {
+          if (g_sc.fc_dst[q] == key) set_add(sn, e, lds_keys());
+        } else if (g_sc.rl_old[q] == key) {
+          set_add(sn, e, lds_keys());
+          bool was = set_remove(sn, e);
+          CHECK(was);
+          if (g_sc.fi_type[q] == 1 /* AR_PARK */) set_add(sn, e, lds_keys());
+        }
+      }
+    }
+    wave_sync();
+    pool_stage_out(key, sn);
+  }
 }
 
 enum { RL_START = 0, RL_PARK = 1, RL_SEND = 2, RL_IDLE_JOB = 3, RL_IDLE_COMMON = 4, RL_FREE_JOB = 5, RL_FREE_COMMON = 6 };
@@ -2459,6 +2518,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   // member before it (in rank) shares that pool.
   bool deferred = false;
   if (V) {
+    pool_leave_table(sp, (uint32_t)lane);
     if (cb_old == 0) pool_leave_many(sp, n);
     const uint32_t nkey = g_sc.fc_dst[rank];
     bool lead = nkey != POOL_NONE;
@@ -2467,23 +2527,8 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   }
   uint64_t dm = wave_ballot(deferred);
   STAT(31, 1), STAT(32, popc64(dm)), STAT(33, n);
-  if (dm) {  // tables that have to grow: one pool at a time with the general code
-    wave_sync();
-    if (lane == 0) {
-      while (dm) {
-        const int l = ctz64(dm);
-        dm &= dm - 1;
-        // lane l's member: find its rank (the executor is the lane) and its pool
-        uint32_t nkey = POOL_NONE;
-        for (uint32_t q = 0; q < n; q++)
-          if (g_sc.fi_e[q] == (uint8_t)l) nkey = g_sc.fc_dst[q];
-        SetImg<uint8_t> sn = pool_open(nkey);
-        for (uint32_t q = 0; q < n; q++)
-          if (g_sc.fc_dst[q] == nkey) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
-        pool_close(nkey, sn);
-      }
-    }
-  }
+  wave_sync();
+  pools_staged<STAGED_ENTER>(dm, n);  // tables with more than 8 slots, or about to grow
   if (any_freed) {
     // every scan that found nothing left schedulable_stages empty (ENV:333, 505-540)
     const int A = g_hot.h.n_active;
@@ -2718,39 +2763,9 @@ SSS_DEV int batch_arrival_events(const FastCtx& f) {
   }
   uint64_t dj = wave_ballot(def_job), ds = wave_ballot(def_stage);
   STAT(34, 1), STAT(35, n), STAT(36, popc64(dj)), STAT(37, popc64(ds)), STAT(38, n - n_x);
-  if (dj | ds) {  // tables with more than 8 slots, or about to grow: one pool at a time with the general code
-    wave_sync();
-    if (lane == 0) {
-      while (dj) {
-        const int l = ctz64(dj);
-        dj &= dj - 1;
-        uint32_t key = POOL_NONE;
-        for (uint32_t q = 0; q < n; q++)
-          if (g_sc.fi_e[q] == (uint8_t)l) key = g_sc.rl_old[q];
-        SetImg<uint8_t> sj = pool_open(key);
-        for (uint32_t q = 0; q < n; q++) {
-          if (g_sc.rl_old[q] != key) continue;
-          set_add(sj, (uint32_t)g_sc.fi_e[q], lds_keys());
-          bool was = set_remove(sj, (uint32_t)g_sc.fi_e[q]);
-          CHECK(was);
-          if (g_sc.fi_type[q] == AR_PARK) set_add(sj, (uint32_t)g_sc.fi_e[q], lds_keys());
-        }
-        pool_close(key, sj);
-      }
-      while (ds) {
-        const int l = ctz64(ds);
-        ds &= ds - 1;
-        uint32_t key = POOL_NONE;
-        for (uint32_t q = 0; q < n; q++)
-          if (g_sc.fi_e[q] == (uint8_t)l) key = g_sc.fc_dst[q];
-        SetImg<uint8_t> sn = pool_open(key);
-        for (uint32_t q = 0; q < n; q++)
-          if (g_sc.fc_dst[q] == key) set_add(sn, (uint32_t)g_sc.fi_e[q], lds_keys());
-        pool_close(key, sn);
-      }
-    }
-  }
   wave_sync();
+  pools_staged<STAGED_PASS>(dj, n);  // tables with more than 8 slots, or about to grow
+  pools_staged<STAGED_ENTER>(ds, n);
   // saturation bit of the stage (ENV:566-582), by its last member: arrivals that start a task leave the
   // demand what it was, parked ones raise it
   if (V && cb_stage + 1 == ct_stage) {
