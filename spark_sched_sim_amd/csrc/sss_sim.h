@@ -1217,6 +1217,15 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
       }
       return out;
     }
+    // 19 or more: whatever order they are added in, the set grows 8 -> 32 (5th key) -> 128 slots (19th key,
+    // set_table_resize(76)), where every executor id sits in its home slot: the image is the same for every order
+    const uint32_t n_idle = (uint32_t)popc64(m);
+    if (n_idle >= 19) {
+      for (int i = 0; i < 128 / 8; i++) ((uint2*)out.tab)[i] = mk_u2(0u, 0u);
+      for (uint64_t r = m; r; r &= r - 1) out.tab[ctz64(r)] = (uint8_t)(ctz64(r) + 2);
+      out.mask = 127, out.fill = out.used = n_idle;
+      return out;
+    }
   }
   SetImg<uint8_t> src = pool_open(key);
   // pool.copy() == set_merge into a fresh set (setA)
@@ -1383,10 +1392,11 @@ enum { FI_SEND = 1, FI_EXEC = 2, FI_PARK = 3 };
 //   * its position in the random stream = the raw outputs consumed by the draws before it, known
 //     without their values (one for random() when the executor-level interval is open, one 32-bit
 //     half for the bounded integer - as in batch_fast_events).
-// Removals from the source pool commute (a removal leaves a dummy, probe chains do not change);
-// additions to a stage's pool are made in item order by lane 0, with one open / close per pool.
+// Removals from the source pool commute (a removal leaves a dummy, probe chains do not change) - unless
+// executors are parked in the source itself (taken out and put back): then its operations run in item order;
+// additions to a pool are made in item order by lane 0 on the staged image (pool_stage_in / _out).
 // Returns n when the chunk was fulfilled. When it holds anything else (a stage short of tasks -> backup
-// scheduling, the source pool as destination, an executor parked in the pool it is in, duration lists
+// scheduling, the source pool as destination, duration lists
 // with one or no entry, a draw that needs Lemire's rejection test) nothing is modified and the
 // return value is the index (< n) of the first item that cannot go this way; [that item, serial_end)
 // - the rest of its commitment - is for the one-at-a-time path, the items before it for a shorter chunk.
@@ -1414,8 +1424,9 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
   const int slot = lds_slot_of()[j];
   const SssPoolHdr src_hdr = g_c.pool_hdr[pool_index(src)];
   const int type = exj != j ? FI_SEND : (in_frontier ? FI_EXEC : FI_PARK);
-  bool bad = active && (dst == src || s < 0 || g_hot.ex_executing[e] || g_hot.ex_loc[e] != src || (type == FI_PARK && src == key_job_pool(j)) ||
-                        (exj >= 0 && exj != src_job) || (type == FI_SEND && j == src_job));
+  // parked in the pool it is in (the source is its job's pool): the move takes it out and puts it back (TRK:188-222)
+  const bool park_here = type == FI_PARK && src == key_job_pool(j);
+  bool bad = active && (dst == src || s < 0 || g_hot.ex_executing[e] || g_hot.ex_loc[e] != src || (exj >= 0 && exj != src_job) || (type == FI_SEND && j == src_job));
   const uint64_t below = bit64(lane) - 1;
   const uint64_t m_act = wave_ballot(active);
   const uint64_t m_exec = wave_ballot(active && type == FI_EXEC), m_park = wave_ballot(active && type == FI_PARK);
@@ -1505,6 +1516,9 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
   }
   // ---- commit ----
   const bool big_src = src_hdr.mask != 7;
+  // removals from the source commute - unless executors are put back in between: then the pool's operations
+  // run in item order on the staged image
+  const bool staged_src = wave_ballot(active && park_here) != 0;
   if (active) {
     double t = wall + g_c.P.moving_delay;
     double dur = 0.0;
@@ -1549,15 +1563,29 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
           lane_atomic_and_u64(&jp->sat_mask, ~bit64(s));
       }
     }
-    if (big_src) {
-      bool was = table_mark_dummy(g_c.pool_tab + (size_t)pool_index(src) * sss_pool_table_bytes(g_c.E), src_hdr.mask, (uint32_t)e);
+    if (big_src && !staged_src) {
+      bool was = table_mark_dummy(pool_table_hbm(src), src_hdr.mask, (uint32_t)e);
       CHECK(was);
     }
   }
   wave_sync();
+  const uint32_t src_jpool = src_job >= 0 ? key_job_pool(src_job) : POOL_NONE;
+  if (staged_src) {
+    SetImg<uint8_t> sset = pool_stage_in(src);
+    if (lane == 0) {
+      for (int i = c0; i < c0 + n; i++) {
+        bool was = set_remove(sset, (uint32_t)g_sc.fi_e[i]);
+        CHECK(was);
+        if (g_sc.fi_type[i] == FI_PARK && src == src_jpool) set_add(sset, (uint32_t)g_sc.fi_e[i], lds_keys());
+      }
+      sset.aux -= (uint32_t)n;
+    }
+    wave_sync();
+    pool_stage_out(src, sset);
+  }
   if (lane == 0) {
     // the source pool's record: n executors and n commitments fewer
-    {
+    if (!staged_src) {
       SetImg<uint8_t> sset = pool_open(src);
       if (!big_src) {
         for (int i = c0; i < c0 + n; i++) {
@@ -1576,18 +1604,31 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
       if (g_sc.fi_detach) (*jobp(src_job)).local_mask &= ~g_sc.fi_detach;
     }
     g_sc.fi_detach = 0;
-    // stage pools receive their executors in item order; commitments are settled; events name their jobs' slots
+  }
+  // stage pools (and, for parked executors, job pools) receive their executors in item order, through the staging
+  // area; the items of one commitment are consecutive and all of one kind
+  for (int i = c0; i < c0 + n;) {
+    const int kk = g_sc.fi_k[i];
+    const uint32_t d = g_sc.fc_dst[kk];
+    int i1 = i, n_ex = 0, n_pk = 0;
+    while (i1 < c0 + n && g_sc.fi_k[i1] == kk) n_ex += g_sc.fi_type[i1] == FI_EXEC, n_pk += g_sc.fi_type[i1] == FI_PARK, i1++;
+    const uint32_t into = n_ex ? d : key_job_pool(key_job(d));
+    if ((n_ex || n_pk) && into != src) {
+      SetImg<uint8_t> dset = pool_stage_in(into);
+      if (lane == 0)
+        for (int q = i; q < i1; q++) set_add(dset, (uint32_t)g_sc.fi_e[q], lds_keys());
+      wave_sync();
+      pool_stage_out(into, dset);
+    }
+    i = i1;
+  }
+  if (lane == 0) {
+    // commitments are settled; events name their jobs' slots
     for (int i = c0; i < c0 + n;) {
       const int kk = g_sc.fi_k[i];
       const uint32_t d = g_sc.fc_dst[kk];
-      int i1 = i, n_ex = 0, n_pk = 0;
-      while (i1 < c0 + n && g_sc.fi_k[i1] == kk) n_ex += g_sc.fi_type[i1] == FI_EXEC, n_pk += g_sc.fi_type[i1] == FI_PARK, i1++;
-      if (n_ex || n_pk) {  // the items of one commitment are all of one kind: into the stage's pool, or into its job's pool
-        const uint32_t into = n_ex ? d : key_job_pool(key_job(d));
-        SetImg<uint8_t> dset = pool_open(into);
-        for (int q = i; q < i1; q++) set_add(dset, (uint32_t)g_sc.fi_e[q], lds_keys());
-        pool_close(into, dset);
-      }
+      int i1 = i, n_pk = 0;
+      while (i1 < c0 + n && g_sc.fi_k[i1] == kk) n_pk += g_sc.fi_type[i1] == FI_PARK, i1++;
       int ci;
       for (ci = 0; ci < H.n_commits; ci++)
         if (g_hot.c_src[ci] == src && g_hot.c_dst[ci] == d) break;
