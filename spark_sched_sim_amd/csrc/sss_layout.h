@@ -220,6 +220,7 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   o = (o + 1) & ~1;
   P->off_slot_job = o, o += 2 * 64;
   P->off_keys = o, o += 2 * (J_cap + 8);
+  o = (o + 15) & ~15;  // the set image is cleared and counted 16 bytes at a time
   P->off_jobset = o, o += 2 * jobset;
   o = (o + 15) & ~15;
   P->off_exdesc = o, o += (int)sizeof(SssExDesc) * E;

@@ -2965,9 +2965,21 @@ SSS_DEV void env_begin(const uint8_t* base) {
   PROF3(23);
   int lane = wave_lane();
   {
-    const uint4* s = (const uint4*)base;
-    uint4* d = (uint4*)&g_hot;
-    for (int i = lane; i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+    // the header, and of the per-executor arrays the entries of this env's executors (commitments: at most one
+    // entry per executor). The rest of the HBM image is never read or written.
+    const SssHot* g = (const SssHot*)base;
+    if (lane < (int)(sizeof(SssHdr) / 16)) ((uint4*)&g_hot.h)[lane] = ((const uint4*)&g->h)[lane];
+    SssEvSlot ev;
+    ev.t = __builtin_inf(), ev.seq = 0, ev.info = EV_NONE;  // the queue's reductions run over all 64 lanes
+    uint32_t loc = POOL_NONE, csrc = 0, cdst = 0, cseq = 0;
+    int16_t job = -1, cn = 0;
+    int8_t ts = -1;
+    uint8_t exe = 0;
+    if (lane < g_c.E)
+      ev = g->ev[lane], loc = g->ex_loc[lane], job = g->ex_job[lane], ts = g->ex_task_stage[lane], exe = g->ex_executing[lane], csrc = g->c_src[lane],
+      cdst = g->c_dst[lane], cseq = g->c_seq[lane], cn = g->c_n[lane];
+    g_hot.ev[lane] = ev, g_hot.ex_loc[lane] = loc, g_hot.ex_job[lane] = job, g_hot.ex_task_stage[lane] = ts, g_hot.ex_executing[lane] = exe;
+    g_hot.c_src[lane] = csrc, g_hot.c_dst[lane] = cdst, g_hot.c_seq[lane] = cseq, g_hot.c_n[lane] = cn;
   }
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
   if (lane < g_c.E) lds_exdesc()[lane].gs = -1;
@@ -3045,9 +3057,13 @@ SSS_DEV void env_end(uint8_t* base) {
   }
   wave_sync();
   {
-    const uint4* s = (const uint4*)&g_hot;
-    uint4* d = (uint4*)base;
-    for (int i = lane; i < (int)(sizeof(SssHot) / 16); i += 64) d[i] = s[i];
+    SssHot* g = (SssHot*)base;
+    if (lane < (int)(sizeof(SssHdr) / 16)) ((uint4*)&g->h)[lane] = ((const uint4*)&g_hot.h)[lane];
+    if (lane < g_c.E) {
+      g->ev[lane] = g_hot.ev[lane], g->ex_loc[lane] = g_hot.ex_loc[lane], g->ex_job[lane] = g_hot.ex_job[lane];
+      g->ex_task_stage[lane] = g_hot.ex_task_stage[lane], g->ex_executing[lane] = g_hot.ex_executing[lane];
+      g->c_src[lane] = g_hot.c_src[lane], g->c_dst[lane] = g_hot.c_dst[lane], g->c_seq[lane] = g_hot.c_seq[lane], g->c_n[lane] = g_hot.c_n[lane];
+    }
   }
 }
 
@@ -3118,6 +3134,42 @@ SSS_DEV_NOINLINE void jobtime_build_set() {
   for (int k = 0; k < g_sc.n_old_active; k++) set_add(all, (uint32_t)lds_old_active()[k], lds_keys());
   for (int k = 0; k < H.n_active; k++) set_add(all, (uint32_t)lds_active()[k], lds_keys());
   g_sc.jobset_mask = (int32_t)all.mask;
+}
+
+// The same image with the whole wave, when it does not depend on the order of the additions: n distinct ids
+// grow the table 8 -> 32 (5th) -> 128 (19th) -> 512 (77th) -> 2048 (307th id) slots, every resize re-inserts
+// into an empty table, and once the table is larger than the largest id every id sits in its home slot with
+// no collision possible - whatever happened in the smaller tables before. Otherwise lane 0 builds it (above).
+SSS_DEV void jobtime_build_set_wave() {
+  const int lane = wave_lane();
+  uint16_t* tab = lds_jobset();
+  const int cap = g_c.P.jobset_slots;
+  const int n_old = g_sc.n_old_active, n_act = g_hot.h.n_active;
+  for (int i = lane * 8; i < cap; i += 64 * 8) *(uint4*)(tab + i) = mk_u4(0u, 0u, 0u, 0u);
+  wave_sync();
+  uint32_t not_max = 0xFFFFFFFFu;
+  for (int k = lane; k < n_old + n_act; k += 64) {
+    const uint32_t id = k < n_old ? lds_old_active()[k] : lds_active()[k - n_old];
+    tab[id] = (uint16_t)(id + 2);
+    not_max = ~id < not_max ? ~id : not_max;
+  }
+  wave_sync();
+  uint32_t cnt = 0;
+  for (int i = lane * 8; i < cap; i += 64 * 8) {
+    const uint4 q = *(const uint4*)(tab + i);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    for (int b = 0; b < 4; b++) cnt += ((w[b] & 0xFFFFu) != 0 ? 1u : 0u) + ((w[b] >> 16) != 0 ? 1u : 0u);
+  }
+  const uint32_t n = wave_sum_u32(cnt);
+  const uint32_t max_id = n ? ~wave_min_u32(not_max) : 0u;
+  const uint32_t mask = n < 5 ? 7u : (n < 19 ? 31u : (n < 77 ? 127u : (n < 307 ? 511u : 2047u)));
+  if (max_id <= mask && (int)mask < cap) {
+    if (lane == 0) g_sc.jobset_mask = (int32_t)mask;
+  } else {
+    wave_sync();
+    if (lane == 0) jobtime_build_set();
+  }
+  wave_sync();
 }
 
 SSS_DEV double jobtime_sum() {
@@ -3508,14 +3560,15 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     g_sc.f_need_jobtime = 0;
     if (!H.err && H.wall_time - g_sc.wall_old != 0.0) {
       if (!(g_sc.jobset_valid && g_sc.jobset_old_v == g_sc.old_version && g_sc.jobset_new_v == g_sc.active_version)) {
-        jobtime_build_set();
+        g_sc.f_need_jobtime = 2;  // the set image is built first
         g_sc.jobset_valid = 1, g_sc.jobset_old_v = g_sc.old_version, g_sc.jobset_new_v = g_sc.active_version;
-      }
-      g_sc.f_need_jobtime = 1;
+      } else
+        g_sc.f_need_jobtime = 1;
     }
   }
   wave_sync();
   double job_time = 0.0;
+  if (g_sc.f_need_jobtime == 2) jobtime_build_set_wave();
   if (g_sc.f_need_jobtime) job_time = jobtime_sum();
   double reward = 0.0;
   if (lane == 0) {
