@@ -1,0 +1,89 @@
+"""Instruction-class counts of the simulator kernels' gfx950 code ("dump the ISA with
+VALU / SALU / LDS counts"). Compiles csrc/sss_hip.hip with -save-temps into a scratch directory and parses
+the device assembly: per kernel the static instruction mix, registers, LDS and scratch; for sss_step_kernel
+also the mix of the batch loop of batch_fast_events (the basic blocks between the loop's two
+wave-minimum reductions are found through the s_memtime-free v_readlane chains; see --loop).
+
+usage: python tools/isa_counts.py [--out profiles/r02_isa.md]"""
+import argparse, collections, os, os.path as osp, re, subprocess, sys, tempfile
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+CLASSES = [("VALU", r"^v_(?!readlane|readfirstlane|writelane)"), ("cross-lane (readlane/writelane/DPP moves)", r"^v_(readlane|readfirstlane|writelane)"),
+           ("SALU", r"^s_(?!waitcnt|load|buffer_load|barrier|branch|cbranch|nop|endpgm|sleep|setprio|memtime|memrealtime)"),
+           ("scalar memory", r"^s_(load|buffer_load|memtime|memrealtime)"), ("LDS", r"^ds_"), ("global / flat memory", r"^(global|flat|buffer|scratch)_"),
+           ("s_waitcnt", r"^s_waitcnt"), ("branches", r"^s_(branch|cbranch)"), ("other", r".")]
+
+
+def compile_asm(tmp):
+    src = osp.join(ROOT, "spark_sched_sim_amd", "csrc", "sss_hip.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function",
+           "-I", osp.dirname(src), "-save-temps", "-o", osp.join(tmp, "lib.so"), src]
+    subprocess.run(cmd, cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return osp.join(tmp, "sss_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def kernels(asm):
+    """name -> (list of instruction mnemonics+operands, metadata dict)"""
+    out, cur, meta = {}, None, collections.defaultdict(dict)
+    for line in open(asm):
+        t = line.strip()
+        m = re.match(r"^(\w+):\s*(;.*)?$", t)
+        if m and not t.startswith(".") and not m.group(1).startswith("BB") and not m.group(1).startswith("LBB"):
+            cur = m.group(1)
+            out[cur] = []
+            continue
+        if t.startswith(".end_amdhsa_kernel") or t.startswith(".Lfunc_end"):
+            cur = None if t.startswith(".Lfunc_end") else cur
+            continue
+        m = re.match(r"^\.amdhsa_(next_free_vgpr|next_free_sgpr|group_segment_fixed_size|private_segment_fixed_size|accum_offset)\s+(\S+)", t)
+        if m:
+            meta["_pending"][m.group(1)] = m.group(2)
+        m = re.match(r"^\.amdhsa_kernel\s+(\w+)", t)
+        if m:
+            meta["_name"] = {"n": m.group(1)}
+            meta["_pending"] = {}
+        if t.startswith(".end_amdhsa_kernel") and "_name" in meta:
+            meta[meta["_name"]["n"]] = dict(meta["_pending"])
+        if cur and t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
+            out[cur].append(t.split(";")[0].strip())
+    return out, meta
+
+
+def mix(instrs):
+    c = collections.Counter()
+    for i in instrs:
+        op = i.split()[0]
+        for name, pat in CLASSES:
+            if re.match(pat, op):
+                c[name] += 1
+                break
+    c["DPP-modified VALU"] = sum(1 for i in instrs if "row_" in i or "quad_perm" in i or "wave_" in i)
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = compile_asm(tmp)
+        ks, meta = kernels(asm)
+    lines = ["# gfx950 instruction mix of the simulator kernels (static counts, `tools/isa_counts.py`)", "",
+             "`hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -save-temps`; every procedure is inlined into the kernels (the", "launch context is read through the kernel-argument segment pointer, which callees do not have).", ""]
+    names = [k for k in ks if k.startswith("sss_") and k.endswith("_kernel")]
+    cols = [n for n, _ in CLASSES] + ["DPP-modified VALU"]
+    lines.append("| kernel | instructions | " + " | ".join(cols) + " | VGPRs | SGPRs | static LDS (B) | scratch (B) |")
+    lines.append("|---|---|" + "---|" * (len(cols) + 4))
+    for k in names:
+        c = mix(ks[k])
+        md = meta.get(k, {})
+        lines.append(f"| `{k}` | {len(ks[k])} | " + " | ".join(str(c[n]) for n in cols) +
+                     f" | {md.get('next_free_vgpr', '?')} | {md.get('next_free_sgpr', '?')} | {md.get('group_segment_fixed_size', '?')} | {md.get('private_segment_fixed_size', '?')} |")
+    text = "\n".join(lines) + "\n"
+    if a.out:
+        open(osp.join(ROOT, a.out) if not osp.isabs(a.out) else a.out, "w").write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
