@@ -23,27 +23,31 @@ def compile_asm(tmp):
 
 
 def kernels(asm):
-    """name -> (list of instruction mnemonics+operands, metadata dict)"""
-    out, cur, meta = {}, None, collections.defaultdict(dict)
+    """name -> list of instructions; name -> {.amdhsa_ directive: value}"""
+    out, cur, meta, kd = {}, None, {}, None
     for line in open(asm):
         t = line.strip()
+        m = re.match(r"^\.amdhsa_kernel\s+(\w+)", t)
+        if m:
+            kd = m.group(1)
+            meta[kd] = {}
+            continue
+        if t.startswith(".end_amdhsa_kernel"):
+            kd = None
+            continue
+        if kd:
+            m = re.match(r"^\.amdhsa_(next_free_vgpr|next_free_sgpr|group_segment_fixed_size|private_segment_fixed_size|accum_offset)\s+(\S+)", t)
+            if m:
+                meta[kd][m.group(1)] = m.group(2)
+            continue
         m = re.match(r"^(\w+):\s*(;.*)?$", t)
-        if m and not t.startswith(".") and not m.group(1).startswith("BB") and not m.group(1).startswith("LBB"):
+        if m and not m.group(1).startswith(("BB", "LBB")):
             cur = m.group(1)
             out[cur] = []
             continue
-        if t.startswith(".end_amdhsa_kernel") or t.startswith(".Lfunc_end"):
-            cur = None if t.startswith(".Lfunc_end") else cur
+        if t.startswith(".Lfunc_end"):
+            cur = None
             continue
-        m = re.match(r"^\.amdhsa_(next_free_vgpr|next_free_sgpr|group_segment_fixed_size|private_segment_fixed_size|accum_offset)\s+(\S+)", t)
-        if m:
-            meta["_pending"][m.group(1)] = m.group(2)
-        m = re.match(r"^\.amdhsa_kernel\s+(\w+)", t)
-        if m:
-            meta["_name"] = {"n": m.group(1)}
-            meta["_pending"] = {}
-        if t.startswith(".end_amdhsa_kernel") and "_name" in meta:
-            meta[meta["_name"]["n"]] = dict(meta["_pending"])
         if cur and t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
             out[cur].append(t.split(";")[0].strip())
     return out, meta
@@ -79,6 +83,10 @@ def main():
         md = meta.get(k, {})
         lines.append(f"| `{k}` | {len(ks[k])} | " + " | ".join(str(c[n]) for n in cols) +
                      f" | {md.get('next_free_vgpr', '?')} | {md.get('next_free_sgpr', '?')} | {md.get('group_segment_fixed_size', '?')} | {md.get('private_segment_fixed_size', '?')} |")
+    pmc = osp.join(ROOT, "profiles", "r02_pmc_step_c2.txt")
+    if osp.exists(pmc):
+        lines += ["", "Dynamic counts of `sss_step_kernel` (rocprofv3 PMC passes over a C2 step-mode run, 4096 waves per launch, mean of the last 40",
+                  "launches; `tools/debug/pmc_probe.sh`):", "", "```"] + open(pmc).read().rstrip().split("\n") + ["```"]
     text = "\n".join(lines) + "\n"
     if a.out:
         open(osp.join(ROOT, a.out) if not osp.isabs(a.out) else a.out, "w").write(text)
