@@ -50,6 +50,7 @@ struct alignas(16) SssScratch {
   int32_t events_this_step;
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
   int32_t pinned_job;             // job of the event being handled: its cache slot is not given away
+  int32_t sel_job, sel_stage;     // the stage an action names (select_stage_wave -> take_action)
   // the idle executors of pool `idle_key`, found with one ballot right before a lane-0 section that asks for
   // them (publish_idle_mask); consumed by the next get_idle_source_executors, valid for nothing else
   uint32_t idle_key;
@@ -152,6 +153,12 @@ SSS_DEV void ctx_init() { prof3_clear(); }
   do {                                       \
     if (!(cond)) FAIL(SSS_ERR_INVARIANT);     \
   } while (0)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__clang__)
+#define SSS_UNROLL4 _Pragma("unroll 4")
+#else
+#define SSS_UNROLL4
 #endif
 
 #ifdef SSS_BATCH_STATS  // emulator-only census of why rounds end (tests/emu, never in the product build)
@@ -2058,8 +2065,9 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
   const double dmin = (double)(xd.dmin_l < xd.dmin_r ? xd.dmin_l : xd.dmin_r);
   const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
   const uint32_t tag = (info & ~0xFFu) | (open ? 0x80u : 0u);  // (job, slot, stage) | draws random()
-  int total = 0;
-  // ---- batch after batch, state in registers; only the stage counters are re-read (other lanes change them) ----
+  int total = 0, rounds = 0;
+  double wall = 0.0;
+  // ---- batch after batch, state in registers (nothing a batch reads from LDS is written by a batch) ----
   for (;;) {
     cand = fast_kind && st.remaining > 0;
     const double key = cand ? sl.t + dmin : sl.t;
@@ -2082,7 +2090,7 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
       STAT(11, (head & unc) != 0), STAT(12, (head & l1) != 0), STAT(13, (head & r0) != 0), STAT(14, (head & ~tfm) != 0);
     }
 #endif
-    if (vm == 0) return total;
+    if (vm == 0) break;
     const uint32_t nmax = (uint32_t)(64 - pos) >> 1;  // two raw outputs per event at most
     uint32_t rank = 0, R = 0, cb = 0, ct = 1;
     while (vm & (vm - 1)) {  // a batch of one needs no ranking
@@ -2107,8 +2115,13 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
       const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
       V = V && rank < rcut;
       vm = wave_ballot(V);
-      if (vm == 0) return total;
+      if (vm == 0) goto done;
       if (!(vm & (vm - 1))) rank = 0, R = 0, cb = 0, ct = 1;
+    }
+    if (!(vm & (vm - 1))) {
+      // a batch of one: the lanes whose events belong to the same stage see its task counter move too
+      const uint32_t gk = wave_readlane_u32(tag, ctz64(vm));
+      ct = ((gk ^ tag) >> 8) == 0 ? 1u : 0u;
     }
     const uint32_t n = (uint32_t)popc64(vm);
     STAT(18 + (n < 13 ? n : 13), 1);
@@ -2139,25 +2152,16 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
     const uint64_t mm = (uint64_t)u32 * len;
     if (wave_ballot(V && (uint32_t)mm < len) != 0) {  // Lemire's rejection test is needed: one at a time
       STAT(17, 1);
-      return total;
+      break;
     }
     // ---- commit: nothing of this batch was modified before this point ----
-    const uint64_t lastm = wave_ballot(V && rank == n - 1);  // the batch's last event: its lane leaves the header behind
+    const uint64_t lastm = wave_ballot(V && rank == n - 1);  // the batch's last event: what it leaves behind is where the next batch starts
+    const double t_ev = sl.t;
     const uint32_t consumed = P + (open ? 1u : 0u) + (fresh ? 1u : 0u);
     const uint32_t u32_after = fresh ? (uint32_t)(x32 >> 32) : u32;  // the half numpy keeps / the one just used up
     if (V) {
       const double dur = (double)f.durations[off + (int)(mm >> 32)];
       const uint32_t seq_new = counter0 + rank;
-      if (rank == n - 1) {
-        SssHdr& h = g_hot.h;
-        h.wall_time = sl.t;
-        h.counter = counter0 + n;
-        h.n_events += n, h.n_fast += n, h.n_batched += n, h.n_rounds++;
-        g_sc.events_this_step += (int32_t)n;
-        g_sc.rng_pos = pos + (int)consumed;
-        h.rng_has32 = fresh ? 1u : 0u;
-        h.rng_u32 = u32_after;
-      }
       sl.t = sl.t + dur, sl.seq = seq_new;
       g_hot.ev[lane].t = sl.t;
       g_hot.ev[lane].seq = seq_new;
@@ -2168,20 +2172,43 @@ SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EV
         f.cdur[slot * f.SP + s] = (float)dur;
         if (st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
         if ((int)st.remaining - ((int)st.moving_to + (int)st.commit_to) <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));
+        st.remaining = (int16_t)(st.remaining + (int)ct);  // (every lane of the stage takes the batch's tasks off its copy below)
       }
     }
-    total += (int)n;
-    // the header fields the next batch starts from, on every lane (from the last event's lane)
+    total += (int)n, rounds++;
+    // the header fields the next batch starts from, on every lane (from the last event's lane); the header
+    // itself is written once, when the batches are over
     const int ll = ctz64(lastm);
+    wall = wave_readlane_f64(t_ev, ll);
     counter0 += n;
     pos += (int)wave_readlane_u32(consumed, ll);
     h0 = wave_readlane_u32(fresh ? 1u : 0u, ll);
     u32_0 = wave_readlane_u32(u32_after, ll);
-    wave_sync();
     EVP_MARK(2);
-    if (64 - pos < rng_need) return total;  // the caller refills the generator's buffer
-    if (fast_kind) st = f.cstages[slot * f.SP + s];  // other events of the stage may have taken tasks
+    // the batch's members have taken `ct` tasks of this lane's stage (ct counts the members with this lane's
+    // stage whether or not the lane is one of them): the copy in the register follows without a round trip
+    // through LDS. Nothing else a batch reads is changed by a batch.
+    if (fast_kind) st.remaining = (int16_t)(st.remaining - (int)ct);
+#ifdef SSS_CHECK_TRACE
+    wave_sync();
+    if (fast_kind && f.cstages[slot * f.SP + s].remaining != st.remaining)
+      fprintf(stderr, "[batch] lane %d: register %d, LDS %d, ct %u cb %u V %d n %u\n", lane, (int)st.remaining, (int)f.cstages[slot * f.SP + s].remaining, ct, cb, (int)V, n);
+#endif
+    if (64 - pos < rng_need) break;  // the caller refills the generator's buffer
   }
+done:
+  if (total > 0 && lane == 0) {
+    SssHdr& h = g_hot.h;
+    h.wall_time = wall;  // the last event's time
+    h.counter = counter0;
+    h.n_events += (uint64_t)total, h.n_fast += (uint64_t)total, h.n_batched += (uint64_t)total, h.n_rounds += (uint64_t)rounds;
+    g_sc.events_this_step += (int32_t)total;
+    g_sc.rng_pos = pos;
+    h.rng_has32 = h0;
+    h.rng_u32 = u32_0;
+  }
+  wave_sync();  // the slots and counters the members wrote are visible to every lane from here
+  return total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2855,10 +2882,11 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
   int lane = wave_lane();
   uint64_t t_obs0 = wave_clock();
   const SssHdr& h = g_hot.h;
-  float* nodes = B.nodes + (size_t)env * L.n_cap * 3;
-  int32_t* el = B.edge_links + (size_t)env * L.ed_cap * 2;
-  int32_t* dag_ptr = B.dag_ptr + (size_t)env * (L.J_cap + 1);
-  int32_t* sup = B.exec_supplies + (size_t)env * L.J_cap;
+  // the output rows alias nothing that is read here: the loads of later iterations may pass earlier stores
+  float* __restrict__ nodes = B.nodes + (size_t)env * L.n_cap * 3;
+  int32_t* __restrict__ el = B.edge_links + (size_t)env * L.ed_cap * 2;
+  int32_t* __restrict__ dag_ptr = B.dag_ptr + (size_t)env * (L.J_cap + 1);
+  int32_t* __restrict__ sup = B.exec_supplies + (size_t)env * L.J_cap;
   int A = h.n_active;
   uint32_t srck = h.curr_source;
   int src_job = (srck == POOL_NONE || srck == POOL_COMMON) ? -1 : key_job(srck);
@@ -2896,13 +2924,17 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     int a = i / SPn, st = i - a * SPn;
     int j = lds_active()[a];
     const SssJob* job = jobp(j);
+    // the stage's counters and duration are fetched along with the job's record, not after it (their
+    // addresses do not depend on it; rows of inactive stages are read and dropped)
+    const int16_t remaining = stgp(j, st)->remaining;
+    const float recent = *durp(j, st);
     uint64_t act = job->active_mask;
     if (st < (int)job->n_stages && (act & bit64(st))) {
       int row = (int)nbase[a] + popc64(act & (bit64(st) - 1));
       // plain stores: non-temporal ones were measured to double the HBM write traffic (partial
       // lines are no longer combined in L2) for no gain in time
-      nodes[row * 3 + 0] = (float)stgp(j, st)->remaining;
-      nodes[row * 3 + 1] = *durp(j, st);
+      nodes[row * 3 + 0] = (float)remaining;
+      nodes[row * 3 + 1] = recent;
       nodes[row * 3 + 2] = (job->sched_mask & bit64(st)) ? 1.0f : 0.0f;
     }
   }
@@ -3071,6 +3103,37 @@ SSS_DEV void env_end(uint8_t* base) {
 // step pieces (lane 0)
 // ------------------------------------------------------------------------------------------
 
+// stage_selection_map[stage_idx] (ENV:284, 386-392): the k-th set bit over the per-job schedulable masks in active
+// order - all lanes, one job each (the records of jobs without a cache slot come from HBM: one round trip for
+// all of them instead of one per job on lane 0). Leaves (job, stage) or (-1, -1) in the mailbox.
+SSS_DEV void select_stage_wave(int stage_idx) {
+  const int lane = wave_lane();
+  const int A = g_hot.h.n_active;
+  int run = 0, fj = -1, fs = -1;
+  for (int a0 = 0; a0 < A && stage_idx >= 0; a0 += 64) {
+    const int a = a0 + lane;
+    uint64_t m = 0;
+    int jj = -1;
+    if (a < A) jj = lds_active()[a], m = jobp(jj)->sched_mask;
+    const uint32_t n = (uint32_t)popc64(m);
+    const int lo = run + (int)wave_scan_excl_u32(n);
+    run += (int)wave_sum_u32(n);
+    const bool mine = stage_idx >= lo && stage_idx < lo + (int)n;
+    const uint64_t hit = wave_ballot(mine);
+    if (hit) {
+      if (mine) {
+        for (int i = 0; i < stage_idx - lo; i++) m &= m - 1;
+        g_sc.sel_job = jj, g_sc.sel_stage = ctz64(m);
+      }
+      fj = 0;
+      break;
+    }
+  }
+  if (fj < 0 && lane == 0) g_sc.sel_job = -1, g_sc.sel_stage = -1;
+  (void)fs;
+  wave_sync();
+}
+
 // ENV:275-315. Returns false if the action was rejected (state untouched).
 SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
   PROF3(17);
@@ -3091,19 +3154,8 @@ SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
     H.err = SSS_ERR_TOO_MANY;
     return false;
   }
-  // stage_selection_map[stage_idx]: k-th set bit over the per-job masks in active order
-  int k = stage_idx, j = -1, s = -1;
-  for (int a = 0; a < H.n_active; a++) {
-    int jj = lds_active()[a];
-    uint64_t m = (*jobp(jj)).sched_mask;
-    int n = popc64(m);
-    if (k < n) {
-      for (int i = 0; i < k; i++) m &= m - 1;
-      j = jj, s = ctz64(m);
-      break;
-    }
-    k -= n;
-  }
+  // stage_selection_map[stage_idx]: found by the whole wave beforehand (select_stage_wave)
+  const int j = g_sc.sel_job, s = g_sc.sel_stage;
   CHECK(j >= 0);
   if (j < 0) return false;
   SssStage st = (*stgp(j, s));
@@ -3507,6 +3559,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   int lane = wave_lane();
   uint64_t t0 = wave_clock();
   publish_idle_mask();  // for fulfil_build_list, should the round end with this action (nothing below moves an executor before it)
+  select_stage_wave(stage_idx);
   if (lane == 0) {
     g_sc.f_round_continues = 1, g_sc.f_fulfil = 0;
     g_sc.events_this_step = 0;
