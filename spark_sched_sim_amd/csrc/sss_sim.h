@@ -2324,7 +2324,7 @@ SSS_DEV bool any_schedulable_without_source() {
   }
   return wave_ballot(any) != 0;
 }
-SSS_DEV int batch_released_events(const FastCtx& f) {
+SSS_DEV int batch_released_events(const FastCtx& f, int head) {
 #ifdef SSS_NO_BATCH
   return 0;
 #endif
@@ -2352,7 +2352,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if ((pre & (pre - 1)) == 0) return 0;  // none, or a single one: the one-event path is as fast
+    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) return 0;  // none, a single one (the one-event path is as fast), or not the head
   }
   // the commitment its pool would serve first (TRK:178-183: the first-inserted one of that source)
   const uint32_t sp = key_stage_pool(j, s);
@@ -2368,6 +2368,8 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   // the job being saturated, to the common pool, and the source is cleared (ENV:331-341, 745-782)
   const bool freed = cand && c_idx < 0;
   cand = cand && (freed || dst != sp);
+  // the head of the queue has to be a member: whenever it turns out not to be one, the round is over
+  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;
   const int j2 = key_job(dst), s2 = key_stage(dst);
   int type = RL_START;
   SssStage st_new = {0, 0, 0, 0};
@@ -2400,6 +2402,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
       }
     }
   }
+  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;
   if (wave_ballot(cand && freed) != 0) {
     // executors idling in a stage's pool would move along with a freed one (ENV:714-728): there are none between events
     const bool idle_in_stage = lane < f.E && !g_hot.ex_executing[lane] && g_hot.ex_loc[lane] != POOL_NONE && g_hot.ex_loc[lane] != POOL_COMMON &&
@@ -2413,6 +2416,7 @@ SSS_DEV int batch_released_events(const FastCtx& f) {
   // the pool the member enters
   const uint32_t enters = start ? dst : (type == RL_SEND ? POOL_NONE : ((type == RL_IDLE_COMMON || type == RL_FREE_COMMON) ? POOL_COMMON : key_job_pool(j)));
   cand = cand && (freed || source == POOL_NONE || enters != source);
+  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;
   // when the event a member pushes can come at the earliest
   const double push_lb = start ? (double)(da.z < db.z ? da.z : db.z) : (type == RL_SEND ? g_c.P.moving_delay : __builtin_inf());
   const double key = cand ? sl.t + push_lb : sl.t;
@@ -2660,7 +2664,7 @@ SSS_DEV bool pool_pass_many(uint32_t jkey, uint32_t n) {
   return true;
 }
 
-SSS_DEV int batch_arrival_events(const FastCtx& f) {
+SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
 #ifdef SSS_NO_BATCH
   return 0;
 #endif
@@ -2681,7 +2685,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if ((pre & (pre - 1)) == 0) return 0;  // none, or a single one: the one-event path is as fast
+    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) return 0;  // none, a single one (the one-event path is as fast), or not the head
   }
   SssStage st = {0, 0, 0, 0};
   const SssJob* jpc = f.cjobs + (cand ? slot : 0);
@@ -2697,6 +2701,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f) {
     if (type == AR_START) push_lb = (double)f.eff[(((size_t)gs * 8 + 0) * 3 + 0) * 4 + 3];
   }
   const bool start = type == AR_START;
+  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;  // the head of the queue has to be a member
   const double key = cand ? sl.t + push_lb : sl.t;
   double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
   if (next_arr < M) M = next_arr;
@@ -3362,9 +3367,9 @@ SSS_DEV void resume_simulation() {
           if (f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0)
             handled = batch_fast_events(f, rng_need, true EVP_PASS);
           else if (64 - g_sc.rng_pos >= rng_need)
-            handled = batch_released_events(f);
+            handled = batch_released_events(f, ex);
         } else if (64 - g_sc.rng_pos >= rng_need) {
-          handled = batch_arrival_events(f);
+          handled = batch_arrival_events(f, ex);
         }
         EVP_MARK(0);  // a round the batch path left early is charged to its first segment
         if (handled > 0) continue;
