@@ -3,8 +3,9 @@ pre-generated PCG64 stream they draw from (rng_refill), under the CPU wave emula
 
 * whole episodes in long launches (the job cache is only rebuilt at launch boundaries, so slots are
   handed from job to job inside a launch) against the C oracle, env by env, bit for bit;
-* the same kernel source compiled with every event going one at a time (-DSSS_NO_BATCH) must leave
-  byte-identical env state after every launch;
+* the same kernel source compiled with every event going one at a time (-DSSS_NO_BATCH: no batches of any
+  kind - task completions with tasks left, released executors, arriving executors - and no lane-parallel
+  fulfilment chunks) must leave byte-identical env state after every launch;
 * the batch path is really taken (device counters);
 * the jump-ahead table against numpy's own PCG64.advance().
 """
@@ -21,6 +22,9 @@ from spark_sched_sim_amd import VecSparkSchedSimEnv
 C2 = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
 E64 = dict(num_executors=64, job_arrival_cap=30, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
 E20 = dict(num_executors=20, job_arrival_cap=40, job_arrival_rate=2.0e-4, moving_delay=500.0, warmup_delay=100.0)
+# BASELINE config 3's executor count (fewer jobs): whole fulfilments of 20-50 executors, pools whose tables outgrow
+# their records, jobs whose last stage drains with nothing left to schedule
+E50 = dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
 
 
 def oracle_summary(pack, cfg, policy_id, seed):
@@ -41,6 +45,8 @@ def oracle_summary(pack, cfg, policy_id, seed):
     (C2, "fair", 0, [3, 4], 500),
     (E64, "hash", 1, [0, 1], 150),
     (E20, "fair", 0, [11], 300),
+    (E50, "fair", 0, [0, 7], 250),
+    (E50, "hash", 1, [2], 333),
 ])
 def test_long_launches_match_oracle(cfg, policy, policy_id, seeds, chunk, pack):
     env = VecSparkSchedSimEnv(cfg, len(seeds), device="cpu", pack=pack, _lib=load_emu())
@@ -60,7 +66,8 @@ def test_long_launches_match_oracle(cfg, policy, policy_id, seeds, chunk, pack):
     env.close()
 
 
-@pytest.mark.parametrize("cfg,policy,seeds,chunk,n_launches", [(C2, "hash", [5, 31133], 37, 12), (E64, "fair", [2], 61, 8)])
+@pytest.mark.parametrize("cfg,policy,seeds,chunk,n_launches", [(C2, "hash", [5, 31133], 37, 12), (E64, "fair", [2], 61, 8), (E50, "fair", [0, 1], 41, 12),
+                                                                (E50, "hash", [3], 29, 10), (E20, "hash", [1, 2], 23, 20)])
 def test_batches_equal_one_event_at_a_time(cfg, policy, seeds, chunk, n_launches, pack):
     """the batch path is an optimisation of the one-at-a-time path, nothing else: same env bytes"""
     envs = [VecSparkSchedSimEnv(cfg, len(seeds), device="cpu", pack=pack, _lib=load_emu(v)) for v in ("", "_nobatch")]
@@ -76,7 +83,10 @@ def test_batches_equal_one_event_at_a_time(cfg, policy, seeds, chunk, n_launches
         assert np.array_equal(a, b), f"launch {it}: env state differs"
         for name in ("nodes", "edge_links", "dag_ptr", "exec_supplies", "obs_i32", "obs_f64"):
             assert np.array_equal(getattr(envs[0], name).numpy(), getattr(envs[1], name).numpy()), (it, name)
-    assert envs[0].counters()["n_batched_events"] > 0 and envs[1].counters()["n_batched_events"] == 0
+    c = envs[0].counters()
+    assert c["n_batched_events"] > 0 and envs[1].counters()["n_batched_events"] == 0
+    if cfg is E50:  # batches of released / arriving executors count as batched but not as "stage has more tasks" events
+        assert c["n_batched_events"] > c["n_fast_events"]
     for e in envs:
         e.close()
 
