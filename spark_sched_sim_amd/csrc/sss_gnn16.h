@@ -1,0 +1,269 @@
+// sss_gnn16.h - the GNN's MLPs with SIXTEEN LANES PER ROW (gfx950 only; the emulator keeps sss_gnn.h's
+// one-thread-per-row formulation, which is also what the one-launch policy kernel uses).
+//
+// Why: one thread pushing a row through Linear-act-Linear-act-Linear is a serial chain of 1 400 - 7 700
+// dependent FMAs fed by LDS broadcasts - ~40 us per launch whether 20 k or 80 k rows are in flight
+// (profiles/r02_decima.md); the nine DAG layers of a Decima step are nine such chains back to back. Here a row is
+// a 16-lane DPP row: lane g owns output neurons g, g + 16, ... of every layer, an input vector lives one element
+// per lane and reaches the other lanes through `v_mov_b32_dpp row_newbcast:k` - no LDS exchange, no barrier -,
+// and the weights sit in LDS transposed so that the 16 lanes of a row read consecutive words (no bank conflicts)
+// while the four rows of a wave read the same words (broadcast).
+//
+// Same arithmetic as sss_gnn.h (fp32 FMAs; sums of hidden vectors are pushed through the last Linear once); only
+// the order of the additions inside a dot product differs - within the 2e-5 agreement the fixtures are held to.
+#pragma once
+#include <utility>
+
+// value of lane K of this lane's 16-lane row
+template <int K>
+SSS_DEV float row_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xF, 0xF, false));
+}
+template <typename F, int... K>
+SSS_DEV void static_for_impl(F&& f, std::integer_sequence<int, K...>) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int N, typename F>
+SSS_DEV void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+// sum over the 16 lanes of a row, on every lane of it
+SSS_DEV float row_sum(float v) {
+  float t = 0.0f;
+  static_for<16>([&](auto kc) { t += row_bcast<decltype(kc)::value>(v); });
+  return t;
+}
+
+template <int ACT>
+SSS_DEV float act16(float v, float slope) {
+  if (ACT == 0) return v > 0.0f ? v : v * slope;
+  return tanhf(v);
+}
+
+// LDS image of one MLP IN -> H1 -> H2 -> OUT (OUT = 16 with H2 = 16, or OUT = 1) for 16 lanes per row;
+// Q1 = H1 / 16, Q2 = H2 / 16 neurons per lane. From the packed parameters [W1 (H1 x IN), b1, W2T (H1 x H2), b2,
+// W3 (OUT x H2), b3] of sss_gnn.h:
+//   w1[i][g][q]      = W1[g + 16 q][i]                      input i, lane g, q < Q1
+//   b1[g][q]
+//   w2[jj][q][g][r]  = W2T[jj + 16 q][g + 16 r]             hidden-1 neuron jj + 16 q (lane jj, register q), r < Q2
+//   b2[g][r]
+//   OUT = 16: w3[k][g] = W3[g][k], b3[g]    OUT = 1: w3[g][r] = W3[0][g + 16 r], b3[0]
+template <int IN, int H1, int H2, int OUT, int ACT>
+struct Mlp16 {
+  static constexpr int Q1 = H1 / 16, Q2 = H2 / 16;
+  static constexpr int W1 = 0, B1 = W1 + IN * H1, W2 = B1 + H1, B2 = W2 + H1 * H2, W3 = B2 + H2, B3 = W3 + OUT * H2, TOTAL = ((B3 + OUT + 3) / 4) * 4;
+  static_assert(H1 % 16 == 0 && H2 % 16 == 0 && (OUT == 1 || (OUT == 16 && H2 == 16)), "layer widths");
+
+  SSS_DEV static void stage(float* lds, const float* __restrict__ w, int tid, int nthreads) {
+    const float* gW1 = w;
+    const float* gb1 = gW1 + H1 * IN;
+    const float* gW2T = gb1 + H1;
+    const float* gb2 = gW2T + H1 * H2;
+    const float* gW3 = gb2 + H2;
+    const float* gb3 = gW3 + OUT * H2;
+    for (int t = tid; t < IN * H1; t += nthreads) {
+      const int q = t % Q1, g = (t / Q1) % 16, i = t / (Q1 * 16);
+      lds[W1 + t] = gW1[(g + 16 * q) * IN + i];
+    }
+    for (int t = tid; t < H1; t += nthreads) lds[B1 + t] = gb1[(t / Q1) + 16 * (t % Q1)];
+    for (int t = tid; t < H1 * H2; t += nthreads) {
+      const int r = t % Q2, g = (t / Q2) % 16, q = (t / (Q2 * 16)) % Q1, jj = t / (Q2 * 16 * Q1);
+      lds[W2 + t] = gW2T[(jj + 16 * q) * H2 + g + 16 * r];
+    }
+    for (int t = tid; t < H2; t += nthreads) lds[B2 + t] = gb2[(t / Q2) + 16 * (t % Q2)];
+    if (OUT == 16) {
+      for (int t = tid; t < 256; t += nthreads) lds[W3 + t] = gW3[(t & 15) * 16 + (t >> 4)];
+      for (int t = tid; t < 16; t += nthreads) lds[B3 + t] = gb3[t];
+    } else {
+      for (int t = tid; t < H2; t += nthreads) lds[W3 + t] = gW3[(t / Q2) + 16 * (t % Q2)];
+      if (tid == 0) lds[B3] = gb3[0];
+    }
+  }
+
+  // first Linear, one input segment: inputs BASE .. BASE + LEN - 1 are elements 0 .. LEN - 1 of the row vector whose
+  // element g this lane holds in `seg`
+  template <int BASE, int LEN>
+  SSS_DEV static void l1(const float* m, float (&a)[Q1], float seg, int g) {
+    _Pragma("clang fp contract(fast)")
+    static_for<LEN>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const float xk = row_bcast<k>(seg);
+      const float* wp = m + W1 + ((BASE + k) * 16 + g) * Q1;
+      static_for<Q1>([&](auto qc) { a[decltype(qc)::value] += wp[decltype(qc)::value] * xk; });
+    });
+  }
+  SSS_DEV static void l1_bias(const float* m, float (&a)[Q1], int g) {
+    static_for<Q1>([&](auto qc) { a[decltype(qc)::value] = m[B1 + g * Q1 + decltype(qc)::value]; });
+  }
+  // activation of hidden 1, second Linear, activation: hidden-2 neurons g + 16 r of the row
+  SSS_DEV static void l2(const float* m, float (&a)[Q1], float (&h)[Q2], int g, float slope) {
+    _Pragma("clang fp contract(fast)")
+    static_for<Q1>([&](auto qc) { a[decltype(qc)::value] = act16<ACT>(a[decltype(qc)::value], slope); });
+    static_for<Q2>([&](auto rc) { h[decltype(rc)::value] = m[B2 + g * Q2 + decltype(rc)::value]; });
+    static_for<16>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      static_for<Q1>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const float tk = row_bcast<k>(a[q]);
+        const float* wp = m + W2 + ((k * Q1 + q) * 16 + g) * Q2;
+        static_for<Q2>([&](auto rc) { h[decltype(rc)::value] += wp[decltype(rc)::value] * tk; });
+      });
+    });
+    static_for<Q2>([&](auto rc) { h[decltype(rc)::value] = act16<ACT>(h[decltype(rc)::value], slope); });
+  }
+  // last Linear(16,16) applied to (a sum of `count`) hidden-2 vector(s): element g of W3 . v + count * b3
+  SSS_DEV static float out16(const float* m, float v, int g, float count) {
+    _Pragma("clang fp contract(fast)")
+    float o0 = m[B3 + g] * count, o1 = 0.0f;
+    static_for<8>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      o0 += m[W3 + (2 * k) * 16 + g] * row_bcast<2 * k>(v);
+      o1 += m[W3 + (2 * k + 1) * 16 + g] * row_bcast<2 * k + 1>(v);
+    });
+    return o0 + o1;
+  }
+  // last Linear(H2,1): the row's score, on every lane of the row
+  SSS_DEV static float out1(const float* m, const float (&h)[Q2], int g) {
+    _Pragma("clang fp contract(fast)")
+    float p = 0.0f;
+    static_for<Q2>([&](auto rc) { p += m[W3 + g * Q2 + decltype(rc)::value] * h[decltype(rc)::value]; });
+    return row_sum(p) + m[B3];
+  }
+};
+
+using MlpGnn = Mlp16<16, 32, 16, 16, 0>;    // message / update / SINK / GLOBSUM-side MLPs: 16 -> 32 -> 16 -> 16
+using MlpPrep = Mlp16<GNN_NF, 32, 16, 16, 0>;
+using MlpDag = Mlp16<GNN_NF + 16, 32, 16, 16, 0>;
+using MlpStage = Mlp16<GNN_NF + 48, 64, 64, 1, 1>;
+using MlpExec = Mlp16<GNN_DF + 33, 64, 64, 1, 1>;
+
+template <typename M>
+SSS_DEV float hidden16_of(const float* m, float x, int g, float slope) {  // 16 inputs, one per lane -> hidden-2 neuron g
+  float a[M::Q1], h[M::Q2];
+  M::l1_bias(m, a, g);
+  M::template l1<0, 16>(m, a, x, g);
+  M::l2(m, a, h, g, slope);
+  return h[0];
+}
+
+// rows of a launch: 16 per workgroup of 256 threads at a time, looping; parameters staged once per workgroup
+#define GNN16_ROWS(r) for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < a.n_rows; r += (int64_t)gridDim.x * 16)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
+  constexpr int F = GNN_EMB;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];
+  const int g = threadIdx.x & 15;
+  if (KIND == GNN_LAYER) {
+    // tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
+    MlpGnn::stage(w_lds, a.w, threadIdx.x, 256);
+    MlpGnn::stage(w_lds + MlpGnn::TOTAL, a.w2, threadIdx.x, 256);
+    __syncthreads();
+    const float* msg = w_lds;
+    const float* upd = w_lds + MlpGnn::TOTAL;
+    GNN16_ROWS(r) {
+      const int64_t n = a.idx0[r];
+      if (n < 0) continue;  // (whole rows: the 16 lanes of a row always agree)
+      const int64_t e0 = a.out_start[n];
+      const int deg = a.out_deg[n];
+      float acc = 0.0f;
+      int used = 0;
+      for (int k = 0; k < deg; k++) {
+        if (!((a.edge_layers[e0 + k] >> a.layer) & 1u)) continue;
+        acc += hidden16_of<MlpGnn>(msg, a.h[a.dst[e0 + k] * F + g], g, a.slope);
+        used++;
+      }
+      const float agg = MlpGnn::out16(msg, acc, g, (float)used);
+      const float h2 = hidden16_of<MlpGnn>(upd, agg, g, a.slope);
+      a.tmp[n * F + g] = a.h_init[n * F + g] + MlpGnn::out16(upd, h2, g, 1.0f);
+    }
+  } else if (KIND == GNN_PREP) {
+    MlpPrep::stage(w_lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    GNN16_ROWS(r) {
+      float aa[MlpPrep::Q1], hh[MlpPrep::Q2];
+      MlpPrep::l1_bias(w_lds, aa, g);
+      MlpPrep::template l1<0, GNN_NF>(w_lds, aa, g < GNN_NF ? a.x[r * GNN_NF + g] : 0.0f, g);
+      MlpPrep::l2(w_lds, aa, hh, g, a.slope);
+      a.out[r * F + g] = MlpPrep::out16(w_lds, hh[0], g, 1.0f);
+    }
+  } else if (KIND == GNN_SINK) {
+    MlpGnn::stage(w_lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    GNN16_ROWS(r) {
+      const float x = a.h_init[r * F + g];
+      const bool par = a.out_deg[r] != 0;
+      const bool skip = a.obs_depth != nullptr && a.obs_depth[a.node_obs[r]] == 0;  // single-layer observation: mlp_prep only
+      if (skip || par) {
+        a.h[r * F + g] = skip ? x : 0.0f;
+        continue;
+      }
+      a.h[r * F + g] = MlpGnn::out16(w_lds, hidden16_of<MlpGnn>(w_lds, x, g, a.slope), g, 1.0f);
+    }
+  } else if (KIND == GNN_DAGHID) {
+    MlpDag::stage(w_lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    GNN16_ROWS(r) {
+      float aa[MlpDag::Q1], hh[MlpDag::Q2];
+      MlpDag::l1_bias(w_lds, aa, g);
+      MlpDag::template l1<0, GNN_NF>(w_lds, aa, g < GNN_NF ? a.x[r * GNN_NF + g] : 0.0f, g);
+      MlpDag::template l1<GNN_NF, 16>(w_lds, aa, a.h[r * F + g], g);
+      MlpDag::l2(w_lds, aa, hh, g, a.slope);
+      a.tmp[r * 16 + g] = hh[0];
+    }
+  } else if (KIND == GNN_GLOBHID) {
+    MlpGnn::stage(w_lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    GNN16_ROWS(r) { a.tmp[r * 16 + g] = hidden16_of<MlpGnn>(w_lds, a.h_dag[r * F + g], g, a.slope); }
+  } else if (KIND == GNN_STAGE) {
+    MlpStage::stage(w_lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    GNN16_ROWS(r) {
+      const int64_t n = a.idx0[r];
+      if (n < 0) continue;
+      float aa[MlpStage::Q1], hh[MlpStage::Q2];
+      MlpStage::l1_bias(w_lds, aa, g);
+      MlpStage::template l1<0, GNN_NF>(w_lds, aa, g < GNN_NF ? a.x[n * GNN_NF + g] : 0.0f, g);
+      MlpStage::template l1<GNN_NF, 16>(w_lds, aa, a.h[n * F + g], g);
+      MlpStage::template l1<GNN_NF + 16, 16>(w_lds, aa, a.h_dag[a.node_job[n] * F + g], g);
+      MlpStage::template l1<GNN_NF + 32, 16>(w_lds, aa, a.h_glob[a.node_obs[n] * F + g], g);
+      MlpStage::l2(w_lds, aa, hh, g, 0.0f);
+      const float v = MlpStage::out1(w_lds, hh, g);
+      if (g == 0) a.out[a.node_obs[n] * a.n_pad + a.node_loc[n]] = v;
+    }
+  } else if (KIND == GNN_EXEC) {
+    MlpExec::stage(w_lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    GNN16_ROWS(r) {
+      const int64_t b = r / a.E;
+      const int c = (int)(r - b * a.E);
+      const int64_t j = a.idx0[b];
+      float aa[MlpExec::Q1], hh[MlpExec::Q2];
+      MlpExec::l1_bias(w_lds, aa, g);
+      MlpExec::template l1<0, GNN_DF>(w_lds, aa, g < GNN_DF ? a.x[a.job_first[j] * GNN_NF + g] : 0.0f, g);
+      MlpExec::template l1<GNN_DF, 16>(w_lds, aa, a.h_dag[j * F + g], g);
+      MlpExec::template l1<GNN_DF + 16, 16>(w_lds, aa, a.h_glob[a.job_obs[j] * F + g], g);
+      MlpExec::template l1<GNN_DF + 32, 1>(w_lds, aa, (float)c / (float)a.E, g);
+      MlpExec::l2(w_lds, aa, hh, g, 0.0f);
+      const float v = MlpExec::out1(w_lds, hh, g);
+      if (g == 0) a.out[r] = c < a.job_cap[j] ? v : -__builtin_inff();
+    }
+  }
+}
+
+template <int KIND>
+constexpr int gnn16_lds_floats() {
+  return KIND == GNN_LAYER ? 2 * MlpGnn::TOTAL : KIND == GNN_PREP ? MlpPrep::TOTAL : KIND == GNN_DAGHID ? MlpDag::TOTAL
+       : KIND == GNN_STAGE ? MlpStage::TOTAL : KIND == GNN_EXEC ? MlpExec::TOTAL : MlpGnn::TOTAL;
+}
+template <int KIND>
+static int gnn16_launch(const SssGnnArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  // a workgroup stages its MLP(s) once (up to 31 KB for the policy heads) and then loops over row tiles: enough
+  // workgroups to fill the 256 CUs a few times over, not one per tile
+  const int64_t tiles = (a.n_rows + 15) / 16;
+  const int64_t cap = KIND == GNN_LAYER ? 2048 : 768;
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+  hipLaunchKernelGGL(sss_gnn16_kernel<KIND>, dim3(grid), dim3(256), gnn16_lds_floats<KIND>() * sizeof(float), (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

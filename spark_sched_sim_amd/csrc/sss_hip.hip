@@ -110,6 +110,8 @@ static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleAr
   return (int)hipGetLastError();
 }
 
+#include "sss_gnn16.h"
+
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
   constexpr int NW = gnn_weight_count<KIND>();
@@ -129,16 +131,22 @@ static int gnn_launch_kind(const SssGnnArgs& a, void* stream) {
 }
 static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
   switch (kind) {
+    // a DAG layer's receiving nodes: few rows per launch and the longest chain (message MLP per edge + update MLP),
+    // nine launches back to back per step: 16 lanes per row (sss_gnn16.h; 41 -> 25 us per launch at 4096 envs)
+    case GNN_LAYER: return gnn16_launch<GNN_LAYER>(a, stream);
+    // one thread per row (sss_gnn.h). Node rows (a million per launch) are throughput-bound, and 64 rows share
+    // every weight read; the two policy heads (45 k rows) measured slower with 16 lanes per row (81 / 72 us
+    // against 52 / 42 us: 31 KB of parameters to stage per workgroup, 128 tanh per row either way)
+    case GNN_STAGE: return gnn_launch_kind<GNN_STAGE>(a, stream);
+    case GNN_EXEC: return gnn_launch_kind<GNN_EXEC>(a, stream);
     case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
-    case GNN_LAYER: return gnn_launch_kind<GNN_LAYER>(a, stream);
+    case GNN_DAGHID: return gnn_launch_kind<GNN_DAGHID>(a, stream);
+    case GNN_GLOBHID: return gnn_launch_kind<GNN_GLOBHID>(a, stream);
+    // copies and range sums: one thread per row (sss_gnn.h)
     case GNN_COMMIT: return gnn_launch_kind<GNN_COMMIT>(a, stream);
     case GNN_DAGSUM: return gnn_launch_kind<GNN_DAGSUM>(a, stream);
     case GNN_GLOBSUM: return gnn_launch_kind<GNN_GLOBSUM>(a, stream);
-    case GNN_STAGE: return gnn_launch_kind<GNN_STAGE>(a, stream);
-    case GNN_EXEC: return gnn_launch_kind<GNN_EXEC>(a, stream);
-    case GNN_DAGHID: return gnn_launch_kind<GNN_DAGHID>(a, stream);
-    case GNN_GLOBHID: return gnn_launch_kind<GNN_GLOBHID>(a, stream);
   }
   return -1;
 }
