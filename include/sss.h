@@ -218,6 +218,11 @@ typedef struct sss_gnn_args {
   const int64_t* job_nodes_dev;
   const int64_t* obs_job_off_dev;
   const int64_t* obs_jobs_dev;
+  /* LAYER, optional: the message / update MLPs once more, laid out for the 16-lanes-per-row kernel (csrc/sss_gnn16.h:
+   * w1[i][g][q] = W1[g+16q][i], b1[g][q], w2[jj][q][g][r] = W2T[jj+16q][g+16r], b2[g][r], w3[k][g] = W3[g][k], b3[g]).
+   * NULL: the kernel transposes w_dev / w2_dev while staging them (slower: strided reads in every workgroup). */
+  const float* w16_dev;
+  const float* w2_16_dev;
 } sss_gnn_args;
 int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
 

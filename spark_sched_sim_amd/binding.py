@@ -75,7 +75,8 @@ class SssGnnArgs(C.Structure):
                 ("out_deg_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("idx0_dev", C.c_void_p), ("dst_dev", C.c_void_p),
                 ("out_start_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
                 ("node_loc_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_first_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
-                ("job_nodes_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("obs_jobs_dev", C.c_void_p)]
+                ("job_nodes_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("obs_jobs_dev", C.c_void_p),
+                ("w16_dev", C.c_void_p), ("w2_16_dev", C.c_void_p)]
 
 
 GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7, "daghid": 8, "globhid": 9}

@@ -53,6 +53,7 @@ struct SssGnnArgs {
   int64_t n_rows;
   const float* w;       // packed parameters of the MLP this launch evaluates
   const float* w2;      // LAYER: the update MLP (w = the message MLP)
+  const float *w16, *w2_16;  // LAYER, nullable: the two MLPs in the 16-lanes-per-row image (sss_gnn16.h)
   float slope;          // LeakyReLU negative slope (GNN MLPs)
   int E;                // EXEC: number of executors
   int layer;            // LAYER

@@ -156,8 +156,16 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
   const int g = threadIdx.x & 15;
   if (KIND == GNN_LAYER) {
     // tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
-    MlpGnn::stage(w_lds, a.w, threadIdx.x, 256);
-    MlpGnn::stage(w_lds + MlpGnn::TOTAL, a.w2, threadIdx.x, 256);
+    if (a.w16 && a.w2_16) {  // the host has the images ready: a straight copy, 16 bytes per thread and pass
+      static_assert(MlpGnn::TOTAL % 4 == 0, "images are copied 16 bytes at a time");
+      for (int t = threadIdx.x; t < MlpGnn::TOTAL / 4; t += 256) {
+        ((float4*)w_lds)[t] = ((const float4*)a.w16)[t];
+        ((float4*)(w_lds + MlpGnn::TOTAL))[t] = ((const float4*)a.w2_16)[t];
+      }
+    } else {
+      MlpGnn::stage(w_lds, a.w, threadIdx.x, 256);
+      MlpGnn::stage(w_lds + MlpGnn::TOTAL, a.w2, threadIdx.x, 256);
+    }
     __syncthreads();
     const float* msg = w_lds;
     const float* upd = w_lds + MlpGnn::TOTAL;
@@ -216,11 +224,15 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
     __syncthreads();
     GNN16_ROWS(r) { a.tmp[r * 16 + g] = hidden16_of<MlpGnn>(w_lds, a.h_dag[r * F + g], g, a.slope); }
   } else if (KIND == GNN_STAGE) {
-    MlpStage::stage(w_lds, a.w, threadIdx.x, 256);
+    if (a.w16) {
+      static_assert(MlpStage::TOTAL % 4 == 0, "images are copied 16 bytes at a time");
+      for (int t = threadIdx.x; t < MlpStage::TOTAL / 4; t += 256) ((float4*)w_lds)[t] = ((const float4*)a.w16)[t];
+    } else
+      MlpStage::stage(w_lds, a.w, threadIdx.x, 256);
     __syncthreads();
     GNN16_ROWS(r) {
       const int64_t n = a.idx0[r];
-      if (n < 0) continue;
+      if (n < 0) break;  // the list is the schedulable nodes followed by padding: nothing but padding from here on
       float aa[MlpStage::Q1], hh[MlpStage::Q2];
       MlpStage::l1_bias(w_lds, aa, g);
       MlpStage::template l1<0, GNN_NF>(w_lds, aa, g < GNN_NF ? a.x[n * GNN_NF + g] : 0.0f, g);
@@ -232,7 +244,11 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
       if (g == 0) a.out[a.node_obs[n] * a.n_pad + a.node_loc[n]] = v;
     }
   } else if (KIND == GNN_EXEC) {
-    MlpExec::stage(w_lds, a.w, threadIdx.x, 256);
+    if (a.w16) {
+      static_assert(MlpExec::TOTAL % 4 == 0, "images are copied 16 bytes at a time");
+      for (int t = threadIdx.x; t < MlpExec::TOTAL / 4; t += 256) ((float4*)w_lds)[t] = ((const float4*)a.w16)[t];
+    } else
+      MlpExec::stage(w_lds, a.w, threadIdx.x, 256);
     __syncthreads();
     GNN16_ROWS(r) {
       const int64_t b = r / a.E;

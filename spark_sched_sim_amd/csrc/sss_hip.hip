@@ -134,11 +134,13 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
     // a DAG layer's receiving nodes: few rows per launch and the longest chain (message MLP per edge + update MLP),
     // nine launches back to back per step: 16 lanes per row (sss_gnn16.h; 41 -> 25 us per launch at 4096 envs)
     case GNN_LAYER: return gnn16_launch<GNN_LAYER>(a, stream);
-    // one thread per row (sss_gnn.h). Node rows (a million per launch) are throughput-bound, and 64 rows share
-    // every weight read; the two policy heads (45 k rows) measured slower with 16 lanes per row (81 / 72 us
-    // against 52 / 42 us: 31 KB of parameters to stage per workgroup, 128 tanh per row either way)
-    case GNN_STAGE: return gnn_launch_kind<GNN_STAGE>(a, stream);
-    case GNN_EXEC: return gnn_launch_kind<GNN_EXEC>(a, stream);
+    // The two policy heads (53-64-64-1 / 36-64-64-1, 128 tanh per row): with few rows the chain of one row is the
+    // bound and 16 lanes per row win (1024 envs: 45 -> 22 us / 41 -> 29 us); with many rows the launch is
+    // throughput-bound and one thread per row, where 64 rows share every weight read, wins (4096 envs: 52 / 42 us
+    // against 59 / 69 us). STAGE's n_rows counts all nodes (its list is padded; ~1 in 22 is schedulable).
+    case GNN_STAGE: return (a.w16 && a.n_rows <= 22 * 24000) ? gnn16_launch<GNN_STAGE>(a, stream) : gnn_launch_kind<GNN_STAGE>(a, stream);
+    case GNN_EXEC: return (a.w16 && a.n_rows <= 24000) ? gnn16_launch<GNN_EXEC>(a, stream) : gnn_launch_kind<GNN_EXEC>(a, stream);
+    // node rows (a million per launch at 4096 envs): throughput-bound, one thread per row (sss_gnn.h)
     case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
     case GNN_DAGHID: return gnn_launch_kind<GNN_DAGHID>(a, stream);

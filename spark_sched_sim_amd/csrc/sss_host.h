@@ -446,6 +446,7 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   a.edge_layers = g->edge_layers_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.node_loc = g->node_loc_dev;
   a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
   a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
+  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev;
   if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
   return 0;

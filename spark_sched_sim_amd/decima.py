@@ -387,8 +387,24 @@ class DecimaPolicy(nn.Module):
                 lin = [m for m in mlp if isinstance(m, nn.Linear)]
                 parts = [lin[0].weight, lin[0].bias, lin[1].weight.t(), lin[1].bias, lin[2].weight, lin[2].bias]
                 return torch.cat([t.detach().float().contiguous().reshape(-1) for t in parts]).contiguous()
+            def pack16(mlp):  # the same MLP (IN -> H1 -> 16 -> 16) as the 16-lanes-per-row image of csrc/sss_gnn16.h
+                lin = [m for m in mlp if isinstance(m, nn.Linear)]
+                W1, b1, W2, b2, W3, b3 = (t.detach().float() for t in (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias))
+                h1, n_in = W1.shape
+                h2 = W2.shape[0]
+                q1, q2 = h1 // 16, h2 // 16
+                parts = [W1.reshape(q1, 16, n_in).permute(2, 1, 0),            # w1[i][g][q] = W1[g + 16 q][i]
+                         b1.reshape(q1, 16).t(),                                 # b1[g][q]
+                         W2.reshape(q2, 16, q1, 16).permute(3, 2, 1, 0),       # w2[jj][q][g][r] = W2[g + 16 r][jj + 16 q]
+                         b2.reshape(q2, 16).t(),                                 # b2[g][r]
+                         W3.t() if W3.shape[0] == 16 else W3.reshape(q2, 16).t(),   # w3[k][g] = W3[g][k]  /  one output: w3[g][r] = W3[0][g + 16 r]
+                         b3]
+                flat = torch.cat([t.contiguous().reshape(-1) for t in parts])
+                return torch.nn.functional.pad(flat, (0, (-flat.numel()) % 4)).contiguous()
             enc = self.encoder
-            w = {"prep": pack(enc.node_encoder.mlp_prep), "msg": pack(enc.node_encoder.mlp_msg), "update": pack(enc.node_encoder.mlp_update),
+            w = {"msg16": pack16(enc.node_encoder.mlp_msg), "update16": pack16(enc.node_encoder.mlp_update),
+                 "stage16": pack16(self.stage_policy_network.mlp_score), "exec16": pack16(self.exec_policy_network.mlp_score),
+                 "prep": pack(enc.node_encoder.mlp_prep), "msg": pack(enc.node_encoder.mlp_msg), "update": pack(enc.node_encoder.mlp_update),
                  "dag": pack(enc.dag_encoder.mlp), "glob": pack(enc.global_encoder.mlp),
                  "stage": pack(self.stage_policy_network.mlp_score), "exec": pack(self.exec_policy_network.mlp_score)}
             slope = float(enc.node_encoder.mlp_prep[1].negative_slope)
@@ -450,7 +466,7 @@ class DecimaPolicy(nn.Module):
         tmp = torch.empty((max(M, J), 16), dtype=torch.float32, device=dev)
         for lvl in range(len(lists) - 1, -1, -1):
             recv = lists[lvl]
-            self._launch("layer", recv.numel(), w["msg"], layer=lvl, w2=w["update"], h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
+            self._launch("layer", recv.numel(), w["msg"], layer=lvl, w2=w["update"], w16=w.get("msg16"), w2_16=w.get("update16"), h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
                          out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"])
             self._launch("commit", recv.numel(), w["msg"], h=h, tmp=tmp, idx0=recv)
         h_dag = torch.empty((J, 16), dtype=torch.float32, device=dev)
@@ -466,7 +482,7 @@ class DecimaPolicy(nn.Module):
         """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
         M = g["x"].shape[0]
         out = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
-        self._launch("stage", M, self._packed[1]["stage"], n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"],
+        self._launch("stage", M, self._packed[1]["stage"], w16=self._packed[1].get("stage16"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"],
                      out=out, idx0=self._index_list(g["stage_mask"]), node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
         return out
 
@@ -495,7 +511,7 @@ class DecimaPolicy(nn.Module):
                                 out["exec_sel"].data_ptr(), out["lgprob"].data_ptr(), out["any_stage"].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
-        self._launch("exec", B * E, self._packed[1]["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
+        self._launch("exec", B * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
                      idx0=job_gid, job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
         self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
         out["env_stage_idx"], out["env_num_exec"] = stage_idx, num_exec
@@ -508,7 +524,7 @@ class DecimaPolicy(nn.Module):
     def _exec_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
         k, E = job_gid.numel(), self.num_executors
         out = torch.empty((k, E), dtype=torch.float32, device=job_gid.device)
-        self._launch("exec", k * E, self._packed[1]["exec"], x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=out,
+        self._launch("exec", k * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=out,
                      idx0=job_gid.contiguous(), job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
         return out
 
