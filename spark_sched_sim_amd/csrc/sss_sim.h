@@ -3067,6 +3067,19 @@ SSS_DEV void env_begin(const uint8_t* base) {
   wave_sync();
 }
 
+// What the on-device policies need of an env (read only: nothing is written back): the header, the ordered
+// active-job list and "no job is cached" - job records then come straight from HBM, one lane each.
+SSS_DEV void env_begin_readonly(const uint8_t* base) {
+  int lane = wave_lane();
+  const SssHot* g = (const SssHot*)base;
+  if (lane < (int)(sizeof(SssHdr) / 16)) ((uint4*)&g_hot.h)[lane] = ((const uint4*)&g->h)[lane];
+  for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
+  wave_sync();
+  int A = g_hot.h.n_active;
+  for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
+  wave_sync();
+}
+
 SSS_DEV void env_end(uint8_t* base) {
   PROF3(24);
   int lane = wave_lane();
@@ -3804,7 +3817,7 @@ SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   ctx_init();
-  env_begin(base);
+  env_begin_readonly(base);
   int si, ne;
   run_policy(policy, param, si, ne);
   if (wave_lane() == 0) stage_idx[env] = si, num_exec[env] = ne;
