@@ -223,6 +223,12 @@ typedef struct sss_gnn_args {
    * NULL: the kernel transposes w_dev / w2_dev while staging them (slower: strided reads in every workgroup). */
   const float* w16_dev;
   const float* w2_16_dev;
+  /* LAYER, optional / MERGE (kind 10): i32 per node, bit l set = the node receives in DAG layer l (sss_decima_graph_build's
+   * node_recv). With it a LAYER launch needs no COMMIT: each node's embedding alternates between h_dev and tmp_dev
+   * (after v updates it is in buffer v & 1; layers run from the highest index down), a layer reads every child's
+   * current buffer and writes the receiver's other one. MERGE (rows = nodes), once after the last layer: h = tmp
+   * where the number of updates is odd. */
+  const int32_t* node_recv_dev;
 } sss_gnn_args;
 int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
 

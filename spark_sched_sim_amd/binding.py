@@ -76,10 +76,10 @@ class SssGnnArgs(C.Structure):
                 ("out_start_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
                 ("node_loc_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_first_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_nodes_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("obs_jobs_dev", C.c_void_p),
-                ("w16_dev", C.c_void_p), ("w2_16_dev", C.c_void_p)]
+                ("w16_dev", C.c_void_p), ("w2_16_dev", C.c_void_p), ("node_recv_dev", C.c_void_p)]
 
 
-GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7, "daghid": 8, "globhid": 9}
+GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7, "daghid": 8, "globhid": 9, "merge": 10}
 
 ERROR_NAMES = {
     1: "invalid action: does not belong to the action space",

@@ -11,6 +11,11 @@
 //   LAYER   tmp[r]    = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
 //                       for the layer's receiving nodes r                       (scheduler.py:214-232)
 //   COMMIT  h[r]      = tmp[r]   (a layer reads the previous h everywhere before any node moves)
+//   With `node_recv` given (bit l of node_recv[n]: n receives in layer l) LAYER needs no COMMIT: every node keeps
+//   its embedding alternately in `h` and `tmp` - after v updates in buffer v & 1 -, a layer reads each child's
+//   current buffer and writes the receiver's OTHER one, so nothing a layer reads is written by it. Layers run from
+//   the highest index down (scheduler.py:209-211), so v = popcount of the bits above the layer's.
+//   MERGE   h[n]      = tmp[n] where n was updated an odd number of times (once, after the last layer)
 //   DAGHID  tmp[n]    = hidden part of dag([x[n], h[n]])
 //   DAGSUM  h_dag[j]  = sum over the job's nodes n of dag([x[n], h[n]])        (scheduler.py:256-262)
 //   GLOBHID tmp[j]    = hidden part of glob(h_dag[j])
@@ -46,7 +51,7 @@
 #define GNN_FP_CONTRACT
 #endif
 
-enum { GNN_PREP = 0, GNN_SINK, GNN_LAYER, GNN_COMMIT, GNN_DAGSUM, GNN_GLOBSUM, GNN_STAGE, GNN_EXEC, GNN_DAGHID, GNN_GLOBHID, GNN_KINDS };
+enum { GNN_PREP = 0, GNN_SINK, GNN_LAYER, GNN_COMMIT, GNN_DAGSUM, GNN_GLOBSUM, GNN_STAGE, GNN_EXEC, GNN_DAGHID, GNN_GLOBHID, GNN_MERGE, GNN_KINDS };
 enum { GNN_EMB = 16, GNN_NF = 5, GNN_DF = 3 };
 
 struct SssGnnArgs {
@@ -54,6 +59,7 @@ struct SssGnnArgs {
   const float* w;       // packed parameters of the MLP this launch evaluates
   const float* w2;      // LAYER: the update MLP (w = the message MLP)
   const float *w16, *w2_16;  // LAYER, nullable: the two MLPs in the 16-lanes-per-row image (sss_gnn16.h)
+  const int32_t* node_recv;  // LAYER (nullable: then COMMIT launches follow) / MERGE: per node, the layers it receives in
   float slope;          // LeakyReLU negative slope (GNN MLPs)
   int E;                // EXEC: number of executors
   int layer;            // LAYER
@@ -141,7 +147,7 @@ constexpr int gnn_weight_count() {
        : (KIND == GNN_DAGSUM || KIND == GNN_DAGHID) ? gnn_mlp_params(GNN_NF + 16, 32, 16, 16)
        : KIND == GNN_STAGE ? gnn_mlp_params(GNN_NF + 48, 64, 64, 1)
        : KIND == GNN_EXEC ? gnn_mlp_params(GNN_DF + 33, 64, 64, 1)
-       : KIND == GNN_COMMIT ? 0 : GNN_W_GNN16;
+       : (KIND == GNN_COMMIT || KIND == GNN_MERGE) ? 0 : GNN_W_GNN16;
 }
 
 // `w` / `w2`: where this thread reads the parameters from (the gfx950 build stages them in LDS and
@@ -172,9 +178,12 @@ SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r, const float* w, const float
     GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     int64_t e0 = a.out_start[n];
     int deg = a.out_deg[n], used = 0;
+    const uint32_t above = a.layer >= 31 ? 0u : ~((2u << a.layer) - 1u);  // the layers that ran before this one
     for (int k = 0; k < deg; k++) {
       if (!((a.edge_layers[e0 + k] >> a.layer) & 1u)) continue;
-      gnn_load<F>(a.h + a.dst[e0 + k] * F, x);
+      const int64_t c = a.dst[e0 + k];
+      const float* cur = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[c] & above) & 1)) ? a.tmp : a.h;
+      gnn_load<F>(cur + c * F, x);
       gnn_hidden<F, 32, 16, 0>(w, x, h2, a.slope);
       GNN_UNROLL for (int i = 0; i < 16; i++) acc[i] += h2[i];
       used++;
@@ -195,11 +204,16 @@ SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r, const float* w, const float
       }
     }
     gnn_hidden<F, 32, 16, 0>(w2, agg, h2, a.slope);
-    gnn_out<F, 32, 16, F>(w2, h2, 1.0f, [&](int o, float v) { a.tmp[n * F + o] = a.h_init[n * F + o] + v; });
+    float* nxt = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[n] & above) & 1)) ? a.h : a.tmp;  // the buffer its current value is NOT in
+    gnn_out<F, 32, 16, F>(w2, h2, 1.0f, [&](int o, float v) { nxt[n * F + o] = a.h_init[n * F + o] + v; });
   } else if (KIND == GNN_COMMIT) {
     int64_t n = a.idx0[r];
     if (n < 0) return;
     GNN_UNROLL for (int i = 0; i < F; i++) a.h[n * F + i] = a.tmp[n * F + i];
+  } else if (KIND == GNN_MERGE) {
+    if (__builtin_popcount((uint32_t)a.node_recv[r]) & 1) {
+      GNN_UNROLL for (int i = 0; i < F; i++) a.h[r * F + i] = a.tmp[r * F + i];
+    }
   } else if (KIND == GNN_DAGHID) {
     float x[GNN_NF + F], h2[16];
     gnn_load<GNN_NF>(a.x + r * GNN_NF, x);

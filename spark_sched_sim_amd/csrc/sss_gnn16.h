@@ -176,14 +176,19 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
       const int deg = a.out_deg[n];
       float acc = 0.0f;
       int used = 0;
+      // with node_recv: embeddings alternate between `h` and `tmp` per update (sss_gnn.h), no COMMIT launch
+      const uint32_t above = a.layer >= 31 ? 0u : ~((2u << a.layer) - 1u);
+      float* nxt = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[n] & above) & 1)) ? a.h : a.tmp;
       for (int k = 0; k < deg; k++) {
         if (!((a.edge_layers[e0 + k] >> a.layer) & 1u)) continue;
-        acc += hidden16_of<MlpGnn>(msg, a.h[a.dst[e0 + k] * F + g], g, a.slope);
+        const int64_t c = a.dst[e0 + k];
+        const float* cur = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[c] & above) & 1)) ? a.tmp : a.h;
+        acc += hidden16_of<MlpGnn>(msg, cur[c * F + g], g, a.slope);
         used++;
       }
       const float agg = MlpGnn::out16(msg, acc, g, (float)used);
       const float h2 = hidden16_of<MlpGnn>(upd, agg, g, a.slope);
-      a.tmp[n * F + g] = a.h_init[n * F + g] + MlpGnn::out16(upd, h2, g, 1.0f);
+      nxt[n * F + g] = a.h_init[n * F + g] + MlpGnn::out16(upd, h2, g, 1.0f);
     }
   } else if (KIND == GNN_PREP) {
     MlpPrep::stage(w_lds, a.w, threadIdx.x, 256);

@@ -147,6 +147,7 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
     case GNN_GLOBHID: return gnn_launch_kind<GNN_GLOBHID>(a, stream);
     // copies and range sums: one thread per row (sss_gnn.h)
     case GNN_COMMIT: return gnn_launch_kind<GNN_COMMIT>(a, stream);
+    case GNN_MERGE: return gnn_launch_kind<GNN_MERGE>(a, stream);
     case GNN_DAGSUM: return gnn_launch_kind<GNN_DAGSUM>(a, stream);
     case GNN_GLOBSUM: return gnn_launch_kind<GNN_GLOBSUM>(a, stream);
   }

@@ -438,7 +438,7 @@ extern "C" int sss_decima_sample(int n_obs, int which, const sss_decima_sample_a
 extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   if (!g) return sss_fail(-1, "NULL argument");
   if (kind < 0 || kind >= GNN_KINDS) return sss_fail(-26, "unknown GNN stage");
-  if (g->n_rows < 0 || !g->w_dev) return sss_fail(-1, "NULL argument");
+  if (g->n_rows < 0 || (!g->w_dev && kind != GNN_COMMIT && kind != GNN_MERGE)) return sss_fail(-1, "NULL argument");
   SssGnnArgs a;
   a.n_rows = g->n_rows, a.w = g->w_dev, a.w2 = g->w2_dev, a.slope = g->slope, a.E = g->num_executors, a.layer = g->layer, a.n_pad = g->n_pad;
   a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev, a.tmp = g->tmp_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev, a.out = g->out_dev;
@@ -446,7 +446,8 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   a.edge_layers = g->edge_layers_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.node_loc = g->node_loc_dev;
   a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
   a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
-  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev;
+  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev;
+  if (kind == GNN_MERGE && !g->node_recv_dev) return sss_fail(-1, "NULL argument");
   if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
   return 0;

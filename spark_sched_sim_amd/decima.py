@@ -464,11 +464,14 @@ class DecimaPolicy(nn.Module):
         from .vec_env import VecSparkSchedSimEnv
         lists = VecSparkSchedSimEnv.decima_layer_lists(g)  # the only device->host sync of the pass
         tmp = torch.empty((max(M, J), 16), dtype=torch.float32, device=dev)
+        # embeddings alternate between `h` and `tmp` per update (include/sss.h node_recv_dev): no COMMIT launch per
+        # layer, one MERGE after the last one
         for lvl in range(len(lists) - 1, -1, -1):
             recv = lists[lvl]
             self._launch("layer", recv.numel(), w["msg"], layer=lvl, w2=w["update"], w16=w.get("msg16"), w2_16=w.get("update16"), h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
-                         out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"])
-            self._launch("commit", recv.numel(), w["msg"], h=h, tmp=tmp, idx0=recv)
+                         out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"], node_recv=g["node_recv"])
+        if len(lists):
+            self._launch("merge", M, w["msg"], h=h, tmp=tmp, node_recv=g["node_recv"])
         h_dag = torch.empty((J, 16), dtype=torch.float32, device=dev)
         self._launch("daghid", M, w["dag"], x=x, h=h, tmp=tmp)
         self._launch("dagsum", J, w["dag"], tmp=tmp, h_dag=h_dag, job_first=g["job_first"], job_nodes=g["job_nodes"])

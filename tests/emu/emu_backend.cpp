@@ -87,6 +87,7 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
     case GNN_SINK: return gnn_run_kind<GNN_SINK>(a);
     case GNN_LAYER: return gnn_run_kind<GNN_LAYER>(a);
     case GNN_COMMIT: return gnn_run_kind<GNN_COMMIT>(a);
+    case GNN_MERGE: return gnn_run_kind<GNN_MERGE>(a);
     case GNN_DAGSUM: return gnn_run_kind<GNN_DAGSUM>(a);
     case GNN_GLOBSUM: return gnn_run_kind<GNN_GLOBSUM>(a);
     case GNN_STAGE: return gnn_run_kind<GNN_STAGE>(a);
