@@ -227,7 +227,7 @@ typedef struct sss_gnn_args {
    * node_recv). With it a LAYER launch needs no COMMIT: each node's embedding alternates between h_dev and tmp_dev
    * (after v updates it is in buffer v & 1; layers run from the highest index down), a layer reads every child's
    * current buffer and writes the receiver's other one. MERGE (rows = nodes), once after the last layer: h = tmp
-   * where the number of updates is odd. */
+   * where the number of updates is odd; DAGHID (kind 8) does that on the fly when it is given node_recv_dev. */
   const int32_t* node_recv_dev;
 } sss_gnn_args;
 int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);

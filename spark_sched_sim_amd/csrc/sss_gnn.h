@@ -15,7 +15,8 @@
 //   its embedding alternately in `h` and `tmp` - after v updates in buffer v & 1 -, a layer reads each child's
 //   current buffer and writes the receiver's OTHER one, so nothing a layer reads is written by it. Layers run from
 //   the highest index down (scheduler.py:209-211), so v = popcount of the bits above the layer's.
-//   MERGE   h[n]      = tmp[n] where n was updated an odd number of times (once, after the last layer)
+//   MERGE   h[n]      = tmp[n] where n was updated an odd number of times (once, after the last layer; DAGHID does
+//                       the same on the fly when it is given node_recv, which saves the launch)
 //   DAGHID  tmp[n]    = hidden part of dag([x[n], h[n]])
 //   DAGSUM  h_dag[j]  = sum over the job's nodes n of dag([x[n], h[n]])        (scheduler.py:256-262)
 //   GLOBHID tmp[j]    = hidden part of glob(h_dag[j])
@@ -217,7 +218,13 @@ SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r, const float* w, const float
   } else if (KIND == GNN_DAGHID) {
     float x[GNN_NF + F], h2[16];
     gnn_load<GNN_NF>(a.x + r * GNN_NF, x);
-    gnn_load<F>(a.h + r * F, x + GNN_NF);
+    if (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[r]) & 1)) {
+      // the MERGE of a node whose embedding ended up in `tmp` (odd number of updates), done here where the row
+      // is read anyway: this thread owns row r of both buffers, and tmp[r] is overwritten only further down
+      gnn_load<F>(a.tmp + r * F, x + GNN_NF);
+      GNN_UNROLL for (int i = 0; i < F; i++) a.h[r * F + i] = x[GNN_NF + i];
+    } else
+      gnn_load<F>(a.h + r * F, x + GNN_NF);
     gnn_hidden<GNN_NF + F, 32, 16, 0>(w, x, h2, a.slope);
     GNN_UNROLL for (int i = 0; i < 16; i++) a.tmp[r * 16 + i] = h2[i];
   } else if (KIND == GNN_DAGSUM) {

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
       float aa[MlpDag::Q1], hh[MlpDag::Q2];
       MlpDag::l1_bias(w_lds, aa, g);
       MlpDag::template l1<0, GNN_NF>(w_lds, aa, g < GNN_NF ? a.x[r * GNN_NF + g] : 0.0f, g);
-      MlpDag::template l1<GNN_NF, 16>(w_lds, aa, a.h[r * F + g], g);
+      float hv = a.h[r * F + g];
+      if (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[r]) & 1)) hv = a.tmp[r * F + g], a.h[r * F + g] = hv;  // MERGE on the fly (sss_gnn.h)
+      MlpDag::template l1<GNN_NF, 16>(w_lds, aa, hv, g);
       MlpDag::l2(w_lds, aa, hh, g, a.slope);
       a.tmp[r * 16 + g] = hh[0];
     }

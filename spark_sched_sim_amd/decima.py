@@ -470,10 +470,9 @@ class DecimaPolicy(nn.Module):
             recv = lists[lvl]
             self._launch("layer", recv.numel(), w["msg"], layer=lvl, w2=w["update"], w16=w.get("msg16"), w2_16=w.get("update16"), h_init=h_init, h=h, tmp=tmp, idx0=recv, dst=g["dst"],
                          out_start=g["out_start"], out_deg=g["out_deg"], edge_layers=g["edge_layers"], node_recv=g["node_recv"])
-        if len(lists):
-            self._launch("merge", M, w["msg"], h=h, tmp=tmp, node_recv=g["node_recv"])
         h_dag = torch.empty((J, 16), dtype=torch.float32, device=dev)
-        self._launch("daghid", M, w["dag"], x=x, h=h, tmp=tmp)
+        # (DAGHID brings the embeddings that ended up in `tmp` home to `h` on the fly: the MERGE of include/sss.h)
+        self._launch("daghid", M, w["dag"], x=x, h=h, tmp=tmp, node_recv=g["node_recv"] if len(lists) else None)
         self._launch("dagsum", J, w["dag"], tmp=tmp, h_dag=h_dag, job_first=g["job_first"], job_nodes=g["job_nodes"])
         h_glob = torch.empty((B, 16), dtype=torch.float32, device=dev)
         self._launch("globhid", J, w["glob"], h_dag=h_dag, tmp=tmp)

@@ -16,6 +16,6 @@ for n in (4096, 1024):
     calls = sum(int(r["Calls"]) for r in rows)
     d = json.load(open(f"gpurun_out/dtrace/e{n}_plain.json"))
     print(n, "envs: kernel time per step %.3f ms, launches per step %.1f, wall per step (unprofiled) %.3f ms, %.2f M env-steps/s" % (tot / 120 / 1e6, calls / 120, d["ms_per_step"], d["value"] / 1e6))
-    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:14]:
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:26]:
         print("   %-46s calls/step %5.1f  avg %7.1f us  per step %7.1f us" % (r["Name"][:46], int(r["Calls"]) / 120, float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 120 / 1e3))
 PY
