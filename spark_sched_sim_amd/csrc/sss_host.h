@@ -323,6 +323,7 @@ extern "C" int sss_bind_buffers(sss_handle* h, const sss_buffers* b) {
   if (((uintptr_t)b->state_dev) & 255) return sss_fail(-21, "state_dev must be 256-byte aligned");
   h->B.state = b->state_dev, h->B.nodes = b->nodes_dev, h->B.edge_links = b->edge_links_dev, h->B.dag_ptr = b->dag_ptr_dev;
   h->B.exec_supplies = b->exec_supplies_dev, h->B.obs_i32 = b->obs_i32_dev, h->B.obs_f64 = b->obs_f64_dev;
+  h->B.gen = h->bound ? h->B.gen + 1 : 1, h->B.gen_pad = 0;
   h->bound = true;
   return 0;
 }

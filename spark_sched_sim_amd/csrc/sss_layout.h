@@ -48,7 +48,7 @@ enum { EV_NONE = 0, EV_TASK_FINISHED = 2, EV_EXECUTOR_READY = 3 };
 #define POOL_NONE 0xFFFFFFFFu
 #define POOL_COMMON 0u
 
-struct SssHdr {            // 288 bytes
+struct SssHdr {            // 304 bytes
   uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
   uint32_t rng_has32, rng_u32;
   double wall_time;
@@ -86,6 +86,14 @@ struct SssHdr {            // 288 bytes
   uint64_t n_batched;      // ... of which handled by the lane-parallel batch path
   uint64_t n_rounds;       // batch rounds that committed at least one event
   uint64_t pad_[2];
+  // The active subgraph (which jobs, in which order, with which stages) changes only when a job arrives or
+  // completes or a stage completes; the observation's edge rows are a function of it alone. graph_version counts
+  // those changes, obs_* say what the edge rows in the caller's buffer were written from: an unchanged graph's
+  // rows are not written again (write_observation).
+  uint32_t graph_version;
+  uint32_t obs_graph_version;  // 0: nothing written yet
+  int32_t obs_n_edges;
+  uint32_t obs_bind_gen;       // SssBuffers::gen of the buffer they were written to
 };
 
 // one pending event per executor at most: 16 bytes, read with a single LDS access.
@@ -183,6 +191,7 @@ struct SssBuffers {        // raw device pointers of torch-allocated tensors
   int32_t* exec_supplies;  // i32[B][J_cap]
   int32_t* obs_i32;        // i32[B][SSS_OBS_I32]
   double* obs_f64;         // f64[B][SSS_OBS_F64]
+  uint32_t gen, gen_pad;   // bumped by every sss_bind_buffers: rows written to other buffers do not count as written
 };
 
 // the first argument of every simulator kernel (sss_sim.h reads it back from the kernel-argument segment)
@@ -264,7 +273,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->state_bytes = L->env_stride * num_envs;
 }
 
-static_assert(sizeof(SssHdr) == 288, "SssHdr must be 288 bytes");
+static_assert(sizeof(SssHdr) == 304, "SssHdr must be 304 bytes");
 static_assert(sizeof(SssHot) % 16 == 0, "SssHot is copied with 16-byte accesses");
 static_assert(sizeof(SssJob) == 64, "SssJob must be one 64-byte line");
 static_assert(sizeof(SssStage) == 8 && sizeof(SssPoolHdr) == 16, "packed records");

@@ -1012,6 +1012,7 @@ SSS_DEV bool job_record_stage_completion(int j, int s) {
     if ((parents & ~completed) == 0) newm |= bit64(ch);
   }
   job.frontier_mask = frontier | newm;
+  H.graph_version++;  // a node left the active subgraph
   return newm != 0;
 }
 
@@ -1757,6 +1758,7 @@ SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created emp
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
   g_sc.active_version++;
+  H.graph_version++;
   if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
 
@@ -1786,6 +1788,7 @@ SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
   H.n_completed++;
   g_sc.pending_free = j;  // its cache slot is written back once the handler has returned
   g_sc.active_version++;
+  H.graph_version++;
   g_c.t_completed[j] = H.wall_time;
   double dur = H.wall_time - g_c.t_arrival[j];
   if (H.dur_n < SSS_DUR_RING) {
@@ -2943,10 +2946,13 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
       nodes[row * 3 + 2] = (job->sched_mask & bit64(st)) ? 1.0f : 0.0f;
     }
   }
-  // pass 3 - lanes over (job, template edge): active subgraph, compacted in (job, edge) order
+  // pass 3 - lanes over (job, template edge): active subgraph, compacted in (job, edge) order. The rows are a
+  // function of the active jobs, their order and their active-stage masks alone: when none of that has changed
+  // since they were last written to this buffer, they are there already.
+  const bool same_graph = h.obs_graph_version == h.graph_version && h.obs_bind_gen == B.gen;
   int ME = g_c.P.max_edges;
-  int base_e = 0;
-  for (int i0 = 0; i0 < A * ME; i0 += 64) {
+  int base_e = same_graph ? h.obs_n_edges : 0;
+  for (int i0 = 0; i0 < (same_graph ? 0 : A * ME); i0 += 64) {
     int i = i0 + lane;
     bool keep = false;
     int eu = 0, ev = 0;
@@ -2987,6 +2993,7 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     g_hot.h.prof[4] += wave_clock() - t_obs0;
 #endif
     g_hot.h.obs_n_nodes = base_n;
+    g_hot.h.obs_graph_version = h.graph_version, g_hot.h.obs_n_edges = base_e, g_hot.h.obs_bind_gen = B.gen;
     g_hot.h.obs_n_sched = h.n_sched;
     g_hot.h.last_reward = reward;
     // SURVEY 8(d) algorithmic bytes of this step: k*140 + 12N + (12N + 4(A+1) + 4A + 8Ed + 12) + 26
@@ -3457,6 +3464,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
     H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
     H.seed = seed, H.time_limit = time_limit;
+    H.graph_version = 1;  // (obs_graph_version = 0: the first observation writes its edge rows)
     H.curr_source = POOL_COMMON;
     g_sc.events_this_step = 0;
     g_sc.reset_more = 0;
