@@ -3306,6 +3306,26 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
     // everything else goes through the out-of-line handlers
     if (fast < 0) FAIL(SSS_ERR_NO_DURATION);
     uint64_t ts0 = wave_clock();
+#ifdef SSS_TAILSTAT  // debug builds (tools/debug/tailstat.sh): which events still go one at a time and why, 16-bit counters in pad_[0..1]
+    {
+      int kind = 0;  // job arrival
+      if (ex != POP_ARRIVAL && fast >= 0) {
+        const SssEvSlot sl0 = g_hot.ev[ex];
+        const int jj = info_job(sl0.info), ss = info_stage(sl0.info);
+        const SssStage st0 = *stgp(jj, ss);
+        if (info_kind(sl0.info) == EV_EXECUTOR_READY) {
+          kind = 1;
+          // why not in a batch: no slot named / stage out of tasks / source conflict / other (single, cut, lists, randomness)
+          const bool in_front = (jobp(jj)->frontier_mask & bit64(ss)) != 0;
+          const uint32_t ent = in_front ? key_stage_pool(jj, ss) : key_job_pool(jj);
+          const int why = info_slot(sl0.info) == INFO_SLOT_NONE ? 0 : (st0.remaining == 0 ? 1 : ((H.curr_source != POOL_NONE && H.curr_source == ent) ? 2 : 3));
+          H.pad_[1] += 1ull << (16 * why);
+        } else
+          kind = st0.remaining > 0 ? 3 : (st0.executing <= 1 ? 2 : 3);  // 2: completes its stage; 3: other task completions
+      }
+      H.pad_[0] += 1ull << (16 * kind);
+    }
+#endif
     if (fast < 0) {
     } else if (ex == POP_ARRIVAL) {
       int job = H.next_arrival;
