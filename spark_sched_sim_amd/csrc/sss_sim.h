@@ -2623,6 +2623,25 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       lane_atomic_and_u64(&jp->sat_mask, ~bit64(s2));
   }
   wave_sync();
+  if (wave_ballot(V && type == RL_SEND) != 0) {
+    // A job with a pending event holds a cache slot if there is one to have (push_event): the jobs executors were
+    // sent to get theirs now, so that the arrivals find their job in LDS (and can be batched in their turn). Last
+    // thing in the batch: handing a slot on may write another job's records back, and nothing above may point
+    // into a slot any more by then.
+    if (lane == 0) {
+      for (uint32_t r = 0; r < n; r++) {
+        if (g_sc.fi_type[r] != RL_SEND) continue;
+        const int e = g_sc.fi_e[r];
+        const uint32_t inf = g_hot.ev[e].info;
+        if (info_slot(inf) != INFO_SLOT_NONE) continue;
+        const int k = cache_acquire(info_job(inf));
+        if (k == SLOT_NONE) continue;
+        g_hot.ev[e].info = info_with_slot(inf, (uint32_t)k);
+        lds_slot_ref()[k]++;
+      }
+    }
+    wave_sync();
+  }
   return (int)n;
 }
 
@@ -3031,30 +3050,43 @@ SSS_DEV void env_begin(const uint8_t* base) {
   wave_sync();
   int A = g_hot.h.n_active;
   for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
-  if (lane == 0) {
-    // the jobs of the pending events get the cache slots (first come, first served); the events learn
-    // the slot their job got for this launch
-    int nK = 0;
+  {
+    // The jobs of the pending events get the cache slots - the jobs with the most pending events first (ties: lowest
+    // executor), so that a burst of executors travelling to one job, or many executors working on one job, never
+    // finds its job without a slot because single events of other jobs were met first. One lane per executor:
+    // same[job] counts and the "first executor of its job" flag come from a readlane sweep over the executors, the
+    // rank of a job among the jobs from a second sweep. The events learn the slot their job got for this launch.
+    const uint32_t info = g_hot.ev[lane].info;  // lanes beyond the executors hold EV_NONE
+    const bool has = info_kind(info) != EV_NONE;
+    const int j = has ? info_job(info) : -1 - lane;
+    uint32_t cnt = 0;
+    bool first = has;
     for (int e = 0; e < g_c.E; e++) {
-      uint32_t info = g_hot.ev[e].info;
-      if (info_kind(info) == EV_NONE) continue;
-      int j = info_job(info);
-      int k = lds_slot_of()[j];
-      if (k == SLOT_NONE && nK < g_c.P.n_slots) {
-        k = nK++;
-        lds_slot_of()[j] = (uint8_t)k;
-        lds_slot_job()[k] = (uint16_t)j;
-      }
-      if (k != SLOT_NONE) lds_slot_ref()[k]++;
-      g_hot.ev[e].info = info_with_slot(info, (uint32_t)k);
+      const int je = (int)wave_readlane_u32((uint32_t)j, e);
+      cnt += je == j ? 1u : 0u;
+      first = first && !(je == j && e < lane);
     }
-    uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    uint64_t used = nK >= 64 ? ~0ull : (bit64(nK) - 1);
-    g_sc.free_slots = all & ~used;
-    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
-    g_sc.events_this_step = 0;
-    g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
-    g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
+    const uint32_t key = first ? ((cnt << 8) | (uint32_t)(63 - lane)) : 0u;  // more events first, then the lower executor
+    uint32_t rank = 0;
+    for (int e = 0; e < g_c.E; e++) rank += wave_readlane_u32(key, e) > key ? 1u : 0u;
+    const int nK = (int)popc64(wave_ballot(first));
+    const int n_used = nK < g_c.P.n_slots ? nK : g_c.P.n_slots;
+    if (first && (int)rank < g_c.P.n_slots) {
+      lds_slot_of()[j] = (uint8_t)rank;
+      lds_slot_job()[rank] = (uint16_t)j;
+      lds_slot_ref()[rank] = (uint8_t)cnt;
+    }
+    wave_sync();
+    if (has) g_hot.ev[lane].info = info_with_slot(info, (uint32_t)lds_slot_of()[j]);
+    if (lane == 0) {
+      uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
+      uint64_t used = n_used >= 64 ? ~0ull : (bit64(n_used) - 1);
+      g_sc.free_slots = all & ~used;
+      g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
+      g_sc.events_this_step = 0;
+      g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
+      g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
+    }
   }
   wave_sync();
   // cached records: per slot 8 x u64 of job record, SP x u64 of stage counters, SP/2 x u64 of durations
