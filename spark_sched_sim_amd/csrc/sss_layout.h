@@ -237,9 +237,14 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   int per_slot = (int)sizeof(SssJob) + 8 * SP + 4 * SP;
   int budget = SSS_LDS_BUDGET - static_bytes;
   int n = (budget - o) / per_slot;
-  if (n < 8) {  // large job capacities: give up the 16-workgroups/CU target instead of the cache
-    n = 24;
-  }
+  // Large job capacities (BASELINE config 3: 200 jobs -> 4.2 KB of lists and maps): the 16-workgroups/CU target
+  // is given up rather than the cache - but not by much. Measured at C3 on MI355X (tools/debug/slots_sweep.sh,
+  // env-steps/s step / fused): 6 slots 8.3 / 24.8 M, 8: 9.1 / 23.6, 10: 9.5 / 24.0, 14: 9.4 / 23.4, 16: 9.4 / 23.2,
+  // 24: 9.0 / 21.3, 32: 8.8 / 20.3, 48: 8.4 / 18.8 - occupancy is worth more than cache coverage beyond ~10 jobs.
+#ifndef SSS_FALLBACK_SLOTS
+#define SSS_FALLBACK_SLOTS 10
+#endif
+  if (n < 8) n = SSS_FALLBACK_SLOTS;
   if (n > 64) n = 64;
   if (n > J_cap) n = J_cap;
   P->n_slots = n, P->jobset_slots = jobset;
