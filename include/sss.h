@@ -173,6 +173,16 @@ typedef struct sss_decima_lists {
 } sss_decima_lists;
 int sss_decima_layer_lists(int num_envs, const sss_decima_lists* a, void* stream);
 
+/* Exclusive prefix sums and totals of n_rows rows of n_cols non-negative counts, one launch (the offsets the two
+ * kernels above are fed: per-env node / edge / job offsets of the compact graph, per-env offsets into each DAG
+ * layer's receiver list; what utils.collate_obsns does with torch.cumsum on the host, decima/utils.py:117-204).
+ * src_dev[row * src_row_stride + col * src_col_stride] (i32; strides in elements, so that columns of the env's
+ * obs_i32 rows can be scanned in place), mask_dev (u8[n_cols], nullable): masked-out columns count as 0.
+ * off_dev: i64[n_rows][n_cols] exclusive prefix along the columns, cnt_dev (nullable): i64[n_rows][n_cols] the
+ * (masked) counts themselves, totals_dev: i64[n_rows]. */
+int sss_prefix_rows(const int32_t* src_dev, int64_t src_row_stride, int64_t src_col_stride, const uint8_t* mask_dev, int n_rows, int n_cols,
+                    int64_t* off_dev, int64_t* cnt_dev, int64_t* totals_dev, void* stream);
+
 /* Decima's GNN forward pass for inference (schedulers/decima/scheduler.py:142-385) on a compact graph
  * written by sss_decima_graph_build: one launch per stage of the pass, each evaluating one whole MLP
  * per row with its gather / scatter fused in. Supports the published architecture

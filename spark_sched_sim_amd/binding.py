@@ -94,7 +94,7 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -121,6 +121,7 @@ class Binding:
         L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]
         L.sss_decima_layer_lists.argtypes = [C.c_int, C.POINTER(SssDecimaLists), C.c_void_p]
+        L.sss_prefix_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_decima_policy.argtypes = [C.c_void_p, C.POINTER(SssDecimaPolicyArgs), C.c_void_p]
         L.sss_decima_sample.argtypes = [C.c_int, C.c_int, C.POINTER(SssDecimaSampleArgs), C.c_void_p]
         L.sss_gnn_launch.argtypes = [C.c_int, C.POINTER(SssGnnArgs), C.c_void_p]

@@ -180,3 +180,31 @@ SSS_KERNEL void sss_decima_lists_kernel(int num_envs, SssDecimaListArgs d) {
     }
   }
 }
+
+// sss_prefix_rows (include/sss.h): one row's exclusive prefix sums, `tid` of `nt` cooperating threads; `part` is
+// scratch for nt partial sums shared by them; `sync` orders the phases.
+struct SssPrefixArgs {
+  const int32_t* src;
+  int64_t row_stride, col_stride;
+  const uint8_t* mask;
+  int n_rows, n_cols;
+  int64_t *off, *cnt, *totals;
+};
+template <typename Sync>
+SSS_DEV void prefix_row(const SssPrefixArgs& a, int row, int tid, int nt, int64_t* part, Sync sync) {
+  const int per = (a.n_cols + nt - 1) / nt;  // a contiguous run of columns per thread
+  const int c0 = tid * per, c1 = c0 + per < a.n_cols ? c0 + per : a.n_cols;
+  int64_t sum = 0;
+  for (int c = c0; c < c1; c++) sum += (a.mask && !a.mask[c]) ? 0 : (int64_t)a.src[row * a.row_stride + c * a.col_stride];
+  part[tid] = sum;
+  sync();
+  int64_t base = 0;
+  for (int t = 0; t < tid; t++) base += part[t];
+  if (tid == nt - 1) a.totals[row] = base + sum;
+  for (int c = c0; c < c1; c++) {
+    const int64_t v = (a.mask && !a.mask[c]) ? 0 : (int64_t)a.src[row * a.row_stride + c * a.col_stride];
+    a.off[(int64_t)row * a.n_cols + c] = base;
+    if (a.cnt) a.cnt[(int64_t)row * a.n_cols + c] = v;
+    base += v;
+  }
+}

@@ -112,6 +112,15 @@ static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleAr
 
 #include "sss_gnn16.h"
 
+__global__ __launch_bounds__(256) void sss_prefix_rows_kernel(SssPrefixArgs a) {
+  __shared__ int64_t part[256];
+  prefix_row(a, (int)blockIdx.x, (int)threadIdx.x, 256, part, [] { __syncthreads(); });
+}
+static int be_launch_prefix_rows(const SssPrefixArgs& a, void* stream) {
+  hipLaunchKernelGGL(sss_prefix_rows_kernel, dim3((unsigned)a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
   constexpr int NW = gnn_weight_count<KIND>();

@@ -436,6 +436,17 @@ extern "C" int sss_decima_sample(int n_obs, int which, const sss_decima_sample_a
   return 0;
 }
 
+extern "C" int sss_prefix_rows(const int32_t* src_dev, int64_t src_row_stride, int64_t src_col_stride, const uint8_t* mask_dev, int n_rows, int n_cols,
+                               int64_t* off_dev, int64_t* cnt_dev, int64_t* totals_dev, void* stream) {
+  if (!src_dev || !off_dev || !totals_dev) return sss_fail(-1, "NULL argument");
+  if (n_rows < 1 || n_cols < 1) return sss_fail(-1, "empty scan");
+  SssPrefixArgs a;
+  a.src = src_dev, a.row_stride = src_row_stride, a.col_stride = src_col_stride, a.mask = mask_dev, a.n_rows = n_rows, a.n_cols = n_cols;
+  a.off = off_dev, a.cnt = cnt_dev, a.totals = totals_dev;
+  if (int rc = be_launch_prefix_rows(a, stream)) return sss_fail(-30, std::string("prefix launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   if (!g) return sss_fail(-1, "NULL argument");
   if (kind < 0 || kind >= GNN_KINDS) return sss_fail(-26, "unknown GNN stage");

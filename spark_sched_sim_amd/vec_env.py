@@ -203,14 +203,16 @@ class VecSparkSchedSimEnv:
                     f[k] = f[k] & active[:, None]
                 f["n_nodes"], f["depth"] = f["n_nodes"] * active, f["depth"] * active
             return compact_graph(f)
-        cnt = self.obs_i32[:, :3].long()  # n_nodes, n_edges, n_jobs
-        act8 = None
-        if active is not None:
-            cnt = cnt * active[:, None]
-            act8 = active.to(torch.uint8).contiguous()
-        cnt_t = cnt.t().contiguous()  # [3, B]: scans along the contiguous axis
-        off = (torch.cumsum(cnt_t, 1) - cnt_t).contiguous()
-        M, Ed, J = (int(v) for v in cnt_t.sum(1).tolist())
+        # per-env counts (n_nodes, n_edges, n_jobs; 0 for inactive envs), their exclusive prefix sums and totals:
+        # one small kernel over the obs_i32 rows in place (include/sss.h sss_prefix_rows) instead of a handful of
+        # tensor ops; the totals are the one device->host sync
+        act8 = active.to(torch.uint8).contiguous() if active is not None else None
+        scan = torch.empty((2, 3, B), dtype=torch.int64, device=dev)
+        tot = torch.empty(3, dtype=torch.int64, device=dev)
+        self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 3, B,
+                                                 scan[0].data_ptr(), scan[1].data_ptr(), tot.data_ptr(), self._stream()))
+        off, cnt_t = scan[0], scan[1]  # [3, B] each
+        M, Ed, J = (int(v) for v in tot.tolist())
         # buffers hold at least one element so that their pointers are never NULL; `g` gets exact views
         pool = self._dg_pool if reuse_buffers else None
 
@@ -250,21 +252,25 @@ class VecSparkSchedSimEnv:
         """for every DAG layer of a graph from `decima_graph` the ids of the nodes it updates (one
         small kernel for all layers; one device->host sync for the list sizes)"""
         if "recv_lists" not in g:
-            cnt = g["layer_cnt"].long()
-            totals = cnt.sum(1).tolist()
+            lc = g["layer_cnt"]  # i32[32, B]
+            dev_l = lc.device
+            scan = torch.empty((32, lc.shape[1]), dtype=torch.int64, device=dev_l)
+            tot = torch.empty(32, dtype=torch.int64, device=dev_l)
+            b = g["_binding"]
+            stream = torch.cuda.current_stream(dev_l).cuda_stream if dev_l.type == "cuda" else 0
+            b.check(b.lib.sss_prefix_rows(lc.data_ptr(), lc.stride(0), 1, None, 32, lc.shape[1], scan.data_ptr(), None, tot.data_ptr(), stream))
+            totals = tot.tolist()
             n_layers = max((lvl + 1 for lvl, c in enumerate(totals) if c), default=0)
             base = [0] * 32
             for lvl in range(1, 32):
                 base[lvl] = base[lvl - 1] + totals[lvl - 1]
-            recv = torch.empty(max(sum(totals), 1), dtype=torch.int64, device=cnt.device)
+            recv = torch.empty(max(sum(totals), 1), dtype=torch.int64, device=dev_l)
             if n_layers:
-                env_off = (torch.cumsum(cnt, 1) - cnt).contiguous()
+                env_off = scan  # exclusive prefix of the per-env receiver counts, per layer
                 a = SssDecimaLists(g["obs_node_off"].data_ptr(), g["obs_nodes"].data_ptr(), g["node_recv"].data_ptr(), env_off.data_ptr(),
                                    (C.c_int64 * 32)(*base), recv.data_ptr(), n_layers)
-                dev = cnt.device
-                stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-                b = g["_binding"]
                 b.check(b.lib.sss_decima_layer_lists(g["n_obs"], C.byref(a), stream))
+                g["_keepalive_lists"] = env_off
             g["recv_lists"] = [recv[base[lvl]: base[lvl] + totals[lvl]] for lvl in range(n_layers)]
         return g["recv_lists"]
 

@@ -60,6 +60,11 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
   return 0;
 }
 
+static int be_launch_prefix_rows(const SssPrefixArgs& a, void*) {
+  int64_t part[1];
+  for (int r = 0; r < a.n_rows; r++) prefix_row(a, r, 0, 1, part, [] {});
+  return 0;
+}
 static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void*) {
   emu::launch(num_envs, [&]() { sss_decima_lists_kernel(num_envs, d); });
   return 0;
