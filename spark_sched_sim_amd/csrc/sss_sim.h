@@ -157,8 +157,10 @@ SSS_DEV void ctx_init() { prof3_clear(); }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__clang__)
 #define SSS_UNROLL4 _Pragma("unroll 4")
+#define SSS_UNROLL8 _Pragma("unroll 8")
 #else
 #define SSS_UNROLL4
+#define SSS_UNROLL8
 #endif
 
 #ifdef SSS_BATCH_STATS  // emulator-only census of why rounds end (tests/emu, never in the product build)
@@ -3093,15 +3095,33 @@ SSS_DEV void env_begin(const uint8_t* base) {
   uint64_t occ = ~g_sc.free_slots & (g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1));
   int nK = popc64(occ);  // slots 0 .. nK-1
   int per = 8 + g_c.SP + g_c.SP / 2;
-  for (int i = lane; i < nK * per; i += 64) {
-    int k = i / per, w = i - k * per;
-    int j = lds_slot_job()[k];
-    if (w < 8)
-      ((uint64_t*)(lds_cjobs() + k))[w] = ((const uint64_t*)(g_c.jobs + j))[w];
-    else if (w < 8 + g_c.SP)
-      ((uint64_t*)(lds_cstages() + k * g_c.SP))[w - 8] = ((const uint64_t*)(g_c.stages + j * g_c.SP))[w - 8];
-    else
-      ((uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP];
+  // eight words per lane at a time: all eight HBM loads are issued before the first LDS store (written as one loop
+  // the stores - which may alias the slot map for all the compiler knows - would serialise the loads: one round
+  // trip per 64 words)
+  for (int i0 = lane; i0 < nK * per; i0 += 64 * 8) {
+    uint64_t v[8];
+    SSS_UNROLL8 for (int u = 0; u < 8; u++) {
+      const int i = i0 + 64 * u;
+      v[u] = 0;
+      if (i < nK * per) {
+        const int k = i / per, w = i - k * per;
+        const int j = lds_slot_job()[k];
+        v[u] = w < 8 ? ((const uint64_t*)(g_c.jobs + j))[w]
+             : (w < 8 + g_c.SP ? ((const uint64_t*)(g_c.stages + j * g_c.SP))[w - 8] : ((const uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP]);
+      }
+    }
+    SSS_UNROLL8 for (int u = 0; u < 8; u++) {
+      const int i = i0 + 64 * u;
+      if (i < nK * per) {
+        const int k = i / per, w = i - k * per;
+        if (w < 8)
+          ((uint64_t*)(lds_cjobs() + k))[w] = v[u];
+        else if (w < 8 + g_c.SP)
+          ((uint64_t*)(lds_cstages() + k * g_c.SP))[w - 8] = v[u];
+        else
+          ((uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP] = v[u];
+      }
+    }
   }
   wave_sync();
 }
