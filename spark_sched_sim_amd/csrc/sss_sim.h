@@ -2991,29 +2991,38 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
   const bool same_graph = h.obs_graph_version == h.graph_version && h.obs_bind_gen == B.gen;
   int ME = g_c.P.max_edges;
   int base_e = same_graph ? h.obs_n_edges : 0;
-  for (int i0 = 0; i0 < (same_graph ? 0 : A * ME); i0 += 64) {
-    int i = i0 + lane;
-    bool keep = false;
-    int eu = 0, ev = 0;
-    if (i < A * ME) {
-      int a = i / ME, e = i - a * ME;
-      int j = lds_active()[a];
-      const SssJob* job = jobp(j);
-      if (e < (int)job->n_edges) {
-        uint64_t act = job->active_mask;
-        int u = g_c.pk.edges[2 * (job->edge_off + e)], v = g_c.pk.edges[2 * (job->edge_off + e) + 1];
-        keep = (act & bit64(u)) && (act & bit64(v));
-        eu = (int)nbase[a] + popc64(act & (bit64(u) - 1));
-        ev = (int)nbase[a] + popc64(act & (bit64(v) - 1));
+  // four groups of 64 (job, edge) pairs at a time: the four job records, then the four edges, are fetched together;
+  // the compaction below stays in (job, edge) order
+  for (int i0 = 0; i0 < (same_graph ? 0 : A * ME); i0 += 64 * 4) {
+    uint64_t act[4];
+    int eoff[4], nb[4];
+    bool has[4];
+    SSS_UNROLL4 for (int u = 0; u < 4; u++) {
+      const int i = i0 + 64 * u + lane;
+      has[u] = false, act[u] = 0, eoff[u] = 0, nb[u] = 0;
+      if (i < A * ME) {
+        const int a = i / ME, e = i - a * ME;
+        const SssJob* job = jobp(lds_active()[a]);
+        has[u] = e < (int)job->n_edges;
+        act[u] = job->active_mask, eoff[u] = job->edge_off + e, nb[u] = (int)nbase[a];
       }
     }
-    uint64_t bal = wave_ballot(keep);
-    if (keep) {
-      int pos = base_e + popc64(bal & lt);
-      el[2 * pos + 0] = eu;
-      el[2 * pos + 1] = ev;
+    int uu[4], vv[4];
+    SSS_UNROLL4 for (int u = 0; u < 4; u++) {
+      uu[u] = 0, vv[u] = 0;
+      if (has[u]) uu[u] = g_c.pk.edges[2 * eoff[u]], vv[u] = g_c.pk.edges[2 * eoff[u] + 1];
     }
-    base_e += popc64(bal);
+    SSS_UNROLL4 for (int u = 0; u < 4; u++) {
+      if (i0 + 64 * u >= A * ME) break;
+      const bool keep = has[u] && (act[u] & bit64(uu[u])) && (act[u] & bit64(vv[u]));
+      const uint64_t bal = wave_ballot(keep);
+      if (keep) {
+        const int pos = base_e + popc64(bal & lt);
+        el[2 * pos + 0] = nb[u] + popc64(act[u] & (bit64(uu[u]) - 1));
+        el[2 * pos + 1] = nb[u] + popc64(act[u] & (bit64(vv[u]) - 1));
+      }
+      base_e += popc64(bal);
+    }
   }
   if (lane == 0) {
     dag_ptr[A] = base_n;
@@ -3327,25 +3336,35 @@ SSS_DEV double jobtime_sum() {
   double beta = g_c.P.beta;
   const uint16_t* tab = lds_jobset();
   double job_time = 0.0;
-  for (int b = 0; b <= mask; b += 64) {
-    uint32_t en = tab[b + lane];  // tables are >= 8 slots; slots beyond the mask are never live
-    bool live = (b + lane) <= mask && en >= 2;
-    double term = 0.0;
-    if (live) {
-      int j = (int)en - 2;
-      double ta = g_c.t_arrival[j], tc = g_c.t_completed[j];
-      double start = ta > wall_old ? ta : wall_old;
-      double end = tc < wall ? tc : wall;
-      if (beta == 0.0)
-        term = end - start;
-      else  // np.exp in the reference: <= 2 ulp agreement only
-        term = fd_exp(-beta * 1e-3 * (start - wall_old)) - fd_exp(-beta * 1e-3 * (end - wall_old));
+  // four groups of 64 slots at a time: the arrival / completion times of all four are on their way from HBM before
+  // the first is used (large tables: 512 slots at 200 jobs); the additions stay in slot order
+  for (int b0 = 0; b0 <= mask; b0 += 256) {
+    double ta[4], tc[4];
+    bool live[4];
+    SSS_UNROLL4 for (int u = 0; u < 4; u++) {
+      const int b = b0 + 64 * u;
+      const uint32_t en = (b + lane) <= mask ? (uint32_t)tab[b + lane] : 0u;  // tables are >= 8 slots; slots beyond the mask are never live
+      live[u] = en >= 2;
+      ta[u] = 0.0, tc[u] = 0.0;
+      if (live[u]) ta[u] = g_c.t_arrival[(int)en - 2], tc[u] = g_c.t_completed[(int)en - 2];
     }
-    uint64_t m = wave_ballot(live);
-    while (m) {
-      int k = ctz64(m);
-      m &= m - 1;
-      job_time += wave_bcast_f64(term, k);
+    SSS_UNROLL4 for (int u = 0; u < 4; u++) {
+      if (b0 + 64 * u > mask) break;
+      double term = 0.0;
+      if (live[u]) {
+        double start = ta[u] > wall_old ? ta[u] : wall_old;
+        double end = tc[u] < wall ? tc[u] : wall;
+        if (beta == 0.0)
+          term = end - start;
+        else  // np.exp in the reference: <= 2 ulp agreement only
+          term = fd_exp(-beta * 1e-3 * (start - wall_old)) - fd_exp(-beta * 1e-3 * (end - wall_old));
+      }
+      uint64_t m = wave_ballot(live[u]);
+      while (m) {
+        int k = ctz64(m);
+        m &= m - 1;
+        job_time += wave_bcast_f64(term, k);
+      }
     }
   }
   if (beta > 0.0) job_time /= beta;
