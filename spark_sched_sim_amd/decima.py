@@ -462,7 +462,7 @@ class DecimaPolicy(nn.Module):
         h = torch.empty_like(h_init)
         self._launch("sink", M, w["update"], h_init=h_init, h=h, out_deg=g["out_deg"], obs_depth=g["obs_depth"], node_obs=g["node_obs"])
         from .vec_env import VecSparkSchedSimEnv
-        lists = VecSparkSchedSimEnv.decima_layer_lists(g)  # the only device->host sync of the pass
+        lists = VecSparkSchedSimEnv.decima_layer_lists(g)  # the pass's device->host sync (sizes of the layer lists)
         tmp = torch.empty((max(M, J), 16), dtype=torch.float32, device=dev)
         # embeddings alternate between `h` and `tmp` per update (include/sss.h node_recv_dev): no COMMIT launch per
         # layer, one MERGE after the last one
