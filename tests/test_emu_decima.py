@@ -118,3 +118,34 @@ def test_reference_checkpoint_loads_unchanged():
     sd = torch.load(path, map_location="cpu")
     assert set(sd) == set(policy.state_dict()) and sum(v.numel() for v in sd.values()) == 20802
     assert all(torch.equal(policy.state_dict()[k], v) for k, v in sd.items())
+
+
+def test_prefix_rows_matches_numpy():
+    """include/sss.h sss_prefix_rows: exclusive prefix sums, masked counts and totals of strided i32 rows"""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    lib = load_emu()
+    lib.sss_prefix_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    B = 37
+    src = torch.from_numpy(rng.integers(0, 1000, size=(B, 8)).astype(np.int32))   # like obs_i32: counts in the columns of per-env rows
+    mask = torch.from_numpy((rng.random(B) < 0.7).astype(np.uint8))
+    for m in (None, mask):
+        off = torch.empty((3, B), dtype=torch.int64)
+        cnt = torch.empty((3, B), dtype=torch.int64)
+        tot = torch.empty(3, dtype=torch.int64)
+        rc = lib.sss_prefix_rows(src.data_ptr(), 1, src.stride(0), m.data_ptr() if m is not None else None, 3, B, off.data_ptr(), cnt.data_ptr(), tot.data_ptr(), None)
+        assert rc == 0
+        want = src[:, :3].numpy().astype(np.int64).T * (m.numpy()[None, :] if m is not None else 1)
+        assert np.array_equal(cnt.numpy(), want)
+        assert np.array_equal(off.numpy(), np.cumsum(want, 1) - want)
+        assert np.array_equal(tot.numpy(), want.sum(1))
+    rows = torch.from_numpy(rng.integers(0, 50, size=(32, B)).astype(np.int32))    # like layer_cnt: contiguous rows, no counts wanted
+    off = torch.empty((32, B), dtype=torch.int64)
+    tot = torch.empty(32, dtype=torch.int64)
+    assert lib.sss_prefix_rows(rows.data_ptr(), rows.stride(0), 1, None, 32, B, off.data_ptr(), None, tot.data_ptr(), None) == 0
+    w = rows.numpy().astype(np.int64)
+    assert np.array_equal(off.numpy(), np.cumsum(w, 1) - w) and np.array_equal(tot.numpy(), w.sum(1))

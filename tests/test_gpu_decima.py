@@ -183,3 +183,22 @@ def test_sixteen_lane_kernels_agree_with_one_thread_per_row():
         assert float((a[fin] - b[fin]).abs().max()) <= 2e-5, name
     assert int(torch.isfinite(wide[2]).sum()) > 96  # schedulable stages were scored
     env.close()
+
+
+def test_prefix_rows_kernel_matches_torch():
+    """include/sss.h sss_prefix_rows on the GPU (256 cooperating threads per row) against torch.cumsum"""
+    import ctypes as C
+
+    from spark_sched_sim_amd.binding import load_library
+    lib = load_library()
+    g = torch.Generator().manual_seed(3)
+    for B in (1, 255, 256, 4096, 5000):
+        src = torch.randint(0, 2000, (B, 8), generator=g, dtype=torch.int32).cuda()
+        mask = (torch.rand(B, generator=g) < 0.6).to(torch.uint8).cuda()
+        off = torch.empty((3, B), dtype=torch.int64, device="cuda")
+        cnt = torch.empty_like(off)
+        tot = torch.empty(3, dtype=torch.int64, device="cuda")
+        assert lib.sss_prefix_rows(src.data_ptr(), 1, src.stride(0), mask.data_ptr(), 3, B, off.data_ptr(), cnt.data_ptr(), tot.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream) == 0
+        want = (src[:, :3].long() * mask[:, None].long()).t()
+        assert torch.equal(cnt, want) and torch.equal(off, torch.cumsum(want, 1) - want) and torch.equal(tot, want.sum(1))
