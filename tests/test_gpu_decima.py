@@ -191,6 +191,7 @@ def test_prefix_rows_kernel_matches_torch():
 
     from spark_sched_sim_amd.binding import load_library
     lib = load_library()
+    lib.sss_prefix_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     g = torch.Generator().manual_seed(3)
     for B in (1, 255, 256, 4096, 5000):
         src = torch.randint(0, 2000, (B, 8), generator=g, dtype=torch.int32).cuda()
