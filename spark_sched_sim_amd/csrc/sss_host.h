@@ -177,6 +177,37 @@ static std::vector<uint64_t> sss_build_pcg_jump() {
   return t;
 }
 
+// The executor-level draw of TPCHDataSampler (tpch.py:222-229) as a threshold on the raw generator output.
+// With n local executors strictly between two levels (left, right) the reference computes
+//   rand_pt = 1 + int(rng.random() * (right - left));  level = left if rand_pt <= n - left else right
+// where rng.random() = (x >> 11) * 2^-53 for the raw 64-bit output x. The outcome is monotone in m = x >> 11
+// (a product of non-negative doubles, then truncation), so there is one threshold T per n with "right" chosen
+// exactly when m >= T. It is found by bisection over the SAME double arithmetic (compiled with
+// -ffp-contract=off like the device code), not derived: entry n holds T, or 2^53 (never) when the interval is closed.
+static std::vector<uint64_t> sss_build_lvl_thr() {
+  static const int lv[8] = {5, 10, 20, 40, 50, 60, 80, 100};
+  std::vector<uint64_t> t(101, 1ull << 53);
+  for (int n = 1; n <= 100; n++) {
+    int ri = (n > 5) + (n > 10) + (n > 20) + (n > 40) + (n > 50) + (n > 60) + (n > 80);
+    int li = (n <= 5 || n == lv[ri]) ? ri : ri - 1;
+    if (li == ri) continue;
+    const double left = (double)lv[li], right = (double)lv[ri];
+    auto picks_right = [&](uint64_t m) {
+      volatile double u = (double)m * (1.0 / 9007199254740992.0);
+      volatile double prod = u * (right - left);
+      int rand_pt = 1 + (int)prod;
+      return !((double)rand_pt <= (double)n - left);
+    };
+    uint64_t lo = 0, hi = 1ull << 53;  // picks_right(lo) is false (rand_pt = 1 <= n - left), "hi" stands for true
+    while (hi - lo > 1) {
+      uint64_t mid = lo + (hi - lo) / 2;
+      if (picks_right(mid)) hi = mid; else lo = mid;
+    }
+    t[n] = hi;
+  }
+  return t;
+}
+
 // The common executor pool right after reset is set(range(E)) (executor_tracker.py:41): the image CPython 3.10
 // builds by adding 0, 1, .., E-1 to an empty set (set_add_entry / set_table_resize for keys with hash(k) == k:
 // LINEAR_PROBES 9, PERTURB_SHIFT 5, resize at fill * 5 >= mask * 3 to the first power of two > 4 * used).
@@ -293,6 +324,11 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
     return sss_fail(-11, "device allocation failed");
   }
   std::vector<uint64_t> jump = sss_build_pcg_jump();
+  const size_t jump_words = jump.size();
+  {
+    std::vector<uint64_t> thr = sss_build_lvl_thr();  // rides in the same allocation
+    jump.insert(jump.end(), thr.begin(), thr.end());
+  }
   h->jump_dev = be_alloc(jump.size() * sizeof(uint64_t));
   if (!h->jump_dev) {
     sss_destroy(h);
@@ -310,6 +346,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   }
   pk.eff = (const int32_t*)h->eff_dev;
   pk.pcg_jump = (const uint64_t*)h->jump_dev;
+  pk.lvl_thr = (const uint64_t*)h->jump_dev + jump_words;
   pk.common_pool = (const uint8_t*)h->common_dev;
   h->pk = pk;
   *out = h;

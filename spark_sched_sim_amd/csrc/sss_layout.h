@@ -181,6 +181,9 @@ struct SssPackDev {
   const int32_t* eff;  // [total_stages][8 executor levels][3 modes][4] = (offset, len | warmup << 30, min duration of the list, 0)
   const uint8_t* common_pool;  // the common pool right after reset, set(range(E)): its 16-byte record, then (tables beyond 8 slots) the table
   const uint64_t* pcg_jump;  // [129][4]: PCG64 jump-ahead by k = -64..64 steps: state' = A * state + C * inc, rows (A_hi, A_lo, C_hi, C_lo)
+  // [101], by the job's executor count n: the executor-level draw of TPCH:222-229 picks the upper level exactly when the raw
+  // generator output x has (x >> 11) >= lvl_thr[n]; 2^53 (never) when n sits on a level (sss_host.h: sss_build_lvl_thr)
+  const uint64_t* lvl_thr;
 };
 
 struct SssBuffers {        // raw device pointers of torch-allocated tensors

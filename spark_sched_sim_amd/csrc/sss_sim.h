@@ -185,6 +185,7 @@ struct Prof3Scope {
   }
 };
 #define PROF3(id) Prof3Scope prof3_scope_##id(id)
+#define PROF3_CALLS(id, n) ((void)(wave_lane() == 0 ? (g_prof3_lds[2 * (id) + 1] += (n)) : 0))  // count units of work instead of calls
 SSS_DEV void prof3_clear() { g_prof3_lds[wave_lane()] = 0; }
 SSS_DEV void prof3_flush() {
   wave_sync();
@@ -195,6 +196,7 @@ SSS_DEV void prof3_flush() {
 SSS_DEV void prof3_clear() {}
 SSS_DEV void prof3_flush() {}
 #define PROF3(id) ((void)0)
+#define PROF3_CALLS(id, n) ((void)0)
 #endif
 
 // ---- LDS pool views ----
@@ -2217,6 +2219,169 @@ done:
 }
 
 // ------------------------------------------------------------------------------------------
+// The fast run (all lanes): consecutive "task finished, its stage has more tasks" events (ENV:452-467 +
+// 584-615 + TPCH:75-106), one per iteration, with everything an iteration needs in registers. Such an
+// event touches its own executor's slot, its stage's task counter and the shared random stream - and
+// changes nothing another such event's handling depends on beyond those: the executor stays on its
+// stage, the job keeps its executors, hence the two candidate duration lists stay what they are. So, one
+// lane per executor, everything is classified ONCE when the run starts; after that an iteration is
+//   * the head of the queue: arg-min over (time, push counter) on the DPP network (EVQ:35);
+//   * its draw: EVERY lane computes, ahead of time and under the generator state the next event will see,
+//     the duration its own event would draw (the executor-level choice of TPCH:222-229 is a threshold on the
+//     raw output, SssPackDev::lvl_thr; numpy's buffered 32-bit Lemire draw with its spare half; the 64 raw
+//     outputs the wave produced ahead sit one per lane and are fetched with v_readlane) - so the one load
+//     from the duration pool is in flight while the head is being found;
+//   * the commit: the head's lane takes its new time and push counter, the lanes of the same stage follow
+//     its task counter, the generator's position moves on - registers and scalars only.
+// LDS sees the result when the run ends (slots, stage counters, most recent durations, saturation, header).
+// The run ends at the first head event that is anything else (other kinds, a stage out of tasks, a job
+// arrival due first, a draw that needs Lemire's rejection loop, lists with one or no entry): that one goes
+// the general way. `w`, `tmin`: the head event found by the caller (pop_event_wave).
+// Returns the number of events handled (0: none, nothing modified).
+// ------------------------------------------------------------------------------------------
+SSS_DEV int fast_run(const FastCtx& f, int w, double tmin) {
+#ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
+  return 0;
+#endif
+  PROF3(30);
+  const int lane = wave_lane();
+  // ---- everything that is read from shared state is read before the first collective ----
+  SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
+  const uint32_t counter = g_hot.h.counter;
+  uint32_t h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  int pos = g_sc.rng_pos;
+  const double next_arr_l = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
+  uint64_t rngv = g_sc.rng_buf[lane];  // raw output `lane` of the buffer (those from rng_pos on are unconsumed)
+  const uint32_t info = sl.info;
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info);
+  bool elig = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
+  int rem = 0, mc = 0, off_l = 0, off_r = 0;
+  uint32_t len_l = 1, len_r = 1;
+  uint64_t thr = 1ull << 53;
+  bool open = false;
+  if (elig) {
+    const SssStage st = f.cstages[slot * f.SP + s];
+    const SssJob* jp = f.cjobs + slot;
+    const uint64_t local = jp->local_mask;
+    const int gs = jp->gs_base + s;
+    const int n_local = popc64(local);
+    int li, ri;
+    executor_interval(n_local, li, ri);
+    SssExDesc xd = f.exdesc[lane];
+    if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) {
+      exdesc_fetch(f, xd, gs, li, ri);
+      f.exdesc[lane] = xd;  // an entry is only ever used with its own executor's events
+    }
+    rem = st.remaining, mc = (int)st.moving_to + (int)st.commit_to;
+    // lists with one entry draw nothing, empty ones fail, the idle-executor fallback adds warmup_delay
+    // (TPCH:88-106): all of those go one at a time
+    elig = n_local > 0 && n_local <= 100 && (xd.lenw_l & LENW_LEN) > 1 && (xd.lenw_r & LENW_LEN) > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
+    if (elig) {
+      off_l = xd.off_l, off_r = xd.off_r, len_l = (uint32_t)(xd.lenw_l & LENW_LEN), len_r = (uint32_t)(xd.lenw_r & LENW_LEN);
+      open = li != ri;
+      if (open) thr = g_c.pk.lvl_thr[n_local];
+    }
+  }
+  const uint32_t tag = info >> 8;  // (job, slot, stage)
+  // wave-uniform values the loop keeps on the scalar unit
+  const uint32_t counter0 = wave_lane0_u32(counter);
+  const double next_arr = wave_lane0_f64(next_arr_l);
+  h0 = wave_lane0_u32(h0), u32_0 = wave_lane0_u32(u32_0), pos = (int)wave_lane0_u32((uint32_t)pos);
+  const uint64_t open_m = wave_ballot(open), elig_m = wave_ballot(elig);
+  const int32_t* durations = f.durations;
+  const int rem0 = rem;
+  const uint32_t seq0 = sl.seq;
+  int total = 0;
+  double wall = 0.0;
+  int32_t lastdur = 0;
+  // Every lane's draw as if its event were the next one (TPCH:216-235 for "same stage"), under the generator state
+  // (pos, h0, u32_0). The load of the duration is issued here and waited for when the head's value is needed -
+  // one iteration later, with the search for the head in between.
+#ifdef SSS_EXP_NOLOAD  /* timing experiment only (wrong durations): what the load from the duration pool costs */
+#define SSS_EXP_DUR(i) (((i) & 1023) + 100)
+#else
+#define SSS_EXP_DUR(i) durations[i]
+#endif
+#define SSS_FAST_DRAW()                                                                                                   \
+  do {                                                                                                                    \
+    if (pos > 62) { /* a draw may take two raw outputs: produce the next 64 (the stream goes on where it stood) */        \
+      if (lane == 0) g_sc.rng_pos = pos;                                                                                  \
+      wave_sync();                                                                                                        \
+      rng_refill();                                                                                                       \
+      rngv = g_sc.rng_buf[lane], pos = 0;                                                                                 \
+    }                                                                                                                     \
+    r0 = wave_readlane_u64(rngv, pos), r1 = wave_readlane_u64(rngv, pos + 1);                                             \
+    const bool sel_r = (r0 >> 11) >= thr; /* thr = 2^53 for a closed level interval: never */                             \
+    const int off = sel_r ? off_r : off_l;                                                                                \
+    const uint32_t len = sel_r ? len_r : len_l;                                                                           \
+    const uint32_t u32 = h0 ? u32_0 : (uint32_t)(open ? r1 : r0); /* numpy's spare half, or the low half of a new output */ \
+    const uint64_t mm = (uint64_t)u32 * len;                                                                              \
+    dur = SSS_EXP_DUR(off + (int)(mm >> 32)); /* (lanes without such an event read entry 0) */                            \
+    /* the head goes this way if it is such an event, its stage has a task left and its draw passes Lemire's test at */   \
+    /* the first attempt */                                                                                               \
+    okm = elig_m & wave_ballot(rem > 0) & wave_ballot((uint32_t)mm >= len);                                               \
+  } while (0)
+  uint64_t r0, r1, okm;
+  int32_t dur;
+  SSS_FAST_DRAW();
+  // no job arrival may be due first (arrivals win ties, EVQ:35)
+  while (((okm >> w) & 1ull) && tmin < next_arr) {
+    // ---- commit the head event (lane w) ----
+    const uint32_t open_w = (uint32_t)(open_m >> w) & 1u;
+    if (!h0) u32_0 = (uint32_t)((open_w ? r1 : r0) >> 32), pos += 1;  // a new raw output: its high half is kept
+    h0 ^= 1u, pos += (int)open_w;
+    const int32_t dur_w = (int32_t)wave_readlane_u32((uint32_t)dur, w);
+    const uint32_t tag_w = wave_readlane_u32(tag, w);
+    const double t_new = tmin + (double)dur_w;
+    if (lane == w) sl.t = t_new, sl.seq = counter0 + (uint32_t)total;
+    if (tag == tag_w) rem -= 1, lastdur = dur_w;  // STG:53-58, ENV:604 (only read back by lanes with such an event)
+    total++, wall = tmin;
+    SSS_FAST_DRAW();  // for the event after this one
+    // ---- the next head (EVQ:44-49) ----
+    tmin = f.E <= 16 ? wave_min_f64_nonneg_row0(sl.t) : wave_min_f64_nonneg(sl.t);
+    const bool at_min = sl.t == tmin;
+    const uint64_t hm = wave_ballot(at_min);  // never empty: the minimum is some lane's value
+    w = ctz64_nz(hm);
+    if (popc64(hm) > 1) {  // equal times: the earlier push wins
+      const uint32_t msq = wave_min_u32(at_min ? sl.seq : 0xFFFFFFFFu);
+      w = ctz64_nz(wave_ballot(at_min && sl.seq == msq));
+    }
+  }
+#undef SSS_FAST_DRAW
+  if (total > 0) {
+    const bool won = sl.seq != seq0, touched = elig && rem != rem0;  // (push counters only grow)
+    if (won) g_hot.ev[lane].t = sl.t, g_hot.ev[lane].seq = sl.seq;
+    SssJob* jp = f.cjobs + (touched ? slot : 0);
+    if (touched) {  // (the lanes of one stage hold the same values)
+      f.cstages[slot * f.SP + s].remaining = (int16_t)rem;
+      f.cdur[slot * f.SP + s] = (float)lastdur;
+      if (rem - mc <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));  // executor demand <= 0 (ENV:566-582)
+    }
+    // a stage whose last task was started in this run is saturated from now on (ENV:595-597): once per stage
+    for (uint64_t zm = wave_ballot(touched && rem == 0); zm;) {
+      const int l = ctz64(zm);
+      const uint32_t tl = wave_readlane_u32(tag, l);
+      if (lane == l) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
+      zm &= ~wave_ballot(touched && tag == tl);
+    }
+    if (lane == 0) {
+      SssHdr& h = g_hot.h;
+      h.wall_time = wall;  // the last event's time
+      h.counter = counter0 + (uint32_t)total;
+      h.n_events += (uint64_t)total, h.n_fast += (uint64_t)total, h.n_batched += (uint64_t)total, h.n_rounds += 1;
+      g_sc.events_this_step += (int32_t)total;
+      g_sc.rng_pos = pos;
+      h.rng_has32 = h0;
+      h.rng_u32 = u32_0;
+    }
+  }
+  wave_sync();  // the slots and counters are visible to every lane from here
+  PROF3_CALLS(30, total - 1);  // (profiling builds: ticks per event of a run)
+  return total;
+}
+
+// ------------------------------------------------------------------------------------------
 // Batches of RELEASED executors (all lanes). The other frequent event while nothing is committable:
 // TASK_FINISHED on a stage with no task left to start (ENV:468-483) whose pool holds a commitment
 // (the policy lined the executor's next stop up). The executor leaves its stage's pool, the commitment
@@ -3477,10 +3642,6 @@ SSS_DEV void resume_simulation() {
     EVP_DECL;
     do {
       status = 0;
-      if (64 - g_sc.rng_pos < rng_need) {
-        rng_refill();
-        EVP_MARK(5);
-      }
       EVP_COUNT(6);
       // the head of the queue decides what kind of round this is
       double t_win = 0.0;
@@ -3490,15 +3651,21 @@ SSS_DEV void resume_simulation() {
       EVP_MARK(3);
       if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {
         int handled = 0;
-        if (info_kind(info_win) == EV_TASK_FINISHED) {
-          // tasks left in its stage: zero or more batches of such events; when they end, the head of the queue
-          // is something else (or the generator's buffer ran low). None left: a batch of released executors
-          if (f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0)
-            handled = batch_fast_events(f, rng_need, true EVP_PASS);
-          else if (64 - g_sc.rng_pos >= rng_need)
-            handled = batch_released_events(f, ex);
-        } else if (64 - g_sc.rng_pos >= rng_need) {
-          handled = batch_arrival_events(f, ex);
+        // tasks left in its stage: a run of such events (fast_run produces the randomness it needs itself); when it
+        // ends, the head of the queue is something else. None left: a batch of released executors. Those and the
+        // batches of arriving executors want `rng_need` raw outputs buffered
+        const bool tf = info_kind(info_win) == EV_TASK_FINISHED;
+        const bool tasks_left = tf && f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0;
+        if (tasks_left) {
+          handled = fast_run(f, ex, t_win);
+        } else {
+#ifndef SSS_NO_BATCH
+          if (64 - g_sc.rng_pos < rng_need) {
+            rng_refill();
+            EVP_MARK(5);
+          }
+#endif
+          handled = tf ? batch_released_events(f, ex) : batch_arrival_events(f, ex);
         }
         EVP_MARK(0);  // a round the batch path left early is charged to its first segment
         if (handled > 0) continue;

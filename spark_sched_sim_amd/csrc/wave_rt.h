@@ -33,7 +33,7 @@ SSS_DEV void wave_sync_local() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-SSS_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
+SSS_DEV uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // v_cmp straight into an SGPR pair
 
 // value of lane 0 on every lane (v_readfirstlane: no LDS round trip); all lanes must be active
 SSS_DEV uint32_t wave_lane0_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -48,64 +48,46 @@ SSS_DEV double wave_bcast_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// min over the 64 lanes on the DPP network (no LDS traffic): quad swaps, half-row and row mirrors
-// give every lane its 16-lane row minimum; the four row results are combined on the scalar unit.
-SSS_DEV uint32_t wave_min_u32(uint32_t v) {
+// Minimum over each 16-lane row on the DPP network (no LDS traffic): quad swaps, half-row and row mirrors
+// leave every lane with its row's minimum. `old` = the identity of min lets the compiler fold each DPP move
+// into the v_min itself (v_min_u32_dpp: one instruction per step).
+SSS_DEV uint32_t dpp_row_min_u32(uint32_t v) {
   uint32_t o;
-  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
   v = o < v ? o : v;
-  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
   v = o < v ? o : v;
-  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
   v = o < v ? o : v;
-  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
   v = o < v ? o : v;
+  return v;
+}
+// min over the 64 lanes: the four row results are combined on the scalar unit
+SSS_DEV uint32_t wave_min_u32(uint32_t v) {
+  v = dpp_row_min_u32(v);
   uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
   uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
   a = a < b ? a : b, c = c < d ? c : d;
   return a < c ? a : c;
 }
+// the same when only lanes 0..15 can hold the minimum (<= 16 executors): the cross-row combine is skipped
+SSS_DEV uint32_t wave_min_u32_row0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_row_min_u32(v), 0); }
 
-// min of non-negative doubles (incl. +inf) over the wave: same DPP pattern on the two halves
+// min of non-negative doubles (incl. +inf) over the wave: they order like their bit patterns, so the minimum of
+// the high words, then the minimum of the low words among the lanes that hold it (two 32-bit passes: 64-bit
+// operands cannot ride the DPP network)
 SSS_DEV double wave_min_f64_nonneg(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-#define SSS_DPP_MIN_STEP(ctrl)                                                      \
-  {                                                                                 \
-    int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);           \
-    int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);           \
-    double o = __hiloint2double(ohi, olo), c = __hiloint2double(hi, lo);            \
-    if (o < c) lo = olo, hi = ohi;                                                  \
-  }
-  SSS_DPP_MIN_STEP(0xB1)
-  SSS_DPP_MIN_STEP(0x4E)
-  SSS_DPP_MIN_STEP(0x141)
-  SSS_DPP_MIN_STEP(0x140)
-#undef SSS_DPP_MIN_STEP
-  double a = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-  double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-  double c = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-  double d = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-  a = a < b ? a : b, c = c < d ? c : d;
-  return a < c ? a : c;
+  const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+  const uint32_t mh = wave_min_u32(hi);
+  const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return __hiloint2double((int)mh, (int)ml);
 }
-
-// the same when only lanes 0..15 can hold anything below +inf (<= 16 executors): the first 16-lane
-// row's minimum is the answer, the cross-row combine is skipped
 SSS_DEV double wave_min_f64_nonneg_row0(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-#define SSS_DPP_MIN_STEP(ctrl)                                                      \
-  {                                                                                 \
-    int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);           \
-    int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);           \
-    double o = __hiloint2double(ohi, olo), c = __hiloint2double(hi, lo);            \
-    if (o < c) lo = olo, hi = ohi;                                                  \
-  }
-  SSS_DPP_MIN_STEP(0xB1)
-  SSS_DPP_MIN_STEP(0x4E)
-  SSS_DPP_MIN_STEP(0x141)
-  SSS_DPP_MIN_STEP(0x140)
-#undef SSS_DPP_MIN_STEP
-  return __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+  const uint32_t mh = wave_min_u32_row0(hi);
+  const uint32_t ml = wave_min_u32_row0(hi == mh ? lo : 0xFFFFFFFFu);
+  return __hiloint2double((int)mh, (int)ml);
 }
 
 SSS_DEV uint64_t wave_min_u64(uint64_t v) {
@@ -138,6 +120,10 @@ SSS_DEV double wave_readlane_f64(double v, int l) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
+SSS_DEV uint64_t wave_readlane_u64(uint64_t v, int l) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
 // read-modify-write used when several lanes commit to the same record in one step
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { atomicAdd(p, v); }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
@@ -168,6 +154,7 @@ SSS_DEV void nt_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 SSS_DEV int popc64(uint64_t x) { return __popcll(x); }
 SSS_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
+SSS_DEV int ctz64_nz(uint64_t x) { return __builtin_ctzll(x); }  // x != 0
 SSS_DEV uint64_t f64_bits(double x) { return (uint64_t)__double_as_longlong(x); }
 SSS_DEV double bits_f64(uint64_t x) { return __longlong_as_double((long long)x); }
 SSS_DEV uint32_t f64_hi32(double x) { return (uint32_t)__double2hiint(x); }

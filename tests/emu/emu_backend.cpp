@@ -110,3 +110,8 @@ extern "C" void sss_test_pcg_jump_table(uint64_t* out) {
   std::vector<uint64_t> t = sss_build_pcg_jump();
   memcpy(out, t.data(), t.size() * sizeof(uint64_t));
 }
+// ... and the executor-level thresholds (101 entries)
+extern "C" void sss_test_lvl_thr_table(uint64_t* out) {
+  std::vector<uint64_t> t = sss_build_lvl_thr();
+  memcpy(out, t.data(), t.size() * sizeof(uint64_t));
+}

@@ -65,6 +65,12 @@ SSS_DEV uint32_t wave_min_u32(uint32_t v) {
   for (int i = 0; i < 64; i++) m = (uint32_t)emu::slot(i) < m ? (uint32_t)emu::slot(i) : m;
   return m;
 }
+SSS_DEV uint32_t wave_min_u32_row0(uint32_t v) {  // lanes 16..63 must not hold anything below row 0's minimum (checked)
+  uint32_t m = wave_min_u32(v);
+  uint32_t m0 = wave_min_u32(emu::lane() < 16 ? v : 0xFFFFFFFFu);
+  if (m != m0) __builtin_trap();
+  return m;
+}
 SSS_DEV uint64_t wave_min_u64(uint64_t v) {
   emu::collective(emu::OP_MIN64, v);
   uint64_t m = ~0ull;
@@ -106,6 +112,10 @@ SSS_DEV float wave_sum_f32(float v) {
 }
 SSS_DEV uint32_t wave_readlane_u32(uint32_t v, int l) { return wave_bcast_u32(v, l); }
 SSS_DEV double wave_readlane_f64(double v, int l) { return wave_bcast_f64(v, l); }
+SSS_DEV uint64_t wave_readlane_u64(uint64_t v, int l) {
+  emu::collective(emu::OP_BCAST, v);
+  return emu::slot(l & 63);
+}
 // fibers run one at a time between collectives: plain read-modify-write is atomic enough
 SSS_DEV void lane_atomic_add_i32(int32_t* p, int32_t v) { *p += v; }
 SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
@@ -126,6 +136,7 @@ SSS_DEV void nt_store(T* p, T v) { *p = v; }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 SSS_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
 SSS_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : -1; }
+SSS_DEV int ctz64_nz(uint64_t x) { if (!x) __builtin_trap(); return __builtin_ctzll(x); }
 SSS_DEV uint64_t f64_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 SSS_DEV double bits_f64(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 SSS_DEV uint32_t f64_hi32(double x) { return (uint32_t)(f64_bits(x) >> 32); }

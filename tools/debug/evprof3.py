@@ -10,7 +10,7 @@ NAMES = {0: "batch_released_events", 1: "trk_add_commitment", 2: "trk_remove_com
          11: "move_executor_to_stage", 12: "fulfill_commitments_from_source", 13: "batch_released_events: commit + lane-0 tail", 14: "handle_executor_arrival",
          15: "process_job_completion", 16: "handle_task_completion", 17: "take_action", 18: "jobtime_build_set", 19: "cache_acquire", 20: "batch_arrival_events",
          21: "find_schedulable_all", 22: "write_observation", 23: "env_begin", 24: "env_end", 25: "jobtime_sum", 26: "resume_simulation", 27: "do_reset",
-         28: "do_step", 29: "run_policy", 30: "batch_fast_events", 31: "handle_popped"}
+         28: "do_step", 29: "run_policy", 30: "fast_run (per EVENT)", 31: "handle_popped"}
 CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
        "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
 lib = load_library()
