@@ -88,8 +88,8 @@ static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes,
 // A wave "fails" when the level key is missing (KeyError) or its list is empty (ValueError from
 // Generator.choice before any draw); len 0 in the result = the exception would escape.
 // Each entry also carries a lower bound of any duration the list can yield (its minimum, plus the
-// whole milliseconds of warmup_delay where that is added): the batched event path (sss_sim.h,
-// batch_fast_events) uses it to bound the time of events that do not exist yet.
+// whole milliseconds of warmup_delay where that is added): the batched event paths (sss_sim.h,
+// batch_released_events / batch_arrival_events) use it to bound the time of events that do not exist yet.
 static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost& ph, const int8_t lvl_of[8], double warmup_delay) {
   const uint32_t* keymask = (const uint32_t*)(pack + ph.sec_off[7]);
   const int32_t* maxlvl = (const int32_t*)(pack + ph.sec_off[8]);

@@ -164,7 +164,7 @@ SSS_DEV void ctx_init() { prof3_clear(); }
 #endif
 
 #ifdef SSS_BATCH_STATS  // emulator-only census of why rounds end (tests/emu, never in the product build)
-extern "C" { extern long long sss_batch_stats[64]; }
+extern "C" { extern long long sss_batch_stats[128]; }
 #define STAT(i, v) ((void)(wave_lane() == 0 ? (sss_batch_stats[i] += (v)) : 0))
 #else
 #define STAT(i, v) ((void)0)
@@ -184,7 +184,15 @@ struct Prof3Scope {
     if (wave_lane() == 0) g_prof3_lds[2 * id] += wave_clock() - t0, g_prof3_lds[2 * id + 1] += 1;
   }
 };
+#ifdef SSS_EVPROF3B  // experiment: ids 1..12 time the sections of batch_released_events instead of the lane-0 procedures
+#define PROF3(id) Prof3Scope prof3_scope_##id((id) >= 1 && (id) <= 12 ? 63 : (id))
+#define PROF3_SEC_BEGIN uint64_t prof3_sec_t = wave_clock()
+#define PROF3_SEC(id) do { uint64_t now_ = wave_clock(); if (wave_lane() == 0) g_prof3_lds[2 * (id)] += now_ - prof3_sec_t, g_prof3_lds[2 * (id) + 1] += 1; prof3_sec_t = now_; } while (0)
+#else
 #define PROF3(id) Prof3Scope prof3_scope_##id(id)
+#define PROF3_SEC_BEGIN ((void)0)
+#define PROF3_SEC(id) ((void)0)
+#endif
 #define PROF3_CALLS(id, n) ((void)(wave_lane() == 0 ? (g_prof3_lds[2 * (id) + 1] += (n)) : 0))  // count units of work instead of calls
 SSS_DEV void prof3_clear() { g_prof3_lds[wave_lane()] = 0; }
 SSS_DEV void prof3_flush() {
@@ -197,6 +205,8 @@ SSS_DEV void prof3_clear() {}
 SSS_DEV void prof3_flush() {}
 #define PROF3(id) ((void)0)
 #define PROF3_CALLS(id, n) ((void)0)
+#define PROF3_SEC_BEGIN ((void)0)
+#define PROF3_SEC(id) ((void)0)
 #endif
 
 // ---- LDS pool views ----
@@ -1403,7 +1413,7 @@ enum { FI_SEND = 1, FI_EXEC = 2, FI_PARK = 3 };
 //     before it (they are detached from the source's job, JOB:86-89);
 //   * its position in the random stream = the raw outputs consumed by the draws before it, known
 //     without their values (one for random() when the executor-level interval is open, one 32-bit
-//     half for the bounded integer - as in batch_fast_events).
+//     half for the bounded integer: numpy's buffered 32-bit path, parity of the buffered half included).
 // Removals from the source pool commute (a removal leaves a dummy, probe chains do not change) - unless
 // executors are parked in the source itself (taken out and put back): then its operations run in item order;
 // additions to a pool are made in item order by lane 0 on the staged image (pool_stage_in / _out).
@@ -1939,7 +1949,7 @@ SSS_DEV void exdesc_fetch(const FastCtx& f, SssExDesc& xd, int gs, int li, int r
 // stage): ENV:452-467 + ENV:584-615 + TPCH:75-106 fused for "same executor continues on the same
 // stage". executing-- / executing++ cancel, executor.task.stage_id already equals the stage
 // (=> the `rest_wave` mode of task_duration), the event slot keeps its kind/job/stage.
-// One event, lane 0 (the lane-parallel version is batch_fast_events below).
+// One event, lane 0 (runs of such events: fast_run below).
 // Returns 1 = handled, 0 = the stage has no remaining task (nothing modified: slow path), -1 = failed.
 template <bool CACHED>
 SSS_DEV int fast_body(const FastCtx& f, int ex, double t_ev, int j, int s, int slot) {
@@ -1999,247 +2009,33 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 }
 
 // ------------------------------------------------------------------------------------------
-// Lane-parallel event batches (all lanes). While nothing is committable the event loop only pops
-// and handles (ENV:326-332), and a TASK_FINISHED whose stage still has tasks touches nothing but
-// its own executor, its stage's counters and the shared random stream. Such events do not have to
-// run one by one: with one lane per executor,
-//   * every pending event that can take that path computes a LOWER BOUND of the time of the event it
-//     will push (its own time + the minimum of the duration lists it can draw from, SssExDesc::dmin);
-//     M = min over those bounds, over the times of all pending events that need the general handlers,
-//     and the next job arrival. Every pending fast event with t < M is popped before anything else
-//     can happen - in time order, and the events they push all land at >= M. That set is the batch;
-//   * the batch members rank themselves by (time, push counter) - heapq's order, EVQ:35 - in a loop
-//     over the members with v_readlane (members are few); the rank gives each member its push counter and - because the number of raw
-//     generator outputs each event consumes is known beforehand (one for random() when its executor
-//     level interval is open, then one 32-bit half for the bounded integer, TPCH:208-235, numpy's
-//     buffered 32-bit path) - its position in the env's random stream, which the wave has produced
-//     ahead of time (rng_refill);
-//   * members of one stage decrement its task counter together; the last of them in time order
-//     leaves its duration as the stage's most recent one (ENV:604).
-// Anything unusual - a stage that would run out of tasks mid-batch, a draw that needs Lemire's
-// rejection test, duration lists with one or no entry - shortens the batch or leaves the round to the
-// one-event-at-a-time path, which is always correct.
-// Returns the number of events handled (0: none, nothing modified).
-// ------------------------------------------------------------------------------------------
-SSS_DEV int batch_fast_events(const FastCtx& f, int rng_need, bool head_known EVP_ARG) {
-  PROF3(30);
-#ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
-  return 0;
-#endif
-  const int lane = wave_lane();
-  // ---- everything that is read from shared state is read before the first collective ----
-  SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
-  uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
-  int pos = g_sc.rng_pos;
-  const double next_arr = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
-  const uint32_t info = sl.info;
-  const uint32_t slot = info_slot(info);
-  const int s = info_stage(info);
-  bool cand = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
-  SssStage st = {0, 0, 0, 0};
-  if (cand) st = f.cstages[slot * f.SP + s];
-  if (!head_known) {
-    // no batch unless the head of the queue is such an event with tasks left in its stage (anything else
-    // bounds the window from below): found out before the executors' duration lists are looked at
-    const bool c1 = cand && st.remaining > 0;
-    const double kq = c1 ? __builtin_inf() : sl.t;
-    const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
-    const double t_stop = next_arr < t_other ? next_arr : t_other;
-    if (wave_ballot(c1 && sl.t < t_stop) == 0) return 0;
-  }
-  SssExDesc xd;
-  xd.gs = -1, xd.li = xd.ri = 0, xd.pad = 0, xd.off_l = xd.off_r = 0, xd.lenw_l = xd.lenw_r = 0, xd.dmin_l = xd.dmin_r = 0;
-  int n_local = 0, li = 0, ri = 0, len_l = 0, len_r = 0;
-  if (cand) {
-    const SssJob* jp = f.cjobs + slot;
-    const uint64_t local = jp->local_mask;
-    const int gs = jp->gs_base + s;
-    n_local = popc64(local);
-    executor_interval(n_local, li, ri);
-    xd = f.exdesc[lane];
-    if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) {
-      exdesc_fetch(f, xd, gs, li, ri);
-      f.exdesc[lane] = xd;  // an entry is only ever used with its own executor's events
-    }
-    len_l = xd.lenw_l & LENW_LEN, len_r = xd.lenw_r & LENW_LEN;
-    // lists with one entry draw nothing, empty ones fail (TPCH:88-106): both go one at a time
-    cand = n_local > 0 && len_l > 1 && len_r > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
-  }
-  // what stays true for this executor's event from batch to batch as long as only batches run: its
-  // stage, the job's local executors, hence the candidate lists and their bound
-  const bool fast_kind = cand;
-  const bool open = li != ri;
-  const double dmin = (double)(xd.dmin_l < xd.dmin_r ? xd.dmin_l : xd.dmin_r);
-  const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
-  const uint32_t tag = (info & ~0xFFu) | (open ? 0x80u : 0u);  // (job, slot, stage) | draws random()
-  int total = 0, rounds = 0;
-  double wall = 0.0;
-  // ---- batch after batch, state in registers (nothing a batch reads from LDS is written by a batch) ----
-  for (;;) {
-    cand = fast_kind && st.remaining > 0;
-    const double key = cand ? sl.t + dmin : sl.t;
-    double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
-    if (next_arr < M) M = next_arr;  // an arrival wins ties against executor events (EVQ:35, counters 0..J-1)
-    bool V = cand && sl.t < M;
-    uint64_t vm = wave_ballot(V);
-    EVP_MARK(0);
-#ifdef SSS_BATCH_STATS
-    {
-      uint64_t cm = wave_ballot(cand), tfm = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED), pend = wave_ballot(sl.t < __builtin_inf());
-      uint64_t unc = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot == INFO_SLOT_NONE);
-      uint64_t l1 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining > 0 && (len_l <= 1 || len_r <= 1));
-      uint64_t r0 = wave_ballot(lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE && st.remaining <= 0);
-      STAT(0, 1), STAT(1, popc64(pend)), STAT(2, popc64(tfm)), STAT(3, popc64(cm)), STAT(4, popc64(vm)), STAT(5, vm == 0);
-      STAT(6, popc64(unc)), STAT(7, popc64(l1)), STAT(8, popc64(r0));
-      double tmin = wave_min_f64_nonneg(sl.t);  // is the head of the queue a candidate at all?
-      uint64_t head = wave_ballot(sl.t == tmin);
-      STAT(9, (head & cm) != 0), STAT(10, next_arr <= tmin);
-      STAT(11, (head & unc) != 0), STAT(12, (head & l1) != 0), STAT(13, (head & r0) != 0), STAT(14, (head & ~tfm) != 0);
-    }
-#endif
-    if (vm == 0) break;
-    const uint32_t nmax = (uint32_t)(64 - pos) >> 1;  // two raw outputs per event at most
-    uint32_t rank = 0, R = 0, cb = 0, ct = 1;
-    while (vm & (vm - 1)) {  // a batch of one needs no ranking
-      // rank = members before this one in (time, push counter) order (EVQ:35: keys are unique),
-      // R = how many of those draw random(), cb / ct = members of the same stage before this one / in total
-      rank = 0, R = 0, cb = 0, ct = 0;
-      for (uint64_t m = vm; m; m &= m - 1) {
-        const int k = ctz64(m);
-        const double tk = wave_readlane_f64(sl.t, k);
-        const uint32_t qk = wave_readlane_u32(sl.seq, k);
-        const uint32_t gk = wave_readlane_u32(tag, k);
-        const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq), same = ((gk ^ tag) >> 8) == 0;
-        rank += lt ? 1u : 0u;
-        R += (lt && (gk & 0x80u)) ? 1u : 0u;
-        cb += (lt && same) ? 1u : 0u;
-        ct += same ? 1u : 0u;
-      }
-      // the stage has fewer tasks left than events before this one, or more events than buffered randomness
-      const bool over = V && (cb >= (uint32_t)st.remaining || rank >= nmax);
-      if (wave_ballot(over) == 0) break;
-      STAT(16, 1);
-      const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
-      V = V && rank < rcut;
-      vm = wave_ballot(V);
-      if (vm == 0) goto done;
-      if (!(vm & (vm - 1))) rank = 0, R = 0, cb = 0, ct = 1;
-    }
-    if (!(vm & (vm - 1))) {
-      // a batch of one: the lanes whose events belong to the same stage see its task counter move too
-      const uint32_t gk = wave_readlane_u32(tag, ctz64(vm));
-      ct = ((gk ^ tag) >> 8) == 0 ? 1u : 0u;
-    }
-    const uint32_t n = (uint32_t)popc64(vm);
-    STAT(18 + (n < 13 ? n : 13), 1);
-    EVP_MARK(1);
-    // ---- the members' draws ----
-    const uint32_t Fr = h0 ? rank >> 1 : (rank + 1) >> 1;  // raw outputs taken by the 32-bit draws of the members before
-    const bool fresh = ((h0 + rank) & 1u) == 0;           // this member's 32-bit draw takes a new raw output (low half)
-    const uint32_t P = R + Fr;
-    int lvl = li;
-    uint64_t x32 = 0;
-    uint32_t u32 = 0;
-    if (V) {
-      if (open) {  // TPCH:222-229
-        const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos + (int)P]) * (right - left));
-        if (!((double)rand_pt <= (double)n_local - left)) lvl = ri;
-      }
-      if (fresh) {
-        x32 = g_sc.rng_buf[pos + (int)P + (open ? 1 : 0)];
-        u32 = (uint32_t)x32;
-      } else if (rank == 0) {
-        u32 = u32_0;  // the half numpy kept from before the batch
-      } else {
-        u32 = (uint32_t)(g_sc.rng_buf[pos + (int)R + (int)Fr - 1] >> 32);  // the half the member before left behind
-      }
-    }
-    const int off = lvl == li ? xd.off_l : xd.off_r;
-    const uint32_t len = (uint32_t)(lvl == li ? len_l : len_r);
-    const uint64_t mm = (uint64_t)u32 * len;
-    if (wave_ballot(V && (uint32_t)mm < len) != 0) {  // Lemire's rejection test is needed: one at a time
-      STAT(17, 1);
-      break;
-    }
-    // ---- commit: nothing of this batch was modified before this point ----
-    const uint64_t lastm = wave_ballot(V && rank == n - 1);  // the batch's last event: what it leaves behind is where the next batch starts
-    const double t_ev = sl.t;
-    const uint32_t consumed = P + (open ? 1u : 0u) + (fresh ? 1u : 0u);
-    const uint32_t u32_after = fresh ? (uint32_t)(x32 >> 32) : u32;  // the half numpy keeps / the one just used up
-    if (V) {
-      const double dur = (double)f.durations[off + (int)(mm >> 32)];
-      const uint32_t seq_new = counter0 + rank;
-      sl.t = sl.t + dur, sl.seq = seq_new;
-      g_hot.ev[lane].t = sl.t;
-      g_hot.ev[lane].seq = seq_new;
-      if (cb + 1 == ct) {  // the stage's last event of the batch (STG:53-58, ENV:595-597,604)
-        SssJob* jp = f.cjobs + slot;
-        st.remaining = (int16_t)(st.remaining - (int)ct);
-        f.cstages[slot * f.SP + s] = st;
-        f.cdur[slot * f.SP + s] = (float)dur;
-        if (st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
-        if ((int)st.remaining - ((int)st.moving_to + (int)st.commit_to) <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));
-        st.remaining = (int16_t)(st.remaining + (int)ct);  // (every lane of the stage takes the batch's tasks off its copy below)
-      }
-    }
-    total += (int)n, rounds++;
-    // the header fields the next batch starts from, on every lane (from the last event's lane); the header
-    // itself is written once, when the batches are over
-    const int ll = ctz64(lastm);
-    wall = wave_readlane_f64(t_ev, ll);
-    counter0 += n;
-    pos += (int)wave_readlane_u32(consumed, ll);
-    h0 = wave_readlane_u32(fresh ? 1u : 0u, ll);
-    u32_0 = wave_readlane_u32(u32_after, ll);
-    EVP_MARK(2);
-    // the batch's members have taken `ct` tasks of this lane's stage (ct counts the members with this lane's
-    // stage whether or not the lane is one of them): the copy in the register follows without a round trip
-    // through LDS. Nothing else a batch reads is changed by a batch.
-    if (fast_kind) st.remaining = (int16_t)(st.remaining - (int)ct);
-#ifdef SSS_CHECK_TRACE
-    wave_sync();
-    if (fast_kind && f.cstages[slot * f.SP + s].remaining != st.remaining)
-      fprintf(stderr, "[batch] lane %d: register %d, LDS %d, ct %u cb %u V %d n %u\n", lane, (int)st.remaining, (int)f.cstages[slot * f.SP + s].remaining, ct, cb, (int)V, n);
-#endif
-    if (64 - pos < rng_need) break;  // the caller refills the generator's buffer
-  }
-done:
-  if (total > 0 && lane == 0) {
-    SssHdr& h = g_hot.h;
-    h.wall_time = wall;  // the last event's time
-    h.counter = counter0;
-    h.n_events += (uint64_t)total, h.n_fast += (uint64_t)total, h.n_batched += (uint64_t)total, h.n_rounds += (uint64_t)rounds;
-    g_sc.events_this_step += (int32_t)total;
-    g_sc.rng_pos = pos;
-    h.rng_has32 = h0;
-    h.rng_u32 = u32_0;
-  }
-  wave_sync();  // the slots and counters the members wrote are visible to every lane from here
-  return total;
-}
-
-// ------------------------------------------------------------------------------------------
 // The fast run (all lanes): consecutive "task finished, its stage has more tasks" events (ENV:452-467 +
 // 584-615 + TPCH:75-106), one per iteration, with everything an iteration needs in registers. Such an
 // event touches its own executor's slot, its stage's task counter and the shared random stream - and
 // changes nothing another such event's handling depends on beyond those: the executor stays on its
 // stage, the job keeps its executors, hence the two candidate duration lists stay what they are. So, one
-// lane per executor, everything is classified ONCE when the run starts; after that an iteration is
-//   * the head of the queue: arg-min over (time, push counter) on the DPP network (EVQ:35);
-//   * its draw: EVERY lane computes, ahead of time and under the generator state the next event will see,
-//     the duration its own event would draw (the executor-level choice of TPCH:222-229 is a threshold on the
-//     raw output, SssPackDev::lvl_thr; numpy's buffered 32-bit Lemire draw with its spare half; the 64 raw
-//     outputs the wave produced ahead sit one per lane and are fetched with v_readlane) - so the one load
-//     from the duration pool is in flight while the head is being found;
-//   * the commit: the head's lane takes its new time and push counter, the lanes of the same stage follow
-//     its task counter, the generator's position moves on - registers and scalars only.
+// lane per executor, everything is classified ONCE when the run starts:
+//   * t_stop = the earliest pending event of any other kind (and the next job arrival: arrivals win ties,
+//     EVQ:35). Only such events earlier than t_stop can be part of this run - the WINDOW;
+//   * the events in the window are ranked by (time, push counter), heapq's order (EVQ:35), once.
+// After that an iteration is
+//   * the head of the queue = the lane with rank 0 (one compare, no reduction);
+//   * its draw: EVERY lane has computed, ahead of time and under the generator state the next event will
+//     see, the duration its own event would draw (the executor-level choice of TPCH:222-229 is a threshold
+//     on the raw output, SssPackDev::lvl_thr; numpy's buffered 32-bit Lemire draw with its spare half; the
+//     64 raw outputs the wave produced ahead sit one per lane and are fetched with v_readlane) - so the
+//     load from the duration pool has been in flight for a whole iteration when its value is needed;
+//   * the commit: the head's lane takes its new time and push counter; the new event is the youngest, so its
+//     rank is the number of window events not later than it, and those move up by one; it leaves the
+//     window if it lands at or after t_stop. The lanes of the same stage follow its task counter, the
+//     generator's position moves on - registers and scalars only.
 // LDS sees the result when the run ends (slots, stage counters, most recent durations, saturation, header).
-// The run ends at the first head event that is anything else (other kinds, a stage out of tasks, a job
-// arrival due first, a draw that needs Lemire's rejection loop, lists with one or no entry): that one goes
-// the general way. `w`, `tmin`: the head event found by the caller (pop_event_wave).
+// The run ends when the window is empty or its head needs anything else (a stage out of tasks, a draw that
+// needs Lemire's rejection loop): the event then at the head of the queue goes the general way.
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
-SSS_DEV int fast_run(const FastCtx& f, int w, double tmin) {
+#define FR_OUT 0x40000000u  // rank of a lane whose event is not in the window (never counts down to 0)
+SSS_DEV int fast_run(const FastCtx& f) {
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
 #endif
@@ -2259,7 +2055,7 @@ SSS_DEV int fast_run(const FastCtx& f, int w, double tmin) {
   int rem = 0, mc = 0, off_l = 0, off_r = 0;
   uint32_t len_l = 1, len_r = 1;
   uint64_t thr = 1ull << 53;
-  bool open = false;
+  uint32_t open_v = 0;  // all ones: the executor-level interval is open (the draw takes random() first)
   if (elig) {
     const SssStage st = f.cstages[slot * f.SP + s];
     const SssJob* jp = f.cjobs + slot;
@@ -2276,79 +2072,102 @@ SSS_DEV int fast_run(const FastCtx& f, int w, double tmin) {
     rem = st.remaining, mc = (int)st.moving_to + (int)st.commit_to;
     // lists with one entry draw nothing, empty ones fail, the idle-executor fallback adds warmup_delay
     // (TPCH:88-106): all of those go one at a time
-    elig = n_local > 0 && n_local <= 100 && (xd.lenw_l & LENW_LEN) > 1 && (xd.lenw_r & LENW_LEN) > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
+    elig = rem > 0 && n_local > 0 && n_local <= 100 && (xd.lenw_l & LENW_LEN) > 1 && (xd.lenw_r & LENW_LEN) > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
     if (elig) {
       off_l = xd.off_l, off_r = xd.off_r, len_l = (uint32_t)(xd.lenw_l & LENW_LEN), len_r = (uint32_t)(xd.lenw_r & LENW_LEN);
-      open = li != ri;
-      if (open) thr = g_c.pk.lvl_thr[n_local];
+      if (li != ri) thr = g_c.pk.lvl_thr[n_local], open_v = 0xFFFFFFFFu;
     }
   }
   const uint32_t tag = info >> 8;  // (job, slot, stage)
   // wave-uniform values the loop keeps on the scalar unit
   const uint32_t counter0 = wave_lane0_u32(counter);
-  const double next_arr = wave_lane0_f64(next_arr_l);
   h0 = wave_lane0_u32(h0), u32_0 = wave_lane0_u32(u32_0), pos = (int)wave_lane0_u32((uint32_t)pos);
-  const uint64_t open_m = wave_ballot(open), elig_m = wave_ballot(elig);
-  const int32_t* durations = f.durations;
+  // ---- the window and the ranks in it ----
+  double t_stop = f.E <= 16 ? wave_min_f64_nonneg_row0(elig ? __builtin_inf() : sl.t) : wave_min_f64_nonneg(elig ? __builtin_inf() : sl.t);
+  {
+    const double na = wave_lane0_f64(next_arr_l);
+    t_stop = na < t_stop ? na : t_stop;
+  }
+  const uint64_t elig_m = wave_ballot(elig);
+  const uint64_t inw_m = wave_ballot(elig && sl.t < t_stop);
+  if (inw_m == 0) return 0;
+  // ranks among the events of the window. An event pushed to t_stop or beyond keeps a place among them (the run
+  // ends before it gets there, see okm); events that start outside never get one.
+  uint32_t rank = FR_OUT;
+  {
+    uint32_t below = 0;
+    for (uint64_t m = inw_m; m; m &= m - 1) {
+      const int k = ctz64_nz(m);
+      const uint64_t tk = wave_readlane_u64(f64_bits(sl.t), k);  // (non-negative doubles order like their bit patterns)
+      const uint32_t qk = wave_readlane_u32(sl.seq, k);
+      below += (tk < f64_bits(sl.t) || (tk == f64_bits(sl.t) && qk < sl.seq)) ? 1u : 0u;
+    }
+    if ((inw_m >> lane) & 1ull) rank = below;
+  }
+  const uint64_t open_m = wave_ballot(open_v != 0);
+  const char* dur_base = (const char*)f.durations;
   const int rem0 = rem;
   const uint32_t seq0 = sl.seq;
-  int total = 0;
+  uint32_t seq_next = counter0;
   double wall = 0.0;
   int32_t lastdur = 0;
   // Every lane's draw as if its event were the next one (TPCH:216-235 for "same stage"), under the generator state
   // (pos, h0, u32_0). The load of the duration is issued here and waited for when the head's value is needed -
-  // one iteration later, with the search for the head in between.
-#ifdef SSS_EXP_NOLOAD  /* timing experiment only (wrong durations): what the load from the duration pool costs */
-#define SSS_EXP_DUR(i) (((i) & 1023) + 100)
-#else
-#define SSS_EXP_DUR(i) durations[i]
-#endif
+  // one iteration later.
 #define SSS_FAST_DRAW()                                                                                                   \
   do {                                                                                                                    \
-    if (pos > 62) { /* a draw may take two raw outputs: produce the next 64 (the stream goes on where it stood) */        \
+    if (__builtin_expect(pos > 62, 0)) { /* a draw may take two raw outputs: produce the next 64 */                       \
       if (lane == 0) g_sc.rng_pos = pos;                                                                                  \
       wave_sync();                                                                                                        \
       rng_refill();                                                                                                       \
       rngv = g_sc.rng_buf[lane], pos = 0;                                                                                 \
     }                                                                                                                     \
     r0 = wave_readlane_u64(rngv, pos), r1 = wave_readlane_u64(rngv, pos + 1);                                             \
-    const bool sel_r = (r0 >> 11) >= thr; /* thr = 2^53 for a closed level interval: never */                             \
-    const int off = sel_r ? off_r : off_l;                                                                                \
-    const uint32_t len = sel_r ? len_r : len_l;                                                                           \
-    const uint32_t u32 = h0 ? u32_0 : (uint32_t)(open ? r1 : r0); /* numpy's spare half, or the low half of a new output */ \
+    const bool sel_l = (r0 >> 11) < thr; /* thr = 2^53 for a closed level interval: always */                             \
+    const int off = sel_l ? off_l : off_r;                                                                                \
+    const uint32_t len = sel_l ? len_l : len_r;                                                                           \
+    /* numpy's spare half, or the low half of a new raw output: the one after random()'s when the interval is open */     \
+    const uint32_t ua = h0 ? u32_0 : (uint32_t)r0, ux = h0 ? 0u : (uint32_t)r0 ^ (uint32_t)r1;                            \
+    const uint32_t u32 = ua ^ (ux & open_v);                                                                              \
     const uint64_t mm = (uint64_t)u32 * len;                                                                              \
-    dur = SSS_EXP_DUR(off + (int)(mm >> 32)); /* (lanes without such an event read entry 0) */                            \
-    /* the head goes this way if it is such an event, its stage has a task left and its draw passes Lemire's test at */   \
-    /* the first attempt */                                                                                               \
-    okm = elig_m & wave_ballot(rem > 0) & wave_ballot((uint32_t)mm >= len);                                               \
+    dur = SSS_EXP_DUR((uint32_t)(off + (int)(mm >> 32))); /* (lanes without such an event read entry 0) */                \
+    /* the head goes this way if it comes before everything else that is pending, its stage has a task left and its */    \
+    /* draw passes Lemire's test at the first attempt */                                                                  \
+    okm = elig_m & wave_ballot(sl.t < t_stop) & wave_ballot(rem > 0) & wave_ballot((uint32_t)mm >= len);                  \
   } while (0)
+#ifdef SSS_EXP_NOLOAD  /* timing experiment only (wrong durations): what the load from the duration pool costs */
+#define SSS_EXP_DUR(i) (int32_t)(((i) & 1023u) + 100u)
+#else
+#define SSS_EXP_DUR(i) (*(const int32_t*)(dur_base + (size_t)((i) << 2)))
+#endif
   uint64_t r0, r1, okm;
   int32_t dur;
   SSS_FAST_DRAW();
-  // no job arrival may be due first (arrivals win ties, EVQ:35)
-  while (((okm >> w) & 1ull) && tmin < next_arr) {
+  for (;;) {
+    const uint64_t hm = wave_ballot(rank == 0);  // the head of the queue, if it is such an event
+    if (hm == 0) break;
+    const int w = ctz64_nz(hm);
+    if (!((okm >> w) & 1ull)) break;
     // ---- commit the head event (lane w) ----
     const uint32_t open_w = (uint32_t)(open_m >> w) & 1u;
     if (!h0) u32_0 = (uint32_t)((open_w ? r1 : r0) >> 32), pos += 1;  // a new raw output: its high half is kept
     h0 ^= 1u, pos += (int)open_w;
+    const double tmin = bits_f64(wave_readlane_u64(f64_bits(sl.t), w));
     const int32_t dur_w = (int32_t)wave_readlane_u32((uint32_t)dur, w);
     const uint32_t tag_w = wave_readlane_u32(tag, w);
     const double t_new = tmin + (double)dur_w;
-    if (lane == w) sl.t = t_new, sl.seq = counter0 + (uint32_t)total;
+    // the new event is the youngest: it comes after every such event that is not later (EVQ:35), and those move up
+    const bool le = f64_bits(sl.t) <= f64_bits(t_new);  // (true for w itself: its old time)
+    const uint32_t rank_w = (uint32_t)popc64(wave_ballot(le) & inw_m) - 1u;
+    if (le) rank -= 1;  // (the lanes outside the ranking are far from 0)
+    if (lane == w) sl.t = t_new, sl.seq = seq_next, rank = rank_w;
     if (tag == tag_w) rem -= 1, lastdur = dur_w;  // STG:53-58, ENV:604 (only read back by lanes with such an event)
-    total++, wall = tmin;
+    seq_next++, wall = tmin;
     SSS_FAST_DRAW();  // for the event after this one
-    // ---- the next head (EVQ:44-49) ----
-    tmin = f.E <= 16 ? wave_min_f64_nonneg_row0(sl.t) : wave_min_f64_nonneg(sl.t);
-    const bool at_min = sl.t == tmin;
-    const uint64_t hm = wave_ballot(at_min);  // never empty: the minimum is some lane's value
-    w = ctz64_nz(hm);
-    if (popc64(hm) > 1) {  // equal times: the earlier push wins
-      const uint32_t msq = wave_min_u32(at_min ? sl.seq : 0xFFFFFFFFu);
-      w = ctz64_nz(wave_ballot(at_min && sl.seq == msq));
-    }
   }
+  const int total = (int)(seq_next - counter0);
 #undef SSS_FAST_DRAW
+#undef SSS_EXP_DUR
   if (total > 0) {
     const bool won = sl.seq != seq0, touched = elig && rem != rem0;  // (push counters only grow)
     if (won) g_hot.ev[lane].t = sl.t, g_hot.ev[lane].seq = sl.seq;
@@ -2360,7 +2179,7 @@ SSS_DEV int fast_run(const FastCtx& f, int w, double tmin) {
     }
     // a stage whose last task was started in this run is saturated from now on (ENV:595-597): once per stage
     for (uint64_t zm = wave_ballot(touched && rem == 0); zm;) {
-      const int l = ctz64(zm);
+      const int l = ctz64_nz(zm);
       const uint32_t tl = wave_readlane_u32(tag, l);
       if (lane == l) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
       zm &= ~wave_ballot(touched && tag == tl);
@@ -2392,10 +2211,15 @@ SSS_DEV int fast_run(const FastCtx& f, int w, double tmin) {
 //   SEND    a stage of another job: it is detached from its job and travels (EXECUTOR_READY after moving_delay);
 //   IDLE    the common pool: it goes to the job's pool, or - the job being saturated - is detached into the
 //           common pool (no event).
-// The source stays what it is (ENV:662-674), nothing becomes committable, the loop goes on. Same
-// construction as batch_fast_events: a window below every event that needs the general handlers and
-// below every event a member can push; members ranked by (time, push counter); draws and push counters
-// by rank; counters of stages and pools by counts. Left to the one-event path: the event that completes
+// The source stays what it is (ENV:662-674), nothing becomes committable, the loop goes on. The
+// construction: every pending event that can go this way computes a LOWER BOUND of the time of the event it
+// will push (its own time + the minimum of the duration lists it can draw from, or moving_delay); M = min over
+// those bounds, the times of all pending events that need the general handlers, and the next arrival. Every
+// member event with t < M is popped before anything else can happen, and what they push lands at >= M: that set
+// is the batch. Members rank themselves by (time, push counter) - heapq's order, EVQ:35 - in a v_readlane loop;
+// the rank gives the push counter and - the number of raw generator outputs a start consumes being known
+// beforehand - its position in the env's random stream, which the wave has produced ahead of time (rng_refill);
+// counters of stages and pools follow from counts. Left to the one-event path: the event that completes
 // its stage (frontier changes), pools without or with exhausted commitments, destination stages short
 // of tasks (backup scheduling), jobs without a cache slot, and members whose outcome would depend on
 // an earlier member of the same job (a start after a detachment: the job's executor count enters the
@@ -2450,15 +2274,18 @@ SSS_DEV bool pool_enter_many(uint32_t nkey, uint32_t n) {
 // whose fc_dst is the pool are added in rank order. PASS (arriving executors, their job's pool, rl_old): each
 // enters and leaves again, or - parked - is taken out and put back by the move to the pool it is already in.
 enum { STAGED_ENTER = 0, STAGED_PASS = 1 };
+// All lanes: the pools the lanes of `dm` speak for, one at a time. `mykey`: the pool this lane's executor enters
+// (ENTER) or passes through (PASS), POOL_NONE for lanes that are not members. ENTER: the members are added in rank
+// order. PASS (arriving executors, their job's pool): each enters and leaves again, or - `parks` - is taken out and
+// put back by the move to the pool it is already in. Through the LDS staging area, lane 0 applying the operations in
+// rank order (CPython puts a key on the LAST dummy of its probe run: with dummies about, additions do not commute).
 template <int MODE>
-SSS_DEV void pools_staged(uint64_t dm, uint32_t n) {
+SSS_DEV void pools_staged(uint64_t dm, uint32_t n, uint32_t mykey, bool parks) {
   const int lane = wave_lane();
   while (dm) {
-    const int l = ctz64(dm);
+    const int l = ctz64_nz(dm);
     dm &= dm - 1;
-    uint32_t key = POOL_NONE;
-    for (uint32_t q = 0; q < n; q++)
-      if (g_sc.fi_e[q] == (uint8_t)l) key = MODE == STAGED_ENTER ? g_sc.fc_dst[q] : g_sc.rl_old[q];
+    const uint32_t key = wave_readlane_u32(mykey, l);
     SetImg<uint8_t> sn = pool_stage_in(key);
     if (lane == 0) {
       for (uint32_t q = 0; q < n; q++) {
@@ -2499,6 +2326,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   return 0;
 #endif
   PROF3(0);
+  PROF3_SEC_BEGIN;
   const int lane = wave_lane();
   // ---- reads ----
   const SssEvSlot sl = g_hot.ev[lane];
@@ -2522,8 +2350,9 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) return 0;  // none, a single one (the one-event path is as fast), or not the head
+    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) { STAT(64, 1); return 0; }  // none, a single one (the one-event path is as fast), or not the head
   }
+  PROF3_SEC(1);
   // the commitment its pool would serve first (TRK:178-183: the first-inserted one of that source)
   const uint32_t sp = key_stage_pool(j, s);
   int c_idx = -1, c_cnt = 0;
@@ -2539,7 +2368,8 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   const bool freed = cand && c_idx < 0;
   cand = cand && (freed || dst != sp);
   // the head of the queue has to be a member: whenever it turns out not to be one, the round is over
-  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;
+  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(65, 1); return 0; }
+  PROF3_SEC(2);
   const int j2 = key_job(dst), s2 = key_stage(dst);
   int type = RL_START;
   SssStage st_new = {0, 0, 0, 0};
@@ -2572,7 +2402,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       }
     }
   }
-  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;
+  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(66, 1); return 0; }
   if (wave_ballot(cand && freed) != 0) {
     // executors idling in a stage's pool would move along with a freed one (ENV:714-728): there are none between events
     const bool idle_in_stage = lane < f.E && !g_hot.ex_executing[lane] && g_hot.ex_loc[lane] != POOL_NONE && g_hot.ex_loc[lane] != POOL_COMMON &&
@@ -2586,7 +2416,8 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // the pool the member enters
   const uint32_t enters = start ? dst : (type == RL_SEND ? POOL_NONE : ((type == RL_IDLE_COMMON || type == RL_FREE_COMMON) ? POOL_COMMON : key_job_pool(j)));
   cand = cand && (freed || source == POOL_NONE || enters != source);
-  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;
+  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(67, 1); return 0; }
+  PROF3_SEC(3);
   // when the event a member pushes can come at the earliest
   const double push_lb = start ? (double)(da.z < db.z ? da.z : db.z) : (type == RL_SEND ? g_c.P.moving_delay : __builtin_inf());
   const double key = cand ? sl.t + push_lb : sl.t;
@@ -2594,7 +2425,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
   uint64_t vm = wave_ballot(V);
-  if (vm == 0) return 0;
+  if (vm == 0) { STAT(68, 1); return 0; }
   const uint32_t nmax = (uint32_t)(64 - pos) >> 1;
   const uint32_t tag_old = (slot << 8) | (uint32_t)s;
   const uint32_t tag_new = (rests ? 0x1FFFFu : (((uint32_t)j2 << 6) | (uint32_t)s2)) | (start ? 0x20000u : 0u) | (open ? 0x40000u : 0u) |
@@ -2630,8 +2461,9 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
     const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
     V = V && rank < rcut;
     vm = wave_ballot(V);
-    if (vm == 0) return 0;
+    if (vm == 0) { STAT(69, 1); return 0; }
   }
+  PROF3_SEC(4);
   const uint32_t n = (uint32_t)popc64(vm);
   const uint32_t n_x = (uint32_t)popc64(wave_ballot(V && start)), n_p = (uint32_t)popc64(wave_ballot(V && pusher));
   const uint32_t n_idle = (uint32_t)popc64(wave_ballot(V && idle));
@@ -2663,7 +2495,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   }
   const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
   const uint64_t mm = (uint64_t)u32 * len;
-  if (wave_ballot(vx && (uint32_t)mm < len) != 0) return 0;
+  if (wave_ballot(vx && (uint32_t)mm < len) != 0) { STAT(70, 1); return 0; }
   // ---- commit ----
   if (V) {
     SssJob* jp = f.cjobs + slot;
@@ -2722,6 +2554,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   }
   wave_sync();
   PROF3(13);
+  PROF3_SEC(5);
   if (lane == 0) {
     // commitments (in rank order, so that entries disappear in the order the one-event path removes them) and slot references
     for (uint32_t r = 0; r < n; r++) {
@@ -2756,6 +2589,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       }
     }
   }
+  PROF3_SEC(6);
   // pools: one lane per pool, all pools at once. A member speaks for the pool it leaves / enters if no
   // member before it (in rank) shares that pool.
   bool deferred = false;
@@ -2770,7 +2604,9 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   uint64_t dm = wave_ballot(deferred);
   STAT(31, 1), STAT(32, popc64(dm)), STAT(33, n);
   wave_sync();
-  pools_staged<STAGED_ENTER>(dm, n);  // tables with more than 8 slots, or about to grow
+  PROF3_SEC(7);
+  pools_staged<STAGED_ENTER>(dm, n, V ? enters : POOL_NONE, false);  // tables with more than 8 slots, or about to grow
+  PROF3_SEC(8);
   if (any_freed) {
     // every scan that found nothing left schedulable_stages empty (ENV:333, 505-540)
     const int A = g_hot.h.n_active;
@@ -2780,6 +2616,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
     }
   }
   wave_sync();
+  PROF3_SEC(9);
   // saturation bits (ENV:566-582): a parked executor's commitment is gone and it did not reach the stage
   if (V && type == RL_PARK) {
     const SssStage t2 = f.cstages[slot * f.SP + s2];
@@ -2790,6 +2627,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       lane_atomic_and_u64(&jp->sat_mask, ~bit64(s2));
   }
   wave_sync();
+  PROF3_SEC(10);
   if (wave_ballot(V && type == RL_SEND) != 0) {
     // A job with a pending event holds a cache slot if there is one to have (push_event): the jobs executors were
     // sent to get theirs now, so that the arrivals find their job in LDS (and can be batched in their turn). Last
@@ -2809,6 +2647,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
     }
     wave_sync();
   }
+  PROF3_SEC(11);
   return (int)n;
 }
 
@@ -2874,7 +2713,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) return 0;  // none, a single one (the one-event path is as fast), or not the head
+    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) { STAT(80, 1); return 0; }  // none, a single one (the one-event path is as fast), or not the head
   }
   SssStage st = {0, 0, 0, 0};
   const SssJob* jpc = f.cjobs + (cand ? slot : 0);
@@ -2890,13 +2729,13 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     if (type == AR_START) push_lb = (double)f.eff[(((size_t)gs * 8 + 0) * 3 + 0) * 4 + 3];
   }
   const bool start = type == AR_START;
-  if (!((wave_ballot(cand) >> head) & 1ull)) return 0;  // the head of the queue has to be a member
+  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(81, 1); return 0; }  // the head of the queue has to be a member
   const double key = cand ? sl.t + push_lb : sl.t;
   double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
   uint64_t vm = wave_ballot(V);
-  if ((vm & (vm - 1)) == 0) return 0;
+  if ((vm & (vm - 1)) == 0) { STAT(82, 1); return 0; }
   // who comes before this member, who shares its job / its stage
   uint64_t before = 0, same_job = 0, same_stage = 0;
   for (uint64_t m = vm; m; m &= m - 1) {
@@ -2934,7 +2773,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
       const uint32_t rcut = wave_min_u32(over ? (uint32_t)popc64(before & vm) : 0xFFFFFFFFu);
       V = V && (uint32_t)popc64(before & vm) < rcut;
       vm = wave_ballot(V);
-      if ((vm & (vm - 1)) == 0) return 0;
+      if ((vm & (vm - 1)) == 0) { STAT(83, 1); return 0; }
     }
   }
   before &= vm;
@@ -2968,7 +2807,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   }
   const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
   const uint64_t mm = (uint64_t)u32 * len;
-  if (wave_ballot(vx && (uint32_t)mm < len) != 0) return 0;
+  if (wave_ballot(vx && (uint32_t)mm < len) != 0) { STAT(84, 1); return 0; }
   // ---- commit ----
   const uint32_t jkey = key_job_pool(j), skey = key_stage_pool(j, s);
   if (V) {
@@ -3026,8 +2865,8 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   uint64_t dj = wave_ballot(def_job), ds = wave_ballot(def_stage);
   STAT(34, 1), STAT(35, n), STAT(36, popc64(dj)), STAT(37, popc64(ds)), STAT(38, n - n_x);
   wave_sync();
-  pools_staged<STAGED_PASS>(dj, n);  // tables with more than 8 slots, or about to grow
-  pools_staged<STAGED_ENTER>(ds, n);
+  pools_staged<STAGED_PASS>(dj, n, V ? jkey : POOL_NONE, !start);  // tables with more than 8 slots, or about to grow
+  pools_staged<STAGED_ENTER>(ds, n, (V && start) ? skey : POOL_NONE, false);
   // saturation bit of the stage (ENV:566-582), by its last member: arrivals that start a task leave the
   // demand what it was, parked ones raise it
   if (V && cb_stage + 1 == ct_stage) {
@@ -3633,10 +3472,10 @@ SSS_DEV void resume_simulation() {
   const int rng_need = 2 * (f.E < 20 ? f.E : 20);
   for (;;) {
     // events run until the wave is needed for a schedulable-stage scan, the queue is empty, or
-    // something failed. A round = one lane-parallel batch of "task finished, stage has more tasks"
-    // events if the head of the queue allows one (batch_fast_events), else one event popped by a
-    // wave reduction and handled on lane 0; the loop decision travels through a lane-0 broadcast
-    // (no LDS flags, no barrier per event).
+    // something failed. A round = a run of "task finished, stage has more tasks" events if the head of
+    // the queue is one (fast_run), a lane-parallel batch of released or arriving executors if it allows
+    // one, else one event popped by a wave reduction and handled on lane 0; the loop decision travels
+    // through a lane-0 broadcast (no LDS flags, no barrier per event).
     uint64_t t_slow = 0;
     int status;
     EVP_DECL;
@@ -3657,7 +3496,7 @@ SSS_DEV void resume_simulation() {
         const bool tf = info_kind(info_win) == EV_TASK_FINISHED;
         const bool tasks_left = tf && f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0;
         if (tasks_left) {
-          handled = fast_run(f, ex, t_win);
+          handled = fast_run(f);
         } else {
 #ifndef SSS_NO_BATCH
           if (64 - g_sc.rng_pos < rng_need) {

@@ -13,7 +13,7 @@ void launch(int grid, const std::function<void()>& body);
 }
 
 #ifdef SSS_BATCH_STATS
-extern "C" { long long sss_batch_stats[64]; }
+extern "C" { long long sss_batch_stats[128]; }
 #endif
 #include "sss_sim.h"
 #include "sss_decima.h"

@@ -1,4 +1,4 @@
-"""The lane-parallel event batches of the event loop (csrc/sss_sim.h batch_fast_events) and the
+"""The fast run and the lane-parallel event batches of the event loop (csrc/sss_sim.h fast_run, batch_*_events) and the
 pre-generated PCG64 stream they draw from (rng_refill), under the CPU wave emulator.
 
 * whole episodes in long launches (the job cache is only rebuilt at launch boundaries, so slots are
@@ -108,3 +108,38 @@ def test_jump_table_is_numpys_advance():
         ref = np.random.PCG64(12345)
         ref.advance(k % (1 << 128))
         assert got == int(ref.state["state"]["state"]), k
+
+
+def test_level_threshold_table_is_the_reference_expression():
+    """sss_host.h sss_build_lvl_thr through its test export: with n local executors strictly between two executor
+    levels the reference draws `rand_pt = 1 + int(rng.random() * (right - left))` and keeps the lower level iff
+    `rand_pt <= n - left` (data_samplers/tpch.py:222-229); rng.random() is (x >> 11) * 2**-53 for the raw output x.
+    The table says: the upper level exactly when (x >> 11) >= thr[n]. Checked with numpy's float64 arithmetic on both
+    sides of every threshold, on random mantissas, and against Generator.random() itself."""
+    lib = load_emu()
+    tab = (C.c_uint64 * 101)()
+    lib.sss_test_lvl_thr_table(tab)
+    thr = [int(x) for x in tab]
+    levels = [5, 10, 20, 40, 50, 60, 80, 100]
+
+    def upper(m, n, left, right):
+        u = np.float64(m) * np.float64(2.0 ** -53)
+        rand_pt = 1 + int(u * np.float64(right - left))
+        return not (np.float64(rand_pt) <= np.float64(n) - np.float64(left))
+
+    rng = np.random.default_rng(7)
+    for n in range(1, 101):
+        enclosing = [(a, b) for a, b in zip(levels, levels[1:]) if a < n < b]
+        if n <= 5 or n in levels or not enclosing:
+            assert thr[n] == 1 << 53, n  # closed interval: never the upper level (and no draw at all)
+            continue
+        left, right = enclosing[0]
+        t = thr[n]
+        assert 0 < t < (1 << 53)
+        assert not upper(t - 1, n, left, right) and upper(t, n, left, right), n
+        for m in [0, 1, (1 << 53) - 1] + [int(x) for x in rng.integers(0, 1 << 53, 200)]:
+            assert upper(m, n, left, right) == (m >= t), (n, m)
+    # the mantissa really is what Generator.random() uses
+    g1, g2 = np.random.Generator(np.random.PCG64(99)), np.random.PCG64(99)
+    raw = g2.random_raw(50)
+    assert [float(np.float64(int(x) >> 11) * 2.0 ** -53) for x in raw] == [float(g1.random()) for _ in range(50)]

@@ -13,6 +13,10 @@ NAMES = {0: "batch_released_events", 1: "trk_add_commitment", 2: "trk_remove_com
          28: "do_step", 29: "run_policy", 30: "fast_run (per EVENT)", 31: "handle_popped"}
 CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
        "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
+import os
+if os.environ.get("SSS_SECTIONS"):
+    NAMES.update({1: "rel: reads .. first exit", 2: "rel: commitment scan", 3: "rel: classify", 4: "rel: window + ranking", 5: "rel: draws + lane commit", 6: "rel: lane-0 commitments",
+                  7: "rel: per-lane pool records", 8: "rel: pools_staged", 9: "rel: sched clear", 10: "rel: sat bits", 11: "rel: send cache_acquire"})
 lib = load_library()
 buf = (C.c_ulonglong * 64)()
 mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
