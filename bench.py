@@ -2,7 +2,7 @@
 """Throughput benchmark of the hot path: env-steps/s of the batched Spark-scheduling simulator.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs B] [--config c2|c3] [--policy hash|fair]
-                    [--mode step|fused] [--no-cpu-baseline] [--no-c3] [--no-decima]
+                    [--mode step|fused] [--no-cpu-baseline] [--no-c3] [--no-decima] [--sustained-s S]
 
 A "step" is ONE batched step of all envs of a rank: on-device policy kernel + step kernel
 (`--mode step`, the drop-in boundary: sss_policy + sss_step per step), or one iteration of the
@@ -23,7 +23,8 @@ trainers/trainer.py:113-121). Weak scaling.
 Prints ONE JSON line on rank 0 (see the driver contract) including `roofline` (SURVEY 8(d) model
 bytes of the dominant kernel / its HIP-event-measured duration / 8 TB/s), `cpu_baseline` (the C
 oracle, oracle/sss_oracle.c, timed on this box's host on a bounded sample), `step_tail` (how much
-of a step launch is the wait for its slowest env) and, at N = 1, a `c3` record with the same
+of a step launch is the wait for its slowest env), `sustained` (the same mode over about a second
+of stepping when the K timed steps are shorter than that) and, at N = 1, a `c3` record with the same
 measurements on BASELINE config 3 (4096 envs, 50 executors, 200 jobs, fair policy).
 """
 from __future__ import annotations
@@ -303,6 +304,9 @@ class Bench:
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel, self.config, self.B, evps),
+                # `traffic` is NOT measured in this run: rocprofv3 cannot wrap itself around a region of a running
+                # process, so the PMC passes are separate runs of this kernel / config (tools/collect_traffic.py)
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this kernel and config, same events per step within 15 %; null if none)",
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                 "kernel_time_frac_of_wall": (kern_ms_all / self.world) * 1e-3 / dt_max,
             },
@@ -368,8 +372,8 @@ def main() -> None:
                          "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
     ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--evprof", action="store_true", help="library built with -DSSS_EVPROF (tools/evprof.sh): report ticks per event-loop round segment")
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of the single-core CPU leg (the all-core and config-3 legs take at most half of it each)")
+    ap.add_argument("--sustained-s", type=float, default=1.2, help="a second, longer timed region in the same mode when the K timed steps last less than this (0: off)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); 'gloo' only for plumbing tests")
     ap.add_argument("--device-index", type=int, default=None, help="override LOCAL_RANK -> device mapping (plumbing tests on one GPU)")
     args = ap.parse_args()
@@ -399,21 +403,19 @@ def main() -> None:
     bench = Bench(args, args.config, policy, B, dev, rank, world)
     cfg = bench.cfg
 
-    ev0 = bench.counters() if args.evprof else None
     primary = bench.measure(args.mode, args.steps, args.warmup)
-    evprof = None
-    if args.evprof:
-        ev1 = bench.counters()
-        dd = {k: ev1[k] - ev0[k] for k in ev1}
-        rounds = max(1, dd["evprof_rounds"])
-        evprof = {"rounds_per_step": rounds / max(1, dd["n_steps"]), "batch_rounds_per_step": dd["n_rounds"] / max(1, dd["n_steps"]),
-                  "ticks_per_round": {"batch_classify_or_early_exit": dd["ticks_slow_events"] / rounds, "batch_member_loop": dd["ticks_action"] / rounds,
-                                      "batch_draw_commit": dd["ticks_events"] / rounds, "single_pop": dd["ticks_reward"] / rounds,
-                                      "single_handler": dd["ticks_observe"] / rounds, "rng_refill": dd["evprof_refill"] / rounds},
-                  "ticks_per_step_total": sum(dd[k] for k in ("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe", "evprof_refill")) / max(1, dd["n_steps"])}
+    # K timed steps can be a few milliseconds (the driver runs --steps 20): the same measurement over a region of
+    # about a second next to it, so that the line also carries a figure that does not depend on which 20 steps it met
+    sustained = None
+    if args.sustained_s > 0 and primary["ms_per_step"] * args.steps < 1e3 * args.sustained_s:
+        k_long = int(min(200_000, max(args.steps + 1, 1e3 * args.sustained_s / max(1e-3, primary["ms_per_step"]))))
+        long_run = bench.measure(args.mode, k_long, 0)
+        sustained = {"value": long_run["value"], "unit": "env-steps/s", "steps": k_long, "ms_per_step": long_run["ms_per_step"], "mode": args.mode,
+                     "events_per_step": long_run["events_per_step"], "roofline": long_run["roofline"],
+                     "what": f"same mode, same envs, {k_long} timed batched steps right after the K = {args.steps} of `value`"}
     other_mode = "fused" if args.mode == "step" else "step"
     secondary = None if args.single_mode else bench.measure(other_mode, args.steps, args.warmup)
-    tail = bench.step_tail() if (world == 1 and args.shards == 1 and not args.evprof) else None
+    tail = bench.step_tail() if (world == 1 and args.shards == 1) else None
 
     if world > 1:
         # the one exchange of the path: all-gather of per-env episode summaries (RCCL)
@@ -458,8 +460,8 @@ def main() -> None:
             "mean_last_episode_return": mean_return,
             "roofline": primary["roofline"],
         }
-        if evprof is not None:
-            out["evprof"] = evprof
+        if sustained is not None:
+            out["sustained"] = sustained
         if tail is not None:
             out["step_tail"] = tail
         if secondary is not None:
@@ -468,28 +470,35 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget)
             try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(6.0, args.cpu_budget))
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(4.0, args.cpu_budget / 2))
             except Exception as e:  # never let the extra baseline take the bench line down
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
     pack = bench.pack
     bench.close()
 
     # BASELINE config 3 next to the headline (N = 1): same measurements, its own roofline and CPU baseline
-    if world == 1 and args.config == "c2" and not args.no_c3 and not args.evprof and args.shards == 1:
+    if world == 1 and args.config == "c2" and not args.no_c3 and args.shards == 1:
         try:
             b3 = Bench(args, "c3", DEFAULT_POLICY["c3"], B, dev, rank, world)
             k3, w3 = max(10, min(args.steps, 300)), max(5, min(args.warmup, 50))
             r3 = b3.measure("step", k3, w3)
             f3 = b3.measure("fused", k3, w3)
+            s3 = None
+            if args.sustained_s > 0 and r3["ms_per_step"] * k3 < 1e3 * args.sustained_s:
+                k3_long = int(min(200_000, max(k3 + 1, 1e3 * args.sustained_s / max(1e-3, r3["ms_per_step"]))))
+                l3 = b3.measure("step", k3_long, 0)
+                s3 = {"value": l3["value"], "unit": "env-steps/s", "steps": k3_long, "ms_per_step": l3["ms_per_step"], "mode": "step", "roofline": l3["roofline"]}
             rec = {"what": f"BASELINE config 3: {B} envs x (50 executors, 200 jobs), fair policy, steady state; {k3} timed batched steps after {w3} warm-up steps",
                    "value": r3["value"], "unit": "env-steps/s", "ms_per_step": r3["ms_per_step"], "events_per_step": r3["events_per_step"],
                    "fast_path_event_frac": r3["fast_path_event_frac"], "batched_event_frac": r3["batched_event_frac"], "events_per_batch": r3["events_per_batch"],
                    "phase_ticks_per_step": r3["phase_ticks_per_step"], "roofline": r3["roofline"], "step_tail": b3.step_tail(12),
                    "other_mode": dict(f3, mode="fused"), "mean_last_episode_return": b3.header_field("last_ep_return").mean().item()}
             b3.close()
+            if s3 is not None:
+                rec["sustained"] = s3
             if not args.no_cpu_baseline:
-                rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(6.0, args.cpu_budget))
-                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(6.0, args.cpu_budget))
+                rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2))
+                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2))
             out["c3"] = rec
         except Exception as e:
             out["c3"] = {"error": repr(e)}

@@ -141,3 +141,16 @@ class Binding:
         h = C.c_void_p()
         self.check(self.lib.sss_create(C.byref(cfg), pack, len(pack), num_envs, device, C.byref(h)))
         return h
+
+
+def device_of(dev):
+    """context manager: `dev` is the current device while inside (no-op for CPU tensors, i.e. the emulator
+    tests). The entry points of include/sss.h that take no env handle (sss_prefix_rows, sss_gnn_launch,
+    sss_decima_sample, sss_decima_layer_lists) launch on the CURRENT device's stream; their callers make
+    the device of the tensors they pass current, so that a caller whose own current device is another GPU
+    (several envs / policies in one process) still works."""
+    import contextlib
+
+    import torch
+    dev = torch.device(dev)
+    return torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()

@@ -170,44 +170,7 @@ extern "C" { extern long long sss_batch_stats[128]; }
 #define STAT(i, v) ((void)0)
 #endif
 
-// -DSSS_EVPROF3 (tools/debug/evprof3.sh): inclusive shader-clock ticks and call counts of the lane-0
-// procedures, in a device-global table read back through sss_debug_prof (timing builds only)
-#ifdef SSS_EVPROF3
-__device__ unsigned long long g_prof3[64];
-__device__ unsigned long long g_prof3_min;  // only launches whose do_step took at least this long are recorded (tail census)
-SSS_SHARED unsigned long long g_prof3_lds[64];  // per-wave totals, added to the table once per launch (prof3_flush)
-struct Prof3Scope {
-  int id;
-  uint64_t t0;
-  __device__ Prof3Scope(int i) : id(i), t0(wave_clock()) {}
-  __device__ ~Prof3Scope() {
-    if (wave_lane() == 0) g_prof3_lds[2 * id] += wave_clock() - t0, g_prof3_lds[2 * id + 1] += 1;
-  }
-};
-#ifdef SSS_EVPROF3B  // experiment: ids 1..12 time the sections of batch_released_events instead of the lane-0 procedures
-#define PROF3(id) Prof3Scope prof3_scope_##id((id) >= 1 && (id) <= 12 ? 63 : (id))
-#define PROF3_SEC_BEGIN uint64_t prof3_sec_t = wave_clock()
-#define PROF3_SEC(id) do { uint64_t now_ = wave_clock(); if (wave_lane() == 0) g_prof3_lds[2 * (id)] += now_ - prof3_sec_t, g_prof3_lds[2 * (id) + 1] += 1; prof3_sec_t = now_; } while (0)
-#else
-#define PROF3(id) Prof3Scope prof3_scope_##id(id)
-#define PROF3_SEC_BEGIN ((void)0)
-#define PROF3_SEC(id) ((void)0)
-#endif
-#define PROF3_CALLS(id, n) ((void)(wave_lane() == 0 ? (g_prof3_lds[2 * (id) + 1] += (n)) : 0))  // count units of work instead of calls
-SSS_DEV void prof3_clear() { g_prof3_lds[wave_lane()] = 0; }
-SSS_DEV void prof3_flush() {
-  wave_sync();
-  if (g_prof3_lds[2 * 28] < g_prof3_min) return;
-  if (g_prof3_lds[wave_lane()]) atomicAdd(&g_prof3[wave_lane()], g_prof3_lds[wave_lane()]);
-}
-#else
-SSS_DEV void prof3_clear() {}
-SSS_DEV void prof3_flush() {}
-#define PROF3(id) ((void)0)
-#define PROF3_CALLS(id, n) ((void)0)
-#define PROF3_SEC_BEGIN ((void)0)
-#define PROF3_SEC(id) ((void)0)
-#endif
+#include "sss_prof.h"  // PROF3 scopes: empty unless a timing build defines SSS_EVPROF3
 
 // ---- LDS pool views ----
 #define LENW_LEN 0x3FFFFFFF  // list length in a duration descriptor (bit 30: warmup_delay is added)
@@ -372,7 +335,7 @@ SSS_DEV uint32_t ss_mix(uint32_t x, uint32_t y) {
 }
 
 // Generator(PCG64(SeedSequence(seed))): gymnasium's Env.reset(seed) (ENV:130)
-SSS_DEV_NOINLINE void rng_seed(SssHdr& h, uint64_t seed) {
+SSS_DEV void rng_seed(SssHdr& h, uint64_t seed) {
   uint32_t ent0 = (uint32_t)seed, ent1 = (uint32_t)(seed >> 32);
   int n_ent = ent1 ? 2 : 1;
   uint32_t pool[4];
@@ -409,7 +372,7 @@ SSS_DEV_NOINLINE void rng_seed(SssHdr& h, uint64_t seed) {
 }
 
 // FDLIBM s_log1p.c as evaluated by glibc 2.35 (split polynomial); domain here is (-1, 0]
-SSS_DEV_NOINLINE double fd_log1p(double x) {
+SSS_DEV double fd_log1p(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, two54 = 1.80143985094819840000e+16,
                Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
@@ -484,7 +447,7 @@ SSS_DEV_NOINLINE double fd_log1p(double x) {
 }
 
 // FDLIBM e_exp.c for finite x <= 0 (wedge test of the ziggurat; discounted rewards)
-SSS_DEV_NOINLINE double fd_exp(double x) {
+SSS_DEV double fd_exp(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
                P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
                P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
@@ -519,7 +482,7 @@ SSS_DEV_NOINLINE double fd_exp(double x) {
   return y * 9.33263618503218878990e-302;
 }
 
-SSS_DEV_NOINLINE double rng_standard_exponential() {
+SSS_DEV double rng_standard_exponential() {
   for (;;) {
     uint64_t ri = rng_next64();
     ri >>= 3;
@@ -875,19 +838,6 @@ SSS_DEV uint32_t trk_peek_commitment(uint32_t src) {
   return dst;
 }
 
-#ifdef SSS_EVPROF2
-#define EVP2_BEGIN uint64_t evp2_t0 = wave_clock()
-#define EVP2_END(i) g_hot.h.pad_[i] += wave_clock() - evp2_t0
-#else
-#define EVP2_BEGIN ((void)0)
-#define EVP2_END(i) ((void)0)
-#endif
-SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send);
-SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {
-  EVP2_BEGIN;
-  trk_move_executor_to_pool_(e, new_pool, send);
-  EVP2_END(0);
-}
 // ---- 8-slot set images held in a register (mask == 7: LINEAR_PROBES never applies, i + 9 > mask) ----
 SSS_DEV uint32_t t8_get(uint64_t t, uint32_t i) { return (uint32_t)(t >> (8 * i)) & 0xFFu; }
 SSS_DEV uint64_t t8_set(uint64_t t, uint32_t i, uint32_t v) { return (t & ~(0xFFull << (8 * i))) | ((uint64_t)v << (8 * i)); }
@@ -927,7 +877,7 @@ SSS_DEV bool set8_add(uint64_t& t, uint32_t& fill, uint32_t& used, uint32_t key)
   return fill * 5 >= 7 * 3;
 }
 
-SSS_DEV void trk_move_executor_to_pool_(int e, uint32_t new_pool, bool send) {  // TRK:188-222
+SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  // TRK:188-222
   PROF3(3);
   SssHot& hot = g_hot;
   uint32_t old = hot.ex_loc[e];
@@ -1107,7 +1057,7 @@ SSS_DEV bool job_passes_filter(int j, int source_job_id) {
 }
 
 // ENV:821-845 -> (job, stage) or job = -1
-SSS_DEV_NOINLINE void find_backup_stage(int e, int& out_j, int& out_s) {
+SSS_DEV void find_backup_stage(int e, int& out_j, int& out_s) {
   PROF3(6);
   out_j = -1, out_s = -1;
   int ejob = g_hot.ex_job[e];
@@ -1212,14 +1162,7 @@ SSS_DEV void publish_idle_mask() {
   uint64_t m = wave_ballot(lane < g_c.E && key != POOL_NONE && g_hot.ex_loc[lane] == key && !g_hot.ex_executing[lane]);
   if (lane == 0) g_sc.idle_key = key, g_sc.idle_mask = m, g_sc.idle_valid = 1;
 }
-SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key);
-SSS_DEV_NOINLINE SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
-  EVP2_BEGIN;
-  SetImg<uint8_t> r = get_idle_source_executors_(key);
-  EVP2_END(1);
-  return r;
-}
-SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
+SSS_DEV SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
   PROF3(9);
   SetImg<uint8_t> out;
   out.tab = g_sc.setB;
@@ -1287,7 +1230,7 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors_(uint32_t key) {
 }
 
 // ENV:745-782 with executor_ids=None: all idle executors of `src`, in set order
-SSS_DEV_NOINLINE void move_idle_executors_all(uint32_t src) {
+SSS_DEV void move_idle_executors_all(uint32_t src) {
   PROF3(10);
   if (src == POOL_NONE) src = H.curr_source;
   CHECK(src != POOL_NONE);
@@ -1315,7 +1258,7 @@ SSS_DEV_NOINLINE void move_idle_executors_all(uint32_t src) {
   }
 }
 
-SSS_DEV_NOINLINE void move_executor_to_stage(int e, int j, int s) {  // ENV:784-819
+SSS_DEV void move_executor_to_stage(int e, int j, int s) {  // ENV:784-819
   PROF3(11);
   if ((*stgp(j, s)).remaining == 0) {
     // _try_backup_schedule
@@ -1358,7 +1301,7 @@ SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
 // ENV:730-743, first half (lane 0): the source's commitments in insertion order (dict copy, TRK:133-134) and the idle
 // executors that will fulfil them, in set.pop() order. What each pop yields does not depend on the
 // fulfilments, so the list is complete before the first executor moves.
-SSS_DEV_NOINLINE void fulfil_build_list() {
+SSS_DEV void fulfil_build_list() {
   PROF3(12);
   SssHot& hot = g_hot;
   uint32_t src = H.curr_source;
@@ -1391,7 +1334,7 @@ SSS_DEV_NOINLINE void fulfil_build_list() {
 }
 
 // ENV:730-743, second half, one executor at a time (lane 0): items [from, fi_m) of the list
-SSS_DEV_NOINLINE void fulfil_serial_range(int from, int to) {
+SSS_DEV void fulfil_serial_range(int from, int to) {
   for (int i = from; i < to && !H.err; i++) fulfill_commitment((int)g_sc.fi_e[i], g_sc.fc_dst[g_sc.fi_k[i]]);
 }
 SSS_DEV void fulfil_serial(int from) { fulfil_serial_range(from, g_sc.fi_m); }
@@ -1787,7 +1730,7 @@ SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
   move_executor_to_stage(e, j, s);
 }
 
-SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
+SSS_DEV void process_job_completion(int j) {  // ENV:682-697
   PROF3(15);
   if (pool_size(key_job_pool(j)) > 0) move_idle_executors_all(key_job_pool(j));
   CHECK(pool_size(key_job_pool(j)) == 0);
@@ -1814,7 +1757,7 @@ SSS_DEV_NOINLINE void process_job_completion(int j) {  // ENV:682-697
   }
 }
 
-SSS_DEV_NOINLINE void handle_task_completion(int e, int j, int s) {  // ENV:452-483
+SSS_DEV void handle_task_completion(int e, int j, int s) {  // ENV:452-483
   PROF3(16);
   SssStage& st = (*stgp(j, s));
   CHECK(!stage_completed(st));
@@ -1908,31 +1851,6 @@ SSS_DEV void fastctx_load(FastCtx& f) {
   f.eff = g_c.pk.eff, f.durations = g_c.pk.durations, f.SP = g_c.SP, f.E = g_c.E;
 }
 
-
-// -DSSS_EVPROF (tools/evprof.sh): shader-clock ticks of the segments of an event-loop round, kept in
-// the header's profiling slots instead of the per-phase totals (timing builds only)
-#ifdef SSS_EVPROF
-struct EvProf {
-  uint64_t t[8];
-  uint64_t last;
-};
-#define EVP_DECL EvProf evp = {{0, 0, 0, 0, 0, 0, 0, 0}, wave_clock()}
-#define EVP_ARG , EvProf& evp
-#define EVP_PASS , evp
-#define EVP_MARK(i)                  \
-  do {                               \
-    uint64_t now_ = wave_clock();    \
-    evp.t[i] += now_ - evp.last;     \
-    evp.last = now_;                 \
-  } while (0)
-#define EVP_COUNT(i) (evp.t[i]++)
-#else
-#define EVP_DECL
-#define EVP_ARG
-#define EVP_PASS
-#define EVP_MARK(i) ((void)0)
-#define EVP_COUNT(i) ((void)0)
-#endif
 
 // the duration lists an executor that stays on pack stage `gs` can draw from next ("same stage"
 // mode of TPCH:75-106): one per candidate executor level (li == ri when the interval is closed)
@@ -3041,9 +2959,7 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
     oi[OBS_NUM_COMMITTABLE] = ncommit, oi[OBS_SOURCE_JOB_IDX] = src_idx;
     oi[OBS_TERMINATED] = h.terminated, oi[OBS_ERR] = h.err;
     of[OBS_REWARD] = reward, of[OBS_WALL_TIME] = h.wall_time;
-#ifndef SSS_EVPROF
     g_hot.h.prof[4] += wave_clock() - t_obs0;
-#endif
     g_hot.h.obs_n_nodes = base_n;
     g_hot.h.obs_graph_version = h.graph_version, g_hot.h.obs_n_edges = base_e, g_hot.h.obs_bind_gen = B.gen;
     g_hot.h.obs_n_sched = h.n_sched;
@@ -3243,7 +3159,7 @@ SSS_DEV void select_stage_wave(int stage_idx) {
 }
 
 // ENV:275-315. Returns false if the action was rejected (state untouched).
-SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
+SSS_DEV bool take_action(int stage_idx, int num_exec) {
   PROF3(17);
   // action_space.contains: stage_idx in [-1, n_nodes), num_exec in [1, E] (ENV:85-94, 404)
   if (stage_idx < -1 || stage_idx >= H.obs_n_nodes || num_exec < 1 || num_exec > g_c.E) {
@@ -3285,7 +3201,7 @@ SSS_DEV_NOINLINE bool take_action(int stage_idx, int num_exec) {
 // ENV:847-874. The float sum runs in CPython set(list + list) iteration order: lane 0 builds the
 // set image (jobtime_build_set), then all lanes evaluate one table slot each and the terms are
 // added in slot order (jobtime_sum) - the additions stay sequential, the HBM reads do not.
-SSS_DEV_NOINLINE void jobtime_build_set() {
+SSS_DEV void jobtime_build_set() {
   PROF3(18);
   SetImg<uint16_t> all;
   all.tab = lds_jobset();
@@ -3399,26 +3315,6 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
     // everything else goes through the out-of-line handlers
     if (fast < 0) FAIL(SSS_ERR_NO_DURATION);
     uint64_t ts0 = wave_clock();
-#ifdef SSS_TAILSTAT  // debug builds (tools/debug/tailstat.sh): which events still go one at a time and why, 16-bit counters in pad_[0..1]
-    {
-      int kind = 0;  // job arrival
-      if (ex != POP_ARRIVAL && fast >= 0) {
-        const SssEvSlot sl0 = g_hot.ev[ex];
-        const int jj = info_job(sl0.info), ss = info_stage(sl0.info);
-        const SssStage st0 = *stgp(jj, ss);
-        if (info_kind(sl0.info) == EV_EXECUTOR_READY) {
-          kind = 1;
-          // why not in a batch: no slot named / stage out of tasks / source conflict / other (single, cut, lists, randomness)
-          const bool in_front = (jobp(jj)->frontier_mask & bit64(ss)) != 0;
-          const uint32_t ent = in_front ? key_stage_pool(jj, ss) : key_job_pool(jj);
-          const int why = info_slot(sl0.info) == INFO_SLOT_NONE ? 0 : (st0.remaining == 0 ? 1 : ((H.curr_source != POOL_NONE && H.curr_source == ent) ? 2 : 3));
-          H.pad_[1] += 1ull << (16 * why);
-        } else
-          kind = st0.remaining > 0 ? 3 : (st0.executing <= 1 ? 2 : 3);  // 2: completes its stage; 3: other task completions
-      }
-      H.pad_[0] += 1ull << (16 * kind);
-    }
-#endif
     if (fast < 0) {
     } else if (ex == POP_ARRIVAL) {
       int job = H.next_arrival;
@@ -3478,16 +3374,13 @@ SSS_DEV void resume_simulation() {
     // through a lane-0 broadcast (no LDS flags, no barrier per event).
     uint64_t t_slow = 0;
     int status;
-    EVP_DECL;
     do {
       status = 0;
-      EVP_COUNT(6);
       // the head of the queue decides what kind of round this is
       double t_win = 0.0;
       uint32_t info_win = 0;
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
-      EVP_MARK(3);
       if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {
         int handled = 0;
         // tasks left in its stage: a run of such events (fast_run produces the randomness it needs itself); when it
@@ -3501,29 +3394,19 @@ SSS_DEV void resume_simulation() {
 #ifndef SSS_NO_BATCH
           if (64 - g_sc.rng_pos < rng_need) {
             rng_refill();
-            EVP_MARK(5);
           }
 #endif
           handled = tf ? batch_released_events(f, ex) : batch_arrival_events(f, ex);
         }
-        EVP_MARK(0);  // a round the batch path left early is charged to its first segment
         if (handled > 0) continue;
         // nothing was touched: the popped event goes the one-at-a-time way, which is always right
       }
       if (lane == 0) status = handle_popped(f, ex, t_win, info_win, t_slow);
       status = (int)wave_lane0_u32((uint32_t)status);
-      EVP_MARK(4);
     } while (status == 0);
     if (lane == 0) {
       g_sc.f_done = status == 1, g_sc.f_scan = status == 2;
-#ifdef SSS_EVPROF
-      for (int i = 0; i < 5; i++) H.prof[i] += evp.t[i];
-#ifndef SSS_EVPROF2
-      H.pad_[0] += evp.t[5], H.pad_[1] += evp.t[6];
-#endif
-#else
       H.prof[0] += t_slow;
-#endif
     }
     wave_sync();
     if (g_sc.f_done) {
@@ -3737,9 +3620,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   if (lane == 0 && H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
   wave_sync();
   uint64_t t1 = wave_clock();
-#ifndef SSS_EVPROF
   if (lane == 0) H.prof[1] += t1 - t0;
-#endif
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
   for (int a = lane; a < g_hot.h.n_active; a += 64) {  // ENV:203 selected_stages.clear(); active jobs at the round's end
     int j = lds_active()[a];
@@ -3778,9 +3659,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     }
     if (H.err) H.need_reset = 1;
     uint64_t t3 = wave_clock();
-#ifndef SSS_EVPROF
     H.prof[2] += t2 - t1, H.prof[3] += t3 - t2;
-#endif
   }
   wave_sync();
   return reward;

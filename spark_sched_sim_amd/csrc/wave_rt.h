@@ -8,9 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define SSS_DEV __device__ __forceinline__
 // everything is inlined into the kernels: the kernel-argument segment pointer (SSS_KERNARG_PTR) is null in callees
-#define SSS_DEV_NOINLINE __device__ __forceinline__
+#define SSS_DEV __device__ __forceinline__
 #define SSS_KERNEL extern "C" __global__ __launch_bounds__(64, 4)
 #define SSS_SHARED __shared__
 #define SSS_SHARED_DYN(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]

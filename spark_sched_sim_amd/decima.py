@@ -428,14 +428,15 @@ class DecimaPolicy(nn.Module):
     def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, **ptrs) -> None:
         import ctypes
 
-        from .binding import GNN_KINDS, SssGnnArgs
+        from .binding import GNN_KINDS, SssGnnArgs, device_of
         a = SssGnnArgs()
         a.n_rows, a.w_dev, a.slope, a.num_executors, a.layer, a.n_pad = int(n_rows), w.data_ptr(), self._packed[2], self.num_executors, layer, n_pad
         for k, t in ptrs.items():
             setattr(a, k + "_dev", t.data_ptr() if t is not None and t.numel() else None)
         dev = w.device
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        self._kb.check(self._kb.lib.sss_gnn_launch(GNN_KINDS[kind], ctypes.byref(a), stream))
+        with device_of(dev):  # (no handle in this entry point: it launches on the current device)
+            self._kb.check(self._kb.lib.sss_gnn_launch(GNN_KINDS[kind], ctypes.byref(a), stream))
 
     def _use_kernels(self, g: dict[str, Any] | None = None) -> bool:
         if getattr(self, "_kb", None) is None or (g is not None and "out_start" not in g):
@@ -496,7 +497,7 @@ class DecimaPolicy(nn.Module):
         (seed = the generator's, counter = number of calls so far)"""
         import ctypes
 
-        from .binding import SssDecimaSampleArgs
+        from .binding import SssDecimaSampleArgs, device_of
         B, E, dev = g["n_obs"], self.num_executors, padded.device
         self._calls = getattr(self, "_calls", 0) + 1
         i64 = lambda: torch.empty(B, dtype=torch.int64, device=dev)  # noqa: E731
@@ -512,10 +513,12 @@ class DecimaPolicy(nn.Module):
                                 stage_idx.data_ptr(), num_exec.data_ptr(), out["stage_sel"].data_ptr(), out["job_idx"].data_ptr(),
                                 out["exec_sel"].data_ptr(), out["lgprob"].data_ptr(), out["any_stage"].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
+        with device_of(dev):
+            self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
         self._launch("exec", B * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
                      idx0=job_gid, job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
-        self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
+        with device_of(dev):
+            self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
         out["env_stage_idx"], out["env_num_exec"] = stage_idx, num_exec
         out["rng"] = (a.rng_seed, a.rng_counter)
         if scores_out is not None:

@@ -47,14 +47,22 @@ def all_gather_episode_summaries(env, group=None) -> torch.Tensor:
     return torch.cat(out, dim=0)
 
 
-def launch_ranks(world_size: int, argv: list[str], port: int | None = None, env: dict | None = None) -> int:
+def launch_ranks(world_size: int, argv: list[str], port: int | None = None, env: dict | None = None,
+                 timeout: float | None = None, grace: float = 5.0) -> int:
     """Starts `world_size` fresh Python processes running `argv` (script + arguments), one rank per
     GPU, with the torch.distributed environment set (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR =
     127.0.0.1, MASTER_PORT) - the stand-in for the reference's own worker start-up
     (trainers/trainer.py:264-293 spawns its rollout processes itself). The caller must not have
     touched the GPU: every rank is a new process, nothing is exec'ed over an initialised one.
     Rank 0 inherits stdout (it prints the result), the other ranks' stdout goes to stderr.
-    Returns the first non-zero exit code, else 0."""
+
+    All ranks are watched together: when one exits with a non-zero code, or `timeout` seconds pass,
+    the ranks still running are terminated (SIGTERM, SIGKILL after `grace` seconds) - a rank that died
+    at start-up would otherwise leave its siblings in `init_process_group` / a collective until the
+    backend's own timeout. Only these children are signalled (by pid). Returns the first non-zero exit
+    code seen, 124 after a timeout, else 0."""
+    import time
+
     if port is None:
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -66,8 +74,36 @@ def launch_ranks(world_size: int, argv: list[str], port: int | None = None, env:
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=None if rank == 0 else sys.stderr))
+
+    def stop_rest() -> None:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_end = time.monotonic() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0 = time.monotonic()
     rc = 0
-    for p in procs:
-        r = p.wait()
-        rc = rc or r
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                print(f"[launch_ranks] rank {codes.index(bad[0])} exited with code {bad[0]}: stopping the other ranks", file=sys.stderr)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                rc = 124
+                print(f"[launch_ranks] {timeout:.0f} s passed: stopping {sum(c is None for c in codes)} running rank(s)", file=sys.stderr)
+                break
+            time.sleep(0.05)
+    finally:
+        stop_rest()
     return rc

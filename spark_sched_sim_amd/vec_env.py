@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import workload
-from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg, SssDecimaGraph, SssDecimaLists
+from .binding import ERROR_NAMES, POLICY_IDS, Binding, SssBuffers, SssCfg, SssDecimaGraph, SssDecimaLists, device_of
 
 OBS_FIELDS = ("n_nodes", "n_edges", "n_jobs", "n_schedulable", "num_committable_execs", "source_job_idx",
               "terminated", "err")
@@ -209,8 +209,9 @@ class VecSparkSchedSimEnv:
         act8 = active.to(torch.uint8).contiguous() if active is not None else None
         scan = torch.empty((2, 3, B), dtype=torch.int64, device=dev)
         tot = torch.empty(3, dtype=torch.int64, device=dev)
-        self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 3, B,
-                                                 scan[0].data_ptr(), scan[1].data_ptr(), tot.data_ptr(), self._stream()))
+        with device_of(dev):  # (sss_prefix_rows takes no handle: it launches on the CURRENT device)
+            self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 3, B,
+                                                     scan[0].data_ptr(), scan[1].data_ptr(), tot.data_ptr(), self._stream()))
         off, cnt_t = scan[0], scan[1]  # [3, B] each
         M, Ed, J = (int(v) for v in tot.tolist())
         # buffers hold at least one element so that their pointers are never NULL; `g` gets exact views
@@ -258,7 +259,8 @@ class VecSparkSchedSimEnv:
             tot = torch.empty(32, dtype=torch.int64, device=dev_l)
             b = g["_binding"]
             stream = torch.cuda.current_stream(dev_l).cuda_stream if dev_l.type == "cuda" else 0
-            b.check(b.lib.sss_prefix_rows(lc.data_ptr(), lc.stride(0), 1, None, 32, lc.shape[1], scan.data_ptr(), None, tot.data_ptr(), stream))
+            with device_of(dev_l):
+                b.check(b.lib.sss_prefix_rows(lc.data_ptr(), lc.stride(0), 1, None, 32, lc.shape[1], scan.data_ptr(), None, tot.data_ptr(), stream))
             totals = tot.tolist()
             n_layers = max((lvl + 1 for lvl, c in enumerate(totals) if c), default=0)
             base = [0] * 32
@@ -269,7 +271,8 @@ class VecSparkSchedSimEnv:
                 env_off = scan  # exclusive prefix of the per-env receiver counts, per layer
                 a = SssDecimaLists(g["obs_node_off"].data_ptr(), g["obs_nodes"].data_ptr(), g["node_recv"].data_ptr(), env_off.data_ptr(),
                                    (C.c_int64 * 32)(*base), recv.data_ptr(), n_layers)
-                b.check(b.lib.sss_decima_layer_lists(g["n_obs"], C.byref(a), stream))
+                with device_of(dev_l):
+                    b.check(b.lib.sss_decima_layer_lists(g["n_obs"], C.byref(a), stream))
                 g["_keepalive_lists"] = env_off
             g["recv_lists"] = [recv[base[lvl]: base[lvl] + totals[lvl]] for lvl in range(n_layers)]
         return g["recv_lists"]
@@ -378,8 +381,6 @@ class VecSparkSchedSimEnv:
         prof = np.ascontiguousarray(hdr[:, HDR_PROF: HDR_PROF + 40]).view(np.uint64).sum(axis=0)
         for k, name in enumerate(("ticks_slow_events", "ticks_action", "ticks_events", "ticks_reward", "ticks_observe")):
             tot[name] = int(prof[k])
-        pad = np.ascontiguousarray(hdr[:, 272:288]).view(np.uint64).sum(axis=0)  # only written by -DSSS_EVPROF builds
-        tot["evprof_refill"], tot["evprof_rounds"] = int(pad[0]), int(pad[1])
         for name in ("n_fast", "n_batched", "n_rounds"):
             off = HDR_OFF[name]
             tot[name + "_events" if name != "n_rounds" else name] = int(np.ascontiguousarray(hdr[:, off: off + 8]).view(np.uint64).sum())

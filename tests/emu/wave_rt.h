@@ -15,7 +15,6 @@
 #include <string.h>
 
 #define SSS_DEV static inline
-#define SSS_DEV_NOINLINE static __attribute__((noinline))
 #define SSS_KERNEL extern "C"
 #define SSS_SHARED static
 #define SSS_SHARED_DYN(name) alignas(16) static uint8_t name[65536]

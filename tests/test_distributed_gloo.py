@@ -206,3 +206,44 @@ def test_bench_starts_its_own_ranks(capfd):
     if r.returncode == 0:
         pytest.skip("a GPU is present: the two ranks ran the bench")
     assert r.stderr.count("bench.py needs an AMD GPU") == 2, r.stderr[-2000:]
+
+
+_FAILING_RANK_SCRIPT = """
+import os, sys, time
+if os.environ["RANK"] == "1":
+    sys.exit(7)            # dies at start-up (bad device, import error, ...)
+time.sleep(600)            # its sibling would wait in init_process_group / a collective
+"""
+
+_HANGING_RANK_SCRIPT = """
+import time
+time.sleep(600)
+"""
+
+
+def test_launch_ranks_stops_the_other_ranks_when_one_fails(tmp_path):
+    """a rank that exits non-zero takes the launch down with its own exit code; the siblings are terminated
+    instead of waiting for the backend's collective timeout"""
+    import time
+
+    sys.path[:0] = [os.path.dirname(HERE)]
+    from spark_sched_sim_amd.distributed import launch_ranks
+
+    script = tmp_path / "rank_fail.py"
+    script.write_text(_FAILING_RANK_SCRIPT)
+    t0 = time.monotonic()
+    assert launch_ranks(2, [str(script)], grace=2.0) == 7
+    assert time.monotonic() - t0 < 60
+
+
+def test_launch_ranks_timeout(tmp_path):
+    import time
+
+    sys.path[:0] = [os.path.dirname(HERE)]
+    from spark_sched_sim_amd.distributed import launch_ranks
+
+    script = tmp_path / "rank_hang.py"
+    script.write_text(_HANGING_RANK_SCRIPT)
+    t0 = time.monotonic()
+    assert launch_ranks(2, [str(script)], timeout=1.0, grace=2.0) == 124
+    assert time.monotonic() - t0 < 60
