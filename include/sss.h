@@ -304,6 +304,15 @@ typedef struct sss_decima_sample_args {
 } sss_decima_sample_args;
 int sss_decima_sample(int n_obs, int which, const sss_decima_sample_args* a, void* stream);
 
+/* The weight and bias gradient of a Linear layer over a minibatch (what autograd's AddmmBackward
+ * computes inside the reference's loss.backward(), trainers/ppo.py:129-131 / schedulers/scheduler.py:44-54):
+ *   gw[n][m] = sum_k dy[k][n] * x[k][m],  gb[n] = sum_k dy[k][n]   for x f32[K][ldx] (M columns used), dy f32[K][ldy]
+ * (N columns used), M, N in 1..64. scratch_dev: f32 workspace of sss_linear_wgrad_scratch(M, N) floats. gb_dev may be
+ * NULL. Launches on the CURRENT device's stream `stream` (no handle). fp32 throughout; the sum runs in a fixed order. */
+int64_t sss_linear_wgrad_scratch(int M, int N);
+int sss_linear_wgrad(const float* x_dev, int64_t ldx, const float* dy_dev, int64_t ldy, int64_t K, int M, int N, float* gw_dev, float* gb_dev,
+                     float* scratch_dev, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

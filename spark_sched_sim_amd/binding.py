@@ -94,7 +94,8 @@ ERROR_NAMES = {
 }
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
-           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch", "sss_last_error", "sss_destroy"]
+           "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -125,6 +126,9 @@ class Binding:
         L.sss_decima_policy.argtypes = [C.c_void_p, C.POINTER(SssDecimaPolicyArgs), C.c_void_p]
         L.sss_decima_sample.argtypes = [C.c_int, C.c_int, C.POINTER(SssDecimaSampleArgs), C.c_void_p]
         L.sss_gnn_launch.argtypes = [C.c_int, C.POINTER(SssGnnArgs), C.c_void_p]
+        L.sss_linear_wgrad_scratch.argtypes = [C.c_int, C.c_int]
+        L.sss_linear_wgrad_scratch.restype = C.c_int64
+        L.sss_linear_wgrad.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
 

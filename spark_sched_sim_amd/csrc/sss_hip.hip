@@ -8,6 +8,7 @@
 #include "sss_decima.h"
 #include "sss_gnn.h"
 #include "sss_decima_policy.h"
+#include "sss_train.h"
 
 #include <stdint.h>
 #include "zig_tables.inc"
@@ -116,6 +117,30 @@ __global__ __launch_bounds__(256) void sss_prefix_rows_kernel(SssPrefixArgs a) {
   __shared__ int64_t part[256];
   prefix_row(a, (int)blockIdx.x, (int)threadIdx.x, 256, part, [] { __syncthreads(); });
 }
+template <int NT>
+static void be_launch_wgrad_nt(const SssWgradArgs& a, int mt, dim3 grid, hipStream_t st) {
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((sss_wgrad_partial_kernel<NT, 1>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((sss_wgrad_partial_kernel<NT, 2>), grid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((sss_wgrad_partial_kernel<NT, 3>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((sss_wgrad_partial_kernel<NT, 4>), grid, dim3(256), 0, st, a); break;
+  }
+}
+static int be_launch_wgrad(const SssWgradArgs& a, void* stream) {
+  const int nt = (a.N + 15) / 16, mt = (a.M + 15) / 16;
+  const dim3 grid((unsigned)a.n_partials);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nt) {
+    case 1: be_launch_wgrad_nt<1>(a, mt, grid, st); break;
+    case 2: be_launch_wgrad_nt<2>(a, mt, grid, st); break;
+    case 3: be_launch_wgrad_nt<3>(a, mt, grid, st); break;
+    default: be_launch_wgrad_nt<4>(a, mt, grid, st); break;
+  }
+  if (int rc = (int)hipGetLastError()) return rc;
+  hipLaunchKernelGGL(sss_wgrad_reduce_kernel, dim3((unsigned)((a.N * a.M + a.N + 15) / 16)), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 static int be_launch_prefix_rows(const SssPrefixArgs& a, void* stream) {
   hipLaunchKernelGGL(sss_prefix_rows_kernel, dim3((unsigned)a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();

@@ -13,6 +13,7 @@
 
 #include "../../include/sss.h"
 #include "sss_layout.h"
+#include "sss_train.h"
 
 static thread_local std::string g_sss_err;
 static int sss_fail(int code, const std::string& msg) {
@@ -499,6 +500,26 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   if (kind == GNN_MERGE && !g->node_recv_dev) return sss_fail(-1, "NULL argument");
   if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
+  return 0;
+}
+
+// the grid of sss_linear_wgrad: at most this many workgroups (4 waves each, 4 per CU) - each writes one partial
+#define SSS_WGRAD_WGS 1024
+extern "C" int64_t sss_linear_wgrad_scratch(int M, int N) {
+  if (M < 1 || N < 1 || M > 64 || N > 64) return 0;
+  return (int64_t)SSS_WGRAD_WGS * (int64_t)(N * M + N);
+}
+extern "C" int sss_linear_wgrad(const float* x_dev, int64_t ldx, const float* dy_dev, int64_t ldy, int64_t K, int M, int N, float* gw_dev, float* gb_dev,
+                                float* scratch_dev, void* stream) {
+  if (!x_dev || !dy_dev || !gw_dev || !scratch_dev) return sss_fail(-1, "NULL argument");
+  if (M < 1 || N < 1 || M > 64 || N > 64) return sss_fail(-29, "sss_linear_wgrad: M and N must be in 1..64");
+  if (K < 0 || ldx < M || ldy < N) return sss_fail(-29, "sss_linear_wgrad: bad row count or leading dimension");
+  SssWgradArgs a;
+  a.x = x_dev, a.dy = dy_dev, a.K = K, a.ldx = ldx, a.ldy = ldy, a.M = M, a.N = N, a.partial = scratch_dev, a.gw = gw_dev, a.gb = gb_dev;
+  // no more workgroups than there are 64-row slabs (at least one: K = 0 still has to write zeros)
+  int64_t slabs = (K + 63) / 64;
+  a.n_partials = (int)(slabs < SSS_WGRAD_WGS ? (slabs > 0 ? slabs : 1) : SSS_WGRAD_WGS);
+  if (int rc = be_launch_wgrad(a, stream)) return sss_fail(-30, std::string("wgrad launch failed: ") + be_error(rc));
   return 0;
 }
 

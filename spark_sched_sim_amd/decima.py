@@ -235,8 +235,9 @@ def make_mlp(input_dim: int, hid_dims: list[int], output_dim: int, act_cls: str,
     layers: list[nn.Module] = []
     prev = input_dim
     dims = list(hid_dims) + [output_dim]
+    from .train_kernels import KernelLinear  # nn.Linear whose weight gradient comes from the hand-written kernel
     for i, d in enumerate(dims):
-        layers.append(nn.Linear(prev, d))
+        layers.append(KernelLinear(prev, d))
         if i < len(dims) - 1:
             layers.append(act(**kwargs))
         prev = d

@@ -95,7 +95,7 @@ class RolloutCollector:
         assert self.base_seeds.shape == (env.num_envs,)
         self.seed_step = int(seed_step)
         self.reset_count = np.zeros(env.num_envs, dtype=np.int64)
-        self.step_counts = torch.zeros(env.num_envs, dtype=torch.long)
+        self.step_counts = torch.zeros(env.num_envs, dtype=torch.long, device=env.device)
         self.E = num_executors
         self.policy = policy
         self.generator = generator
@@ -132,15 +132,20 @@ class RolloutCollector:
         elapsed = torch.zeros(B, dtype=torch.float64, device=dev)
         active = torch.ones(B, dtype=torch.bool, device=dev)
         rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
-        while bool(active.any()):
+        any_active = bool(active.any())
+        while any_active:
             g = self.env.decima_graph(active)  # recorded for training
             a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.act(g, self.generator)
-            self.step_counts += active.cpu().long()
+            self.step_counts += active.long()
             stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
             num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)
             obs, rew, term, trunc, info = self.tl_env.step({"stage_idx": stage_idx.contiguous(), "num_exec": num_exec.contiguous()})
             bad = (info["err"] != 0) & active
-            if bool(bad.any()):
+            done = (term | trunc) & active & ~bad
+            # ONE device->host round trip for everything the loop's control flow needs this step: an env failed / an
+            # episode ended / (sync mode) envs that go on after this step
+            any_bad, any_done, any_left = torch.stack([bad.any(), done.any(), (active & ~bad & ~done).any()]).tolist()
+            if any_bad:
                 self.env_errors += int(bad.sum())
                 if self.on_env_error == "raise":
                     from .binding import ERROR_NAMES
@@ -160,7 +165,6 @@ class RolloutCollector:
                 if not bool(active.any()):
                     break
             new_wall = torch.where(active, info["wall_time"], wall)
-            done = (term | trunc) & active
             rec["g"].append(g)
             rec["active"].append(active)
             rec["rewards"].append(torch.where(active, rew, torch.zeros_like(rew)))
@@ -172,15 +176,17 @@ class RolloutCollector:
                 elapsed = torch.where(active, elapsed + (new_wall - wall), elapsed)
                 rec["t_after"].append(elapsed)
                 rec["resets"].append(done)
-                if bool(done.any()):
+                if any_done:
                     obs = self._reset(mask=done)
                     new_wall = torch.where(done, torch.zeros_like(new_wall), new_wall)
                 active = active & (elapsed < duration)
+                any_active = bool(active.any())
             else:
                 rec["t_before"].append(wall)
                 rec["t_after"].append(new_wall)
                 rec["resets"].append(torch.zeros_like(done))
                 active = active & ~done
+                any_active = any_left
             wall = new_wall
         self._obs, self._wall = obs, wall
         st = lambda k: torch.stack(rec[k]) if rec[k] else torch.zeros((0, B), device=dev)  # noqa: E731

@@ -60,6 +60,24 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
   return 0;
 }
 
+#include "sss_train.h"
+// sss_linear_wgrad on the host (the MFMA kernel is gfx950-only): plain loops, same results up to summation order
+static int be_launch_wgrad(const SssWgradArgs& a, void*) {
+  for (int n = 0; n < a.N; n++) {
+    for (int m = 0; m < a.M; m++) {
+      double s = 0;
+      for (int64_t k = 0; k < a.K; k++) s += (double)a.dy[k * a.ldy + n] * (double)a.x[k * a.ldx + m];
+      a.gw[n * a.M + m] = (float)s;
+    }
+    if (a.gb) {
+      double s = 0;
+      for (int64_t k = 0; k < a.K; k++) s += (double)a.dy[k * a.ldy + n];
+      a.gb[n] = (float)s;
+    }
+  }
+  return 0;
+}
+
 static int be_launch_prefix_rows(const SssPrefixArgs& a, void*) {
   int64_t part[1];
   for (int r = 0; r < a.n_rows; r++) prefix_row(a, r, 0, 1, part, [] {});

@@ -1,6 +1,8 @@
 """SURVEY 8(f) next-2 / next-3 under the CPU wave emulator: rollout collection (sync and async),
 returns, baselines, evaluate_actions, the PPO CLIP loss and one optimiser step against values
 recorded from the reference's own trainer code (tests/golden/make_ppo_golden.py)."""
+import pytest
+
 from emu_util import load_emu
 from training_util import check_async_pipeline, check_sync_pipeline
 
@@ -115,3 +117,25 @@ def test_collector_truncates_a_rollout_whose_env_stalls(pack=None):
             base = sequence_baselines(ro, ret, 1, 2)
             assert torch.isfinite(ret).all() and torch.isfinite(base).all()
         env.close()
+
+
+def test_linear_wgrad_entry_point_on_the_host_backend():
+    """include/sss.h sss_linear_wgrad through the emulator library's host implementation: the argument plumbing of
+    spark_sched_sim_amd.train_kernels.linear_wgrad (strided rows, bias on / off, error codes)"""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+    from spark_sched_sim_amd.train_kernels import linear_wgrad
+
+    b = Binding(load_emu())
+    g = torch.Generator().manual_seed(3)
+    for K, M, N in ((1, 5, 1), (37, 21, 16), (1000, 53, 64), (513, 64, 64)):
+        big = torch.randn((K, M + 3), generator=g)
+        x, dy = big[:, :M], torch.randn((K, N), generator=g)  # x: rows strided
+        gw, gb = linear_wgrad(x, dy, binding=b)
+        assert torch.allclose(gw, dy.t() @ x, rtol=1e-5, atol=1e-4) and torch.allclose(gb, dy.sum(0), rtol=1e-5, atol=1e-4)
+        gw2, none = linear_wgrad(x, dy, want_bias=False, binding=b)
+        assert none is None and torch.equal(gw2, gw)
+    with pytest.raises(ValueError):
+        linear_wgrad(torch.zeros((4, 65)), torch.zeros((4, 3)), binding=b)
