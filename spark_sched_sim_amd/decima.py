@@ -270,10 +270,11 @@ class _NodeEncoder(nn.Module):
         # nodes that are never the source end of an edge start from update(h_init), the rest from 0
         is_parent = torch.zeros(M, dtype=torch.bool, device=x.device).index_fill_(0, src, True)
         h = torch.where(is_parent[:, None], torch.zeros_like(h_init), self.mlp_update(h_init))
+        # (row gathers as index_select: its backward is one index_add_, the advanced-indexing form sorts its indices first)
         for e, recv in reversed(layers):
-            msg = self.mlp_msg(h[dst[e]])
+            msg = self.mlp_msg(h.index_select(0, dst[e]))
             agg = torch.zeros_like(h_init).index_add_(0, src[e], msg)
-            h = h.index_copy(0, recv, h_init[recv] + self.mlp_update(agg[recv]))
+            h = h.index_copy(0, recv, h_init.index_select(0, recv) + self.mlp_update(agg.index_select(0, recv)))
         if per_obs_skip:
             h = torch.where((g["obs_depth"] > 0)[g["node_obs"]][:, None], h, h_init)
         return h
@@ -543,14 +544,14 @@ class DecimaPolicy(nn.Module):
     def stage_scores(self, g: dict[str, Any], h: dict[str, torch.Tensor]):
         """scores of the schedulable stages only (scheduler.py:289-318): (f32[S], global node ids i64[S])"""
         idx = g["stage_mask"].nonzero(as_tuple=True)[0]
-        inp = torch.cat([g["x"][idx], h["node"][idx], h["dag"][g["node_job"][idx]], h["glob"][g["node_obs"][idx]]], -1)
+        inp = torch.cat([g["x"][idx], h["node"].index_select(0, idx), h["dag"].index_select(0, g["node_job"][idx]), h["glob"].index_select(0, g["node_obs"][idx])], -1)
         return self.stage_policy_network.mlp_score(inp).squeeze(-1), idx
 
     def exec_scores(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
         """f32[k,E] for jobs `job_gid` (global job ids, i64[k]); entry e scores "e+1 executors"; -inf
         where that count is not allowed for the job (scheduler.py:337-385)"""
         E = self.num_executors
-        base = torch.cat([g["x"][g["job_first"][job_gid], :NUM_DAG_FEATURES], h["dag"][job_gid], h["glob"][g["job_obs"][job_gid]]], -1)
+        base = torch.cat([g["x"][g["job_first"][job_gid], :NUM_DAG_FEATURES], h["dag"].index_select(0, job_gid), h["glob"].index_select(0, g["job_obs"][job_gid])], -1)
         acts = (torch.arange(E, device=base.device) / E).to(base.dtype)
         inp = torch.cat([base[:, None, :].expand(-1, E, -1), acts[None, :, None].expand(base.shape[0], -1, -1)], -1)
         s = self.exec_policy_network.mlp_score(inp).squeeze(-1)

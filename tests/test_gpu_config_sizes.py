@@ -71,3 +71,53 @@ def test_config5_rank_share_one_ppo_iteration(tmp_path):
     assert all(np.isfinite(hist[0][k]) for k in ("policy loss", "entropy", "approx kl div"))
     assert any(not torch.equal(before[k], v) for k, v in tr.policy.state_dict().items())
     tr.close()
+
+
+def test_config5_full_shape_synchronous_iteration(tmp_path, pack):
+    """BASELINE config 5 at its full shape on one rank's share (1024 of the 8192 envs): ONE synchronous PPO iteration of
+    config/decima_tpch.yaml - every env plays a whole episode under its stochastic time limit
+    (trainers/rollout_worker.py:133-157), Decima samples every action, every observation is recorded, then 3 epochs x 10
+    minibatches of the CLIP loss (trainers/ppo.py:73-138). Checked: finite loss / KL, the parameters moved, and for 16 of
+    the envs the simulator's trajectory under the recorded actions against the C oracle, step by step, bit for bit."""
+    from oracle_binding import OracleEnv
+    from spark_sched_sim_amd.training import Trainer
+
+    train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=256, num_rollouts=4, seed=42, checkpointing_freq=10 ** 9,
+                 num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3,
+                 opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir=str(tmp_path), on_env_error="truncate")
+    env_cfg = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), env_cfg, train, device="cuda:0")
+    assert tr.env.num_envs == 1024 and tr.rollout_duration is None
+    before = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    tr.policy.eval()
+    ro = tr.collector.collect_sync(with_stats=False)
+    seeds = tr.collector.seeds - tr.collector.seed_step  # the episode every env just played
+    limits = tr.collector.tl_env.time_limit.cpu().numpy()
+    T, B = ro.active.shape
+    n = int(ro.active.sum())
+    assert B == 1024 and T > 1000 and n > 1_000_000  # whole episodes: thousands of decisions per env
+    # every env ran until its episode ended (all jobs done, or its time limit passed): nobody is active after the last step
+    last = ro.active.long().sum(0) - 1
+    t_end = ro.t_after[last, torch.arange(B, device=last.device)].cpu().numpy()
+    tr.policy.train()
+    learn = tr.ppo.train_on_rollouts(ro)
+    assert all(np.isfinite(learn[k]) for k in ("policy loss", "entropy", "approx kl div")), learn
+    assert any(not torch.equal(before[k], v) for k, v in tr.policy.state_dict().items())
+    # 16 envs through the oracle under the recorded actions
+    sample = np.linspace(0, B - 1, 16).astype(int)
+    act_s, act_n = ro.stage_sel[:, sample].cpu().numpy(), ro.exec_sel[:, sample].cpu().numpy() + 1
+    rew, wall, alive = ro.rewards[:, sample].cpu().numpy(), ro.t_after[:, sample].cpu().numpy(), ro.active[:, sample].cpu().numpy()
+    oenv = {k: v for k, v in env_cfg.items() if k != "mean_time_limit"}
+    for col, b in enumerate(sample):
+        o = OracleEnv(pack, oenv)
+        assert o.reset(int(seeds[b]), float(limits[b])) == 0
+        steps = int(alive[:, col].sum())
+        assert steps > 0 and alive[:steps, col].all()
+        for t in range(steps):
+            e, r, term = o.step(int(act_s[t, col]), int(act_n[t, col]))
+            assert e == 0, (b, t, e)
+            assert bits(r) == bits(rew[t, col]) and bits(o.info().wall_time) == bits(wall[t, col]), (b, t)
+            assert term == (t == steps - 1 and wall[t, col] < limits[b]) or (not term and wall[t, col] >= limits[b]), (b, t, term)
+        assert bits(t_end[b]) == bits(wall[steps - 1, col])
+        o.close()
+    tr.close()
