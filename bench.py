@@ -130,7 +130,7 @@ def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float) -> dict:
             "sample": f"{len(res)} processes x ~{budget_s:.0f} s of whole episodes, same config and policy (C oracle)"}
 
 
-def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float):
+def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float, key: str = "hi"):
     """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes), recorded under profiles/ by tools/collect_traffic.py for this
     exact kernel/config - and this regime: the record carries the events per step it was measured
@@ -143,7 +143,7 @@ def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float
             if rec["kernel"] == kernel and rec["config"] == config and rec["envs"] == envs:
                 ref = rec.get("events_per_step")
                 if ref and abs(events_per_step - ref) <= 0.15 * ref:
-                    return rec["hbm_bytes_per_launch"]
+                    return rec["hbm_bytes_per_launch"] if key == "hi" else rec.get("hbm_bytes_per_launch_lo")
     except Exception:
         return None
     return None
@@ -304,6 +304,9 @@ class Bench:
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel, self.config, self.B, evps),
+                # the same passes with FETCH_SIZE at face value: the streaming calibration (x2) over-corrects narrow scattered
+                # reads, which the counter reports as whole 128-byte lines (profiles/r03_traffic_calibration.json)
+                "traffic_lo": measured_traffic(kernel, self.config, self.B, evps, "lo"),
                 # `traffic` is NOT measured in this run: rocprofv3 cannot wrap itself around a region of a running
                 # process, so the PMC passes are separate runs of this kernel / config (tools/collect_traffic.py)
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this kernel and config, same events per step within 15 %; null if none)",
