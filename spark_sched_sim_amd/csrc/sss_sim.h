@@ -1937,7 +1937,7 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 //     EVQ:35). Only such events earlier than t_stop can be part of this run - the WINDOW;
 //   * the events in the window are ranked by (time, push counter), heapq's order (EVQ:35), once.
 // After that an iteration is
-//   * the head of the queue = the lane with rank 0 (one compare, no reduction);
+//   * the head of the queue = the lane with rank 1 (one compare, no reduction);
 //   * its draw: EVERY lane has computed, ahead of time and under the generator state the next event will
 //     see, the duration its own event would draw (the executor-level choice of TPCH:222-229 is a threshold
 //     on the raw output, SssPackDev::lvl_thr; numpy's buffered 32-bit Lemire draw with its spare half; the
@@ -1952,7 +1952,7 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 // needs Lemire's rejection loop): the event then at the head of the queue goes the general way.
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
-#define FR_OUT 0x40000000u  // rank of a lane whose event is not in the window (never counts down to 0)
+#define FR_OUT 0x40000000u  // rank of a lane whose event is not in the window (never counts down to the head's rank, 1)
 SSS_DEV int fast_run(const FastCtx& f) {
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
@@ -2020,7 +2020,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
       const uint32_t qk = wave_readlane_u32(sl.seq, k);
       below += (tk < f64_bits(sl.t) || (tk == f64_bits(sl.t) && qk < sl.seq)) ? 1u : 0u;
     }
-    if ((inw_m >> lane) & 1ull) rank = below;
+    if ((inw_m >> lane) & 1ull) rank = below + 1;  // (the head has rank 1)
   }
   const uint64_t open_m = wave_ballot(open_v != 0);
   const char* dur_base = (const char*)f.durations;
@@ -2065,10 +2065,10 @@ SSS_DEV int fast_run(const FastCtx& f) {
   do {                                                                                                                    \
     SSS_FAST_DRAW(ANY_OPEN);                                                                                              \
     for (;;) {                                                                                                            \
-      const uint64_t hm = wave_ballot(rank == 0); /* the head of the queue, if it is such an event */                     \
+      /* the head of the queue, if it is such an event and may go this way (else: the run is over) */                     \
+      const uint64_t hm = wave_ballot(rank == 1) & okm;                                                                   \
       if (hm == 0) break;                                                                                                 \
       const int w = ctz64_nz(hm);                                                                                         \
-      if (!((okm >> w) & 1ull)) break;                                                                                    \
       /* ---- commit the head event (lane w) ---- */                                                                      \
       const uint32_t open_w = (ANY_OPEN) ? (uint32_t)(open_m >> w) & 1u : 0u;                                             \
       if (!h0) u32_0 = (uint32_t)((open_w ? r1 : r0) >> 32), pos += 1; /* a new raw output: its high half is kept */      \
@@ -2079,7 +2079,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
       const double t_new = tmin + (double)dur_w;                                                                          \
       /* the new event is the youngest: it comes after every such event that is not later (EVQ:35); those move up */      \
       const bool le = f64_bits(sl.t) <= f64_bits(t_new); /* (true for w itself: its old time) */                          \
-      const uint32_t rank_w = (uint32_t)popc64(wave_ballot(le) & inw_m) - 1u;                                             \
+      const uint32_t rank_w = (uint32_t)popc64(wave_ballot(le) & inw_m); /* (ranks count from 1) */                       \
       if (le) rank -= 1; /* (the lanes outside the ranking are far from 0) */                                             \
       if (lane == w) sl.t = t_new, sl.seq = seq_next, rank = rank_w;                                                      \
       if (tag == tag_w) rem -= 1, lastdur = dur_w; /* STG:53-58, ENV:604 (only read back by lanes with such an event) */  \
