@@ -724,6 +724,94 @@ SSS_DEV void pool_stage_out(uint32_t key, const SetImg<uint8_t>& s) {
   if (lane == 0) pool_close(key, s);
   wave_sync();
 }
+// ---- set operations on a STAGED image with the whole wave (all lanes; every lane keeps the same header) ----
+// An operation on a table of 16 slots or more examines a probe group - the home slot and the nine after it
+// (LINEAR_PROBES) - with one lane per entry: one LDS access for the group, three ballots, and the rules of
+// set_add_entry / set_discard_entry on bit masks (a key is found if it comes before the group's first empty slot;
+// an addition reuses the LAST dummy seen before the first empty slot). Lane 0 writes the one byte that changes.
+// About 20 instructions per operation, where the one-lane code pays an LDS round trip per entry. 8-slot tables (one
+// probe per step) and resizes stay with the one-lane code (staged_sync_from_lane0 brings the lanes' headers back in step).
+SSS_DEV void staged_fix_location(SetImg<uint8_t>& s) {  // where a staged image lives follows from its size
+  const bool small = s.mask == 7;
+  s.tab = small ? g_sc.pool8 : g_sc.setA, s.cap = small ? 8u : (uint32_t)sss_pool_table_bytes(g_c.E), s.wide = false;
+}
+SSS_DEV void staged_sync_from_lane0(SetImg<uint8_t>& s) {
+  wave_sync();
+  s.mask = wave_lane0_u32(s.mask), s.fill = wave_lane0_u32(s.fill), s.used = wave_lane0_u32(s.used);
+  staged_fix_location(s);
+}
+// set_add; returns with the image updated (a resize included)
+SSS_DEV void staged_add(SetImg<uint8_t>& s, uint32_t key) {
+  const int lane = wave_lane();
+  if (s.mask < 15) {  // (wave-uniform)
+    if (lane == 0) set_add(s, key, lds_keys());
+    staged_sync_from_lane0(s);
+    return;
+  }
+  const uint8_t* tab = g_sc.setA;
+  const uint32_t mask = s.mask;
+  uint32_t i = key & mask, perturb = key;
+  int freeslot = -1, idx = -1;
+  for (;;) {
+    const uint32_t probes = (i + 9 <= mask) ? 9u : 0u;
+    const bool in = (uint32_t)lane <= probes;
+    const uint32_t en = in ? (uint32_t)tab[i + (in ? lane : 0)] : 0xFFu;
+    const uint64_t zm = wave_ballot(in && en == 0), mm = wave_ballot(in && en == key + 2), dm = wave_ballot(in && en == 1);
+    const uint64_t before = zm ? (bit64(ctz64_nz(zm)) - 1) : ~0ull;  // the entries the scan reaches before it stops
+    if (mm & before) return;  // already a member
+    if (dm & before) freeslot = (int)i + 63 - __builtin_clzll(dm & before);
+    if (zm) {
+      idx = (int)i + ctz64_nz(zm);
+      break;
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+  bool resize = false;
+  if (freeslot >= 0) {
+    s.used++;
+    if (lane == 0) g_sc.setA[freeslot] = (uint8_t)(key + 2);
+  } else {
+    s.fill++, s.used++;
+    if (lane == 0) g_sc.setA[idx] = (uint8_t)(key + 2);
+    resize = s.fill * 5 >= mask * 3;
+  }
+  wave_sync();  // the byte is there before any lane looks at the table again
+  if (resize) {
+    if (lane == 0) set_resize(s, s.used * 4, lds_keys());
+    staged_sync_from_lane0(s);
+  }
+}
+// set_remove; returns whether the key was a member
+SSS_DEV bool staged_remove(SetImg<uint8_t>& s, uint32_t key) {
+  const int lane = wave_lane();
+  if (s.mask < 15) {
+    uint32_t was = 0;
+    if (lane == 0) was = set_remove(s, key) ? 1u : 0u;
+    was = wave_lane0_u32(was);
+    staged_sync_from_lane0(s);
+    return was != 0;
+  }
+  const uint8_t* tab = g_sc.setA;
+  const uint32_t mask = s.mask;
+  uint32_t i = key & mask, perturb = key;
+  for (;;) {
+    const uint32_t probes = (i + 9 <= mask) ? 9u : 0u;
+    const bool in = (uint32_t)lane <= probes;
+    const uint32_t en = in ? (uint32_t)tab[i + (in ? lane : 0)] : 0xFFu;
+    const uint64_t zm = wave_ballot(in && en == 0), mm = wave_ballot(in && en == key + 2);
+    const uint64_t before = zm ? (bit64(ctz64_nz(zm)) - 1) : ~0ull;
+    if (mm & before) {
+      if (lane == 0) g_sc.setA[i + (uint32_t)ctz64_nz(mm & before)] = 1;
+      s.used--;
+      wave_sync();
+      return true;
+    }
+    if (zm) return false;
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
 SSS_DEV int pool_size(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].used; }
 SSS_DEV int pool_commit_from(uint32_t key) { return key == POOL_NONE ? 0 : (int)g_c.pool_hdr[pool_index(key)].commit_from; }
 
@@ -1537,14 +1625,12 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
   const uint32_t src_jpool = src_job >= 0 ? key_job_pool(src_job) : POOL_NONE;
   if (staged_src) {
     SetImg<uint8_t> sset = pool_stage_in(src);
-    if (lane == 0) {
-      for (int i = c0; i < c0 + n; i++) {
-        bool was = set_remove(sset, (uint32_t)g_sc.fi_e[i]);
-        CHECK(was);
-        if (g_sc.fi_type[i] == FI_PARK && src == src_jpool) set_add(sset, (uint32_t)g_sc.fi_e[i], lds_keys());
-      }
-      sset.aux -= (uint32_t)n;
+    for (int i = c0; i < c0 + n; i++) {  // (every lane: the operations run on the whole wave, staged_add / staged_remove)
+      bool was = staged_remove(sset, (uint32_t)g_sc.fi_e[i]);
+      CHECK(was);
+      if (g_sc.fi_type[i] == FI_PARK && src == src_jpool) staged_add(sset, (uint32_t)g_sc.fi_e[i]);
     }
+    sset.aux -= (uint32_t)n;
     wave_sync();
     pool_stage_out(src, sset);
   }
@@ -1580,8 +1666,7 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
     const uint32_t into = n_ex ? d : key_job_pool(key_job(d));
     if ((n_ex || n_pk) && into != src) {
       SetImg<uint8_t> dset = pool_stage_in(into);
-      if (lane == 0)
-        for (int q = i; q < i1; q++) set_add(dset, (uint32_t)g_sc.fi_e[q], lds_keys());
+      for (int q = i; q < i1; q++) staged_add(dset, (uint32_t)g_sc.fi_e[q]);
       wave_sync();
       pool_stage_out(into, dset);
     }
@@ -2206,27 +2291,25 @@ enum { STAGED_ENTER = 0, STAGED_PASS = 1 };
 // All lanes: the pools the lanes of `dm` speak for, one at a time. `mykey`: the pool this lane's executor enters
 // (ENTER) or passes through (PASS), POOL_NONE for lanes that are not members. ENTER: the members are added in rank
 // order. PASS (arriving executors, their job's pool): each enters and leaves again, or - `parks` - is taken out and
-// put back by the move to the pool it is already in. Through the LDS staging area, lane 0 applying the operations in
-// rank order (CPython puts a key on the LAST dummy of its probe run: with dummies about, additions do not commute).
+// put back by the move to the pool it is already in. Through the LDS staging area, the operations applied in rank order
+// (CPython puts a key on the LAST dummy of its probe run: with dummies about, additions do not commute), each with the
+// whole wave (staged_add / staged_remove).
 template <int MODE>
 SSS_DEV void pools_staged(uint64_t dm, uint32_t n, uint32_t mykey, bool parks) {
-  const int lane = wave_lane();
   while (dm) {
     const int l = ctz64_nz(dm);
     dm &= dm - 1;
     const uint32_t key = wave_readlane_u32(mykey, l);
     SetImg<uint8_t> sn = pool_stage_in(key);
-    if (lane == 0) {
-      for (uint32_t q = 0; q < n; q++) {
-        const uint32_t e = g_sc.fi_e[q];
-        if (MODE == STAGED_ENTER) {
-          if (g_sc.fc_dst[q] == key) set_add(sn, e, lds_keys());
-        } else if (g_sc.rl_old[q] == key) {
-          set_add(sn, e, lds_keys());
-          bool was = set_remove(sn, e);
-          CHECK(was);
-          if (g_sc.fi_type[q] == 1 /* AR_PARK */) set_add(sn, e, lds_keys());
-        }
+    for (uint32_t q = 0; q < n; q++) {  // (wave-uniform: the lists are read by every lane)
+      const uint32_t e = g_sc.fi_e[q];
+      if (MODE == STAGED_ENTER) {
+        if (g_sc.fc_dst[q] == key) staged_add(sn, e);
+      } else if (g_sc.rl_old[q] == key) {
+        staged_add(sn, e);
+        bool was = staged_remove(sn, e);
+        CHECK(was);
+        if (g_sc.fi_type[q] == 1 /* AR_PARK */) staged_add(sn, e);
       }
     }
     wave_sync();
