@@ -201,6 +201,23 @@ SSS_DEV float* durp(int j, int st) {  // stage.most_recent_duration (observed as
   return s != SLOT_NONE ? lds_cdur() + s * g_c.SP + st : g_c.durations + j * g_c.SP + st;
 }
 
+// all three at once (one look-up of the job's slot). A view stays valid until the next cache_acquire / cache_release:
+// those can move a job's records between HBM and LDS
+struct JobView {
+  SssJob* job;
+  SssStage* st;  // [stage]
+  float* dur;    // [stage]
+};
+SSS_DEV JobView jobview(int j) {
+  const int s = lds_slot_of()[j];
+  JobView v;
+  if (s != SLOT_NONE)
+    v.job = lds_cjobs() + s, v.st = lds_cstages() + s * g_c.SP, v.dur = lds_cdur() + s * g_c.SP;
+  else
+    v.job = g_c.jobs + j, v.st = g_c.stages + j * g_c.SP, v.dur = g_c.durations + j * g_c.SP;
+  return v;
+}
+
 // pool keys
 SSS_DEV uint32_t key_job_pool(int j) { return (uint32_t)(j + 1) << 8; }
 SSS_DEV uint32_t key_stage_pool(int j, int s) { return ((uint32_t)(j + 1) << 8) | (uint32_t)(s + 1); }
@@ -840,13 +857,13 @@ SSS_DEV int trk_num_committable() {  // TRK:107-113
 }
 
 // executor demand bookkeeping: sat bit of stage (j, s) <=> remaining - (moving_to + commit_to) <= 0 (ENV:566-582)
-SSS_DEV void update_sat(int j, int s) {
-  SssStage st = (*stgp(j, s));
-  int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
-  uint64_t m = (*jobp(j)).sat_mask;
-  m = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
-  (*jobp(j)).sat_mask = m;
+SSS_DEV void update_sat(const JobView& v, int s) {
+  const SssStage st = v.st[s];
+  const int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
+  const uint64_t m = v.job->sat_mask;
+  v.job->sat_mask = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
 }
+SSS_DEV void update_sat(int j, int s) { update_sat(jobview(j), s); }
 
 SSS_DEV void add_supply(int job, int d) {
   if (job < 0) {
@@ -881,8 +898,9 @@ SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
   CHECK((int)g_c.pool_hdr[ps].used >= (int)g_c.pool_hdr[ps].commit_from);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
-    (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to + n);
-    update_sat(dj, ds);
+    const JobView v = jobview(dj);
+    v.st[ds].commit_to = (int16_t)(v.st[ds].commit_to + n);
+    update_sat(v, ds);
   }
   if (dj != key_job(src)) add_supply(dj, n);
 }
@@ -904,9 +922,11 @@ SSS_DEV uint32_t trk_remove_commitment(int e, uint32_t dst) {
   CHECK(g_c.pool_hdr[ps].commit_from >= 0);
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
-    (*stgp(dj, ds)).commit_to = (int16_t)((*stgp(dj, ds)).commit_to - 1);
-    CHECK((*stgp(dj, ds)).commit_to >= 0);
-    update_sat(dj, ds);
+    const JobView v = jobview(dj);
+    const int c = (int)v.st[ds].commit_to - 1;
+    CHECK(c >= 0);
+    v.st[ds].commit_to = (int16_t)c;
+    update_sat(v, ds);
   }
   if (hot.c_n[i] == 0) {  // dict.pop(dst): swap-remove, order lives in c_seq
     int last = H.n_commits - 1;
@@ -1018,11 +1038,15 @@ SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  /
   }
   int nj = key_job(new_pool), ns = key_stage(new_pool);
   CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
-  (*stgp(nj, ns)).moving_to = (int16_t)((*stgp(nj, ns)).moving_to + 1);
-  update_sat(nj, ns);
+  {
+    const JobView v = jobview(nj);
+    v.st[ns].moving_to = (int16_t)(v.st[ns].moving_to + 1);
+    update_sat(v, ns);
+    const int sup = (int)v.job->supply + 1;  // add_supply(nj, 1)
+    v.job->supply = (int16_t)sup;
+  }
   int oj = key_job(old);
   CHECK(oj != nj);
-  add_supply(nj, 1);
   if (oj >= 0) add_supply(oj, -1);
 }
 
@@ -1090,9 +1114,8 @@ SSS_DEV void executor_interval(int n, int& li, int& ri) {
 // exception-driven fallback chain (TPCH:88-106; a missing key or an empty list raises before any
 // draw) are resolved once per template on the host into `eff` (sss_host.h: sss_build_eff), so the
 // device does one descriptor load, the draw, and one value load.
-SSS_DEV double task_duration(int j, int s, int e) {
+SSS_DEV double task_duration(const SssJob* job, int s, int e) {
   PROF3(5);
-  const SssJob* job = jobp(j);
   int gs = job->gs_base + s;
   int n_local = popc64(job->local_mask);
   CHECK(n_local > 0 && n_local <= g_c.E);
@@ -1207,16 +1230,22 @@ SSS_DEV void push_event(int e, double t, int kind, int j, int s) {  // EVQ:34-35
 
 SSS_DEV void execute_next_task(int e, int j, int s) {  // ENV:584-615
   PROF3(7);
-  SssStage& st = (*stgp(j, s));
+  const JobView v = jobview(j);  // (valid up to push_event, which may hand the job a cache slot)
+  SssStage st = v.st[s];
   CHECK(st.remaining > 0 && g_hot.ex_job[e] == j && !g_hot.ex_executing[e]);
   st.remaining = (int16_t)(st.remaining - 1);  // STG:53-58
   st.executing = (int16_t)(st.executing + 1);
-  if (st.remaining == 0) (*jobp(j)).sat_count = (int16_t)((*jobp(j)).sat_count + 1);
-  update_sat(j, s);
-  double d = task_duration(j, s, e);
+  v.st[s] = st;
+  if (st.remaining == 0) v.job->sat_count = (int16_t)(v.job->sat_count + 1);
+  {
+    const int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);  // update_sat on the values at hand
+    const uint64_t m = v.job->sat_mask;
+    v.job->sat_mask = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
+  }
+  double d = task_duration(v.job, s, e);
   g_hot.ex_task_stage[e] = (int8_t)s;
   g_hot.ex_executing[e] = 1;
-  *durp(j, s) = (float)d;
+  v.dur[s] = (float)d;
   push_event(e, H.wall_time + d, EV_TASK_FINISHED, j, s);
 }
 
@@ -1806,11 +1835,14 @@ SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created emp
 
 SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
   PROF3(14);
-  job_attach_executor(j, e);
-  SssStage& st = (*stgp(j, s));
-  st.moving_to = (int16_t)(st.moving_to - 1);  // TRK:185-187
-  CHECK(st.moving_to >= 0);
-  update_sat(j, s);
+  const JobView v = jobview(j);
+  CHECK(g_hot.ex_task_stage[e] < 0);  // JOB:81-84
+  v.job->local_mask |= bit64(e);
+  g_hot.ex_job[e] = (int16_t)j;
+  const int mv = (int)v.st[s].moving_to - 1;  // TRK:185-187
+  CHECK(mv >= 0);
+  v.st[s].moving_to = (int16_t)mv;
+  update_sat(v, s);
   trk_move_executor_to_pool(e, key_job_pool(j), false);
   move_executor_to_stage(e, j, s);
 }
@@ -2977,13 +3009,12 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
       remaining[u] = 0, recent[u] = 0.0f, act[u] = 0, sched[u] = 0, nst[u] = 0;
       if (i < A * SPn) {
         const int a = i / SPn, st = i - a * SPn;
-        const int j = lds_active()[a];
-        const SssJob* job = jobp(j);
+        const JobView v = jobview(lds_active()[a]);  // one look-up of the job's slot for the three records
         // the stage's counters and duration are fetched along with the job's record, not after it (their
         // addresses do not depend on it; rows of inactive stages are read and dropped)
-        remaining[u] = stgp(j, st)->remaining;
-        recent[u] = *durp(j, st);
-        act[u] = job->active_mask, sched[u] = job->sched_mask, nst[u] = (int)job->n_stages;
+        remaining[u] = v.st[st].remaining;
+        recent[u] = v.dur[st];
+        act[u] = v.job->active_mask, sched[u] = v.job->sched_mask, nst[u] = (int)v.job->n_stages;
       }
     }
     SSS_UNROLL4 for (int u = 0; u < 4; u++) {

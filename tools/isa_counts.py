@@ -1,8 +1,6 @@
 """Instruction-class counts of the simulator kernels' gfx950 code ("dump the ISA with
 VALU / SALU / LDS counts"). Compiles csrc/sss_hip.hip with -save-temps into a scratch directory and parses
-the device assembly: per kernel the static instruction mix, registers, LDS and scratch; for sss_step_kernel
-also the mix of the batch loop of batch_fast_events (the basic blocks between the loop's two
-wave-minimum reductions are found through the s_memtime-free v_readlane chains; see --loop).
+the device assembly: per kernel the static instruction mix, registers, LDS and scratch.
 
 usage: python tools/isa_counts.py [--out profiles/r02_isa.md]"""
 import argparse, collections, os, os.path as osp, re, subprocess, sys, tempfile
@@ -83,7 +81,7 @@ def main():
         md = meta.get(k, {})
         lines.append(f"| `{k}` | {len(ks[k])} | " + " | ".join(str(c[n]) for n in cols) +
                      f" | {md.get('next_free_vgpr', '?')} | {md.get('next_free_sgpr', '?')} | {md.get('group_segment_fixed_size', '?')} | {md.get('private_segment_fixed_size', '?')} |")
-    pmc = osp.join(ROOT, "profiles", "r02_pmc_step_c2.txt")
+    pmc = osp.join(ROOT, "profiles", "r03_pmc_step_c2.txt")
     if osp.exists(pmc):
         lines += ["", "Dynamic counts of `sss_step_kernel` (rocprofv3 PMC passes over a C2 step-mode run, 4096 waves per launch, mean of the last 40",
                   "launches; `tools/debug/pmc_probe.sh`):", "", "```"] + open(pmc).read().rstrip().split("\n") + ["```"]
