@@ -870,9 +870,10 @@ SSS_DEV void add_supply(int job, int d) {
     H.supply_none += d;
     CHECK(H.supply_none >= 0);
   } else {
-    int v = (int)(*jobp(job)).supply + d;
+    SssJob* jp = jobp(job);
+    int v = (int)jp->supply + d;
     CHECK(v >= 0);
-    (*jobp(job)).supply = (int16_t)v;
+    jp->supply = (int16_t)v;
   }
 }
 
@@ -1056,12 +1057,13 @@ SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  /
 
 SSS_DEV void job_attach_executor(int j, int e) {  // JOB:81-84
   CHECK(g_hot.ex_task_stage[e] < 0);
-  (*jobp(j)).local_mask |= bit64(e);
+  jobp(j)->local_mask |= bit64(e);
   g_hot.ex_job[e] = (int16_t)j;
 }
 SSS_DEV void job_detach_executor(int j, int e) {  // JOB:86-89
-  CHECK((*jobp(j)).local_mask & bit64(e));
-  (*jobp(j)).local_mask &= ~bit64(e);
+  SssJob* jp = jobp(j);
+  CHECK(jp->local_mask & bit64(e));
+  jp->local_mask &= ~bit64(e);
   g_hot.ex_job[e] = -1;
   g_hot.ex_task_stage[e] = -1;
 }
@@ -1264,7 +1266,8 @@ SSS_DEV void move_idle_executor(uint32_t src, int e) {
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
   int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)(*jobp(j)).sat_count == (int)(*jobp(j)).n_stages;  // JOB:53-55
+  const SssJob* jp = jobp(j);
+  bool is_sat = (int)jp->sat_count == (int)jp->n_stages;  // JOB:53-55
   if (s < 0 && !is_sat) return;
   uint32_t dst = is_sat ? POOL_COMMON : key_job_pool(j);
   trk_move_executor_to_pool(e, dst, false);
@@ -1353,7 +1356,8 @@ SSS_DEV void move_idle_executors_all(uint32_t src) {
   CHECK(src != POOL_NONE);
   if (src == POOL_NONE || src == POOL_COMMON) return;
   int j = key_job(src), s = key_stage(src);
-  bool is_sat = (int)(*jobp(j)).sat_count == (int)(*jobp(j)).n_stages;
+  const SssJob* jp0 = jobp(j);
+  bool is_sat = (int)jp0->sat_count == (int)jp0->n_stages;
   if (s < 0 && !is_sat) {
     // nothing moves (ENV:766-769) - but the reference has built the idle list by then and asserts that it
     // is not empty ("[_move_idle_executors],2"): the pool's idle members are the executors located in it
@@ -1377,7 +1381,8 @@ SSS_DEV void move_idle_executors_all(uint32_t src) {
 
 SSS_DEV void move_executor_to_stage(int e, int j, int s) {  // ENV:784-819
   PROF3(11);
-  if ((*stgp(j, s)).remaining == 0) {
+  JobView v = jobview(j);  // (nothing below hands out cache slots before the view's last use)
+  if (v.st[s].remaining == 0) {
     // _try_backup_schedule
     int bj, bs;
     find_backup_stage(e, bj, bs);
@@ -1386,14 +1391,15 @@ SSS_DEV void move_executor_to_stage(int e, int j, int s) {  // ENV:784-819
       return;
     }
     j = bj, s = bs;  // a schedulable stage has demand > 0, hence remaining > 0: no second detour
-    CHECK((*stgp(j, s)).remaining > 0);
+    v = jobview(j);
+    CHECK(v.st[s].remaining > 0);
     if (H.err) return;
   }
   if (g_hot.ex_job[e] != j) {
     send_executor(e, j, s);
     return;
   }
-  if (!((*jobp(j)).frontier_mask & bit64(s))) {
+  if (!(v.job->frontier_mask & bit64(s))) {
     g_hot.ex_task_stage[e] = -1;
     trk_move_executor_to_pool(e, key_job_pool(j), false);
     return;
@@ -1876,9 +1882,11 @@ SSS_DEV void process_job_completion(int j) {  // ENV:682-697
 
 SSS_DEV void handle_task_completion(int e, int j, int s) {  // ENV:452-483
   PROF3(16);
-  SssStage& st = (*stgp(j, s));
+  SssStage* stp = stgp(j, s);
+  SssStage st = *stp;  // (one 8-byte access; the copy is what the tests below look at)
   CHECK(!stage_completed(st));
   st.executing = (int16_t)(st.executing - 1);  // STG:60-62
+  *stp = st;
   g_hot.ex_executing[e] = 0;
   if (st.remaining > 0) {
     execute_next_task(e, j, s);
@@ -1902,8 +1910,10 @@ SSS_DEV void handle_task_completion(int e, int j, int s) {  // ENV:452-483
   }
 #endif
   bool frontier_changed = false;
-  if (stage_completed(st)) frontier_changed = job_record_stage_completion(j, s);  // ENV:676-680
-  if ((*jobp(j)).active_mask == 0) process_job_completion(j);                      // JOB:49-51
+  if (stage_completed(st)) {
+    frontier_changed = job_record_stage_completion(j, s);        // ENV:676-680
+    if ((*jobp(j)).active_mask == 0) process_job_completion(j);  // JOB:49-51 (only a stage's completion can empty the job)
+  }
   // _handle_released_executor ENV:639-660
   uint32_t sp = key_stage_pool(j, s);
   uint32_t dst = trk_peek_commitment(sp);
