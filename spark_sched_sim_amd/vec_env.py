@@ -71,10 +71,7 @@ class VecSparkSchedSimEnv:
         self.exec_supplies = torch.zeros((B, d.job_cap), dtype=torch.int32, device=dev)
         self.obs_i32 = torch.zeros((B, d.obs_i32), dtype=torch.int32, device=dev)
         self.obs_f64 = torch.zeros((B, d.obs_f64), dtype=torch.float64, device=dev)
-        bufs = SssBuffers(self.state.data_ptr(), self.nodes.data_ptr(), self.edge_links.data_ptr(),
-                          self.dag_ptr.data_ptr(), self.exec_supplies.data_ptr(), self.obs_i32.data_ptr(),
-                          self.obs_f64.data_ptr())
-        self._b.check(self._b.lib.sss_bind_buffers(self._h, C.byref(bufs)))
+        self.rebind_buffers()
         self._seeds = torch.zeros(B, dtype=torch.int64, device=dev)
         self._tl = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
         self._mask = torch.ones(B, dtype=torch.uint8, device=dev)
@@ -94,6 +91,16 @@ class VecSparkSchedSimEnv:
         self.observation_space = self.single_observation_space
 
     # ---- plumbing ---------------------------------------------------------------------
+
+    def rebind_buffers(self) -> None:
+        """(re)registers the observation / state tensors with the library (include/sss.h sss_bind_buffers). Every
+        call starts a new buffer generation: rows the env skips while nothing changed (the edge rows of an
+        unchanged active subgraph) are written again at the next step. The supported way to hand over new
+        buffers - or buffers whose contents were changed behind the env's back: assign the tensors, then call this."""
+        bufs = SssBuffers(self.state.data_ptr(), self.nodes.data_ptr(), self.edge_links.data_ptr(),
+                          self.dag_ptr.data_ptr(), self.exec_supplies.data_ptr(), self.obs_i32.data_ptr(),
+                          self.obs_f64.data_ptr())
+        self._b.check(self._b.lib.sss_bind_buffers(self._h, C.byref(bufs)))
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0

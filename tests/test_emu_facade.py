@@ -137,3 +137,48 @@ def test_step_returns_copies_of_the_small_vectors():
         assert torch.equal(rew, rew0) and torch.equal(wt, wt0)
     assert any(float(k[2].max()) > 0 for k in kept)
     vec.close()
+
+
+def test_edge_rows_are_rewritten_after_a_rebind(pack):
+    """write_observation skips an env's edge rows while its active subgraph is what they were written from
+    (csrc/sss_sim.h, INTEGRATION.md "Aliasing": the observation buffers are read-only for the caller). A caller that
+    swaps or edits the buffers rebinds them (`rebind_buffers` -> sss_bind_buffers starts a new buffer generation) and
+    gets the rows written again at the next step; without the rebind an in-place edit would persist - which is the
+    documented contract, checked here as well so that a change of it is noticed."""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+
+    cfg = dict(num_executors=10, job_arrival_cap=12, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 2, device="cpu", pack=pack, _lib=load_emu())
+    env.reset(seed=[5, 6])
+    # a step that leaves the active subgraph as it is: no job arrives or completes, no stage completes
+    for _ in range(50):
+        before = env.header_field("n_active").clone(), env.obs_i32[:, 1].clone()
+        snap = env.edge_links.clone()
+        ver = [env.header(k)["n_events"] for k in range(2)]
+        act = env.policy_actions("fair")
+        env.step(act)
+        same = torch.equal(env.edge_links, snap) and torch.equal(env.obs_i32[:, 1], before[1]) and int(env.obs_i32[:, 1].min()) > 0
+        if same:
+            break
+    assert same, "no step with an unchanged subgraph found"
+    good = env.edge_links.clone()
+    n_edges = env.obs_i32[:, 1].clone()
+    # scribble, step once more with the subgraph unchanged again if possible; either way a rebind restores the rows
+    env.edge_links.fill_(-7)
+    env.rebind_buffers()
+    env.step(env.policy_actions("fair"))
+    for k in range(2):
+        ne = int(env.obs_i32[k, 1])
+        assert ne > 0 and int(env.edge_links[k, :ne].min()) >= 0, "edge rows were not rewritten after the rebind"
+    # and without a rebind the skipped rows are left alone (the read-only contract)
+    snap2, ne2 = env.edge_links.clone(), env.obs_i32[:, 1].clone()
+    env.edge_links[:, 0, 0] = -9
+    env.step(env.policy_actions("fair"))
+    unchanged = [k for k in range(2) if int(env.obs_i32[k, 1]) == int(ne2[k]) and torch.equal(env.edge_links[k, 1:], snap2[k, 1:])]
+    for k in unchanged:
+        assert int(env.edge_links[k, 0, 0]) in (-9, int(snap2[k, 0, 0]))  # kept (skipped) or rewritten (graph changed back to equal rows)
+    env.close()
+    assert good.shape == snap.shape and n_edges.numel() == 2

@@ -203,3 +203,29 @@ def test_prefix_rows_kernel_matches_torch():
                                    torch.cuda.current_stream().cuda_stream) == 0
         want = (src[:, :3].long() * mask[:, None].long()).t()
         assert torch.equal(cnt, want) and torch.equal(off, torch.cumsum(want, 1) - want) and torch.equal(tot, want.sum(1))
+
+
+@pytest.mark.gpu
+def test_decima_step_with_another_current_device(pack):
+    """the entry points without an env handle (sss_prefix_rows, sss_gnn_launch, sss_decima_sample, sss_decima_layer_lists)
+    launch on the CURRENT device; their callers make the tensors' device current (binding.device_of). With two GPUs in
+    one process: an env on cuda:1 stepped by a policy while cuda:0 is current."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs in one process")
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    torch.cuda.set_device(0)
+    env = VecSparkSchedSimEnv(cfg, 64, device="cuda:1", pack=pack)
+    torch.manual_seed(0)
+    policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:1").eval()
+    env.reset(seed=0)
+    for _ in range(5):
+        assert torch.cuda.current_device() == 0
+        act, aux = policy.schedule_env(env)
+        env.step(act)
+    assert torch.isfinite(aux["lgprob"]).all() and int((env.obs_i32[:, 7] != 0).sum()) == 0
+    env.close()
