@@ -2767,7 +2767,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) { STAT(80, 1); return 0; }  // none, a single one (the one-event path is as fast), or not the head
+    if (!((pre >> head) & 1ull)) { STAT(80, 1); return 0; }  // not the head (a single member is fine: this path is cheaper than the general handler)
   }
   SssStage st = {0, 0, 0, 0};
   const SssJob* jpc = f.cjobs + (cand ? slot : 0);
@@ -2789,7 +2789,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
   uint64_t vm = wave_ballot(V);
-  if ((vm & (vm - 1)) == 0) { STAT(82, 1); return 0; }
+  if (vm == 0) { STAT(82, 1); return 0; }
   // who comes before this member, who shares its job / its stage
   uint64_t before = 0, same_job = 0, same_stage = 0;
   for (uint64_t m = vm; m; m &= m - 1) {
@@ -2827,7 +2827,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
       const uint32_t rcut = wave_min_u32(over ? (uint32_t)popc64(before & vm) : 0xFFFFFFFFu);
       V = V && (uint32_t)popc64(before & vm) < rcut;
       vm = wave_ballot(V);
-      if ((vm & (vm - 1)) == 0) { STAT(83, 1); return 0; }
+      if (vm == 0) { STAT(83, 1); return 0; }
     }
   }
   before &= vm;
