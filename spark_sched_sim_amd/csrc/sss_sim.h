@@ -69,6 +69,7 @@ struct alignas(16) SssScratch {
   // index of its commitment in the snapshot, and what became of it in a lane-parallel chunk
   uint8_t fi_e[SSS_MAX_EXEC], fi_k[SSS_MAX_EXEC], fi_type[SSS_MAX_EXEC];
   int32_t fi_m, fi_m_par, f_fulfil;
+  int32_t fc_n, fc_pad_[3];       // entries of the snapshot
   uint32_t rl_old[SSS_MAX_EXEC];  // batch_released_events: the members' old pools and commitment entries, by rank
   uint8_t rl_idx[SSS_MAX_EXEC];
   uint32_t rl_seq[SSS_MAX_EXEC];
@@ -1421,28 +1422,32 @@ SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
   move_executor_to_stage(e, key_job(dst), key_stage(dst));
 }
 
-// ENV:730-743, first half (lane 0): the source's commitments in insertion order (dict copy, TRK:133-134) and the idle
-// executors that will fulfil them, in set.pop() order. What each pop yields does not depend on the
-// fulfilments, so the list is complete before the first executor moves.
+// ENV:730-743, first half. The source's commitments in insertion order (dict copy, TRK:133-134) - all lanes, one
+// commitment entry each: an entry's place is the number of the source's entries inserted before it (a v_readlane
+// sweep over those entries; lane 0 alone would scan the whole list once per entry) ...
+SSS_DEV void fulfil_order_commitments() {
+  const int lane = wave_lane();
+  const uint32_t src = g_hot.h.curr_source;
+  const bool mine = lane < g_hot.h.n_commits && g_hot.c_src[lane] == src;
+  const uint32_t seq = g_hot.c_seq[lane];
+  const uint32_t dst = g_hot.c_dst[lane];
+  const int16_t num = g_hot.c_n[lane];
+  const uint64_t mm = wave_ballot(mine);
+  uint32_t place = 0;
+  for (uint64_t m = mm; m; m &= m - 1) place += wave_readlane_u32(seq, ctz64_nz(m)) < seq ? 1u : 0u;
+  if (mine) g_sc.fc_dst[place] = dst, g_sc.fc_num[place] = num;
+  if (lane == 0) g_sc.fc_n = popc64(mm);
+  wave_sync();
+}
+// ... and (lane 0) the idle executors that will fulfil them, in set.pop() order. What each pop yields does not depend
+// on the fulfilments, so the list is complete before the first executor moves.
 SSS_DEV void fulfil_build_list() {
   PROF3(12);
-  SssHot& hot = g_hot;
   uint32_t src = H.curr_source;
   SetImg<uint8_t> idle = get_idle_source_executors(src);
-  uint32_t* dsts = g_sc.fc_dst;
-  int16_t* nums = g_sc.fc_num;
-  int n = 0;
-  uint32_t last_seq = 0;
-  bool first = true;
-  for (;;) {
-    uint32_t best = 0xFFFFFFFFu;
-    int bi = -1;
-    for (int i = 0; i < H.n_commits; i++)
-      if (hot.c_src[i] == src && (first || hot.c_seq[i] > last_seq) && hot.c_seq[i] < best) best = hot.c_seq[i], bi = i;
-    if (bi < 0) break;
-    dsts[n] = hot.c_dst[bi], nums[n] = hot.c_n[bi], n++;
-    last_seq = best, first = false;
-  }
+  const uint32_t* dsts = g_sc.fc_dst;
+  const int16_t* nums = g_sc.fc_num;
+  const int n = g_sc.fc_n;
   int m = 0, m_par = -1;
   for (int i = 0; i < n; i++) {
     int num = nums[i];
@@ -3734,15 +3739,20 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
         if (!(trk_num_committable() > 0 && H.n_sched > 0)) {
           // commitment round is over (ENV:195-203)
           commit_remaining_executors();
-          fulfil_build_list();
           g_sc.f_fulfil = 1;
         }
       }
     }
-    g_sc.idle_valid = 0;
+    if (!g_sc.f_fulfil) g_sc.idle_valid = 0;
   }
   wave_sync();
   if (g_sc.f_fulfil) {
+    fulfil_order_commitments();
+    if (lane == 0) {
+      fulfil_build_list();
+      g_sc.idle_valid = 0;
+    }
+    wave_sync();
     fulfil_run();
     if (lane == 0) {
       H.curr_source = POOL_NONE;
