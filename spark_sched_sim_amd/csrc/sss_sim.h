@@ -2163,25 +2163,18 @@ SSS_DEV int fast_run(const FastCtx& f) {
   int32_t lastdur = 0;
   // Every lane's draw as if its event were the next one (TPCH:216-235 for "same stage"), under the generator state
   // (pos, h0, u32_0). The load of the duration is issued here and waited for when the head's value is needed -
-  // one iteration later. ANY_OPEN = 0: no executor of the run sits between two executor levels - nobody draws
-  // random(), every draw is one 32-bit half, and the level choice, the second raw output and the per-lane select
-  // drop out of the loop (about one instruction in six).
-#define SSS_FAST_DRAW(ANY_OPEN)                                                                                           \
+  // one iteration later. When no executor of the run sits between two executor levels nobody draws random(), every
+  // draw is one 32-bit half, and the level choice, the second raw output, the per-lane selects and the bookkeeping
+  // of the spare half drop out of the loop (SSS_FAST_DRAW0 below: about one instruction in four).
+#define SSS_FAST_DRAW(r0, r1)                                                                                             \
   do {                                                                                                                    \
-    if (__builtin_expect(pos > 62, 0)) { /* a draw may take two raw outputs: produce the next 64 */                       \
-      if (lane == 0) g_sc.rng_pos = pos;                                                                                  \
-      wave_sync();                                                                                                        \
-      rng_refill();                                                                                                       \
-      rngv = g_sc.rng_buf[lane], pos = 0;                                                                                 \
-    }                                                                                                                     \
-    r0 = wave_readlane_u64(rngv, pos);                                                                                    \
-    if (ANY_OPEN) r1 = wave_readlane_u64(rngv, pos + 1);                                                                  \
-    const bool sel_l = !(ANY_OPEN) || (r0 >> 11) < thr; /* thr = 2^53 for a closed level interval: always */              \
+    r0 = wave_readlane_u64(rngv, pos), r1 = wave_readlane_u64(rngv, pos + 1);                                             \
+    const bool sel_l = (r0 >> 11) < thr; /* thr = 2^53 for a closed level interval: always */                             \
     const int off = sel_l ? off_l : off_r;                                                                                \
     const uint32_t len = sel_l ? len_l : len_r;                                                                           \
     /* numpy's spare half, or the low half of a new raw output: the one after random()'s when the interval is open */     \
-    const uint32_t ua = h0 ? u32_0 : (uint32_t)r0, ux = (h0 || !(ANY_OPEN)) ? 0u : (uint32_t)r0 ^ (uint32_t)r1;           \
-    const uint32_t u32 = (ANY_OPEN) ? ua ^ (ux & open_v) : ua;                                                            \
+    const uint32_t ua = h0 ? u32_0 : (uint32_t)r0, ux = h0 ? 0u : (uint32_t)r0 ^ (uint32_t)r1;                            \
+    const uint32_t u32 = ua ^ (ux & open_v);                                                                              \
     const uint64_t mm = (uint64_t)u32 * len;                                                                              \
     dur = SSS_EXP_DUR((uint32_t)(off + (int)(mm >> 32))); /* (lanes without such an event read entry 0) */                \
     /* the head goes this way if it comes before everything else that is pending, its stage has a task left and its */    \
@@ -2193,39 +2186,101 @@ SSS_DEV int fast_run(const FastCtx& f) {
 #else
 #define SSS_EXP_DUR(i) (*(const int32_t*)(dur_base + (size_t)((i) << 2)))
 #endif
-#define SSS_FAST_LOOP(ANY_OPEN)                                                                                           \
+  // the head of the queue commits (registers only): lane w takes its new time and push counter
+#define SSS_FAST_COMMIT(w)                                                                                                \
   do {                                                                                                                    \
-    SSS_FAST_DRAW(ANY_OPEN);                                                                                              \
-    for (;;) {                                                                                                            \
-      /* the head of the queue, if it is such an event and may go this way (else: the run is over) */                     \
-      const uint64_t hm = wave_ballot(rank == 1) & okm;                                                                   \
-      if (hm == 0) break;                                                                                                 \
-      const int w = ctz64_nz(hm);                                                                                         \
-      /* ---- commit the head event (lane w) ---- */                                                                      \
-      const uint32_t open_w = (ANY_OPEN) ? (uint32_t)(open_m >> w) & 1u : 0u;                                             \
-      if (!h0) u32_0 = (uint32_t)((open_w ? r1 : r0) >> 32), pos += 1; /* a new raw output: its high half is kept */      \
-      h0 ^= 1u, pos += (int)open_w;                                                                                       \
-      const double tmin = bits_f64(wave_readlane_u64(f64_bits(sl.t), w));                                                 \
-      const int32_t dur_w = (int32_t)wave_readlane_u32((uint32_t)dur, w);                                                 \
-      const uint32_t tag_w = wave_readlane_u32(tag, w);                                                                   \
-      const double t_new = tmin + (double)dur_w;                                                                          \
-      /* the new event is the youngest: it comes after every such event that is not later (EVQ:35); those move up */      \
-      const bool le = f64_bits(sl.t) <= f64_bits(t_new); /* (true for w itself: its old time) */                          \
-      const uint32_t rank_w = (uint32_t)popc64(wave_ballot(le) & inw_m); /* (ranks count from 1) */                       \
-      if (le) rank -= 1; /* (the lanes outside the ranking are far from 0) */                                             \
-      if (lane == w) sl.t = t_new, sl.seq = seq_next, rank = rank_w;                                                      \
-      if (tag == tag_w) rem -= 1, lastdur = dur_w; /* STG:53-58, ENV:604 (only read back by lanes with such an event) */  \
-      seq_next++, wall = tmin;                                                                                            \
-      SSS_FAST_DRAW(ANY_OPEN); /* for the event after this one */                                                         \
+    const double tmin = bits_f64(wave_readlane_u64(f64_bits(sl.t), w));                                                   \
+    const int32_t dur_w = (int32_t)wave_readlane_u32((uint32_t)dur, w);                                                   \
+    const uint32_t tag_w = wave_readlane_u32(tag, w);                                                                     \
+    const double t_new = tmin + (double)dur_w;                                                                            \
+    /* the new event is the youngest: it comes after every such event that is not later (EVQ:35); those move up */        \
+    const bool le = f64_bits(sl.t) <= f64_bits(t_new); /* (true for w itself: its old time) */                            \
+    const uint32_t rank_w = (uint32_t)popc64(wave_ballot(le) & inw_m); /* (ranks count from 1) */                         \
+    if (le) rank -= 1; /* (the lanes outside the ranking are far from 0) */                                               \
+    if (lane == w) sl.t = t_new, sl.seq = seq_next, rank = rank_w;                                                        \
+    if (tag == tag_w) rem -= 1, lastdur = dur_w; /* STG:53-58, ENV:604 (only read back by lanes with such an event) */    \
+    seq_next++, wall = tmin;                                                                                              \
+  } while (0)
+  // The generator's buffer is refilled between passes of an outer loop, so that the loop over the events holds
+  // wave-uniform branches only (the compiler then leaves its control flow alone: a scalar compare and branch).
+#define SSS_FAST_REFILL(LAST)                                                                                             \
+  do {                                                                                                                    \
+    if (pos > (LAST)) {                                                                                                   \
+      if (lane == 0) g_sc.rng_pos = pos;                                                                                  \
+      wave_sync();                                                                                                        \
+      rng_refill();                                                                                                       \
+      rngv = g_sc.rng_buf[lane], pos = 0;                                                                                 \
     }                                                                                                                     \
   } while (0)
-  uint64_t r0 = 0, r1 = 0, okm;
+  uint64_t okm;
   int32_t dur;
-  if (open_m != 0)
-    SSS_FAST_LOOP(1);
-  else
-    SSS_FAST_LOOP(0);
-#undef SSS_FAST_LOOP
+  if (open_m != 0) {
+    // some executor of the run draws random() first: the general form
+    for (bool more = true; more;) {
+      more = false;
+      SSS_FAST_REFILL(62);  // a draw may take two raw outputs
+      uint64_t r0, r1;
+      SSS_FAST_DRAW(r0, r1);
+      for (;;) {
+        // the head of the queue, if it is such an event and may go this way (else: the run is over)
+        const uint64_t hm = wave_ballot(rank == 1) & okm;
+        if (hm == 0) break;
+        const int w = ctz64_nz(hm);
+        const uint32_t open_w = (uint32_t)(open_m >> w) & 1u;
+        if (!h0) u32_0 = (uint32_t)((open_w ? r1 : r0) >> 32), pos += 1;  // a new raw output: its high half is kept
+        h0 ^= 1u, pos += (int)open_w;
+        SSS_FAST_COMMIT(w);
+        if (__builtin_expect(pos > 62, 0)) {
+          more = true;
+          break;
+        }
+        SSS_FAST_DRAW(r0, r1);  // for the event after this one
+      }
+    }
+  } else {
+    // Every draw is one 32-bit half of the raw stream, in order: low(raw[p]), high(raw[p]), low(raw[p+1]), ... - the
+    // loop is written two events per round, so that which half comes next is a matter of where in the loop we are.
+#define SSS_FAST_DRAW0(U32)                                                                                               \
+  do {                                                                                                                    \
+    const uint64_t mm = (uint64_t)(uint32_t)(U32) * len_l;                                                                \
+    dur = SSS_EXP_DUR((uint32_t)(off_l + (int)(mm >> 32)));                                                               \
+    okm = elig_m & wave_ballot(sl.t < t_stop) & wave_ballot(rem > 0) & wave_ballot((uint32_t)mm >= len_l);                \
+  } while (0)
+    bool more = true;
+    if (h0) {  // numpy's spare half first
+      SSS_FAST_DRAW0(u32_0);
+      const uint64_t hm = wave_ballot(rank == 1) & okm;
+      more = hm != 0;
+      if (more) SSS_FAST_COMMIT(ctz64_nz(hm));
+    }
+    while (more) {
+      more = false;
+      SSS_FAST_REFILL(63);
+      SSS_FAST_DRAW0(wave_readlane_u32((uint32_t)rngv, pos));
+      for (;;) {
+        // (generator state here: pos, no spare half)
+        const uint64_t hm = wave_ballot(rank == 1) & okm;
+        if (hm == 0) break;
+        SSS_FAST_COMMIT(ctz64_nz(hm));
+        u32_0 = wave_readlane_u32((uint32_t)(rngv >> 32), pos);
+        pos += 1;
+        SSS_FAST_DRAW0(u32_0);
+        // (generator state here: pos, the spare half u32_0)
+        const uint64_t hm1 = wave_ballot(rank == 1) & okm;
+        if (hm1 == 0) break;
+        SSS_FAST_COMMIT(ctz64_nz(hm1));
+        if (__builtin_expect(pos > 63, 0)) {
+          more = true;
+          break;
+        }
+        SSS_FAST_DRAW0(wave_readlane_u32((uint32_t)rngv, pos));
+      }
+    }
+    h0 = (h0 ^ (seq_next - counter0)) & 1u;  // one half per event
+#undef SSS_FAST_DRAW0
+  }
+#undef SSS_FAST_REFILL
+#undef SSS_FAST_COMMIT
   const int total = (int)(seq_next - counter0);
 #undef SSS_FAST_DRAW
 #undef SSS_EXP_DUR
