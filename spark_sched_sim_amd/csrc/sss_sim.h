@@ -1000,6 +1000,7 @@ SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  /
   uint4 ro = mk_u4(7u, 0u, 0u, 0u), rn = ro;
   if (has_old) ro = *(const uint4*)ho;
   if (has_new && !same) rn = *(const uint4*)hn;
+  STAT(100, 1), STAT(101, has_old), STAT(102, has_old && (ro.x & 0xFFFFu) != 7), STAT(103, has_new), STAT(104, has_new && ((same ? ro.x : rn.x) & 0xFFFFu) != 7), STAT(105, same);
   if (has_old) {
     if ((ro.x & 0xFFFFu) == 7) {
       uint64_t t = (uint64_t)ro.z | ((uint64_t)ro.w << 32);
@@ -2090,6 +2091,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
   return 0;
 #endif
   PROF3(30);
+  PROF3_SEC_BEGIN;
   const int lane = wave_lane();
   // ---- everything that is read from shared state is read before the first collective ----
   SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
@@ -2129,6 +2131,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
     }
   }
   const uint32_t tag = info >> 8;  // (job, slot, stage)
+  PROF3_FSEC(1);
   // wave-uniform values the loop keeps on the scalar unit
   const uint32_t counter0 = wave_lane0_u32(counter);
   h0 = wave_lane0_u32(h0), u32_0 = wave_lane0_u32(u32_0), pos = (int)wave_lane0_u32((uint32_t)pos);
@@ -2140,7 +2143,9 @@ SSS_DEV int fast_run(const FastCtx& f) {
   }
   const uint64_t elig_m = wave_ballot(elig);
   const uint64_t inw_m = wave_ballot(elig && sl.t < t_stop);
+  STAT(90, 1), STAT(91, inw_m == 0), STAT(92, popc64(inw_m));
   if (inw_m == 0) return 0;
+  PROF3_FSEC(2);
   // ranks among the events of the window. An event pushed to t_stop or beyond keeps a place among them (the run
   // ends before it gets there, see okm); events that start outside never get one.
   uint32_t rank = FR_OUT;
@@ -2154,6 +2159,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
     }
     if ((inw_m >> lane) & 1ull) rank = below + 1;  // (the head has rank 1)
   }
+  PROF3_FSEC(3);
   const uint64_t open_m = wave_ballot(open_v != 0);
   const char* dur_base = (const char*)f.durations;
   const int rem0 = rem;
@@ -2282,6 +2288,13 @@ SSS_DEV int fast_run(const FastCtx& f) {
 #undef SSS_FAST_REFILL
 #undef SSS_FAST_COMMIT
   const int total = (int)(seq_next - counter0);
+  PROF3_FSEC(4);
+#ifdef SSS_BATCH_STATS  // why the run ended: the window is used up / the head's stage has no task left / other
+  {
+    const uint64_t hr = wave_ballot(rank == 1), a = wave_ballot(sl.t < t_stop), b = wave_ballot(rem > 0);
+    STAT(93, total), STAT(94, total == 0), STAT(95, (hr & ~a) != 0), STAT(96, (hr & a & ~b) != 0), STAT(97, (hr & a & b) != 0);
+  }
+#endif
 #undef SSS_FAST_DRAW
 #undef SSS_EXP_DUR
   if (total > 0) {
@@ -2312,6 +2325,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
     }
   }
   wave_sync();  // the slots and counters are visible to every lane from here
+  PROF3_FSEC(5);
   PROF3_CALLS(30, total - 1);  // (profiling builds: ticks per event of a run)
   return total;
 }

@@ -17,6 +17,10 @@ import os
 if os.environ.get("SSS_SECTIONS"):
     NAMES.update({1: "rel: reads .. first exit", 2: "rel: commitment scan", 3: "rel: classify", 4: "rel: window + ranking", 5: "rel: draws + lane commit", 6: "rel: lane-0 commitments",
                   7: "rel: per-lane pool records", 8: "rel: pools_staged", 9: "rel: sched clear", 10: "rel: sat bits", 11: "rel: send cache_acquire"})
+if os.environ.get("SSS_SECTIONS") == "fast":
+    NAMES.update({1: "fast: reads + classification", 2: "fast: t_stop, window", 3: "fast: ranking", 4: "fast: the loop (incl. first draw)", 5: "fast: write-back"})
+    for k in range(6, 13):
+        NAMES.pop(k, None)
 lib = load_library()
 buf = (C.c_ulonglong * 64)()
 mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
