@@ -313,6 +313,36 @@ int64_t sss_linear_wgrad_scratch(int M, int N);
 int sss_linear_wgrad(const float* x_dev, int64_t ldx, const float* dy_dev, int64_t ldy, int64_t K, int M, int N, float* gw_dev, float* gb_dev,
                      float* scratch_dev, void* stream);
 
+/* One MLP of Decima's networks (schedulers/decima/utils.py:44-64: Linear - act - Linear - act - Linear) over a minibatch of
+ * rows, forward and backward, for the PPO update (trainers/ppo.py:104-138 -> scheduler.py:101-139 -> the nn.Sequential
+ * forward / autograd backward of every MLP). All tensors f32, row-major, contiguous.
+ *   forward:  a1 = act(W1 x + b1) [rows,h1], a2 = act(W2 a1 + b2) [rows,h2], y = W3 a2 + b3 [rows,out_dim]   (a1, a2, y written)
+ *   backward: g2 = (W3^T dy) * act'(a2), g1 = (W2^T g2) * act'(a1), dx = W1^T g1 (dx_dev NULL: not computed) - g1 / g2 are the
+ *             gradients w.r.t. the two hidden layers' pre-activations, so that the parameter gradients are
+ *             sss_linear_wgrad(x = a2, dy = dy), (a1, g2), (x, g1).
+ * w_dev: the MLP's parameters packed [W1 (h1 x in), b1, W2^T (h1 x h2), b2, W3 (out x h2), b3] as for sss_gnn_launch.
+ * act: 0 LeakyReLU(slope), 1 Tanh. Shapes: the seven MLPs of config/decima_tpch.yaml:66-78 - (in, 32, 16, 16, LeakyReLU)
+ * with in = 5 / 16 / 21 and (in, 64, 64, 1, Tanh) with in = 53 / 36; sss_mlp_supported says whether a shape is one of them
+ * (anything else: error). Launches on the CURRENT device's stream `stream` (no handle). fp32 FMAs in a fixed order. */
+typedef struct sss_mlp_args {
+  int64_t rows;
+  int32_t in_dim, h1, h2, out_dim;
+  int32_t act;
+  float slope;
+  const float* w_dev;
+  const float* x_dev;  /* forward */
+  float* a1_dev;
+  float* a2_dev;
+  float* y_dev;        /* forward */
+  const float* dy_dev; /* backward */
+  float* g1_dev;       /* backward */
+  float* g2_dev;       /* backward */
+  float* dx_dev;       /* backward, nullable */
+} sss_mlp_args;
+int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act);
+int sss_mlp_forward(const sss_mlp_args* a, void* stream);
+int sss_mlp_backward(const sss_mlp_args* a, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

@@ -112,6 +112,7 @@ static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleAr
 }
 
 #include "sss_gnn16.h"
+#include "sss_train16.h"
 
 __global__ __launch_bounds__(256) void sss_prefix_rows_kernel(SssPrefixArgs a) {
   __shared__ int64_t part[256];

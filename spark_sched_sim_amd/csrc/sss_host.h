@@ -523,6 +523,35 @@ extern "C" int sss_linear_wgrad(const float* x_dev, int64_t ldx, const float* dy
   return 0;
 }
 
+static int sss_mlp_check(const sss_mlp_args* a, bool backward) {
+  if (!a || !a->w_dev || !a->a1_dev || !a->a2_dev) return sss_fail(-1, "NULL argument");
+  if (a->rows < 0) return sss_fail(-31, "sss_mlp: negative row count");
+  if (backward ? (!a->dy_dev || !a->g1_dev || !a->g2_dev) : (!a->x_dev || !a->y_dev)) return sss_fail(-1, "NULL argument");
+  return 0;
+}
+static SssMlpArgs sss_mlp_args_of(const sss_mlp_args* a) {
+  SssMlpArgs m;
+  m.rows = a->rows, m.in_dim = a->in_dim, m.h1 = a->h1, m.h2 = a->h2, m.out_dim = a->out_dim, m.act = a->act, m.slope = a->slope;
+  m.w = a->w_dev, m.x = a->x_dev, m.a1 = a->a1_dev, m.a2 = a->a2_dev, m.y = a->y_dev, m.dy = a->dy_dev, m.g1 = a->g1_dev, m.g2 = a->g2_dev, m.dx = a->dx_dev;
+  return m;
+}
+extern "C" int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act) {
+  const bool gnn = h1 == 32 && h2 == 16 && out_dim == 16 && act == 0, head = h1 == 64 && h2 == 64 && out_dim == 1 && act == 1;
+  return (gnn && (in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16)) || (head && (in_dim == GNN_NF + 48 || in_dim == GNN_DF + 33));
+}
+extern "C" int sss_mlp_forward(const sss_mlp_args* a, void* stream) {
+  if (int rc = sss_mlp_check(a, false)) return rc;
+  if (!sss_mlp_supported(a->in_dim, a->h1, a->h2, a->out_dim, a->act)) return sss_fail(-31, "sss_mlp: not one of the architecture's MLP shapes");
+  if (int rc = be_launch_mlp(sss_mlp_args_of(a), 0, stream)) return sss_fail(-30, std::string("mlp forward launch failed: ") + be_error(rc));
+  return 0;
+}
+extern "C" int sss_mlp_backward(const sss_mlp_args* a, void* stream) {
+  if (int rc = sss_mlp_check(a, true)) return rc;
+  if (!sss_mlp_supported(a->in_dim, a->h1, a->h2, a->out_dim, a->act)) return sss_fail(-31, "sss_mlp: not one of the architecture's MLP shapes");
+  if (int rc = be_launch_mlp(sss_mlp_args_of(a), 1, stream)) return sss_fail(-30, std::string("mlp backward launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
   BeDeviceGuard guard(h->device);

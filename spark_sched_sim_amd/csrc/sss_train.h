@@ -12,6 +12,24 @@
 #pragma once
 #include <stdint.h>
 
+// one MLP of the architecture, forward or backward (kernels: sss_train16.h; arithmetic stated there)
+struct SssMlpArgs {
+  int64_t rows;
+  int32_t in_dim, h1, h2, out_dim;
+  int32_t act;       // 0: LeakyReLU(slope), 1: Tanh
+  float slope;
+  const float* w;    // packed parameters [W1 (H1 x IN), b1, W2^T (H1 x H2), b2, W3 (OUT x H2), b3] (sss_gnn.h)
+  const float* x;    // f32[rows, IN]
+  float* a1;         // f32[rows, H1]   forward: written; backward: read
+  float* a2;         // f32[rows, H2]
+  float* y;          // forward: f32[rows, OUT]
+  const float* dy;   // backward: f32[rows, OUT]
+  float* g1;         // backward: f32[rows, H1]
+  float* g2;         // backward: f32[rows, H2]
+  float* dx;         // backward: f32[rows, IN], or null (the input needs no gradient)
+};
+
+
 struct SssWgradArgs {
   const float* x;   // [K][ldx], M columns used
   const float* dy;  // [K][ldy], N columns used

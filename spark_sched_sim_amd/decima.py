@@ -235,13 +235,15 @@ def make_mlp(input_dim: int, hid_dims: list[int], output_dim: int, act_cls: str,
     layers: list[nn.Module] = []
     prev = input_dim
     dims = list(hid_dims) + [output_dim]
-    from .train_kernels import KernelLinear  # nn.Linear whose weight gradient comes from the hand-written kernel
+    # nn.Linear whose weight gradient comes from the hand-written kernel, inside an nn.Sequential that evaluates the
+    # architecture's three-layer MLPs with one forward and one backward kernel in the training path
+    from .train_kernels import KernelLinear, KernelMLP
     for i, d in enumerate(dims):
         layers.append(KernelLinear(prev, d))
         if i < len(dims) - 1:
             layers.append(act(**kwargs))
         prev = d
-    return nn.Sequential(*layers)
+    return KernelMLP(*layers)
 
 
 class _NodeEncoder(nn.Module):

@@ -6,6 +6,12 @@ minibatch on the GPU: gw = dy^T x with 10^5 .. 10^7 rows and at most 64 x 64 out
 handles worst - 68 % of a PPO update's device time before (profiles/r03_ppo.md). What the reference runs here is
 autograd's AddmmBackward inside `loss.backward()` (trainers/ppo.py:129-131, schedulers/scheduler.py:44-54).
 Small inputs and CPU tensors take torch's own path.
+
+`KernelMLP` is the `nn.Sequential` the reference builds for every network of the architecture (decima/utils.py:44-64:
+Linear - act - Linear - act - Linear, same module numbering, same `state_dict`) evaluated by ONE forward kernel and, in the
+backward pass, one kernel for the three input-side gradients plus three `sss_linear_wgrad` calls (`sss_mlp_forward` /
+`sss_mlp_backward`, csrc/sss_train16.h) - instead of three addmm, two activations, three mm, three wgrad and two activation
+backward launches with their intermediate tensors. What the reference runs here: `nn.Sequential.forward` under autograd.
 """
 from __future__ import annotations
 
@@ -80,3 +86,117 @@ class KernelLinear(nn.Linear):
                 and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS and self.in_features <= 64 and self.out_features <= 64):
             return _LinearFn.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
+
+
+def pack_mlp(lin1: nn.Linear, lin2: nn.Linear, lin3: nn.Linear) -> torch.Tensor:
+    """[W1, b1, W2^T, b2, W3, b3] as one flat tensor (include/sss.h sss_gnn_launch / sss_mlp_forward)"""
+    parts = [lin1.weight, lin1.bias, lin2.weight.t(), lin2.bias, lin3.weight, lin3.bias]
+    return torch.cat([t.detach().float().contiguous().reshape(-1) for t in parts]).contiguous()
+
+
+def _mlp_args(dims, act, slope, rows, w, x=None, a1=None, a2=None, y=None, dy=None, g1=None, g2=None, dx=None):
+    from .binding import SssMlpArgs
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    return SssMlpArgs(rows, dims[0], dims[1], dims[2], dims[3], act, slope, p(w), p(x), p(a1), p(a2), p(y), p(dy), p(g1), p(g2), p(dx))
+
+
+def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None):
+    """(a1 f32[rows, H1], a2 f32[rows, H2], y f32[rows, OUT]) of `sss_mlp_forward` for x f32[rows, IN] (contiguous)"""
+    import ctypes
+
+    from .binding import device_of
+    b = binding if binding is not None else _binding()
+    rows, dev = x.shape[0], x.device
+    assert x.dim() == 2 and x.shape[1] == dims[0] and x.is_contiguous() and x.dtype == torch.float32
+    a1 = torch.empty((rows, dims[1]), dtype=torch.float32, device=dev)
+    a2 = torch.empty((rows, dims[2]), dtype=torch.float32, device=dev)
+    y = torch.empty((rows, dims[3]), dtype=torch.float32, device=dev)
+    a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, y=y)
+    with device_of(dev):
+        b.check(b.lib.sss_mlp_forward(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+    return a1, a2, y
+
+
+def mlp_backward(dy: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, want_dx: bool = True, binding=None):
+    """(g1 f32[rows, H1], g2 f32[rows, H2], dx f32[rows, IN] | None) of `sss_mlp_backward`: the gradients w.r.t. the two hidden
+    layers' pre-activations and the input, for dy f32[rows, OUT]"""
+    import ctypes
+
+    from .binding import device_of
+    b = binding if binding is not None else _binding()
+    rows, dev = a1.shape[0], a1.device
+    dy = dy.contiguous()
+    assert dy.shape == (rows, dims[3]) and dy.dtype == torch.float32
+    g1, g2 = torch.empty_like(a1), torch.empty_like(a2)
+    dx = torch.empty((rows, dims[0]), dtype=torch.float32, device=dev) if want_dx else None
+    a = _mlp_args(dims, act, slope, rows, packed, a1=a1, a2=a2, dy=dy, g1=g1, g2=g2, dx=dx)
+    with device_of(dev):
+        b.check(b.lib.sss_mlp_backward(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+    return g1, g2, dx
+
+
+class _MlpFn(torch.autograd.Function):
+    """y = W3 act(W2 act(W1 x + b1) + b2) + b3 for x f32[rows, IN]; saves x and the two hidden activations"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, packed, act, slope):
+        dims = (w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0])
+        a1, a2, y = mlp_forward(x, packed, dims, act, slope)
+        ctx.save_for_backward(x, a1, a2, packed)
+        ctx.dims, ctx.act, ctx.slope = dims, act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a1, a2, packed = ctx.saved_tensors
+        dy = dy.contiguous()
+        g1, g2, dx = mlp_backward(dy, a1, a2, packed, ctx.dims, ctx.act, ctx.slope, want_dx=ctx.needs_input_grad[0])
+        gw3, gb3 = linear_wgrad(a2, dy)
+        gw2, gb2 = linear_wgrad(a1, g2)
+        gw1, gb1 = linear_wgrad(x, g1)
+        return dx, gw1, gb1, gw2, gb2, gw3, gb3, None, None, None
+
+
+class KernelMLP(nn.Sequential):
+    """Linear - act - Linear - act - Linear with the reference's module numbering; large float32 minibatches on the GPU go
+    through the fused forward / backward kernels when the shape is one of the architecture's (`sss_mlp_supported`)"""
+
+    # The two policy heads (53 / 36 -> 64 -> 64 -> 1, Tanh) have kernels too (tested), but 64-wide layers on sixteen
+    # lanes per row are LDS-bound (every FMA reads its own weight word): 600 k rows forward + backward 2.50 / 1.54 ms
+    # against 1.46 / 1.28 ms for the three library GEMMs with the MFMA weight-gradient kernel - they keep the layer
+    # path. The GNN's 32 / 16-wide MLPs: 1.10 - 1.32 ms against 2.07 - 2.33 ms at 2.5 M rows (tools/debug/mlp_time.py).
+    FUSE_WIDE = False
+
+    def _fused_spec(self):
+        spec = getattr(self, "_spec", None)
+        if spec is None:
+            spec = False
+            mods = list(self)
+            if len(mods) == 5 and all(isinstance(mods[i], nn.Linear) and mods[i].bias is not None for i in (0, 2, 4)) and type(mods[1]) is type(mods[3]):
+                act = mods[1]
+                kind = (0, float(act.negative_slope)) if isinstance(act, nn.LeakyReLU) else (1, 0.0) if isinstance(act, nn.Tanh) else None
+                dims = (mods[0].in_features, mods[0].out_features, mods[2].out_features, mods[4].out_features)
+                if (kind is not None and mods[2].in_features == dims[1] and mods[4].in_features == dims[2] and (dims[1] <= 32 or self.FUSE_WIDE)
+                        and _binding().lib.sss_mlp_supported(*dims, kind[0])):
+                    spec = (kind[0], kind[1])
+            self._spec = spec
+        return spec
+
+    def _packed_for_step(self) -> torch.Tensor:
+        """the packed parameters, re-packed when an optimiser step (or anything else) has written to them"""
+        l1, l2, l3 = self[0], self[2], self[4]
+        ver = tuple(t._version for t in (l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias)) + (l1.weight.data_ptr(),)
+        if getattr(self, "_pack_ver", None) != ver:
+            self._pack, self._pack_ver = pack_mlp(l1, l2, l3), ver
+        return self._pack
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS and torch.is_grad_enabled()
+                and self[0].weight.requires_grad):
+            spec = self._fused_spec()
+            if spec:
+                l1, l2, l3 = self[0], self[2], self[4]
+                y = _MlpFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, self._packed_for_step(),
+                                 spec[0], spec[1])
+                return y.reshape(x.shape[:-1] + (y.shape[-1],))
+        return super().forward(x)

@@ -78,6 +78,57 @@ static int be_launch_wgrad(const SssWgradArgs& a, void*) {
   return 0;
 }
 
+// sss_mlp_forward / sss_mlp_backward on the host (the 16-lanes-per-row kernels are gfx950-only): the arithmetic of
+// sss_train16.h with plain loops
+static float emu_act(int act, float v, float slope) { return act == 0 ? (v > 0.0f ? v : v * slope) : tanhf(v); }
+static float emu_act_grad(int act, float a, float slope) { return act == 0 ? (a > 0.0f ? 1.0f : slope) : 1.0f - a * a; }
+static int be_launch_mlp(const SssMlpArgs& a, int backward, void*) {
+  const int IN = a.in_dim, H1 = a.h1, H2 = a.h2, OUT = a.out_dim;
+  const float* W1 = a.w;
+  const float* b1 = W1 + H1 * IN;
+  const float* W2T = b1 + H1;
+  const float* b2 = W2T + H1 * H2;
+  const float* W3 = b2 + H2;
+  const float* b3 = W3 + OUT * H2;
+  for (int64_t r = 0; r < a.rows; r++) {
+    if (!backward) {
+      for (int j = 0; j < H1; j++) {
+        float v = b1[j];
+        for (int i = 0; i < IN; i++) v += W1[j * IN + i] * a.x[r * IN + i];
+        a.a1[r * H1 + j] = emu_act(a.act, v, a.slope);
+      }
+      for (int m = 0; m < H2; m++) {
+        float v = b2[m];
+        for (int j = 0; j < H1; j++) v += W2T[j * H2 + m] * a.a1[r * H1 + j];
+        a.a2[r * H2 + m] = emu_act(a.act, v, a.slope);
+      }
+      for (int o = 0; o < OUT; o++) {
+        float v = b3[o];
+        for (int m = 0; m < H2; m++) v += W3[o * H2 + m] * a.a2[r * H2 + m];
+        a.y[r * OUT + o] = v;
+      }
+    } else {
+      for (int m = 0; m < H2; m++) {
+        float v = 0.0f;
+        for (int o = 0; o < OUT; o++) v += W3[o * H2 + m] * a.dy[r * OUT + o];
+        a.g2[r * H2 + m] = v * emu_act_grad(a.act, a.a2[r * H2 + m], a.slope);
+      }
+      for (int j = 0; j < H1; j++) {
+        float v = 0.0f;
+        for (int m = 0; m < H2; m++) v += W2T[j * H2 + m] * a.g2[r * H2 + m];
+        a.g1[r * H1 + j] = v * emu_act_grad(a.act, a.a1[r * H1 + j], a.slope);
+      }
+      if (a.dx)
+        for (int i = 0; i < IN; i++) {
+          float v = 0.0f;
+          for (int j = 0; j < H1; j++) v += W1[j * IN + i] * a.g1[r * H1 + j];
+          a.dx[r * IN + i] = v;
+        }
+    }
+  }
+  return 0;
+}
+
 static int be_launch_prefix_rows(const SssPrefixArgs& a, void*) {
   int64_t part[1];
   for (int r = 0; r < a.n_rows; r++) prefix_row(a, r, 0, 1, part, [] {});

@@ -139,3 +139,39 @@ def test_linear_wgrad_entry_point_on_the_host_backend():
         assert none is None and torch.equal(gw2, gw)
     with pytest.raises(ValueError):
         linear_wgrad(torch.zeros((4, 65)), torch.zeros((4, 3)), binding=b)
+
+
+def test_mlp_entry_points_on_the_host_backend():
+    """include/sss.h sss_mlp_forward / sss_mlp_backward through the emulator library's host implementation against
+    autograd on the same MLP: the argument plumbing of spark_sched_sim_amd.train_kernels.mlp_forward / mlp_backward
+    (packed parameters, activations handed from forward to backward, optional dx) and the shape filter"""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+    from spark_sched_sim_amd.decima import make_mlp
+    from spark_sched_sim_amd.train_kernels import linear_wgrad, mlp_backward, mlp_forward, pack_mlp
+
+    b = Binding(load_emu())
+    torch.manual_seed(4)
+    for dims, act_cls, kw, act, slope in (((5, 32, 16, 16), "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), ((16, 32, 16, 16), "LeakyReLU", dict(negative_slope=0.2), 0, 0.2),
+                                          ((21, 32, 16, 16), "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), ((53, 64, 64, 1), "Tanh", {}, 1, 0.0),
+                                          ((36, 64, 64, 1), "Tanh", {}, 1, 0.0)):
+        assert b.lib.sss_mlp_supported(*dims, act) == 1
+        mlp = make_mlp(dims[0], [dims[1], dims[2]], dims[3], act_cls, kw)
+        x = torch.randn((37, dims[0]), requires_grad=True)
+        y_ref = mlp(x)
+        dy = torch.randn_like(y_ref)
+        y_ref.backward(dy)
+        packed = pack_mlp(mlp[0], mlp[2], mlp[4])
+        a1, a2, y = mlp_forward(x.detach(), packed, dims, act, slope, binding=b)
+        assert torch.allclose(y, y_ref.detach(), rtol=1e-5, atol=1e-5)
+        g1, g2, dx = mlp_backward(dy, a1, a2, packed, dims, act, slope, binding=b)
+        assert torch.allclose(dx, x.grad, rtol=1e-4, atol=1e-5)
+        for lin, xin, g in ((mlp[4], a2, dy), (mlp[2], a1, g2), (mlp[0], x.detach(), g1)):
+            gw, gb = linear_wgrad(xin, g, binding=b)
+            assert torch.allclose(gw, lin.weight.grad, rtol=1e-4, atol=1e-4) and torch.allclose(gb, lin.bias.grad, rtol=1e-4, atol=1e-4)
+        assert mlp_backward(dy, a1, a2, packed, dims, act, slope, want_dx=False, binding=b)[2] is None
+    assert b.lib.sss_mlp_supported(7, 32, 16, 16, 0) == 0 and b.lib.sss_mlp_supported(16, 32, 16, 16, 1) == 0
+    with pytest.raises(ValueError):
+        mlp_forward(torch.zeros((4, 7)), torch.zeros(2000), (7, 32, 16, 16), 0, 0.2, binding=b)

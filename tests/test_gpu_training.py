@@ -86,3 +86,65 @@ def test_linear_wgrad_kernel_matches_torch():
     assert torch.allclose(xin.grad, xin2.grad, rtol=1e-5, atol=1e-5)
     assert torch.allclose(lin_k.weight.grad, lin_t.weight.grad, rtol=1e-4, atol=2e-3)
     assert torch.allclose(lin_k.bias.grad, lin_t.bias.grad, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_mlp_kernels_match_autograd():
+    """csrc/sss_train16.h (forward and backward of a whole MLP, 16 lanes per row) against torch in fp64 on the same
+    parameters, for the five MLP shapes of the published architecture and row counts around the tile sizes; then
+    `KernelMLP` (what `make_mlp` builds) through autograd against the plain nn.Sequential, and bit-identical repeats"""
+    import torch
+
+    from spark_sched_sim_amd.decima import make_mlp
+    from spark_sched_sim_amd.train_kernels import KernelMLP, mlp_backward, mlp_forward, pack_mlp
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    shapes = (((5, 32, 16, 16), "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), ((16, 32, 16, 16), "LeakyReLU", dict(negative_slope=0.2), 0, 0.2),
+              ((21, 32, 16, 16), "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), ((53, 64, 64, 1), "Tanh", {}, 1, 0.0), ((36, 64, 64, 1), "Tanh", {}, 1, 0.0))
+    for dims, act_cls, kw, act, slope in shapes:
+        mlp = make_mlp(dims[0], [dims[1], dims[2]], dims[3], act_cls, kw).to(dev)
+        assert isinstance(mlp, KernelMLP)
+        ref = torch.nn.Sequential(*[type(m)(m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else type(m)(**kw) for m in mlp]).to(dev).double()
+        ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+        packed = pack_mlp(mlp[0], mlp[2], mlp[4])
+        for rows in (1, 15, 16, 17, 4099, 70001):
+            x = torch.randn((rows, dims[0]), device=dev)
+            xr = x.double().requires_grad_(True)
+            h1 = ref[1](ref[0](xr))
+            h2 = ref[3](ref[2](h1))
+            y_ref = ref[4](h2)
+            dy = torch.randn((rows, dims[3]), device=dev)
+            a1, a2, y = mlp_forward(x, packed, dims, act, slope)
+            assert (y.double() - y_ref).abs().max().item() <= 2e-5 and (a1.double() - h1).abs().max().item() <= 1e-5 and (a2.double() - h2).abs().max().item() <= 1e-5
+            g1, g2, dx = mlp_backward(dy, a1, a2, packed, dims, act, slope)
+            y_ref.backward(dy.double())
+            assert (dx.double() - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item()), (dims, rows)
+            # g1 / g2 are the gradients w.r.t. the pre-activations: their products with the layer inputs are the weight gradients
+            gw2_ref = ref[2].weight.grad
+            assert ((g2.double().t() @ a1.double()) - gw2_ref).abs().max().item() <= 1e-4 * max(1.0, gw2_ref.abs().max().item()), (dims, rows)
+            gw1_ref = ref[0].weight.grad
+            assert ((g1.double().t() @ x.double()) - gw1_ref).abs().max().item() <= 1e-4 * max(1.0, gw1_ref.abs().max().item()), (dims, rows)
+            ref.zero_grad()
+            again = mlp_backward(dy, a1, a2, packed, dims, act, slope)
+            assert torch.equal(again[0], g1) and torch.equal(again[1], g2) and torch.equal(again[2], dx)
+        # through autograd: the module against the same layers evaluated one by one (the wide heads stay on the layer path
+        # in production, KernelMLP.FUSE_WIDE: switched on here so that their kernels are the ones compared)
+        mlp.FUSE_WIDE, mlp._spec = True, None
+        x = torch.randn((20000, dims[0]), device=dev, requires_grad=True)
+        x2 = x.detach().clone().requires_grad_(True)
+        w = torch.randn((20000, dims[3]), device=dev)
+        (mlp(x) * w).sum().backward()
+        got = {k: p.grad.clone() for k, p in mlp.named_parameters()}
+        mlp.zero_grad()
+        (torch.nn.Sequential.forward(mlp, x2) * w).sum().backward()
+        assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
+        for k, p in mlp.named_parameters():
+            assert torch.allclose(got[k], p.grad, rtol=1e-4, atol=5e-3), (dims, k)
+        # the packed parameters follow an optimiser step
+        before = mlp(x.detach().requires_grad_(True)).detach().clone()
+        with torch.no_grad():
+            for p in mlp.parameters():
+                p.add_(0.01)
+        after = mlp(x.detach().requires_grad_(True)).detach()
+        assert not torch.allclose(before, after) and torch.allclose(after, torch.nn.Sequential.forward(mlp, x.detach()), rtol=1e-5, atol=1e-5)
