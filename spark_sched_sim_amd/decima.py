@@ -253,6 +253,14 @@ class _NodeEncoder(nn.Module):
         self.mlp_msg = make_mlp(emb, output_dim=emb, **mlp_kwargs)
         self.mlp_update = make_mlp(emb, output_dim=emb, **mlp_kwargs)
 
+    KERNEL_MESSAGE_PASSING = True
+
+    def _kernel_message_passing(self, h_init: torch.Tensor) -> bool:
+        """the training path on a GPU, with the published 16 -> 32 -> 16 -> 16 LeakyReLU MLPs"""
+        from .train_kernels import MIN_ROWS, KernelMLP
+        return (self.KERNEL_MESSAGE_PASSING and h_init.is_cuda and h_init.dtype == torch.float32 and torch.is_grad_enabled() and h_init.requires_grad
+                and h_init.shape[0] >= MIN_ROWS and h_init.shape[1] == 16 and all(isinstance(m, KernelMLP) and m._fused_spec() for m in (self.mlp_msg, self.mlp_update)))
+
     def forward(self, g: dict[str, Any], per_obs_skip: bool) -> torch.Tensor:
         """child -> parent ("reverse flow") message passing one DAG layer at a time, deepest layer
         first (scheduler.py:192-236). Per layer only that layer's edges and receiving nodes are
@@ -272,11 +280,17 @@ class _NodeEncoder(nn.Module):
         # nodes that are never the source end of an edge start from update(h_init), the rest from 0
         is_parent = torch.zeros(M, dtype=torch.bool, device=x.device).index_fill_(0, src, True)
         h = torch.where(is_parent[:, None], torch.zeros_like(h_init), self.mlp_update(h_init))
-        # (row gathers as index_select: its backward is one index_add_, the advanced-indexing form sorts its indices first)
-        for e, recv in reversed(layers):
-            msg = self.mlp_msg(h.index_select(0, dst[e]))
-            agg = torch.zeros_like(h_init).index_add_(0, src[e], msg)
-            h = h.index_copy(0, recv, h_init.index_select(0, recv) + self.mlp_update(agg.index_select(0, recv)))
+        if self._kernel_message_passing(h_init):
+            # one autograd node for the whole loop, both MLPs on the MLP kernels (train_kernels._MessagePassFn)
+            from .train_kernels import message_passing
+            plan = [(dst[e], torch.searchsorted(recv, src[e]), recv) for e, recv in reversed(layers)]
+            h = message_passing(h_init, h, plan, self.mlp_msg, self.mlp_update)
+        else:
+            # (row gathers as index_select: its backward is one index_add_, the advanced-indexing form sorts its indices first)
+            for e, recv in reversed(layers):
+                msg = self.mlp_msg(h.index_select(0, dst[e]))
+                agg = torch.zeros_like(h_init).index_add_(0, src[e], msg)
+                h = h.index_copy(0, recv, h_init.index_select(0, recv) + self.mlp_update(agg.index_select(0, recv)))
         if per_obs_skip:
             h = torch.where((g["obs_depth"] > 0)[g["node_obs"]][:, None], h, h_init)
         return h

@@ -100,24 +100,31 @@ def _mlp_args(dims, act, slope, rows, w, x=None, a1=None, a2=None, y=None, dy=No
     return SssMlpArgs(rows, dims[0], dims[1], dims[2], dims[3], act, slope, p(w), p(x), p(a1), p(a2), p(y), p(dy), p(g1), p(g2), p(dx))
 
 
-def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None):
-    """(a1 f32[rows, H1], a2 f32[rows, H2], y f32[rows, OUT]) of `sss_mlp_forward` for x f32[rows, IN] (contiguous)"""
+def _out(t, rows, width, dev):
+    if t is None:
+        return torch.empty((rows, width), dtype=torch.float32, device=dev)
+    assert t.shape == (rows, width) and t.is_contiguous() and t.dtype == torch.float32
+    return t
+
+
+def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None, a1=None, a2=None, y=None):
+    """(a1 f32[rows, H1], a2 f32[rows, H2], y f32[rows, OUT]) of `sss_mlp_forward` for x f32[rows, IN] (contiguous); written
+    into the tensors given, or into new ones"""
     import ctypes
 
     from .binding import device_of
     b = binding if binding is not None else _binding()
     rows, dev = x.shape[0], x.device
     assert x.dim() == 2 and x.shape[1] == dims[0] and x.is_contiguous() and x.dtype == torch.float32
-    a1 = torch.empty((rows, dims[1]), dtype=torch.float32, device=dev)
-    a2 = torch.empty((rows, dims[2]), dtype=torch.float32, device=dev)
-    y = torch.empty((rows, dims[3]), dtype=torch.float32, device=dev)
+    a1, a2, y = _out(a1, rows, dims[1], dev), _out(a2, rows, dims[2], dev), _out(y, rows, dims[3], dev)
     a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, y=y)
     with device_of(dev):
         b.check(b.lib.sss_mlp_forward(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
     return a1, a2, y
 
 
-def mlp_backward(dy: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, want_dx: bool = True, binding=None):
+def mlp_backward(dy: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, want_dx: bool = True, binding=None,
+                 g1=None, g2=None):
     """(g1 f32[rows, H1], g2 f32[rows, H2], dx f32[rows, IN] | None) of `sss_mlp_backward`: the gradients w.r.t. the two hidden
     layers' pre-activations and the input, for dy f32[rows, OUT]"""
     import ctypes
@@ -127,7 +134,7 @@ def mlp_backward(dy: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: t
     rows, dev = a1.shape[0], a1.device
     dy = dy.contiguous()
     assert dy.shape == (rows, dims[3]) and dy.dtype == torch.float32
-    g1, g2 = torch.empty_like(a1), torch.empty_like(a2)
+    g1, g2 = _out(g1, rows, dims[1], dev), _out(g2, rows, dims[2], dev)
     dx = torch.empty((rows, dims[0]), dtype=torch.float32, device=dev) if want_dx else None
     a = _mlp_args(dims, act, slope, rows, packed, a1=a1, a2=a2, dy=dy, g1=g1, g2=g2, dx=dx)
     with device_of(dev):
@@ -200,3 +207,88 @@ class KernelMLP(nn.Sequential):
                                  spec[0], spec[1])
                 return y.reshape(x.shape[:-1] + (y.shape[-1],))
         return super().forward(x)
+
+
+class _MessagePassFn(torch.autograd.Function):
+    """The node encoder's message passing (scheduler.py:209-232: for every DAG layer, deepest first,
+    h[recv] = h_init[recv] + update(sum over the layer's edges (recv -> child) of msg(h[child]))) as ONE autograd node.
+
+    The tensor-op form builds a full-size aggregate and a new copy of the whole embedding tensor per layer, forward and
+    backward (`index_copy` of a functional graph). Here the embeddings are updated in place in a working buffer, the
+    aggregates are compact (one row per receiving node), the backward pass walks the layers the other way on ONE gradient
+    buffer (rows of receivers are taken out and cleared, gather gradients are added in), both MLPs run on the MLP kernels
+    into slices of per-call buffers - so that their six weight gradients are six `sss_linear_wgrad` calls over all layers
+    together. `layers`: [(child ids of the layer's edges, position of each edge's receiver in `recv`, recv)], in
+    processing order."""
+
+    DIMS = (16, 32, 16, 16)
+
+    @staticmethod
+    def forward(ctx, h_init, h0, layers, slope, packed_msg, packed_upd, *params):
+        dev, D = h_init.device, _MessagePassFn.DIMS
+        ne = sum(int(c.numel()) for c, _, _ in layers)
+        nr = sum(int(r.numel()) for _, _, r in layers)
+        f = lambda n, w: torch.empty((n, w), dtype=torch.float32, device=dev)  # noqa: E731
+        mx, ma1, ma2 = f(ne, 16), f(ne, 32), f(ne, 16)  # message MLP: inputs and hidden activations of every edge, layer after layer
+        ux, ua1, ua2 = f(nr, 16), f(nr, 32), f(nr, 16)  # update MLP: the same per receiving node
+        h = h0.clone()
+        eo = ro = 0
+        for child, pos, recv in layers:
+            n_e, n_r = int(child.numel()), int(recv.numel())
+            if n_e == 0 or n_r == 0:
+                continue
+            xs = mx[eo:eo + n_e]
+            torch.index_select(h, 0, child, out=xs)
+            _, _, my = mlp_forward(xs, packed_msg, D, 0, slope, a1=ma1[eo:eo + n_e], a2=ma2[eo:eo + n_e])
+            agg = ux[ro:ro + n_r]
+            agg.zero_().index_add_(0, pos, my)
+            _, _, uy = mlp_forward(agg, packed_upd, D, 0, slope, a1=ua1[ro:ro + n_r], a2=ua2[ro:ro + n_r])
+            h.index_copy_(0, recv, uy.add_(h_init.index_select(0, recv)))  # (every read of the layer came before this write)
+            eo, ro = eo + n_e, ro + n_r
+        ctx.layers, ctx.slope = layers, slope
+        ctx.save_for_backward(mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh_in):
+        mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd = ctx.saved_tensors
+        layers, slope, D = ctx.layers, ctx.slope, _MessagePassFn.DIMS
+        dev = gh_in.device
+        f = lambda t: torch.empty_like(t)  # noqa: E731
+        mdy, mg1, mg2 = f(mx), f(ma1), f(ma2)
+        udy, ug1, ug2 = f(ux), f(ua1), f(ua2)
+        gh = gh_in.clone()  # gradient w.r.t. the embeddings as they were before the layer being undone
+        g_init = torch.zeros_like(gh)
+        eo, ro = int(mx.shape[0]), int(ux.shape[0])
+        for child, pos, recv in reversed(layers):
+            n_e, n_r = int(child.numel()), int(recv.numel())
+            if n_e == 0 or n_r == 0:
+                continue
+            eo, ro = eo - n_e, ro - n_r
+            g_new = udy[ro:ro + n_r]
+            torch.index_select(gh, 0, recv, out=g_new)
+            gh.index_fill_(0, recv, 0.0)  # the receivers' previous embeddings were overwritten
+            g_init.index_add_(0, recv, g_new)
+            _, _, g_agg = mlp_backward(g_new, ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, 0, slope, g1=ug1[ro:ro + n_r], g2=ug2[ro:ro + n_r])
+            g_msg = mdy[eo:eo + n_e]
+            torch.index_select(g_agg, 0, pos, out=g_msg)
+            _, _, g_xs = mlp_backward(g_msg, ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, 0, slope, g1=mg1[eo:eo + n_e], g2=mg2[eo:eo + n_e])
+            gh.index_add_(0, child, g_xs)
+        grads = []
+        for x, a1, a2, dy, g1, g2 in ((mx, ma1, ma2, mdy, mg1, mg2), (ux, ua1, ua2, udy, ug1, ug2)):
+            if x.shape[0] == 0:
+                grads += [None] * 6
+                continue
+            gw1, gb1 = linear_wgrad(x, g1)
+            gw2, gb2 = linear_wgrad(a1, g2)
+            gw3, gb3 = linear_wgrad(a2, dy)
+            grads += [gw1, gb1, gw2, gb2, gw3, gb3]
+        return (g_init, gh, None, None, None, None) + tuple(grads)
+
+
+def message_passing(h_init: torch.Tensor, h0: torch.Tensor, layers, mlp_msg: "KernelMLP", mlp_update: "KernelMLP") -> torch.Tensor:
+    """`_MessagePassFn` for the two MLPs' current parameters (16 -> 32 -> 16 -> 16, LeakyReLU)"""
+    slope = float(mlp_msg[1].negative_slope)
+    pm, pu = mlp_msg._packed_for_step(), mlp_update._packed_for_step()
+    params = [t for m in (mlp_msg, mlp_update) for lin in (m[0], m[2], m[4]) for t in (lin.weight, lin.bias)]
+    return _MessagePassFn.apply(h_init, h0, layers, slope, pm, pu, *params)

@@ -148,3 +148,43 @@ def test_mlp_kernels_match_autograd():
                 p.add_(0.01)
         after = mlp(x.detach().requires_grad_(True)).detach()
         assert not torch.allclose(before, after) and torch.allclose(after, torch.nn.Sequential.forward(mlp, x.detach()), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_message_passing_function_matches_the_tensor_op_form():
+    """train_kernels._MessagePassFn (the node encoder's loop over the DAG layers as one autograd node on the MLP kernels)
+    against the tensor-op form of `_NodeEncoder.forward` on the same recorded graph: embeddings, and through a scalar of
+    them the gradients of every parameter of the encoder and of the node features' embedding"""
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    dev = torch.device("cuda:0")
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 512, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
+    env.reset(seed=7)
+    env.rollout("fair", 150)
+    g = env.decima_graph(None)
+    torch.manual_seed(3)
+    pol = DecimaPolicy(num_executors=10, **AGENT).to(dev)
+    enc = pol.encoder.node_encoder
+    with torch.no_grad():  # (biases start at zero, scheduler.py:66-69: give them values so that their gradients are exercised)
+        for n_, p_ in enc.named_parameters():
+            if "bias" in n_:
+                p_.normal_(0.0, 0.1)
+    assert g["x"].shape[0] >= 8192 and int(g["obs_depth"].max()) >= 3
+    w = torch.randn((g["x"].shape[0], 16), device=dev)
+    out = {}
+    for flag in (True, False):
+        type(enc).KERNEL_MESSAGE_PASSING = flag
+        pol.zero_grad()
+        h = enc(g, per_obs_skip=False)
+        assert enc._kernel_message_passing(enc.mlp_prep(g["x"])) == flag
+        (h * w).sum().backward()
+        out[flag] = (h.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()})
+    type(enc).KERNEL_MESSAGE_PASSING = True
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-4, atol=2e-5)
+    for k in out[True][1]:
+        a, b = out[True][1][k], out[False][1][k]
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * max(1.0, float(b.abs().max()))), (k, float((a - b).abs().max()), float(b.abs().max()))
+    env.close()
