@@ -313,6 +313,52 @@ int64_t sss_linear_wgrad_scratch(int M, int N);
 int sss_linear_wgrad(const float* x_dev, int64_t ldx, const float* dy_dev, int64_t ldy, int64_t K, int M, int N, float* gw_dev, float* gb_dev,
                      float* scratch_dev, void* stream);
 
+/* The per-step bookkeeping of the rollout workers for all envs at once (trainers/rollout_worker.py:133-159 sync, :162-206
+ * async, with spark_sched_sim/wrappers StochasticTimeLimit's truncation rule), two launches around sss_step:
+ *   phase 0: stage_idx[b] = active[b] ? stage_sel[b] : SSS_SKIP_ENV, num_exec[b] = max(1, 1 + exec_sel[b])
+ *   phase 1: from the step's outputs (obs_f64 = [reward, wall_time], obs_i32[6] terminated, [7] error code) and time_limit:
+ *            an env with an error code leaves the collection (pending_reset set, its step not recorded); row t of the
+ *            [T][num_envs] record arrays (active, reward - 0 for frozen envs -, the sample, times, reset flag):
+ *              sync:  t_before = the env's clock before the step, t_after = after it; the env stops when its episode ends
+ *              async: t_before / t_after = simulated time collected before / after; resets = the episode ended (the caller
+ *                     resets those envs; their clock restarts at 0); the env stops when `duration` is reached
+ *            wall / elapsed / step_counts / active are updated in place;
+ *            flags (i32[8], zero on entry, OR-ed): [0] an env failed, [1] an episode ended, [2] an env goes on,
+ *            [3] 1 + index of a failed env, [4] an env was recorded.
+ * Launches on the CURRENT device's stream `stream` (no handle). */
+typedef struct sss_collect_args {
+  int32_t num_envs;
+  int32_t asynchronous;
+  int64_t t;
+  double duration;
+  const double* obs_f64_dev;
+  const int32_t* obs_i32_dev;
+  int64_t obs_i32_stride;
+  const double* time_limit_dev;
+  uint8_t* active_dev;
+  double* wall_dev;
+  double* elapsed_dev;
+  int64_t* step_counts_dev;
+  uint8_t* pending_reset_dev;
+  const int64_t* stage_sel_dev;
+  const int64_t* job_idx_dev;
+  const int64_t* exec_sel_dev;
+  const float* lgprob_dev;
+  int32_t* stage_idx_dev;
+  int32_t* num_exec_dev;
+  uint8_t* rec_active_dev;
+  double* rec_t_before_dev;
+  double* rec_t_after_dev;
+  double* rec_rewards_dev;
+  int64_t* rec_stage_sel_dev;
+  int64_t* rec_job_idx_dev;
+  int64_t* rec_exec_sel_dev;
+  float* rec_lgprobs_dev;
+  uint8_t* rec_resets_dev;
+  int32_t* flags_dev;
+} sss_collect_args;
+int sss_collect_step(const sss_collect_args* a, int phase, void* stream);
+
 /* One MLP of Decima's networks (schedulers/decima/utils.py:44-64: Linear - act - Linear - act - Linear) over a minibatch of
  * rows, forward and backward, for the PPO update (trainers/ppo.py:104-138 -> scheduler.py:101-139 -> the nn.Sequential
  * forward / autograd backward of every MLP). All tensors f32, row-major, contiguous.

@@ -93,6 +93,15 @@ ERROR_NAMES = {
     10: "more job arrivals than max_jobs",
 }
 
+class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args
+    _fields_ = [("num_envs", C.c_int32), ("asynchronous", C.c_int32), ("t", C.c_int64), ("duration", C.c_double), ("obs_f64_dev", C.c_void_p), ("obs_i32_dev", C.c_void_p),
+                ("obs_i32_stride", C.c_int64), ("time_limit_dev", C.c_void_p), ("active_dev", C.c_void_p), ("wall_dev", C.c_void_p), ("elapsed_dev", C.c_void_p),
+                ("step_counts_dev", C.c_void_p), ("pending_reset_dev", C.c_void_p), ("stage_sel_dev", C.c_void_p), ("job_idx_dev", C.c_void_p), ("exec_sel_dev", C.c_void_p),
+                ("lgprob_dev", C.c_void_p), ("stage_idx_dev", C.c_void_p), ("num_exec_dev", C.c_void_p), ("rec_active_dev", C.c_void_p), ("rec_t_before_dev", C.c_void_p),
+                ("rec_t_after_dev", C.c_void_p), ("rec_rewards_dev", C.c_void_p), ("rec_stage_sel_dev", C.c_void_p), ("rec_job_idx_dev", C.c_void_p),
+                ("rec_exec_sel_dev", C.c_void_p), ("rec_lgprobs_dev", C.c_void_p), ("rec_resets_dev", C.c_void_p), ("flags_dev", C.c_void_p)]
+
+
 class SssMlpArgs(C.Structure):  # include/sss.h sss_mlp_args
     _fields_ = [("rows", C.c_int64), ("in_dim", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
                 ("w_dev", C.c_void_p), ("x_dev", C.c_void_p), ("a1_dev", C.c_void_p), ("a2_dev", C.c_void_p), ("y_dev", C.c_void_p), ("dy_dev", C.c_void_p),
@@ -101,7 +110,7 @@ class SssMlpArgs(C.Structure):  # include/sss.h sss_mlp_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_last_error", "sss_destroy"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -135,6 +144,7 @@ class Binding:
         L.sss_linear_wgrad_scratch.argtypes = [C.c_int, C.c_int]
         L.sss_linear_wgrad_scratch.restype = C.c_int64
         L.sss_linear_wgrad.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sss_collect_step.argtypes = [C.POINTER(SssCollectArgs), C.c_int, C.c_void_p]
         L.sss_mlp_supported.argtypes = [C.c_int] * 5
         L.sss_mlp_forward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
         L.sss_mlp_backward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]

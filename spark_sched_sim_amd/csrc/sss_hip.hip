@@ -9,6 +9,7 @@
 #include "sss_gnn.h"
 #include "sss_decima_policy.h"
 #include "sss_train.h"
+#include "sss_collect.h"
 
 #include <stdint.h>
 #include "zig_tables.inc"
@@ -139,6 +140,15 @@ static int be_launch_wgrad(const SssWgradArgs& a, void* stream) {
   }
   if (int rc = (int)hipGetLastError()) return rc;
   hipLaunchKernelGGL(sss_wgrad_reduce_kernel, dim3((unsigned)((a.N * a.M + a.N + 15) / 16)), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sss_collect_kernel(SssCollectArgs a, int phase) {
+  const int b = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (b < a.num_envs) collect_env(a, phase, b, [&](int i, int v) { atomicOr(a.flags + i, v); });
+}
+static int be_launch_collect(const SssCollectArgs& a, int phase, void* stream) {
+  hipLaunchKernelGGL(sss_collect_kernel, dim3((unsigned)((a.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, phase);
   return (int)hipGetLastError();
 }
 

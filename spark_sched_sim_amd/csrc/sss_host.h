@@ -523,6 +523,31 @@ extern "C" int sss_linear_wgrad(const float* x_dev, int64_t ldx, const float* dy
   return 0;
 }
 
+extern "C" int sss_collect_step(const sss_collect_args* c, int phase, void* stream) {
+  if (!c) return sss_fail(-1, "NULL argument");
+  if (phase != 0 && phase != 1) return sss_fail(-32, "sss_collect_step: phase must be 0 (actions) or 1 (record)");
+  if (c->num_envs < 0 || c->t < 0) return sss_fail(-32, "sss_collect_step: negative size");
+  if (!c->active_dev || !c->stage_sel_dev || !c->exec_sel_dev) return sss_fail(-1, "NULL argument");
+  if (phase == 0 && (!c->stage_idx_dev || !c->num_exec_dev)) return sss_fail(-1, "NULL argument");
+  if (phase == 1 && (!c->obs_f64_dev || !c->obs_i32_dev || !c->time_limit_dev || !c->wall_dev || !c->elapsed_dev || !c->step_counts_dev || !c->pending_reset_dev ||
+                     !c->job_idx_dev || !c->lgprob_dev || !c->rec_active_dev || !c->rec_t_before_dev || !c->rec_t_after_dev || !c->rec_rewards_dev ||
+                     !c->rec_stage_sel_dev || !c->rec_job_idx_dev || !c->rec_exec_sel_dev || !c->rec_lgprobs_dev || !c->rec_resets_dev || !c->flags_dev))
+    return sss_fail(-1, "NULL argument");
+  if (phase == 1 && c->obs_i32_stride < 8) return sss_fail(-32, "sss_collect_step: obs_i32 rows have 8 entries");
+  SssCollectArgs a;
+  a.num_envs = c->num_envs, a.asynchronous = c->asynchronous, a.t = c->t, a.duration = c->duration;
+  a.obs_f64 = c->obs_f64_dev, a.obs_i32 = c->obs_i32_dev, a.obs_i32_stride = c->obs_i32_stride, a.time_limit = c->time_limit_dev;
+  a.active = c->active_dev, a.wall = c->wall_dev, a.elapsed = c->elapsed_dev, a.step_counts = c->step_counts_dev, a.pending_reset = c->pending_reset_dev;
+  a.stage_sel = c->stage_sel_dev, a.job_idx = c->job_idx_dev, a.exec_sel = c->exec_sel_dev, a.lgprob = c->lgprob_dev;
+  a.stage_idx = c->stage_idx_dev, a.num_exec = c->num_exec_dev;
+  a.rec_active = c->rec_active_dev, a.rec_t_before = c->rec_t_before_dev, a.rec_t_after = c->rec_t_after_dev, a.rec_rewards = c->rec_rewards_dev;
+  a.rec_stage_sel = c->rec_stage_sel_dev, a.rec_job_idx = c->rec_job_idx_dev, a.rec_exec_sel = c->rec_exec_sel_dev, a.rec_lgprobs = c->rec_lgprobs_dev;
+  a.rec_resets = c->rec_resets_dev, a.flags = c->flags_dev;
+  if (a.num_envs == 0) return 0;
+  if (int rc = be_launch_collect(a, phase, stream)) return sss_fail(-30, std::string("collect launch failed: ") + be_error(rc));
+  return 0;
+}
+
 static int sss_mlp_check(const sss_mlp_args* a, bool backward) {
   if (!a || !a->w_dev || !a->a1_dev || !a->a2_dev) return sss_fail(-1, "NULL argument");
   if (a->rows < 0) return sss_fail(-31, "sss_mlp: negative row count");

@@ -120,79 +120,90 @@ class RolloutCollector:
         return {k: v.cpu().numpy() for k, v in self.env.rollout_stats().items()}
 
     def _loop(self, asynchronous: bool, duration: float, with_stats: bool) -> Rollouts:
+        """Both worker loops. Per step: the compact graph of the active envs' observations (recorded), the policy's
+        sample, `sss_collect_step` phase 0 (actions), `sss_step`, `sss_collect_step` phase 1 (time limit, who failed /
+        finished / goes on, the step's row of the record, the envs' clocks) and ONE device->host read of the flags the
+        control flow needs. The record lives in [T_cap, B] device arrays that grow geometrically."""
+        import ctypes
+
+        from .binding import SssCollectArgs, device_of
         env, dev, B = self.env, self.env.device, self.env.num_envs
         if not asynchronous or self._obs is None:
             self._obs = self._reset()
             self._wall = torch.zeros(B, dtype=torch.float64, device=dev)
-        obs, wall = self._obs, self._wall
+        wall = self._wall
         if asynchronous and self._pending_reset is not None:
-            obs = self._reset(mask=self._pending_reset)
+            self._reset(mask=self._pending_reset)
             wall = torch.where(self._pending_reset, torch.zeros_like(wall), wall)
         self._pending_reset = None
+        wall = wall.clone()
         elapsed = torch.zeros(B, dtype=torch.float64, device=dev)
-        active = torch.ones(B, dtype=torch.bool, device=dev)
-        rec: dict[str, list] = {k: [] for k in ("g", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
-        any_active = bool(active.any())
+        active = torch.ones(B, dtype=torch.uint8, device=dev)  # (bool view for the graph kernel and the caller's policy)
+        pending = torch.zeros(B, dtype=torch.uint8, device=dev)
+        stage_idx = torch.empty(B, dtype=torch.int32, device=dev)
+        num_exec = torch.empty(B, dtype=torch.int32, device=dev)
+        spec = (("active", torch.uint8), ("t_before", torch.float64), ("t_after", torch.float64), ("rewards", torch.float64), ("stage_sel", torch.int64),
+                ("job_idx", torch.int64), ("exec_sel", torch.int64), ("lgprobs", torch.float32), ("resets", torch.uint8))
+        cap = 1024
+        rec = {k: torch.empty((cap, B), dtype=dt, device=dev) for k, dt in spec}
+        flags = torch.zeros((cap, 8), dtype=torch.int32, device=dev)
+        graphs: list[dict[str, Any]] = []
+        lib, stream = env._b.lib, env._stream()
+        t, n_failed = 0, 0
+        any_active = B > 0
         while any_active:
-            g = self.env.decima_graph(active)  # recorded for training
+            if t == cap:  # grow the record
+                for k in rec:
+                    rec[k] = torch.cat([rec[k], torch.empty_like(rec[k])])
+                flags = torch.cat([flags, torch.zeros_like(flags)])
+                cap *= 2
+            act_b = active.view(torch.bool)
+            g = self.env.decima_graph(act_b)  # recorded for training
             a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.act(g, self.generator)
-            self.step_counts += active.long()
-            stage_idx = torch.where(active, a["stage_sel"], torch.full_like(a["stage_sel"], SKIP_ENV)).to(torch.int32)
-            num_exec = (1 + a["exec_sel"]).clamp(min=1).to(torch.int32)
-            obs, rew, term, trunc, info = self.tl_env.step({"stage_idx": stage_idx.contiguous(), "num_exec": num_exec.contiguous()})
-            bad = (info["err"] != 0) & active
-            done = (term | trunc) & active & ~bad
-            # ONE device->host round trip for everything the loop's control flow needs this step: an env failed / an
-            # episode ended / (sync mode) envs that go on after this step
-            any_bad, any_done, any_left = torch.stack([bad.any(), done.any(), (active & ~bad & ~done).any()]).tolist()
+            sel = [a[k] if a[k].dtype == torch.int64 and a[k].is_contiguous() else a[k].to(torch.int64).contiguous() for k in ("stage_sel", "job_idx", "exec_sel")]
+            lg = a["lgprob"] if a["lgprob"].dtype == torch.float32 and a["lgprob"].is_contiguous() else a["lgprob"].float().contiguous()
+            c = SssCollectArgs(B, int(asynchronous), t, float(duration), env.obs_f64.data_ptr(), env.obs_i32.data_ptr(), env.obs_i32.stride(0),
+                               self.tl_env.time_limit.data_ptr(), active.data_ptr(), wall.data_ptr(), elapsed.data_ptr(), self.step_counts.data_ptr(),
+                               pending.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), sel[2].data_ptr(), lg.data_ptr(), stage_idx.data_ptr(), num_exec.data_ptr(),
+                               *(rec[k].data_ptr() for k, _ in spec), flags[t].data_ptr())
+            with device_of(dev):
+                env._b.check(lib.sss_collect_step(ctypes.byref(c), 0, stream))
+            env.step_async(stage_idx, num_exec)
+            with device_of(dev):
+                env._b.check(lib.sss_collect_step(ctypes.byref(c), 1, stream))
+            # ONE device->host round trip for everything the loop's control flow needs this step
+            any_bad, any_done, any_left, bad_env, any_recorded = flags[t, :5].tolist()
             if any_bad:
-                self.env_errors += int(bad.sum())
+                n_bad = int(pending.sum()) - n_failed
+                n_failed += n_bad
+                self.env_errors += n_bad
                 if self.on_env_error == "raise":
                     from .binding import ERROR_NAMES
-                    b = int(bad.nonzero()[0])
-                    code = int(info["err"][b])
-                    err = RuntimeError(f"env {b} (seed {int(self.seeds[b] - self.seed_step)}), rollout step {len(rec['g'])}: "
+                    b = bad_env - 1
+                    code = int(env.obs_i32[b, 7])
+                    err = RuntimeError(f"env {b} (seed {int(self.seeds[b] - self.seed_step)}), rollout step {t}: "
                                        f"{ERROR_NAMES.get(code, code)}; action stage_idx={int(stage_idx[b])} num_exec={int(num_exec[b])}")
                     # what a bug report needs: the env's seed, time limit and action history
                     err.case = {"seed": int(self.seeds[b] - self.seed_step), "time_limit": float(self.tl_env.time_limit[b]), "code": code,
-                                "stage_idx": [int(x[b]) for x in rec["stage_sel"]] + [int(stage_idx[b])],
-                                "num_exec": [int(x[b]) + 1 for x in rec["exec_sel"]] + [int(num_exec[b])]}
+                                "stage_idx": [int(x) for x in rec["stage_sel"][:t, b]] + [int(stage_idx[b])],
+                                "num_exec": [int(x) + 1 for x in rec["exec_sel"][:t, b]] + [int(num_exec[b])]}
                     raise err
                 # truncate: the failing step is not recorded and the env sits out the rest of this
                 # collection (async: it starts its next episode at the next collection)
-                active = active & ~bad
-                self._pending_reset = bad if self._pending_reset is None else (self._pending_reset | bad)
-                if not bool(active.any()):
+                if not any_recorded:
                     break
-            new_wall = torch.where(active, info["wall_time"], wall)
-            rec["g"].append(g)
-            rec["active"].append(active)
-            rec["rewards"].append(torch.where(active, rew, torch.zeros_like(rew)))
-            for k in ("stage_sel", "job_idx", "exec_sel"):
-                rec[k].append(a[k].clone())
-            rec["lgprobs"].append(a["lgprob"].float().clone())
-            if asynchronous:
-                rec["t_before"].append(elapsed)
-                elapsed = torch.where(active, elapsed + (new_wall - wall), elapsed)
-                rec["t_after"].append(elapsed)
-                rec["resets"].append(done)
-                if any_done:
-                    obs = self._reset(mask=done)
-                    new_wall = torch.where(done, torch.zeros_like(new_wall), new_wall)
-                active = active & (elapsed < duration)
-                any_active = bool(active.any())
-            else:
-                rec["t_before"].append(wall)
-                rec["t_after"].append(new_wall)
-                rec["resets"].append(torch.zeros_like(done))
-                active = active & ~done
-                any_active = any_left
-            wall = new_wall
-        self._obs, self._wall = obs, wall
-        st = lambda k: torch.stack(rec[k]) if rec[k] else torch.zeros((0, B), device=dev)  # noqa: E731
-        return Rollouts(graph=concat_graphs(rec["g"]), active=st("active"), t_before=st("t_before"), t_after=st("t_after"),
-                        rewards=st("rewards"), stage_sel=st("stage_sel"), job_idx=st("job_idx"), exec_sel=st("exec_sel"),
-                        lgprobs=st("lgprobs"), resets=st("resets"), stats=self._stats() if with_stats else {})
+            graphs.append(g)
+            if asynchronous and any_done:
+                self._reset(mask=rec["resets"][t].view(torch.bool))
+            t += 1
+            any_active = bool(any_left)
+        if n_failed:
+            self._pending_reset = pending.view(torch.bool)
+        self._obs, self._wall = True, wall  # (_obs: the envs are inside their episodes)
+        out = {k: rec[k][:t] for k, _ in spec}
+        return Rollouts(graph=concat_graphs(graphs), active=out["active"].view(torch.bool), t_before=out["t_before"], t_after=out["t_after"],
+                        rewards=out["rewards"], stage_sel=out["stage_sel"], job_idx=out["job_idx"], exec_sel=out["exec_sel"],
+                        lgprobs=out["lgprobs"], resets=out["resets"].view(torch.bool), stats=self._stats() if with_stats else {})
 
     def collect_sync(self, with_stats: bool = True) -> Rollouts:
         """one full episode per env (rollout_worker.py:133-159)"""
