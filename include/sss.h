@@ -304,6 +304,60 @@ typedef struct sss_decima_sample_args {
 } sss_decima_sample_args;
 int sss_decima_sample(int n_obs, int which, const sss_decima_sample_args* a, void* stream);
 
+/* Decima's encoder for one batch of observations in ONE call (scheduler.py:142-283: node embeddings by message passing over
+ * the DAG layers, per-job and per-observation summaries): the launches sss_gnn_launch offers one by one - PREP, SINK, one LAYER
+ * per DAG layer from max_depth - 1 down to 0, DAGHID (+ MERGE), DAGSUM, GLOBHID, GLOBSUM - preceded by the scan and the kernel
+ * that build the layers' lists of receiving nodes. The lists' lengths never leave the device: a LAYER launch is sized by n_nodes
+ * and reads its row count and list position from layer_totals_dev, so the call enqueues everything and returns (no device->host
+ * round trip; with sss_gnn_launch the caller has to read the list sizes back between SINK and the first LAYER).
+ * max_depth: an upper bound of the observations' DAG depth (e.g. the deepest template of the workload); layers beyond an
+ * observation's own depth are empty. Graph arrays as written by sss_decima_graph_build (dst_dev / edge_layers_dev may be NULL
+ * when the batch has no edge); layer_cnt_dev = its i32[32][n_obs] output. Parameters packed as for sss_gnn_launch (w_msg16_dev / w_update16_dev: the optional 16-lane images). Outputs:
+ * h_dev f32[n_nodes,16] node embeddings, h_dag_dev f32[n_jobs,16], h_glob_dev f32[n_obs,16]; h_init_dev f32[n_nodes,16] and
+ * tmp_dev f32[max(n_nodes, n_jobs),16] are work space, as are env_off_dev i64[32 * n_obs], layer_totals_dev i64[32] and
+ * recv_dev i64[recv_cap] with recv_cap >= n_nodes * max_depth. Launches on the CURRENT device's stream (no handle). */
+typedef struct sss_gnn_encode_args {
+  int64_t n_nodes, n_jobs;
+  int32_t n_obs, max_depth;
+  float slope;
+  int32_t pad_;
+  const float* w_prep_dev;
+  const float* w_update_dev;
+  const float* w_msg_dev;
+  const float* w_dag_dev;
+  const float* w_glob_dev;
+  const float* w_msg16_dev;     /* nullable */
+  const float* w_update16_dev;  /* nullable */
+  const float* x_dev;
+  const int32_t* out_deg_dev;
+  const int32_t* obs_depth_dev;
+  const int64_t* node_obs_dev;
+  const int64_t* dst_dev;
+  const int64_t* out_start_dev;
+  const uint32_t* edge_layers_dev;
+  const int32_t* node_recv_dev;
+  const int64_t* job_first_dev;
+  const int64_t* job_nodes_dev;
+  const int64_t* obs_job_off_dev;
+  const int64_t* obs_jobs_dev;
+  const int64_t* obs_node_off_dev;
+  const int64_t* obs_nodes_dev;
+  const int32_t* layer_cnt_dev;
+  float* h_init_dev;
+  float* h_dev;
+  float* tmp_dev;
+  float* h_dag_dev;
+  float* h_glob_dev;
+  int64_t* env_off_dev;
+  int64_t* layer_totals_dev;
+  int64_t* recv_dev;
+  int64_t recv_cap;
+  int64_t layer_rows_hint[32]; /* host values: roughly how many nodes layer l updates (e.g. layer_totals of the previous step,
+                                  read back lazily); only sizes the launch grids - every row is processed whatever it says.
+                                  0: no idea (the grid is sized by n_nodes) */
+} sss_gnn_encode_args;
+int sss_gnn_encode(const sss_gnn_encode_args* a, void* stream);
+
 /* The weight and bias gradient of a Linear layer over a minibatch (what autograd's AddmmBackward
  * computes inside the reference's loss.backward(), trainers/ppo.py:129-131 / schedulers/scheduler.py:44-54):
  *   gw[n][m] = sum_k dy[k][n] * x[k][m],  gb[n] = sum_k dy[k][n]   for x f32[K][ldx] (M columns used), dy f32[K][ldy]

@@ -93,6 +93,14 @@ ERROR_NAMES = {
     10: "more job arrivals than max_jobs",
 }
 
+class SssGnnEncodeArgs(C.Structure):  # include/sss.h sss_gnn_encode_args
+    _fields_ = ([("n_nodes", C.c_int64), ("n_jobs", C.c_int64), ("n_obs", C.c_int32), ("max_depth", C.c_int32), ("slope", C.c_float), ("pad_", C.c_int32)]
+                + [(k + "_dev", C.c_void_p) for k in ("w_prep", "w_update", "w_msg", "w_dag", "w_glob", "w_msg16", "w_update16", "x", "out_deg", "obs_depth", "node_obs", "dst",
+                                                      "out_start", "edge_layers", "node_recv", "job_first", "job_nodes", "obs_job_off", "obs_jobs", "obs_node_off",
+                                                      "obs_nodes", "layer_cnt", "h_init", "h", "tmp", "h_dag", "h_glob", "env_off", "layer_totals", "recv")]
+                + [("recv_cap", C.c_int64), ("layer_rows_hint", C.c_int64 * 32)])
+
+
 class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args
     _fields_ = [("num_envs", C.c_int32), ("asynchronous", C.c_int32), ("t", C.c_int64), ("duration", C.c_double), ("obs_f64_dev", C.c_void_p), ("obs_i32_dev", C.c_void_p),
                 ("obs_i32_stride", C.c_int64), ("time_limit_dev", C.c_void_p), ("active_dev", C.c_void_p), ("wall_dev", C.c_void_p), ("elapsed_dev", C.c_void_p),
@@ -110,7 +118,7 @@ class SssMlpArgs(C.Structure):  # include/sss.h sss_mlp_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_last_error", "sss_destroy"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_gnn_encode", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -144,6 +152,7 @@ class Binding:
         L.sss_linear_wgrad_scratch.argtypes = [C.c_int, C.c_int]
         L.sss_linear_wgrad_scratch.restype = C.c_int64
         L.sss_linear_wgrad.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sss_gnn_encode.argtypes = [C.POINTER(SssGnnEncodeArgs), C.c_void_p]
         L.sss_collect_step.argtypes = [C.POINTER(SssCollectArgs), C.c_int, C.c_void_p]
         L.sss_mlp_supported.argtypes = [C.c_int] * 5
         L.sss_mlp_forward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]

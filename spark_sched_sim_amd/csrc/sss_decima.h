@@ -38,6 +38,7 @@ struct SssDecimaListArgs {
   int64_t layer_base[32];    // start of layer l's list inside recv
   int64_t* recv;             // i64[sum of all counts]
   int n_layers;
+  const int64_t* totals;     // nullable: i64[32] on the device, the lists' lengths - layer_base is then their running sum
 };
 
 SSS_SHARED_DYN(g_dec_lds);
@@ -170,8 +171,10 @@ SSS_KERNEL void sss_decima_lists_kernel(int num_envs, SssDecimaListArgs d) {
   if (n == 0) return;
   int64_t n0 = d.node_off[env];
   uint64_t lt = bit64(lane) - 1;
+  int64_t base = 0;
   for (int l = 0; l < d.n_layers; l++) {
-    int64_t pos = d.layer_base[l] + d.env_off[(size_t)l * num_envs + env];
+    int64_t pos = (d.totals ? base : d.layer_base[l]) + d.env_off[(size_t)l * num_envs + env];
+    if (d.totals) base += d.totals[l];
     for (int i0 = 0; i0 < n; i0 += 64) {
       bool on = i0 + lane < n && ((d.node_recv[n0 + i0 + lane] >> l) & 1u);
       uint64_t bal = wave_ballot(on);

@@ -61,6 +61,9 @@ struct SssGnnArgs {
   const float* w2;      // LAYER: the update MLP (w = the message MLP)
   const float *w16, *w2_16;  // LAYER, nullable: the two MLPs in the 16-lanes-per-row image (sss_gnn16.h)
   const int32_t* node_recv;  // LAYER (nullable: then COMMIT launches follow) / MERGE: per node, the layers it receives in
+  const int64_t* layer_totals;  // LAYER, nullable: i64[32] on the device - the row count is layer_totals[layer] and idx0 starts
+                                // after the lists of the layers below it (no host round trip for the list sizes); n_rows is then
+                                // an upper bound that sizes the grid
   float slope;          // LeakyReLU negative slope (GNN MLPs)
   int E;                // EXEC: number of executors
   int layer;            // LAYER

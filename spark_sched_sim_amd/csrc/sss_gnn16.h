@@ -156,6 +156,12 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
   const int g = threadIdx.x & 15;
   if (KIND == GNN_LAYER) {
     // tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
+    if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode): most workgroups of a sparse layer leave here
+      int64_t off = 0;
+      for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
+      a.n_rows = a.layer_totals[a.layer], a.idx0 += off;
+      if ((int64_t)blockIdx.x * 16 >= a.n_rows) return;
+    }
     if (a.w16 && a.w2_16) {  // the host has the images ready: a straight copy, 16 bytes per thread and pass
       static_assert(MlpGnn::TOTAL % 4 == 0, "images are copied 16 bytes at a time");
       for (int t = threadIdx.x; t < MlpGnn::TOTAL / 4; t += 256) {

@@ -435,7 +435,7 @@ extern "C" int sss_decima_layer_lists(int num_envs, const sss_decima_lists* g, v
   SssDecimaListArgs d;
   d.node_off = g->node_off_dev, d.obs_nodes = g->obs_nodes_dev, d.node_recv = g->node_recv_dev, d.env_off = g->env_off_dev;
   for (int l = 0; l < 32; l++) d.layer_base[l] = g->layer_base[l];
-  d.recv = g->recv_dev, d.n_layers = g->n_layers;
+  d.recv = g->recv_dev, d.n_layers = g->n_layers, d.totals = nullptr;
   if (int rc = be_launch_decima_lists(num_envs, d, stream)) return sss_fail(-30, std::string("decima lists launch failed: ") + be_error(rc));
   return 0;
 }
@@ -496,10 +496,69 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   a.edge_layers = g->edge_layers_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.node_loc = g->node_loc_dev;
   a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
   a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
-  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev;
+  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev, a.layer_totals = nullptr;
   if (kind == GNN_MERGE && !g->node_recv_dev) return sss_fail(-1, "NULL argument");
   if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
+  return 0;
+}
+
+// The encoder of a Decima step in one call: list sizes stay on the device (the layer launches are sized by an upper bound
+// and read their row count themselves), so nothing here waits for the device.
+extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
+  if (!g) return sss_fail(-1, "NULL argument");
+  if (g->n_nodes < 0 || g->n_jobs < 0 || g->n_obs < 1) return sss_fail(-33, "sss_gnn_encode: bad sizes");
+  if (g->max_depth < 0 || g->max_depth > 32) return sss_fail(-27, "bad layer count");
+  if (!g->w_prep_dev || !g->w_update_dev || !g->w_msg_dev || !g->w_dag_dev || !g->w_glob_dev || !g->x_dev || !g->out_deg_dev || !g->obs_depth_dev || !g->node_obs_dev ||
+      !g->out_start_dev || !g->node_recv_dev || !g->job_first_dev || !g->job_nodes_dev || !g->obs_job_off_dev || !g->obs_jobs_dev ||
+      !g->obs_node_off_dev || !g->obs_nodes_dev || !g->layer_cnt_dev || !g->h_init_dev || !g->h_dev || !g->tmp_dev || !g->h_dag_dev || !g->h_glob_dev ||
+      !g->env_off_dev || !g->layer_totals_dev || !g->recv_dev)
+    return sss_fail(-1, "NULL argument");
+  // (dst_dev / edge_layers_dev may be NULL: a batch without edges)
+  if (g->recv_cap < g->n_nodes * (int64_t)g->max_depth) return sss_fail(-33, "sss_gnn_encode: recv_dev must hold n_nodes * max_depth entries");
+  if (g->n_nodes == 0 || g->n_jobs == 0) return 0;
+  auto fail = [](const char* what, int rc) { return sss_fail(-30, std::string(what) + " launch failed: " + be_error(rc)); };
+  // lengths of the layers' lists of receiving nodes, their per-env offsets, the lists
+  SssPrefixArgs p;
+  p.src = g->layer_cnt_dev, p.row_stride = g->n_obs, p.col_stride = 1, p.mask = nullptr, p.n_rows = 32, p.n_cols = g->n_obs;
+  p.off = g->env_off_dev, p.cnt = nullptr, p.totals = g->layer_totals_dev;
+  if (int rc = be_launch_prefix_rows(p, stream)) return fail("prefix", rc);
+  if (g->max_depth > 0) {
+    SssDecimaListArgs d;
+    d.node_off = g->obs_node_off_dev, d.obs_nodes = g->obs_nodes_dev, d.node_recv = (const uint32_t*)g->node_recv_dev, d.env_off = g->env_off_dev;
+    for (int l = 0; l < 32; l++) d.layer_base[l] = 0;
+    d.recv = g->recv_dev, d.n_layers = g->max_depth, d.totals = g->layer_totals_dev;
+    if (int rc = be_launch_decima_lists(g->n_obs, d, stream)) return fail("decima lists", rc);
+  }
+  SssGnnArgs a;
+  memset(&a, 0, sizeof a);
+  a.slope = g->slope, a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev, a.tmp = g->tmp_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev;
+  a.out_deg = g->out_deg_dev, a.obs_depth = g->obs_depth_dev, a.node_obs = g->node_obs_dev, a.dst = g->dst_dev, a.out_start = g->out_start_dev;
+  a.edge_layers = g->edge_layers_dev, a.job_first = g->job_first_dev, a.job_nodes = g->job_nodes_dev, a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
+  auto run = [&](int kind, int64_t rows, const float* w) {
+    a.n_rows = rows, a.w = w;
+    return be_launch_gnn(kind, a, stream);
+  };
+  a.out = g->h_init_dev;
+  if (int rc = run(GNN_PREP, g->n_nodes, g->w_prep_dev)) return fail("gnn", rc);
+  a.out = nullptr;
+  if (int rc = run(GNN_SINK, g->n_nodes, g->w_update_dev)) return fail("gnn", rc);
+  // the layers, deepest first (scheduler.py:209-211): embeddings alternate between h and tmp per update (sss_gnn.h)
+  a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev;
+  a.w2 = g->w_update_dev, a.w16 = g->w_msg16_dev, a.w2_16 = g->w_update16_dev;
+  for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
+    a.layer = lvl;
+    // (n_rows only sizes the grid here: the kernel reads the list's length itself and strides over all of it)
+    int64_t rows = g->layer_rows_hint[lvl] > 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : g->n_nodes;
+    if (rows > g->n_nodes) rows = g->n_nodes;
+    if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
+  }
+  a.idx0 = nullptr, a.layer_totals = nullptr, a.w2 = nullptr, a.w16 = nullptr, a.w2_16 = nullptr, a.layer = 0;
+  if (int rc = run(GNN_DAGHID, g->n_nodes, g->w_dag_dev)) return fail("gnn", rc);  // (brings the embeddings left in tmp home: MERGE)
+  a.node_recv = nullptr;
+  if (int rc = run(GNN_DAGSUM, g->n_jobs, g->w_dag_dev)) return fail("gnn", rc);
+  if (int rc = run(GNN_GLOBHID, g->n_jobs, g->w_glob_dev)) return fail("gnn", rc);
+  if (int rc = run(GNN_GLOBSUM, g->n_obs, g->w_glob_dev)) return fail("gnn", rc);
   return 0;
 }
 

@@ -476,6 +476,8 @@ class DecimaPolicy(nn.Module):
         x = g["x"]
         dev = x.device
         M, J, B = x.shape[0], g["job_obs"].numel(), g["n_obs"]
+        if "max_depth" in g and "layer_cnt" in g and 0 <= g["max_depth"] <= 32:
+            return self._encode_one_call(g, w)
         h_init = torch.empty((M, 16), dtype=torch.float32, device=dev)
         self._launch("prep", M, w["prep"], x=x, out=h_init)
         h = torch.empty_like(h_init)
@@ -496,6 +498,38 @@ class DecimaPolicy(nn.Module):
         h_glob = torch.empty((B, 16), dtype=torch.float32, device=dev)
         self._launch("globhid", J, w["glob"], h_dag=h_dag, tmp=tmp)
         self._launch("globsum", B, w["glob"], tmp=tmp, h_glob=h_glob, obs_job_off=g["obs_job_off"], obs_jobs=g["obs_jobs"])
+        return {"node": h, "dag": h_dag, "glob": h_glob}
+
+    @torch.no_grad()
+    def _encode_one_call(self, g: dict[str, Any], w: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        """the encoder through `sss_gnn_encode` (include/sss.h): every launch of the pass enqueued by one call, the layers'
+        list sizes stay on the device - no device->host round trip between the graph kernel and the scores"""
+        import ctypes
+
+        from .binding import SssGnnEncodeArgs, device_of
+        x = g["x"]
+        dev = x.device
+        M, J, B, D = x.shape[0], g["job_obs"].numel(), g["n_obs"], int(g["max_depth"])
+        f32 = lambda n: torch.empty((n, 16), dtype=torch.float32, device=dev)  # noqa: E731
+        h_init, h, tmp, h_dag, h_glob = f32(M), f32(M), f32(max(M, J)), f32(J), f32(B)
+        sc = getattr(self, "_enc_scratch", None)
+        need = max(M * D, 1)
+        if sc is None or sc["recv"].device != dev or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
+            hint = torch.zeros(32, dtype=torch.int64)
+            sc = self._enc_scratch = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
+                                      "env_off": torch.empty(32 * B, dtype=torch.int64, device=dev), "tot": torch.empty(32, dtype=torch.int64, device=dev),
+                                      "hint": hint.pin_memory() if dev.type == "cuda" else hint}
+        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731  (a batch without edges: dst / edge_layers empty)
+        a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
+                             p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
+                             p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
+                             p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(sc["tot"]), p(sc["recv"]), sc["recv"].numel(),
+                             # the list sizes of the PREVIOUS pass, copied back without waiting (whatever is there: they only size grids)
+                             (ctypes.c_int64 * 32)(*sc["hint"].tolist()))
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        with device_of(dev):
+            self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
+        sc["hint"].copy_(sc["tot"], non_blocking=True)
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()

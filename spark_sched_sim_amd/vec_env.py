@@ -80,6 +80,8 @@ class VecSparkSchedSimEnv:
         self._act_nexec = torch.ones(B, dtype=torch.int32, device=dev)
         self._closed = False
         self._dg_pool: dict[int, torch.Tensor] = {}
+        from .workload import pack_max_depth
+        self.max_dag_depth = pack_max_depth(self._pack)  # bound of an observation's DAG layers: sizes sss_gnn_encode's layer launches
         # gymnasium.vector.VectorEnv attributes; the per-env action space is the reference's at
         # construction (its stage_idx bound follows each observation: valid range is [-1, n_nodes[i]))
         from .spaces import make_action_space, make_observation_space
@@ -249,6 +251,7 @@ class VecSparkSchedSimEnv:
                                "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")))
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
+        g["max_depth"] = self.max_dag_depth
         g["obs_nodes"], g["obs_jobs"] = cnt_t[0], cnt_t[2]
         g["obs_node_off"], g["obs_job_off"] = off[0], off[2]
         g["_keepalive"] = (off, act8)

@@ -360,6 +360,26 @@ def pack_section(pack: bytes, name: str) -> np.ndarray:
     return np.frombuffer(pack, dtype=_SECTIONS[i][1], count=length // np.dtype(_SECTIONS[i][1]).itemsize, offset=off)
 
 
+def pack_max_depth(pack: bytes) -> int:
+    """the longest path (in edges) of any template's stage DAG: an upper bound of the number of DAG layers
+    (topological generations beyond the first, decima/utils.py:246-267) an observation of this workload can have"""
+    edges, e_off, s_off = pack_section(pack, "edges"), pack_section(pack, "tmpl_edge_off"), pack_section(pack, "tmpl_stage_off")
+    best = 0
+    for t in range(len(e_off) - 1):
+        n = int(s_off[t + 1] - s_off[t])
+        es = np.asarray(edges).reshape(-1, 2)[int(e_off[t]): int(e_off[t + 1])].tolist()
+        dist = [0] * n
+        for _ in range(n):  # longest-path relaxation (the DAGs have at most 64 stages)
+            moved = False
+            for u, v in es:
+                if dist[v] < dist[u] + 1:
+                    dist[v], moved = dist[u] + 1, True
+            if not moved:
+                break
+        best = max(best, max(dist, default=0))
+    return best
+
+
 def build_pack(raw: dict | None = None, seed: int = DEFAULT_SEED) -> bytes:
     if raw is None:
         raw = make_raw_workload(seed)

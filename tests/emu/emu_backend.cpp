@@ -164,7 +164,15 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
   switch (kind) {
     case GNN_PREP: return gnn_run_kind<GNN_PREP>(a);
     case GNN_SINK: return gnn_run_kind<GNN_SINK>(a);
-    case GNN_LAYER: return gnn_run_kind<GNN_LAYER>(a);
+    case GNN_LAYER: {
+      SssGnnArgs b = a;
+      if (b.layer_totals) {  // (the gfx950 kernel reads the list's length and position from the device, sss_gnn16.h)
+        int64_t off = 0;
+        for (int l = 0; l < b.layer; l++) off += b.layer_totals[l];
+        b.n_rows = b.layer_totals[b.layer], b.idx0 += off;
+      }
+      return gnn_run_kind<GNN_LAYER>(b);
+    }
     case GNN_COMMIT: return gnn_run_kind<GNN_COMMIT>(a);
     case GNN_MERGE: return gnn_run_kind<GNN_MERGE>(a);
     case GNN_DAGSUM: return gnn_run_kind<GNN_DAGSUM>(a);
