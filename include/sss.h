@@ -156,6 +156,11 @@ typedef struct sss_decima_graph {
   int64_t* out_start_dev; /* i64[M] flat id of the node's first out-edge; a node's out-edges are contiguous */
   int32_t* out_deg_dev;   /* i32[M] number of out-edges */
   int32_t* layer_cnt_dev; /* i32[32][num_envs]: [l][b] = nodes of env b that are sources of layer-l edges */
+  /* optional (both or neither): sched_off_dev i64[num_envs] = exclusive prefix sums of the envs' schedulable-stage counts
+   * (obs_i32[OBS_N_SCHED], 0 for inactive envs); sched_list_dev then receives the flat ids of the schedulable nodes, env by
+   * env in node order - the row list of the stage-score launch (sss_gnn_launch STAGE), with no padding */
+  const int64_t* sched_off_dev;
+  int64_t* sched_list_dev;
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
 

@@ -42,7 +42,7 @@ class SssDecimaGraph(C.Structure):
                 ("node_recv_dev", C.c_void_p), ("stage_mask_dev", C.c_void_p), ("src_dev", C.c_void_p), ("dst_dev", C.c_void_p),
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
-                ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p)]
+                ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p), ("sched_off_dev", C.c_void_p), ("sched_list_dev", C.c_void_p)]
 
 
 class SssDecimaLists(C.Structure):

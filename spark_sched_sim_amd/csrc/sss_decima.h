@@ -28,6 +28,8 @@ struct SssDecimaArgs {
   int32_t* out_deg;    // i32[M] number of out-edges
   int32_t* obs_depth;
   int32_t* layer_cnt;   // i32[32][B]: number of receiving nodes of DAG layer l in env b
+  const int64_t* sched_off;  // nullable, i64[B]: exclusive prefix of the envs' schedulable-stage counts ...
+  int64_t* sched_list;       // ... and where the flat ids of the schedulable nodes go, env by env in node order
 };
 
 struct SssDecimaListArgs {
@@ -147,6 +149,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
     }
     uint64_t bal = wave_ballot(sched);
     if (i < n) d.sched_rank[n0 + i] = sched ? (int64_t)(run + popc64(bal & lt)) : -1;
+    if (sched && d.sched_list) d.sched_list[d.sched_off[env] + run + popc64(bal & lt)] = n0 + i;
     run += popc64(bal);
   }
   depth = ~wave_min_u32(~depth);

@@ -6,6 +6,7 @@
 // output fused in:
 //
 //   PREP    h_init[n] = prep(x[n])                                            (scheduler.py:200)
+//           (given the update MLP as `w2` and `h`, the same launch also does SINK for the row)
 //   SINK    h[n]      = is_parent[n] ? 0 : update(h_init[n])                  (scheduler.py:206-209)
 //                       (h_init[n] instead where the node's observation has a single DAG layer, :196-198)
 //   LAYER   tmp[r]    = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
@@ -160,10 +161,20 @@ template <int KIND>
 SSS_DEV void gnn_row(const SssGnnArgs& a, int64_t r, const float* w, const float* w2) {
   constexpr int F = GNN_EMB;
   if (KIND == GNN_PREP) {
-    float x[GNN_NF], h2[16];
+    float x[GNN_NF], h2[16], hi[F];
     gnn_load<GNN_NF>(a.x + r * GNN_NF, x);
     gnn_hidden<GNN_NF, 32, 16, 0>(w, x, h2, a.slope);
-    gnn_out<GNN_NF, 32, 16, F>(w, h2, 1.0f, [&](int o, float v) { a.out[r * F + o] = v; });
+    gnn_out<GNN_NF, 32, 16, F>(w, h2, 1.0f, [&](int o, float v) { hi[o] = v, a.out[r * F + o] = v; });
+    if (a.w2 && a.h) {  // SINK in the same pass (w2 = the update MLP): the row's h_init is still in registers
+      bool par = a.out_deg[r] != 0;
+      bool skip = a.obs_depth != nullptr && a.obs_depth[a.node_obs[r]] == 0;
+      if (skip || par) {
+        GNN_UNROLL for (int i = 0; i < F; i++) a.h[r * F + i] = skip ? hi[i] : 0.0f;
+        return;
+      }
+      gnn_hidden<F, 32, 16, 0>(w2, hi, h2, a.slope);
+      gnn_out<F, 32, 16, F>(w2, h2, 1.0f, [&](int o, float v) { a.h[r * F + o] = v; });
+    }
   } else if (KIND == GNN_SINK) {
     float x[F], h2[16];
     gnn_load<F>(a.h_init + r * F, x);

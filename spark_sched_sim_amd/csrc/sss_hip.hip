@@ -160,10 +160,10 @@ static int be_launch_prefix_rows(const SssPrefixArgs& a, void* stream) {
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
   constexpr int NW = gnn_weight_count<KIND>();
-  constexpr int NW2 = KIND == GNN_LAYER ? GNN_W_GNN16 : 0;
+  constexpr int NW2 = (KIND == GNN_LAYER || KIND == GNN_PREP) ? GNN_W_GNN16 : 0;  // (PREP: the update MLP of a fused SINK)
   __shared__ __attribute__((aligned(16))) float w_lds[NW + NW2 + 4];
   for (int i = threadIdx.x; i < NW; i += 256) w_lds[i] = a.w[i];
-  if (NW2) for (int i = threadIdx.x; i < NW2; i += 256) w_lds[NW + i] = a.w2[i];
+  if (NW2 && a.w2) for (int i = threadIdx.x; i < NW2; i += 256) w_lds[NW + i] = a.w2[i];
   __syncthreads();
   int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r < a.n_rows) gnn_row<KIND>(a, r, w_lds, w_lds + NW);
@@ -183,7 +183,8 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
     // bound and 16 lanes per row win (1024 envs: 45 -> 22 us / 41 -> 29 us); with many rows the launch is
     // throughput-bound and one thread per row, where 64 rows share every weight read, wins (4096 envs: 52 / 42 us
     // against 59 / 69 us). STAGE's n_rows counts all nodes (its list is padded; ~1 in 22 is schedulable).
-    case GNN_STAGE: return (a.w16 && a.n_rows <= 22 * 24000) ? gnn16_launch<GNN_STAGE>(a, stream) : gnn_launch_kind<GNN_STAGE>(a, stream);
+    // (a.layer != 0: the list holds exactly the schedulable nodes, sss_decima_graph_build's sched_list)
+    case GNN_STAGE: return (a.w16 && a.n_rows <= (a.layer ? 24000 : 22 * 24000)) ? gnn16_launch<GNN_STAGE>(a, stream) : gnn_launch_kind<GNN_STAGE>(a, stream);
     case GNN_EXEC: return (a.w16 && a.n_rows <= 24000) ? gnn16_launch<GNN_EXEC>(a, stream) : gnn_launch_kind<GNN_EXEC>(a, stream);
     // node rows (a million per launch at 4096 envs): throughput-bound, one thread per row (sss_gnn.h)
     case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);

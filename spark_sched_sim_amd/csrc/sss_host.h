@@ -425,6 +425,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   d.src = g->src_dev, d.dst = g->dst_dev, d.edge_obs = g->edge_obs_dev, d.edge_layers = g->edge_layers_dev;
   d.job_obs = g->job_obs_dev, d.job_cap = g->job_cap_dev, d.job_first = g->job_first_dev, d.obs_depth = g->obs_depth_dev;
   d.job_nodes = g->job_nodes_dev, d.out_start = g->out_start_dev, d.out_deg = g->out_deg_dev, d.layer_cnt = g->layer_cnt_dev;
+  d.sched_off = g->sched_off_dev, d.sched_list = g->sched_off_dev ? g->sched_list_dev : nullptr;
+  if (g->sched_off_dev && !g->sched_list_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));
   return 0;
 }
@@ -539,10 +541,9 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
     a.n_rows = rows, a.w = w;
     return be_launch_gnn(kind, a, stream);
   };
-  a.out = g->h_init_dev;
+  a.out = g->h_init_dev, a.w2 = g->w_update_dev;  // PREP and SINK in one pass over the nodes
   if (int rc = run(GNN_PREP, g->n_nodes, g->w_prep_dev)) return fail("gnn", rc);
   a.out = nullptr;
-  if (int rc = run(GNN_SINK, g->n_nodes, g->w_update_dev)) return fail("gnn", rc);
   // the layers, deepest first (scheduler.py:209-211): embeddings alternate between h and tmp per update (sss_gnn.h)
   a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev;
   a.w2 = g->w_update_dev, a.w16 = g->w_msg16_dev, a.w2_16 = g->w_update16_dev;

@@ -537,8 +537,12 @@ class DecimaPolicy(nn.Module):
         """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
         M = g["x"].shape[0]
         out = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
-        self._launch("stage", M, self._packed[1]["stage"], w16=self._packed[1].get("stage16"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"], h_glob=h["glob"],
-                     out=out, idx0=self._index_list(g["stage_mask"]), node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
+        if "sched_list" in g:  # the graph kernel's list of the schedulable nodes: exactly the rows to score (layer=1: no padding)
+            rows, idx0, exact = g["sched_list"].numel(), g["sched_list"], 1
+        else:
+            rows, idx0, exact = M, self._index_list(g["stage_mask"]), 0
+        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, w16=self._packed[1].get("stage16"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
+                     h_glob=h["glob"], out=out, idx0=idx0, node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
         return out
 
     @torch.no_grad()

@@ -216,13 +216,14 @@ class VecSparkSchedSimEnv:
         # one small kernel over the obs_i32 rows in place (include/sss.h sss_prefix_rows) instead of a handful of
         # tensor ops; the totals are the one device->host sync
         act8 = active.to(torch.uint8).contiguous() if active is not None else None
-        scan = torch.empty((2, 3, B), dtype=torch.int64, device=dev)
-        tot = torch.empty(3, dtype=torch.int64, device=dev)
+        # (rows of the scan: n_nodes, n_edges, n_jobs, n_sched = columns 0..3 of obs_i32)
+        scan = torch.empty((2, 4, B), dtype=torch.int64, device=dev)
+        tot = torch.empty(4, dtype=torch.int64, device=dev)
         with device_of(dev):  # (sss_prefix_rows takes no handle: it launches on the CURRENT device)
-            self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 3, B,
+            self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 4, B,
                                                      scan[0].data_ptr(), scan[1].data_ptr(), tot.data_ptr(), self._stream()))
-        off, cnt_t = scan[0], scan[1]  # [3, B] each
-        M, Ed, J = (int(v) for v in tot.tolist())
+        off, cnt_t = scan[0], scan[1]  # [4, B] each
+        M, Ed, J, S = (int(v) for v in tot.tolist())
         # buffers hold at least one element so that their pointers are never NULL; `g` gets exact views
         pool = self._dg_pool if reuse_buffers else None
 
@@ -240,15 +241,16 @@ class VecSparkSchedSimEnv:
                "src": mk(Ed, torch.int64), "dst": mk(Ed, torch.int64), "edge_obs": mk(Ed, torch.int64), "edge_layers": mk(Ed, torch.int32),
                "job_obs": mk(J, torch.int64), "job_cap": mk(J, torch.int64), "job_first": mk(J, torch.int64), "obs_depth": mk(B, torch.int32),
                "job_nodes": mk(J, torch.int64), "out_start": mk(M, torch.int64), "out_deg": mk(M, torch.int32),
-               "layer_cnt": torch.empty((32, B), dtype=torch.int32, device=dev)}
+               "layer_cnt": torch.empty((32, B), dtype=torch.int32, device=dev), "sched_list": mk(S, torch.int64)}
         size = {"x": M, "node_obs": M, "node_loc": M, "node_job": M, "sched_rank": M, "gen": M, "node_recv": M, "stage_mask": M,
                 "src": Ed, "dst": Ed, "edge_obs": Ed, "edge_layers": Ed, "job_obs": J, "job_cap": J, "job_first": J, "obs_depth": B,
-                "job_nodes": J, "out_start": M, "out_deg": M, "layer_cnt": 32}
+                "job_nodes": J, "out_start": M, "out_deg": M, "layer_cnt": 32, "sched_list": S}
         g = {k: v[: size[k]] for k, v in buf.items()}
         a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
-                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")))
+                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
+                           off[3].data_ptr(), buf["sched_list"].data_ptr())
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
         g["max_depth"] = self.max_dag_depth

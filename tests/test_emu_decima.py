@@ -38,6 +38,35 @@ def test_sampled_actions_are_always_valid():
     env.close()
 
 
+def test_graph_kernel_lists_and_one_call_encoder():
+    """`decima_graph`'s list of schedulable nodes (what the stage-score launch iterates over) is `stage_mask`'s index
+    list, with and without frozen envs; and the encoder enqueued by one call (`sss_gnn_encode`: list sizes left on the
+    device, PREP and SINK in one pass) produces the embeddings of the launch-by-launch path, bit for bit"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 6, device="cpu", auto_reset=True, _lib=load_emu())
+    torch.manual_seed(7)
+    policy = DecimaPolicy(num_executors=10, **AGENT).eval()
+    policy.bind_kernels(env._b)
+    env.reset(seed=100)
+    env.rollout("fair", 40)
+    for active in (None, torch.tensor([True, False, True, True, False, True])):
+        g = env.decima_graph(active)
+        assert torch.equal(g["sched_list"], g["stage_mask"].nonzero(as_tuple=True)[0]) and g["sched_list"].numel() > 0
+        assert g["max_depth"] == env.max_dag_depth and int(g["obs_depth"].max()) <= g["max_depth"]
+        one = policy._encode_kernels(g)
+        g2 = {k: v for k, v in g.items() if k != "max_depth"}  # without the bound: launch by launch, list sizes read back
+        ref = policy._encode_kernels(g2)
+        for k in ("node", "dag", "glob"):
+            assert torch.equal(one[k], ref[k]), k
+    env.close()
+
+
 def test_reference_style_decima_episode():
     """the single-env harness of the reference (examples.py:84-102) with the Decima plugin:
     env_wrapper_cls(env) + schedule(obs) sampling through `random.choices` under a fixed
