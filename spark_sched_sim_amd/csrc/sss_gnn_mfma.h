@@ -1,0 +1,265 @@
+// sss_gnn_mfma.h - the GNN's 16 -> 32 -> 16 -> 16 MLPs on the matrix cores (gfx950 only; the emulator keeps sss_gnn.h).
+//
+// The DAG-layer launches are the largest share of a Decima step (nine launches, 219 of ~745 us of kernel time at 4096 envs,
+// profiles/r03_bench.md), and in the 16-lanes-per-row form of sss_gnn16.h a row's Linear costs one DPP move, one LDS read and
+// one FMA per weight. `v_mfma_f32_16x16x4_f32` (exact fp32 products, fp32 accumulation - the same arithmetic class, at twice
+// the FMA rate of the vector unit and with no data movement between the layers) does a 16-row tile's Linear in a few
+// instructions. One wave owns a tile of 16 rows; it computes Y^T = W X^T:
+//   A operand (lane l: A[i = l & 15][k = l >> 4])   a weight W[16 t' + i][n(step, k)]        - loaded once per wave, in registers
+//   B operand (lane l: B[k = l >> 4][j = l & 15])   the input X[row j][n(step, k)]
+//   D (four registers r: D[4 (l >> 4) + r][j])      output neurons 16 t' + 4 q + r of row j, q = l >> 4
+// A K-step carries any four input features as long as A and B agree; taking step (t, r) = features {16 t + 4 q + r, q = 0..3}
+// makes register r of output tile t of one layer exactly the B operand of step (t, r) of the next: the layers chain with no
+// shuffle, no LDS, no barrier. Rows enter the same way: lane (q, j) loads the float4 X[row j][4 q .. 4 q + 3] (16 features).
+// Same packed parameters as everywhere ([W1, b1, W2^T, b2, W3, b3], sss_gnn.h); only the summation order inside a dot product
+// differs from the other formulations - within the 2e-5 agreement the fixtures are held to.
+#pragma once
+
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+
+SSS_DEV mfma_f4 mfma16(float a, float b, mfma_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+SSS_DEV mfma_f4 leaky4(mfma_f4 v, float slope) {
+  mfma_f4 o;
+  o.x = v.x > 0.0f ? v.x : v.x * slope, o.y = v.y > 0.0f ? v.y : v.y * slope, o.z = v.z > 0.0f ? v.z : v.z * slope, o.w = v.w > 0.0f ? v.w : v.w * slope;
+  return o;
+}
+
+// the A operands and bias registers of one 16 -> 32 -> 16 -> 16 MLP for lane l (i = l & 15, q = l >> 4)
+struct MfmaGnnMlp {
+  float a1[2][4];  // [t'][r]  W1[16 t' + i][4 q + r]
+  float a2[2][4];  // [t][r]   W2[i][16 t + 4 q + r]
+  float a3[4];     // [r]      W3[i][4 q + r]
+  mfma_f4 b1[2];   // [t'] . r b1[16 t' + 4 q + r]
+  mfma_f4 b2, b3;  //          b2[4 q + r], b3[4 q + r]
+  SSS_DEV void load(const float* __restrict__ w, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const float* W1 = w;
+    const float* B1 = W1 + 32 * 16;
+    const float* W2T = B1 + 32;  // [j][m] = W2[m][j]
+    const float* B2 = W2T + 32 * 16;
+    const float* W3 = B2 + 16;
+    const float* B3 = W3 + 16 * 16;
+    for (int t = 0; t < 2; t++)
+      for (int r = 0; r < 4; r++) {
+        a1[t][r] = W1[(16 * t + i) * 16 + 4 * q + r];
+        a2[t][r] = W2T[(16 * t + 4 * q + r) * 16 + i];
+      }
+    for (int r = 0; r < 4; r++) a3[r] = W3[i * 16 + 4 * q + r];
+    for (int t = 0; t < 2; t++) b1[t] = mfma_f4{B1[16 * t + 4 * q], B1[16 * t + 4 * q + 1], B1[16 * t + 4 * q + 2], B1[16 * t + 4 * q + 3]};
+    b2 = mfma_f4{B2[4 * q], B2[4 * q + 1], B2[4 * q + 2], B2[4 * q + 3]};
+    b3 = mfma_f4{B3[4 * q], B3[4 * q + 1], B3[4 * q + 2], B3[4 * q + 3]};
+  }
+  // hidden-2 activations of the tile's rows (register r: neuron 4 q + r) for inputs x (register r: feature 4 q + r)
+  SSS_DEV mfma_f4 hidden(mfma_f4 x, float slope) const {
+    mfma_f4 d0 = b1[0], d1 = b1[1];
+    d0 = mfma16(a1[0][0], x.x, d0), d1 = mfma16(a1[1][0], x.x, d1);
+    d0 = mfma16(a1[0][1], x.y, d0), d1 = mfma16(a1[1][1], x.y, d1);
+    d0 = mfma16(a1[0][2], x.z, d0), d1 = mfma16(a1[1][2], x.z, d1);
+    d0 = mfma16(a1[0][3], x.w, d0), d1 = mfma16(a1[1][3], x.w, d1);
+    d0 = leaky4(d0, slope), d1 = leaky4(d1, slope);
+    // two accumulators (the dependent-issue latency of the instruction is longer than its issue interval), added at the end
+    mfma_f4 e0 = b2, e1 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    e0 = mfma16(a2[0][0], d0.x, e0), e1 = mfma16(a2[1][0], d1.x, e1);
+    e0 = mfma16(a2[0][1], d0.y, e0), e1 = mfma16(a2[1][1], d1.y, e1);
+    e0 = mfma16(a2[0][2], d0.z, e0), e1 = mfma16(a2[1][2], d1.z, e1);
+    e0 = mfma16(a2[0][3], d0.w, e0), e1 = mfma16(a2[1][3], d1.w, e1);
+    return leaky4(e0 + e1, slope);
+  }
+  // the last Linear applied to (a sum of `count` per row) hidden-2 vector(s): W3 . v + count * b3
+  SSS_DEV mfma_f4 out(mfma_f4 v, float count) const {
+    mfma_f4 f = b3 * count;
+    f = mfma16(a3[0], v.x, f), f = mfma16(a3[1], v.y, f), f = mfma16(a3[2], v.z, f), f = mfma16(a3[3], v.w, f);
+    return f;
+  }
+};
+
+// LAYER (sss_gnn.h): tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) ), 16 receiving
+// nodes per wave and pass. Out-edge slot k of all 16 rows goes through the message MLP together (rows without such an edge
+// contribute zero), so a tile costs 16 MFMAs per slot + 24 for the aggregate and the update MLP.
+__global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
+  if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode)
+    int64_t off = 0;
+    for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
+    a.n_rows = a.layer_totals[a.layer], a.idx0 += off;
+    if ((int64_t)blockIdx.x * 64 >= a.n_rows) return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  MfmaGnnMlp msg, upd;
+  msg.load(a.w, lane), upd.load(a.w2, lane);
+  const uint32_t above = a.layer >= 31 ? 0u : ~((2u << a.layer) - 1u);
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t r = tile * 16 + j;
+    const int64_t n = r < a.n_rows ? a.idx0[r] : -1;
+    const bool valid = n >= 0;
+    const int64_t e0 = valid ? a.out_start[n] : 0;
+    const int deg = valid ? a.out_deg[n] : 0;
+    mfma_f4 acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    float used = 0.0f;
+    for (int k = 0; __builtin_amdgcn_ballot_w64(k < deg) != 0; k++) {
+      const bool use = k < deg && ((a.edge_layers[e0 + k] >> a.layer) & 1u);
+      mfma_f4 x = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (use) {
+        const int64_t c = a.dst[e0 + k];
+        const float* cur = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[c] & above) & 1)) ? a.tmp : a.h;
+        x = *(const mfma_f4*)(cur + c * 16 + 4 * q);
+      }
+      const mfma_f4 h2 = msg.hidden(x, a.slope);
+      if (use) acc += h2, used += 1.0f;
+    }
+    const mfma_f4 agg = msg.out(acc, used);
+    const mfma_f4 y = upd.out(upd.hidden(agg, a.slope), 1.0f);
+    if (valid) {
+      float* nxt = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[n] & above) & 1)) ? a.h : a.tmp;
+      const mfma_f4 hi = *(const mfma_f4*)(a.h_init + n * 16 + 4 * q);
+      *(mfma_f4*)(nxt + n * 16 + 4 * q) = hi + y;
+    }
+  }
+}
+
+static int gnn_layer_mfma_launch(const SssGnnArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  const int64_t wgs = (a.n_rows + 63) / 64;  // four tiles of 16 rows per workgroup and pass
+  const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+  hipLaunchKernelGGL(sss_gnn_layer_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// tanh(v) = 1 - 2 / (1 + e^(2v)) on the transcendental unit (v_exp_f32, v_rcp_f32): absolute error ~1e-7, saturates
+// correctly at both ends; the library tanhf costs ~40 instructions, and a tile of a policy head needs 32 per lane
+SSS_DEV float fast_tanh(float v) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * v)); }
+
+// ---- the two policy heads (IN -> 64 -> 64 -> 1, Tanh) -------------------------------------------------------------------
+// Same chaining; the 2 x 4096 weights of the first two Linears do not fit a wave's registers, so their A-operand images sit
+// in LDS in [step][lane] order (one conflict-free 4-byte read per MFMA). The input row is U segments of 16 features, each a
+// float4 per lane from its own source row (node embedding, job summary, observation summary, raw features): `col(u, f)` names
+// the column of W1 that feature f of segment u multiplies (-1: padding). The last Linear has one output: 16 FMAs per lane on
+// the vector unit and a sum over the four lanes of a row.
+template <int U>
+struct MfmaHead {
+  static constexpr int NS = 4 * U;                 // K-steps of the first Linear
+  static constexpr int A1 = 0, A2 = A1 + 4 * NS * 64, B1 = A2 + 4 * 16 * 64, B2 = B1 + 64, TOTAL = B2 + 64;
+  template <typename Col>
+  SSS_DEV static void stage(float* lds, const float* __restrict__ w, int in_dim, int tid, int nthreads, Col col) {
+    const float* W1 = w;
+    const float* gB1 = W1 + 64 * in_dim;
+    const float* W2T = gB1 + 64;  // [n][m] = W2[m][n]
+    const float* gB2 = W2T + 64 * 64;
+    for (int t = tid; t < 4 * NS * 64; t += nthreads) {
+      const int lane = t & 63, s = (t >> 6) % NS, tp = t / (64 * NS);
+      const int c = col(s >> 2, 4 * (lane >> 4) + (s & 3));
+      lds[A1 + t] = c >= 0 ? W1[(16 * tp + (lane & 15)) * in_dim + c] : 0.0f;
+    }
+    for (int t = tid; t < 4 * 16 * 64; t += nthreads) {
+      const int lane = t & 63, s = (t >> 6) & 15, tp = t >> 10;
+      lds[A2 + t] = W2T[(16 * (s >> 2) + 4 * (lane >> 4) + (s & 3)) * 64 + 16 * tp + (lane & 15)];
+    }
+    for (int t = tid; t < 64; t += nthreads) lds[B1 + t] = gB1[t], lds[B2 + t] = gB2[t];
+  }
+  // the row's score (on every lane of the row's four) from its input segments x[u] (register r: feature 4 q + r of segment u)
+  SSS_DEV static float score(const float* lds, const mfma_f4 (&x)[U], const float (&w3)[16], float b3, int lane) {
+    const int q = lane >> 4;
+    mfma_f4 d[4], e[4];
+#pragma unroll
+    for (int tp = 0; tp < 4; tp++) {
+      d[tp] = *(const mfma_f4*)(lds + B1 + 16 * tp + 4 * q);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float* ap = lds + A1 + ((tp * NS + 4 * u) * 64) + lane;
+        d[tp] = mfma16(ap[0], x[u].x, d[tp]), d[tp] = mfma16(ap[64], x[u].y, d[tp]);
+        d[tp] = mfma16(ap[128], x[u].z, d[tp]), d[tp] = mfma16(ap[192], x[u].w, d[tp]);
+      }
+    }
+#pragma unroll
+    for (int tp = 0; tp < 4; tp++) d[tp] = mfma_f4{fast_tanh(d[tp].x), fast_tanh(d[tp].y), fast_tanh(d[tp].z), fast_tanh(d[tp].w)};
+#pragma unroll
+    for (int tp = 0; tp < 4; tp++) {
+      e[tp] = *(const mfma_f4*)(lds + B2 + 16 * tp + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float* ap = lds + A2 + ((tp * 16 + 4 * t) * 64) + lane;
+        e[tp] = mfma16(ap[0], d[t].x, e[tp]), e[tp] = mfma16(ap[64], d[t].y, e[tp]);
+        e[tp] = mfma16(ap[128], d[t].z, e[tp]), e[tp] = mfma16(ap[192], d[t].w, e[tp]);
+      }
+    }
+    float p = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      p += w3[4 * t] * fast_tanh(e[t].x), p += w3[4 * t + 1] * fast_tanh(e[t].y), p += w3[4 * t + 2] * fast_tanh(e[t].z), p += w3[4 * t + 3] * fast_tanh(e[t].w);
+    }
+    p += __shfl_xor(p, 16), p += __shfl_xor(p, 32);
+    return p + b3;
+  }
+};
+
+// STAGE: score[obs(n), loc(n)] = stage([x, h, h_dag[job], h_glob[obs]] of schedulable node n) - segments h, h_dag, h_glob, x
+// EXEC:  score[b, c] = exec([x[first(j), :3], h_dag[j], h_glob[obs(j)], c / E]) - segments h_dag, h_glob, (x0, x1, x2, c / E)
+template <int KIND>
+__global__ __launch_bounds__(256) void sss_gnn_head_mfma_kernel(SssGnnArgs a) {
+  constexpr int U = KIND == GNN_STAGE ? 4 : 3;
+  constexpr int IN = KIND == GNN_STAGE ? GNN_NF + 48 : GNN_DF + 33;
+  using H = MfmaHead<U>;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];
+  if (a.w2_16) {  // the host has the images ready (decima.py `_mfma_head_image`, the layout of MfmaHead::stage): a straight copy
+    static_assert(H::TOTAL % 4 == 0, "images are copied 16 bytes at a time");
+    for (int t = threadIdx.x; t < H::TOTAL / 4; t += 256) ((float4*)w_lds)[t] = ((const float4*)a.w2_16)[t];
+  } else
+    H::stage(w_lds, a.w, IN, threadIdx.x, 256, [](int u, int f) {
+      if (KIND == GNN_STAGE) return u == 0 ? GNN_NF + f : u == 1 ? GNN_NF + 16 + f : u == 2 ? GNN_NF + 32 + f : (f < GNN_NF ? f : -1);
+      return u == 0 ? GNN_DF + f : u == 1 ? GNN_DF + 16 + f : (f < GNN_DF ? f : (f == GNN_DF ? GNN_DF + 32 : -1));
+    });
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float* W3 = a.w + 64 * IN + 64 + 64 * 64 + 64;
+  float w3[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) w3[4 * t + r] = W3[16 * t + 4 * q + r];
+  const float b3 = W3[64];
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t r = tile * 16 + j;
+    const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    mfma_f4 x[U];
+    if (KIND == GNN_STAGE) {
+      const int64_t n = r < a.n_rows ? a.idx0[r] : -1;
+      const bool valid = n >= 0;
+      if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;  // (a padded list: nothing but -1 from some row on)
+      x[0] = valid ? *(const mfma_f4*)(a.h + n * 16 + 4 * q) : zero;
+      x[1] = valid ? *(const mfma_f4*)(a.h_dag + a.node_job[n] * 16 + 4 * q) : zero;
+      x[2] = valid ? *(const mfma_f4*)(a.h_glob + a.node_obs[n] * 16 + 4 * q) : zero;
+      x[3] = zero;
+      if (valid && q == 0) x[3] = mfma_f4{a.x[n * GNN_NF], a.x[n * GNN_NF + 1], a.x[n * GNN_NF + 2], a.x[n * GNN_NF + 3]};
+      if (valid && q == 1) x[3].x = a.x[n * GNN_NF + 4];
+      const float v = H::score(w_lds, x, w3, b3, lane);
+      if (valid && q == 0) a.out[a.node_obs[n] * a.n_pad + a.node_loc[n]] = v;
+    } else {
+      const bool valid = r < a.n_rows;
+      const int64_t b = valid ? r / a.E : 0;
+      const int c = (int)(r - b * a.E);
+      const int64_t jj = a.idx0[b];
+      x[0] = valid ? *(const mfma_f4*)(a.h_dag + jj * 16 + 4 * q) : zero;
+      x[1] = valid ? *(const mfma_f4*)(a.h_glob + a.job_obs[jj] * 16 + 4 * q) : zero;
+      x[2] = zero;
+      if (valid && q == 0) {
+        const float* xr = a.x + a.job_first[jj] * GNN_NF;
+        x[2] = mfma_f4{xr[0], xr[1], xr[2], (float)c / (float)a.E};
+      }
+      const float v = H::score(w_lds, x, w3, b3, lane);
+      if (valid && q == 0) a.out[r] = c < a.job_cap[jj] ? v : -__builtin_inff();
+    }
+  }
+}
+
+template <int KIND>
+static int gnn_head_mfma_launch(const SssGnnArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  constexpr int U = KIND == GNN_STAGE ? 4 : 3;
+  const int64_t wgs = (a.n_rows + 63) / 64;
+  const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);  // (33 KB of LDS images per workgroup, staged once and reused over its tiles)
+  hipLaunchKernelGGL(sss_gnn_head_mfma_kernel<KIND>, dim3(grid), dim3(256), (size_t)MfmaHead<U>::TOTAL * sizeof(float), (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

@@ -12,6 +12,7 @@
 #include "sss_collect.h"
 
 #include <stdint.h>
+#include <stdlib.h>
 #include "zig_tables.inc"
 
 static int be_set_device(int device) { return (int)hipSetDevice(device); }
@@ -113,6 +114,7 @@ static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleAr
 }
 
 #include "sss_gnn16.h"
+#include "sss_gnn_mfma.h"
 #include "sss_train16.h"
 
 __global__ __launch_bounds__(256) void sss_prefix_rows_kernel(SssPrefixArgs a) {
@@ -178,14 +180,27 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
   switch (kind) {
     // a DAG layer's receiving nodes: few rows per launch and the longest chain (message MLP per edge + update MLP),
     // nine launches back to back per step: 16 lanes per row (sss_gnn16.h; 41 -> 25 us per launch at 4096 envs)
-    case GNN_LAYER: return gnn16_launch<GNN_LAYER>(a, stream);
+    // (since round 3 on the matrix cores, sss_gnn_mfma.h: 16 rows per wave, the three Linears of an MLP chained in registers;
+    //  SSS_GNN_LAYER16=1 in the environment selects the 16-lane form for comparisons)
+    case GNN_LAYER: {
+      static const bool lanes16 = getenv("SSS_GNN_LAYER16") != nullptr;
+      return lanes16 ? gnn16_launch<GNN_LAYER>(a, stream) : gnn_layer_mfma_launch(a, stream);
+    }
     // The two policy heads (53-64-64-1 / 36-64-64-1, 128 tanh per row): with few rows the chain of one row is the
     // bound and 16 lanes per row win (1024 envs: 45 -> 22 us / 41 -> 29 us); with many rows the launch is
     // throughput-bound and one thread per row, where 64 rows share every weight read, wins (4096 envs: 52 / 42 us
     // against 59 / 69 us). STAGE's n_rows counts all nodes (its list is padded; ~1 in 22 is schedulable).
     // (a.layer != 0: the list holds exactly the schedulable nodes, sss_decima_graph_build's sched_list)
-    case GNN_STAGE: return (a.w16 && a.n_rows <= (a.layer ? 24000 : 22 * 24000)) ? gnn16_launch<GNN_STAGE>(a, stream) : gnn_launch_kind<GNN_STAGE>(a, stream);
-    case GNN_EXEC: return (a.w16 && a.n_rows <= 24000) ? gnn16_launch<GNN_EXEC>(a, stream) : gnn_launch_kind<GNN_EXEC>(a, stream);
+    case GNN_STAGE: {
+      static const bool no_mfma = getenv("SSS_GNN_HEADS_VALU") != nullptr;  // (comparisons: the two vector-unit forms)
+      if (!no_mfma) return gnn_head_mfma_launch<GNN_STAGE>(a, stream);
+      return (a.w16 && a.n_rows <= (a.layer ? 24000 : 22 * 24000)) ? gnn16_launch<GNN_STAGE>(a, stream) : gnn_launch_kind<GNN_STAGE>(a, stream);
+    }
+    case GNN_EXEC: {
+      static const bool no_mfma = getenv("SSS_GNN_HEADS_VALU") != nullptr;
+      if (!no_mfma) return gnn_head_mfma_launch<GNN_EXEC>(a, stream);
+      return (a.w16 && a.n_rows <= 24000) ? gnn16_launch<GNN_EXEC>(a, stream) : gnn_launch_kind<GNN_EXEC>(a, stream);
+    }
     // node rows (a million per launch at 4096 envs): throughput-bound, one thread per row (sss_gnn.h)
     case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);

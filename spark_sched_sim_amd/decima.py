@@ -419,9 +419,33 @@ class DecimaPolicy(nn.Module):
                          b3]
                 flat = torch.cat([t.contiguous().reshape(-1) for t in parts])
                 return torch.nn.functional.pad(flat, (0, (-flat.numel()) % 4)).contiguous()
+            def head_image(mlp, cols):  # a policy head (IN -> 64 -> 64 -> 1) as the A-operand images of csrc/sss_gnn_mfma.h MfmaHead
+                lin = [m for m in mlp if isinstance(m, nn.Linear)]
+                W1, b1, W2, b2 = (t.detach().float() for t in (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias))
+                dev = W1.device
+                lane = torch.arange(64, device=dev)
+                i, q = lane & 15, lane >> 4
+                col = torch.as_tensor(cols, dtype=torch.long, device=dev)  # [U, 16]: column of W1 feature f of segment u multiplies, -1 = padding
+                U = col.shape[0]
+                step = torch.arange(4 * U, device=dev)
+                c = col[(step >> 2)[:, None], 4 * q[None, :] + (step & 3)[:, None]]  # [NS, 64]
+                rows = (16 * torch.arange(4, device=dev))[:, None, None] + i[None, None, :]  # [4, 1, 64]
+                a1 = torch.where(c[None] >= 0, W1[rows.expand(4, 4 * U, 64), c.clamp(min=0)[None].expand(4, 4 * U, 64)], torch.zeros((), device=dev))
+                s16 = torch.arange(16, device=dev)
+                n_in = 16 * (s16 >> 2)[:, None] + 4 * q[None, :] + (s16 & 3)[:, None]  # [16, 64]
+                a2 = W2[rows.expand(4, 16, 64), n_in[None].expand(4, 16, 64)]
+                flat = torch.cat([a1.reshape(-1), a2.reshape(-1), b1, b2])
+                assert flat.numel() % 4 == 0
+                return flat.contiguous()
+            f16 = list(range(16))
+            stage_cols = [[NUM_NODE_FEATURES + f for f in f16], [NUM_NODE_FEATURES + 16 + f for f in f16], [NUM_NODE_FEATURES + 32 + f for f in f16],
+                          [f if f < NUM_NODE_FEATURES else -1 for f in f16]]
+            exec_cols = [[NUM_DAG_FEATURES + f for f in f16], [NUM_DAG_FEATURES + 16 + f for f in f16],
+                         [f if f < NUM_DAG_FEATURES else (NUM_DAG_FEATURES + 32 if f == NUM_DAG_FEATURES else -1) for f in f16]]
             enc = self.encoder
             w = {"msg16": pack16(enc.node_encoder.mlp_msg), "update16": pack16(enc.node_encoder.mlp_update),
                  "stage16": pack16(self.stage_policy_network.mlp_score), "exec16": pack16(self.exec_policy_network.mlp_score),
+                 "stage_mfma": head_image(self.stage_policy_network.mlp_score, stage_cols), "exec_mfma": head_image(self.exec_policy_network.mlp_score, exec_cols),
                  "prep": pack(enc.node_encoder.mlp_prep), "msg": pack(enc.node_encoder.mlp_msg), "update": pack(enc.node_encoder.mlp_update),
                  "dag": pack(enc.dag_encoder.mlp), "glob": pack(enc.global_encoder.mlp),
                  "stage": pack(self.stage_policy_network.mlp_score), "exec": pack(self.exec_policy_network.mlp_score)}
@@ -541,7 +565,7 @@ class DecimaPolicy(nn.Module):
             rows, idx0, exact = g["sched_list"].numel(), g["sched_list"], 1
         else:
             rows, idx0, exact = M, self._index_list(g["stage_mask"]), 0
-        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, w16=self._packed[1].get("stage16"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
+        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, w16=self._packed[1].get("stage16"), w2_16=self._packed[1].get("stage_mfma"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
                      h_glob=h["glob"], out=out, idx0=idx0, node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
         return out
 
@@ -571,7 +595,7 @@ class DecimaPolicy(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         with device_of(dev):
             self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
-        self._launch("exec", B * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
+        self._launch("exec", B * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), w2_16=self._packed[1].get("exec_mfma"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
                      idx0=job_gid, job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
         with device_of(dev):
             self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
@@ -585,7 +609,7 @@ class DecimaPolicy(nn.Module):
     def _exec_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
         k, E = job_gid.numel(), self.num_executors
         out = torch.empty((k, E), dtype=torch.float32, device=job_gid.device)
-        self._launch("exec", k * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=out,
+        self._launch("exec", k * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), w2_16=self._packed[1].get("exec_mfma"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=out,
                      idx0=job_gid.contiguous(), job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
         return out
 
