@@ -31,17 +31,19 @@ struct MfmaGnnMlp {
   float a3[4];     // [r]      W3[i][4 q + r]
   mfma_f4 b1[2];   // [t'] . r b1[16 t' + 4 q + r]
   mfma_f4 b2, b3;  //          b2[4 q + r], b3[4 q + r]
-  SSS_DEV void load(const float* __restrict__ w, int lane) {
+  // `in_dim`: width of the MLP's first Linear; the 16-feature segment these A operands multiply is columns col0 .. col0 + n_col - 1
+  // of it (features beyond n_col: zero weights)
+  SSS_DEV void load(const float* __restrict__ w, int lane, int in_dim = 16, int col0 = 0, int n_col = 16) {
     const int i = lane & 15, q = lane >> 4;
     const float* W1 = w;
-    const float* B1 = W1 + 32 * 16;
+    const float* B1 = W1 + 32 * in_dim;
     const float* W2T = B1 + 32;  // [j][m] = W2[m][j]
     const float* B2 = W2T + 32 * 16;
     const float* W3 = B2 + 16;
     const float* B3 = W3 + 16 * 16;
     for (int t = 0; t < 2; t++)
       for (int r = 0; r < 4; r++) {
-        a1[t][r] = W1[(16 * t + i) * 16 + 4 * q + r];
+        a1[t][r] = 4 * q + r < n_col ? W1[(16 * t + i) * in_dim + col0 + 4 * q + r] : 0.0f;
         a2[t][r] = W2T[(16 * t + 4 * q + r) * 16 + i];
       }
     for (int r = 0; r < 4; r++) a3[r] = W3[i * 16 + 4 * q + r];
@@ -58,6 +60,25 @@ struct MfmaGnnMlp {
     d0 = mfma16(a1[0][3], x.w, d0), d1 = mfma16(a1[1][3], x.w, d1);
     d0 = leaky4(d0, slope), d1 = leaky4(d1, slope);
     // two accumulators (the dependent-issue latency of the instruction is longer than its issue interval), added at the end
+    mfma_f4 e0 = b2, e1 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    e0 = mfma16(a2[0][0], d0.x, e0), e1 = mfma16(a2[1][0], d1.x, e1);
+    e0 = mfma16(a2[0][1], d0.y, e0), e1 = mfma16(a2[1][1], d1.y, e1);
+    e0 = mfma16(a2[0][2], d0.z, e0), e1 = mfma16(a2[1][2], d1.z, e1);
+    e0 = mfma16(a2[0][3], d0.w, e0), e1 = mfma16(a2[1][3], d1.w, e1);
+    return leaky4(e0 + e1, slope);
+  }
+  // the same with a second input segment (its A operands `s1`: another column range of the same W1)
+  SSS_DEV mfma_f4 hidden2(mfma_f4 x, mfma_f4 xs, const float (&s1)[2][4], float slope) const {
+    mfma_f4 d0 = b1[0], d1 = b1[1];
+    d0 = mfma16(a1[0][0], x.x, d0), d1 = mfma16(a1[1][0], x.x, d1);
+    d0 = mfma16(a1[0][1], x.y, d0), d1 = mfma16(a1[1][1], x.y, d1);
+    d0 = mfma16(a1[0][2], x.z, d0), d1 = mfma16(a1[1][2], x.z, d1);
+    d0 = mfma16(a1[0][3], x.w, d0), d1 = mfma16(a1[1][3], x.w, d1);
+    d0 = mfma16(s1[0][0], xs.x, d0), d1 = mfma16(s1[1][0], xs.x, d1);
+    d0 = mfma16(s1[0][1], xs.y, d0), d1 = mfma16(s1[1][1], xs.y, d1);
+    d0 = mfma16(s1[0][2], xs.z, d0), d1 = mfma16(s1[1][2], xs.z, d1);
+    d0 = mfma16(s1[0][3], xs.w, d0), d1 = mfma16(s1[1][3], xs.w, d1);
+    d0 = leaky4(d0, slope), d1 = leaky4(d1, slope);
     mfma_f4 e0 = b2, e1 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
     e0 = mfma16(a2[0][0], d0.x, e0), e1 = mfma16(a2[1][0], d1.x, e1);
     e0 = mfma16(a2[0][1], d0.y, e0), e1 = mfma16(a2[1][1], d1.y, e1);
@@ -261,5 +282,75 @@ static int gnn_head_mfma_launch(const SssGnnArgs& a, void* stream) {
   const int64_t wgs = (a.n_rows + 63) / 64;
   const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);  // (33 KB of LDS images per workgroup, staged once and reused over its tiles)
   hipLaunchKernelGGL(sss_gnn_head_mfma_kernel<KIND>, dim3(grid), dim3(256), (size_t)MfmaHead<U>::TOTAL * sizeof(float), (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// ---- node / job rows ----------------------------------------------------------------------------------------------------
+// the row's raw features x[n][0..4] as a 16-feature segment: lane (q, j) holds features 4 q .. 4 q + 3
+SSS_DEV mfma_f4 mfma_x_segment(const float* __restrict__ x, int64_t n, int q, bool valid) {
+  mfma_f4 v = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (valid && q == 0) v = mfma_f4{x[n * GNN_NF], x[n * GNN_NF + 1], x[n * GNN_NF + 2], x[n * GNN_NF + 3]};
+  if (valid && q == 1) v.x = x[n * GNN_NF + 4];
+  return v;
+}
+
+// PREP + SINK (sss_gnn.h): h_init[n] = prep(x[n]); h[n] = is_parent[n] ? 0 : update(h_init[n]) (h_init[n] for observations with a
+// single DAG layer) - the update MLP takes h_init straight from the registers the prep MLP left it in.
+// DAGHID: tmp[n] = hidden part of dag([x[n], h[n]]), with the MERGE of embeddings that ended up in tmp.
+// GLOBHID: tmp[j] = hidden part of glob(h_dag[j]).
+template <int KIND>
+__global__ __launch_bounds__(256) void sss_gnn_rows_mfma_kernel(SssGnnArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  MfmaGnnMlp m0, m1;
+  float s1[2][4];
+  if (KIND == GNN_PREP) m0.load(a.w, lane, GNN_NF, 0, GNN_NF), m1.load(a.w2, lane);
+  if (KIND == GNN_DAGHID) {
+    m0.load(a.w, lane, GNN_NF + 16, GNN_NF, 16);  // the embedding's columns of the first Linear ...
+    m1.load(a.w, lane, GNN_NF + 16, 0, GNN_NF);   // ... and the raw features' (only their first-Linear operands are used)
+    for (int t = 0; t < 2; t++)
+      for (int r = 0; r < 4; r++) s1[t][r] = m1.a1[t][r];
+  }
+  if (KIND == GNN_GLOBHID) m0.load(a.w, lane);
+  const int64_t n_tiles = (a.n_rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t n = tile * 16 + j;
+    const bool valid = n < a.n_rows;
+    if (KIND == GNN_PREP) {
+      const mfma_f4 hi = m0.out(m0.hidden(mfma_x_segment(a.x, n, q, valid), a.slope), 1.0f);
+      mfma_f4 h = m1.out(m1.hidden(hi, a.slope), 1.0f);
+      if (valid) {
+        *(mfma_f4*)(a.out + n * 16 + 4 * q) = hi;
+        const bool par = a.out_deg[n] != 0;
+        const bool skip = a.obs_depth != nullptr && a.obs_depth[a.node_obs[n]] == 0;
+        if (skip) h = hi;
+        else if (par) h = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        *(mfma_f4*)(a.h + n * 16 + 4 * q) = h;
+      }
+    } else if (KIND == GNN_DAGHID) {
+      mfma_f4 hv = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (valid) {
+        if (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[n]) & 1)) {
+          hv = *(const mfma_f4*)(a.tmp + n * 16 + 4 * q);  // MERGE: an odd number of updates left the embedding in tmp
+          *(mfma_f4*)(a.h + n * 16 + 4 * q) = hv;
+        } else
+          hv = *(const mfma_f4*)(a.h + n * 16 + 4 * q);
+      }
+      const mfma_f4 h2 = m0.hidden2(hv, mfma_x_segment(a.x, n, q, valid), s1, a.slope);
+      if (valid) *(mfma_f4*)(a.tmp + n * 16 + 4 * q) = h2;
+    } else {
+      const mfma_f4 xv = valid ? *(const mfma_f4*)(a.h_dag + n * 16 + 4 * q) : mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      const mfma_f4 h2 = m0.hidden(xv, a.slope);
+      if (valid) *(mfma_f4*)(a.tmp + n * 16 + 4 * q) = h2;
+    }
+  }
+}
+
+template <int KIND>
+static int gnn_rows_mfma_launch(const SssGnnArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  const int64_t wgs = (a.n_rows + 63) / 64;
+  const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+  hipLaunchKernelGGL(sss_gnn_rows_mfma_kernel<KIND>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

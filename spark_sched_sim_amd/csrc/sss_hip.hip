@@ -201,11 +201,21 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
       if (!no_mfma) return gnn_head_mfma_launch<GNN_EXEC>(a, stream);
       return (a.w16 && a.n_rows <= 24000) ? gnn16_launch<GNN_EXEC>(a, stream) : gnn_launch_kind<GNN_EXEC>(a, stream);
     }
-    // node rows (a million per launch at 4096 envs): throughput-bound, one thread per row (sss_gnn.h)
-    case GNN_PREP: return gnn_launch_kind<GNN_PREP>(a, stream);
+    // node rows (a million per launch at 4096 envs): on the matrix cores as well (sss_gnn_mfma.h; SSS_GNN_ROWS_VALU=1 selects
+    // the one-thread-per-row form of sss_gnn.h for comparisons). A PREP launch without the fused SINK keeps that form.
+    case GNN_PREP: {
+      static const bool valu = getenv("SSS_GNN_ROWS_VALU") != nullptr;
+      return (!valu && a.w2 && a.h) ? gnn_rows_mfma_launch<GNN_PREP>(a, stream) : gnn_launch_kind<GNN_PREP>(a, stream);
+    }
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
-    case GNN_DAGHID: return gnn_launch_kind<GNN_DAGHID>(a, stream);
-    case GNN_GLOBHID: return gnn_launch_kind<GNN_GLOBHID>(a, stream);
+    case GNN_DAGHID: {
+      static const bool valu = getenv("SSS_GNN_ROWS_VALU") != nullptr;
+      return valu ? gnn_launch_kind<GNN_DAGHID>(a, stream) : gnn_rows_mfma_launch<GNN_DAGHID>(a, stream);
+    }
+    case GNN_GLOBHID: {
+      static const bool valu = getenv("SSS_GNN_ROWS_VALU") != nullptr;
+      return valu ? gnn_launch_kind<GNN_GLOBHID>(a, stream) : gnn_rows_mfma_launch<GNN_GLOBHID>(a, stream);
+    }
     // copies and range sums: one thread per row (sss_gnn.h)
     case GNN_COMMIT: return gnn_launch_kind<GNN_COMMIT>(a, stream);
     case GNN_MERGE: return gnn_launch_kind<GNN_MERGE>(a, stream);
