@@ -64,6 +64,7 @@ def main():
         t3 = time.perf_counter()
     print(json.dumps({"train_s_profiled": t3 - t2}))
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=a.top, max_name_column_width=70))
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=a.top, max_name_column_width=70))
 
 
 if __name__ == "__main__":
