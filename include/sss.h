@@ -415,6 +415,9 @@ typedef struct sss_collect_args {
   float* rec_lgprobs_dev;
   uint8_t* rec_resets_dev;
   int32_t* flags_dev;
+  const uint8_t* in_group_dev; /* nullable: only envs with in_group[b] != 0 take part in this call (phase 0 gives the others
+                                  SSS_SKIP_ENV, phase 1 leaves their state and their entries of row t alone): the caller can
+                                  keep two groups of envs one step apart on two streams, sharing the record */
 } sss_collect_args;
 int sss_collect_step(const sss_collect_args* a, int phase, void* stream);
 

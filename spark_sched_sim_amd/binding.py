@@ -107,7 +107,8 @@ class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args
                 ("step_counts_dev", C.c_void_p), ("pending_reset_dev", C.c_void_p), ("stage_sel_dev", C.c_void_p), ("job_idx_dev", C.c_void_p), ("exec_sel_dev", C.c_void_p),
                 ("lgprob_dev", C.c_void_p), ("stage_idx_dev", C.c_void_p), ("num_exec_dev", C.c_void_p), ("rec_active_dev", C.c_void_p), ("rec_t_before_dev", C.c_void_p),
                 ("rec_t_after_dev", C.c_void_p), ("rec_rewards_dev", C.c_void_p), ("rec_stage_sel_dev", C.c_void_p), ("rec_job_idx_dev", C.c_void_p),
-                ("rec_exec_sel_dev", C.c_void_p), ("rec_lgprobs_dev", C.c_void_p), ("rec_resets_dev", C.c_void_p), ("flags_dev", C.c_void_p)]
+                ("rec_exec_sel_dev", C.c_void_p), ("rec_lgprobs_dev", C.c_void_p), ("rec_resets_dev", C.c_void_p), ("flags_dev", C.c_void_p),
+                ("in_group_dev", C.c_void_p)]
 
 
 class SssMlpArgs(C.Structure):  # include/sss.h sss_mlp_args

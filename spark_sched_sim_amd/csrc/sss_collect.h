@@ -47,6 +47,8 @@ struct SssCollectArgs {
   int64_t* rec_exec_sel;
   float* rec_lgprobs;
   uint8_t* rec_resets;
+  const uint8_t* in_group;   // nullable: only envs with in_group[b] != 0 take part in this call (their step was launched with
+                             // the others skipped) - two groups of envs can then be one step apart on two streams
   int32_t* flags;            // [8], zero on entry: an env failed / an episode ended / somebody goes on / 1 + a failed env / somebody was recorded
 };
 
@@ -54,12 +56,14 @@ struct SssCollectArgs {
 
 template <typename OrFn>
 SSS_DEV void collect_env(const SssCollectArgs& a, int phase, int b, OrFn flag_or) {
+  const bool member = a.in_group == nullptr || a.in_group[b] != 0;
   if (phase == 0) {
-    a.stage_idx[b] = a.active[b] ? (int32_t)a.stage_sel[b] : SSS_COLLECT_SKIP_ENV;
+    a.stage_idx[b] = (member && a.active[b]) ? (int32_t)a.stage_sel[b] : SSS_COLLECT_SKIP_ENV;
     const int64_t n = 1 + a.exec_sel[b];
     a.num_exec[b] = (int32_t)(n < 1 ? 1 : n);
     return;
   }
+  if (!member) return;
   const int64_t row = a.t * (int64_t)a.num_envs + b;
   const bool was_active = a.active[b] != 0;
   const double reward = a.obs_f64[2 * b], wall_time = a.obs_f64[2 * b + 1];

@@ -602,7 +602,7 @@ extern "C" int sss_collect_step(const sss_collect_args* c, int phase, void* stre
   a.stage_idx = c->stage_idx_dev, a.num_exec = c->num_exec_dev;
   a.rec_active = c->rec_active_dev, a.rec_t_before = c->rec_t_before_dev, a.rec_t_after = c->rec_t_after_dev, a.rec_rewards = c->rec_rewards_dev;
   a.rec_stage_sel = c->rec_stage_sel_dev, a.rec_job_idx = c->rec_job_idx_dev, a.rec_exec_sel = c->rec_exec_sel_dev, a.rec_lgprobs = c->rec_lgprobs_dev;
-  a.rec_resets = c->rec_resets_dev, a.flags = c->flags_dev;
+  a.rec_resets = c->rec_resets_dev, a.flags = c->flags_dev, a.in_group = c->in_group_dev;
   if (a.num_envs == 0) return 0;
   if (int rc = be_launch_collect(a, phase, stream)) return sss_fail(-30, std::string("collect launch failed: ") + be_error(rc));
   return 0;

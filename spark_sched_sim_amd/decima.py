@@ -536,11 +536,13 @@ class DecimaPolicy(nn.Module):
         M, J, B, D = x.shape[0], g["job_obs"].numel(), g["n_obs"], int(g["max_depth"])
         f32 = lambda n: torch.empty((n, 16), dtype=torch.float32, device=dev)  # noqa: E731
         h_init, h, tmp, h_dag, h_glob = f32(M), f32(M), f32(max(M, J)), f32(J), f32(B)
-        sc = getattr(self, "_enc_scratch", None)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        pool = self.__dict__.setdefault("_enc_scratch", {})  # one set of work buffers per stream: passes on different streams overlap
+        sc = pool.get((dev, stream))
         need = max(M * D, 1)
-        if sc is None or sc["recv"].device != dev or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
+        if sc is None or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
             hint = torch.zeros(32, dtype=torch.int64)
-            sc = self._enc_scratch = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
+            sc = pool[(dev, stream)] = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
                                       "env_off": torch.empty(32 * B, dtype=torch.int64, device=dev), "tot": torch.empty(32, dtype=torch.int64, device=dev),
                                       "hint": hint.pin_memory() if dev.type == "cuda" else hint}
         p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731  (a batch without edges: dst / edge_layers empty)
@@ -550,7 +552,6 @@ class DecimaPolicy(nn.Module):
                              p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(sc["tot"]), p(sc["recv"]), sc["recv"].numel(),
                              # the list sizes of the PREVIOUS pass, copied back without waiting (whatever is there: they only size grids)
                              (ctypes.c_int64 * 32)(*sc["hint"].tolist()))
-        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         with device_of(dev):
             self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
         sc["hint"].copy_(sc["tot"], non_blocking=True)

@@ -40,6 +40,7 @@ class Rollouts:
     lgprobs: torch.Tensor       # f32[T,B]
     resets: torch.Tensor        # bool[T,B] (async: the env was reset right after this step)
     stats: dict[str, np.ndarray] = field(default_factory=dict)
+    obs_index: torch.Tensor | None = None  # i64[T,B]: which observation of `graph` belongs to (t, b); None: t * B + b
 
     @property
     def lengths(self) -> torch.Tensor:
@@ -59,7 +60,8 @@ class Rollouts:
         """observation ids of all recorded steps in the reference's order (rollout-major:
         `chain(*obsns_list)`, ppo.py:58-62)"""
         T, B = self.active.shape
-        ids = (torch.arange(T, device=self.active.device)[:, None] * B + torch.arange(B, device=self.active.device)[None, :])
+        ids = self.obs_index if self.obs_index is not None else (
+            torch.arange(T, device=self.active.device)[:, None] * B + torch.arange(B, device=self.active.device)[None, :])
         return ids.t()[self.active.t()]
 
     def flat(self, x: torch.Tensor) -> torch.Tensor:
@@ -80,13 +82,19 @@ class RolloutCollector:
     SSS_SKIP_ENV until the others catch up."""
 
     def __init__(self, env, mean_time_limit: float, base_seeds: Sequence[int], seed_step: int, num_executors: int,
-                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None, on_env_error: str = "raise"):
-        """on_env_error: what to do when an env reports an error from `step` - in practice the
+                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None, on_env_error: str = "raise", groups: int = 1):
+        """groups: the envs are split into that many groups that take their steps alternately, each on its own HIP stream (the
+        idea: while one group's step launch waits for its slowest env the other group's policy kernels have the device). The
+        record and the results per env are the same as with one group; on one MI355X it is SLOWER (every launch of the policy
+        pass is latency-bound and costs a half-size group as much as the whole batch: 0.88 -> 1.84 ms per row of the record
+        with two groups, profiles/r03_ppo.md), so 1 is the default.
+        on_env_error: what to do when an env reports an error from `step` - in practice the
         reference's `[step]` assertion (spark_sched_sim.py:212-215), which valid Decima actions can
         trigger (tests/golden/stall_case.json). "raise" = the reference's behaviour (the worker
         aborts, the trainer stops, rollout_worker.py:110-112 / trainer.py:117-124); "truncate" = the
         rollout ends before the failing step and training goes on (`env_errors` counts them)."""
         assert on_env_error in ("raise", "truncate")
+        self.groups = max(1, min(int(groups), env.num_envs))
         self.on_env_error = on_env_error
         self.env_errors = 0
         self.env = env
@@ -120,14 +128,17 @@ class RolloutCollector:
         return {k: v.cpu().numpy() for k, v in self.env.rollout_stats().items()}
 
     def _loop(self, asynchronous: bool, duration: float, with_stats: bool) -> Rollouts:
-        """Both worker loops. Per step: the compact graph of the active envs' observations (recorded), the policy's
-        sample, `sss_collect_step` phase 0 (actions), `sss_step`, `sss_collect_step` phase 1 (time limit, who failed /
-        finished / goes on, the step's row of the record, the envs' clocks) and ONE device->host read of the flags the
-        control flow needs. The record lives in [T_cap, B] device arrays that grow geometrically."""
+        """Both worker loops. Per step of a group of envs: the compact graph of its active envs' observations (recorded),
+        the policy's sample, `sss_collect_step` phase 0 (actions; the other groups' envs skip), `sss_step`,
+        `sss_collect_step` phase 1 (time limit, who failed / finished / goes on, the step's row of the record, the envs'
+        clocks). The flags the control flow needs are read when the group's NEXT step is about to be enqueued - by then the
+        other groups' work has been enqueued behind it (one device->host read per group and step, plus the graph totals).
+        The record lives in [T_cap, B] device arrays that grow geometrically."""
+        import contextlib
         import ctypes
 
         from .binding import SssCollectArgs, device_of
-        env, dev, B = self.env, self.env.device, self.env.num_envs
+        env, dev, B, G = self.env, self.env.device, self.env.num_envs, self.groups
         if not asynchronous or self._obs is None:
             self._obs = self._reset()
             self._wall = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -140,39 +151,39 @@ class RolloutCollector:
         elapsed = torch.zeros(B, dtype=torch.float64, device=dev)
         active = torch.ones(B, dtype=torch.uint8, device=dev)  # (bool view for the graph kernel and the caller's policy)
         pending = torch.zeros(B, dtype=torch.uint8, device=dev)
-        stage_idx = torch.empty(B, dtype=torch.int32, device=dev)
-        num_exec = torch.empty(B, dtype=torch.int32, device=dev)
         spec = (("active", torch.uint8), ("t_before", torch.float64), ("t_after", torch.float64), ("rewards", torch.float64), ("stage_sel", torch.int64),
                 ("job_idx", torch.int64), ("exec_sel", torch.int64), ("lgprobs", torch.float32), ("resets", torch.uint8))
         cap = 1024
-        rec = {k: torch.empty((cap, B), dtype=dt, device=dev) for k, dt in spec}
-        flags = torch.zeros((cap, 8), dtype=torch.int32, device=dev)
-        graphs: list[dict[str, Any]] = []
-        lib, stream = env._b.lib, env._stream()
-        t, n_failed = 0, 0
-        any_active = B > 0
-        while any_active:
-            if t == cap:  # grow the record
-                for k in rec:
-                    rec[k] = torch.cat([rec[k], torch.empty_like(rec[k])])
-                flags = torch.cat([flags, torch.zeros_like(flags)])
-                cap *= 2
-            act_b = active.view(torch.bool)
-            g = self.env.decima_graph(act_b)  # recorded for training
-            a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.act(g, self.generator)
-            sel = [a[k] if a[k].dtype == torch.int64 and a[k].is_contiguous() else a[k].to(torch.int64).contiguous() for k in ("stage_sel", "job_idx", "exec_sel")]
-            lg = a["lgprob"] if a["lgprob"].dtype == torch.float32 and a["lgprob"].is_contiguous() else a["lgprob"].float().contiguous()
-            c = SssCollectArgs(B, int(asynchronous), t, float(duration), env.obs_f64.data_ptr(), env.obs_i32.data_ptr(), env.obs_i32.stride(0),
-                               self.tl_env.time_limit.data_ptr(), active.data_ptr(), wall.data_ptr(), elapsed.data_ptr(), self.step_counts.data_ptr(),
-                               pending.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), sel[2].data_ptr(), lg.data_ptr(), stage_idx.data_ptr(), num_exec.data_ptr(),
-                               *(rec[k].data_ptr() for k, _ in spec), flags[t].data_ptr())
-            with device_of(dev):
-                env._b.check(lib.sss_collect_step(ctypes.byref(c), 0, stream))
-            env.step_async(stage_idx, num_exec)
-            with device_of(dev):
-                env._b.check(lib.sss_collect_step(ctypes.byref(c), 1, stream))
-            # ONE device->host round trip for everything the loop's control flow needs this step
-            any_bad, any_done, any_left, bad_env, any_recorded = flags[t, :5].tolist()
+        rec = {k: torch.zeros((cap, B), dtype=dt, device=dev) for k, dt in spec}  # (zeros: rows a group never reaches read as inactive)
+        flags = torch.zeros((cap, G, 8), dtype=torch.int32, device=dev)
+        group_of = (torch.arange(B, device=dev) * G) // max(B, 1)
+        member = [(group_of == k).to(torch.uint8) for k in range(G)] if G > 1 else [None]
+        member_b = [m.view(torch.bool) if m is not None else None for m in member]
+        use_streams = G > 1 and dev.type == "cuda"
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        streams = [torch.cuda.Stream(device=dev) if use_streams else None for _ in range(G)]
+        for st in streams:
+            if st is not None:
+                st.wait_stream(main)
+        acts = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(G)]
+        lib = env._b.lib
+        graphs: dict[tuple[int, int], dict[str, Any]] = {}
+        issued = [0] * G             # steps enqueued per group
+        unread: list[Any] = [None] * G  # (t, graph, stage_idx, num_exec) of the group's step whose flags have not been read yet
+        alive = [B > 0] * G
+        n_failed = 0
+
+        def sync_all():
+            if use_streams:
+                for st in streams:
+                    st.synchronize()
+
+        def read_flags(k: int) -> None:
+            """what became of group k's last step: the ONE device->host read per group and step beside the graph totals"""
+            nonlocal n_failed
+            t, g, stage_idx, num_exec = unread[k]
+            unread[k] = None
+            any_bad, any_done, any_left, bad_env, any_recorded = flags[t, k, :5].tolist()
             if any_bad:
                 n_bad = int(pending.sum()) - n_failed
                 n_failed += n_bad
@@ -191,19 +202,70 @@ class RolloutCollector:
                 # truncate: the failing step is not recorded and the env sits out the rest of this
                 # collection (async: it starts its next episode at the next collection)
                 if not any_recorded:
-                    break
-            graphs.append(g)
+                    alive[k] = False
+                    return
+            graphs[(t, k)] = g
             if asynchronous and any_done:
-                self._reset(mask=rec["resets"][t].view(torch.bool))
-            t += 1
-            any_active = bool(any_left)
+                done = rec["resets"][t].view(torch.bool)
+                self._reset(mask=done if member_b[k] is None else done & member_b[k])
+            alive[k] = bool(any_left)
+
+        def enqueue(k: int) -> None:
+            nonlocal cap, flags
+            t = issued[k]
+            if t == cap:  # grow the record (every stream has to be done with the old arrays)
+                sync_all()
+                for name in rec:
+                    rec[name] = torch.cat([rec[name], torch.zeros_like(rec[name])])
+                flags = torch.cat([flags, torch.zeros_like(flags)])
+                cap *= 2
+            act_b = active.view(torch.bool) if member_b[k] is None else active.view(torch.bool) & member_b[k]
+            g = self.env.decima_graph(act_b)  # recorded for training
+            a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.act(g, self.generator)
+            sel = [a[n] if a[n].dtype == torch.int64 and a[n].is_contiguous() else a[n].to(torch.int64).contiguous() for n in ("stage_sel", "job_idx", "exec_sel")]
+            lg = a["lgprob"] if a["lgprob"].dtype == torch.float32 and a["lgprob"].is_contiguous() else a["lgprob"].float().contiguous()
+            stage_idx, num_exec = acts[k]
+            c = SssCollectArgs(B, int(asynchronous), t, float(duration), env.obs_f64.data_ptr(), env.obs_i32.data_ptr(), env.obs_i32.stride(0),
+                               self.tl_env.time_limit.data_ptr(), active.data_ptr(), wall.data_ptr(), elapsed.data_ptr(), self.step_counts.data_ptr(),
+                               pending.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), sel[2].data_ptr(), lg.data_ptr(), stage_idx.data_ptr(), num_exec.data_ptr(),
+                               *(rec[name].data_ptr() for name, _ in spec), flags[t, k].data_ptr(), member[k].data_ptr() if member[k] is not None else None)
+            stream = env._stream()
+            with device_of(dev):
+                env._b.check(lib.sss_collect_step(ctypes.byref(c), 0, stream))
+            env.step_async(stage_idx, num_exec)
+            with device_of(dev):
+                env._b.check(lib.sss_collect_step(ctypes.byref(c), 1, stream))
+            unread[k] = (t, g, stage_idx, num_exec)
+            issued[k] = t + 1
+
+        try:
+            while any(alive) or any(u is not None for u in unread):
+                for k in range(G):
+                    with (torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()):
+                        if unread[k] is not None:
+                            read_flags(k)
+                        if alive[k]:
+                            enqueue(k)
+        finally:
+            sync_all()
+            if use_streams:
+                for st in streams:
+                    main.wait_stream(st)
         if n_failed:
             self._pending_reset = pending.view(torch.bool)
         self._obs, self._wall = True, wall  # (_obs: the envs are inside their episodes)
-        out = {k: rec[k][:t] for k, _ in spec}
-        return Rollouts(graph=concat_graphs(graphs), active=out["active"].view(torch.bool), t_before=out["t_before"], t_after=out["t_after"],
+        keys = sorted(graphs)
+        T = max((t for t, _ in keys), default=-1) + 1
+        out = {name: rec[name][:T] for name, _ in spec}
+        obs_index = None
+        if G > 1:  # observation (t, b) sits in the graph its group recorded at step t
+            pos = np.full((max(T, 1), G), 0, dtype=np.int64)
+            for i, (t, k) in enumerate(keys):
+                pos[t, k] = i
+            obs_index = torch.from_numpy(pos[:T]).to(dev)[:, group_of] * B + torch.arange(B, device=dev)[None, :]
+        return Rollouts(graph=concat_graphs([graphs[key] for key in keys]), active=out["active"].view(torch.bool), t_before=out["t_before"], t_after=out["t_after"],
                         rewards=out["rewards"], stage_sel=out["stage_sel"], job_idx=out["job_idx"], exec_sel=out["exec_sel"],
-                        lgprobs=out["lgprobs"], resets=out["resets"].view(torch.bool), stats=self._stats() if with_stats else {})
+                        lgprobs=out["lgprobs"], resets=out["resets"].view(torch.bool), stats=self._stats() if with_stats else {}, obs_index=obs_index)
 
     def collect_sync(self, with_stats: bool = True) -> Rollouts:
         """one full episode per env (rollout_worker.py:133-159)"""
@@ -470,7 +532,10 @@ class Trainer:
         gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
         gen.manual_seed(self.seed * 1000003 + self.rank)
         self.collector = RolloutCollector(self.env, self.env_cfg["mean_time_limit"], base_seeds, total_sequences, E,
-                                          policy=self.policy, generator=gen, on_env_error=train_cfg.get("on_env_error", "raise"))
+                                          policy=self.policy, generator=gen, on_env_error=train_cfg.get("on_env_error", "raise"),
+                                          # (`collector_groups` > 1: alternating groups of envs on their own streams - measured
+                                          # slower on one MI355X, profiles/r03_ppo.md; one group is the default)
+                                          groups=int(train_cfg.get("collector_groups", 1)))
         self.ppo = PPO(self.policy, train_cfg, generator=gen)
         self.history: list[dict[str, float]] = []
 

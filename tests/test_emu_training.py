@@ -175,3 +175,31 @@ def test_mlp_entry_points_on_the_host_backend():
     assert b.lib.sss_mlp_supported(7, 32, 16, 16, 0) == 0 and b.lib.sss_mlp_supported(16, 32, 16, 16, 1) == 0
     with pytest.raises(ValueError):
         mlp_forward(torch.zeros((4, 7)), torch.zeros(2000), (7, 32, 16, 16), 0, 0.2, binding=b)
+
+
+def test_two_groups_of_envs_record_what_one_group_records():
+    """`RolloutCollector(groups=2)` - the envs take their steps in two alternating groups (on two streams on the GPU), the
+    flags of a group's step are read one step late - against `groups=1`: the same record per env, and every sample's
+    observation id (`Rollouts.sample_ids`) points at the same observation of the recorded graph"""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.training import RolloutCollector
+    from training_util import counter_act_fn
+
+    cfg = dict(num_executors=10, job_arrival_cap=8, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    res = {}
+    for groups in (1, 2):
+        for mode in ("sync", "async"):
+            env = VecSparkSchedSimEnv(cfg, 5, device="cpu", auto_reset=False, _lib=load_emu())
+            col = RolloutCollector(env, 5.0e5, [11, 12, 13, 14, 15], seed_step=5, num_executors=10, act_fn=counter_act_fn, groups=groups)
+            ro = col.collect_sync(with_stats=False) if mode == "sync" else col.collect_async(2.0e5, with_stats=False)
+            ids = ro.sample_ids()
+            res[(groups, mode)] = ([ro.rollout(b) for b in range(5)], ro.graph["obs_nodes"][ids], ro.graph["obs_jobs"][ids], ro.flat(ro.rewards))
+            env.close()
+    for mode in ("sync", "async"):
+        one, two = res[(1, mode)], res[(2, mode)]
+        for ra, rb in zip(one[0], two[0]):
+            assert ra.keys() == rb.keys() and all((ra[k] == rb[k]).all() and ra[k].shape == rb[k].shape for k in ra)
+        assert one[1].numel() > 50 and all(torch.equal(a, b) for a, b in zip(one[1:], two[1:]))

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rollout-duration", type=float, default=0.0)
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--device-index", type=int, default=None)
+    ap.add_argument("--collector-groups", type=int, default=1)
     a = ap.parse_args()
     import os
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # BASELINE config 5: `python tools/bench_ppo.py --gpus 8 --sequences 256 --rollouts 4`
@@ -37,7 +38,8 @@ def main():
         raise SystemExit(launch_ranks(a.gpus, [osp.abspath(__file__)] + sys.argv[1:]))
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=a.sequences, num_rollouts=a.rollouts, seed=42,
                  checkpointing_freq=10 ** 9, num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04,
-                 beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo")
+                 beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo",
+                 collector_groups=a.collector_groups)
     if a.rollout_duration:
         train["rollout_duration"] = a.rollout_duration
     env = dict(num_executors=a.executors, job_arrival_cap=a.jobs, job_arrival_rate=4.0e-5, moving_delay=2000.0,

@@ -20,10 +20,11 @@ def main():
     ap.add_argument("--rollouts", type=int, default=4)
     ap.add_argument("--duration", type=float, default=1.5e6, help="simulated ms per env and collection")
     ap.add_argument("--rows", type=int, default=25)
+    ap.add_argument("--groups", type=int, default=1)
     a = ap.parse_args()
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=a.sequences, num_rollouts=a.rollouts, seed=42, checkpointing_freq=10 ** 9, num_epochs=3,
                  num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4),
-                 max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo", rollout_duration=a.duration)
+                 max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo", rollout_duration=a.duration, collector_groups=a.groups)
     env = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
     tr = Trainer(AGENT, env, train, device="cuda:0")
     tr.policy.eval()
