@@ -166,10 +166,152 @@ static int mlp16_launch(const SssMlpArgs& a, bool backward, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ---- the GNN-shaped MLPs (IN -> 32 -> 16 -> 16, LeakyReLU) on the matrix cores ---------------------------------------------
+// Same chaining as the inference kernels (sss_gnn_mfma.h: a wave owns 16 rows, Y^T = W X^T, K-step (t, r) = features
+// {16 t + 4 q + r}, an output tile's registers are the next Linear's B operands). Forward additionally stores the two hidden
+// activations (a lane holds four consecutive neurons of its row: 16-byte stores); backward runs the chain the other way with
+// the transposed weights as A operands: G2^T = W3^T dY^T, G1^T = W2^T G2^T, dX^T = W1^T G1^T, each followed by the
+// activation's derivative taken from the stored activations - all in registers.
+template <int IN>
+__global__ __launch_bounds__(256) void sss_mlp_mfma_fwd_kernel(SssMlpArgs a) {
+  constexpr int U = (IN + 15) / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  MfmaGnnMlp m;
+  m.load(a.w, lane, IN, 0, IN < 16 ? IN : 16);
+  float s1[2][4];  // second input segment (IN > 16)
+  if (U > 1) {
+    MfmaGnnMlp m2;
+    m2.load(a.w, lane, IN, 16, IN - 16);
+    for (int t = 0; t < 2; t++)
+      for (int r = 0; r < 4; r++) s1[t][r] = m2.a1[t][r];
+  }
+  const int64_t n_tiles = (a.rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + j;
+    const bool valid = row < a.rows;
+    mfma_f4 x0 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f}, x1 = x0;
+    if (valid) {
+      const float* xr = a.x + row * IN;
+      float v[4];
+      for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? xr[4 * q + r] : 0.0f;
+      x0 = mfma_f4{v[0], v[1], v[2], v[3]};
+      if (U > 1) {
+        for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? xr[16 + 4 * q + r] : 0.0f;
+        x1 = mfma_f4{v[0], v[1], v[2], v[3]};
+      }
+    }
+    // the first Linear and its activation (kept: the backward pass needs them), then the rest of the chain
+    mfma_f4 d0 = m.b1[0], d1 = m.b1[1];
+    d0 = mfma16(m.a1[0][0], x0.x, d0), d1 = mfma16(m.a1[1][0], x0.x, d1);
+    d0 = mfma16(m.a1[0][1], x0.y, d0), d1 = mfma16(m.a1[1][1], x0.y, d1);
+    d0 = mfma16(m.a1[0][2], x0.z, d0), d1 = mfma16(m.a1[1][2], x0.z, d1);
+    d0 = mfma16(m.a1[0][3], x0.w, d0), d1 = mfma16(m.a1[1][3], x0.w, d1);
+    if (U > 1) {
+      d0 = mfma16(s1[0][0], x1.x, d0), d1 = mfma16(s1[1][0], x1.x, d1);
+      d0 = mfma16(s1[0][1], x1.y, d0), d1 = mfma16(s1[1][1], x1.y, d1);
+      d0 = mfma16(s1[0][2], x1.z, d0), d1 = mfma16(s1[1][2], x1.z, d1);
+      d0 = mfma16(s1[0][3], x1.w, d0), d1 = mfma16(s1[1][3], x1.w, d1);
+    }
+    d0 = leaky4(d0, a.slope), d1 = leaky4(d1, a.slope);
+    mfma_f4 e0 = m.b2, e1 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    e0 = mfma16(m.a2[0][0], d0.x, e0), e1 = mfma16(m.a2[1][0], d1.x, e1);
+    e0 = mfma16(m.a2[0][1], d0.y, e0), e1 = mfma16(m.a2[1][1], d1.y, e1);
+    e0 = mfma16(m.a2[0][2], d0.z, e0), e1 = mfma16(m.a2[1][2], d1.z, e1);
+    e0 = mfma16(m.a2[0][3], d0.w, e0), e1 = mfma16(m.a2[1][3], d1.w, e1);
+    const mfma_f4 h2 = leaky4(e0 + e1, a.slope);
+    const mfma_f4 y = m.out(h2, 1.0f);
+    if (valid) {
+      *(mfma_f4*)(a.a1 + row * 32 + 4 * q) = d0, *(mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) = d1;
+      *(mfma_f4*)(a.a2 + row * 16 + 4 * q) = h2;
+      *(mfma_f4*)(a.y + row * 16 + 4 * q) = y;
+    }
+  }
+}
+
+SSS_DEV mfma_f4 leaky4_grad(mfma_f4 g, mfma_f4 act, float slope) {  // g * act'(.) from the activation's output
+  return mfma_f4{g.x * (act.x > 0.0f ? 1.0f : slope), g.y * (act.y > 0.0f ? 1.0f : slope), g.z * (act.z > 0.0f ? 1.0f : slope), g.w * (act.w > 0.0f ? 1.0f : slope)};
+}
+
+template <int IN>
+__global__ __launch_bounds__(256) void sss_mlp_mfma_bwd_kernel(SssMlpArgs a) {
+  constexpr int U = (IN + 15) / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const float* W1 = a.w;
+  const float* W2T = W1 + 32 * IN + 32;  // [j][m] = W2[m][j]
+  const float* W3 = W2T + 32 * 16 + 16;
+  // A operands of the transposed products, lane (i, q), register r <-> K index 4 q + r (+ 16 t)
+  float t3[4], t2[2][4], t1[U][2][4];
+  for (int r = 0; r < 4; r++) t3[r] = W3[(4 * q + r) * 16 + i];                                   // W3^T[i][4 q + r]
+  for (int tp = 0; tp < 2; tp++)
+    for (int r = 0; r < 4; r++) t2[tp][r] = W2T[(16 * tp + i) * 16 + 4 * q + r];                   // W2^T[16 t' + i][4 q + r]
+  for (int u = 0; u < U; u++)
+    for (int t = 0; t < 2; t++)
+      for (int r = 0; r < 4; r++) t1[u][t][r] = 16 * u + i < IN ? W1[(16 * t + 4 * q + r) * IN + 16 * u + i] : 0.0f;  // W1^T[16 u + i][16 t + 4 q + r]
+  const int j = i;
+  const int64_t n_tiles = (a.rows + 15) / 16;
+  const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + j;
+    const bool valid = row < a.rows;
+    const mfma_f4 dy = valid ? *(const mfma_f4*)(a.dy + row * 16 + 4 * q) : zero;
+    const mfma_f4 a2 = valid ? *(const mfma_f4*)(a.a2 + row * 16 + 4 * q) : zero;
+    const mfma_f4 a10 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 4 * q) : zero;
+    const mfma_f4 a11 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) : zero;
+    mfma_f4 g2 = zero;
+    g2 = mfma16(t3[0], dy.x, g2), g2 = mfma16(t3[1], dy.y, g2), g2 = mfma16(t3[2], dy.z, g2), g2 = mfma16(t3[3], dy.w, g2);
+    g2 = leaky4_grad(g2, a2, a.slope);
+    mfma_f4 g10 = zero, g11 = zero;
+    g10 = mfma16(t2[0][0], g2.x, g10), g11 = mfma16(t2[1][0], g2.x, g11);
+    g10 = mfma16(t2[0][1], g2.y, g10), g11 = mfma16(t2[1][1], g2.y, g11);
+    g10 = mfma16(t2[0][2], g2.z, g10), g11 = mfma16(t2[1][2], g2.z, g11);
+    g10 = mfma16(t2[0][3], g2.w, g10), g11 = mfma16(t2[1][3], g2.w, g11);
+    g10 = leaky4_grad(g10, a10, a.slope), g11 = leaky4_grad(g11, a11, a.slope);
+    if (valid) {
+      *(mfma_f4*)(a.g2 + row * 16 + 4 * q) = g2;
+      *(mfma_f4*)(a.g1 + row * 32 + 4 * q) = g10, *(mfma_f4*)(a.g1 + row * 32 + 16 + 4 * q) = g11;
+    }
+    if (a.dx) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        mfma_f4 dx = zero;
+        dx = mfma16(t1[u][0][0], g10.x, dx), dx = mfma16(t1[u][0][1], g10.y, dx), dx = mfma16(t1[u][0][2], g10.z, dx), dx = mfma16(t1[u][0][3], g10.w, dx);
+        dx = mfma16(t1[u][1][0], g11.x, dx), dx = mfma16(t1[u][1][1], g11.y, dx), dx = mfma16(t1[u][1][2], g11.z, dx), dx = mfma16(t1[u][1][3], g11.w, dx);
+        if (valid) {
+          float* o = a.dx + row * IN + 16 * u + 4 * q;
+          if (16 * u + 4 * q + 0 < IN) o[0] = dx.x;
+          if (16 * u + 4 * q + 1 < IN) o[1] = dx.y;
+          if (16 * u + 4 * q + 2 < IN) o[2] = dx.z;
+          if (16 * u + 4 * q + 3 < IN) o[3] = dx.w;
+        }
+      }
+    }
+  }
+}
+
+template <int IN>
+static int mlp_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
+  if (a.rows <= 0) return 0;
+  const int64_t wgs = (a.rows + 63) / 64;
+  const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+  if (backward)
+    hipLaunchKernelGGL(sss_mlp_mfma_bwd_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(sss_mlp_mfma_fwd_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 // the MLP shapes of the published architecture (config/decima_tpch.yaml:66-78); anything else: -1 (the caller keeps autograd)
 static int be_launch_mlp(const SssMlpArgs& a, int backward, void* stream) {
   const bool gnn = a.h1 == 32 && a.h2 == 16 && a.out_dim == 16 && a.act == 0;
   const bool head = a.h1 == 64 && a.h2 == 64 && a.out_dim == 1 && a.act == 1;
+  static const bool lanes16 = getenv("SSS_MLP_LANES16") != nullptr;  // (comparisons: the 16-lanes-per-row kernels for the GNN shapes too)
+  if (gnn && !lanes16) {
+    if (a.in_dim == GNN_NF) return mlp_mfma_launch<GNN_NF>(a, backward, stream);
+    if (a.in_dim == 16) return mlp_mfma_launch<16>(a, backward, stream);
+    if (a.in_dim == GNN_NF + 16) return mlp_mfma_launch<GNN_NF + 16>(a, backward, stream);
+  }
   if (gnn && a.in_dim == GNN_NF) return mlp16_launch<GNN_NF, 32, 16, 16, 0>(a, backward, stream);
   if (gnn && a.in_dim == 16) return mlp16_launch<16, 32, 16, 16, 0>(a, backward, stream);
   if (gnn && a.in_dim == GNN_NF + 16) return mlp16_launch<GNN_NF + 16, 32, 16, 16, 0>(a, backward, stream);
@@ -177,3 +319,4 @@ static int be_launch_mlp(const SssMlpArgs& a, int backward, void* stream) {
   if (head && a.in_dim == GNN_DF + 33) return mlp16_launch<GNN_DF + 33, 64, 64, 1, 1>(a, backward, stream);
   return -1;
 }
+
