@@ -359,7 +359,7 @@ typedef struct sss_gnn_encode_args {
   int64_t recv_cap;
   int64_t layer_rows_hint[32]; /* host values: roughly how many nodes layer l updates (e.g. layer_totals of the previous step,
                                   read back lazily); only sizes the launch grids - every row is processed whatever it says.
-                                  0: no idea (the grid is sized by n_nodes) */
+                                  -1: no idea (the grid is sized by n_nodes) */
 } sss_gnn_encode_args;
 int sss_gnn_encode(const sss_gnn_encode_args* a, void* stream);
 

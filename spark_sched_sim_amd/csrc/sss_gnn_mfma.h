@@ -97,6 +97,37 @@ struct MfmaGnnMlp {
 // LAYER (sss_gnn.h): tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) ), 16 receiving
 // nodes per wave and pass. Out-edge slot k of all 16 rows goes through the message MLP together (rows without such an edge
 // contribute zero), so a tile costs 16 MFMAs per slot + 24 for the aggregate and the update MLP.
+// One tile: rows idx0[first + j], j < count (count <= 16), of DAG layer `layer`.
+SSS_DEV void gnn_layer_mfma_tile(const SssGnnArgs& a, const MfmaGnnMlp& msg, const MfmaGnnMlp& upd, const int64_t* idx0, int64_t first, int count, int layer,
+                                  int lane) {
+  const int j = lane & 15, q = lane >> 4;
+  const uint32_t above = layer >= 31 ? 0u : ~((2u << layer) - 1u);
+  const int64_t n = j < count ? idx0[first + j] : -1;
+  const bool valid = n >= 0;
+  const int64_t e0 = valid ? a.out_start[n] : 0;
+  const int deg = valid ? a.out_deg[n] : 0;
+  mfma_f4 acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  float used = 0.0f;
+  for (int k = 0; __builtin_amdgcn_ballot_w64(k < deg) != 0; k++) {
+    const bool use = k < deg && ((a.edge_layers[e0 + k] >> layer) & 1u);
+    mfma_f4 x = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (use) {
+      const int64_t c = a.dst[e0 + k];
+      const float* cur = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[c] & above) & 1)) ? a.tmp : a.h;
+      x = *(const mfma_f4*)(cur + c * 16 + 4 * q);
+    }
+    const mfma_f4 h2 = msg.hidden(x, a.slope);
+    if (use) acc += h2, used += 1.0f;
+  }
+  const mfma_f4 agg = msg.out(acc, used);
+  const mfma_f4 y = upd.out(upd.hidden(agg, a.slope), 1.0f);
+  if (valid) {
+    float* nxt = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[n] & above) & 1)) ? a.h : a.tmp;
+    const mfma_f4 hi = *(const mfma_f4*)(a.h_init + n * 16 + 4 * q);
+    *(mfma_f4*)(nxt + n * 16 + 4 * q) = hi + y;
+  }
+}
+
 __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
   if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode)
     int64_t off = 0;
@@ -105,37 +136,12 @@ __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
     if ((int64_t)blockIdx.x * 64 >= a.n_rows) return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
   MfmaGnnMlp msg, upd;
   msg.load(a.w, lane), upd.load(a.w2, lane);
-  const uint32_t above = a.layer >= 31 ? 0u : ~((2u << a.layer) - 1u);
   const int64_t n_tiles = (a.n_rows + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t r = tile * 16 + j;
-    const int64_t n = r < a.n_rows ? a.idx0[r] : -1;
-    const bool valid = n >= 0;
-    const int64_t e0 = valid ? a.out_start[n] : 0;
-    const int deg = valid ? a.out_deg[n] : 0;
-    mfma_f4 acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-    float used = 0.0f;
-    for (int k = 0; __builtin_amdgcn_ballot_w64(k < deg) != 0; k++) {
-      const bool use = k < deg && ((a.edge_layers[e0 + k] >> a.layer) & 1u);
-      mfma_f4 x = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (use) {
-        const int64_t c = a.dst[e0 + k];
-        const float* cur = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[c] & above) & 1)) ? a.tmp : a.h;
-        x = *(const mfma_f4*)(cur + c * 16 + 4 * q);
-      }
-      const mfma_f4 h2 = msg.hidden(x, a.slope);
-      if (use) acc += h2, used += 1.0f;
-    }
-    const mfma_f4 agg = msg.out(acc, used);
-    const mfma_f4 y = upd.out(upd.hidden(agg, a.slope), 1.0f);
-    if (valid) {
-      float* nxt = (a.node_recv && (__builtin_popcount((uint32_t)a.node_recv[n] & above) & 1)) ? a.h : a.tmp;
-      const mfma_f4 hi = *(const mfma_f4*)(a.h_init + n * 16 + 4 * q);
-      *(mfma_f4*)(nxt + n * 16 + 4 * q) = hi + y;
-    }
+    const int64_t left = a.n_rows - tile * 16;
+    gnn_layer_mfma_tile(a, msg, upd, a.idx0, tile * 16, left < 16 ? (int)left : 16, a.layer, lane);
   }
 }
 

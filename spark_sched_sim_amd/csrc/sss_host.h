@@ -550,7 +550,7 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
     a.layer = lvl;
     // (n_rows only sizes the grid here: the kernel reads the list's length itself and strides over all of it)
-    int64_t rows = g->layer_rows_hint[lvl] > 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : g->n_nodes;
+    int64_t rows = g->layer_rows_hint[lvl] >= 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : g->n_nodes;
     if (rows > g->n_nodes) rows = g->n_nodes;
     if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
   }

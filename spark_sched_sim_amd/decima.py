@@ -541,7 +541,7 @@ class DecimaPolicy(nn.Module):
         sc = pool.get((dev, stream))
         need = max(M * D, 1)
         if sc is None or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
-            hint = torch.zeros(32, dtype=torch.int64)
+            hint = torch.full((32,), -1, dtype=torch.int64)  # (unknown until the first pass's lengths have come back)
             sc = pool[(dev, stream)] = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
                                       "env_off": torch.empty(32 * B, dtype=torch.int64, device=dev), "tot": torch.empty(32, dtype=torch.int64, device=dev),
                                       "hint": hint.pin_memory() if dev.type == "cuda" else hint}
