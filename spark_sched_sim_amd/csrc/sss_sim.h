@@ -3217,16 +3217,19 @@ SSS_DEV void env_begin(const uint8_t* base) {
     const uint32_t info = g_hot.ev[lane].info;  // lanes beyond the executors hold EV_NONE
     const bool has = info_kind(info) != EV_NONE;
     const int j = has ? info_job(info) : -1 - lane;
+    // (one pass per DISTINCT job with an event, not per executor: at 50 executors a third of the iterations)
     uint32_t cnt = 0;
-    bool first = has;
-    for (int e = 0; e < g_c.E; e++) {
-      const int je = (int)wave_readlane_u32((uint32_t)j, e);
-      cnt += je == j ? 1u : 0u;
-      first = first && !(je == j && e < lane);
+    bool first = false;
+    for (uint64_t m = wave_ballot(has); m;) {
+      const int l = ctz64_nz(m);
+      const int jl = (int)wave_readlane_u32((uint32_t)j, l);
+      const uint64_t same = wave_ballot(has && j == jl);
+      if (has && j == jl) cnt = (uint32_t)popc64(same), first = lane == l;  // (l is the lowest executor of its job)
+      m &= ~same;
     }
     const uint32_t key = first ? ((cnt << 8) | (uint32_t)(63 - lane)) : 0u;  // more events first, then the lower executor
     uint32_t rank = 0;
-    for (int e = 0; e < g_c.E; e++) rank += wave_readlane_u32(key, e) > key ? 1u : 0u;
+    for (uint64_t m = wave_ballot(first); m; m &= m - 1) rank += wave_readlane_u32(key, ctz64_nz(m)) > key ? 1u : 0u;
     const int nK = (int)popc64(wave_ballot(first));
     const int n_used = nK < g_c.P.n_slots ? nK : g_c.P.n_slots;
     if (first && (int)rank < g_c.P.n_slots) {
