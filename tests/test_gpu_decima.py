@@ -229,3 +229,60 @@ def test_decima_step_with_another_current_device(pack):
         env.step(act)
     assert torch.isfinite(aux["lgprob"]).all() and int((env.obs_i32[:, 7] != 0).sum()) == 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_matrix_core_gnn_equals_the_vector_unit_forms(tmp_path):
+    """csrc/sss_gnn_mfma.h (DAG layers, node / job rows and both policy heads as chained v_mfma_f32_16x16x4_f32) against the
+    vector-unit kernels of sss_gnn.h / sss_gnn16.h on the same recorded graphs and parameters: a child process runs the
+    same script with SSS_GNN_LAYER16 / SSS_GNN_ROWS_VALU / SSS_GNN_HEADS_VALU set (the forms are chosen once per process).
+    Embeddings, job / observation summaries, stage and executor scores agree within 2e-5 (fp32, different summation order;
+    the heads' tanh is exp / rcp based on the matrix-core path: ~1e-7)."""
+    import os
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[3])
+from decima_util import AGENT
+from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
+from spark_sched_sim_amd.decima import DecimaPolicy
+out = {}
+for name, cfg, n_env, steps in (("c2", dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), 300, 120),
+                                 ("e50", dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), 37, 200)):
+    env = VecSparkSchedSimEnv(cfg, n_env, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
+    env.reset(seed=5)
+    env.rollout("fair", steps)
+    torch.manual_seed(9)
+    pol = DecimaPolicy(num_executors=cfg["num_executors"], **AGENT).to("cuda:0").eval()
+    with torch.no_grad():
+        for n_, p_ in pol.named_parameters():
+            if "bias" in n_:
+                p_.normal_(0.0, 0.1)
+    pol.bind_kernels(env._b)
+    g = env.decima_graph(None)
+    h = pol._encode_kernels(g)
+    s = pol._stage_scores_kernels(g, h)
+    jobs = torch.arange(0, g["job_obs"].numel(), 3, device="cuda:0")
+    es = pol._exec_scores_kernels(g, h, jobs)
+    for k, v in (("node", h["node"]), ("dag", h["dag"]), ("glob", h["glob"]), ("stage", s), ("exec", es)):
+        out[name + "_" + k] = v.cpu().numpy()
+    env.close()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("mfma", {}), ("valu", {"SSS_GNN_LAYER16": "1", "SSS_GNN_ROWS_VALU": "1", "SSS_GNN_HEADS_VALU": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, "-c", script, path, root, os.path.join(root, "tests")], check=True, env=dict(os.environ, **extra), timeout=600)
+        res[tag] = dict(np.load(path))
+    assert res["mfma"].keys() == res["valu"].keys() and len(res["mfma"]) == 10
+    for k, a in res["mfma"].items():
+        b = res["valu"][k]
+        assert a.shape == b.shape and a.size > 0
+        fin = np.isfinite(b)
+        assert (np.isfinite(a) == fin).all(), k  # (-inf marks slots that are not schedulable / executor counts beyond the cap)
+        assert np.abs(a[fin] - b[fin]).max() <= 2e-5 * max(1.0, float(np.abs(b[fin]).max())), (k, float(np.abs(a[fin] - b[fin]).max()))
