@@ -188,3 +188,17 @@ def test_message_passing_function_matches_the_tensor_op_form():
         a, b = out[True][1][k], out[False][1][k]
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * max(1.0, float(b.abs().max()))), (k, float((a - b).abs().max()), float(b.abs().max()))
     env.close()
+
+
+@pytest.mark.gpu
+def test_mlp_kernels_16_lane_forms_in_a_child_process():
+    """the GNN-shaped training MLPs run on the matrix cores by default; their 16-lanes-per-row kernels (kept for the policy
+    heads and for comparisons, SSS_MLP_LANES16) go through the same checks in a child process that selects them"""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "test_mlp_kernels_match_autograd", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, SSS_MLP_LANES16="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
