@@ -42,7 +42,8 @@ class SssDecimaGraph(C.Structure):
                 ("node_recv_dev", C.c_void_p), ("stage_mask_dev", C.c_void_p), ("src_dev", C.c_void_p), ("dst_dev", C.c_void_p),
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
-                ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p), ("sched_off_dev", C.c_void_p), ("sched_list_dev", C.c_void_p)]
+                ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p), ("sched_off_dev", C.c_void_p), ("sched_list_dev", C.c_void_p),
+                ("layer_totals_dev", C.c_void_p), ("recv_lists_dev", C.c_void_p), ("recv_stride", C.c_int64)]
 
 
 class SssDecimaLists(C.Structure):
@@ -98,7 +99,7 @@ class SssGnnEncodeArgs(C.Structure):  # include/sss.h sss_gnn_encode_args
                 + [(k + "_dev", C.c_void_p) for k in ("w_prep", "w_update", "w_msg", "w_dag", "w_glob", "w_msg16", "w_update16", "x", "out_deg", "obs_depth", "node_obs", "dst",
                                                       "out_start", "edge_layers", "node_recv", "job_first", "job_nodes", "obs_job_off", "obs_jobs", "obs_node_off",
                                                       "obs_nodes", "layer_cnt", "h_init", "h", "tmp", "h_dag", "h_glob", "env_off", "layer_totals", "recv")]
-                + [("recv_cap", C.c_int64), ("layer_rows_hint", C.c_int64 * 32)])
+                + [("recv_cap", C.c_int64), ("recv_stride", C.c_int64), ("layer_rows_hint", C.c_int64 * 32)])
 
 
 class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args

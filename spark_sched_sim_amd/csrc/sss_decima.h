@@ -30,6 +30,12 @@ struct SssDecimaArgs {
   int32_t* layer_cnt;   // i32[32][B]: number of receiving nodes of DAG layer l in env b
   const int64_t* sched_off;  // nullable, i64[B]: exclusive prefix of the envs' schedulable-stage counts ...
   int64_t* sched_list;       // ... and where the flat ids of the schedulable nodes go, env by env in node order
+  // nullable: the layers' lists of receiving nodes written by this kernel itself - layer l's list is recv_lists[l * recv_stride ..]
+  // (recv_stride >= total node count), its length layer_totals[l] (i64[32], ZERO on entry): an env reserves its share of a list
+  // with one fetch-add, so the order of the envs inside a list varies from launch to launch (the layer launches do not care)
+  int64_t* layer_totals;
+  int64_t* recv_lists;
+  int64_t recv_stride;
 };
 
 struct SssDecimaListArgs {
@@ -164,6 +170,19 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
     }
   }
   if (lane < 32) d.layer_cnt[(size_t)lane * L.num_envs + env] = (int32_t)cnt;
+  if (d.recv_lists) {
+    int64_t base = 0;
+    if (lane < 32 && cnt) base = global_fetch_add_i64(d.layer_totals + lane, (int64_t)cnt);
+    for (uint32_t l = 0; l < depth; l++) {
+      int64_t pos = (int64_t)l * d.recv_stride + (int64_t)wave_readlane_u64((uint64_t)base, (int)l);
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const bool on = i0 + lane < n && ((recv[i0 + lane] >> l) & 1u);
+        const uint64_t bal = wave_ballot(on);
+        if (on) d.recv_lists[pos + popc64(bal & lt)] = n0 + i0 + lane;
+        pos += popc64(bal);
+      }
+    }
+  }
 }
 
 // the receiving nodes of every DAG layer as index lists (layer l = recv[layer_base[l] ...), env by

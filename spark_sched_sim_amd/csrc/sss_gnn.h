@@ -65,6 +65,7 @@ struct SssGnnArgs {
   const int64_t* layer_totals;  // LAYER, nullable: i64[32] on the device - the row count is layer_totals[layer] and idx0 starts
                                 // after the lists of the layers below it (no host round trip for the list sizes); n_rows is then
                                 // an upper bound that sizes the grid
+  int64_t idx0_stride;          // ... with layer_totals: > 0 = layer l's list starts at idx0[l * idx0_stride] (the graph kernel's lists)
   float slope;          // LeakyReLU negative slope (GNN MLPs)
   int E;                // EXEC: number of executors
   int layer;            // LAYER

@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
   if (KIND == GNN_LAYER) {
     // tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
     if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode): most workgroups of a sparse layer leave here
-      int64_t off = 0;
-      for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
+      int64_t off = (int64_t)a.layer * a.idx0_stride;
+      if (a.idx0_stride == 0)
+        for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
       a.n_rows = a.layer_totals[a.layer], a.idx0 += off;
       if ((int64_t)blockIdx.x * 16 >= a.n_rows) return;
     }

@@ -130,8 +130,9 @@ SSS_DEV void gnn_layer_mfma_tile(const SssGnnArgs& a, const MfmaGnnMlp& msg, con
 
 __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
   if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode)
-    int64_t off = 0;
-    for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
+    int64_t off = (int64_t)a.layer * a.idx0_stride;
+    if (a.idx0_stride == 0)
+      for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
     a.n_rows = a.layer_totals[a.layer], a.idx0 += off;
     if ((int64_t)blockIdx.x * 64 >= a.n_rows) return;
   }

@@ -426,6 +426,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   d.job_obs = g->job_obs_dev, d.job_cap = g->job_cap_dev, d.job_first = g->job_first_dev, d.obs_depth = g->obs_depth_dev;
   d.job_nodes = g->job_nodes_dev, d.out_start = g->out_start_dev, d.out_deg = g->out_deg_dev, d.layer_cnt = g->layer_cnt_dev;
   d.sched_off = g->sched_off_dev, d.sched_list = g->sched_off_dev ? g->sched_list_dev : nullptr;
+  d.layer_totals = g->layer_totals_dev, d.recv_lists = g->layer_totals_dev ? g->recv_lists_dev : nullptr, d.recv_stride = g->recv_stride;
+  if (g->layer_totals_dev && (!g->recv_lists_dev || g->recv_stride < 1)) return sss_fail(-1, "NULL argument");
   if (g->sched_off_dev && !g->sched_list_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));
   return 0;
@@ -498,7 +500,7 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   a.edge_layers = g->edge_layers_dev, a.node_job = g->node_job_dev, a.node_obs = g->node_obs_dev, a.node_loc = g->node_loc_dev;
   a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
   a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
-  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev, a.layer_totals = nullptr;
+  a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev, a.layer_totals = nullptr, a.idx0_stride = 0;
   if (kind == GNN_MERGE && !g->node_recv_dev) return sss_fail(-1, "NULL argument");
   if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
@@ -514,18 +516,21 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   if (!g->w_prep_dev || !g->w_update_dev || !g->w_msg_dev || !g->w_dag_dev || !g->w_glob_dev || !g->x_dev || !g->out_deg_dev || !g->obs_depth_dev || !g->node_obs_dev ||
       !g->out_start_dev || !g->node_recv_dev || !g->job_first_dev || !g->job_nodes_dev || !g->obs_job_off_dev || !g->obs_jobs_dev ||
       !g->obs_node_off_dev || !g->obs_nodes_dev || !g->layer_cnt_dev || !g->h_init_dev || !g->h_dev || !g->tmp_dev || !g->h_dag_dev || !g->h_glob_dev ||
-      !g->env_off_dev || !g->layer_totals_dev || !g->recv_dev)
+      (!g->env_off_dev && g->recv_stride == 0) || !g->layer_totals_dev || !g->recv_dev)
     return sss_fail(-1, "NULL argument");
   // (dst_dev / edge_layers_dev may be NULL: a batch without edges)
-  if (g->recv_cap < g->n_nodes * (int64_t)g->max_depth) return sss_fail(-33, "sss_gnn_encode: recv_dev must hold n_nodes * max_depth entries");
+  if (g->recv_stride ? (g->recv_stride < g->n_nodes || g->recv_cap < g->recv_stride * (int64_t)g->max_depth) : g->recv_cap < g->n_nodes * (int64_t)g->max_depth)
+    return sss_fail(-33, "sss_gnn_encode: recv_dev must hold n_nodes * max_depth entries");
   if (g->n_nodes == 0 || g->n_jobs == 0) return 0;
   auto fail = [](const char* what, int rc) { return sss_fail(-30, std::string(what) + " launch failed: " + be_error(rc)); };
   // lengths of the layers' lists of receiving nodes, their per-env offsets, the lists
+  // (recv_stride != 0: sss_decima_graph_build has written the lists and their lengths already - recv_lists_dev / layer_totals_dev)
   SssPrefixArgs p;
   p.src = g->layer_cnt_dev, p.row_stride = g->n_obs, p.col_stride = 1, p.mask = nullptr, p.n_rows = 32, p.n_cols = g->n_obs;
   p.off = g->env_off_dev, p.cnt = nullptr, p.totals = g->layer_totals_dev;
-  if (int rc = be_launch_prefix_rows(p, stream)) return fail("prefix", rc);
-  if (g->max_depth > 0) {
+  if (g->recv_stride == 0)
+    if (int rc = be_launch_prefix_rows(p, stream)) return fail("prefix", rc);
+  if (g->max_depth > 0 && g->recv_stride == 0) {
     SssDecimaListArgs d;
     d.node_off = g->obs_node_off_dev, d.obs_nodes = g->obs_nodes_dev, d.node_recv = (const uint32_t*)g->node_recv_dev, d.env_off = g->env_off_dev;
     for (int l = 0; l < 32; l++) d.layer_base[l] = 0;
@@ -545,7 +550,7 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   if (int rc = run(GNN_PREP, g->n_nodes, g->w_prep_dev)) return fail("gnn", rc);
   a.out = nullptr;
   // the layers, deepest first (scheduler.py:209-211): embeddings alternate between h and tmp per update (sss_gnn.h)
-  a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev;
+  a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev, a.idx0_stride = g->recv_stride;
   a.w2 = g->w_update_dev, a.w16 = g->w_msg16_dev, a.w2_16 = g->w_update16_dev;
   for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
     a.layer = lvl;
@@ -554,7 +559,7 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
     if (rows > g->n_nodes) rows = g->n_nodes;
     if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
   }
-  a.idx0 = nullptr, a.layer_totals = nullptr, a.w2 = nullptr, a.w16 = nullptr, a.w2_16 = nullptr, a.layer = 0;
+  a.idx0 = nullptr, a.layer_totals = nullptr, a.idx0_stride = 0, a.w2 = nullptr, a.w16 = nullptr, a.w2_16 = nullptr, a.layer = 0;
   if (int rc = run(GNN_DAGHID, g->n_nodes, g->w_dag_dev)) return fail("gnn", rc);  // (brings the embeddings left in tmp home: MERGE)
   a.node_recv = nullptr;
   if (int rc = run(GNN_DAGSUM, g->n_jobs, g->w_dag_dev)) return fail("gnn", rc);

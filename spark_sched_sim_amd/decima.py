@@ -546,15 +546,19 @@ class DecimaPolicy(nn.Module):
                                       "env_off": torch.empty(32 * B, dtype=torch.int64, device=dev), "tot": torch.empty(32, dtype=torch.int64, device=dev),
                                       "hint": hint.pin_memory() if dev.type == "cuda" else hint}
         p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731  (a batch without edges: dst / edge_layers empty)
+        # the graph kernel's own lists, if this graph is still the last one its env built on this stream (else: scan + list kernel here)
+        ls, epoch = g.get("_layer_lists", (None, -1))
+        fresh = ls is not None and ls["epoch"] == epoch and ls["recv"].device == dev and ls["stride"] >= M
+        tot_t, recv_t, stride = (g["layer_totals"], ls["recv"], ls["stride"]) if fresh else (sc["tot"], sc["recv"], 0)
         a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
                              p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
                              p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
-                             p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(sc["tot"]), p(sc["recv"]), sc["recv"].numel(),
+                             p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
                              # the list sizes of the PREVIOUS pass, copied back without waiting (whatever is there: they only size grids)
                              (ctypes.c_int64 * 32)(*sc["hint"].tolist()))
         with device_of(dev):
             self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
-        sc["hint"].copy_(sc["tot"], non_blocking=True)
+        sc["hint"].copy_(tot_t, non_blocking=True)
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()

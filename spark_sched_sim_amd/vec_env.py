@@ -80,6 +80,7 @@ class VecSparkSchedSimEnv:
         self._act_nexec = torch.ones(B, dtype=torch.int32, device=dev)
         self._closed = False
         self._dg_pool: dict[int, torch.Tensor] = {}
+        self._layer_scratch: dict = {}
         from .workload import pack_max_depth
         self.max_dag_depth = pack_max_depth(self._pack)  # bound of an observation's DAG layers: sizes sss_gnn_encode's layer launches
         # gymnasium.vector.VectorEnv attributes; the per-env action space is the reference's at
@@ -246,14 +247,25 @@ class VecSparkSchedSimEnv:
                 "src": Ed, "dst": Ed, "edge_obs": Ed, "edge_layers": Ed, "job_obs": J, "job_cap": J, "job_first": J, "obs_depth": B,
                 "job_nodes": J, "out_start": M, "out_deg": M, "layer_cnt": 32, "sched_list": S}
         g = {k: v[: size[k]] for k, v in buf.items()}
+        # the layers' lists of receiving nodes, written by the graph kernel itself into work space the env keeps per stream
+        # (max_dag_depth lists of up to M ids; lengths in `layer_totals`): valid until the next decima_graph on this stream
+        D = self.max_dag_depth
+        skey = (dev, self._stream())
+        ls = self._layer_scratch.get(skey)
+        if ls is None or ls["recv"].numel() < max(M, 1) * max(D, 1):
+            ls = self._layer_scratch[skey] = {"recv": torch.empty(max(2 * M, 1 << 14) * max(D, 1), dtype=torch.int64, device=dev), "epoch": 0}
+        ls["epoch"] += 1
+        ls["stride"] = ls["recv"].numel() // max(D, 1)
+        layer_totals = torch.zeros(32, dtype=torch.int64, device=dev)
         a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
                                "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
-                           off[3].data_ptr(), buf["sched_list"].data_ptr())
+                           off[3].data_ptr(), buf["sched_list"].data_ptr(), layer_totals.data_ptr(), ls["recv"].data_ptr(), ls["stride"])
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
         g["max_depth"] = self.max_dag_depth
+        g["layer_totals"], g["_layer_lists"] = layer_totals, (ls, ls["epoch"])
         g["obs_nodes"], g["obs_jobs"] = cnt_t[0], cnt_t[2]
         g["obs_node_off"], g["obs_job_off"] = off[0], off[2]
         g["_keepalive"] = (off, act8)

@@ -167,8 +167,9 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
     case GNN_LAYER: {
       SssGnnArgs b = a;
       if (b.layer_totals) {  // (the gfx950 kernel reads the list's length and position from the device, sss_gnn16.h)
-        int64_t off = 0;
-        for (int l = 0; l < b.layer; l++) off += b.layer_totals[l];
+        int64_t off = (int64_t)b.layer * b.idx0_stride;
+        if (b.idx0_stride == 0)
+          for (int l = 0; l < b.layer; l++) off += b.layer_totals[l];
         b.n_rows = b.layer_totals[b.layer], b.idx0 += off;
       }
       return gnn_run_kind<GNN_LAYER>(b);

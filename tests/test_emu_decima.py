@@ -64,6 +64,14 @@ def test_graph_kernel_lists_and_one_call_encoder():
         ref = policy._encode_kernels(g2)
         for k in ("node", "dag", "glob"):
             assert torch.equal(one[k], ref[k]), k
+        # the graph kernel's own layer lists live in work space of the env: a graph that is no longer the last one built
+        # has its lists rebuilt by the encoder (same embeddings)
+        assert g["_layer_lists"][0]["epoch"] == g["_layer_lists"][1]
+        env.decima_graph(active)
+        assert g["_layer_lists"][0]["epoch"] != g["_layer_lists"][1]
+        again = policy._encode_kernels(g)
+        for k in ("node", "dag", "glob"):
+            assert torch.equal(again[k], ref[k]), k
     env.close()
 
 
