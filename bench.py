@@ -149,7 +149,7 @@ def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float
     return None
 
 
-def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int = 20) -> dict:
+def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 400, warmup: int = 100) -> dict:
     """extra, not the headline: the same B envs with a sampled Decima action (GNN policy, random-init
     weights of the published architecture) for every env on every step - graph kernel, GNN kernels,
     sampling kernels, sss_step (spark_sched_sim_amd/decima.py)"""

@@ -81,6 +81,7 @@ class VecSparkSchedSimEnv:
         self._closed = False
         self._dg_pool: dict[int, torch.Tensor] = {}
         self._layer_scratch: dict = {}
+        self._never = None
         from .workload import pack_max_depth
         self.max_dag_depth = pack_max_depth(self._pack)  # bound of an observation's DAG layers: sizes sss_gnn_encode's layer launches
         # gymnasium.vector.VectorEnv attributes; the per-env action space is the reference's at
@@ -175,9 +176,13 @@ class VecSparkSchedSimEnv:
             raise ValueError("invalid action: does not belong to the action space")  # Dict.contains
         self.step_async(actions["stage_idx"], actions["num_exec"])
         obs = self._obs()
-        small = torch.cat([self.obs_f64, self.obs_i32[:, 6:8].to(torch.float64)], dim=1)  # ONE copy: reward, wall_time, terminated, err
-        terminated = small[:, 2] != 0
-        return obs, small[:, 0], terminated, torch.zeros_like(terminated), {"wall_time": small[:, 1], "err": small[:, 3].to(torch.int32)}
+        # the small per-env vectors are COPIES (two copy launches + one compare): reward / wall_time, terminated / err
+        f64 = self.obs_f64.clone()
+        i32 = self.obs_i32[:, 6:8].clone()
+        terminated = i32[:, 0] != 0
+        if self._never is None or self._never.shape != terminated.shape:
+            self._never = torch.zeros_like(terminated)  # (truncation is the time-limit wrapper's business: always False here; shared, read-only)
+        return obs, f64[:, 0], terminated, self._never, {"wall_time": f64[:, 1], "err": i32[:, 1]}
 
     # ---- on-device policies and fused rollouts ---------------------------------------------
 
