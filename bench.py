@@ -149,10 +149,13 @@ def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float
     return None
 
 
-def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 400, warmup: int = 100) -> dict:
+def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int = 20, steady_after: int = 600, steady_steps: int = 1200) -> dict:
     """extra, not the headline: the same B envs with a sampled Decima action (GNN policy, random-init
     weights of the published architecture) for every env on every step - graph kernel, GNN kernels,
-    sampling kernels, sss_step (spark_sched_sim_amd/decima.py)"""
+    sampling kernels, sss_step (spark_sched_sim_amd/decima.py). Two windows: steps 20..120 after the reset (the window
+    the earlier rounds quote: every env early in its first episode) and `steady`: 1200 steps after 600 - two episode
+    lengths under this policy; the envs stay roughly in phase, so the cost of a step swings with the phase of the episode
+    (0.63 .. 0.89 ms, tools/debug/decima_windows.py) and only an average over episodes is a stable figure."""
     import torch
 
     from spark_sched_sim_amd import VecSparkSchedSimEnv
@@ -165,17 +168,26 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 400, warmup: int =
     policy = DecimaPolicy(num_executors=cfg["num_executors"], **agent).to(dev).eval()
     gen = torch.Generator(device=dev).manual_seed(1)
     env.reset(seed=0)
-    for i in range(warmup + steps):
-        if i == warmup:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        act, _ = policy.schedule_env(env, generator=gen)
-        env.step(act)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def run(n: int) -> float:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            act, _ = policy.schedule_env(env, generator=gen)
+            env.step(act)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(warmup)
+    dt = run(steps)
+    run(max(0, steady_after - warmup - steps))
+    nodes = int(env.obs_i32[:, 0].sum())
+    dts = run(steady_steps)
     err = int((env.obs_i32[:, 7] != 0).sum())
     env.close()
     return {"value": B * steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "envs_in_error_state": err,
+            "steady": {"value": B * steady_steps / dts, "ms_per_step": 1e3 * dts / steady_steps, "steps": steady_steps, "after_steps": steady_after,
+                       "active_nodes_per_env": nodes / B},
             "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
 
 
