@@ -185,10 +185,10 @@ struct MfmaHead {
     }
     for (int t = tid; t < 64; t += nthreads) lds[B1 + t] = gB1[t], lds[B2 + t] = gB2[t];
   }
-  // the row's score (on every lane of the row's four) from its input segments x[u] (register r: feature 4 q + r of segment u)
-  SSS_DEV static float score(const float* lds, const mfma_f4 (&x)[U], const float (&w3)[16], float b3, int lane) {
+  // the two hidden layers' activations of the tile's rows (d[t] / e[t], register r: neuron 16 t + 4 q + r) from the input
+  // segments x[u] (register r: feature 4 q + r of segment u)
+  SSS_DEV static void hidden(const float* lds, const mfma_f4 (&x)[U], int lane, mfma_f4 (&d)[4], mfma_f4 (&e)[4]) {
     const int q = lane >> 4;
-    mfma_f4 d[4], e[4];
 #pragma unroll
     for (int tp = 0; tp < 4; tp++) {
       d[tp] = *(const mfma_f4*)(lds + B1 + 16 * tp + 4 * q);
@@ -211,11 +211,19 @@ struct MfmaHead {
         e[tp] = mfma16(ap[128], d[t].z, e[tp]), e[tp] = mfma16(ap[192], d[t].w, e[tp]);
       }
     }
+#pragma unroll
+    for (int tp = 0; tp < 4; tp++) e[tp] = mfma_f4{fast_tanh(e[tp].x), fast_tanh(e[tp].y), fast_tanh(e[tp].z), fast_tanh(e[tp].w)};
+  }
+  // the row's score (on every lane of the row's four): the last Linear has one output - 16 FMAs per lane and a sum over the row's lanes
+  SSS_DEV static float score(const float* lds, const mfma_f4 (&x)[U], const float (&w3)[16], float b3, int lane) {
+    mfma_f4 d[4], e[4];
+    hidden(lds, x, lane, d, e);
+    return reduce(e, w3, b3);
+  }
+  SSS_DEV static float reduce(const mfma_f4 (&e)[4], const float (&w3)[16], float b3) {
     float p = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      p += w3[4 * t] * fast_tanh(e[t].x), p += w3[4 * t + 1] * fast_tanh(e[t].y), p += w3[4 * t + 2] * fast_tanh(e[t].z), p += w3[4 * t + 3] * fast_tanh(e[t].w);
-    }
+    for (int t = 0; t < 4; t++) p += w3[4 * t] * e[t].x, p += w3[4 * t + 1] * e[t].y, p += w3[4 * t + 2] * e[t].z, p += w3[4 * t + 3] * e[t].w;
     p += __shfl_xor(p, 16), p += __shfl_xor(p, 32);
     return p + b3;
   }

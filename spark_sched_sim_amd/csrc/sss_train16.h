@@ -302,6 +302,136 @@ static int mlp_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ---- the two policy heads (IN -> 64 -> 64 -> 1, Tanh) of the update on the matrix cores ---------------------------------
+// Forward: the inference chain (sss_gnn_mfma.h MfmaHead; the input is a dense row here: segment u = columns 16 u .. 16 u + 15)
+// plus 16-byte stores of the two 64-wide activations. Backward: g2 = w3 * dy * (1 - a2^2) on the vector unit (one output),
+// then G1^T = W2^T G2^T and dX^T = W1^T G1^T with the transposed weights as LDS A-operand images, (1 - a1^2) in between.
+template <int IN>
+__global__ __launch_bounds__(256) void sss_mlp_head_mfma_fwd_kernel(SssMlpArgs a) {
+  constexpr int U = (IN + 15) / 16;
+  using H = MfmaHead<U>;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];
+  H::stage(w_lds, a.w, IN, threadIdx.x, 256, [](int u, int f) { return 16 * u + f < IN ? 16 * u + f : -1; });
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float* W3 = a.w + 64 * IN + 64 + 64 * 64 + 64;
+  float w3[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) w3[4 * t + r] = W3[16 * t + 4 * q + r];
+  const float b3 = W3[64];
+  const int64_t n_tiles = (a.rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + j;
+    const bool valid = row < a.rows;
+    mfma_f4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = (valid && 16 * u + 4 * q + r < IN) ? a.x[row * IN + 16 * u + 4 * q + r] : 0.0f;
+      x[u] = mfma_f4{v[0], v[1], v[2], v[3]};
+    }
+    mfma_f4 d[4], e[4];
+    H::hidden(w_lds, x, lane, d, e);
+    const float y = H::reduce(e, w3, b3);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) *(mfma_f4*)(a.a1 + row * 64 + 16 * t + 4 * q) = d[t], *(mfma_f4*)(a.a2 + row * 64 + 16 * t + 4 * q) = e[t];
+      if (q == 0) a.y[row] = y;
+    }
+  }
+}
+
+template <int IN>
+__global__ __launch_bounds__(256) void sss_mlp_head_mfma_bwd_kernel(SssMlpArgs a) {
+  constexpr int U = (IN + 15) / 16;
+  constexpr int T2 = 0, T1 = T2 + 4 * 16 * 64;  // (+ U * 16 * 64 floats of T1: the launch sizes the LDS)
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];
+  {
+    const float* W1 = a.w;
+    const float* W2T = W1 + 64 * IN + 64;  // [n][m] = W2[m][n]
+    for (int t = threadIdx.x; t < 4 * 16 * 64; t += 256) {  // T2[(tp, s)][lane] = W2^T[16 tp + i][16 (s >> 2) + 4 q + (s & 3)]
+      const int lane = t & 63, s = (t >> 6) & 15, tp = t >> 10;
+      w_lds[T2 + t] = W2T[(16 * tp + (lane & 15)) * 64 + 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3)];
+    }
+    for (int t = threadIdx.x; t < U * 16 * 64; t += 256) {  // T1[(u, s)][lane] = W1^T[16 u + i][16 (s >> 2) + 4 q + (s & 3)]
+      const int lane = t & 63, s = (t >> 6) & 15, u = t >> 10;
+      const int c = 16 * u + (lane & 15);
+      w_lds[T1 + t] = c < IN ? W1[(16 * (s >> 2) + 4 * (lane >> 4) + (s & 3)) * IN + c] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float* W3 = a.w + 64 * IN + 64 + 64 * 64 + 64;
+  float w3[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) w3[4 * t + r] = W3[16 * t + 4 * q + r];
+  const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int64_t n_tiles = (a.rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + j;
+    const bool valid = row < a.rows;
+    const float dy = valid ? a.dy[row] : 0.0f;
+    mfma_f4 g2[4], g1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const mfma_f4 a2 = valid ? *(const mfma_f4*)(a.a2 + row * 64 + 16 * t + 4 * q) : zero;
+      g2[t] = mfma_f4{w3[4 * t] * dy * (1.0f - a2.x * a2.x), w3[4 * t + 1] * dy * (1.0f - a2.y * a2.y), w3[4 * t + 2] * dy * (1.0f - a2.z * a2.z),
+                      w3[4 * t + 3] * dy * (1.0f - a2.w * a2.w)};
+      if (valid) *(mfma_f4*)(a.g2 + row * 64 + 16 * t + 4 * q) = g2[t];
+    }
+#pragma unroll
+    for (int tp = 0; tp < 4; tp++) {
+      mfma_f4 acc = zero;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float* ap = w_lds + T2 + ((tp * 16 + 4 * t) * 64) + lane;
+        acc = mfma16(ap[0], g2[t].x, acc), acc = mfma16(ap[64], g2[t].y, acc), acc = mfma16(ap[128], g2[t].z, acc), acc = mfma16(ap[192], g2[t].w, acc);
+      }
+      const mfma_f4 a1 = valid ? *(const mfma_f4*)(a.a1 + row * 64 + 16 * tp + 4 * q) : zero;
+      g1[tp] = mfma_f4{acc.x * (1.0f - a1.x * a1.x), acc.y * (1.0f - a1.y * a1.y), acc.z * (1.0f - a1.z * a1.z), acc.w * (1.0f - a1.w * a1.w)};
+      if (valid) *(mfma_f4*)(a.g1 + row * 64 + 16 * tp + 4 * q) = g1[tp];
+    }
+    if (a.dx) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        mfma_f4 dx = zero;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const float* ap = w_lds + T1 + ((u * 16 + 4 * t) * 64) + lane;
+          dx = mfma16(ap[0], g1[t].x, dx), dx = mfma16(ap[64], g1[t].y, dx), dx = mfma16(ap[128], g1[t].z, dx), dx = mfma16(ap[192], g1[t].w, dx);
+        }
+        if (valid) {
+          float* o = a.dx + row * IN + 16 * u + 4 * q;
+          if (16 * u + 4 * q + 0 < IN) o[0] = dx.x;
+          if (16 * u + 4 * q + 1 < IN) o[1] = dx.y;
+          if (16 * u + 4 * q + 2 < IN) o[2] = dx.z;
+          if (16 * u + 4 * q + 3 < IN) o[3] = dx.w;
+        }
+      }
+    }
+  }
+}
+
+template <int IN>
+static int mlp_head_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
+  if (a.rows <= 0) return 0;
+  constexpr int U = (IN + 15) / 16;
+  const int64_t wgs = (a.rows + 63) / 64;
+  const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);  // (32 KB of LDS images per workgroup, built once and reused over its tiles)
+  if (backward)
+    hipLaunchKernelGGL(sss_mlp_head_mfma_bwd_kernel<IN>, dim3(grid), dim3(256), (size_t)(4 * 16 * 64 + U * 16 * 64) * sizeof(float), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(sss_mlp_head_mfma_fwd_kernel<IN>, dim3(grid), dim3(256), (size_t)MfmaHead<U>::TOTAL * sizeof(float), (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 // the MLP shapes of the published architecture (config/decima_tpch.yaml:66-78); anything else: -1 (the caller keeps autograd)
 static int be_launch_mlp(const SssMlpArgs& a, int backward, void* stream) {
   const bool gnn = a.h1 == 32 && a.h2 == 16 && a.out_dim == 16 && a.act == 0;
@@ -311,6 +441,10 @@ static int be_launch_mlp(const SssMlpArgs& a, int backward, void* stream) {
     if (a.in_dim == GNN_NF) return mlp_mfma_launch<GNN_NF>(a, backward, stream);
     if (a.in_dim == 16) return mlp_mfma_launch<16>(a, backward, stream);
     if (a.in_dim == GNN_NF + 16) return mlp_mfma_launch<GNN_NF + 16>(a, backward, stream);
+  }
+  if (head && !lanes16) {
+    if (a.in_dim == GNN_NF + 48) return mlp_head_mfma_launch<GNN_NF + 48>(a, backward, stream);
+    if (a.in_dim == GNN_DF + 33) return mlp_head_mfma_launch<GNN_DF + 33>(a, backward, stream);
   }
   if (gnn && a.in_dim == GNN_NF) return mlp16_launch<GNN_NF, 32, 16, 16, 0>(a, backward, stream);
   if (gnn && a.in_dim == 16) return mlp16_launch<16, 32, 16, 16, 0>(a, backward, stream);

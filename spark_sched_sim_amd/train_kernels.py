@@ -168,11 +168,11 @@ class KernelMLP(nn.Sequential):
     """Linear - act - Linear - act - Linear with the reference's module numbering; large float32 minibatches on the GPU go
     through the fused forward / backward kernels when the shape is one of the architecture's (`sss_mlp_supported`)"""
 
-    # The two policy heads (53 / 36 -> 64 -> 64 -> 1, Tanh) have kernels too (tested), but 64-wide layers on sixteen
-    # lanes per row are LDS-bound (every FMA reads its own weight word): 600 k rows forward + backward 2.50 / 1.54 ms
-    # against 1.46 / 1.28 ms for the three library GEMMs with the MFMA weight-gradient kernel - they keep the layer
-    # path. The GNN's 32 / 16-wide MLPs: 1.10 - 1.32 ms against 2.07 - 2.33 ms at 2.5 M rows (tools/debug/mlp_time.py).
-    FUSE_WIDE = False
+    # The two policy heads (53 / 36 -> 64 -> 64 -> 1, Tanh) go through the kernels as well since they run on the matrix cores
+    # (csrc/sss_train16.h sss_mlp_head_mfma_*: 600 k rows forward + backward 0.77 / 0.65 ms against 1.46 / 1.28 ms for the three
+    # library GEMMs with the MFMA weight-gradient kernel; their 16-lanes-per-row form was LDS-bound and slower, 2.50 / 1.54 ms).
+    # The GNN's 32 / 16-wide MLPs: 2.5 M rows forward + backward ~0.9 ms against 2.1 - 2.3 ms (tools/debug/mlp_time.py).
+    FUSE_WIDE = True
 
     def _fused_spec(self):
         spec = getattr(self, "_spec", None)

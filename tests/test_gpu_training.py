@@ -128,9 +128,8 @@ def test_mlp_kernels_match_autograd():
             ref.zero_grad()
             again = mlp_backward(dy, a1, a2, packed, dims, act, slope)
             assert torch.equal(again[0], g1) and torch.equal(again[1], g2) and torch.equal(again[2], dx)
-        # through autograd: the module against the same layers evaluated one by one (the wide heads stay on the layer path
-        # in production, KernelMLP.FUSE_WIDE: switched on here so that their kernels are the ones compared)
-        mlp.FUSE_WIDE, mlp._spec = True, None
+        # through autograd: the module against the same layers evaluated one by one
+        assert mlp._fused_spec()
         x = torch.randn((20000, dims[0]), device=dev, requires_grad=True)
         x2 = x.detach().clone().requires_grad_(True)
         w = torch.randn((20000, dims[3]), device=dev)

@@ -2,6 +2,10 @@ import os.path as osp, sys
 sys.path.insert(0, osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__)))))
 import torch, time
 from spark_sched_sim_amd.decima import make_mlp
+from spark_sched_sim_amd.train_kernels import KernelMLP
+import os
+if os.environ.get("FUSE_WIDE"):
+    KernelMLP.FUSE_WIDE = True
 dev=torch.device("cuda:0")
 for dims, act_cls, kw in (((5,32,16,16),"LeakyReLU",dict(negative_slope=0.2)), ((16,32,16,16),"LeakyReLU",dict(negative_slope=0.2)), ((21,32,16,16),"LeakyReLU",dict(negative_slope=0.2)), ((53,64,64,1),"Tanh",{}), ((36,64,64,1),"Tanh",{})):
     mlp = make_mlp(dims[0],[dims[1],dims[2]],dims[3],act_cls,kw).to(dev)
