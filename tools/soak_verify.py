@@ -28,6 +28,7 @@ def bits(x):
 
 
 def main():
+    stride = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # every stride-th env is replayed on the oracle (usage: soak_verify.py [stride])
     pack = workload.default_pack()
     B, base = 4096, 777
     for name, cfg, policy, pid, steps in CASES:
@@ -42,7 +43,7 @@ def main():
         wl = env.header_field("last_ep_wall").cpu().numpy()
         err = env.obs_i32[:, 7].cpu().numpy()
         bad, checked = 0, 0
-        for i in list(range(0, B, 64)):
+        for i in list(range(0, B, stride)):
             if ep[i] == 0 or err[i]:
                 continue
             k = int(ep[i]) - 1
