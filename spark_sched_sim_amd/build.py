@@ -25,9 +25,12 @@ def sources() -> list[str]:
 
 
 OUT = osp.join(CSRC, "libsss_hip.so")
+# translation units: the C ABI + every kernel for up to 64 executors, and the wide instantiation of the simulator kernels
+# (65..128 executors: the same sss_sim.h with -DSSS_WIDE, csrc/sss_wide.h)
+UNITS = ["sss_hip.hip", "sss_hip_wide.hip"]
 
 # -ffp-contract=off: f64 event times / rewards must round exactly as the reference's do (no FMA fusion)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function", "-I", CSRC]
 
 
@@ -38,20 +41,36 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build the HIP extension)")
 
 
-def needs_build() -> bool:
-    if not osp.exists(OUT):
+def needs_build(out: str = OUT) -> bool:
+    if not osp.exists(out):
         return True
-    t = osp.getmtime(OUT)
+    t = osp.getmtime(out)
     return any(osp.getmtime(s) > t for s in sources())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        cmd = [hipcc()] + FLAGS + ["-o", OUT, osp.join(CSRC, "sss_hip.hip")]
+def build(force: bool = False, verbose: bool = False, out: str = OUT, extra_flags: tuple[str, ...] = ()) -> str:
+    """compiles the translation units side by side, links them into `out`. `extra_flags`: test builds only (tests/gpu_variant.py)"""
+    if force or needs_build(out):
+        from concurrent.futures import ThreadPoolExecutor
+        objdir = osp.join(osp.dirname(out), "build", osp.splitext(osp.basename(out))[0])
+        os.makedirs(objdir, exist_ok=True)
+        cc = hipcc()
+
+        def compile_unit(unit: str) -> str:
+            obj = osp.join(objdir, osp.splitext(unit)[0] + ".o")
+            cmd = [cc] + FLAGS + list(extra_flags) + ["-c", "-o", obj, osp.join(CSRC, unit)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            return obj
+
+        with ThreadPoolExecutor(len(UNITS)) as pool:
+            objs = list(pool.map(compile_unit, UNITS))
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -54,8 +54,10 @@ struct SssCollectArgs {
 
 #define SSS_COLLECT_SKIP_ENV (-2147483647 - 1)  // include/sss.h SSS_SKIP_ENV
 
-template <typename OrFn>
-SSS_DEV void collect_env(const SssCollectArgs& a, int phase, int b, OrFn flag_or) {
+// flag_or(i, v): flags[i] |= v; flag_max(i, v): flags[i] = max(flags[i], v) - slot 3 names ONE failed env (the one with
+// the largest index when several fail in the same step), so it takes a maximum, not an OR of indices
+template <typename OrFn, typename MaxFn>
+SSS_DEV void collect_env(const SssCollectArgs& a, int phase, int b, OrFn flag_or, MaxFn flag_max) {
   const bool member = a.in_group == nullptr || a.in_group[b] != 0;
   if (phase == 0) {
     a.stage_idx[b] = (member && a.active[b]) ? (int32_t)a.stage_sel[b] : SSS_COLLECT_SKIP_ENV;
@@ -73,7 +75,7 @@ SSS_DEV void collect_env(const SssCollectArgs& a, int phase, int b, OrFn flag_or
   const bool done = (terminated || truncated) && was_active && !bad;
   // an env that failed sits out the rest of this collection; its failing step is not recorded (training.py, "truncate")
   const bool act = was_active && !bad;
-  if (bad) a.pending_reset[b] = 1, flag_or(0, 1), flag_or(3, b + 1);
+  if (bad) a.pending_reset[b] = 1, flag_or(0, 1), flag_max(3, b + 1);
   if (done) flag_or(1, 1);
   const double wall = a.wall[b];
   double new_wall = act ? wall_time : wall;

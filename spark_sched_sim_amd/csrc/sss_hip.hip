@@ -147,7 +147,7 @@ static int be_launch_wgrad(const SssWgradArgs& a, void* stream) {
 
 __global__ __launch_bounds__(256) void sss_collect_kernel(SssCollectArgs a, int phase) {
   const int b = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (b < a.num_envs) collect_env(a, phase, b, [&](int i, int v) { atomicOr(a.flags + i, v); });
+  if (b < a.num_envs) collect_env(a, phase, b, [&](int i, int v) { atomicOr(a.flags + i, v); }, [&](int i, int v) { atomicMax(a.flags + i, v); });
 }
 static int be_launch_collect(const SssCollectArgs& a, int phase, void* stream) {
   hipLaunchKernelGGL(sss_collect_kernel, dim3((unsigned)((a.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, phase);
@@ -176,46 +176,37 @@ static int gnn_launch_kind(const SssGnnArgs& a, void* stream) {
   hipLaunchKernelGGL(sss_gnn_kernel<KIND>, dim3((unsigned)((a.n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
+// Which formulation a GNN launch takes is fixed when the library is compiled. The product build runs every MLP of the pass on
+// the matrix cores (sss_gnn_mfma.h); a TEST build with -DSSS_TEST_VECTOR_FORMS (tests/gpu_variant.py -> tests/_build/) takes the
+// vector-unit kernels of sss_gnn.h / sss_gnn16.h / sss_train16.h instead, so that the two can be compared on the same inputs.
+#ifdef SSS_TEST_VECTOR_FORMS
+static constexpr bool kVectorForms = true;
+#else
+static constexpr bool kVectorForms = false;
+#endif
 static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
   switch (kind) {
     // a DAG layer's receiving nodes: few rows per launch and the longest chain (message MLP per edge + update MLP),
-    // nine launches back to back per step: 16 lanes per row (sss_gnn16.h; 41 -> 25 us per launch at 4096 envs)
-    // (since round 3 on the matrix cores, sss_gnn_mfma.h: 16 rows per wave, the three Linears of an MLP chained in registers;
-    //  SSS_GNN_LAYER16=1 in the environment selects the 16-lane form for comparisons)
-    case GNN_LAYER: {
-      static const bool lanes16 = getenv("SSS_GNN_LAYER16") != nullptr;
-      return lanes16 ? gnn16_launch<GNN_LAYER>(a, stream) : gnn_layer_mfma_launch(a, stream);
-    }
-    // The two policy heads (53-64-64-1 / 36-64-64-1, 128 tanh per row): with few rows the chain of one row is the
-    // bound and 16 lanes per row win (1024 envs: 45 -> 22 us / 41 -> 29 us); with many rows the launch is
+    // nine launches back to back per step: 16 rows per wave on the matrix cores, the three Linears of an MLP chained in
+    // registers (sss_gnn_mfma.h; round 2's 16-lanes-per-row form, sss_gnn16.h: 41 -> 25 us per launch at 4096 envs)
+    case GNN_LAYER: return kVectorForms ? gnn16_launch<GNN_LAYER>(a, stream) : gnn_layer_mfma_launch(a, stream);
+    // The two policy heads (53-64-64-1 / 36-64-64-1, 128 tanh per row). Vector forms: with few rows the chain of one row is
+    // the bound and 16 lanes per row win (1024 envs: 45 -> 22 us / 41 -> 29 us); with many rows the launch is
     // throughput-bound and one thread per row, where 64 rows share every weight read, wins (4096 envs: 52 / 42 us
     // against 59 / 69 us). STAGE's n_rows counts all nodes (its list is padded; ~1 in 22 is schedulable).
     // (a.layer != 0: the list holds exactly the schedulable nodes, sss_decima_graph_build's sched_list)
-    case GNN_STAGE: {
-      static const bool no_mfma = getenv("SSS_GNN_HEADS_VALU") != nullptr;  // (comparisons: the two vector-unit forms)
-      if (!no_mfma) return gnn_head_mfma_launch<GNN_STAGE>(a, stream);
+    case GNN_STAGE:
+      if (!kVectorForms) return gnn_head_mfma_launch<GNN_STAGE>(a, stream);
       return (a.w16 && a.n_rows <= (a.layer ? 24000 : 22 * 24000)) ? gnn16_launch<GNN_STAGE>(a, stream) : gnn_launch_kind<GNN_STAGE>(a, stream);
-    }
-    case GNN_EXEC: {
-      static const bool no_mfma = getenv("SSS_GNN_HEADS_VALU") != nullptr;
-      if (!no_mfma) return gnn_head_mfma_launch<GNN_EXEC>(a, stream);
+    case GNN_EXEC:
+      if (!kVectorForms) return gnn_head_mfma_launch<GNN_EXEC>(a, stream);
       return (a.w16 && a.n_rows <= 24000) ? gnn16_launch<GNN_EXEC>(a, stream) : gnn_launch_kind<GNN_EXEC>(a, stream);
-    }
-    // node rows (a million per launch at 4096 envs): on the matrix cores as well (sss_gnn_mfma.h; SSS_GNN_ROWS_VALU=1 selects
-    // the one-thread-per-row form of sss_gnn.h for comparisons). A PREP launch without the fused SINK keeps that form.
-    case GNN_PREP: {
-      static const bool valu = getenv("SSS_GNN_ROWS_VALU") != nullptr;
-      return (!valu && a.w2 && a.h) ? gnn_rows_mfma_launch<GNN_PREP>(a, stream) : gnn_launch_kind<GNN_PREP>(a, stream);
-    }
+    // node rows (a million per launch at 4096 envs): on the matrix cores as well. A PREP launch without the fused SINK keeps
+    // the one-thread-per-row form of sss_gnn.h.
+    case GNN_PREP: return (!kVectorForms && a.w2 && a.h) ? gnn_rows_mfma_launch<GNN_PREP>(a, stream) : gnn_launch_kind<GNN_PREP>(a, stream);
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
-    case GNN_DAGHID: {
-      static const bool valu = getenv("SSS_GNN_ROWS_VALU") != nullptr;
-      return valu ? gnn_launch_kind<GNN_DAGHID>(a, stream) : gnn_rows_mfma_launch<GNN_DAGHID>(a, stream);
-    }
-    case GNN_GLOBHID: {
-      static const bool valu = getenv("SSS_GNN_ROWS_VALU") != nullptr;
-      return valu ? gnn_launch_kind<GNN_GLOBHID>(a, stream) : gnn_rows_mfma_launch<GNN_GLOBHID>(a, stream);
-    }
+    case GNN_DAGHID: return kVectorForms ? gnn_launch_kind<GNN_DAGHID>(a, stream) : gnn_rows_mfma_launch<GNN_DAGHID>(a, stream);
+    case GNN_GLOBHID: return kVectorForms ? gnn_launch_kind<GNN_GLOBHID>(a, stream) : gnn_rows_mfma_launch<GNN_GLOBHID>(a, stream);
     // copies and range sums: one thread per row (sss_gnn.h)
     case GNN_COMMIT: return gnn_launch_kind<GNN_COMMIT>(a, stream);
     case GNN_MERGE: return gnn_launch_kind<GNN_MERGE>(a, stream);

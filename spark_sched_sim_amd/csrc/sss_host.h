@@ -14,6 +14,11 @@
 #include "../../include/sss.h"
 #include "sss_layout.h"
 #include "sss_train.h"
+#include "sss_wide.h"
+
+// envs with more than 64 executors run on the wide instantiation of the kernels (sss_wide.h)
+static bool sss_is_wide(int num_executors) { return num_executors > 64; }
+static int sss_hot_bytes(int num_executors) { return sss_is_wide(num_executors) ? sss_wide_hot_bytes() : (int)sizeof(SssHot); }
 
 static thread_local std::string g_sss_err;
 static int sss_fail(int code, const std::string& msg) {
@@ -69,7 +74,7 @@ static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes,
   if (!cfg) return sss_fail(-1, "cfg is NULL");
   if (sss_pack_parse((const uint8_t*)pack, pack_bytes, ph)) return sss_fail(-2, "workload pack is malformed (expected SSSPACK2, 154 templates, <= 64 stages/job, <= 255 edges/job)");
   if (num_envs < 1) return sss_fail(-3, "num_envs must be >= 1");
-  if (cfg->num_executors < 1 || cfg->num_executors > SSS_MAX_EXEC) return sss_fail(-4, "num_executors must be in [1, 64] (one lane per executor)");
+  if (cfg->num_executors < 1 || cfg->num_executors > SSS_MAX_EXEC_ANY) return sss_fail(-4, "num_executors must be in [1, 128]");
   int cap = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0;
   int jc = cfg->max_jobs > 0 ? cfg->max_jobs : cap;
   if (jc <= 0) return sss_fail(-5, "max_jobs is required when job_arrival_cap is None");
@@ -97,15 +102,17 @@ static std::vector<int32_t> sss_build_eff(const uint8_t* pack, const SssPackHost
   const int32_t* desc = (const int32_t*)(pack + ph.sec_off[10]);
   const int32_t* durations = (const int32_t*)(pack + ph.sec_off[11]);
   int warm_floor = warmup_delay > 0 ? (warmup_delay < 1e9 ? (int)floor(warmup_delay) : 1000000000) : 0;
-  std::vector<int32_t> eff((size_t)ph.total_stages * 8 * 3 * 4, 0);
+  // rows 0 .. 8 * total_stages - 1: the eight executor levels; the tail (SssPackDev::eff0): "level" 8 = a key that is in no
+  // first_wave dict - num_local_executors == exec_cap > 100 yields key 0 (tpch.py:244, 258-260) - hence always the largest level
+  std::vector<int32_t> eff((size_t)ph.total_stages * 9 * 3 * 4, 0);
   for (int gs = 0; gs < ph.total_stages; gs++)
-    for (int i = 0; i < 8; i++) {
-      int lvl = lvl_of[i];
+    for (int i = 0; i < 9; i++) {
+      int lvl = i < 8 ? lvl_of[i] : -1;
       if (lvl < 0 || !((keymask[gs] >> lvl) & 1)) lvl = maxlvl[gs];
       auto d = [&](int wave, int k) { return desc[((gs * 3 + wave) * ph.L + lvl) * 2 + k]; };
       static const int chain[3][3] = {{0, 1, -1}, {2, 1, 0}, {1, 0, -1}};
       for (int mode = 0; mode < 3; mode++) {
-        int32_t* out = &eff[(((size_t)gs * 8 + i) * 3 + mode) * 4];
+        int32_t* out = i < 8 ? &eff[(((size_t)gs * 8 + i) * 3 + mode) * 4] : &eff[(size_t)ph.total_stages * 8 * 3 * 4 + ((size_t)gs * 3 + mode) * 4];
         for (int k = 0; k < 3; k++) {
           int wave = chain[mode][k];
           if (wave < 0) break;
@@ -151,7 +158,7 @@ extern "C" int sss_query_dims(const sss_cfg* cfg, const void* pack, size_t pack_
   if (int rc = sss_validate(cfg, pack, pack_bytes, num_envs, &ph, &J_cap)) return rc;
   if (!out) return sss_fail(-1, "out is NULL");
   SssLayout L;
-  sss_compute_layout(&L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job);
+  sss_compute_layout(&L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job, sss_hot_bytes(cfg->num_executors));
   sss_fill_dims(L, out);
   return 0;
 }
@@ -263,7 +270,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   if (int rc = be_set_device(device)) return sss_fail(-10, "cannot select device " + std::to_string(device) + ": " + be_error(rc));
   sss_handle* h = new sss_handle();
   h->cfg = *cfg, h->ph = ph, h->device = device, h->bound = false;
-  sss_compute_layout(&h->L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job);
+  sss_compute_layout(&h->L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job, sss_hot_bytes(cfg->num_executors));
   memset(&h->B, 0, sizeof(h->B));
 
   // pack + ziggurat tables -> device
@@ -314,7 +321,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
       if (levels[l] == exec_levels[i]) P.lvl_of[i] = (int8_t)l;
   }
   P.max_edges = ph.max_edges_per_job;
-  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, h->L.E, SSS_STATIC_LDS_BYTES)) {
+  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, h->L.E, sss_is_wide(h->L.E) ? sss_wide_static_lds_bytes() : SSS_STATIC_LDS_BYTES)) {
     sss_destroy(h);
     return sss_fail(-12, "LDS working set does not fit");
   }
@@ -346,6 +353,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
     return sss_fail(-11, "device allocation failed");
   }
   pk.eff = (const int32_t*)h->eff_dev;
+  pk.eff0 = pk.eff + (size_t)ph.total_stages * 8 * 3 * 4;
   pk.pcg_jump = (const uint64_t*)h->jump_dev;
   pk.lvl_thr = (const uint64_t*)h->jump_dev + jump_words;
   pk.common_pool = (const uint8_t*)h->common_dev;
@@ -376,7 +384,9 @@ extern "C" int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double*
   if (!h || !seeds_dev) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
   BeDeviceGuard guard(h->device);
-  if (int rc = be_launch_reset(sss_args(h), h->L.num_envs, seeds_dev, time_limits_dev, mask_dev, stream)) return sss_fail(-30, std::string("reset launch failed: ") + be_error(rc));
+  const SssKernelArgs ka = sss_args(h);
+  if (int rc = sss_is_wide(h->L.E) ? sss_wide_launch_reset(ka, h->L.num_envs, seeds_dev, time_limits_dev, mask_dev, stream)
+                                   : be_launch_reset(ka, h->L.num_envs, seeds_dev, time_limits_dev, mask_dev, stream)) return sss_fail(-30, std::string("reset launch failed: ") + be_error(rc));
   return 0;
 }
 
@@ -384,7 +394,9 @@ extern "C" int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32
   if (!h || !stage_idx_dev || !num_exec_dev) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
   BeDeviceGuard guard(h->device);
-  if (int rc = be_launch_step(sss_args(h), h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("step launch failed: ") + be_error(rc));
+  const SssKernelArgs ka = sss_args(h);
+  if (int rc = sss_is_wide(h->L.E) ? sss_wide_launch_step(ka, h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, stream)
+                                   : be_launch_step(ka, h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("step launch failed: ") + be_error(rc));
   return 0;
 }
 
@@ -393,7 +405,9 @@ extern "C" int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_i
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
   BeDeviceGuard guard(h->device);
   if (policy < 0 || policy > 2) return sss_fail(-23, "unknown policy");
-  if (int rc = be_launch_policy(sss_args(h), h->L.num_envs, policy, param, stage_idx_dev, num_exec_dev, stream)) return sss_fail(-30, std::string("policy launch failed: ") + be_error(rc));
+  const SssKernelArgs ka = sss_args(h);
+  if (int rc = sss_is_wide(h->L.E) ? sss_wide_launch_policy(ka, h->L.num_envs, policy, param, stage_idx_dev, num_exec_dev, stream)
+                                   : be_launch_policy(ka, h->L.num_envs, policy, param, stage_idx_dev, num_exec_dev, stream)) return sss_fail(-30, std::string("policy launch failed: ") + be_error(rc));
   return 0;
 }
 
@@ -403,7 +417,9 @@ extern "C" int sss_rollout(sss_handle* h, int policy, int param, int n_steps, in
   BeDeviceGuard guard(h->device);
   if (policy < 0 || policy > 2) return sss_fail(-23, "unknown policy");
   if (n_steps < 0) return sss_fail(-24, "n_steps must be >= 0");
-  if (int rc = be_launch_rollout(sss_args(h), h->L.num_envs, policy, param, n_steps, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("rollout launch failed: ") + be_error(rc));
+  const SssKernelArgs ka = sss_args(h);
+  if (int rc = sss_is_wide(h->L.E) ? sss_wide_launch_rollout(ka, h->L.num_envs, policy, param, n_steps, auto_reset, seed_stride, stream)
+                                   : be_launch_rollout(ka, h->L.num_envs, policy, param, n_steps, auto_reset, seed_stride, stream)) return sss_fail(-30, std::string("rollout launch failed: ") + be_error(rc));
   return 0;
 }
 

@@ -10,15 +10,36 @@
 #pragma once
 #include <stdint.h>
 
-#define SSS_MAX_EXEC 64       // one lane per executor
+// One lane per executor up to 64 executors: event slots, batch ranking, fast runs, executor-pool set images in registers.
+// 65..128 executors (the reference takes any num_executors, spark_sched_sim.py:37; its level table reaches 100,
+// tpch.py:237-262) run on a second instantiation of the same source compiled with -DSSS_WIDE (csrc/sss_hip_wide.hip):
+// two executors per lane in the queue's pop and the staging loops, every event through the one-at-a-time handlers.
+#ifdef SSS_WIDE
+#define SSS_MAX_EXEC 128
+#else
+#define SSS_MAX_EXEC 64
+#endif
+#define SSS_MAX_EXEC_ANY 128  // what the host accepts (it picks the instantiation by num_executors)
 #define SSS_MAX_STAGES 64     // stage bit masks are 64 bits
 #define SSS_MAX_JOBS 1024     // job ids are 16 bit; job-id set scratch lives in LDS (sss_sim.h)
 #define SSS_JOBSET_SLOTS 2048  // CPython table for <= 1228 distinct small ints
 #define SSS_MAX_LEVELS 16
-#define SSS_SET_TABLE 256     // bytes of a set image holding <= 63 small ints at any resize (CPython grows to > 4 * used)
+// bytes of a scratch set image built from scratch (no dummies) or by set.copy(): <= 63 small ints at any resize fit 256 slots
+// (CPython grows to > 4 * used, copies to > 2 * used); 128 ints: 512 slots
+#ifdef SSS_WIDE
+#define SSS_SET_TABLE 512
+#else
+#define SSS_SET_TABLE 256
+#endif
 // bytes per executor-pool image: a pool that holds all 64 executors when its fill (keys + dummies)
-// crosses 3/5 of a 128-slot table is rebuilt into 512 slots (set_table_resize(used * 4 = 256))
-#define sss_pool_table_bytes(E) ((E) >= 64 ? 2 * SSS_SET_TABLE : SSS_SET_TABLE)
+// crosses 3/5 of a 128-slot table is rebuilt into 512 slots (set_table_resize(used * 4 = 256)); one that holds
+// 128 when a 512-slot table fills up goes to 1024 (used * 4 = 512)
+#define sss_pool_table_bytes_any(E) ((E) >= 128 ? 1024 : ((E) >= 64 ? 512 : 256))  // host: layout of either instantiation
+#ifdef SSS_WIDE
+#define sss_pool_table_bytes(E) ((E) >= 128 ? 1024 : 512)  // device, 65..128 executors
+#else
+#define sss_pool_table_bytes(E) ((E) >= 64 ? 512 : 256)    // device, <= 64 executors
+#endif
 #define SSS_DUR_RING 200      // deque(maxlen=200), reference spark_sched_sim.py:83
 #define SSS_OBS_I32 8
 #define SSS_OBS_F64 2
@@ -179,6 +200,7 @@ struct SssPackDev {
   const uint64_t* zig_ke;
   const double *zig_we, *zig_fe;
   const int32_t* eff;  // [total_stages][8 executor levels][3 modes][4] = (offset, len | warmup << 30, min duration of the list, 0)
+  const int32_t* eff0; // [total_stages][3 modes][4]: the same for an executor key that is in no first_wave dict (always the stage's largest level)
   const uint8_t* common_pool;  // the common pool right after reset, set(range(E)): its 16-byte record, then (tables beyond 8 slots) the table
   const uint64_t* pcg_jump;  // [129][4]: PCG64 jump-ahead by k = -64..64 steps: state' = A * state + C * inc, rows (A_hi, A_lo, C_hi, C_lo)
   // [101], by the job's executor count n: the executor-level draw of TPCH:222-229 picks the upper level exactly when the raw
@@ -231,7 +253,7 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   P->off_slot_ref = o, o += 64;
   o = (o + 1) & ~1;
   P->off_slot_job = o, o += 2 * 64;
-  P->off_keys = o, o += 2 * (J_cap + 8);
+  P->off_keys = o, o += 2 * ((J_cap > E ? J_cap : E) + 8);  // live keys of a set being rebuilt: job ids or executor ids
   o = (o + 15) & ~15;  // the set image is cleared and counted 16 bytes at a time
   P->off_jobset = o, o += 2 * jobset;
   o = (o + 15) & ~15;
@@ -247,7 +269,7 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
 #ifndef SSS_FALLBACK_SLOTS
 #define SSS_FALLBACK_SLOTS 10
 #endif
-  if (n < 8) n = SSS_FALLBACK_SLOTS;
+  if (n < 8) n = E > 64 ? 24 : SSS_FALLBACK_SLOTS;  // (more than 64 executors: more jobs with pending events, occupancy is gone anyway)
   if (n > 64) n = 64;
   if (n > J_cap) n = J_cap;
   P->n_slots = n, P->jobset_slots = jobset;
@@ -258,7 +280,8 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   return P->pool_bytes + static_bytes <= 65536 ? 0 : -1;
 }
 
-static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_cap, int SP, int n_levels, int max_edges_per_job) {
+// hot_bytes: sizeof(SssHot) of the instantiation that will run the env (its arrays have SSS_MAX_EXEC entries)
+static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_cap, int SP, int n_levels, int max_edges_per_job, int hot_bytes) {
   SP = (SP + 1) & ~1;  // even stride: a job's stage row (8 B records) stays 16-byte aligned
   L->num_envs = num_envs, L->E = E, L->J_cap = J_cap, L->SP = SP, L->L = n_levels;
   L->n_pools = 1 + J_cap + J_cap * SP;
@@ -266,7 +289,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->max_edges_per_job = max_edges_per_job;
   L->ed_cap = J_cap * max_edges_per_job;
   L->pad_ = 0;
-  int64_t o = (int64_t)sizeof(SssHot);
+  int64_t o = (int64_t)hot_bytes;
   L->off_active = o, o = sss_align(o + 2 * (int64_t)J_cap, 64);
   L->off_jobs = o, o += (int64_t)sizeof(SssJob) * J_cap;
   L->off_t_arrival = o, o += 8 * (int64_t)J_cap;
@@ -274,7 +297,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->off_stages = o, o = sss_align(o + 8 * (int64_t)J_cap * SP, 64);
   L->off_durations = o, o = sss_align(o + 4 * (int64_t)J_cap * SP, 64);
   L->off_pool_hdr = o, o = sss_align(o + (int64_t)sizeof(SssPoolHdr) * L->n_pools, 64);
-  L->off_pool_tab = o, o += (int64_t)sss_pool_table_bytes(E) * L->n_pools;
+  L->off_pool_tab = o, o += (int64_t)sss_pool_table_bytes_any(E) * L->n_pools;
   L->off_dur_ring = o, o += 8 * SSS_DUR_RING;
   L->off_old_active = o, o += 2 * (int64_t)J_cap;
   L->env_stride = sss_align(o, 256);

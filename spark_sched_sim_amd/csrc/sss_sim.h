@@ -20,6 +20,19 @@
 // No oracle code is used here: this is an independent implementation on different data
 // structures (bit masks, flat slot arrays, fixed-capacity set images); tests compare the two.
 #pragma once
+// -DSSS_WIDE: the instantiation for 65..128 executors (csrc/sss_hip_wide.hip, tests/emu/emu_wide.cpp). Two executors per lane
+// where lanes stand for executors outside the event chain (the queue's pop, staging at launch boundaries, episode
+// initialisation); the lane-parallel event machinery - fast runs, event batches, chunked fulfilment, all written for one lane per
+// executor - is compiled out (SSS_NO_BATCH): every event goes through the one-at-a-time handlers, which are the reference's
+// control flow restated and do not care how many executors there are. Same results, by the same parity tests; slower per event.
+#if defined(SSS_WIDE) && !defined(SSS_NO_BATCH)
+#define SSS_NO_BATCH 1
+#endif
+#ifdef SSS_WIDE
+#define SSS_KNAME(name) name##_wide
+#else
+#define SSS_KNAME(name) name
+#endif
 #include "../../include/sss.h"
 #include "sss_layout.h"
 #include <wave_rt.h>  // csrc/wave_rt.h (gfx950) or tests/emu/wave_rt.h (CPU emulator), chosen by -I order
@@ -64,6 +77,9 @@ struct alignas(16) SssScratch {
   uint64_t free_slots;            // bit k set <=> cache slot k is free
   double wall_old;
   uint32_t fc_dst[SSS_MAX_EXEC];  // snapshot of the source's commitments (fulfill_commitments_from_source)
+#ifdef SSS_WIDE
+  uint32_t fc_seq[SSS_MAX_EXEC];  // their insertion numbers while the snapshot is sorted (fulfil_order_commitments)
+#endif
   int16_t fc_num[SSS_MAX_EXEC];
   // the executors that fulfil them, in the order the reference pops them (fulfil_build_list): executor,
   // index of its commitment in the snapshot, and what became of it in a lane-parallel chunk
@@ -231,6 +247,20 @@ SSS_DEV int pool_index(uint32_t k) {
   return 1 + g_c.J_cap + j * g_c.SP + s;
 }
 SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
+
+// job.local_executors (JOB:81-89) is only ever counted (TPCH:217, the executor-level key). Up to 64 executors it is kept as a
+// bit mask (the event batches update it with lane masks); the wide instantiation keeps the count itself in the same field.
+#ifdef SSS_WIDE
+SSS_DEV int local_count(uint64_t m) { return (int)m; }
+SSS_DEV uint64_t local_with(uint64_t m, int) { return m + 1; }
+SSS_DEV uint64_t local_without(uint64_t m, int) { return m - 1; }
+SSS_DEV bool local_has(uint64_t m, int) { return m != 0; }
+#else
+SSS_DEV int local_count(uint64_t m) { return popc64(m); }
+SSS_DEV uint64_t local_with(uint64_t m, int e) { return m | bit64(e); }
+SSS_DEV uint64_t local_without(uint64_t m, int e) { return m & ~bit64(e); }
+SSS_DEV bool local_has(uint64_t m, int e) { return (m & bit64(e)) != 0; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // numpy Generator(PCG64) stream (lane 0). Restates numpy/random: SeedSequence, pcg64 XSL-RR,
@@ -720,7 +750,9 @@ SSS_DEV SetImg<uint8_t> pool_stage_in(uint32_t key) {
   const int lane = wave_lane();
   const uint4 rec = *(const uint4*)(g_c.pool_hdr + pool_index(key));
   const uint32_t bytes = sss_pool_table_bytes(g_c.E);
+#ifndef SSS_WIDE  // (staged images belong to the event batches: not part of the wide instantiation)
   static_assert(2 * SSS_SET_TABLE <= 64 * 8, "one 8-byte access per lane moves a whole table");
+#endif
   if ((uint32_t)lane * 8 < bytes) ((uint2*)g_sc.setA)[lane] = ((const uint2*)pool_table_hbm(key))[lane];
   SetImg<uint8_t> s;
   s.mask = rec.x & 0xFFFFu, s.fill = rec.x >> 16, s.used = rec.y & 0xFFFFu, s.finger = 0, s.aux = rec.y >> 16;
@@ -1059,13 +1091,14 @@ SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  /
 
 SSS_DEV void job_attach_executor(int j, int e) {  // JOB:81-84
   CHECK(g_hot.ex_task_stage[e] < 0);
-  jobp(j)->local_mask |= bit64(e);
+  SssJob* jp = jobp(j);
+  jp->local_mask = local_with(jp->local_mask, e);
   g_hot.ex_job[e] = (int16_t)j;
 }
 SSS_DEV void job_detach_executor(int j, int e) {  // JOB:86-89
   SssJob* jp = jobp(j);
-  CHECK(jp->local_mask & bit64(e));
-  jp->local_mask &= ~bit64(e);
+  CHECK(local_has(jp->local_mask, e));
+  jp->local_mask = local_without(jp->local_mask, e);
   g_hot.ex_job[e] = -1;
   g_hot.ex_task_stage[e] = -1;
 }
@@ -1111,6 +1144,18 @@ SSS_DEV void executor_interval(int n, int& li, int& ri) {
   // index of the first level >= n (levels above 80 only matter for n > 80)
   ri = (n > 5) + (n > 10) + (n > 20) + (n > 40) + (n > 50) + (n > 60) + (n > 80);
   li = (n <= 5 || n == exec_level_value(ri)) ? ri : ri - 1;
+#ifdef SSS_WIDE
+  // exec_cap > 100 (TPCH:258-260): rows 101 .. exec_cap - 1 are (100, 100); row exec_cap itself keeps np.zeros' (0, 0), and
+  // key 0 is in no first_wave dict, so the stage's largest level is taken (TPCH:231-233): "level" 8, served by SssPackDev::eff0
+  if (n > 100) li = ri = (n == g_c.E ? 8 : 7);
+#endif
+}
+// the resolved duration list of (pack stage, executor level index, executor mode): sss_host.h sss_build_eff
+SSS_DEV const int32_t* eff_row(const int32_t* eff, int gs, int li, int mode) {
+#ifdef SSS_WIDE
+  if (li == 8) return g_c.pk.eff0 + ((size_t)gs * 3 + mode) * 4;
+#endif
+  return eff + (((size_t)gs * 8 + li) * 3 + mode) * 4;
 }
 
 // TPCH:75-106, 216-235. Which list is sampled is a pure function of (stage, executor level, executor
@@ -1121,7 +1166,7 @@ SSS_DEV void executor_interval(int n, int& li, int& ri) {
 SSS_DEV double task_duration(const SssJob* job, int s, int e) {
   PROF3(5);
   int gs = job->gs_base + s;
-  int n_local = popc64(job->local_mask);
+  int n_local = local_count(job->local_mask);
   CHECK(n_local > 0 && n_local <= g_c.E);
   if (n_local <= 0 || n_local > g_c.E) return 0.0;
   int li, ri;
@@ -1133,7 +1178,7 @@ SSS_DEV double task_duration(const SssJob* job, int s, int e) {
   }
   int task_stage = g_hot.ex_task_stage[e];
   int mode = task_stage < 0 ? 0 : (task_stage == s ? 1 : 2);  // idle / same stage id (TPCH:95) / other
-  const int32_t* d = g_c.pk.eff + (((size_t)gs * 8 + li) * 3 + mode) * 4;
+  const int32_t* d = eff_row(g_c.pk.eff, gs, li, mode);
   int off = d[0], lenw = d[1];
   int len = lenw & 0x3FFFFFFF;
   if (len == 0) {
@@ -1279,6 +1324,9 @@ SSS_DEV void move_idle_executor(uint32_t src, int e) {
 // set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
 // all lanes: which executors sit idle in the source pool (a pool's members are the executors located in it)
 SSS_DEV void publish_idle_mask() {
+#ifdef SSS_WIDE  // (a 64-bit mask of executors: the pool's copy is walked instead, get_idle_source_executors)
+  return;
+#endif
   int lane = wave_lane();
   uint32_t key = g_hot.h.curr_source;
   uint64_t m = wave_ballot(lane < g_c.E && key != POOL_NONE && g_hot.ex_loc[lane] == key && !g_hot.ex_executing[lane]);
@@ -1429,6 +1477,20 @@ SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
 SSS_DEV void fulfil_order_commitments() {
   const int lane = wave_lane();
   const uint32_t src = g_hot.h.curr_source;
+#ifdef SSS_WIDE  // up to 128 entries: lane 0 sorts the source's few by insertion
+  if (lane == 0) {
+    int n = 0;
+    for (int i = 0; i < g_hot.h.n_commits; i++) {
+      if (g_hot.c_src[i] != src) continue;
+      int q = n++;
+      for (; q > 0 && g_sc.fc_seq[q - 1] > g_hot.c_seq[i]; q--) g_sc.fc_dst[q] = g_sc.fc_dst[q - 1], g_sc.fc_num[q] = g_sc.fc_num[q - 1], g_sc.fc_seq[q] = g_sc.fc_seq[q - 1];
+      g_sc.fc_dst[q] = g_hot.c_dst[i], g_sc.fc_num[q] = g_hot.c_n[i], g_sc.fc_seq[q] = g_hot.c_seq[i];
+    }
+    g_sc.fc_n = n;
+  }
+  wave_sync();
+  return;
+#endif
   const bool mine = lane < g_hot.h.n_commits && g_hot.c_src[lane] == src;
   const uint32_t seq = g_hot.c_seq[lane];
   const uint32_t dst = g_hot.c_dst[lane];
@@ -1849,7 +1911,7 @@ SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
   PROF3(14);
   const JobView v = jobview(j);
   CHECK(g_hot.ex_task_stage[e] < 0);  // JOB:81-84
-  v.job->local_mask |= bit64(e);
+  v.job->local_mask = local_with(v.job->local_mask, e);
   g_hot.ex_job[e] = (int16_t)j;
   const int mv = (int)v.st[s].moving_to - 1;  // TRK:185-187
   CHECK(mv >= 0);
@@ -1951,6 +2013,24 @@ SSS_DEV void handle_task_completion(int e, int j, int s) {  // ENV:452-483
 // beyond the one read of the slots. All lanes call it; every lane gets the same result.
 SSS_DEV int pop_event_wave(double next_arrival_t, double& t_win, uint32_t& info_win) {
   int lane = wave_lane();
+#ifdef SSS_WIDE
+  {
+    // two executors per lane: the lane's earlier event (by (time, push counter)) enters the wave-wide minimum
+    const SssEvSlot a = g_hot.ev[lane], b = g_hot.ev[lane + 64];
+    const bool b_first = b.t < a.t || (b.t == a.t && b.seq < a.seq);
+    const SssEvSlot sl = b_first ? b : a;
+    const int mine = b_first ? lane + 64 : lane;
+    const double tmin = wave_min_f64_nonneg(sl.t);
+    const bool at_min = sl.t == tmin;
+    const uint32_t msq = wave_min_u32(at_min ? sl.seq : 0xFFFFFFFFu);  // equal times: the earlier push wins (EVQ:35)
+    const int wl = ctz64(wave_ballot(at_min && sl.seq == msq));
+    if (next_arrival_t <= tmin && next_arrival_t < __builtin_inf()) return POP_ARRIVAL;
+    if (!(tmin < __builtin_inf())) return POP_EMPTY;
+    t_win = tmin;
+    info_win = wave_readlane_u32(sl.info, wl);
+    return (int)wave_readlane_u32((uint32_t)mine, wl);
+  }
+#endif
   SssEvSlot sl = g_hot.ev[lane];
   // times are >= +0.0; +inf for empty slots and for the lanes beyond the executors
   double tmin = g_c.E <= 16 ? wave_min_f64_nonneg_row0(sl.t) : wave_min_f64_nonneg(sl.t);
@@ -1988,9 +2068,9 @@ SSS_DEV void fastctx_load(FastCtx& f) {
 // the duration lists an executor that stays on pack stage `gs` can draw from next ("same stage"
 // mode of TPCH:75-106): one per candidate executor level (li == ri when the interval is closed)
 SSS_DEV void exdesc_fetch(const FastCtx& f, SssExDesc& xd, int gs, int li, int ri) {
-  const int4 a = *(const int4*)(f.eff + (((size_t)gs * 8 + li) * 3 + 1) * 4);
+  const int4 a = *(const int4*)eff_row(f.eff, gs, li, 1);
   int4 b = a;
-  if (ri != li) b = *(const int4*)(f.eff + (((size_t)gs * 8 + ri) * 3 + 1) * 4);
+  if (ri != li) b = *(const int4*)eff_row(f.eff, gs, ri, 1);
   xd.gs = gs, xd.li = (int8_t)li, xd.ri = (int8_t)ri, xd.pad = 0;
   xd.off_l = a.x, xd.lenw_l = a.y, xd.dmin_l = a.z;
   xd.off_r = b.x, xd.lenw_r = b.y, xd.dmin_r = b.z;
@@ -2024,7 +2104,7 @@ SSS_DEV int fast_body(const FastCtx& f, int ex, double t_ev, int j, int s, int s
   if (demand <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));  // fire-and-forget: nothing below waits for the old mask
   *sp = st;
   // task_duration, executor mode 1 ("same stage")
-  int n_local = popc64(local);
+  int n_local = local_count(local);
   int li, ri;
   executor_interval(n_local, li, ri);
   if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) {
@@ -3190,24 +3270,46 @@ SSS_DEV void env_begin(const uint8_t* base) {
     // entry per executor). The rest of the HBM image is never read or written.
     const SssHot* g = (const SssHot*)base;
     if (lane < (int)(sizeof(SssHdr) / 16)) ((uint4*)&g_hot.h)[lane] = ((const uint4*)&g->h)[lane];
-    SssEvSlot ev;
-    ev.t = __builtin_inf(), ev.seq = 0, ev.info = EV_NONE;  // the queue's reductions run over all 64 lanes
-    uint32_t loc = POOL_NONE, csrc = 0, cdst = 0, cseq = 0;
-    int16_t job = -1, cn = 0;
-    int8_t ts = -1;
-    uint8_t exe = 0;
-    if (lane < g_c.E)
-      ev = g->ev[lane], loc = g->ex_loc[lane], job = g->ex_job[lane], ts = g->ex_task_stage[lane], exe = g->ex_executing[lane], csrc = g->c_src[lane],
-      cdst = g->c_dst[lane], cseq = g->c_seq[lane], cn = g->c_n[lane];
-    g_hot.ev[lane] = ev, g_hot.ex_loc[lane] = loc, g_hot.ex_job[lane] = job, g_hot.ex_task_stage[lane] = ts, g_hot.ex_executing[lane] = exe;
-    g_hot.c_src[lane] = csrc, g_hot.c_dst[lane] = cdst, g_hot.c_seq[lane] = cseq, g_hot.c_n[lane] = cn;
+    for (int x = lane; x < SSS_MAX_EXEC; x += 64) {  // (one entry per lane; two in the wide instantiation)
+      SssEvSlot ev;
+      ev.t = __builtin_inf(), ev.seq = 0, ev.info = EV_NONE;  // the queue's reductions run over all slots
+      uint32_t loc = POOL_NONE, csrc = 0, cdst = 0, cseq = 0;
+      int16_t job = -1, cn = 0;
+      int8_t ts = -1;
+      uint8_t exe = 0;
+      if (x < g_c.E)
+        ev = g->ev[x], loc = g->ex_loc[x], job = g->ex_job[x], ts = g->ex_task_stage[x], exe = g->ex_executing[x], csrc = g->c_src[x],
+        cdst = g->c_dst[x], cseq = g->c_seq[x], cn = g->c_n[x];
+      g_hot.ev[x] = ev, g_hot.ex_loc[x] = loc, g_hot.ex_job[x] = job, g_hot.ex_task_stage[x] = ts, g_hot.ex_executing[x] = exe;
+      g_hot.c_src[x] = csrc, g_hot.c_dst[x] = cdst, g_hot.c_seq[x] = cseq, g_hot.c_n[x] = cn;
+    }
   }
   for (int i = lane; i < g_c.J_cap; i += 64) lds_slot_of()[i] = SLOT_NONE;
-  if (lane < g_c.E) lds_exdesc()[lane].gs = -1;
+  for (int x = lane; x < g_c.E; x += 64) lds_exdesc()[x].gs = -1;
   lds_slot_ref()[lane] = 0;
   wave_sync();
   int A = g_hot.h.n_active;
   for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
+#ifdef SSS_WIDE
+  // the jobs of the pending events get the cache slots, in executor order (lane 0: cache_acquire brings the records in)
+  if (lane == 0) {
+    g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
+    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
+    g_sc.events_this_step = 0;
+    g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
+    g_sc.rng_pos = 64;
+    for (int x = 0; x < g_c.E; x++) {
+      const uint32_t info = g_hot.ev[x].info;
+      if (info_kind(info) == EV_NONE) continue;
+      const int k = cache_acquire(info_job(info));
+      if (k == SLOT_NONE) continue;
+      lds_slot_ref()[k]++;
+      g_hot.ev[x].info = info_with_slot(info, (uint32_t)k);
+    }
+  }
+  wave_sync();
+  return;
+#endif
   {
     // The jobs of the pending events get the cache slots - the jobs with the most pending events first (ties: lowest
     // executor), so that a burst of executors travelling to one job, or many executors working on one job, never
@@ -3319,18 +3421,18 @@ SSS_DEV void env_end(uint8_t* base) {
       ((uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP];
   }
   for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
-  if (lane < g_c.E) {  // the HBM image of an event does not name an LDS slot
-    uint32_t info = g_hot.ev[lane].info;
-    if (info_kind(info) != EV_NONE) g_hot.ev[lane].info = info_with_slot(info, INFO_SLOT_NONE);
+  for (int x = lane; x < g_c.E; x += 64) {  // the HBM image of an event does not name an LDS slot
+    uint32_t info = g_hot.ev[x].info;
+    if (info_kind(info) != EV_NONE) g_hot.ev[x].info = info_with_slot(info, INFO_SLOT_NONE);
   }
   wave_sync();
   {
     SssHot* g = (SssHot*)base;
     if (lane < (int)(sizeof(SssHdr) / 16)) ((uint4*)&g->h)[lane] = ((const uint4*)&g_hot.h)[lane];
-    if (lane < g_c.E) {
-      g->ev[lane] = g_hot.ev[lane], g->ex_loc[lane] = g_hot.ex_loc[lane], g->ex_job[lane] = g_hot.ex_job[lane];
-      g->ex_task_stage[lane] = g_hot.ex_task_stage[lane], g->ex_executing[lane] = g_hot.ex_executing[lane];
-      g->c_src[lane] = g_hot.c_src[lane], g->c_dst[lane] = g_hot.c_dst[lane], g->c_seq[lane] = g_hot.c_seq[lane], g->c_n[lane] = g_hot.c_n[lane];
+    for (int x = lane; x < g_c.E; x += 64) {
+      g->ev[x] = g_hot.ev[x], g->ex_loc[x] = g_hot.ex_loc[x], g->ex_job[x] = g_hot.ex_job[x];
+      g->ex_task_stage[x] = g_hot.ex_task_stage[x], g->ex_executing[x] = g_hot.ex_executing[x];
+      g->c_src[x] = g_hot.c_src[x], g->c_dst[x] = g_hot.c_dst[x], g->c_seq[x] = g_hot.c_seq[x], g->c_n[x] = g_hot.c_n[x];
     }
   }
 }
@@ -3578,6 +3680,7 @@ SSS_DEV void resume_simulation() {
   // raw generator outputs the event loop wants to find buffered at the top of a round: two per
   // event of a batch (batches are cut to what is there, so this only has to be "enough")
   const int rng_need = 2 * (f.E < 20 ? f.E : 20);
+  (void)rng_need;
   for (;;) {
     // events run until the wave is needed for a schedulable-stage scan, the queue is empty, or
     // something failed. A round = a run of "task finished, stage has more tasks" events if the head of
@@ -3720,12 +3823,12 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     wave_sync();
   }
   // executors + event slots + commitments
-  if (lane < SSS_MAX_EXEC) {
-    hot.ev[lane].t = __builtin_inf(), hot.ev[lane].seq = 0, hot.ev[lane].info = EV_NONE;
-    hot.ex_loc[lane] = lane < g_c.E ? POOL_COMMON : POOL_NONE;
-    hot.ex_job[lane] = -1;
-    hot.ex_task_stage[lane] = -1, hot.ex_executing[lane] = 0;
-    hot.c_src[lane] = POOL_NONE, hot.c_dst[lane] = POOL_NONE, hot.c_seq[lane] = 0, hot.c_n[lane] = 0;
+  for (int x = lane; x < SSS_MAX_EXEC; x += 64) {
+    hot.ev[x].t = __builtin_inf(), hot.ev[x].seq = 0, hot.ev[x].info = EV_NONE;
+    hot.ex_loc[x] = x < g_c.E ? POOL_COMMON : POOL_NONE;
+    hot.ex_job[x] = -1;
+    hot.ex_task_stage[x] = -1, hot.ex_executing[x] = 0;
+    hot.c_src[x] = POOL_NONE, hot.c_dst[x] = POOL_NONE, hot.c_seq[x] = 0, hot.c_n[x] = 0;
   }
   wave_sync();
   int J = hot.h.J;
@@ -3887,7 +3990,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
 // ------------------------------------------------------------------------------------------
 
 // reset envs whose mask byte is non-zero (mask == nullptr: all)
-SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const double* time_limits, const uint8_t* mask) {
+SSS_KERNEL void SSS_KNAME(sss_reset_kernel)(SssKernelArgs a, const uint64_t* seeds, const double* time_limits, const uint8_t* mask) {
   int env = wave_env();
   if (mask && !mask[env]) return;
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
@@ -3900,7 +4003,7 @@ SSS_KERNEL void sss_reset_kernel(SssKernelArgs a, const uint64_t* seeds, const d
 
 // one step() per env; with auto_reset != 0 an env that is terminated at entry starts its next
 // episode instead (seed += seed_stride), like a vector env in "next-step" autoreset mode
-SSS_KERNEL void sss_step_kernel(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
+SSS_KERNEL void SSS_KNAME(sss_step_kernel)(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
   int env = wave_env();
   if (stage_idx[env] == SSS_SKIP_ENV) return;  // wave-uniform: the env is not touched at all
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
@@ -4032,7 +4135,7 @@ SSS_DEV void run_policy(int policy, int param, int& stage_idx, int& num_exec) {
 }
 
 // writes one action per env into stage_idx / num_exec (for sss_step)
-SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_t* stage_idx, int32_t* num_exec) {
+SSS_KERNEL void SSS_KNAME(sss_policy_kernel)(SssKernelArgs a, int policy, int param, int32_t* stage_idx, int32_t* num_exec) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   ctx_init();
@@ -4044,7 +4147,7 @@ SSS_KERNEL void sss_policy_kernel(SssKernelArgs a, int policy, int param, int32_
 
 // n_steps x (policy -> step -> observe) per env in one launch; the env's hot block and job cache
 // stay in LDS in between. Every step still writes the full observation, as the reference's step() does.
-SSS_KERNEL void sss_rollout_kernel(SssKernelArgs a, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride) {
+SSS_KERNEL void SSS_KNAME(sss_rollout_kernel)(SssKernelArgs a, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride) {
   int env = wave_env();
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   ctx_init();

@@ -436,7 +436,12 @@ static int mlp_head_mfma_launch(const SssMlpArgs& a, bool backward, void* stream
 static int be_launch_mlp(const SssMlpArgs& a, int backward, void* stream) {
   const bool gnn = a.h1 == 32 && a.h2 == 16 && a.out_dim == 16 && a.act == 0;
   const bool head = a.h1 == 64 && a.h2 == 64 && a.out_dim == 1 && a.act == 1;
-  static const bool lanes16 = getenv("SSS_MLP_LANES16") != nullptr;  // (comparisons: the 16-lanes-per-row kernels for the GNN shapes too)
+  // (a -DSSS_TEST_VECTOR_FORMS test build takes the 16-lanes-per-row kernels for every shape: comparisons)
+#ifdef SSS_TEST_VECTOR_FORMS
+  constexpr bool lanes16 = true;
+#else
+  constexpr bool lanes16 = false;
+#endif
   if (gnn && !lanes16) {
     if (a.in_dim == GNN_NF) return mlp_mfma_launch<GNN_NF>(a, backward, stream);
     if (a.in_dim == 16) return mlp_mfma_launch<16>(a, backward, stream);

@@ -50,11 +50,13 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, want_bias: bool = True, bind
     need = int(b.lib.sss_linear_wgrad_scratch(M, N))
     if need <= 0:
         raise ValueError(f"sss_linear_wgrad supports 1..64 features, got M={M}, N={N}")
-    key = (dev.type, dev.index)
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    # one partial-sum buffer per (device, stream): the partial and the reduce kernel of two backward passes on different
+    # streams must not meet in it
+    key = (dev.type, dev.index, stream)
     sc = _SCRATCH.get(key)
     if sc is None or sc.numel() < need:
         sc = _SCRATCH[key] = torch.empty(max(need, int(b.lib.sss_linear_wgrad_scratch(64, 64))), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
     with device_of(dev):
         b.check(b.lib.sss_linear_wgrad(x.data_ptr(), x.stride(0) if K > 1 else max(M, x.stride(0)), dy.data_ptr(), dy.stride(0) if K > 1 else max(N, dy.stride(0)),
                                        K, M, N, gw.data_ptr(), gb.data_ptr() if gb is not None else None, sc.data_ptr(), stream))

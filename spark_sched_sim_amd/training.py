@@ -78,7 +78,9 @@ class RolloutCollector:
     Env b plays worker rank b: seed of its k-th episode = base_seeds[b] + seed_step * k
     (rollout_worker.py:118-120, trainer.py:264-269), time limit from `StochasticTimeLimit`'s rule.
     `act_fn(g, step_counts)` (g = compact graph of the active envs' observations) returns
-    `DecimaPolicy.act`'s dict; the default samples from `policy`. Envs that are done (sync) or have filled their duration (async) are frozen with
+    `DecimaPolicy.act`'s dict; the default samples from `policy`. `step_counts` is an int64 tensor ON THE ENV'S DEVICE (the
+    collection kernels update it in place): an `act_fn` that mixes it with CPU tensors has to move it (`.cpu()` is one sync
+    per step). Envs that are done (sync) or have filled their duration (async) are frozen with
     SSS_SKIP_ENV until the others catch up."""
 
     def __init__(self, env, mean_time_limit: float, base_seeds: Sequence[int], seed_step: int, num_executors: int,
@@ -161,7 +163,11 @@ class RolloutCollector:
         member_b = [m.view(torch.bool) if m is not None else None for m in member]
         use_streams = G > 1 and dev.type == "cuda"
         main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-        streams = [torch.cuda.Stream(device=dev) if use_streams else None for _ in range(G)]
+        # the groups' streams are created once per collector: the per-stream work buffers of the graph / encoder calls
+        # (vec_env._layer_scratch, decima._enc_scratch) are keyed by stream and would pile up with fresh streams per call
+        if use_streams and len(getattr(self, "_streams", ())) != G:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
+        streams = list(self._streams) if use_streams else [None] * G
         for st in streams:
             if st is not None:
                 st.wait_stream(main)

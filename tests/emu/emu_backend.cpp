@@ -63,7 +63,7 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
 #include "sss_train.h"
 #include "sss_collect.h"
 static int be_launch_collect(const SssCollectArgs& a, int phase, void*) {
-  for (int b = 0; b < a.num_envs; b++) collect_env(a, phase, b, [&](int i, int v) { a.flags[i] |= v; });
+  for (int b = 0; b < a.num_envs; b++) collect_env(a, phase, b, [&](int i, int v) { a.flags[i] |= v; }, [&](int i, int v) { a.flags[i] = v > a.flags[i] ? v : a.flags[i]; });
   return 0;
 }
 // sss_linear_wgrad on the host (the MFMA kernel is gfx950-only): plain loops, same results up to summation order

@@ -48,6 +48,13 @@ TESTYAML = dict(num_executors=50, job_arrival_cap=10, job_arrival_rate=4.0e-5, m
 BIGE = dict(num_executors=64, job_arrival_cap=30, job_arrival_rate=8.0e-5, moving_delay=2000.0,
             warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler")
 
+# more than 64 executors (round 4: the wide instantiation of the kernels): the level table's top (tpch.py:238), and beyond it
+# - 120 executors, few jobs: rows 101..119 of executor_intervals are (100, 100), row 120 stays (0, 0) (tpch.py:258-260)
+E100 = dict(num_executors=100, job_arrival_cap=40, job_arrival_rate=1.0e-4, moving_delay=2000.0,
+            warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler")
+E120 = dict(num_executors=120, job_arrival_cap=6, job_arrival_rate=2.0e-5, moving_delay=2000.0,
+            warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler")
+
 # name -> (env_cfg, policy, seeds, reset options)
 SETS = {
     "c1_fair": (C1, "fair", [1234] + list(range(20)), None),
@@ -63,6 +70,9 @@ SETS = {
     "c1_fair_beta": (dict(C1, beta=5.0e-3), "fair", [11, 12], None),
     # the reference's RandomScheduler plugin (legacy MT19937 RandomState(seed), heuristics/random_scheduler.py)
     "c1_random": (C1, "random", [7, 8], None),
+    "e100_fair": (E100, "fair", [0, 1], None),
+    "e100_hash": (E100, "hash", [2], None),
+    "e120_hash": (E120, "hash", [0, 1, 2, 3], None),
 }
 
 

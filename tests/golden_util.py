@@ -7,7 +7,7 @@ import numpy as np
 
 GOLDEN_DIR = osp.join(osp.dirname(osp.abspath(__file__)), "golden")
 ALL_SETS = ["tiny_hash", "tiny_fair_tlimit", "c1_fair", "c1_hash", "c1_fifo", "c3_fair", "c3_hash",
-            "testyaml_fair", "bige_hash"]
+            "testyaml_fair", "bige_hash", "e100_fair", "e100_hash", "e120_hash"]
 
 
 class Golden:

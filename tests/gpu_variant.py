@@ -1,0 +1,26 @@
+"""Test builds of the HIP library (TEST INFRASTRUCTURE): the product sources compiled with an extra -D into tests/_build/, for
+comparisons between formulations of the same kernel. The product library (spark_sched_sim_amd/csrc/libsss_hip.so) has no
+run-time switches; `-DSSS_TEST_VECTOR_FORMS` selects the vector-unit GNN / MLP kernels (csrc/sss_gnn.h, sss_gnn16.h,
+sss_train16.h) where the product takes the matrix-core ones (csrc/sss_hip.hip: kVectorForms)."""
+import ctypes
+import os
+import os.path as osp
+
+HERE = osp.dirname(osp.abspath(__file__))
+VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",)}
+
+
+def variant_path(name: str) -> str:
+    return osp.join(HERE, "_build", f"libsss_hip_{name}.so")
+
+
+def build_variant(name: str, verbose: bool = False) -> str:
+    """builds (if stale) and returns the path; hipcc cross-compiles, so the build container can do it ahead of the GPU box"""
+    from spark_sched_sim_amd import build as hip_build
+
+    os.makedirs(osp.join(HERE, "_build"), exist_ok=True)
+    return hip_build.build(out=variant_path(name), extra_flags=VARIANTS[name], verbose=verbose)
+
+
+def load_variant(name: str) -> ctypes.CDLL:
+    return ctypes.CDLL(build_variant(name))

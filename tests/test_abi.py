@@ -36,7 +36,7 @@ def test_query_dims_and_validation(hip_lib, pack):
     d = b.query_dims(SssCfg(10, 50, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), pack, 4096)
     assert (d.num_envs, d.num_executors, d.job_cap, d.stage_stride) == (4096, 10, 50, 18)
     assert d.node_cap == 50 * 18 and d.env_stride % 256 == 0 and d.state_bytes == d.env_stride * 4096
-    for bad_cfg, what in ((SssCfg(65, 50, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), "num_executors"),
+    for bad_cfg, what in ((SssCfg(129, 50, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), "num_executors"),
                           (SssCfg(10, 0, 0, 0, 4e-5, 2000.0, 1000.0, 0.0), "max_jobs"),
                           (SssCfg(10, 50, 0, 0, 0.0, 2000.0, 1000.0, 0.0), "job_arrival_rate")):
         with pytest.raises(ValueError, match=what):

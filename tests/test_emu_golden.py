@@ -16,6 +16,10 @@ CASES = [
     ("bige_hash", [0], 300),
     ("testyaml_fair", [3], None),
     ("c3_fair", [0], 250),
+    # more than 64 executors: the wide instantiation of the kernels (csrc/sss_sim.h with SSS_WIDE, tests/emu/emu_wide.cpp)
+    ("e100_fair", [0], None),
+    ("e100_hash", [2], 600),
+    ("e120_hash", [0, 1, 2, 3], None),   # 120 executors on <= 6 jobs: more than 100 local executors, and all 120 (tpch.py:258-260)
 ]
 
 

@@ -29,6 +29,8 @@ def test_kernel_source_under_asan_ubsan():
         bad += replay_golden("c1_fair", [1234], pack, device="cpu", lib=lib, max_steps=150)
         bad += replay_golden("bige_hash", [0], pack, device="cpu", lib=lib, max_steps=120)
         bad += replay_golden("tiny_fair_tlimit", [0, 1], pack, device="cpu", lib=lib)
+        bad += replay_golden("e100_hash", [2], pack, device="cpu", lib=lib, max_steps=250)   # the wide instantiation
+        bad += replay_golden("e120_hash", [0], pack, device="cpu", lib=lib)
         bad += run_policy_episode("tiny_hash", "hash", 30, [0, 1], pack, lib=lib, fused=1)
         bad += run_policy_episode("testyaml_fair", "fair", 0, [3], pack, lib=lib, max_steps=80)
         print("SANITIZED-OK" if not bad else bad)

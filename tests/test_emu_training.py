@@ -119,6 +119,40 @@ def test_collector_truncates_a_rollout_whose_env_stalls(pack=None):
         env.close()
 
 
+def test_two_envs_failing_in_the_same_step_name_a_real_env():
+    """flags[3] ("1 + index of a failed env") took an OR over the failing envs - two envs failing in the
+    same step decoded to an env that did not fail (or to one beyond the batch). It is a maximum now: envs 2 and 3 both replay
+    tests/golden/stall_case.json, the report names env 3 with env 3's seed and action history and the stalled-simulation code."""
+    import json
+    import os.path as osp
+
+    import torch
+
+    from golden_util import GOLDEN_DIR
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.training import RolloutCollector
+
+    c = json.load(open(osp.join(GOLDEN_DIR, "stall_case.json")))
+    cfg = {k: v for k, v in c["env_cfg"].items() if k != "mean_time_limit"}
+    B = 4
+
+    def replay(g, counts):  # envs 2 and 3 replay the recorded actions, envs 0 and 1 always take (stage 0, 1 executor)
+        t = min(int(counts[2]), len(c["stage_idx"]) - 1)
+        z = torch.zeros(B, dtype=torch.long)
+        return {"stage_sel": torch.tensor([0, 0, c["stage_idx"][t], c["stage_idx"][t]]), "job_idx": z,
+                "exec_sel": torch.tensor([0, 0, c["num_exec"][t] - 1, c["num_exec"][t] - 1]), "lgprob": torch.zeros(B),
+                "any_stage": torch.ones(B, dtype=torch.bool)}
+
+    env = VecSparkSchedSimEnv(cfg, B, device="cpu", _lib=load_emu())
+    col = RolloutCollector(env, c["env_cfg"]["mean_time_limit"], [c["seed"] + 1, c["seed"] + 2, c["seed"], c["seed"]], 1, 10, act_fn=replay,
+                           on_env_error="raise")
+    with pytest.raises(RuntimeError, match=r"env 3 .*simulation stalled") as ei:
+        col.collect_sync(with_stats=False)
+    assert ei.value.case["seed"] == c["seed"] and ei.value.case["stage_idx"] == c["stage_idx"] and ei.value.case["code"] == 5
+    assert col.env_errors == 2
+    env.close()
+
+
 def test_linear_wgrad_entry_point_on_the_host_backend():
     """include/sss.h sss_linear_wgrad through the emulator library's host implementation: the argument plumbing of
     spark_sched_sim_amd.train_kernels.linear_wgrad (strided rows, bias on / off, error codes)"""

@@ -235,7 +235,8 @@ def test_decima_step_with_another_current_device(pack):
 def test_matrix_core_gnn_equals_the_vector_unit_forms(tmp_path):
     """csrc/sss_gnn_mfma.h (DAG layers, node / job rows and both policy heads as chained v_mfma_f32_16x16x4_f32) against the
     vector-unit kernels of sss_gnn.h / sss_gnn16.h on the same recorded graphs and parameters: a child process runs the
-    same script with SSS_GNN_LAYER16 / SSS_GNN_ROWS_VALU / SSS_GNN_HEADS_VALU set (the forms are chosen once per process).
+    same script on a TEST build of the library compiled with -DSSS_TEST_VECTOR_FORMS (tests/gpu_variant.py; the formulation is
+    fixed when a library is compiled - the product library has no run-time switch).
     Embeddings, job / observation summaries, stage and executor scores agree within 2e-5 (fp32, different summation order;
     the heads' tanh is exp / rcp based on the matrix-core path: ~1e-7)."""
     import os
@@ -247,13 +248,15 @@ def test_matrix_core_gnn_equals_the_vector_unit_forms(tmp_path):
     script = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[3])
+import ctypes
 from decima_util import AGENT
 from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
 from spark_sched_sim_amd.decima import DecimaPolicy
+lib = ctypes.CDLL(sys.argv[4]) if len(sys.argv) > 4 else None
 out = {}
 for name, cfg, n_env, steps in (("c2", dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), 300, 120),
                                  ("e50", dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), 37, 200)):
-    env = VecSparkSchedSimEnv(cfg, n_env, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
+    env = VecSparkSchedSimEnv(cfg, n_env, device="cuda:0", pack=workload.default_pack(), auto_reset=True, _lib=lib)
     env.reset(seed=5)
     env.rollout("fair", steps)
     torch.manual_seed(9)
@@ -275,9 +278,11 @@ np.savez(sys.argv[1], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, extra in (("mfma", {}), ("valu", {"SSS_GNN_LAYER16": "1", "SSS_GNN_ROWS_VALU": "1", "SSS_GNN_HEADS_VALU": "1"})):
+    from gpu_variant import build_variant
+
+    for tag, extra in (("mfma", []), ("valu", [build_variant("vecforms")])):
         path = str(tmp_path / (tag + ".npz"))
-        subprocess.run([sys.executable, "-c", script, path, root, os.path.join(root, "tests")], check=True, env=dict(os.environ, **extra), timeout=600)
+        subprocess.run([sys.executable, "-c", script, path, root, os.path.join(root, "tests")] + extra, check=True, timeout=900)
         res[tag] = dict(np.load(path))
     assert res["mfma"].keys() == res["valu"].keys() and len(res["mfma"]) == 10
     for k, a in res["mfma"].items():

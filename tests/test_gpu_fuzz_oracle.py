@@ -33,6 +33,10 @@ CASES = [
                              warmup_delay=1000.0), "fair", 3.0e6),
     ("discounted", _cfg(10, 30, 4.0e-5, beta=5.0e-3), "fair", None),
     ("thousand_jobs", _cfg(40, 1000, 2.0e-3, md=200.0), "fair", None),   # the build's job-capacity limit
+    ("hundred_executors", _cfg(100, 120, 1.0e-4), "fair", None),      # > 64 executors: the wide instantiation of the kernels
+    ("e128_hash", _cfg(128, 60, 2.0e-4), "hash", None),
+    ("e101_few_jobs", _cfg(101, 3, 2.0e-5), "hash", None),            # num_local_executors in 101 .. exec_cap (tpch.py:258-260)
+    ("e65_fair", _cfg(65, 50, 1.0e-4), "fair", None),
     ("tiny_time_limit", dict(num_executors=5, job_arrival_cap=None, max_jobs=50, job_arrival_rate=1.0e-4, moving_delay=2000.0,
                              warmup_delay=1000.0), "fair", 5.0e3),        # mostly single-job episodes
 ]

@@ -18,6 +18,9 @@ CASES = [
     ("bige_hash", [0, 1, 2], None),
     ("c3_fair", [0, 1], None),
     ("c3_hash", [7], None),
+    ("e100_fair", [0, 1], None),      # more than 64 executors: sss_*_kernel_wide (csrc/sss_hip_wide.hip)
+    ("e100_hash", [2], None),
+    ("e120_hash", [0, 1, 2, 3], None),
 ]
 
 

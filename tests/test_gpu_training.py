@@ -90,6 +90,10 @@ def test_linear_wgrad_kernel_matches_torch():
 
 @pytest.mark.gpu
 def test_mlp_kernels_match_autograd():
+    _check_mlp_kernels_match_autograd()
+
+
+def _check_mlp_kernels_match_autograd():
     """csrc/sss_train16.h (forward and backward of a whole MLP, 16 lanes per row) against torch in fp64 on the same
     parameters, for the five MLP shapes of the published architecture and row counts around the tile sizes; then
     `KernelMLP` (what `make_mlp` builds) through autograd against the plain nn.Sequential, and bit-identical repeats"""
@@ -190,14 +194,13 @@ def test_message_passing_function_matches_the_tensor_op_form():
 
 
 @pytest.mark.gpu
-def test_mlp_kernels_16_lane_forms_in_a_child_process():
-    """the GNN-shaped training MLPs run on the matrix cores by default; their 16-lanes-per-row kernels (kept for the policy
-    heads and for comparisons, SSS_MLP_LANES16) go through the same checks in a child process that selects them"""
-    import os
-    import subprocess
-    import sys
+def test_mlp_kernels_16_lane_forms(monkeypatch):
+    """the GNN-shaped training MLPs run on the matrix cores in the product library; their 16-lanes-per-row kernels (kept for
+    comparisons) go through the same checks on a TEST build of the library compiled with -DSSS_TEST_VECTOR_FORMS
+    (tests/gpu_variant.py): the formulation is fixed when a library is compiled, there is no run-time switch"""
+    from gpu_variant import load_variant
+    from spark_sched_sim_amd import train_kernels
+    from spark_sched_sim_amd.binding import Binding
 
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "test_mlp_kernels_match_autograd", "-p", "no:cacheprovider"],
-                       env=dict(os.environ, SSS_MLP_LANES16="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    monkeypatch.setattr(train_kernels, "_BINDING", Binding(load_variant("vecforms")))
+    _check_mlp_kernels_match_autograd()
