@@ -91,6 +91,23 @@ print(json.dumps([steps, time.perf_counter() - t0]))
 """
 
 
+def reference_python_baseline(config: str):
+    """the reference Python env itself, timed in the BUILD CONTAINER by tools/time_reference.py (it cannot travel to the GPU box:
+    /root/reference does not exist there) - the committed record profiles/reference_python.json, quoted with its hardware"""
+    path = osp.join(ROOT, "profiles", "reference_python.json")
+    try:
+        rec = json.load(open(path))
+        c = rec["configs"][{"c2": "c1", "c3": "c3"}[config]]
+        return {"value": c["one_core"]["env_only"], "unit": "env-steps/s", "cores": 1, "kind": "reference",
+                "all_cores": {"value": c["all_cores"]["env_only"], "processes": c["all_cores"]["processes"]},
+                "env_plus_scheduler_incl_reset": c["one_core"]["including_reset"],
+                "sample": f"{c['episodes']} episodes / {c['steps']} steps, fair scheduler, time.perf_counter around env.step only (examples.py:84-102 loop)",
+                "hardware": rec["hardware"], "measured_in_this_run": False,
+                "source": "profiles/reference_python.json (tools/time_reference.py; same executors / jobs / arrival rate as this record's config, 1 env)"}
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """host cores this process may actually use: affinity mask and cgroup CPU quota included"""
     n = os.cpu_count() or 1
@@ -473,9 +490,13 @@ def main() -> None:
             "events_per_batch": primary["events_per_batch"],
             "phase_ticks_per_step": primary["phase_ticks_per_step"],
             "mean_last_episode_return": mean_return,
-            "roofline": primary["roofline"],
+            # the roofline figures of the line are the SUSTAINED window's when there is one (>= --sustained-s of stepping in the
+            # same mode): K = 20 timed steps are 3-4 ms and carry whatever bytes per launch those 20 steps happened to have
+            "roofline": dict(sustained["roofline"], window=f"{sustained['steps']} batched steps (the `sustained` record)") if sustained is not None
+                        else dict(primary["roofline"], window=f"the K = {args.steps} timed steps"),
         }
         if sustained is not None:
+            out["roofline_k_steps"] = dict(primary["roofline"], window=f"the K = {args.steps} timed steps of `value`")
             out["sustained"] = sustained
         if tail is not None:
             out["step_tail"] = tail
@@ -488,6 +509,9 @@ def main() -> None:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(4.0, args.cpu_budget / 2))
             except Exception as e:  # never let the extra baseline take the bench line down
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
+            ref_py = reference_python_baseline(args.config)
+            if ref_py is not None:
+                out["cpu_baseline_reference_python"] = ref_py
     pack = bench.pack
     bench.close()
 
@@ -506,7 +530,8 @@ def main() -> None:
             rec = {"what": f"BASELINE config 3: {B} envs x (50 executors, 200 jobs), fair policy, steady state; {k3} timed batched steps after {w3} warm-up steps",
                    "value": r3["value"], "unit": "env-steps/s", "ms_per_step": r3["ms_per_step"], "events_per_step": r3["events_per_step"],
                    "fast_path_event_frac": r3["fast_path_event_frac"], "batched_event_frac": r3["batched_event_frac"], "events_per_batch": r3["events_per_batch"],
-                   "phase_ticks_per_step": r3["phase_ticks_per_step"], "roofline": r3["roofline"], "step_tail": b3.step_tail(12),
+                   "phase_ticks_per_step": r3["phase_ticks_per_step"], "roofline": s3["roofline"] if s3 is not None else r3["roofline"],
+                   "roofline_k_steps": r3["roofline"], "step_tail": b3.step_tail(12),
                    "other_mode": dict(f3, mode="fused"), "mean_last_episode_return": b3.header_field("last_ep_return").mean().item()}
             b3.close()
             if s3 is not None:
@@ -514,6 +539,9 @@ def main() -> None:
             if not args.no_cpu_baseline:
                 rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2))
                 rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2))
+                ref_py = reference_python_baseline("c3")
+                if ref_py is not None:
+                    rec["cpu_baseline_reference_python"] = ref_py
             out["c3"] = rec
         except Exception as e:
             out["c3"] = {"error": repr(e)}

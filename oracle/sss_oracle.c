@@ -30,6 +30,7 @@
 
 typedef struct {
   int T, L, s_max, total_stages, total_edges, total_durations;
+  int n_sizes, n_queries; /* len(QUERY_SIZES), NUM_QUERIES of the trace set (TPCH:14-15); T = n_queries * n_sizes */
   const int32_t *levels, *tmpl_stage_off, *tmpl_edge_off, *stage_num_tasks;
   const double *stage_rough;
   const uint64_t *stage_parent_mask, *stage_child_mask;
@@ -43,6 +44,9 @@ static int pack_parse(const uint8_t *p, size_t n, pack_view *v) {
   v->T = (int)h[0], v->L = (int)h[1], v->s_max = (int)h[2];
   v->total_stages = (int)h[3], v->total_edges = (int)h[4], v->total_durations = (int)h[5];
   if (h[6] != 12) return -1;
+  v->n_sizes = h[7] > 0 ? (int)h[7] : 7; /* header word 7: sizes per query; 0 = the reference's seven (TPCH:14) */
+  if (v->T < 1 || v->T % v->n_sizes) return -1;
+  v->n_queries = v->T / v->n_sizes;
   const int64_t *toc = h + 8;
   const void *sec[12];
   for (int i = 0; i < 12; i++) {
@@ -889,11 +893,11 @@ int sso_reset(sss_oracle *o, uint64_t seed, double time_limit) {
       cap = cap ? cap * 2 : 64;
       jobs = realloc(jobs, sizeof(job_t) * (size_t)cap);
     }
-    int q = (int)sso_integers(&o->rng, 22);    /* TPCH:177 (query_num - 1) */
-    int size = (int)sso_integers(&o->rng, 7);  /* TPCH:178 */
+    int q = (int)sso_integers(&o->rng, (uint32_t)o->pk.n_queries);  /* TPCH:177 (query_num - 1) */
+    int size = (int)sso_integers(&o->rng, (uint32_t)o->pk.n_sizes); /* TPCH:178 */
     job_t *job = &jobs[J];
     memset(job, 0, sizeof(*job));
-    job->tmpl = q * 7 + size;
+    job->tmpl = q * o->pk.n_sizes + size;
     job->n_stages = o->pk.tmpl_stage_off[job->tmpl + 1] - o->pk.tmpl_stage_off[job->tmpl];
     job->edge_off = o->pk.tmpl_edge_off[job->tmpl];
     job->n_edges = o->pk.tmpl_edge_off[job->tmpl + 1] - job->edge_off;
@@ -1131,7 +1135,7 @@ sss_oracle *sso_create(const void *pack, size_t pack_bytes, const sso_cfg *cfg) 
   sss_oracle *o = calloc(1, sizeof(*o));
   o->pack_copy = malloc(pack_bytes);
   memcpy(o->pack_copy, pack, pack_bytes);
-  if (pack_parse(o->pack_copy, pack_bytes, &o->pk) || o->pk.T != 154 || cfg->num_executors < 1) {
+  if (pack_parse(o->pack_copy, pack_bytes, &o->pk) || cfg->num_executors < 1) {
     free(o->pack_copy);
     free(o);
     return NULL;

@@ -28,6 +28,7 @@ static int sss_fail(int code, const std::string& msg) {
 
 struct SssPackHost {
   int T, L, s_max, total_stages, total_edges, total_durations;
+  int n_sizes, n_queries;  // len(QUERY_SIZES), NUM_QUERIES of the trace set (tpch.py:14-15); T = n_queries * n_sizes
   int64_t sec_off[12], sec_len[12];
   int max_edges_per_job;
 };
@@ -45,7 +46,12 @@ static int sss_pack_parse(const uint8_t* p, size_t n, SssPackHost* v) {
     if (e[0] < 0 || e[1] < 0 || (size_t)(e[0] + e[1]) > n || (e[0] & 7)) return -1;
     v->sec_off[i] = e[0], v->sec_len[i] = e[1];
   }
-  if (v->T != 154 || v->L < 1 || v->L > SSS_MAX_LEVELS || v->s_max < 1 || v->s_max > SSS_MAX_STAGES) return -1;
+  // header word 7: input sizes per query; 0 = the reference's seven (tpch.py:14), which keeps packs written before the word
+  // had a meaning - the frozen default among them, whose digest the fixtures record - byte for byte what they were
+  v->n_sizes = h[7] > 0 ? (int)h[7] : 7;
+  if (v->T < 1 || v->T % v->n_sizes || v->L < 1 || v->L > SSS_MAX_LEVELS || v->s_max < 1 || v->s_max > SSS_MAX_STAGES) return -1;
+  v->n_queries = v->T / v->n_sizes;
+  if ((size_t)v->sec_len[1] < sizeof(int32_t) * ((size_t)v->T + 1) || (size_t)v->sec_len[2] < sizeof(int32_t) * ((size_t)v->T + 1)) return -1;
   const int32_t* eo = (const int32_t*)(p + v->sec_off[2]);
   int me = 0;
   for (int t = 0; t < v->T; t++) me = eo[t + 1] - eo[t] > me ? eo[t + 1] - eo[t] : me;
@@ -72,7 +78,7 @@ struct sss_handle {
 
 static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, SssPackHost* ph, int* J_cap) {
   if (!cfg) return sss_fail(-1, "cfg is NULL");
-  if (sss_pack_parse((const uint8_t*)pack, pack_bytes, ph)) return sss_fail(-2, "workload pack is malformed (expected SSSPACK2, 154 templates, <= 64 stages/job, <= 255 edges/job)");
+  if (sss_pack_parse((const uint8_t*)pack, pack_bytes, ph)) return sss_fail(-2, "workload pack is malformed (expected SSSPACK2, n_queries x n_sizes templates, <= 64 stages/job, <= 255 edges/job)");
   if (num_envs < 1) return sss_fail(-3, "num_envs must be >= 1");
   if (cfg->num_executors < 1 || cfg->num_executors > SSS_MAX_EXEC_ANY) return sss_fail(-4, "num_executors must be in [1, 128]");
   int cap = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0;
@@ -289,6 +295,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
 
   SssPackDev pk;
   memset(&pk, 0, sizeof(pk));
+  pk.n_queries = ph.n_queries, pk.n_sizes = ph.n_sizes;
   pk.T = ph.T, pk.L = ph.L, pk.s_max = ph.s_max, pk.total_stages = ph.total_stages, pk.total_edges = ph.total_edges;
   pk.total_durations = ph.total_durations;
   const uint8_t* b = (const uint8_t*)h->pack_dev;

@@ -106,7 +106,8 @@ struct SssHdr {            // 304 bytes
   uint64_t n_fast;         // TASK_FINISHED events that took the "stage has more tasks" path (batched or one at a time)
   uint64_t n_batched;      // ... of which handled by the lane-parallel batch path
   uint64_t n_rounds;       // batch rounds that committed at least one event
-  uint64_t pad_[2];
+  uint64_t err_line;       // diagnostics: source line (csrc/sss_sim.h) of the check that set `err` last (0: none so far); survives resets
+  uint64_t pad_[1];
   // The active subgraph (which jobs, in which order, with which stages) changes only when a job arrives or
   // completes or a stage completes; the observation's edge rows are a function of it alone. graph_version counts
   // those changes, obs_* say what the edge rows in the caller's buffer were written from: an unchanged graph's
@@ -192,6 +193,7 @@ struct SssParams {
 // read-only workload pack, device pointers (see spark_sched_sim_amd/workload.py)
 struct SssPackDev {
   int32_t T, L, s_max, total_stages, total_edges, total_durations;
+  int32_t n_queries, n_sizes;  // NUM_QUERIES, len(QUERY_SIZES) of the trace set (tpch.py:14-15): a job's template is query * n_sizes + size
   const int32_t *levels, *tmpl_stage_off, *tmpl_edge_off, *stage_num_tasks;
   const double* stage_rough;
   const uint64_t *stage_parent_mask, *stage_child_mask;

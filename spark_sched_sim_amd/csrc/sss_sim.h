@@ -149,12 +149,12 @@ SSS_DEV void ctx_init() { prof3_clear(); }
 #include <stdio.h>
 #define FAIL(code)                                                                          \
   do {                                                                                      \
-    if (H.err == 0) fprintf(stderr, "[FAIL] line %d: code %d\n", __LINE__, (int)(code)), H.err = (code); \
+    if (H.err == 0) fprintf(stderr, "[FAIL] line %d: code %d\n", __LINE__, (int)(code)), H.err = (code), H.err_line = __LINE__; \
   } while (0)
 #else
-#define FAIL(code)                 \
-  do {                             \
-    if (H.err == 0) H.err = (code); \
+#define FAIL(code)                                         \
+  do {                                                     \
+    if (H.err == 0) H.err = (code), H.err_line = __LINE__; \
   } while (0)
 #endif
 #ifdef SSS_CHECK_TRACE
@@ -3694,6 +3694,12 @@ SSS_DEV void resume_simulation() {
       // the head of the queue decides what kind of round this is
       double t_win = 0.0;
       uint32_t info_win = 0;
+#ifdef SSS_WIDE
+      // Every round here is "lane 0 handles one event, then every lane looks at the queue again" with nothing in between (no
+      // fast run, no batch - those end in barriers): the barrier makes lane 0's LDS writes of the previous round (event slots,
+      // arrival cursor) something the other lanes' reads below cannot have been scheduled ahead of
+      wave_sync();
+#endif
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
       if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {
@@ -3768,11 +3774,11 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     double last_ep_return = H.last_ep_return, last_ep_wall = H.last_ep_wall;
     uint64_t prof[5];
     for (int i = 0; i < 5; i++) prof[i] = H.prof[i];
-    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds, pad0_keep = H.pad_[0], pad1_keep = H.pad_[1];
+    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds, pad0_keep = H.err_line, pad1_keep = H.pad_[0];
     SssHdr z = {};
     H = z;
     for (int i = 0; i < 5; i++) H.prof[i] = prof[i];
-    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep, H.pad_[0] = pad0_keep, H.pad_[1] = pad1_keep;
+    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep, H.err_line = pad0_keep, H.pad_[0] = pad1_keep;
     H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
     H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
@@ -3811,9 +3817,9 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
           more = false;
           break;
         }
-        int q = (int)rng_integers(22);     // TPCH:177
-        int size = (int)rng_integers(7);   // TPCH:178
-        (*jobp(J)).gs_base = q * 7 + size;  // template id for now; resolved to pack rows below
+        int q = (int)rng_integers((uint32_t)g_c.pk.n_queries);   // TPCH:177
+        int size = (int)rng_integers((uint32_t)g_c.pk.n_sizes);  // TPCH:178
+        (*jobp(J)).gs_base = q * g_c.pk.n_sizes + size;  // template id for now; resolved to pack rows below
         g_c.t_arrival[J] = t;
         J++;
         t += g_c.P.mean_interarrival * rng_standard_exponential();  // TPCH:70

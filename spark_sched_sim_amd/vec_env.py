@@ -422,7 +422,8 @@ HDR_OFF = {"wall_time": 40, "time_limit": 48, "seed": 56, "n_steps": 64, "n_even
            "counter": 88, "next_arrival": 92, "J": 96, "n_active": 100, "n_completed": 104, "curr_source": 108,
            "n_sched": 112, "terminated": 136, "err": 140, "need_reset": 144, "dur_head": 148, "dur_n": 152,
            "episodes": 156, "last_reward": 160, "ep_return": 168, "last_ep_return": 176, "last_ep_wall": 184,
-           "ep_steps": 192, "last_ep_steps": 196, "next_arrival_t": 200, "n_fast": 248, "n_batched": 256, "n_rounds": 264}
+           "ep_steps": 192, "last_ep_steps": 196, "next_arrival_t": 200, "n_fast": 248, "n_batched": 256, "n_rounds": 264,
+           "err_line": 272}  # source line of the kernel-side check that failed last (diagnostics for bug reports)
 HDR_W = {"wall_time": np.float64, "time_limit": np.float64, "seed": np.uint64, "n_steps": np.uint64,
          "n_events": np.uint64, "model_bytes": np.uint64, "counter": np.uint32, "next_arrival": np.int32,
          "J": np.int32, "n_active": np.int32, "n_completed": np.int32, "curr_source": np.uint32,
@@ -430,4 +431,4 @@ HDR_W = {"wall_time": np.float64, "time_limit": np.float64, "seed": np.uint64, "
          "dur_head": np.int32, "dur_n": np.int32, "episodes": np.int32, "last_reward": np.float64,
          "ep_return": np.float64, "last_ep_return": np.float64, "last_ep_wall": np.float64,
          "ep_steps": np.int32, "last_ep_steps": np.int32, "next_arrival_t": np.float64, "n_fast": np.uint64,
-         "n_batched": np.uint64, "n_rounds": np.uint64}
+         "n_batched": np.uint64, "n_rounds": np.uint64, "err_line": np.uint64}

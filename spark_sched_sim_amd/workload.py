@@ -47,10 +47,27 @@ _SIZE_SCALE = {"2g": 1, "5g": 2, "10g": 4, "20g": 8, "50g": 20, "80g": 32, "100g
 _LEVELS = [2, 5, 10, 20, 40, 50, 60, 80, 100]
 
 
-def template_index(query_num: int, size_idx: int) -> int:
+def template_index(query_num: int, size_idx: int, n_sizes: int = len(QUERY_SIZES)) -> int:
     """template id used by the pack: query-major. `query_num` is 1-based as in
     tpch.py:177, `size_idx` indexes QUERY_SIZES as drawn in tpch.py:178."""
-    return (query_num - 1) * len(QUERY_SIZES) + size_idx
+    return (query_num - 1) * n_sizes + size_idx
+
+
+def trace_set_shape(raw: dict) -> tuple[list[str], int]:
+    """(query sizes, number of queries) of a raw trace set {(size, query_num): ...}: the reference's constants QUERY_SIZES /
+    NUM_QUERIES (tpch.py:14-15) for its own dataset; a user's trace set may have any number of either. Sizes in the reference's
+    order where they are the reference's, else as first met; queries must be numbered 1..n for every size."""
+    sizes: list[str] = []
+    for size, _ in raw:
+        if size not in sizes:
+            sizes.append(size)
+    if set(sizes) <= set(QUERY_SIZES):
+        sizes.sort(key=QUERY_SIZES.index)
+    n_q = max(q for _, q in raw)
+    missing = [(sz, q) for sz in sizes for q in range(1, n_q + 1) if (sz, q) not in raw]
+    if missing:
+        raise ValueError(f"trace set is not a full (size x query) grid: missing {missing[:4]}")
+    return sizes, n_q
 
 
 # --------------------------------------------------------------------------
@@ -134,14 +151,16 @@ def _make_stage_durations(
     return {"fresh_durations": fresh, "first_wave": first, "rest_wave": rest}
 
 
-def make_raw_workload(seed: int = DEFAULT_SEED) -> dict[tuple[str, int], tuple[np.ndarray, dict]]:
-    """-> {(size, query_num): (adj_mat int64[S,S], {stage: {wave: {level: [int]}}})}"""
+def make_raw_workload(seed: int = DEFAULT_SEED, query_sizes: list[str] | None = None, num_queries: int = NUM_QUERIES) -> dict[tuple[str, int], tuple[np.ndarray, dict]]:
+    """-> {(size, query_num): (adj_mat int64[S,S], {stage: {wave: {level: [int]}}})}; by default the reference's grid of
+    7 sizes x 22 queries (the frozen set the fixtures were recorded on); other grids for tests of other trace-set shapes"""
     rng = np.random.default_rng(seed)
     raw: dict[tuple[str, int], tuple[np.ndarray, dict]] = {}
-    for q in range(1, NUM_QUERIES + 1):
+    query_sizes = list(QUERY_SIZES) if query_sizes is None else list(query_sizes)
+    for q in range(1, num_queries + 1):
         n_stages = int(rng.integers(2, 19))
         adj = _make_dag(rng, n_stages)
-        for size in QUERY_SIZES:
+        for size in query_sizes:
             scale = _SIZE_SCALE[size]
             td = {}
             for s in range(n_stages):
@@ -235,7 +254,13 @@ _SECTIONS = (
 )
 
 
-def build_pack_arrays(raw: dict) -> dict[str, np.ndarray]:
+def build_pack_arrays(raw: dict, query_sizes: list[str] | None = None, num_queries: int | None = None) -> dict[str, np.ndarray]:
+    """`query_sizes` / `num_queries`: the sampler's QUERY_SIZES / NUM_QUERIES (tpch.py:14-15: `integers(NUM_QUERIES)`,
+    `choice(QUERY_SIZES)` index the templates); by default whatever grid `raw` holds (the reference's 7 x 22 for its own data)"""
+    if query_sizes is None or num_queries is None:
+        found_sizes, found_q = trace_set_shape(raw)
+        query_sizes = found_sizes if query_sizes is None else list(query_sizes)
+        num_queries = found_q if num_queries is None else int(num_queries)
     level_set = set()
     for _, td in raw.values():
         for st in td.values():
@@ -254,8 +279,8 @@ def build_pack_arrays(raw: dict) -> dict[str, np.ndarray]:
     dur_chunks: list[np.ndarray] = []
     dur_off = 0
 
-    for q in range(1, NUM_QUERIES + 1):
-        for size in QUERY_SIZES:
+    for q in range(1, num_queries + 1):
+        for size in query_sizes:
             adj, td = raw[(size, q)]
             tc = _template_constants(np.asarray(adj), td)
             n = tc["n"]
@@ -295,6 +320,7 @@ def build_pack_arrays(raw: dict) -> dict[str, np.ndarray]:
             tmpl_edge_off.append(len(edges))
 
     return {
+        "n_sizes": len(query_sizes),
         "levels": np.asarray(levels, dtype=np.int32),
         "tmpl_stage_off": np.asarray(tmpl_stage_off, dtype=np.int32),
         "tmpl_edge_off": np.asarray(tmpl_edge_off, dtype=np.int32),
@@ -315,7 +341,11 @@ def serialize_pack(arrs: dict[str, np.ndarray]) -> bytes:
     magic[8] | i64 header[8] | i64 toc[nsec][2] (byte offset, byte length) | sections (8-aligned)
 
     header = (n_templates, n_levels, s_max, total_stages, total_edges,
-              total_durations, n_sections, 0)
+              total_durations, n_sections, n_sizes or 0)
+
+    n_templates = n_queries * n_sizes (a job's template is query * n_sizes + size, tpch.py:177-178). The last word holds n_sizes,
+    or 0 for the reference's seven: packs of 7-size trace sets - the frozen default, whose digest the fixtures record - stay
+    byte for byte what they were before the word had a meaning.
     """
     T = arrs["tmpl_stage_off"].size - 1
     L = arrs["levels"].size
@@ -328,8 +358,9 @@ def serialize_pack(arrs: dict[str, np.ndarray]) -> bytes:
         int(arrs["edges"].shape[0]),
         int(arrs["durations"].size),
         len(_SECTIONS),
-        0,
+        0 if int(arrs.get("n_sizes", 7)) == len(QUERY_SIZES) else int(arrs["n_sizes"]),
     ]
+    assert T % int(arrs.get("n_sizes", 7)) == 0
     head_bytes = 8 + 8 * len(header) + 16 * len(_SECTIONS)
     off = (head_bytes + 7) & ~7
     toc = []
@@ -380,10 +411,17 @@ def pack_max_depth(pack: bytes) -> int:
     return best
 
 
-def build_pack(raw: dict | None = None, seed: int = DEFAULT_SEED) -> bytes:
+def build_pack(raw: dict | None = None, seed: int = DEFAULT_SEED, query_sizes: list[str] | None = None, num_queries: int | None = None) -> bytes:
     if raw is None:
         raw = make_raw_workload(seed)
-    return serialize_pack(build_pack_arrays(raw))
+    return serialize_pack(build_pack_arrays(raw, query_sizes, num_queries))
+
+
+def pack_shape(pack: bytes) -> tuple[int, int]:
+    """(number of queries, number of sizes) of a serialized pack"""
+    h = struct.unpack_from("<8q", pack, 8)
+    n_sizes = h[7] if h[7] > 0 else len(QUERY_SIZES)
+    return h[0] // n_sizes, n_sizes
 
 
 def pack_digest(pack: bytes) -> str:
@@ -400,14 +438,17 @@ def default_pack(seed: int = DEFAULT_SEED) -> bytes:
     return _CACHE[seed]
 
 
-def pack_from_reference_layout(root: str) -> bytes:
+def pack_from_reference_layout(root: str, query_sizes: list[str] | None = None, num_queries: int | None = None) -> bytes:
     """compile a trace set stored in the reference's on-disk layout (e.g. the real
-    TPC-H traces, if a user has them) into a pack."""
+    TPC-H traces, if a user has them) into a pack. `query_sizes` / `num_queries` default to the reference's constants
+    (tpch.py:14-15: 7 sizes x 22 queries); a user whose trace set differs passes theirs, as they would edit those two lines."""
+    query_sizes = list(QUERY_SIZES) if query_sizes is None else list(query_sizes)
+    num_queries = NUM_QUERIES if num_queries is None else int(num_queries)
     raw = {}
-    for size in QUERY_SIZES:
-        for q in range(1, NUM_QUERIES + 1):
+    for size in query_sizes:
+        for q in range(1, num_queries + 1):
             d = osp.join(root, "data", "tpch", size)
             adj = np.load(osp.join(d, f"adj_mat_{q}.npy"), allow_pickle=True)
             td = np.load(osp.join(d, f"task_duration_{q}.npy"), allow_pickle=True).item()
             raw[(size, q)] = (adj, td)
-    return build_pack(raw)
+    return build_pack(raw, query_sizes=query_sizes, num_queries=num_queries)

@@ -73,6 +73,10 @@ SETS = {
     "e100_fair": (E100, "fair", [0, 1], None),
     "e100_hash": (E100, "hash", [2], None),
     "e120_hash": (E120, "hash", [0, 1, 2, 3], None),
+    # a trace set of another shape - 5 queries x 2 sizes, its own generator seed - as a user would have it after editing
+    # QUERY_SIZES / NUM_QUERIES (tpch.py:14-15); here those two module constants are set on the imported module
+    "q5s2_fair": (dict(C1, job_arrival_cap=25), "fair", [0, 1, 2], None, (["2g", "10g"], 5, 77)),
+    "q5s2_hash": (dict(C1, job_arrival_cap=25), "hash", [3, 4], None, (["2g", "10g"], 5, 77)),
 }
 
 
@@ -106,7 +110,8 @@ def hash_policy(obs, seed: int, step: int, p_none_permille: int = 30):
     return {"stage_idx": stage_idx, "num_exec": num_exec}
 
 
-def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls):
+def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls, sizes=tuple(workload.QUERY_SIZES)):
+    sizes = list(sizes)
     env = gym.make("spark_sched_sim:SparkSchedSimEnv-v0", env_cfg=dict(env_cfg))
     if policy == "fair":
         sched = sched_cls(env_cfg["num_executors"], dynamic_partition=True)
@@ -189,7 +194,7 @@ def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls):
     jobs = env.unwrapped.jobs
     out["t_arrival"] = np.asarray([jobs[j].t_arrival for j in sorted(jobs)], dtype=np.float64)
     out["template"] = np.asarray(
-        [workload.template_index(int(jobs[j].query_num), workload.QUERY_SIZES.index(str(jobs[j].query_size)))
+        [workload.template_index(int(jobs[j].query_num), sizes.index(str(jobs[j].query_size)), len(sizes))
          for j in sorted(jobs)], dtype=np.int32)
     for i, (nodes, el, ptr, sup) in enumerate(full):
         out[f"full{i}_nodes"], out[f"full{i}_edges"] = nodes, el
@@ -200,32 +205,46 @@ def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls):
 
 def main(argv):
     names = argv or list(SETS)
-    raw = workload.make_raw_workload()
-    pack = workload.build_pack(raw)
-    with tempfile.TemporaryDirectory() as tmp:
-        workload.write_reference_layout(raw, tmp)
-        os.chdir(tmp)  # the reference reads data/tpch relative to cwd (tpch.py:48,119)
-        gym, sched_cls, metrics = import_reference()
-        for name in names:
-            env_cfg, policy, seeds, options = SETS[name]
-            blob = {}
-            for seed in seeds:
-                ep = run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls)
-                for k, v in ep.items():
-                    blob[f"s{seed}_{k}"] = v
-                print(f"{name} seed={seed}: {len(ep['stage_idx']) - 1} steps, "
-                      f"{int(ep['num_completed'])}/{int(ep['num_jobs'])} jobs"
-                      + (f"  ERROR at step {int(ep['error_step'])}: {ep['error_msg']}" if ep["error_step"] >= 0 else ""),
-                      flush=True)
-            blob["seeds"] = np.asarray(seeds, dtype=np.int64)
-            blob["policy"] = np.asarray(policy)
-            blob["pack_sha256"] = np.asarray(workload.pack_digest(pack))
-            blob["cfg_keys"] = np.asarray(sorted(k for k in env_cfg if k != "data_sampler_cls"))
-            blob["cfg_vals"] = np.asarray(
-                [np.nan if env_cfg[k] is None else float(env_cfg[k]) for k in sorted(env_cfg) if k != "data_sampler_cls"],
-                dtype=np.float64)
-            blob["time_limit"] = np.float64((options or {}).get("time_limit", np.inf))
-            np.savez_compressed(osp.join(HERE, f"{name}.npz"), **blob)
+    cwd0 = os.getcwd()
+    gym = sched_cls = metrics = None
+    for name in names:
+        env_cfg, policy, seeds, options = SETS[name][:4]
+        shape = SETS[name][4] if len(SETS[name]) > 4 else None
+        sizes, n_queries, raw_seed = shape if shape else (list(workload.QUERY_SIZES), workload.NUM_QUERIES, workload.DEFAULT_SEED)
+        raw = workload.make_raw_workload(raw_seed, sizes, n_queries)
+        pack = workload.build_pack(raw)
+        with tempfile.TemporaryDirectory() as tmp:
+            workload.write_reference_layout(raw, tmp)
+            os.chdir(tmp)  # the reference reads data/tpch relative to cwd (tpch.py:48,119)
+            if gym is None:
+                gym, sched_cls, metrics = import_reference()
+            from spark_sched_sim.data_samplers import tpch
+            keep = (tpch.QUERY_SIZES, tpch.NUM_QUERIES)
+            tpch.QUERY_SIZES, tpch.NUM_QUERIES = list(sizes), n_queries  # (the reference's own values unless the set names a shape)
+            try:
+                blob = {}
+                for seed in seeds:
+                    ep = run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls, sizes)
+                    for k, v in ep.items():
+                        blob[f"s{seed}_{k}"] = v
+                    print(f"{name} seed={seed}: {len(ep['stage_idx']) - 1} steps, "
+                          f"{int(ep['num_completed'])}/{int(ep['num_jobs'])} jobs"
+                          + (f"  ERROR at step {int(ep['error_step'])}: {ep['error_msg']}" if ep["error_step"] >= 0 else ""),
+                          flush=True)
+            finally:
+                tpch.QUERY_SIZES, tpch.NUM_QUERIES = keep
+                os.chdir(cwd0)
+        blob["seeds"] = np.asarray(seeds, dtype=np.int64)
+        blob["policy"] = np.asarray(policy)
+        blob["pack_sha256"] = np.asarray(workload.pack_digest(pack))
+        if shape:  # what tests/golden_util.py needs to rebuild the set's pack
+            blob["trace_sizes"], blob["trace_queries"], blob["trace_seed"] = np.asarray(sizes), np.int64(n_queries), np.int64(raw_seed)
+        blob["cfg_keys"] = np.asarray(sorted(k for k in env_cfg if k != "data_sampler_cls"))
+        blob["cfg_vals"] = np.asarray(
+            [np.nan if env_cfg[k] is None else float(env_cfg[k]) for k in sorted(env_cfg) if k != "data_sampler_cls"],
+            dtype=np.float64)
+        blob["time_limit"] = np.float64((options or {}).get("time_limit", np.inf))
+        np.savez_compressed(osp.join(HERE, f"{name}.npz"), **blob)
 
 
 if __name__ == "__main__":

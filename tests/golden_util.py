@@ -7,7 +7,10 @@ import numpy as np
 
 GOLDEN_DIR = osp.join(osp.dirname(osp.abspath(__file__)), "golden")
 ALL_SETS = ["tiny_hash", "tiny_fair_tlimit", "c1_fair", "c1_hash", "c1_fifo", "c3_fair", "c3_hash",
-            "testyaml_fair", "bige_hash", "e100_fair", "e100_hash", "e120_hash"]
+            "testyaml_fair", "bige_hash", "e100_fair", "e100_hash", "e120_hash", "q5s2_fair", "q5s2_hash"]
+
+
+_PACKS: dict = {}
 
 
 class Golden:
@@ -26,6 +29,17 @@ class Golden:
         self.seeds = [int(s) for s in self.z["seeds"]]
         self.policy = str(self.z["policy"])
         self.pack_sha256 = str(self.z["pack_sha256"])
+
+    def pack(self, default: bytes) -> bytes:
+        """the workload pack the set was recorded on: the frozen default, or - sets that name a trace-set shape (make_golden.py:
+        q5s2_*) - the pack of that many sizes x queries from that generator seed"""
+        if "trace_sizes" not in self.z:
+            return default
+        from spark_sched_sim_amd import workload
+        key = (tuple(str(x) for x in self.z["trace_sizes"]), int(self.z["trace_queries"]), int(self.z["trace_seed"]))
+        if key not in _PACKS:
+            _PACKS[key] = workload.build_pack(workload.make_raw_workload(key[2], list(key[0]), key[1]))
+        return _PACKS[key]
 
     def ep(self, seed: int, key: str):
         return self.z[f"s{seed}_{key}"]

@@ -14,6 +14,7 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
                   reward_rtol: float = 0.0, rewards_out: list | None = None):
     """one env per seed, all stepped together; returns a list of mismatch descriptions"""
     g = Golden(name)
+    pack = g.pack(pack)
     seeds = list(seeds)
     cfg = dict(g.cfg)
     if cfg.get("job_arrival_cap") is None:

@@ -19,6 +19,8 @@ CASES = [
     # more than 64 executors: the wide instantiation of the kernels (csrc/sss_sim.h with SSS_WIDE, tests/emu/emu_wide.cpp)
     ("e100_fair", [0], None),
     ("e100_hash", [2], 600),
+    ("q5s2_fair", [0, 1], None),         # a trace set of 5 queries x 2 sizes (the pack header carries the shape)
+    ("q5s2_hash", [3], None),
     ("e120_hash", [0, 1, 2, 3], None),   # 120 executors on <= 6 jobs: more than 100 local executors, and all 120 (tpch.py:258-260)
 ]
 

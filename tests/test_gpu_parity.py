@@ -21,6 +21,8 @@ CASES = [
     ("e100_fair", [0, 1], None),      # more than 64 executors: sss_*_kernel_wide (csrc/sss_hip_wide.hip)
     ("e100_hash", [2], None),
     ("e120_hash", [0, 1, 2, 3], None),
+    ("q5s2_fair", [0, 1, 2], None),   # a trace set of 5 queries x 2 sizes
+    ("q5s2_hash", [3, 4], None),
 ]
 
 

@@ -60,6 +60,7 @@ def replay(env: OracleEnv, g: Golden, seed: int, check_full: bool = True):
 @pytest.mark.parametrize("name", ALL_SETS + ["c1_fair_beta"])
 def test_oracle_matches_reference_trajectories(name, pack):
     g = Golden(name)
+    pack = g.pack(pack)
     assert g.pack_sha256 == workload.pack_digest(pack), "fixtures were recorded on a different workload pack"
     env = OracleEnv(pack, g.cfg)
     for seed in g.seeds[: MAX_SEEDS.get(name, 3)]:
