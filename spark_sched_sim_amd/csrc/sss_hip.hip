@@ -220,8 +220,8 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
 
 #ifdef SSS_EVPROF3  // timing builds only (tools/debug/evprof3.sh): reads and clears the scoped profiler's table
 extern "C" int sss_debug_prof(unsigned long long* out64) {
-  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
-  static const unsigned long long zeros[64] = {0};
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
+  static const unsigned long long zeros[96] = {0};
   return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
 }
 extern "C" int sss_debug_prof_min(unsigned long long min_step_ticks) {

@@ -48,7 +48,7 @@
 // counters (what the event chain touches on every event), and scratch for set images.
 struct alignas(16) SssScratch {
   uint8_t pool8[8];  // the 8-slot table of the pool that is open (pool_open / pool_close)
-  uint8_t pad8_[8];
+  uint8_t pool8b[8]; // ... of a second pool staged next to it (pool_pair_stage)
   // the next raw outputs of the env's PCG64 stream, produced 64 at a time by the whole wave
   // (rng_refill); rng_pos of them are consumed; rng_pos == 64: none buffered, the header holds the
   // generator's state as numpy would have it
@@ -188,6 +188,11 @@ extern "C" { extern long long sss_batch_stats[128]; }
 #endif
 
 #include "sss_prof.h"  // PROF3 scopes: empty unless a timing build defines SSS_EVPROF3
+#if defined(SSS_CHECK_TRACE) && defined(SSS_UTRACE)
+#define UTRACE(tag) do { if (wave_lane() < 2 && getenv("SSS_UTRACE")) fprintf(stderr, "[u] lane %d %s\n", wave_lane(), tag); } while (0)
+#else
+#define UTRACE(tag) ((void)0)
+#endif
 
 // ---- LDS pool views ----
 #define LENW_LEN 0x3FFFFFFF  // list length in a duration descriptor (bit 30: warmup_delay is added)
@@ -736,7 +741,7 @@ SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
   SssPoolHdr* hd = g_c.pool_hdr + pool_index(key);
   const uint32_t w0 = s.mask | (s.fill << 16), w1 = (s.used & 0xFFFFu) | (s.aux << 16);
   if (s.mask == 7) {
-    const uint2 t = *(const uint2*)g_sc.pool8;
+    const uint2 t = *(const uint2*)s.small;  // (g_sc.pool8, or the second staging area's 8-slot scratch)
     *(uint4*)hd = mk_u4(w0, w1, t.x, t.y);
   } else
     *(uint4*)hd = mk_u4(w0, w1, 0u, 0u);  // the table lives in the overflow area; the inline bytes are kept clean
@@ -783,7 +788,7 @@ SSS_DEV void pool_stage_out(uint32_t key, const SetImg<uint8_t>& s) {
 // probe per step) and resizes stay with the one-lane code (staged_sync_from_lane0 brings the lanes' headers back in step).
 SSS_DEV void staged_fix_location(SetImg<uint8_t>& s) {  // where a staged image lives follows from its size
   const bool small = s.mask == 7;
-  s.tab = small ? g_sc.pool8 : g_sc.setA, s.cap = small ? 8u : (uint32_t)sss_pool_table_bytes(g_c.E), s.wide = false;
+  s.tab = small ? s.small : s.big, s.cap = small ? 8u : (uint32_t)sss_pool_table_bytes(g_c.E), s.wide = false;
 }
 SSS_DEV void staged_sync_from_lane0(SetImg<uint8_t>& s) {
   wave_sync();
@@ -798,7 +803,7 @@ SSS_DEV void staged_add(SetImg<uint8_t>& s, uint32_t key) {
     staged_sync_from_lane0(s);
     return;
   }
-  const uint8_t* tab = g_sc.setA;
+  uint8_t* const tab = s.big;  // (the staging area the image was brought into: setA, or setB for a second pool)
   const uint32_t mask = s.mask;
   uint32_t i = key & mask, perturb = key;
   int freeslot = -1, idx = -1;
@@ -820,10 +825,10 @@ SSS_DEV void staged_add(SetImg<uint8_t>& s, uint32_t key) {
   bool resize = false;
   if (freeslot >= 0) {
     s.used++;
-    if (lane == 0) g_sc.setA[freeslot] = (uint8_t)(key + 2);
+    if (lane == 0) tab[freeslot] = (uint8_t)(key + 2);
   } else {
     s.fill++, s.used++;
-    if (lane == 0) g_sc.setA[idx] = (uint8_t)(key + 2);
+    if (lane == 0) tab[idx] = (uint8_t)(key + 2);
     resize = s.fill * 5 >= mask * 3;
   }
   wave_sync();  // the byte is there before any lane looks at the table again
@@ -842,7 +847,7 @@ SSS_DEV bool staged_remove(SetImg<uint8_t>& s, uint32_t key) {
     staged_sync_from_lane0(s);
     return was != 0;
   }
-  const uint8_t* tab = g_sc.setA;
+  uint8_t* const tab = s.big;
   const uint32_t mask = s.mask;
   uint32_t i = key & mask, perturb = key;
   for (;;) {
@@ -852,7 +857,7 @@ SSS_DEV bool staged_remove(SetImg<uint8_t>& s, uint32_t key) {
     const uint64_t zm = wave_ballot(in && en == 0), mm = wave_ballot(in && en == key + 2);
     const uint64_t before = zm ? (bit64(ctz64_nz(zm)) - 1) : ~0ull;
     if (mm & before) {
-      if (lane == 0) g_sc.setA[i + (uint32_t)ctz64_nz(mm & before)] = 1;
+      if (lane == 0) tab[i + (uint32_t)ctz64_nz(mm & before)] = 1;
       s.used--;
       wave_sync();
       return true;
@@ -1017,6 +1022,104 @@ SSS_DEV bool set8_add(uint64_t& t, uint32_t& fill, uint32_t& used, uint32_t key)
   fill++, used++;
   t = t8_set(t, i, key + 2);
   return fill * 5 >= 7 * 3;
+}
+
+// ------------------------------------------------------------------------------------------
+// Two pools at once through the LDS staging areas (all lanes). An executor that changes pools touches two set
+// images - the one it leaves and the one it enters - and on lane 0 every one of them is a chain of dependent HBM
+// round trips: the record, then (tables beyond 8 slots) the probe group, then the stores. Here both records and
+// both tables are fetched with ONE round trip - every lane loads 8 bytes of each table whatever the records will
+// say about their sizes - land in setA / setB (+ pool8 / pool8b for 8-slot tables), are operated on with the whole
+// wave (staged_add / staged_remove) and go back with one store per lane. Tables of up to 256 bytes (fewer than
+// 64 executors). pool_pair_fetch (loads in flight) .. pool_pair_stage (in LDS, images ready) .. operations ..
+// pool_pair_flush.
+// ------------------------------------------------------------------------------------------
+struct PoolPairRegs {
+  uint4 rec_a, rec_b;  // the two 16-byte records
+  uint2 tab_a, tab_b;  // this lane's 8 bytes of either table
+};
+SSS_DEV PoolPairRegs pool_pair_fetch(uint32_t key_a, uint32_t key_b, bool has_b) {
+  const int lane = wave_lane();
+  PoolPairRegs r;
+  r.rec_a = *(const uint4*)(g_c.pool_hdr + pool_index(key_a));
+  r.rec_b = mk_u4(7u, 0u, 0u, 0u);
+  r.tab_a = mk_u2(0u, 0u), r.tab_b = r.tab_a;
+  const bool in = (uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E);
+  if (in) r.tab_a = ((const uint2*)pool_table_hbm(key_a))[lane];
+  if (has_b) {
+    r.rec_b = *(const uint4*)(g_c.pool_hdr + pool_index(key_b));
+    if (in) r.tab_b = ((const uint2*)pool_table_hbm(key_b))[lane];
+  }
+  return r;
+}
+// An image of the pair: the set header, and the table - in a register, the same on every lane, while it has 8 slots (set8_add /
+// set8_remove: no LDS, no barrier; at BASELINE config 2 nearly every pool, at config 3 the pools of jobs with few executors),
+// else in its staging area, operated on with the whole wave (staged_add / staged_remove).
+struct PairImg {
+  SetImg<uint8_t> s;
+  uint64_t t8;
+  uint32_t mask_before;  // the record's mask when it was fetched
+};
+SSS_DEV PairImg pool_pair_image(const uint4 rec, uint8_t* area, uint8_t* small8) {
+  PairImg p;
+  p.s.mask = rec.x & 0xFFFFu, p.s.fill = rec.x >> 16, p.s.used = rec.y & 0xFFFFu, p.s.finger = 0, p.s.aux = rec.y >> 16;
+  p.s.big = area, p.s.big_wide = false, p.s.small = small8;
+  staged_fix_location(p.s);
+  p.t8 = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+  p.mask_before = p.s.mask;
+  return p;
+}
+// (ends with a barrier: the tables beyond 8 slots are in LDS)
+SSS_DEV void pool_pair_stage(const PoolPairRegs& r, bool has_b, PairImg& a, PairImg& b) {
+  const int lane = wave_lane();
+  const bool in = (uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E);
+  if (in) ((uint2*)g_sc.setA)[lane] = r.tab_a;
+  a = pool_pair_image(r.rec_a, g_sc.setA, g_sc.pool8);
+  if (has_b && in) ((uint2*)g_sc.setB)[lane] = r.tab_b;
+  b = pool_pair_image(r.rec_b, g_sc.setB, g_sc.pool8b);
+  wave_sync();
+}
+// the image has just been through a resize on lane 0 (its header is in step again): an 8-slot result goes to the register
+SSS_DEV void pair_after_resize(PairImg& p) {
+  if (p.s.mask == 7) {
+    const uint2 t = *(const uint2*)p.s.small;
+    p.t8 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    wave_sync();  // every lane has read the scratch before the next resize may write it (8-slot operations have no barrier of their own)
+  }
+}
+SSS_DEV void pair_add(PairImg& p, uint32_t key) {  // set_add (all lanes)
+  if (p.s.mask == 7) {
+    if (!set8_add(p.t8, p.s.fill, p.s.used, key)) return;
+    // fill * 5 >= mask * 3: set_table_resize(used * 4) - through the 8-slot scratch, on lane 0; the result may have 8 slots or more
+    if (wave_lane() == 0) {
+      *(uint2*)p.s.small = mk_u2((uint32_t)p.t8, (uint32_t)(p.t8 >> 32));
+      p.s.tab = p.s.small, p.s.cap = 8, p.s.wide = false;
+      set_resize(p.s, p.s.used * 4, lds_keys());
+    }
+    staged_sync_from_lane0(p.s);
+    pair_after_resize(p);
+    return;
+  }
+  const uint32_t m0 = p.s.mask;
+  staged_add(p.s, key);
+  if (p.s.mask != m0) pair_after_resize(p);
+}
+SSS_DEV bool pair_remove(PairImg& p, uint32_t key) {  // set_remove (all lanes)
+  if (p.s.mask == 7) return set8_remove(p.t8, p.s.used, key);
+  return staged_remove(p.s, key);
+}
+// one image back to HBM: the record, and the table area unless the image had 8 slots before and has 8 slots now (the
+// area then holds what was fetched). Like pool_stage_out the whole area goes back, so that the HBM bytes are what the
+// one-operation-at-a-time code leaves, dead slots included.
+SSS_DEV void pool_pair_flush_one(uint32_t key, const PairImg& p) {
+  const int lane = wave_lane();
+  if ((p.mask_before != 7 || p.s.mask != 7) && (uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E))
+    ((uint2*)pool_table_hbm(key))[lane] = ((const uint2*)p.s.big)[lane];
+  if (lane == 0) {
+    const uint32_t w0 = p.s.mask | (p.s.fill << 16), w1 = (p.s.used & 0xFFFFu) | (p.s.aux << 16);
+    const bool small = p.s.mask == 7;  // (larger tables live in the overflow area; the inline bytes are kept clean)
+    *(uint4*)(g_c.pool_hdr + pool_index(key)) = mk_u4(w0, w1, small ? (uint32_t)p.t8 : 0u, small ? (uint32_t)(p.t8 >> 32) : 0u);
+  }
 }
 
 SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  // TRK:188-222
@@ -1475,6 +1578,7 @@ SSS_DEV void fulfill_commitment(int e, uint32_t dst) {  // ENV:699-712
 // commitment entry each: an entry's place is the number of the source's entries inserted before it (a v_readlane
 // sweep over those entries; lane 0 alone would scan the whole list once per entry) ...
 SSS_DEV void fulfil_order_commitments() {
+  PROF3(36);
   const int lane = wave_lane();
   const uint32_t src = g_hot.h.curr_source;
 #ifdef SSS_WIDE  // up to 128 entries: lane 0 sorts the source's few by insertion
@@ -1558,6 +1662,7 @@ enum { FI_SEND = 1, FI_EXEC = 2, FI_PARK = 3 };
 // - the rest of its commitment - is for the one-at-a-time path, the items before it for a shorter chunk.
 // ------------------------------------------------------------------------------------------
 SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
+  PROF3(35);
   const int lane = wave_lane();
   const bool active = lane < n;
   const int idx = c0 + (active ? lane : 0);
@@ -1805,8 +1910,95 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
   return n;
 }
 
+// The tail of a fulfilment (all lanes): items [from, to) of the list, all of them commitments to the COMMON pool - what
+// is left of the source's idle executors when a scheduling round ends (ENV:196, 487-503; the common pool is committed to
+// last). Each one settles its commitment (TRK:159-176) and - ENV:702-705 -> 745-782 with a list of one - stays where it is
+// (the source is the common pool, or the pool of a job that still has unsaturated stages), or moves from the source to
+// its job's pool (the source is a stage's pool), or - the job being saturated - is detached into the common pool. Every
+// item has the same source and the same destination, so the whole run is: the commitment entry shrinks by n, the two
+// pool images come in with one round trip (pool_pair_*), n removals and n additions in item order with the whole wave,
+// and lane 0 rewrites the executors' records. One at a time on lane 0 this was ~8 k ticks per executor - the dependent HBM
+// round trips of trk_move_executor_to_pool - and up to 50 executors long: ~100 k ticks of the slowest envs' steps at
+// BASELINE config 3. Returns false, with nothing modified, when the run has to go one at a time (64 executors: two
+// 512-byte tables do not fit the staging areas).
+SSS_DEV bool fulfil_common_wave(int from, int to) {
+  UTRACE("fulfil_common_wave");
+  PROF3(39);
+  const int lane = wave_lane();
+  const int n = to - from;
+  // ---- reads ----
+  const uint32_t src = g_hot.h.curr_source;
+  const int n_commits = g_hot.h.n_commits;
+  const bool c_mine = lane < n_commits && g_hot.c_src[lane] == src && g_hot.c_dst[lane] == POOL_COMMON;
+  const int c_num = g_hot.c_n[lane];
+  const int j = key_job(src), s = key_stage(src);
+  bool moves = false, is_sat = false;
+  SssJob* jp = nullptr;
+  if (src != POOL_NONE && src != POOL_COMMON) {
+    jp = jobp(j);
+    is_sat = (int)jp->sat_count == (int)jp->n_stages;  // JOB:53-55
+    moves = s >= 0 || is_sat;                          // ENV:766-769: a job's pool keeps its executors while the job has work
+  }
+  const uint32_t dstp = is_sat ? POOL_COMMON : key_job_pool(j);
+  const uint64_t cm = wave_ballot(c_mine);
+  if (wave_ballot(!(n > 0 && src != POOL_NONE && g_c.E < 64 && cm != 0 && (cm & (cm - 1)) == 0)) != 0) return false;
+  const int ci = ctz64_nz(cm);
+  const int c_left = (int)wave_readlane_u32((uint32_t)c_num, ci) - n;
+  if (wave_ballot(c_left < 0) != 0) return false;
+  // ---- from here on the items are consumed ----
+  uint64_t moved_m = 0;
+  if (moves) {
+    const PoolPairRegs pr = pool_pair_fetch(src, dstp, true);
+    PairImg so, sn;
+    pool_pair_stage(pr, true, so, sn);
+    for (int i = from; i < to; i++) {  // (wave-uniform: every lane reads the list)
+      const uint32_t e = g_sc.fi_e[i];
+      moved_m |= bit64((int)e);
+      bool was = pair_remove(so, e);  // TRK:188-222
+      CHECK(was);
+      pair_add(sn, e);
+    }
+    so.s.aux -= (uint32_t)n;  // the source's outgoing commitments (TRK:159-176)
+    wave_sync();
+    pool_pair_flush_one(src, so);
+    pool_pair_flush_one(dstp, sn);
+  }
+  if (lane == 0) {
+    SssHdr& h = g_hot.h;
+    if (!moves) {
+      SssPoolHdr* hd = g_c.pool_hdr + pool_index(src);
+      hd->commit_from = (int16_t)(hd->commit_from - n);
+      CHECK(hd->commit_from >= 0);
+    }
+    if (j >= 0) {  // commitments of a job's executors to the common pool counted as its supply (TRK:146-154, 159-176)
+      h.supply_none -= n;
+      CHECK(h.supply_none >= 0);
+    }
+    g_hot.c_n[ci] = (int16_t)c_left;
+    if (c_left == 0) {  // dict.pop: swap-remove, the order lives in c_seq
+      const int last = h.n_commits - 1;
+      g_hot.c_src[ci] = g_hot.c_src[last], g_hot.c_dst[ci] = g_hot.c_dst[last], g_hot.c_n[ci] = g_hot.c_n[last], g_hot.c_seq[ci] = g_hot.c_seq[last];
+      h.n_commits = last;
+    }
+    if (moves) {
+      for (int i = from; i < to; i++) {
+        const int e = g_sc.fi_e[i];
+        g_hot.ex_loc[e] = dstp;
+        if (dstp == POOL_COMMON) g_hot.ex_job[e] = -1, g_hot.ex_task_stage[e] = -1;  // JOB:86-89
+      }
+      if (dstp == POOL_COMMON) {
+        CHECK((jp->local_mask & moved_m) == moved_m);
+        jp->local_mask &= ~moved_m;
+      }
+    }
+  }
+  wave_sync();
+  return true;
+}
+
 // ENV:730-743, second half (all lanes): lane-parallel chunks while the list allows, the rest one at a time
 SSS_DEV void fulfil_run() {
+  PROF3(33);
   const int m = g_sc.fi_m, m_par = g_sc.fi_m_par;
   int done = 0;
 #ifndef SSS_NO_BATCH
@@ -1836,6 +2028,11 @@ SSS_DEV void fulfil_run() {
     }
     STAT(53, 1), STAT(55, n);
     done += n;
+  }
+  // the commitments to the common pool (a suffix of the list): one source, one destination - with the whole wave
+  if (done == m_par && m_par < m && wave_ballot(g_hot.h.err != 0) == 0 && fulfil_common_wave(m_par, m)) {
+    STAT(123, 1), STAT(124, m - m_par);
+    done = m;
   }
 #endif
   STAT(56, m - done);
@@ -2012,6 +2209,7 @@ SSS_DEV void handle_task_completion(int e, int j, int s) {  // ENV:452-483
 // executor, lexicographic min over (time, push counter) on the DPP network - no LDS round trips
 // beyond the one read of the slots. All lanes call it; every lane gets the same result.
 SSS_DEV int pop_event_wave(double next_arrival_t, double& t_win, uint32_t& info_win) {
+  PROF3(37);
   int lane = wave_lane();
 #ifdef SSS_WIDE
   {
@@ -2167,6 +2365,7 @@ SSS_DEV int fast_task_completion(const FastCtx& f, int ex, double t_ev, int j, i
 // ------------------------------------------------------------------------------------------
 #define FR_OUT 0x40000000u  // rank of a lane whose event is not in the window (never counts down to the head's rank, 1)
 SSS_DEV int fast_run(const FastCtx& f) {
+  UTRACE("fast_run");
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
   return 0;
 #endif
@@ -2437,6 +2636,15 @@ SSS_DEV int fast_run(const FastCtx& f) {
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
 #define RL_NO_COMMITMENT 0xFFu  // rl_idx of a member whose pool holds no commitment
+// candidates in the window below which the events go one by one (lean_released / lean_arrival). Measured at BASELINE config 3,
+// step launches (profiles/r04_bench.md): 2 / 2 0.342 ms, 3 / 2 0.343, 4 / 3 0.346, 6 / 3 0.351 - a batch of two already beats two
+// single events; config 2 does not care (0.171 ms throughout)
+#ifndef SSS_MIN_RELEASED_BATCH
+#define SSS_MIN_RELEASED_BATCH 2
+#endif
+#ifndef SSS_MIN_ARRIVAL_BATCH
+#define SSS_MIN_ARRIVAL_BATCH 2
+#endif
 // One lane per pool (batch_released_events): every member of ranks [0, n) that leaves pool `okey` is taken out
 // of it - one fetch and one store of the pool's record; removals commute - and the pool's outgoing
 // commitments shrink by as many.
@@ -2530,6 +2738,7 @@ SSS_DEV bool any_schedulable_without_source() {
   return wave_ballot(any) != 0;
 }
 SSS_DEV int batch_released_events(const FastCtx& f, int head) {
+  UTRACE("batch_released");
 #ifdef SSS_NO_BATCH
   return 0;
 #endif
@@ -2558,7 +2767,8 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if ((pre & (pre - 1)) == 0 || !((pre >> head) & 1ull)) { STAT(64, 1); return 0; }  // none, a single one (the one-event path is as fast), or not the head
+    // none or too few (a single one goes the wave-uniform single-event way, lean_released), or not the head
+    if (popc64(pre) < SSS_MIN_RELEASED_BATCH || !((pre >> head) & 1ull)) { STAT(64, 1); return 0; }
   }
   PROF3_SEC(1);
   // the commitment its pool would serve first (TRK:178-183: the first-inserted one of that source)
@@ -2901,10 +3111,12 @@ SSS_DEV bool pool_pass_many(uint32_t jkey, uint32_t n) {
 }
 
 SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
+  UTRACE("batch_arrival");
 #ifdef SSS_NO_BATCH
   return 0;
 #endif
   PROF3(20);
+  PROF3_SEC_BEGIN;
   const int lane = wave_lane();
   // ---- reads ----
   const SssEvSlot sl = g_hot.ev[lane];
@@ -2921,8 +3133,9 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if (!((pre >> head) & 1ull)) { STAT(80, 1); return 0; }  // not the head (a single member is fine: this path is cheaper than the general handler)
+    if (popc64(pre) < SSS_MIN_ARRIVAL_BATCH || !((pre >> head) & 1ull)) { STAT(80, 1); return 0; }  // none, too few (lean_arrival), or not the head
   }
+  PROF3_ASEC(1);
   SssStage st = {0, 0, 0, 0};
   const SssJob* jpc = f.cjobs + (cand ? slot : 0);
   int gs = 0, n_base = 0, type = AR_START;
@@ -2938,12 +3151,14 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   }
   const bool start = type == AR_START;
   if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(81, 1); return 0; }  // the head of the queue has to be a member
+  PROF3_ASEC(2);
   const double key = cand ? sl.t + push_lb : sl.t;
   double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
   uint64_t vm = wave_ballot(V);
   if (vm == 0) { STAT(82, 1); return 0; }
+  PROF3_ASEC(3);
   // who comes before this member, who shares its job / its stage
   uint64_t before = 0, same_job = 0, same_stage = 0;
   for (uint64_t m = vm; m; m &= m - 1) {
@@ -2956,6 +3171,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     same_job |= info_job(ik) == j ? bit64(k) : 0ull;
     same_stage |= ((ik ^ info) >> 8) == 0 ? bit64(k) : 0ull;
   }
+  PROF3_ASEC(4);
   // the executor count of the job when this member draws (JOB:81-84: every member before it has been attached)
   const int n_local = n_base + popc64(before & same_job) + 1;
   int li = 0, ri = 0;
@@ -3016,6 +3232,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
   const uint64_t mm = (uint64_t)u32 * len;
   if (wave_ballot(vx && (uint32_t)mm < len) != 0) { STAT(84, 1); return 0; }
+  PROF3_ASEC(5);
   // ---- commit ----
   const uint32_t jkey = key_job_pool(j), skey = key_stage_pool(j, s);
   if (V) {
@@ -3058,10 +3275,35 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     }
   }
   wave_sync();
+  PROF3_ASEC(6);
   // pools: one lane per pool. The first member of a job speaks for the job's pool, the first starter of a
   // stage for the stage's
   bool def_job = false, def_stage = false;
-  if (V) {
+  // every member arrives at the same stage (executors of one fulfilment; a single member): the job's pool and the stage's are
+  // the only two images involved - both through the pair staging, one HBM round trip for the batch (fewer than 64 executors)
+  const bool one_stage = f.E < 64 && wave_ballot(V && same_stage != vm) == 0;
+  if (one_stage) {
+    const int l0 = ctz64_nz(vm);
+    const uint32_t jk = wave_readlane_u32(jkey, l0), sk = wave_readlane_u32(skey, l0);
+    const bool starts = n_x != 0;  // (the members of one stage all start, or all park)
+    PROF3_ASEC(7);
+    const PoolPairRegs pr = pool_pair_fetch(jk, sk, starts);
+    PairImg sj, ss;
+    pool_pair_stage(pr, starts, sj, ss);
+    PROF3_ASEC(10);
+    for (uint32_t q = 0; q < n; q++) {  // rank order (wave-uniform: every lane reads the list)
+      const uint32_t e = g_sc.fi_e[q];
+      pair_add(sj, e);  // ENV:446: into the job's pool ...
+      bool was = pair_remove(sj, e);  // ... and out again (the move to the stage's pool), or - parked - out and back in (TRK:188-222 with old == new)
+      CHECK(was);
+      if (starts) pair_add(ss, e); else pair_add(sj, e);
+    }
+    wave_sync();
+    PROF3_ASEC(11);
+    pool_pair_flush_one(jk, sj);
+    if (starts) pool_pair_flush_one(sk, ss);
+    PROF3_ASEC(12);
+  } else if (V) {
     if ((before & same_job) == 0) def_job = !pool_pass_many(jkey, n);
     if (start && cb_take == 0) def_stage = !pool_enter_many(skey, n);
   }
@@ -3073,8 +3315,11 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   uint64_t dj = wave_ballot(def_job), ds = wave_ballot(def_stage);
   STAT(34, 1), STAT(35, n), STAT(36, popc64(dj)), STAT(37, popc64(ds)), STAT(38, n - n_x);
   wave_sync();
+  PROF3_ASEC(7);
   pools_staged<STAGED_PASS>(dj, n, V ? jkey : POOL_NONE, !start);  // tables with more than 8 slots, or about to grow
+  PROF3_ASEC(8);
   pools_staged<STAGED_ENTER>(ds, n, (V && start) ? skey : POOL_NONE, false);
+  PROF3_ASEC(9);
   // saturation bit of the stage (ENV:566-582), by its last member: arrivals that start a task leave the
   // demand what it was, parked ones raise it
   if (V && cb_stage + 1 == ct_stage) {
@@ -3087,6 +3332,374 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   }
   wave_sync();
   return (int)n;
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE released executor (all lanes, wave-uniform control flow): TASK_FINISHED on a stage with no task left to start,
+// not the stage's last running task, the stage's pool holding a commitment - what batch_released_events does for
+// several such events at once, for the single one that heads the queue (most of them are alone: the batch declines,
+// and the lane-0 handlers - handle_task_completion -> fulfill_commitment -> move_executor_to_stage ->
+// trk_move_executor_to_pool -> execute_next_task - took ~14 k ticks per event in the slowest envs of a config-3 launch,
+// nearly half of it the dependent HBM round trips of the two pool images). Here every lane reads the same state and
+// takes the same decisions; the commitment is found with one ballot over the list (one entry per lane); both pool
+// images come in with one round trip (pool_pair_*), the duration descriptor rides along, the draw is computed from
+// the buffered raw outputs before anything is modified (a draw that needs Lemire's rejection loop goes the general way),
+// and lane 0 writes the scalars. By destination of the commitment (ENV:639-660, 699-712, 784-819):
+//   START  a stage of the same job that is in the frontier: into its pool, a task starts (ENV:584-615, TPCH:75-106);
+//   PARK   ... not in the frontier yet: into the job's pool (ENV:808-813);
+//   SEND   a stage of another job (whose records are cached): detached, EXECUTOR_READY after moving_delay (ENV:617-637);
+//   IDLE   the common pool: into the job's pool, or - the job being saturated - detached into the common pool (ENV:745-782).
+// Left to the general handlers: no commitment (the executor becomes the source), the event that completes its stage, a
+// destination stage out of tasks (backup scheduling), an executor that would enter the current source (it becomes
+// committable), 64 executors (two 512-byte tables do not fit the staging areas), lists that draw nothing.
+// Returns 1 = the event is consumed, 0 = nothing was modified.
+// ------------------------------------------------------------------------------------------
+SSS_DEV int lean_released(const FastCtx& f, int ex, double t_ev, uint32_t info) {
+  UTRACE("lean_released");
+#ifdef SSS_NO_BATCH
+  return 0;
+#endif
+  PROF3(32);
+  const int lane = wave_lane();
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info), j = info_job(info);
+  // Every lane reads the same words and takes the same decisions. A "no" sends lane 0 into the general handler, which
+  // rewrites the state the lanes look at: so every decision is taken by a ballot - all lanes have evaluated it, on the
+  // same state, before any lane acts on it (shared state is read before the collective that guards its use).
+  // ---- reads ----
+  const SssStage st_old = f.cstages[slot * f.SP + s];
+  const uint32_t source = g_hot.h.curr_source;
+  const int n_commits = g_hot.h.n_commits;
+  const int A = g_hot.h.n_active;
+  const uint32_t counter0 = g_hot.h.counter;
+  uint32_t h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  const uint32_t sp = key_stage_pool(j, s);
+  const bool mine = st_old.remaining == 0 && st_old.executing >= 2 && g_hot.ex_job[ex] == j && f.E < 64;  // (64 executors: two 512-byte tables)
+  const bool c_mine = mine && lane < n_commits && g_hot.c_src[lane] == sp;
+  const uint32_t c_seq = g_hot.c_seq[lane], c_dst = g_hot.c_dst[lane];
+  const int c_num = g_hot.c_n[lane];
+  // the commitment its pool serves first (TRK:178-183: the first-inserted entry of that source)
+  const uint64_t cm = wave_ballot(c_mine);
+  STAT(120, 1), STAT(121, cm == 0);
+  if (cm == 0) return 0;
+  int ci = ctz64_nz(cm);
+  if (cm & (cm - 1)) {
+    const uint32_t best = wave_min_u32(c_mine ? c_seq : 0xFFFFFFFFu);
+    ci = ctz64_nz(wave_ballot(c_mine && c_seq == best));
+  }
+  const uint32_t dst = wave_readlane_u32(c_dst, ci);
+  const int c_left = (int)wave_readlane_u32((uint32_t)c_num, ci) - 1;
+  SssJob* const jp = f.cjobs + slot;
+  const bool job_sat = (int)jp->sat_count == (int)jp->n_stages;  // JOB:53-55
+  const int j2 = key_job(dst), s2 = key_stage(dst);  // the stage the commitment names (-1, -1: the common pool)
+  bool ok = dst != sp && (dst == POOL_COMMON || s2 >= 0);
+  // where the executor goes: the committed stage - or, that stage having no task left, a backup stage (ENV:784-797, 821-845)
+  int tj = j2, ts = s2;
+  bool backup = false;
+  if (ok && dst != POOL_COMMON) {
+    const SssStage st_c = j2 == j ? f.cstages[slot * f.SP + s2] : *stgp(j2, s2);
+    backup = st_c.remaining <= 0;
+  }
+  if (backup) {  // (wave-uniform) _find_backup_stage: the executor's own job first, then the others in arrival order
+    tj = -1, ts = -1;
+    const int srcj = j <= 0 ? trk_source_job_id() : j;  // `if not source_job_id` (ENV:521): job id 0 is falsy
+    uint64_t m_own = 0;
+    if (j == srcj || (int)jp->supply < f.E) m_own = ready_mask_of_job(*jp, true);
+    if (m_own)
+      tj = j, ts = ctz64_nz(m_own);
+    else {
+      const int n_others = A - (jp->active_mask != 0 ? 1 : 0);  // an empty list of others means "all active jobs" (ENV:518-519)
+      for (int a0 = 0; a0 < A && tj < 0; a0 += 64) {
+        const int a = a0 + lane;
+        int jj = -1, ss = -1;
+        if (a < A) {
+          jj = lds_active()[a];
+          if (!(n_others > 0 && jj == j)) {
+            const SssJob* q = jobp(jj);
+            // (the commitment is settled before the search, TRK:159-176: the committed stage's job counts one executor fewer)
+            if (jj == srcj || (int)q->supply - ((jj == j2 && j2 != j) ? 1 : 0) < f.E) {
+              const uint64_t m = ready_mask_of_job(*q, true);
+              if (m) ss = ctz64_nz(m);
+            }
+          }
+        }
+        const uint64_t hm = wave_ballot(ss >= 0);
+        if (hm) tj = (int)wave_readlane_u32((uint32_t)jj, ctz64_nz(hm)), ts = (int)wave_readlane_u32((uint32_t)ss, ctz64_nz(hm));
+      }
+    }
+  }
+  // what becomes of it
+  int type;
+  uint32_t tslot = slot;
+  SssStage st_t = {0, 0, 0, 0};
+  if (tj < 0)  // the common pool was committed to, or no backup stage: ENV:745-782 with a list of one
+    type = job_sat ? RL_IDLE_COMMON : RL_IDLE_JOB;
+  else {
+    if (tj != j) tslot = f.slot_of[tj];  // another job: its records have to be cached
+    if (tslot == SLOT_NONE) {
+      ok = false, type = RL_SEND;
+    } else {
+      st_t = f.cstages[tslot * f.SP + ts];
+      ok = ok && st_t.remaining > 0;
+      type = tj != j ? RL_SEND : ((jp->frontier_mask & bit64(ts)) ? RL_START : RL_PARK);
+    }
+  }
+  const uint32_t enters = type == RL_START ? key_stage_pool(j, ts) : (type == RL_SEND ? POOL_NONE : (type == RL_IDLE_COMMON ? POOL_COMMON : key_job_pool(j)));
+  // an executor that enters the source would become committable (ENV:331-338, TRK:107-113): general path
+  ok = ok && (source == POOL_NONE || enters != source);
+  // everything that comes from HBM is asked for here, in one go: both pool images now (whether or not the event will go this
+  // way: loads are harmless), the duration descriptors below - their round trips overlap
+  const PoolPairRegs pr = pool_pair_fetch(sp, enters, enters != POOL_NONE);
+  const bool start = ok && type == RL_START;
+  int n_local = 0, li = 0, ri = 0;
+  int4 da = mk_i4(0, 0, 0, 0), db = da;
+  if (start) {  // TPCH:75-106: the executor's last task was on another stage of the job ("first_wave" mode)
+    n_local = popc64(jp->local_mask);
+    ok = n_local > 0 && n_local <= f.E && ts != s;
+    if (ok) {
+      executor_interval(n_local, li, ri);
+      const int gs2 = jp->gs_base + ts;
+      da = *(const int4*)(f.eff + (((size_t)gs2 * 8 + li) * 3 + 2) * 4);
+      db = li != ri ? *(const int4*)(f.eff + (((size_t)gs2 * 8 + ri) * 3 + 2) * 4) : da;
+      ok = (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;  // lists that draw nothing / fail: one at a time
+    }
+  }
+  const bool refill = start && ok && g_sc.rng_pos > 62;  // (a draw takes up to two raw outputs)
+  STAT(122, !ok);
+  if (wave_ballot(!ok) != 0) return 0;
+  if (refill) rng_refill();
+  // the draw, from the buffered raw outputs (TPCH:216-235, numpy's buffered 32-bit Lemire path)
+  int pos = g_sc.rng_pos;
+  double dur = 0.0;
+  bool reject = false;
+  if (start) {
+    int4 dd = da;
+    if (li != ri) {
+      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos]) * (right - left));
+      pos += 1;
+      if (!((double)rand_pt <= (double)n_local - left)) dd = db;
+    }
+    uint32_t u32;
+    if (h0)
+      u32 = u32_0, h0 = 0;
+    else {
+      const uint64_t x = g_sc.rng_buf[pos];
+      pos += 1;
+      u32 = (uint32_t)x, u32_0 = (uint32_t)(x >> 32), h0 = 1;
+    }
+    const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
+    const uint64_t mm = (uint64_t)u32 * len;
+    reject = (uint32_t)mm < len;  // Lemire's rejection test would loop: one at a time
+    dur = (double)f.durations[dd.x + (int)(mm >> 32)];
+    if (dd.y >> 30) dur += g_c.P.warmup_delay;
+  }
+  if (wave_ballot(reject) != 0) return 0;
+  STAT(111, 1), STAT(112 + type, 1), STAT(117, backup);
+  // ---- nothing has been modified up to here; from here on the event is consumed ----
+  PairImg so, sn;
+  pool_pair_stage(pr, enters != POOL_NONE, so, sn);
+  {
+    bool was = pair_remove(so, (uint32_t)ex);  // TRK:188-222
+    CHECK(was);
+    so.s.aux -= 1;  // the pool's outgoing commitments (TRK:159-176)
+    if (enters != POOL_NONE) pair_add(sn, (uint32_t)ex);
+    wave_sync();
+    pool_pair_flush_one(sp, so);
+    if (enters != POOL_NONE) pool_pair_flush_one(enters, sn);
+  }
+  if (lane == 0) {
+    SssHdr& h = g_hot.h;
+    h.wall_time = t_ev;
+    h.n_events += 1, h.n_batched += 1, h.n_rounds += 1;
+    g_sc.events_this_step += 1;
+    // the stage it leaves (STG:60-62)
+    f.cstages[slot * f.SP + s].executing = (int16_t)(st_old.executing - 1);
+    // the commitment (TRK:159-176): dict.pop when it is used up - swap-remove, the order lives in c_seq
+    g_hot.c_n[ci] = (int16_t)c_left;
+    if (c_left == 0) {  // (entry `last` may be this one: the dead entry's bytes are what trk_remove_commitment leaves)
+      const int last = h.n_commits - 1;
+      g_hot.c_src[ci] = g_hot.c_src[last], g_hot.c_dst[ci] = g_hot.c_dst[last], g_hot.c_n[ci] = g_hot.c_n[last], g_hot.c_seq[ci] = g_hot.c_seq[last];
+      h.n_commits = last;
+    }
+    if (dst == POOL_COMMON) {
+      h.supply_none -= 1;  // a commitment to the common pool counted as its supply (TRK:146-154, 159-176)
+      CHECK(h.supply_none >= 0);
+    } else {  // the committed stage: one commitment fewer; another job's executor count: one fewer (TRK:159-176)
+      const JobView v = jobview(j2);
+      const int c = (int)v.st[s2].commit_to - 1;
+      CHECK(c >= 0);
+      v.st[s2].commit_to = (int16_t)c;
+      update_sat(v, s2);
+      if (j2 != j) v.job->supply = (int16_t)(v.job->supply - 1);
+    }
+    uint32_t new_info = EV_NONE;
+    double new_t = __builtin_inf();
+    if (tj >= 0) {  // the stage it goes to
+      SssStage* spt = f.cstages + tslot * f.SP + ts;
+      SssJob* jpt = f.cjobs + tslot;
+      SssStage t2 = *spt;
+      if (type == RL_START) {
+        t2.remaining = (int16_t)(t2.remaining - 1), t2.executing = (int16_t)(t2.executing + 1);  // STG:53-58
+        if (t2.remaining == 0) jpt->sat_count = (int16_t)(jpt->sat_count + 1);  // ENV:595-597
+        f.cdur[slot * f.SP + ts] = (float)dur;  // ENV:604
+        new_t = t_ev + dur, new_info = ev_info(EV_TASK_FINISHED, j, ts, slot);
+        g_sc.rng_pos = pos, h.rng_has32 = h0, h.rng_u32 = u32_0;
+      } else if (type == RL_SEND) {
+        t2.moving_to = (int16_t)(t2.moving_to + 1);        // TRK:206-216
+        jpt->supply = (int16_t)(jpt->supply + 1);          // the new job's executor count ...
+        jp->supply = (int16_t)(jp->supply - 1);            // ... and the old one's (TRK:218-221)
+        new_t = t_ev + g_c.P.moving_delay, new_info = ev_info(EV_EXECUTOR_READY, tj, ts, tslot);
+      }
+      *spt = t2;
+      const int demand = (int)t2.remaining - ((int)t2.moving_to + (int)t2.commit_to);  // ENV:566-582
+      const uint64_t m = jpt->sat_mask;
+      jpt->sat_mask = demand <= 0 ? (m | bit64(ts)) : (m & ~bit64(ts));
+    }
+    // the executor
+    g_hot.ex_executing[ex] = type == RL_START ? 1 : 0;
+    g_hot.ex_loc[ex] = enters;
+    if (type == RL_START) g_hot.ex_task_stage[ex] = (int8_t)ts;
+    if (type == RL_PARK) g_hot.ex_task_stage[ex] = -1;  // ENV:808-813
+    if (type == RL_SEND || type == RL_IDLE_COMMON) {      // JOB:86-89
+      jp->local_mask &= ~bit64(ex);
+      g_hot.ex_job[ex] = -1, g_hot.ex_task_stage[ex] = -1;
+    }
+    // its event slot and the cache-slot references of the events' jobs
+    SssEvSlot sl;
+    sl.t = new_t, sl.seq = counter0, sl.info = new_info;
+    if (new_info == EV_NONE) sl.seq = g_hot.ev[ex].seq;
+    g_hot.ev[ex] = sl;
+    if (new_info != EV_NONE) h.counter = counter0 + 1;
+    if (type != RL_START) {
+      lds_slot_ref()[slot]--;
+      if (type == RL_SEND) lds_slot_ref()[tslot]++;
+    }
+  }
+  wave_sync();
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE arriving executor (all lanes, wave-uniform control flow): EXECUTOR_READY (ENV:440-450) for a job whose records
+// are cached - the single-member case of batch_arrival_events without the batch machinery (window, ranking, per-pool
+// leaders), in the style of lean_released: decisions by ballot on state every lane reads alike, both pool images (the
+// job's, which the executor passes through, and the stage's) with one round trip, the idle executor's duration draw
+// (TPCH:88-94: fresh durations, else first wave + warmup_delay) from the buffered raw outputs before anything is modified.
+//   START  the stage is in the frontier and has a task left: into the stage's pool, a task starts (ENV:584-615);
+//   PARK   not in the frontier yet: it waits in the job's pool (ENV:808-813).
+// Left to the general handler: a stage out of tasks (backup scheduling, ENV:784-797), an executor that would stay in the
+// current source (it becomes committable), 64 executors, lists that draw nothing, a draw that needs Lemire's loop.
+// Returns 1 = the event is consumed, 0 = nothing was modified.
+// ------------------------------------------------------------------------------------------
+SSS_DEV int lean_arrival(const FastCtx& f, int ex, double t_ev, uint32_t info) {
+  UTRACE("lean_arrival");
+#ifdef SSS_NO_BATCH
+  return 0;
+#endif
+  PROF3(38);
+  const int lane = wave_lane();
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info), j = info_job(info);
+  // ---- reads (every lane the same words) ----
+  SssJob* const jp = f.cjobs + slot;
+  SssStage* const stp = f.cstages + slot * f.SP + s;
+  const SssStage st = *stp;
+  const uint32_t source = g_hot.h.curr_source;
+  const uint32_t counter0 = g_hot.h.counter;
+  uint32_t h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
+  const uint64_t local = jp->local_mask;
+  const bool start = (jp->frontier_mask & bit64(s)) != 0;
+  const uint32_t jkey = key_job_pool(j), skey = key_stage_pool(j, s);
+  const PoolPairRegs pr = pool_pair_fetch(jkey, skey, start);  // (asked for right away: its round trip overlaps the descriptors')
+  // with a source pool set, an executor that stays in it would become committable (ENV:331-338): general path
+  bool ok = f.E < 64 && st.remaining > 0 && st.moving_to > 0 && g_hot.ex_task_stage[ex] < 0 && (source == POOL_NONE || source != (start ? skey : jkey));
+  const int n_local = popc64(local) + 1;  // JOB:81-84: the executor is attached before it draws
+  int li = 0, ri = 0;
+  int4 da = mk_i4(0, 0, 0, 0), db = da;
+  if (ok && start) {
+    ok = n_local <= f.E;
+    if (ok) {
+      executor_interval(n_local, li, ri);
+      const int gs = jp->gs_base + s;
+      da = *(const int4*)(f.eff + (((size_t)gs * 8 + li) * 3 + 0) * 4);
+      db = li != ri ? *(const int4*)(f.eff + (((size_t)gs * 8 + ri) * 3 + 0) * 4) : da;
+      ok = (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
+    }
+  }
+  const bool refill = ok && start && g_sc.rng_pos > 62;
+  if (wave_ballot(!ok) != 0) return 0;
+  if (refill) rng_refill();
+  int pos = g_sc.rng_pos;
+  double dur = 0.0;
+  bool reject = false;
+  if (start) {
+    int4 dd = da;
+    if (li != ri) {
+      const double left = (double)exec_level_value(li), right = (double)exec_level_value(ri);
+      const int rand_pt = 1 + (int)(u64_to_unit(g_sc.rng_buf[pos]) * (right - left));
+      pos += 1;
+      if (!((double)rand_pt <= (double)n_local - left)) dd = db;
+    }
+    uint32_t u32;
+    if (h0)
+      u32 = u32_0, h0 = 0;
+    else {
+      const uint64_t x = g_sc.rng_buf[pos];
+      pos += 1;
+      u32 = (uint32_t)x, u32_0 = (uint32_t)(x >> 32), h0 = 1;
+    }
+    const uint32_t len = (uint32_t)(dd.y & LENW_LEN);
+    const uint64_t mm = (uint64_t)u32 * len;
+    reject = (uint32_t)mm < len;
+    dur = (double)f.durations[dd.x + (int)(mm >> 32)];
+    if (dd.y >> 30) dur += g_c.P.warmup_delay;
+  }
+  if (wave_ballot(reject) != 0) return 0;
+  STAT(125, 1), STAT(126, start);
+  // ---- from here on the event is consumed ----
+  PairImg sj, ss;
+  pool_pair_stage(pr, start, sj, ss);
+  {
+    pair_add(sj, (uint32_t)ex);  // ENV:446: into the job's pool ...
+    bool was = pair_remove(sj, (uint32_t)ex);  // ... and out again, or - parked - out and back in (TRK:188-222 with old == new)
+    CHECK(was);
+    if (start) pair_add(ss, (uint32_t)ex); else pair_add(sj, (uint32_t)ex);
+    wave_sync();
+    pool_pair_flush_one(jkey, sj);
+    if (start) pool_pair_flush_one(skey, ss);
+  }
+  if (lane == 0) {
+    SssHdr& h = g_hot.h;
+    h.wall_time = t_ev;
+    h.n_events += 1, h.n_batched += 1, h.n_rounds += 1;
+    g_sc.events_this_step += 1;
+    jp->local_mask = local | bit64(ex);  // JOB:81-84
+    g_hot.ex_job[ex] = (int16_t)j;
+    SssStage t2 = st;
+    t2.moving_to = (int16_t)(t2.moving_to - 1);  // TRK:185-187
+    SssEvSlot sl = g_hot.ev[ex];
+    if (start) {
+      t2.remaining = (int16_t)(t2.remaining - 1), t2.executing = (int16_t)(t2.executing + 1);  // STG:53-58
+      if (t2.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);                      // ENV:595-597
+      f.cdur[slot * f.SP + s] = (float)dur;                                                     // ENV:604
+      sl.t = t_ev + dur, sl.seq = counter0, sl.info = ev_info(EV_TASK_FINISHED, j, s, slot);
+      h.counter = counter0 + 1;
+      g_sc.rng_pos = pos, h.rng_has32 = h0, h.rng_u32 = u32_0;
+      g_hot.ex_task_stage[ex] = (int8_t)s, g_hot.ex_executing[ex] = 1, g_hot.ex_loc[ex] = skey;
+    } else {
+      sl.t = __builtin_inf(), sl.info = EV_NONE;
+      g_hot.ex_task_stage[ex] = -1, g_hot.ex_loc[ex] = jkey;  // ENV:808-813
+      lds_slot_ref()[slot]--;  // its event is gone (a starter's new event names the job's slot again)
+    }
+    g_hot.ev[ex] = sl;
+    *stp = t2;
+    const int demand = (int)t2.remaining - ((int)t2.moving_to + (int)t2.commit_to);  // ENV:566-582
+    const uint64_t m = jp->sat_mask;
+    jp->sat_mask = demand <= 0 ? (m | bit64(s)) : (m & ~bit64(s));
+  }
+  wave_sync();
+  return 1;
 }
 
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
@@ -3445,6 +4058,7 @@ SSS_DEV void env_end(uint8_t* base) {
 // order - all lanes, one job each (the records of jobs without a cache slot come from HBM: one round trip for
 // all of them instead of one per job on lane 0). Leaves (job, stage) or (-1, -1) in the mailbox.
 SSS_DEV void select_stage_wave(int stage_idx) {
+  PROF3(34);
   const int lane = wave_lane();
   const int A = g_hot.h.n_active;
   int run = 0, fj = -1, fs = -1;
@@ -3613,6 +4227,7 @@ SSS_DEV double jobtime_sum() {
 // lane 0: one popped event. Returns 0 = keep going, 1 = queue empty / failed, 2 = a scan is needed
 // (committable executors exist).
 SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_win, uint64_t& t_slow) {
+  UTRACE("handle_popped");
   PROF3(31);
   if (ex == POP_EMPTY) return 1;
   H.n_events++;
@@ -3718,6 +4333,8 @@ SSS_DEV void resume_simulation() {
           }
 #endif
           handled = tf ? batch_released_events(f, ex) : batch_arrival_events(f, ex);
+          // a released executor on its own (the usual case): the wave-uniform single-event path
+          if (handled == 0) handled = tf ? lean_released(f, ex, t_win, info_win) : lean_arrival(f, ex, t_win, info_win);
         }
         if (handled > 0) continue;
         // nothing was touched: the popped event goes the one-at-a-time way, which is always right

@@ -21,8 +21,23 @@
 SSS_DEV int wave_lane() { return (int)threadIdx.x; }
 SSS_DEV int wave_env() { return (int)blockIdx.x; }
 
-// workgroup == one wave: s_barrier is free, what matters is the LDS/global fence
+// Ordering point between the lanes of the env's wave: what any lane wrote to LDS or global memory before it is what every
+// lane reads after it. The workgroup IS one wavefront (SSS_KERNEL: 64 threads), so the synchronisation scope is "wavefront":
+// a wave's LDS operations execute in issue order and its vector memory operations reach the L1 in issue order, which is why
+// the AMDGPU memory model needs no instruction at all for a wavefront-scope release / acquire - the pair below only keeps the
+// COMPILER from moving or caching memory accesses across the point. __syncthreads() here meant s_waitcnt vmcnt(0) lgkmcnt(0)
+// at every one of the hundreds of ordering points of a step: a full HBM round trip whenever a store was in flight (gfx9
+// counts stores in vmcnt) - in the slowest envs of a launch that was most of what the lane-parallel paths waited for.
+// -DSSS_SYNC_WORKGROUP restores the workgroup-scope form (A/B comparisons).
+#ifdef SSS_SYNC_WORKGROUP
 SSS_DEV void wave_sync() { __syncthreads(); }
+#else
+SSS_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
 
 // ordering point inside ONE wavefront of a larger workgroup: earlier LDS / global writes of any lane
 // are visible to every lane afterwards; no workgroup barrier (other wavefronts are not involved)

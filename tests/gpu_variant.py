@@ -7,7 +7,13 @@ import os
 import os.path as osp
 
 HERE = osp.dirname(osp.abspath(__file__))
-VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",)}
+VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
+            # timing builds for tools/debug/evprof3.py (scoped profiler of the lane-0 procedures, csrc/sss_prof.h)
+            "evprof3": ("-DSSS_EVPROF3",), "evprof3b": ("-DSSS_EVPROF3", "-DSSS_EVPROF3B"), "evprof3c": ("-DSSS_EVPROF3", "-DSSS_EVPROF3C"),
+            "evprof3d": ("-DSSS_EVPROF3", "-DSSS_EVPROF3D"),
+            # batch-size thresholds of the event loop (A/B timing: copied over the product library on the GPU box by hand)
+            "thr22": ("-DSSS_MIN_RELEASED_BATCH=2", "-DSSS_MIN_ARRIVAL_BATCH=2"), "thr32": ("-DSSS_MIN_RELEASED_BATCH=3", "-DSSS_MIN_ARRIVAL_BATCH=2"),
+            "thr63": ("-DSSS_MIN_RELEASED_BATCH=6", "-DSSS_MIN_ARRIVAL_BATCH=3")}
 
 
 def variant_path(name: str) -> str:
@@ -24,3 +30,11 @@ def build_variant(name: str, verbose: bool = False) -> str:
 
 def load_variant(name: str) -> ctypes.CDLL:
     return ctypes.CDLL(build_variant(name))
+
+
+if __name__ == "__main__":  # python tests/gpu_variant.py evprof3 ...: build ahead of a gpurun call (the .so travels with the snapshot)
+    import sys
+
+    sys.path.insert(0, osp.dirname(HERE))
+    for n in sys.argv[1:]:
+        print(build_variant(n, verbose=False))
