@@ -2086,9 +2086,27 @@ SSS_DEV int cache_acquire(int j) {  // HBM -> LDS if the job has no slot yet; re
   k = ctz64(g_sc.free_slots);
   g_sc.free_slots &= g_sc.free_slots - 1;
   lds_cjobs()[k] = g_c.jobs[j];
-  for (int s = 0; s < g_c.SP; s++) {
-    lds_cstages()[k * g_c.SP + s] = g_c.stages[j * g_c.SP + s];
-    lds_cdur()[k * g_c.SP + s] = g_c.durations[j * g_c.SP + s];
+  {
+    // stage counters (SP x 8 bytes) and recent durations (SP x 4 bytes; SP is even) as 64-bit words, eight HBM loads in
+    // flight before the first LDS store: written as one load-store loop every word was a round trip of its own (the
+    // compiler keeps the loop's loads behind its stores) - ~25 k ticks per miss at 18 stages
+    const uint64_t* gs = (const uint64_t*)(g_c.stages + j * g_c.SP);
+    const uint64_t* gd = (const uint64_t*)(g_c.durations + j * g_c.SP);
+    uint64_t* ls = (uint64_t*)(lds_cstages() + k * g_c.SP);
+    uint64_t* ld = (uint64_t*)(lds_cdur() + k * g_c.SP);
+    const int nw = g_c.SP + g_c.SP / 2;
+    for (int w0 = 0; w0 < nw; w0 += 8) {
+      uint64_t v[8];
+      SSS_UNROLL8 for (int u = 0; u < 8; u++) {
+        const int w = w0 + u;
+        v[u] = w < g_c.SP ? gs[w < g_c.SP ? w : 0] : (w < nw ? gd[w - g_c.SP] : 0ull);
+      }
+      SSS_UNROLL8 for (int u = 0; u < 8; u++) {
+        const int w = w0 + u;
+        if (w < g_c.SP) ls[w] = v[u];
+        else if (w < nw) ld[w - g_c.SP] = v[u];
+      }
+    }
   }
   lds_slot_of()[j] = (uint8_t)k;
   lds_slot_job()[k] = (uint16_t)j;
@@ -2851,35 +2869,42 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // rank among all members / among the pushers / among the starters; starters before with an open level
   // interval; members before that leave the same stage; starters before on the same new stage; members of
   // the same job before that detach from it / start a task
-  uint32_t rank, rank_p, rank_x, R, cb_old, cb_take, ct_take, det_job, start_job, stir;
-  for (;;) {
-    rank = 0, rank_p = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take = 0, det_job = 0, start_job = 0, stir = 0;
-    for (uint64_t m = vm; m; m &= m - 1) {
-      const int k = ctz64(m);
-      const double tk = wave_readlane_f64(sl.t, k);
-      const uint32_t qk = wave_readlane_u32(sl.seq, k);
-      const uint32_t ok = wave_readlane_u32(tag_old, k), nk = wave_readlane_u32(tag_new, k);
-      const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq);
-      const bool xk = (nk & 0x20000u) != 0, same_new = ((nk ^ tag_new) & 0x1FFFFu) == 0, same_old = ok == tag_old, same_job = ((ok ^ tag_old) >> 8) == 0;
-      rank += lt ? 1u : 0u;
-      rank_p += (lt && (nk & 0x100000u)) ? 1u : 0u;
-      rank_x += (lt && xk) ? 1u : 0u;
-      R += (lt && (nk & 0x40000u)) ? 1u : 0u;
-      cb_old += (lt && same_old) ? 1u : 0u;
-      cb_take += (lt && xk && same_new) ? 1u : 0u;
-      ct_take += (xk && same_new) ? 1u : 0u;
-      det_job += (lt && same_job && (nk & 0x80000u)) ? 1u : 0u;
-      start_job += (lt && same_job && xk) ? 1u : 0u;
-      stir += (lt && (nk & 0x300000u)) ? 1u : 0u;  // members before that change a stage's demand or a job's executor count
-    }
+  // One sweep over the members. Everything a member needs is a count over the members BEFORE it - except ct_take, the
+  // starters of its new stage in the whole batch, which is kept as a lane mask. When members have to go (the first one that
+  // completes its stage / finds its commitment used up / its new stage dry / depends on an earlier member of its job / runs
+  // out of buffered randomness, and everybody after it), the survivors' counts do not change - their predecessors all
+  // survive - so there is no second sweep: the mask is intersected with the survivors.
+  uint32_t rank = 0, rank_p = 0, rank_x = 0, R = 0, cb_old = 0, cb_take = 0, ct_take, det_job = 0, start_job = 0, stir = 0;
+  uint64_t take_m = 0;
+  for (uint64_t m = vm; m; m &= m - 1) {
+    const int k = ctz64(m);
+    const double tk = wave_readlane_f64(sl.t, k);
+    const uint32_t qk = wave_readlane_u32(sl.seq, k);
+    const uint32_t ok = wave_readlane_u32(tag_old, k), nk = wave_readlane_u32(tag_new, k);
+    const bool lt = tk < sl.t || (tk == sl.t && qk < sl.seq);
+    const bool xk = (nk & 0x20000u) != 0, same_new = ((nk ^ tag_new) & 0x1FFFFu) == 0, same_old = ok == tag_old, same_job = ((ok ^ tag_old) >> 8) == 0;
+    rank += lt ? 1u : 0u;
+    rank_p += (lt && (nk & 0x100000u)) ? 1u : 0u;
+    rank_x += (lt && xk) ? 1u : 0u;
+    R += (lt && (nk & 0x40000u)) ? 1u : 0u;
+    cb_old += (lt && same_old) ? 1u : 0u;
+    cb_take += (lt && xk && same_new) ? 1u : 0u;
+    take_m |= (xk && same_new) ? bit64(k) : 0ull;
+    det_job += (lt && same_job && (nk & 0x80000u)) ? 1u : 0u;
+    start_job += (lt && same_job && xk) ? 1u : 0u;
+    stir += (lt && (nk & 0x300000u)) ? 1u : 0u;  // members before that change a stage's demand or a job's executor count
+  }
+  {
     // completes its stage / the commitment is used up / the new stage runs dry / depends on an earlier member of its job / randomness
     const bool over = V && ((int)cb_old + 2 > (int)st_old.executing || (!freed && (int)cb_old >= c_cnt) || (!rests && (int)cb_take >= (int)st_new.remaining) ||
                             (start && det_job > 0) || (rests && start_job > 0) || (freed && stir > 0) || rank_x >= nmax);
-    if (wave_ballot(over) == 0) break;
-    const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
-    V = V && rank < rcut;
-    vm = wave_ballot(V);
-    if (vm == 0) { STAT(69, 1); return 0; }
+    if (wave_ballot(over) != 0) {
+      const uint32_t rcut = wave_min_u32(over ? rank : 0xFFFFFFFFu);
+      V = V && rank < rcut;
+      vm = wave_ballot(V);
+      if (vm == 0) { STAT(69, 1); return 0; }
+    }
+    ct_take = (uint32_t)popc64(take_m & vm);
   }
   PROF3_SEC(4);
   const uint32_t n = (uint32_t)popc64(vm);
@@ -2973,6 +2998,51 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   wave_sync();
   PROF3(13);
   PROF3_SEC(5);
+  // The usual batch: executors of ONE stage that finish close together - they leave the same pool, take the same commitment
+  // (the pool's first-inserted one) and go the same way. One entry of the commitment list shrinks by n, the two pool images
+  // come in with one round trip (pool_pair_*: n removals, n additions in rank order), the cache-slot references move in one go.
+  const uint32_t sp_h = wave_readlane_u32(sp, head), en_h = wave_readlane_u32(enters, head);
+  const int type_h = (int)wave_readlane_u32((uint32_t)type, head);
+  const bool uniform = f.E < 64 && wave_ballot(V && (sp != sp_h || enters != en_h || type != type_h)) == 0;
+  if (uniform) {
+    const bool freed_h = wave_readlane_u32(freed ? 1u : 0u, head) != 0;
+    const int ci_h = (int)wave_readlane_u32((uint32_t)c_idx, head);
+    const uint32_t slot_h = wave_readlane_u32(slot, head);
+    const PoolPairRegs pr = pool_pair_fetch(sp_h, en_h, en_h != POOL_NONE);
+    if (lane == 0) {
+      if (!freed_h) {  // TRK:159-176, n times: dict.pop when the entry is used up (swap-remove, the order lives in c_seq)
+        const int left = (int)g_hot.c_n[ci_h] - (int)n;
+        CHECK(left >= 0);
+        g_hot.c_n[ci_h] = (int16_t)left;
+        if (left == 0) {
+          const int last = H.n_commits - 1;
+          g_hot.c_src[ci_h] = g_hot.c_src[last], g_hot.c_dst[ci_h] = g_hot.c_dst[last], g_hot.c_n[ci_h] = g_hot.c_n[last], g_hot.c_seq[ci_h] = g_hot.c_seq[last];
+          H.n_commits = last;
+        }
+      }
+      if (type_h != RL_START) {  // their events are gone, or name another job: that many references to the old job's cache slot fewer
+        lds_slot_ref()[slot_h] = (uint8_t)(lds_slot_ref()[slot_h] - n);
+        if (type_h == RL_SEND) {
+          const uint32_t ns = info_slot(g_hot.ev[g_sc.fi_e[0]].info);
+          if (ns != INFO_SLOT_NONE) lds_slot_ref()[ns] = (uint8_t)(lds_slot_ref()[ns] + n);
+        }
+      }
+    }
+    PairImg so, sn;
+    pool_pair_stage(pr, en_h != POOL_NONE, so, sn);
+    for (uint32_t q = 0; q < n; q++) {  // rank order (wave-uniform: every lane reads the list)
+      const uint32_t e = g_sc.fi_e[q];
+      bool was = pair_remove(so, e);
+      CHECK(was);
+      if (en_h != POOL_NONE) pair_add(sn, e);
+    }
+    if (!freed_h) so.s.aux -= n;  // the pool's outgoing commitments
+    wave_sync();
+    pool_pair_flush_one(sp_h, so);
+    if (en_h != POOL_NONE) pool_pair_flush_one(en_h, sn);
+    STAT(31, 1), STAT(33, n), STAT(127, 1);
+    wave_sync();
+  } else {
   if (lane == 0) {
     // commitments (in rank order, so that entries disappear in the order the one-event path removes them) and slot references
     for (uint32_t r = 0; r < n; r++) {
@@ -3024,6 +3094,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   wave_sync();
   PROF3_SEC(7);
   pools_staged<STAGED_ENTER>(dm, n, V ? enters : POOL_NONE, false);  // tables with more than 8 slots, or about to grow
+  }
   PROF3_SEC(8);
   if (any_freed) {
     // every scan that found nothing left schedulable_stages empty (ENV:333, 505-540)
@@ -3702,6 +3773,69 @@ SSS_DEV int lean_arrival(const FastCtx& f, int ex, double t_ev, uint32_t info) {
   return 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// The executors a completing job leaves behind (all lanes), ahead of the event that completes it: when the last running
+// task of a job's last active stage finishes, _process_job_completion (ENV:682-697) flushes the idle executors parked in
+// the job's pool into the common pool (ENV:745-782: list(set) order of the idle set, TRK:188-222 + JOB:86-89 each) - on lane 0
+// that is ~8 k ticks per executor (the dependent HBM round trips of trk_move_executor_to_pool), ~60 k per completed job
+// at BASELINE config 3. Nothing between the event's pop and that flush touches the two pools or those executors, so
+// the flush is done here, with the whole wave, before the lane-0 handler runs: lane 0 builds the list (the same
+// get_idle_source_executors image), both pool images come in with one round trip (pool_pair_*), n removals and n additions
+// in list order; the handler then finds the job's pool empty and skips its own loop. Only called for a TASK_FINISHED event
+// of a cached job; does nothing unless that event completes the job.
+// ------------------------------------------------------------------------------------------
+SSS_DEV void preflush_completing_job(const FastCtx& f, uint32_t info) {
+#ifdef SSS_NO_BATCH
+  return;
+#endif
+  const int lane = wave_lane();
+  const uint32_t slot = info_slot(info);
+  const int s = info_stage(info), j = info_job(info);
+  const SssStage st = f.cstages[slot * f.SP + s];
+  const SssJob* jp = f.cjobs + slot;
+  const bool completes = st.remaining == 0 && st.executing == 1 && jp->active_mask == bit64(s) && (int)jp->sat_count == (int)jp->n_stages && f.E < 64;
+  if (wave_ballot(completes) == 0) return;
+  PROF3(40);
+  const uint32_t jkey = key_job_pool(j);
+  if (lane == 0) {
+    int m = 0;
+    if (pool_size(jkey) > 0) {
+      SetImg<uint8_t> idle = get_idle_source_executors(jkey);
+      for (uint32_t i = 0; i <= idle.mask; i++)  // list(set): ascending slot order
+        if (idle.tab[i] >= 2) g_sc.fi_e[m++] = (uint8_t)(idle.tab[i] - 2);
+    }
+    g_sc.fi_m = m;
+  }
+  wave_sync();
+  const int m = g_sc.fi_m;
+  if (m == 0) return;
+  const PoolPairRegs pr = pool_pair_fetch(jkey, POOL_COMMON, true);
+  PairImg so, sn;
+  pool_pair_stage(pr, true, so, sn);
+  uint64_t moved_m = 0;
+  for (int i = 0; i < m; i++) {
+    const uint32_t e = g_sc.fi_e[i];
+    moved_m |= bit64((int)e);
+    bool was = pair_remove(so, e);
+    CHECK(was);
+    pair_add(sn, e);
+  }
+  wave_sync();
+  pool_pair_flush_one(jkey, so);
+  pool_pair_flush_one(POOL_COMMON, sn);
+  if (lane == 0) {
+    SssJob* jw = f.cjobs + slot;
+    CHECK((jw->local_mask & moved_m) == moved_m);
+    jw->local_mask &= ~moved_m;  // JOB:86-89
+    for (int i = 0; i < m; i++) {
+      const int e = g_sc.fi_e[i];
+      g_hot.ex_loc[e] = POOL_COMMON, g_hot.ex_job[e] = -1, g_hot.ex_task_stage[e] = -1;
+    }
+  }
+  STAT(118, 1), STAT(119, m);
+  wave_sync();
+}
+
 // _find_schedulable_stages() over all active jobs (ENV:505-540): one lane per stage of a job,
 // ballot gives the job's ready mask; sat_mask makes the parent test a mask operation.
 // Returns len(schedulable_stages); lane 0 stores the per-job masks.
@@ -4335,6 +4469,8 @@ SSS_DEV void resume_simulation() {
           handled = tf ? batch_released_events(f, ex) : batch_arrival_events(f, ex);
           // a released executor on its own (the usual case): the wave-uniform single-event path
           if (handled == 0) handled = tf ? lean_released(f, ex, t_win, info_win) : lean_arrival(f, ex, t_win, info_win);
+          // the event that completes a job: the executors parked in the job's pool are flushed with the whole wave first
+          if (handled == 0 && tf) preflush_completing_job(f, info_win);
         }
         if (handled > 0) continue;
         // nothing was touched: the popped event goes the one-at-a-time way, which is always right

@@ -13,7 +13,7 @@ NAMES = {0: "batch_released_events", 1: "trk_add_commitment", 2: "trk_remove_com
          15: "process_job_completion", 16: "handle_task_completion", 17: "take_action", 18: "jobtime_build_set", 19: "cache_acquire", 20: "batch_arrival_events",
          21: "find_schedulable_all", 22: "write_observation", 23: "env_begin", 24: "env_end", 25: "jobtime_sum", 26: "resume_simulation", 27: "do_reset",
          28: "do_step", 29: "run_policy", 30: "fast_run (per EVENT)", 31: "handle_popped", 32: "lean_released", 33: "fulfil_run", 34: "select_stage_wave",
-         35: "fulfil_chunk", 36: "fulfil_order_commitments", 37: "pop_event_wave", 38: "lean_arrival", 39: "fulfil_common_wave"}
+         35: "fulfil_chunk", 36: "fulfil_order_commitments", 37: "pop_event_wave", 38: "lean_arrival", 39: "fulfil_common_wave", 40: "preflush_completing_job"}
 CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
        "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
 import os

@@ -37,7 +37,7 @@ LABEL = {1 + 93: "fast-run events", 1 + 90: "fast_run calls", 1 + 31: "released 
          1 + 56: "fulfil serial items", 1 + 110: "n_commits at single TF (sum)", 1 + 24: "single TF: no commitment", 1 + 25: "single TF: to common", 1 + 26: "single TF: send",
          1 + 27: "single TF: park", 1 + 28: "single TF: start", 1 + 29: "single TF: completes stage",
          1 + 120: "lean_released tried", 1 + 121: "  exit: not such an event / no commitment", 1 + 122: "  exit: classification", 1 + 111: "lean_released handled",
-         1 + 112: "  start", 1 + 113: "  park", 1 + 114: "  send", 1 + 115: "  idle -> job pool", 1 + 116: "  idle -> common pool", 1 + 117: "  of those: to a backup stage / none found", 1 + 125: "lean_arrival handled", 1 + 126: "  start", 1 + 123: "fulfil common suffix (wave)", 1 + 124: "  items"}
+         1 + 112: "  start", 1 + 113: "  park", 1 + 114: "  send", 1 + 115: "  idle -> job pool", 1 + 116: "  idle -> common pool", 1 + 117: "  of those: to a backup stage / none found", 1 + 125: "lean_arrival handled", 1 + 126: "  start", 1 + 118: "job completion: pool flushed by the wave", 1 + 119: "  executors", 1 + 127: "released batches: uniform path", 1 + 123: "fulfil common suffix (wave)", 1 + 124: "  items"}
 ev = rows[:, 0]
 if len(sys.argv) > 4 and sys.argv[4] == "cost":
     # bins by an estimate of the step's ticks (kilo-ticks per item from the GPU's scoped profile) instead of its events
