@@ -43,9 +43,12 @@ CONFIGS = {
     # C2 sizing = reference examples.py:15-23 (10 executors, 50 jobs); C3 = config/decima_tpch.yaml:81-85
     "c2": dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
     "c3": dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
+    # not a BASELINE config: config 3's sizing at the top of the reference's executor-level table (tpch.py:238) - more than
+    # 64 executors run on the wide instantiation of the kernels (csrc/sss_hip_wide.hip: every event one at a time)
+    "e100": dict(num_executors=100, job_arrival_cap=200, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
 }
-DEFAULT_POLICY = {"c2": "hash", "c3": "fair"}
-PREROLL_STEPS = {"c2": 1500, "c3": 6000}  # a few episodes each (about 600 / 4000 steps long)
+DEFAULT_POLICY = {"c2": "hash", "c3": "fair", "e100": "fair"}
+PREROLL_STEPS = {"c2": 1500, "c3": 6000, "e100": 6000}  # a few episodes each (about 600 / 4000 steps long)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -97,7 +100,7 @@ def reference_python_baseline(config: str):
     path = osp.join(ROOT, "profiles", "reference_python.json")
     try:
         rec = json.load(open(path))
-        c = rec["configs"][{"c2": "c1", "c3": "c3"}[config]]
+        c = rec["configs"][{"c2": "c1", "c3": "c3"}[config]]  # (KeyError for other configs: no record)
         return {"value": c["one_core"]["env_only"], "unit": "env-steps/s", "cores": 1, "kind": "reference",
                 "all_cores": {"value": c["all_cores"]["env_only"], "processes": c["all_cores"]["processes"]},
                 "env_plus_scheduler_incl_reset": c["one_core"]["including_reset"],

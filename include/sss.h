@@ -25,7 +25,7 @@ typedef struct sss_handle sss_handle;
 
 /* env_cfg of the reference (spark_sched_sim.py:34-52, data_samplers/tpch.py:19-26) */
 typedef struct sss_cfg {
-  int32_t num_executors;   /* env_cfg["num_executors"], 1..64 */
+  int32_t num_executors;   /* env_cfg["num_executors"], 1..128 (65..128: the wide instantiation of the kernels) */
   int32_t job_arrival_cap; /* env_cfg.get("job_arrival_cap"); <= 0 means None */
   int32_t max_jobs;        /* arena capacity in jobs; 0 = job_arrival_cap (required when cap is None) */
   int32_t reserved;

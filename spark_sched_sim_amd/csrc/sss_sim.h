@@ -2663,6 +2663,12 @@ SSS_DEV int fast_run(const FastCtx& f) {
 #ifndef SSS_MIN_ARRIVAL_BATCH
 #define SSS_MIN_ARRIVAL_BATCH 2
 #endif
+// executor count from which the batches take their pools through the pair staging (pool_pair_*) when all members share them:
+// with few executors nearly every pool image has 8 slots and lives in its 16-byte record, where the per-lane register paths
+// (pool_leave_many / pool_enter_many / pool_pass_many) are cheaper than staging
+#ifndef SSS_PAIR_MIN_E
+#define SSS_PAIR_MIN_E 1
+#endif
 // One lane per pool (batch_released_events): every member of ranks [0, n) that leaves pool `okey` is taken out
 // of it - one fetch and one store of the pool's record; removals commute - and the pool's outgoing
 // commitments shrink by as many.
@@ -3003,7 +3009,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // come in with one round trip (pool_pair_*: n removals, n additions in rank order), the cache-slot references move in one go.
   const uint32_t sp_h = wave_readlane_u32(sp, head), en_h = wave_readlane_u32(enters, head);
   const int type_h = (int)wave_readlane_u32((uint32_t)type, head);
-  const bool uniform = f.E < 64 && wave_ballot(V && (sp != sp_h || enters != en_h || type != type_h)) == 0;
+  const bool uniform = f.E >= SSS_PAIR_MIN_E && f.E < 64 && wave_ballot(V && (sp != sp_h || enters != en_h || type != type_h)) == 0;
   if (uniform) {
     const bool freed_h = wave_readlane_u32(freed ? 1u : 0u, head) != 0;
     const int ci_h = (int)wave_readlane_u32((uint32_t)c_idx, head);
@@ -3352,7 +3358,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   bool def_job = false, def_stage = false;
   // every member arrives at the same stage (executors of one fulfilment; a single member): the job's pool and the stage's are
   // the only two images involved - both through the pair staging, one HBM round trip for the batch (fewer than 64 executors)
-  const bool one_stage = f.E < 64 && wave_ballot(V && same_stage != vm) == 0;
+  const bool one_stage = f.E >= SSS_PAIR_MIN_E && f.E < 64 && wave_ballot(V && same_stage != vm) == 0;
   if (one_stage) {
     const int l0 = ctz64_nz(vm);
     const uint32_t jk = wave_readlane_u32(jkey, l0), sk = wave_readlane_u32(skey, l0);
@@ -4468,7 +4474,9 @@ SSS_DEV void resume_simulation() {
 #endif
           handled = tf ? batch_released_events(f, ex) : batch_arrival_events(f, ex);
           // a released executor on its own (the usual case): the wave-uniform single-event path
+#ifndef SSS_NO_LEAN  // (A/B timing builds)
           if (handled == 0) handled = tf ? lean_released(f, ex, t_win, info_win) : lean_arrival(f, ex, t_win, info_win);
+#endif
           // the event that completes a job: the executors parked in the job's pool are flushed with the whole wave first
           if (handled == 0 && tf) preflush_completing_job(f, info_win);
         }

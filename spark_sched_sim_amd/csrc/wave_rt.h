@@ -10,7 +10,10 @@
 
 // everything is inlined into the kernels: the kernel-argument segment pointer (SSS_KERNARG_PTR) is null in callees
 #define SSS_DEV __device__ __forceinline__
-#define SSS_KERNEL extern "C" __global__ __launch_bounds__(64, 4)
+#ifndef SSS_WAVES_PER_SIMD
+#define SSS_WAVES_PER_SIMD 4
+#endif
+#define SSS_KERNEL extern "C" __global__ __launch_bounds__(64, SSS_WAVES_PER_SIMD)
 #define SSS_SHARED __shared__
 #define SSS_SHARED_DYN(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
 
@@ -18,7 +21,17 @@
 // usable from any device function
 #define SSS_KERNARG_PTR() ((const void*)__builtin_amdgcn_kernarg_segment_ptr())
 
+#ifdef SSS_OPAQUE_LANE
+// (experiment) the lane id through an opaque move: what is computed from it is computed where it is used instead of being
+// hoisted out of the event loop and kept - spilled - across it
+SSS_DEV int wave_lane() {
+  int l = (int)threadIdx.x;
+  asm volatile("" : "+v"(l));
+  return l;
+}
+#else
 SSS_DEV int wave_lane() { return (int)threadIdx.x; }
+#endif
 SSS_DEV int wave_env() { return (int)blockIdx.x; }
 
 // Ordering point between the lanes of the env's wave: what any lane wrote to LDS or global memory before it is what every

@@ -48,15 +48,10 @@ def test_trainer_runs_and_checkpoints(tmp_path):
 def test_train(tmp_path):
     """the reference's one integration test (reference test/test_train.py:5-7): load the YAML,
     `make_trainer(cfg).train()`, pass if nothing raises - same configuration, on the batched env"""
-    import os.path as osp
-
-    import yaml
-
     from spark_sched_sim_amd.training import make_trainer
+    from training_util import reference_smoke_test_config
 
-    with open(osp.join(osp.dirname(osp.abspath(__file__)), "test_train.yaml")) as stream:
-        cfg = yaml.safe_load(stream)
-    cfg["trainer"]["artifacts_dir"] = str(tmp_path)
+    cfg = reference_smoke_test_config(str(tmp_path))
     tr = make_trainer(cfg, device="cpu", _lib=load_emu())
     tr.train(verbose=False)
     assert tr.history[0]["samples"] > 0

@@ -143,3 +143,18 @@ def check_async_pipeline(device, lib):
             r = check_rollout(ro, g, p, b)
             assert np.array_equal(r["resets"], g[p + "resets"]), p
     env.close()
+
+
+def reference_smoke_test_config(artifacts_dir: str) -> dict:
+    """the hyper-parameters of the reference's own smoke test, in its config schema (reference test/test.yaml:1-41: one PPO
+    iteration, one job sequence x two rollouts, 50 executors, 10 jobs) - built here instead of kept as a YAML file"""
+    return {
+        "trainer": dict(trainer_cls="PPO", num_iterations=1, num_sequences=1, num_rollouts=2, seed=42, artifacts_dir=artifacts_dir,
+                        checkpointing_freq=50, use_tensorboard=False, num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01,
+                        entropy_coeff=0.04, beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5),
+        "agent": dict(agent_cls="DecimaScheduler", embed_dim=16,
+                      gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(inplace=True, negative_slope=0.2)),
+                      policy_mlp_kwargs=dict(hid_dims=[64, 64], act_cls="Tanh")),
+        "env": dict(num_executors=50, job_arrival_cap=10, moving_delay=2000.0, mean_time_limit=2.0e7, job_arrival_rate=4.0e-5,
+                    warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"),
+    }
