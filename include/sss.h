@@ -252,6 +252,10 @@ typedef struct sss_gnn_args {
    * current buffer and writes the receiver's other one. MERGE (rows = nodes), once after the last layer: h = tmp
    * where the number of updates is odd; DAGHID (kind 8) does that on the fly when it is given node_recv_dev. */
   const int32_t* node_recv_dev;
+  /* optional: the row count on the device (i64[1]) - for a Decima step without a device->host round trip (the graph's totals
+   * stay where sss_prefix_rows left them). n_rows then only sizes the launch grid (any positive guess, e.g. last step's total);
+   * every kernel strides over all *n_rows_dev rows. Not for LAYER (its list lengths come from layer_totals in sss_gnn_encode). */
+  const int64_t* n_rows_dev;
 } sss_gnn_args;
 int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
 
@@ -371,6 +375,12 @@ typedef struct sss_gnn_encode_args {
   int64_t layer_rows_hint[32]; /* host values: roughly how many nodes layer l updates (e.g. layer_totals of the previous step,
                                   read back lazily); only sizes the launch grids - every row is processed whatever it says.
                                   -1: no idea (the grid is sized by n_nodes) */
+  /* optional, both or neither: the node / job totals on the device (i64[1] each, e.g. sss_prefix_rows' totals_dev) - n_nodes /
+   * n_jobs above are then CAPACITIES (what the buffers hold; they also size the grids unless the hints say less) and nothing
+   * on the host needs the real totals: the launches read them (sss_gnn_args::n_rows_dev) */
+  const int64_t* n_nodes_dev;
+  const int64_t* n_jobs_dev;
+  int64_t n_nodes_hint, n_jobs_hint; /* with the pointers: roughly the real totals (grid sizes); <= 0: use the capacities */
 } sss_gnn_encode_args;
 int sss_gnn_encode(const sss_gnn_encode_args* a, void* stream);
 

@@ -77,7 +77,7 @@ class SssGnnArgs(C.Structure):
                 ("out_start_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("node_job_dev", C.c_void_p), ("node_obs_dev", C.c_void_p),
                 ("node_loc_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_first_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_nodes_dev", C.c_void_p), ("obs_job_off_dev", C.c_void_p), ("obs_jobs_dev", C.c_void_p),
-                ("w16_dev", C.c_void_p), ("w2_16_dev", C.c_void_p), ("node_recv_dev", C.c_void_p)]
+                ("w16_dev", C.c_void_p), ("w2_16_dev", C.c_void_p), ("node_recv_dev", C.c_void_p), ("n_rows_dev", C.c_void_p)]
 
 
 GNN_KINDS = {"prep": 0, "sink": 1, "layer": 2, "commit": 3, "dagsum": 4, "globsum": 5, "stage": 6, "exec": 7, "daghid": 8, "globhid": 9, "merge": 10}
@@ -99,7 +99,8 @@ class SssGnnEncodeArgs(C.Structure):  # include/sss.h sss_gnn_encode_args
                 + [(k + "_dev", C.c_void_p) for k in ("w_prep", "w_update", "w_msg", "w_dag", "w_glob", "w_msg16", "w_update16", "x", "out_deg", "obs_depth", "node_obs", "dst",
                                                       "out_start", "edge_layers", "node_recv", "job_first", "job_nodes", "obs_job_off", "obs_jobs", "obs_node_off",
                                                       "obs_nodes", "layer_cnt", "h_init", "h", "tmp", "h_dag", "h_glob", "env_off", "layer_totals", "recv")]
-                + [("recv_cap", C.c_int64), ("recv_stride", C.c_int64), ("layer_rows_hint", C.c_int64 * 32)])
+                + [("recv_cap", C.c_int64), ("recv_stride", C.c_int64), ("layer_rows_hint", C.c_int64 * 32),
+                   ("n_nodes_dev", C.c_void_p), ("n_jobs_dev", C.c_void_p), ("n_nodes_hint", C.c_int64), ("n_jobs_hint", C.c_int64)])
 
 
 class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args

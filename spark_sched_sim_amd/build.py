@@ -30,7 +30,13 @@ OUT = osp.join(CSRC, "libsss_hip.so")
 UNITS = ["sss_hip.hip", "sss_hip_wide.hip"]
 
 # -ffp-contract=off: f64 event times / rewards must round exactly as the reference's do (no FMA fusion)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+# -mllvm -disable-machine-licm: the simulator kernels are one function each (everything is inlined: the launch context lives in
+#   the kernel-argument segment) whose event loop spans tens of thousands of instructions; machine LICM hoists dozens of cheap
+#   per-lane values (lane masks, LDS addresses) out of that loop and the register allocator then spills them across it: 272 /
+#   640 bytes of scratch per lane in sss_step_kernel / sss_rollout_kernel against 32 / 48 without the pass - 16 KB of spill stores
+#   per env-step, three times the HBM write traffic, fused C2 -8 % (profiles/r04_bench.md section 4). The GNN / MLP kernels do not
+#   care (Decima step 0.605 -> 0.599 ms).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm",
          "-Wall", "-Wno-unused-function", "-I", CSRC]
 
 

@@ -58,6 +58,8 @@ enum { GNN_EMB = 16, GNN_NF = 5, GNN_DF = 3 };
 
 struct SssGnnArgs {
   int64_t n_rows;
+  const int64_t* n_rows_dev;  // nullable: the row count lives on the device (a Decima step without a host round trip); n_rows then
+                              // only sizes the grid - the kernels stride over all rows - and may be any positive guess
   const float* w;       // packed parameters of the MLP this launch evaluates
   const float* w2;      // LAYER: the update MLP (w = the message MLP)
   const float *w16, *w2_16;  // LAYER, nullable: the two MLPs in the 16-lanes-per-row image (sss_gnn16.h)

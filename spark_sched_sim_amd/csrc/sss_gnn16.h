@@ -147,7 +147,7 @@ SSS_DEV float hidden16_of(const float* m, float x, int g, float slope) {  // 16 
 }
 
 // rows of a launch: 16 per workgroup of 256 threads at a time, looping; parameters staged once per workgroup
-#define GNN16_ROWS(r) for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < a.n_rows; r += (int64_t)gridDim.x * 16)
+#define GNN16_ROWS(r) for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4), r##_end = a.n_rows_dev ? *a.n_rows_dev : a.n_rows; r < r##_end; r += (int64_t)gridDim.x * 16)
 
 template <int KIND>
 __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {

@@ -134,11 +134,13 @@ __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
     if (a.idx0_stride == 0)
       for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
     a.n_rows = a.layer_totals[a.layer], a.idx0 += off;
+    a.n_rows_dev = nullptr;
     if ((int64_t)blockIdx.x * 64 >= a.n_rows) return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   MfmaGnnMlp msg, upd;
   msg.load(a.w, lane), upd.load(a.w2, lane);
+  if (a.n_rows_dev) a.n_rows = *a.n_rows_dev;  // (the row count of a step without a host round trip)
   const int64_t n_tiles = (a.n_rows + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t left = a.n_rows - tile * 16;
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(256) void sss_gnn_head_mfma_kernel(SssGnnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) w3[4 * t + r] = W3[16 * t + 4 * q + r];
   const float b3 = W3[64];
+  if (a.n_rows_dev) a.n_rows = *a.n_rows_dev;  // (the row count of a step without a host round trip)
   const int64_t n_tiles = (a.n_rows + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t r = tile * 16 + j;
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(256) void sss_gnn_rows_mfma_kernel(SssGnnArgs a) {
       for (int r = 0; r < 4; r++) s1[t][r] = m1.a1[t][r];
   }
   if (KIND == GNN_GLOBHID) m0.load(a.w, lane);
+  if (a.n_rows_dev) a.n_rows = *a.n_rows_dev;  // (the row count of a step without a host round trip)
   const int64_t n_tiles = (a.n_rows + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t n = tile * 16 + j;

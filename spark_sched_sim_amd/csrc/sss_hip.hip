@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void sss_gnn_kernel(SssGnnArgs a) {
   for (int i = threadIdx.x; i < NW; i += 256) w_lds[i] = a.w[i];
   if (NW2 && a.w2) for (int i = threadIdx.x; i < NW2; i += 256) w_lds[NW + i] = a.w2[i];
   __syncthreads();
-  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r < a.n_rows) gnn_row<KIND>(a, r, w_lds, w_lds + NW);
+  const int64_t rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) gnn_row<KIND>(a, r, w_lds, w_lds + NW);
 }
 template <int KIND>
 static int gnn_launch_kind(const SssGnnArgs& a, void* stream) {

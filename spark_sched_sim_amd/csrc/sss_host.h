@@ -524,6 +524,8 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
   a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
   a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev, a.layer_totals = nullptr, a.idx0_stride = 0;
+  a.n_rows_dev = kind == GNN_LAYER ? nullptr : g->n_rows_dev;
+  if (a.n_rows_dev && a.n_rows < 1) a.n_rows = 1;  // (the count is on the device: n_rows is a grid-size guess)
   if (kind == GNN_MERGE && !g->node_recv_dev) return sss_fail(-1, "NULL argument");
   if (kind == GNN_LAYER && !g->w2_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_gnn(kind, a, stream)) return sss_fail(-30, std::string("gnn launch failed: ") + be_error(rc));
@@ -544,7 +546,12 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   // (dst_dev / edge_layers_dev may be NULL: a batch without edges)
   if (g->recv_stride ? (g->recv_stride < g->n_nodes || g->recv_cap < g->recv_stride * (int64_t)g->max_depth) : g->recv_cap < g->n_nodes * (int64_t)g->max_depth)
     return sss_fail(-33, "sss_gnn_encode: recv_dev must hold n_nodes * max_depth entries");
+  if ((g->n_nodes_dev == nullptr) != (g->n_jobs_dev == nullptr)) return sss_fail(-33, "sss_gnn_encode: n_nodes_dev and n_jobs_dev go together");
   if (g->n_nodes == 0 || g->n_jobs == 0) return 0;
+  const bool on_dev = g->n_nodes_dev != nullptr;
+  // grid sizes: the real totals when the host has them, else a guess with some room (the kernels stride over all rows)
+  auto guess = [](int64_t hint, int64_t cap) { int64_t v = hint > 0 ? hint + hint / 4 + 64 : cap; return v > cap ? cap : (v < 1 ? 1 : v); };
+  const int64_t rows_nodes = on_dev ? guess(g->n_nodes_hint, g->n_nodes) : g->n_nodes, rows_jobs = on_dev ? guess(g->n_jobs_hint, g->n_jobs) : g->n_jobs;
   auto fail = [](const char* what, int rc) { return sss_fail(-30, std::string(what) + " launch failed: " + be_error(rc)); };
   // lengths of the layers' lists of receiving nodes, their per-env offsets, the lists
   // (recv_stride != 0: sss_decima_graph_build has written the lists and their lengths already - recv_lists_dev / layer_totals_dev)
@@ -565,12 +572,12 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   a.slope = g->slope, a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev, a.tmp = g->tmp_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev;
   a.out_deg = g->out_deg_dev, a.obs_depth = g->obs_depth_dev, a.node_obs = g->node_obs_dev, a.dst = g->dst_dev, a.out_start = g->out_start_dev;
   a.edge_layers = g->edge_layers_dev, a.job_first = g->job_first_dev, a.job_nodes = g->job_nodes_dev, a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
-  auto run = [&](int kind, int64_t rows, const float* w) {
-    a.n_rows = rows, a.w = w;
+  auto run = [&](int kind, int64_t rows, const float* w, const int64_t* rows_dev = nullptr) {
+    a.n_rows = rows, a.w = w, a.n_rows_dev = rows_dev;
     return be_launch_gnn(kind, a, stream);
   };
   a.out = g->h_init_dev, a.w2 = g->w_update_dev;  // PREP and SINK in one pass over the nodes
-  if (int rc = run(GNN_PREP, g->n_nodes, g->w_prep_dev)) return fail("gnn", rc);
+  if (int rc = run(GNN_PREP, rows_nodes, g->w_prep_dev, g->n_nodes_dev)) return fail("gnn", rc);
   a.out = nullptr;
   // the layers, deepest first (scheduler.py:209-211): embeddings alternate between h and tmp per update (sss_gnn.h)
   a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev, a.idx0_stride = g->recv_stride;
@@ -578,15 +585,15 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
     a.layer = lvl;
     // (n_rows only sizes the grid here: the kernel reads the list's length itself and strides over all of it)
-    int64_t rows = g->layer_rows_hint[lvl] >= 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : g->n_nodes;
+    int64_t rows = g->layer_rows_hint[lvl] >= 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : rows_nodes;
     if (rows > g->n_nodes) rows = g->n_nodes;
     if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
   }
   a.idx0 = nullptr, a.layer_totals = nullptr, a.idx0_stride = 0, a.w2 = nullptr, a.w16 = nullptr, a.w2_16 = nullptr, a.layer = 0;
-  if (int rc = run(GNN_DAGHID, g->n_nodes, g->w_dag_dev)) return fail("gnn", rc);  // (brings the embeddings left in tmp home: MERGE)
+  if (int rc = run(GNN_DAGHID, rows_nodes, g->w_dag_dev, g->n_nodes_dev)) return fail("gnn", rc);  // (brings the embeddings left in tmp home: MERGE)
   a.node_recv = nullptr;
-  if (int rc = run(GNN_DAGSUM, g->n_jobs, g->w_dag_dev)) return fail("gnn", rc);
-  if (int rc = run(GNN_GLOBHID, g->n_jobs, g->w_glob_dev)) return fail("gnn", rc);
+  if (int rc = run(GNN_DAGSUM, rows_jobs, g->w_dag_dev, g->n_jobs_dev)) return fail("gnn", rc);
+  if (int rc = run(GNN_GLOBHID, rows_jobs, g->w_glob_dev, g->n_jobs_dev)) return fail("gnn", rc);
   if (int rc = run(GNN_GLOBSUM, g->n_obs, g->w_glob_dev)) return fail("gnn", rc);
   return 0;
 }

@@ -4449,12 +4449,12 @@ SSS_DEV void resume_simulation() {
       // the head of the queue decides what kind of round this is
       double t_win = 0.0;
       uint32_t info_win = 0;
-#ifdef SSS_WIDE
-      // Every round here is "lane 0 handles one event, then every lane looks at the queue again" with nothing in between (no
-      // fast run, no batch - those end in barriers): the barrier makes lane 0's LDS writes of the previous round (event slots,
-      // arrival cursor) something the other lanes' reads below cannot have been scheduled ahead of
+      // A round can be "lane 0 handles one event, then every lane looks at the queue again" with nothing in between (the fast run
+      // and the batches end in ordering points, a declined attempt and the one-at-a-time handler do not): this one makes lane 0's
+      // LDS writes of the previous round (event slots, arrival cursor, stage counters) something the other lanes' reads below
+      // cannot have been scheduled ahead of. Found on the GPU with the wide instantiation (every round is of that kind there; the
+      // emulator's lanes run one after the other and cannot show it); at wavefront scope the point costs no instruction.
       wave_sync();
-#endif
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
       if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {

@@ -487,12 +487,14 @@ class DecimaPolicy(nn.Module):
         self._plist = None
         return super()._apply(fn, *args, **kwargs)
 
-    def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, **ptrs) -> None:
+    def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, n_rows_dev: torch.Tensor | None = None, **ptrs) -> None:
+        """`n_rows_dev`: i64[1] on the device holding the real row count (`n_rows` is then a grid-size guess)"""
         import ctypes
 
         from .binding import GNN_KINDS, SssGnnArgs, device_of
         a = SssGnnArgs()
         a.n_rows, a.w_dev, a.slope, a.num_executors, a.layer, a.n_pad = int(n_rows), w.data_ptr(), self._packed[2], self.num_executors, layer, n_pad
+        a.n_rows_dev = n_rows_dev.data_ptr() if n_rows_dev is not None else None
         for k, t in ptrs.items():
             setattr(a, k + "_dev", t.data_ptr() if t is not None and t.numel() else None)
         dev = w.device
@@ -554,12 +556,21 @@ class DecimaPolicy(nn.Module):
         x = g["x"]
         dev = x.device
         M, J, B, D = x.shape[0], g["job_obs"].numel(), g["n_obs"], int(g["max_depth"])
-        f32 = lambda n: torch.empty((n, 16), dtype=torch.float32, device=dev)  # noqa: E731
-        h_init, h, tmp, h_dag, h_glob = f32(M), f32(M), f32(max(M, J)), f32(J), f32(B)
+        on_dev = "totals_dev" in g  # a capacity graph (env.decima_graph_on_device): M, J are capacities, the totals live on the device
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        f32 = lambda n: torch.empty((n, 16), dtype=torch.float32, device=dev)  # noqa: E731
+        if on_dev:  # work buffers at capacity, kept per stream (no allocation per step)
+            hb = self.__dict__.setdefault("_enc_cap", {})
+            key = (dev, stream, M, J, B)
+            if key not in hb:
+                hb.clear()
+                hb[key] = (f32(M), f32(M), f32(max(M, J)), f32(J), f32(B))
+            h_init, h, tmp, h_dag, h_glob = hb[key]
+        else:
+            h_init, h, tmp, h_dag, h_glob = f32(M), f32(M), f32(max(M, J)), f32(J), f32(B)
         pool = self.__dict__.setdefault("_enc_scratch", {})  # one set of work buffers per stream: passes on different streams overlap
         sc = pool.get((dev, stream))
-        need = max(M * D, 1)
+        need = 1 if on_dev else max(M * D, 1)  # (a capacity graph always comes with the graph kernel's own lists)
         if sc is None or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
             hint = torch.full((32,), -1, dtype=torch.int64)  # (unknown until the first pass's lengths have come back)
             sc = pool[(dev, stream)] = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
@@ -575,7 +586,9 @@ class DecimaPolicy(nn.Module):
                              p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
                              p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
                              # the list sizes of the PREVIOUS pass, copied back without waiting (whatever is there: they only size grids)
-                             (ctypes.c_int64 * 32)(*sc["hint"].tolist()))
+                             (ctypes.c_int64 * 32)(*sc["hint"].tolist()),
+                             g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None,
+                             int(g["totals_hint"][0]) if on_dev else 0, int(g["totals_hint"][2]) if on_dev else 0)
         with device_of(dev):
             self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
         sc["hint"].copy_(tot_t, non_blocking=True)
@@ -585,12 +598,24 @@ class DecimaPolicy(nn.Module):
     def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor]) -> torch.Tensor:
         """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
         M = g["x"].shape[0]
-        out = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
-        if "sched_list" in g:  # the graph kernel's list of the schedulable nodes: exactly the rows to score (layer=1: no padding)
-            rows, idx0, exact = g["sched_list"].numel(), g["sched_list"], 1
+        rows_dev = None
+        if "totals_dev" in g:  # capacity graph: the number of schedulable nodes is on the device; the score matrix is kept and refilled
+            ob = self.__dict__.setdefault("_score_cap", {})
+            key = (g["x"].device, g["n_obs"], g["n_pad"])
+            if key not in ob:
+                ob.clear()
+                ob[key] = torch.empty((g["n_obs"], g["n_pad"]), dtype=torch.float32, device=g["x"].device)
+            out = ob[key].fill_(float("-inf"))
+            hint = int(g["totals_hint"][3])
+            rows, idx0, exact, rows_dev = (hint + hint // 4 + 64 if hint > 0 else g["sched_list"].numel()), g["sched_list"], 1, g["totals_dev"][3:4]
+            rows = min(rows, g["sched_list"].numel())
         else:
-            rows, idx0, exact = M, self._index_list(g["stage_mask"]), 0
-        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, w16=self._packed[1].get("stage16"), w2_16=self._packed[1].get("stage_mfma"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
+            out = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
+            if "sched_list" in g:  # the graph kernel's list of the schedulable nodes: exactly the rows to score (layer=1: no padding)
+                rows, idx0, exact = g["sched_list"].numel(), g["sched_list"], 1
+            else:
+                rows, idx0, exact = M, self._index_list(g["stage_mask"]), 0
+        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, n_rows_dev=rows_dev, w16=self._packed[1].get("stage16"), w2_16=self._packed[1].get("stage_mfma"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
                      h_glob=h["glob"], out=out, idx0=idx0, node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
         return out
 
@@ -752,7 +777,8 @@ class DecimaPolicy(nn.Module):
         return {"stage_idx": stage_idx.to(torch.int32), "num_exec": (1 + a["exec_sel"]).to(torch.int32)}
 
     @torch.no_grad()
-    def schedule_env(self, env, generator: torch.Generator | None = None, active: torch.Tensor | None = None, one_launch: bool = False):
+    def schedule_env(self, env, generator: torch.Generator | None = None, active: torch.Tensor | None = None, one_launch: bool = False,
+                     host_sync: bool | None = None):
         """Decima in the loop on a `VecSparkSchedSimEnv`: one sampled action per env. Default: the
         graph kernel + the row-parallel GNN kernels + `act` (rows of ALL envs share every launch, so
         the lanes stay full). `one_launch=True` uses the per-env policy kernel (`act_env`; its draw
@@ -765,7 +791,10 @@ class DecimaPolicy(nn.Module):
         if one_launch:
             self._calls = getattr(self, "_calls", 0) + 1
             return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
-        a = self.act(env.decima_graph(active, reuse_buffers=True), generator)
+        # no device->host round trip when the graph kernel and the GNN kernels can do the whole step (the graph's totals stay on
+        # the device); else the graph with exact sizes (one read-back of its totals)
+        on_dev = host_sync is False or (host_sync is None and self._use_kernels() and 16 * env.dims.node_cap <= 65536)
+        a = self.act(env.decima_graph_on_device(active) if on_dev else env.decima_graph(active, reuse_buffers=True), generator)
         return self.env_actions(a), a
 
     @torch.no_grad()

@@ -199,6 +199,55 @@ class VecSparkSchedSimEnv:
         self._b.check(self._b.lib.sss_rollout(self._h, POLICY_IDS[policy], int(param), int(n_steps), int(self.auto_reset),
                                               self.seed_stride, self._stream()))
 
+    def decima_graph_on_device(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5) -> dict[str, Any]:
+        """`decima_graph` without the device->host round trip: the graph's totals (nodes, edges, jobs, schedulable nodes) stay on
+        the device (`g["totals_dev"]`, i64[4]); every array is a buffer of the env at its CAPACITY (num_envs x node_cap nodes, ...),
+        only its leading `totals_dev[k]` rows are meaningful, and the kernels downstream read the counts themselves
+        (sss_gnn_args::n_rows_dev, sss_gnn_encode_args::n_nodes_dev). `g["totals_hint"]`: the previous call's totals, copied back
+        without waiting (pinned memory) - grid sizes only. For act-and-forget inference (`DecimaPolicy.schedule_env`): the buffers are
+        overwritten by the next call; graphs that are kept (rollout recording, training) use `decima_graph`."""
+        B, dev, d = self.num_envs, self.device, self.dims
+        assert 16 * d.node_cap <= 65536, "the graph kernel's LDS working set does not fit this node capacity"
+        D = self.max_dag_depth
+        ws = getattr(self, "_dg_dev", None)
+        if ws is None:
+            Mc, Ec, Jc = B * d.node_cap, B * d.edge_cap, B * d.job_cap
+            e = lambda n, dt, *tail: torch.empty((max(n, 1), *tail), dtype=dt, device=dev)  # noqa: E731
+            hint = torch.full((4,), -1, dtype=torch.int64)
+            ws = self._dg_dev = {
+                "x": e(Mc, torch.float32, 5), "node_obs": e(Mc, torch.int64), "node_loc": e(Mc, torch.int64), "node_job": e(Mc, torch.int64),
+                "sched_rank": e(Mc, torch.int64), "gen": e(Mc, torch.int32), "node_recv": e(Mc, torch.int32), "stage_mask": e(Mc, torch.bool),
+                "src": e(Ec, torch.int64), "dst": e(Ec, torch.int64), "edge_obs": e(Ec, torch.int64), "edge_layers": e(Ec, torch.int32),
+                "job_obs": e(Jc, torch.int64), "job_cap": e(Jc, torch.int64), "job_first": e(Jc, torch.int64), "obs_depth": e(B, torch.int32),
+                "job_nodes": e(Jc, torch.int64), "out_start": e(Mc, torch.int64), "out_deg": e(Mc, torch.int32),
+                "layer_cnt": e(32, torch.int32, B), "sched_list": e(Mc, torch.int64),
+                "scan": e(2, torch.int64, 4, B), "tot": e(4, torch.int64), "layer_totals": torch.zeros(32, dtype=torch.int64, device=dev),
+                "recv": e(Mc * max(D, 1), torch.int64), "hint": hint.pin_memory() if dev.type == "cuda" else hint, "epoch": 0}
+        act8 = active.to(torch.uint8).contiguous() if active is not None else None
+        scan, tot = ws["scan"], ws["tot"]
+        with device_of(dev):
+            self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 4, B,
+                                                     scan[0].data_ptr(), scan[1].data_ptr(), tot.data_ptr(), self._stream()))
+        off, cnt_t = scan[0], scan[1]
+        ws["layer_totals"].zero_()
+        ws["epoch"] += 1
+        stride = ws["recv"].numel() // max(D, 1)
+        a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
+                           float(num_tasks_scale), float(work_scale), *(ws[k].data_ptr() for k in (
+                               "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
+                               "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
+                           off[3].data_ptr(), ws["sched_list"].data_ptr(), ws["layer_totals"].data_ptr(), ws["recv"].data_ptr(), stride)
+        self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
+        g = {k: ws[k] for k in ("x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst", "edge_obs",
+                                "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt", "sched_list")}
+        g["n_obs"], g["n_pad"], g["max_depth"] = B, d.node_cap, D
+        g["layer_totals"], g["_layer_lists"] = ws["layer_totals"], ({"recv": ws["recv"], "stride": stride, "epoch": ws["epoch"]}, ws["epoch"])
+        g["obs_nodes"], g["obs_jobs"], g["obs_node_off"], g["obs_job_off"] = cnt_t[0], cnt_t[2], off[0], off[2]
+        g["totals_dev"], g["totals_hint"] = tot, ws["hint"].clone()  # (M, Ed, J, S); the hint: whatever has arrived of the previous call's
+        ws["hint"].copy_(tot, non_blocking=True)
+        g["_keepalive"], g["_binding"] = (off, act8), self._b
+        return g
+
     def decima_graph(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5,
                      reuse_buffers: bool = False) -> dict[str, Any]:
         """the current observations of all envs (or of those with `active[b]` True) as Decima's

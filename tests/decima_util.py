@@ -186,3 +186,45 @@ def check_policy_draw(ak, acts_k, cg, f, es_all, job_off, seed, counter):
             assert ek[c_sel] >= ek.max() - 1e-4 and int(acts_k["num_exec"][b]) == c_sel + 1, (b, "exec draw")
             lg += float(es[b, c_sel] - (np.log(np.exp(es[b][ok] - es[b][ok].max()).sum()) + es[b][ok].max()))
         assert abs(float(ak["lgprob"][b]) - lg) <= 1e-4, (b, "lgprob", float(ak["lgprob"][b]), lg)
+
+
+def check_on_device_step_equals_the_synchronous_one(device, lib=None, n_envs=6, steps=60, cfg=None):
+    """`DecimaPolicy.schedule_env` without a device->host round trip (capacity buffers, the graph's totals on the device,
+    kernels that read their row counts themselves - env.decima_graph_on_device) against the path that reads the totals back:
+    same observations, same generator seed and draw counter -> the same actions, log-probabilities bit for bit, and the same
+    embeddings / scores on the meaningful rows. Also with some envs inactive."""
+    import torch
+
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = cfg or dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, n_envs, device=device, auto_reset=True, _lib=lib)
+    torch.manual_seed(7)
+    policy = DecimaPolicy(num_executors=cfg["num_executors"], **AGENT).to(device).eval()
+    with torch.no_grad():
+        for n_, p_ in policy.named_parameters():
+            if "bias" in n_:
+                p_.normal_(0.0, 0.1)
+    gen = torch.Generator(device=device).manual_seed(11)
+    env.reset(seed=100)
+    for t in range(steps):
+        active = None if t % 3 else (torch.arange(n_envs, device=device) % 4 != 1)
+        calls = getattr(policy, "_calls", 0)
+        act_a, aux_a = policy.schedule_env(env, generator=gen, active=active, host_sync=True)
+        act_a = {k: v.clone() for k, v in act_a.items()}
+        aux_a = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in aux_a.items()}
+        policy._calls = calls  # the same draw counter for the second pass
+        act_b, aux_b = policy.schedule_env(env, generator=gen, active=active, host_sync=False)
+        sel = torch.ones(n_envs, dtype=torch.bool, device=device) if active is None else active
+        for k in ("stage_idx", "num_exec"):
+            assert torch.equal(act_a[k][sel], act_b[k][sel]), (t, k)
+        assert torch.equal(aux_a["lgprob"][sel & aux_a["any_stage"]], aux_b["lgprob"][sel & aux_b["any_stage"]]), t
+        assert torch.equal(aux_a["any_stage"][sel], aux_b["any_stage"][sel]), t
+        if active is not None:  # inactive envs are not stepped by this policy: the heuristic takes them along
+            fair = env.policy_actions("fair")
+            for k in ("stage_idx", "num_exec"):
+                act_b[k] = torch.where(sel, act_b[k], fair[k])
+        _, _, _, _, info = env.step(act_b)
+        assert not info["err"].any(), t
+    env.close()

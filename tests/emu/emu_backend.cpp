@@ -157,7 +157,8 @@ static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleAr
 
 template <int KIND>
 static int gnn_run_kind(const SssGnnArgs& a) {
-  for (int64_t r = 0; r < a.n_rows; r++) gnn_row<KIND>(a, r, a.w, a.w2);
+  const int64_t rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  for (int64_t r = 0; r < rows; r++) gnn_row<KIND>(a, r, a.w, a.w2);
   return 0;
 }
 static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {

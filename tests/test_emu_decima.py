@@ -186,3 +186,9 @@ def test_prefix_rows_matches_numpy():
     assert lib.sss_prefix_rows(rows.data_ptr(), rows.stride(0), 1, None, 32, B, off.data_ptr(), None, tot.data_ptr(), None) == 0
     w = rows.numpy().astype(np.int64)
     assert np.array_equal(off.numpy(), np.cumsum(w, 1) - w) and np.array_equal(tot.numpy(), w.sum(1))
+
+
+def test_decima_step_without_host_round_trip_equals_the_synchronous_one():
+    from decima_util import check_on_device_step_equals_the_synchronous_one
+
+    check_on_device_step_equals_the_synchronous_one("cpu", load_emu(), n_envs=5, steps=40)

@@ -291,3 +291,16 @@ np.savez(sys.argv[1], **out)
         fin = np.isfinite(b)
         assert (np.isfinite(a) == fin).all(), k  # (-inf marks slots that are not schedulable / executor counts beyond the cap)
         assert np.abs(a[fin] - b[fin]).max() <= 2e-5 * max(1.0, float(np.abs(b[fin]).max())), (k, float(np.abs(a[fin] - b[fin]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n_envs,steps", [
+    (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), 512, 150),
+    (dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), 96, 120),
+])
+def test_decima_step_without_host_round_trip_equals_the_synchronous_one(cfg, n_envs, steps):
+    """env.decima_graph_on_device + kernels that read their row counts from the device (sss_gnn_args::n_rows_dev,
+    sss_gnn_encode_args::n_nodes_dev) against the path that reads the graph's totals back: same actions and log-probabilities"""
+    from decima_util import check_on_device_step_equals_the_synchronous_one
+
+    check_on_device_step_equals_the_synchronous_one("cuda:0", None, n_envs=n_envs, steps=steps, cfg=cfg)

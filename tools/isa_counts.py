@@ -14,7 +14,7 @@ CLASSES = [("VALU", r"^v_(?!readlane|readfirstlane|writelane)"), ("cross-lane (r
 
 def compile_asm(tmp):
     src = osp.join(ROOT, "spark_sched_sim_amd", "csrc", "sss_hip.hip")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm", "-c", "-Wno-unused-function",
            "-I", osp.dirname(src), "-save-temps", "-o", osp.join(tmp, "lib.so"), src]
     subprocess.run(cmd, cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return osp.join(tmp, "sss_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
