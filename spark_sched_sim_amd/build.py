@@ -18,7 +18,7 @@ ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 def sources() -> list[str]:
     """everything the library is compiled from: every source / header / table under csrc/ plus the C ABI header"""
     import glob
-    out = [osp.join(ROOT, "include", "sss.h")]
+    out = [osp.join(ROOT, "include", "sss.h"), osp.abspath(__file__)]  # (this file: the compiler flags)
     for pat in ("*.hip", "*.h", "*.inc"):
         out += sorted(glob.glob(osp.join(CSRC, pat)))
     return out

@@ -20,6 +20,12 @@ CASES = [
     ("c2_hash0", dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash", 1, 60000),
     ("c3_fair", dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 40000),
     ("e64_fair", dict(num_executors=64, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 30000),
+    # round 4: the wave-uniform single-event paths and the pair staging under other regimes - random actions at 50 executors (backup
+    # scheduling, sends), zero delays, bursts - and the wide instantiation
+    ("e50_hash0", dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash", 1, 30000),
+    ("e33_zero_delays_hash0", dict(num_executors=33, job_arrival_cap=80, job_arrival_rate=1.0e-4, moving_delay=0.0, warmup_delay=0.0), "hash", 1, 30000),
+    ("burst_fair", dict(num_executors=20, job_arrival_cap=120, job_arrival_rate=4.0e-4, moving_delay=500.0, warmup_delay=100.0), "fair", 0, 30000),
+    ("e100_fair_wide", dict(num_executors=100, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 12000),
 ]
 
 
