@@ -192,3 +192,99 @@ def test_decima_step_without_host_round_trip_equals_the_synchronous_one():
     from decima_util import check_on_device_step_equals_the_synchronous_one
 
     check_on_device_step_equals_the_synchronous_one("cpu", load_emu(), n_envs=5, steps=40)
+
+
+def test_kernel_weight_images_are_the_documented_permutations():
+    """host-side packing of the Decima MLPs for the 16-lanes-per-row kernels (csrc/sss_gnn16.h) and for the matrix-core policy
+    heads (csrc/sss_gnn_mfma.h MfmaHead) - `DecimaPolicy._packed_weights` builds them with reshapes / permutes / fancy indexing;
+    here every entry is checked against the layout the kernels document, with plain index arithmetic (runs on the CPU: the
+    images are only ever EXECUTED by gfx950 kernels, so this is where their construction gets a second opinion)"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd.decima import NUM_DAG_FEATURES, NUM_NODE_FEATURES, DecimaPolicy
+
+    torch.manual_seed(3)
+    pol = DecimaPolicy(num_executors=10, **AGENT).eval()
+    with torch.no_grad():
+        for p_ in pol.parameters():
+            p_.normal_(0.0, 1.0)
+    w = pol._packed_weights()
+
+    def lin(mlp):
+        return [m for m in mlp if isinstance(m, torch.nn.Linear)]
+
+    # 16-lane images: w1[i][g][q] = W1[g + 16 q][i], b1[g][q], w2[jj][q][g][r] = W2[g + 16 r][jj + 16 q], b2[g][r], w3, b3
+    for name, mlp in (("msg16", pol.encoder.node_encoder.mlp_msg), ("update16", pol.encoder.node_encoder.mlp_update),
+                      ("stage16", pol.stage_policy_network.mlp_score), ("exec16", pol.exec_policy_network.mlp_score)):
+        l1, l2, l3 = lin(mlp)
+        W1, b1, W2, b2, W3, b3 = (t.detach() for t in (l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias))
+        h1, n_in = W1.shape
+        h2 = W2.shape[0]
+        q1, q2 = h1 // 16, h2 // 16
+        img = w[name].tolist()
+        o = 0
+        for i in range(n_in):
+            for g in range(16):
+                for q in range(q1):
+                    assert img[o] == float(W1[g + 16 * q, i]), (name, "w1", i, g, q)
+                    o += 1
+        for g in range(16):
+            for q in range(q1):
+                assert img[o] == float(b1[g + 16 * q]), (name, "b1")
+                o += 1
+        for jj in range(16):
+            for q in range(q1):
+                for g in range(16):
+                    for r in range(q2):
+                        assert img[o] == float(W2[g + 16 * r, jj + 16 * q]), (name, "w2", jj, q, g, r)
+                        o += 1
+        for g in range(16):
+            for r in range(q2):
+                assert img[o] == float(b2[g + 16 * r]), (name, "b2")
+                o += 1
+        if W3.shape[0] == 16:   # w3[k][g] = W3[g][k]
+            for k in range(h2):
+                for g in range(16):
+                    assert img[o] == float(W3[g, k]), (name, "w3")
+                    o += 1
+        else:                   # one output: w3[g][r] = W3[0][g + 16 r]
+            for g in range(16):
+                for r in range(q2):
+                    assert img[o] == float(W3[0, g + 16 * r]), (name, "w3")
+                    o += 1
+        for k in range(b3.numel()):
+            assert img[o] == float(b3[k])
+            o += 1
+        assert all(v == 0.0 for v in img[o:]) and len(img) % 4 == 0   # padding to whole float4s
+
+    # matrix-core head images: K-step (u, r) of lane (q, i) holds feature col[u][4 q + r]; A1[tile][step][lane] = W1[16 tile + i][that column] (0 where
+    # the column is padding), A2[tile][s][lane] = W2[16 tile + i][16 (s >> 2) + 4 q + (s & 3)], then b1, b2
+    f16 = list(range(16))
+    stage_cols = [[NUM_NODE_FEATURES + f for f in f16], [NUM_NODE_FEATURES + 16 + f for f in f16], [NUM_NODE_FEATURES + 32 + f for f in f16],
+                  [f if f < NUM_NODE_FEATURES else -1 for f in f16]]
+    exec_cols = [[NUM_DAG_FEATURES + f for f in f16], [NUM_DAG_FEATURES + 16 + f for f in f16],
+                 [f if f < NUM_DAG_FEATURES else (NUM_DAG_FEATURES + 32 if f == NUM_DAG_FEATURES else -1) for f in f16]]
+    for name, mlp, cols in (("stage_mfma", pol.stage_policy_network.mlp_score, stage_cols), ("exec_mfma", pol.exec_policy_network.mlp_score, exec_cols)):
+        l1, l2, _ = lin(mlp)
+        W1, b1, W2, b2 = (t.detach() for t in (l1.weight, l1.bias, l2.weight, l2.bias))
+        U = len(cols)
+        img = w[name].tolist()
+        o = 0
+        for tile in range(4):
+            for step in range(4 * U):
+                for lane in range(64):
+                    i, q = lane & 15, lane >> 4
+                    c = cols[step >> 2][4 * q + (step & 3)]
+                    assert img[o] == (float(W1[16 * tile + i, c]) if c >= 0 else 0.0), (name, "a1", tile, step, lane)
+                    o += 1
+        for tile in range(4):
+            for s in range(16):
+                for lane in range(64):
+                    i, q = lane & 15, lane >> 4
+                    assert img[o] == float(W2[16 * tile + i, 16 * (s >> 2) + 4 * q + (s & 3)]), (name, "a2", tile, s, lane)
+                    o += 1
+        assert img[o: o + 64] == b1.tolist() and img[o + 64: o + 128] == b2.tolist() and len(img) == o + 128
+        # every input column of the first Linear appears exactly once among the K-steps (no feature dropped or doubled)
+        used = sorted(c for row in cols for c in row if c >= 0)
+        assert used == list(range(W1.shape[1])), name
