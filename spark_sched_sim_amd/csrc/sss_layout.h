@@ -240,9 +240,9 @@ static inline int64_t sss_align(int64_t x, int64_t a) { return (x + a - 1) / a *
 struct SssExDesc {          // 32 bytes, two 16-byte LDS accesses
   int32_t gs;              // pack stage row the entries belong to, -1 = invalid
   int8_t li, ri;           // the two candidate executor levels (equal when the level interval is closed)
-  int16_t pad;
+  int16_t thr_n;           // the executor count `thr` below was fetched for (-1: none): fast_run keeps the level threshold with the entry
   int32_t off_l, lenw_l;   // list of (stage, level li, "same stage" mode)
-  int32_t dmin_l, dmin_r;  // lower bounds of a duration drawn from either list
+  uint32_t thr_lo, thr_hi; // SssPackDev::lvl_thr[thr_n]: the raw-output threshold of the executor-level draw (TPCH:222-229)
   int32_t off_r, lenw_r;   // ... level ri
 };
 

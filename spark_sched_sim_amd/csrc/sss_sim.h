@@ -1108,6 +1108,39 @@ SSS_DEV bool pair_remove(PairImg& p, uint32_t key) {  // set_remove (all lanes)
   if (p.s.mask == 7) return set8_remove(p.t8, p.s.used, key);
   return staged_remove(p.s, key);
 }
+// n members leave the pool at once (all lanes): list[from .. to) are their ids. Removals commute - a removal leaves a dummy, no
+// probe chain changes - so on a staged table every member's own lane finds and marks its slot (the table is in LDS: the lanes'
+// probe loops run side by side); an 8-slot image in the register is walked by every lane alike. Fewer than 64 members.
+SSS_DEV void pair_remove_many(PairImg& p, const uint8_t* list, int from, int to) {
+  const int n = to - from;
+  if (p.s.mask == 7) {
+    for (int i = from; i < to; i++) {
+      bool was = set8_remove(p.t8, p.s.used, (uint32_t)list[i]);
+      CHECK(was);
+    }
+    return;
+  }
+  const int lane = wave_lane();
+  if (lane < n) {
+    uint8_t* const tab = p.s.big;
+    const uint32_t key = list[from + lane], mask = p.s.mask;
+    uint32_t i = key & mask, perturb = key;
+    bool done = false;
+    for (int guard = 0; guard < 64 && !done; guard++) {
+      const uint32_t probes = (i + 9 <= mask) ? 9u : 0u;
+      for (uint32_t q = 0; q <= probes && !done; q++) {
+        const uint32_t en = tab[i + q];
+        if (en == key + 2) tab[i + q] = 1, done = true;
+        else if (en == 0) guard = 64;  // (not a member: reported below)
+      }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+    CHECK(done);
+  }
+  p.s.used -= (uint32_t)n;
+  wave_sync();
+}
 // one image back to HBM: the record, and the table area unless the image had 8 slots before and has 8 slots now (the
 // area then holds what was fetched). Like pool_stage_out the whole area goes back, so that the HBM bytes are what the
 // one-operation-at-a-time code leaves, dead slots included.
@@ -1951,11 +1984,10 @@ SSS_DEV bool fulfil_common_wave(int from, int to) {
     const PoolPairRegs pr = pool_pair_fetch(src, dstp, true);
     PairImg so, sn;
     pool_pair_stage(pr, true, so, sn);
-    for (int i = from; i < to; i++) {  // (wave-uniform: every lane reads the list)
+    pair_remove_many(so, g_sc.fi_e, from, to);  // TRK:188-222, the removals (they commute: every member's own lane)
+    for (int i = from; i < to; i++) {  // ... the additions, in item order (wave-uniform: every lane reads the list)
       const uint32_t e = g_sc.fi_e[i];
       moved_m |= bit64((int)e);
-      bool was = pair_remove(so, e);  // TRK:188-222
-      CHECK(was);
       pair_add(sn, e);
     }
     so.s.aux -= (uint32_t)n;  // the source's outgoing commitments (TRK:159-176)
@@ -2287,9 +2319,9 @@ SSS_DEV void exdesc_fetch(const FastCtx& f, SssExDesc& xd, int gs, int li, int r
   const int4 a = *(const int4*)eff_row(f.eff, gs, li, 1);
   int4 b = a;
   if (ri != li) b = *(const int4*)eff_row(f.eff, gs, ri, 1);
-  xd.gs = gs, xd.li = (int8_t)li, xd.ri = (int8_t)ri, xd.pad = 0;
-  xd.off_l = a.x, xd.lenw_l = a.y, xd.dmin_l = a.z;
-  xd.off_r = b.x, xd.lenw_r = b.y, xd.dmin_r = b.z;
+  xd.gs = gs, xd.li = (int8_t)li, xd.ri = (int8_t)ri, xd.thr_n = -1;
+  xd.off_l = a.x, xd.lenw_l = a.y, xd.thr_lo = 0;
+  xd.off_r = b.x, xd.lenw_r = b.y, xd.thr_hi = 0;
 }
 
 // The common event (97-99 % of all events are TASK_FINISHED, most of them with tasks left in the
@@ -2414,17 +2446,22 @@ SSS_DEV int fast_run(const FastCtx& f) {
     int li, ri;
     executor_interval(n_local, li, ri);
     SssExDesc xd = f.exdesc[lane];
-    if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) {
-      exdesc_fetch(f, xd, gs, li, ri);
-      f.exdesc[lane] = xd;  // an entry is only ever used with its own executor's events
+    bool xd_new = false;
+    if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) exdesc_fetch(f, xd, gs, li, ri), xd_new = true;
+    // the level threshold of an open interval rides with the entry (it is a function of the job's executor count alone): one
+    // load from the pack per change of that count instead of one per run
+    if (li != ri && (int)xd.thr_n != n_local && n_local > 0 && n_local <= 100) {
+      const uint64_t t = g_c.pk.lvl_thr[n_local];
+      xd.thr_n = (int16_t)n_local, xd.thr_lo = (uint32_t)t, xd.thr_hi = (uint32_t)(t >> 32), xd_new = true;
     }
+    if (xd_new) f.exdesc[lane] = xd;  // an entry is only ever used with its own executor's events
     rem = st.remaining, mc = (int)st.moving_to + (int)st.commit_to;
     // lists with one entry draw nothing, empty ones fail, the idle-executor fallback adds warmup_delay
     // (TPCH:88-106): all of those go one at a time
     elig = rem > 0 && n_local > 0 && n_local <= 100 && (xd.lenw_l & LENW_LEN) > 1 && (xd.lenw_r & LENW_LEN) > 1 && !(xd.lenw_l >> 30) && !(xd.lenw_r >> 30);
     if (elig) {
       off_l = xd.off_l, off_r = xd.off_r, len_l = (uint32_t)(xd.lenw_l & LENW_LEN), len_r = (uint32_t)(xd.lenw_r & LENW_LEN);
-      if (li != ri) thr = g_c.pk.lvl_thr[n_local], open_v = 0xFFFFFFFFu;
+      if (li != ri) thr = (uint64_t)xd.thr_lo | ((uint64_t)xd.thr_hi << 32), open_v = 0xFFFFFFFFu;
     }
   }
   const uint32_t tag = info >> 8;  // (job, slot, stage)
@@ -3036,12 +3073,9 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
     }
     PairImg so, sn;
     pool_pair_stage(pr, en_h != POOL_NONE, so, sn);
-    for (uint32_t q = 0; q < n; q++) {  // rank order (wave-uniform: every lane reads the list)
-      const uint32_t e = g_sc.fi_e[q];
-      bool was = pair_remove(so, e);
-      CHECK(was);
-      if (en_h != POOL_NONE) pair_add(sn, e);
-    }
+    pair_remove_many(so, g_sc.fi_e, 0, (int)n);  // (removals commute: every member's own lane)
+    if (en_h != POOL_NONE)
+      for (uint32_t q = 0; q < n; q++) pair_add(sn, (uint32_t)g_sc.fi_e[q]);  // rank order (wave-uniform: every lane reads the list)
     if (!freed_h) so.s.aux -= n;  // the pool's outgoing commitments
     wave_sync();
     pool_pair_flush_one(sp_h, so);
@@ -3819,11 +3853,10 @@ SSS_DEV void preflush_completing_job(const FastCtx& f, uint32_t info) {
   PairImg so, sn;
   pool_pair_stage(pr, true, so, sn);
   uint64_t moved_m = 0;
+  pair_remove_many(so, g_sc.fi_e, 0, m);
   for (int i = 0; i < m; i++) {
     const uint32_t e = g_sc.fi_e[i];
     moved_m |= bit64((int)e);
-    bool was = pair_remove(so, e);
-    CHECK(was);
     pair_add(sn, e);
   }
   wave_sync();
