@@ -472,6 +472,61 @@ int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act);
 int sss_mlp_forward(const sss_mlp_args* a, void* stream);
 int sss_mlp_backward(const sss_mlp_args* a, void* stream);
 
+/* The rollout workers' record of observations, built while collecting (trainers/rollout_worker.py:133-159 appends every
+ * observation to its buffer; trainers/trainer.py:208-233 with schedulers/decima/utils.py:117-204 collates them into one batch graph
+ * for the update): the compact graph of one step - the arrays sss_decima_graph_build wrote, `totals_dev` = sss_prefix_rows'
+ * totals [nodes, edges, jobs, ..] - is appended to the arena's arrays at the cursors in `cursor_dev` (i64[8], on the device:
+ * [0..3] rows appended so far of the node / edge / job / observation arrays, [4] steps appended, [5] set to 1 instead when
+ * something would not fit `capacity` - nothing is written then). An array is copied as `per_row` elements of `elem_bytes`
+ * (1, 4, 8) per row of its `kind` (0 nodes, 1 edges, 2 jobs, 3 observations = n_obs rows per step); 8-byte id arrays get the
+ * cursor of what they name added (`shift`: 0 none, 1 node ids, 2 job ids, 3 observation ids). No device->host traffic.
+ * `rows_hint`: roughly the largest number of elements an array has this step (grid size only; <= 0: a default). */
+#define SSS_ARENA_MAX_ARRAYS 24
+typedef struct sss_arena_array {
+  const void* src_dev;
+  void* dst_dev;
+  int32_t elem_bytes, per_row, kind, shift;
+} sss_arena_array;
+typedef struct sss_arena_args {
+  int32_t n_arrays, n_obs;
+  const int64_t* totals_dev;
+  int64_t* cursor_dev;
+  int64_t capacity[4];
+  int64_t rows_hint;
+  sss_arena_array arrays[SSS_ARENA_MAX_ARRAYS];
+} sss_arena_args;
+int sss_arena_append(const sss_arena_args* a, void* stream);
+
+/* Row gathers / scatters of the PPO update (what PyG's message passing, the score networks' `torch.cat([x[idx], h[idx], ..])`
+ * inputs and the per-job / per-observation sums run as index_select / index_add_ under autograd in the reference:
+ * schedulers/decima/scheduler.py:209-232, :246-283, :289-318, :337-385). `a` is the list side (row i, leading dimension ld_a
+ * floats - it may be a column slice of a wider matrix), `b` / `c` the table side (row idx[i], contiguous rows of `width` floats):
+ *   SSS_ROWS_GATHER       a[i] = b[idx[i]]
+ *   SSS_ROWS_SCATTER_ADD  b[idx[i]] += a[i]                  (float atomics: the order of the additions into a row is not fixed)
+ *   SSS_ROWS_UPDATE       b[idx[i]] = a[i] + c[idx[i]]       (idx without repeats)
+ *   SSS_ROWS_TAKE         a[i] = b[idx[i]], b[idx[i]] = 0, c[idx[i]] += a[i]     (idx without repeats)
+ *   SSS_ROWS_SCATTER      b[idx[i]] = a[i]                   (idx without repeats)
+ *   SSS_ROWS_SEGMENT_SUM  b[s] = sum of a[i], idx[s] <= i < idx[s + 1]  (idx: n + 1 non-decreasing row offsets of the n segments;
+ *                         no atomics, the additions run in row order)
+ * idx entries must be valid rows of the tables (not checked). Launches on the CURRENT device's stream `stream` (no handle). */
+#define SSS_ROWS_GATHER 0
+#define SSS_ROWS_SCATTER_ADD 1
+#define SSS_ROWS_UPDATE 2
+#define SSS_ROWS_TAKE 3
+#define SSS_ROWS_SCATTER 4
+#define SSS_ROWS_SEGMENT_SUM 5
+typedef struct sss_rows_args {
+  int64_t n;              /* rows of the list */
+  int64_t ld_a;           /* floats between rows of a (>= width) */
+  int32_t width;          /* floats per row, 1..64 */
+  int32_t op;             /* SSS_ROWS_* */
+  const int64_t* idx_dev; /* i64[n] (SEGMENT_SUM: i64[n + 1]) */
+  float* a_dev;
+  float* b_dev;
+  float* c_dev;           /* UPDATE / TAKE only */
+} sss_rows_args;
+int sss_rows_op(const sss_rows_args* a, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

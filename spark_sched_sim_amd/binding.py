@@ -119,9 +119,23 @@ class SssMlpArgs(C.Structure):  # include/sss.h sss_mlp_args
                 ("g1_dev", C.c_void_p), ("g2_dev", C.c_void_p), ("dx_dev", C.c_void_p)]
 
 
+class SssRowsArgs(C.Structure):  # include/sss.h sss_rows_args
+    _fields_ = [("n", C.c_int64), ("ld_a", C.c_int64), ("width", C.c_int32), ("op", C.c_int32), ("idx_dev", C.c_void_p), ("a_dev", C.c_void_p), ("b_dev", C.c_void_p),
+                ("c_dev", C.c_void_p)]
+
+
+class SssArenaArray(C.Structure):  # include/sss.h sss_arena_array
+    _fields_ = [("src_dev", C.c_void_p), ("dst_dev", C.c_void_p), ("elem_bytes", C.c_int32), ("per_row", C.c_int32), ("kind", C.c_int32), ("shift", C.c_int32)]
+
+
+class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
+    _fields_ = [("n_arrays", C.c_int32), ("n_obs", C.c_int32), ("totals_dev", C.c_void_p), ("cursor_dev", C.c_void_p), ("capacity", C.c_int64 * 4),
+                ("rows_hint", C.c_int64), ("arrays", SssArenaArray * 24)]
+
+
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_gnn_encode", "sss_last_error", "sss_destroy"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_arena_append", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -160,6 +174,8 @@ class Binding:
         L.sss_mlp_supported.argtypes = [C.c_int] * 5
         L.sss_mlp_forward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
         L.sss_mlp_backward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
+        L.sss_arena_append.argtypes = [C.POINTER(SssArenaArgs), C.c_void_p]
+        L.sss_rows_op.argtypes = [C.POINTER(SssRowsArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
 

@@ -9,6 +9,7 @@
 #include "sss_gnn.h"
 #include "sss_decima_policy.h"
 #include "sss_train.h"
+#include "sss_rows.h"
 #include "sss_collect.h"
 
 #include <stdint.h>
@@ -148,6 +149,16 @@ static int be_launch_wgrad(const SssWgradArgs& a, void* stream) {
 __global__ __launch_bounds__(256) void sss_collect_kernel(SssCollectArgs a, int phase) {
   const int b = (int)(blockIdx.x * 256 + threadIdx.x);
   if (b < a.num_envs) collect_env(a, phase, b, [&](int i, int v) { atomicOr(a.flags + i, v); }, [&](int i, int v) { atomicMax(a.flags + i, v); });
+}
+static int be_launch_rows(const SssRowsArgs& r, void* stream) { return sss_rows_launch(r, stream); }
+#include "sss_arena.h"
+static int be_launch_arena(const SssArenaArgs& a, int64_t rows_hint, void* stream) {
+  int64_t bx = rows_hint > 0 ? (rows_hint + 1023) / 1024 : 256;
+  bx = bx < 1 ? 1 : bx > 2048 ? 2048 : bx;
+  if (a.n_arrays > 0) hipLaunchKernelGGL(sss_arena_copy_kernel, dim3((unsigned)bx, (unsigned)a.n_arrays), dim3(256), 0, (hipStream_t)stream, a);
+  if (int rc = (int)hipGetLastError()) return rc;
+  hipLaunchKernelGGL(sss_arena_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
 }
 static int be_launch_collect(const SssCollectArgs& a, int phase, void* stream) {
   hipLaunchKernelGGL(sss_collect_kernel, dim3((unsigned)((a.num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, phase);

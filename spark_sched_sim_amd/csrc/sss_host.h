@@ -14,6 +14,7 @@
 #include "../../include/sss.h"
 #include "sss_layout.h"
 #include "sss_train.h"
+#include "sss_rows.h"
 #include "sss_wide.h"
 
 // envs with more than 64 executors run on the wide instantiation of the kernels (sss_wide.h)
@@ -669,6 +670,39 @@ extern "C" int sss_mlp_backward(const sss_mlp_args* a, void* stream) {
   if (int rc = sss_mlp_check(a, true)) return rc;
   if (!sss_mlp_supported(a->in_dim, a->h1, a->h2, a->out_dim, a->act)) return sss_fail(-31, "sss_mlp: not one of the architecture's MLP shapes");
   if (int rc = be_launch_mlp(sss_mlp_args_of(a), 1, stream)) return sss_fail(-30, std::string("mlp backward launch failed: ") + be_error(rc));
+  return 0;
+}
+
+#include "sss_arena.h"
+static int be_launch_arena(const SssArenaArgs& a, int64_t rows_hint, void* stream);
+extern "C" int sss_arena_append(const sss_arena_args* a, void* stream) {
+  if (!a || !a->totals_dev || !a->cursor_dev) return sss_fail(-1, "NULL argument");
+  if (a->n_arrays < 0 || a->n_arrays > SSS_ARENA_MAX_ARRAYS || a->n_obs < 0) return sss_fail(-34, "sss_arena_append: bad array or observation count");
+  SssArenaArgs r;
+  r.n_arrays = a->n_arrays, r.n_obs = a->n_obs, r.totals = a->totals_dev, r.cursor = a->cursor_dev;
+  for (int k = 0; k < 4; k++) r.capacity[k] = a->capacity[k];
+  for (int i = 0; i < a->n_arrays; i++) {
+    const sss_arena_array& s = a->arrays[i];
+    if (!s.src_dev || !s.dst_dev) return sss_fail(-1, "NULL argument");
+    if ((s.elem_bytes != 1 && s.elem_bytes != 4 && s.elem_bytes != 8) || s.per_row < 1 || s.kind < 0 || s.kind > 3 || s.shift < 0 || s.shift > 3 ||
+        (s.shift && s.elem_bytes != 8))
+      return sss_fail(-34, "sss_arena_append: bad array description");
+    r.arrays[i].src = s.src_dev, r.arrays[i].dst = s.dst_dev, r.arrays[i].elem_bytes = s.elem_bytes, r.arrays[i].per_row = s.per_row, r.arrays[i].kind = s.kind,
+    r.arrays[i].shift = s.shift;
+  }
+  if (int rc = be_launch_arena(r, a->rows_hint, stream)) return sss_fail(-30, std::string("arena launch failed: ") + be_error(rc));
+  return 0;
+}
+
+extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
+  if (!a || !a->a_dev || !a->b_dev || (a->n > 0 && !a->idx_dev)) return sss_fail(-1, "NULL argument");
+  if (a->op < 0 || a->op > 5) return sss_fail(-33, "sss_rows_op: unknown operation");
+  if (a->width < 1 || a->width > 64 || a->ld_a < a->width || a->n < 0) return sss_fail(-33, "sss_rows_op: width must be in 1..64, ld_a >= width, n >= 0");
+  if ((a->op == 2 || a->op == 3) && !a->c_dev) return sss_fail(-1, "NULL argument");
+  SssRowsArgs r;
+  r.n = a->n, r.ld_a = a->ld_a, r.width = a->width, r.op = a->op, r.idx = a->idx_dev, r.a = a->a_dev, r.b = a->b_dev, r.c = a->c_dev;
+  if (r.n == 0) return 0;
+  if (int rc = be_launch_rows(r, stream)) return sss_fail(-30, std::string("rows launch failed: ") + be_error(rc));
   return 0;
 }
 

@@ -297,9 +297,12 @@ class _NodeEncoder(nn.Module):
         layers = graph_layers(g)
         if not layers:
             return h_init
-        # nodes that are never the source end of an edge start from update(h_init), the rest from 0
+        # nodes that are never the source end of an edge start from update(h_init), the rest from 0 (the reference evaluates
+        # the update network on every node and masks; only the rows that are kept are evaluated here)
+        from .train_kernels import gather_rows, segment_sum
         is_parent = torch.zeros(M, dtype=torch.bool, device=x.device).index_fill_(0, src, True)
-        h = torch.where(is_parent[:, None], torch.zeros_like(h_init), self.mlp_update(h_init))
+        leaf = (~is_parent).nonzero(as_tuple=True)[0]
+        h = segment_sum(self.mlp_update(gather_rows(h_init, leaf, unique=True)), leaf, M, "unique")
         if self._kernel_message_passing(h_init):
             # one autograd node for the whole loop, both MLPs on the MLP kernels (train_kernels._MessagePassFn)
             from .train_kernels import message_passing
@@ -323,8 +326,9 @@ class _DagEncoder(nn.Module):
 
     def forward(self, h_node: torch.Tensor, g: dict[str, Any]) -> torch.Tensor:
         """per-job sums f32[J,emb] (scheduler.py:246-262)"""
+        from .train_kernels import segment_sum
         y = self.mlp(torch.cat([g["x"], h_node], -1))
-        return torch.zeros((g["job_obs"].numel(), y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, g["node_job"], y)
+        return segment_sum(y, g["node_job"], g["job_obs"].numel(), "sorted")  # (an observation's nodes are stored job by job)
 
 
 class _GlobalEncoder(nn.Module):
@@ -334,8 +338,9 @@ class _GlobalEncoder(nn.Module):
 
     def forward(self, h_dag: torch.Tensor, g: dict[str, Any]) -> torch.Tensor:
         """per-observation sums f32[n_obs,emb] (scheduler.py:265-283)"""
+        from .train_kernels import segment_sum
         y = self.mlp(h_dag)
-        return torch.zeros((g["n_obs"], y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, g["job_obs"], y)
+        return segment_sum(y, g["job_obs"], g["n_obs"], "sorted")
 
 
 class _Encoder(nn.Module):
@@ -671,20 +676,31 @@ class DecimaPolicy(nn.Module):
 
     def stage_scores(self, g: dict[str, Any], h: dict[str, torch.Tensor]):
         """scores of the schedulable stages only (scheduler.py:289-318): (f32[S], global node ids i64[S])"""
+        from .train_kernels import concat_rows
         idx = g["stage_mask"].nonzero(as_tuple=True)[0]
-        inp = torch.cat([g["x"][idx], h["node"].index_select(0, idx), h["dag"].index_select(0, g["node_job"][idx]), h["glob"].index_select(0, g["node_obs"][idx])], -1)
+        inp = concat_rows([(g["x"], idx), (h["node"], idx), (h["dag"], g["node_job"][idx]), (h["glob"], g["node_obs"][idx])])
         return self.stage_policy_network.mlp_score(inp).squeeze(-1), idx
 
     def exec_scores(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor) -> torch.Tensor:
         """f32[k,E] for jobs `job_gid` (global job ids, i64[k]); entry e scores "e+1 executors"; -inf
-        where that count is not allowed for the job (scheduler.py:337-385)"""
+        where that count is not allowed for the job (scheduler.py:337-385).
+
+        The reference evaluates the network on all k x E (job, count) pairs and masks afterwards. Only the allowed pairs
+        (count <= the job's cap) reach the softmax or carry a gradient, so only those rows are built and evaluated here - at
+        BASELINE config 5 a job allows 7 of 50 counts on average, and the k x E form was a fifth of a PPO update's device time
+        (profiles/r04_ppo.md). A row's score does not depend on the other rows of the call: the values are the same."""
+        from .train_kernels import concat_rows
         E = self.num_executors
         base = torch.cat([g["x"][g["job_first"][job_gid], :NUM_DAG_FEATURES], h["dag"].index_select(0, job_gid), h["glob"].index_select(0, g["job_obs"][job_gid])], -1)
-        acts = (torch.arange(E, device=base.device) / E).to(base.dtype)
-        inp = torch.cat([base[:, None, :].expand(-1, E, -1), acts[None, :, None].expand(base.shape[0], -1, -1)], -1)
+        k, dev = base.shape[0], base.device
+        acts = (torch.arange(E, device=dev) / E).to(base.dtype)
+        caps = g["job_cap"][job_gid].clamp(min=0, max=E)
+        total = int(caps.sum())  # (device -> host: the number of rows)
+        owner = torch.repeat_interleave(torch.arange(k, device=dev), caps, output_size=total)
+        count = torch.arange(total, device=dev) - (torch.cumsum(caps, 0) - caps)[owner]
+        inp = concat_rows([(base, owner), (acts[:, None], count)])
         s = self.exec_policy_network.mlp_score(inp).squeeze(-1)
-        mask = torch.arange(E, device=base.device)[None, :] < g["job_cap"][job_gid][:, None]
-        return torch.where(mask, s, torch.full_like(s, float("-inf")))
+        return torch.full((k, E), float("-inf"), dtype=s.dtype, device=dev).index_put((owner, count), s)
 
     @torch.no_grad()
     def act(self, g: dict[str, Any], generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:

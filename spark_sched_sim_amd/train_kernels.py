@@ -90,6 +90,146 @@ class KernelLinear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
+ROWS_GATHER, ROWS_SCATTER_ADD, ROWS_UPDATE, ROWS_TAKE, ROWS_SCATTER, ROWS_SEGMENT_SUM = 0, 1, 2, 3, 4, 5  # include/sss.h SSS_ROWS_*
+
+
+def rows_op(op: int, idx: torch.Tensor, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor | None = None, binding=None) -> None:
+    """`sss_rows_op` (include/sss.h; csrc/sss_rows.h): `a` f32[n, width] is the list side (a column slice of a wider row-major
+    matrix is allowed), `b` / `c` f32[rows, width] contiguous tables, `idx` i64[n]"""
+    import ctypes
+
+    from .binding import SssRowsArgs, device_of
+    bnd = binding if binding is not None else _binding()
+    width = a.shape[1]
+    n = b.shape[0] if op == ROWS_SEGMENT_SUM else a.shape[0]  # (SEGMENT_SUM: idx = the n + 1 row offsets of b's n segments)
+    if n == 0:
+        return
+    idx = idx.contiguous()
+    assert idx.dtype == torch.int64 and idx.numel() == (n + 1 if op == ROWS_SEGMENT_SUM else n)
+    assert a.dtype == b.dtype == torch.float32 and a.stride(1) == 1 and b.is_contiguous() and b.dim() == 2 and b.shape[1] == width
+    assert c is None or (c.dtype == torch.float32 and c.is_contiguous() and c.shape == b.shape)
+    dev = b.device
+    args = SssRowsArgs(n, a.stride(0) if a.shape[0] > 1 else max(width, a.stride(0)), width, op, idx.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None)
+    with device_of(dev):
+        bnd.check(bnd.lib.sss_rows_op(ctypes.byref(args), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+
+
+def _rows_ok(t: torch.Tensor, n: int) -> bool:
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and 1 <= t.shape[1] <= 64 and n >= MIN_ROWS
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """table[idx] (rows); backward: the gradient rows are added into a zero table with float atomics"""
+
+    @staticmethod
+    def forward(ctx, table, idx, unique):
+        table = table.contiguous()
+        out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+        rows_op(ROWS_GATHER, idx, out, table)
+        ctx.save_for_backward(idx)
+        ctx.rows, ctx.unique = table.shape[0], unique
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        if g.stride(1) != 1 or (g.stride(0) < g.shape[1] and g.shape[0] > 1):  # (an expanded gradient)
+            g = g.contiguous()
+        gt = torch.zeros((ctx.rows, g.shape[1]), dtype=torch.float32, device=g.device)
+        rows_op(ROWS_SCATTER if ctx.unique else ROWS_SCATTER_ADD, idx, g, gt)
+        return gt, None, None
+
+
+def segment_offsets(idx: torch.Tensor, n_seg: int) -> torch.Tensor:
+    """i64[n_seg + 1] row offsets of the segments of a NON-DECREASING owner array (segment s = rows ptr[s] .. ptr[s + 1])"""
+    return torch.searchsorted(idx, torch.arange(n_seg + 1, device=idx.device))
+
+
+class _SegmentSumFn(torch.autograd.Function):
+    """out[idx[i]] += y[i] into a zero [n_seg, width] table; backward: the gradient of a row is its segment's.
+    mode "sorted": idx is non-decreasing - every segment is a range of rows, summed in row order without atomics;
+    mode "unique": idx has no repeats - plain stores; else float atomics"""
+
+    @staticmethod
+    def forward(ctx, y, idx, n_seg, mode):
+        if y.stride(1) != 1:
+            y = y.contiguous()
+        if mode == "sorted":
+            out = torch.empty((n_seg, y.shape[1]), dtype=torch.float32, device=y.device)
+            rows_op(ROWS_SEGMENT_SUM, segment_offsets(idx, n_seg), y, out)
+        else:
+            out = torch.zeros((n_seg, y.shape[1]), dtype=torch.float32, device=y.device)
+            rows_op(ROWS_SCATTER if mode == "unique" else ROWS_SCATTER_ADD, idx, y, out)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        gy = torch.empty((idx.numel(), g.shape[1]), dtype=torch.float32, device=g.device)
+        rows_op(ROWS_GATHER, idx, gy, g)
+        return gy, None, None, None
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, unique: bool = False) -> torch.Tensor:
+    """`table.index_select(0, idx)` for a 2-D table, on the row kernels when it is a large float32 gather on the GPU
+    (`unique`: idx has no repeats - the backward pass stores instead of adding)"""
+    if _rows_ok(table, idx.numel()) and torch.is_grad_enabled():
+        return _GatherRowsFn.apply(table, idx.contiguous(), unique)
+    return table.index_select(0, idx)
+
+
+def segment_sum(y: torch.Tensor, idx: torch.Tensor, n_seg: int, mode: str = "") -> torch.Tensor:
+    """`zeros(n_seg, width).index_add_(0, idx, y)`, on the row kernels when it is a large float32 sum on the GPU. `mode`: what
+    the caller knows about idx - "sorted" (non-decreasing), "unique" (no repeats) or "" (see `_SegmentSumFn`)"""
+    if _rows_ok(y, y.shape[0]) and torch.is_grad_enabled():
+        return _SegmentSumFn.apply(y, idx.contiguous(), n_seg, mode)
+    return torch.zeros((n_seg, y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, idx, y)
+
+
+class _ConcatRowsFn(torch.autograd.Function):
+    """cat([t_0[idx_0], t_1[idx_1], ...], -1) written in place by one gather per part (no intermediate rows, no copy into the
+    concatenation); backward: one scatter-add per part straight from the column slice of the gradient"""
+
+    @staticmethod
+    def forward(ctx, n_parts, *args):
+        tables, idxs = [t.contiguous() for t in args[:n_parts]], list(args[n_parts:])
+        n = idxs[0].numel()
+        out = torch.empty((n, sum(t.shape[1] for t in tables)), dtype=torch.float32, device=tables[0].device)
+        off = 0
+        for t, ix in zip(tables, idxs):
+            rows_op(ROWS_GATHER, ix, out[:, off:off + t.shape[1]], t)
+            off += t.shape[1]
+        ctx.save_for_backward(*idxs)
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idxs = ctx.saved_tensors
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        grads, off = [], 0
+        for k, (shape, ix) in enumerate(zip(ctx.shapes, idxs)):
+            if ctx.needs_input_grad[1 + k]:
+                gt = torch.zeros(shape, dtype=torch.float32, device=g.device)
+                rows_op(ROWS_SCATTER_ADD, ix, g[:, off:off + shape[1]], gt)
+                grads.append(gt)
+            else:
+                grads.append(None)
+            off += shape[1]
+        return (None, *grads, *([None] * len(idxs)))
+
+
+def concat_rows(parts) -> torch.Tensor:
+    """`torch.cat([t.index_select(0, idx) for t, idx in parts], -1)`; on the row kernels when large, float32, on the GPU"""
+    n = parts[0][1].numel()
+    if all(_rows_ok(t, n) for t, _ in parts) and torch.is_grad_enabled():
+        return _ConcatRowsFn.apply(len(parts), *[t for t, _ in parts], *[ix.contiguous() for _, ix in parts])
+    return torch.cat([t.index_select(0, ix) for t, ix in parts], -1)
+
+
 def pack_mlp(lin1: nn.Linear, lin2: nn.Linear, lin3: nn.Linear) -> torch.Tensor:
     """[W1, b1, W2^T, b2, W3, b3] as one flat tensor (include/sss.h sss_gnn_launch / sss_mlp_forward)"""
     parts = [lin1.weight, lin1.bias, lin2.weight.t(), lin2.bias, lin3.weight, lin3.bias]
@@ -234,18 +374,21 @@ class _MessagePassFn(torch.autograd.Function):
         mx, ma1, ma2 = f(ne, 16), f(ne, 32), f(ne, 16)  # message MLP: inputs and hidden activations of every edge, layer after layer
         ux, ua1, ua2 = f(nr, 16), f(nr, 32), f(nr, 16)  # update MLP: the same per receiving node
         h = h0.clone()
+        h_init = h_init.contiguous()
         eo = ro = 0
         for child, pos, recv in layers:
             n_e, n_r = int(child.numel()), int(recv.numel())
             if n_e == 0 or n_r == 0:
                 continue
             xs = mx[eo:eo + n_e]
-            torch.index_select(h, 0, child, out=xs)
+            rows_op(ROWS_GATHER, child, xs, h)
             _, _, my = mlp_forward(xs, packed_msg, D, 0, slope, a1=ma1[eo:eo + n_e], a2=ma2[eo:eo + n_e])
             agg = ux[ro:ro + n_r]
-            agg.zero_().index_add_(0, pos, my)
+            # the layer's edges are listed receiver by receiver (graph_layers: edge ids ascending, edges stored source node by
+            # source node), so a receiver's messages are a range of rows: summed in order, no atomics
+            rows_op(ROWS_SEGMENT_SUM, segment_offsets(pos, n_r), my, agg)
             _, _, uy = mlp_forward(agg, packed_upd, D, 0, slope, a1=ua1[ro:ro + n_r], a2=ua2[ro:ro + n_r])
-            h.index_copy_(0, recv, uy.add_(h_init.index_select(0, recv)))  # (every read of the layer came before this write)
+            rows_op(ROWS_UPDATE, recv, uy, h, h_init)  # h[recv] = uy + h_init[recv] (every read of the layer came before this write)
             eo, ro = eo + n_e, ro + n_r
         ctx.layers, ctx.slope = layers, slope
         ctx.save_for_backward(mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd)
@@ -259,7 +402,7 @@ class _MessagePassFn(torch.autograd.Function):
         f = lambda t: torch.empty_like(t)  # noqa: E731
         mdy, mg1, mg2 = f(mx), f(ma1), f(ma2)
         udy, ug1, ug2 = f(ux), f(ua1), f(ua2)
-        gh = gh_in.clone()  # gradient w.r.t. the embeddings as they were before the layer being undone
+        gh = gh_in.contiguous().clone()  # gradient w.r.t. the embeddings as they were before the layer being undone
         g_init = torch.zeros_like(gh)
         eo, ro = int(mx.shape[0]), int(ux.shape[0])
         for child, pos, recv in reversed(layers):
@@ -268,14 +411,13 @@ class _MessagePassFn(torch.autograd.Function):
                 continue
             eo, ro = eo - n_e, ro - n_r
             g_new = udy[ro:ro + n_r]
-            torch.index_select(gh, 0, recv, out=g_new)
-            gh.index_fill_(0, recv, 0.0)  # the receivers' previous embeddings were overwritten
-            g_init.index_add_(0, recv, g_new)
+            # g_new = gh[recv]; gh[recv] = 0 (the receivers' previous embeddings were overwritten); g_init[recv] += g_new
+            rows_op(ROWS_TAKE, recv, g_new, gh, g_init)
             _, _, g_agg = mlp_backward(g_new, ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, 0, slope, g1=ug1[ro:ro + n_r], g2=ug2[ro:ro + n_r])
             g_msg = mdy[eo:eo + n_e]
-            torch.index_select(g_agg, 0, pos, out=g_msg)
+            rows_op(ROWS_GATHER, pos, g_msg, g_agg)
             _, _, g_xs = mlp_backward(g_msg, ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, 0, slope, g1=mg1[eo:eo + n_e], g2=mg2[eo:eo + n_e])
-            gh.index_add_(0, child, g_xs)
+            rows_op(ROWS_SCATTER_ADD, child, g_xs, gh)
         grads = []
         for x, a1, a2, dy, g1, g2 in ((mx, ma1, ma2, mdy, mg1, mg2), (ux, ua1, ua2, udy, ug1, ug2)):
             if x.shape[0] == 0:

@@ -525,6 +525,14 @@ class Trainer:
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", 0)
         self.device = dev
+        if dev.type == "cuda" and train_cfg.get("allocator_rounding", True):
+            # The sizes of a minibatch's tensors (GBs at BASELINE config 5) differ by a percent from one minibatch to the next; the
+            # caching allocator then keeps asking the driver for slightly larger blocks (0.1 s per hipMalloc, 0.9 s of a 3.4 s
+            # update: profiles/r04_ppo.md). Rounding request sizes up to eighths of a power of two makes the blocks reusable.
+            try:
+                torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:8")
+            except Exception:  # (an allocator backend without the option)
+                pass
         E = int(self.env_cfg["num_executors"])
         kw = {k: v for k, v in agent_cfg.items() if k != "agent_cls"}
         self.policy = DecimaPolicy(num_executors=E, opt_cls=train_cfg["opt_cls"], opt_kwargs=train_cfg.get("opt_kwargs"),

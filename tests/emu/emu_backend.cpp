@@ -66,6 +66,24 @@ static int be_launch_collect(const SssCollectArgs& a, int phase, void*) {
   for (int b = 0; b < a.num_envs; b++) collect_env(a, phase, b, [&](int i, int v) { a.flags[i] |= v; }, [&](int i, int v) { a.flags[i] = v > a.flags[i] ? v : a.flags[i]; });
   return 0;
 }
+// sss_rows_op on the host: the element statement of sss_rows.h in plain loops
+#include "sss_rows.h"
+static int be_launch_rows(const SssRowsArgs& r, void*) {
+  for (int64_t i = 0; i < r.n; i++)
+    for (int j = 0; j < r.width; j++) sss_rows_element(r, i, j, [](float* p, float v) { *p += v; });
+  return 0;
+}
+// sss_arena_append on the host
+#include "sss_arena.h"
+static int be_launch_arena(const SssArenaArgs& a, int64_t, void*) {
+  if (arena_fits(a))
+    for (int k = 0; k < a.n_arrays; k++) {
+      const int64_t n = arena_rows(a, a.arrays[k].kind) * a.arrays[k].per_row;
+      for (int64_t e = 0; e < n; e++) arena_copy_element(a, a.arrays[k], e);
+    }
+  arena_advance(a);
+  return 0;
+}
 // sss_linear_wgrad on the host (the MFMA kernel is gfx950-only): plain loops, same results up to summation order
 static int be_launch_wgrad(const SssWgradArgs& a, void*) {
   for (int n = 0; n < a.N; n++) {

@@ -206,6 +206,18 @@ def test_mlp_entry_points_on_the_host_backend():
         mlp_forward(torch.zeros((4, 7)), torch.zeros(2000), (7, 32, 16, 16), 0, 0.2, binding=b)
 
 
+def test_rows_entry_point_on_the_host_backend():
+    """include/sss.h sss_rows_op through the emulator library's host implementation against torch indexing: the argument
+    plumbing of spark_sched_sim_amd.train_kernels.rows_op (the four operations, a list side that is a column slice, widths that
+    are and are not multiples of four, error codes)"""
+    from training_util import check_rows_ops
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+
+    check_rows_ops(Binding(load_emu()), "cpu", n=300)
+
+
 def test_two_groups_of_envs_record_what_one_group_records():
     """`RolloutCollector(groups=2)` - the envs take their steps in two alternating groups (on two streams on the GPU), the
     flags of a group's step are read one step late - against `groups=1`: the same record per env, and every sample's

@@ -171,6 +171,15 @@ def test_message_passing_function_matches_the_tensor_op_form():
             if "bias" in n_:
                 p_.normal_(0.0, 0.1)
     assert g["x"].shape[0] >= 8192 and int(g["obs_depth"].max()) >= 3
+    # the orders the sums of the update rely on (train_kernels.segment_sum "sorted", _MessagePassFn): an observation's nodes are
+    # stored job by job, its jobs together, a layer's edges receiver by receiver - also after a minibatch has been cut out
+    from spark_sched_sim_amd.decima import graph_layers, select_observations
+    sub = select_observations(g, torch.randperm(g["n_obs"], device=dev)[: g["n_obs"] // 2])
+    for gg in (g, sub):
+        nondecr = lambda v: bool((v[1:] >= v[:-1]).all())  # noqa: E731
+        assert nondecr(gg["node_job"]) and nondecr(gg["job_obs"]) and nondecr(gg["node_obs"])
+        for e, recv in graph_layers(gg):
+            assert nondecr(gg["src"][e]) and nondecr(recv)
     w = torch.randn((g["x"].shape[0], 16), device=dev)
     out = {}
     for flag in (True, False):
@@ -186,6 +195,49 @@ def test_message_passing_function_matches_the_tensor_op_form():
         a, b = out[True][1][k], out[False][1][k]
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * max(1.0, float(b.abs().max()))), (k, float((a - b).abs().max()), float(b.abs().max()))
     env.close()
+
+
+@pytest.mark.gpu
+def test_rows_kernels_match_torch_indexing():
+    """`sss_rows_kernel` (csrc/sss_rows.h) against torch indexing, 16-byte and 4-byte forms, and the autograd functions built on
+    it (`gather_rows`, `segment_sum`, `concat_rows`) against index_select / index_add_ / cat through autograd"""
+    from training_util import check_rows_ops
+
+    from spark_sched_sim_amd.binding import Binding
+    from spark_sched_sim_amd.train_kernels import concat_rows, gather_rows, segment_sum
+
+    dev = torch.device("cuda:0")
+    check_rows_ops(Binding(), dev, n=100_003)
+    torch.manual_seed(5)
+    n, rows = 50_000, 9_000
+    t1 = torch.randn((rows, 16), device=dev, requires_grad=True)
+    t2 = torch.randn((rows // 3, 16), device=dev, requires_grad=True)
+    x = torch.randn((rows, 5), device=dev)
+    i1, i2 = torch.randint(0, rows, (n,), device=dev), torch.randint(0, rows // 3, (n,), device=dev)
+    w = torch.randn((n, 37), device=dev)
+    got = concat_rows([(x, i1), (t1, i1), (t2, i2)])
+    want = torch.cat([x[i1], t1.index_select(0, i1), t2.index_select(0, i2)], -1)
+    assert torch.equal(got, want)
+    ga = torch.autograd.grad((got * w).sum(), (t1, t2))
+    gb = torch.autograd.grad((want * w).sum(), (t1, t2))
+    assert all(torch.allclose(a, b, rtol=1e-4, atol=1e-4) for a, b in zip(ga, gb))
+    y = torch.randn((n, 16), device=dev, requires_grad=True)
+    seg = torch.sort(torch.randint(0, rows, (n,), device=dev))[0]
+    wv = torch.randn((rows, 16), device=dev)
+    for mode in ("", "sorted"):
+        s1, s2 = segment_sum(y, seg, rows, mode), torch.zeros((rows, 16), device=dev).index_add_(0, seg, y)
+        assert torch.allclose(s1, s2, rtol=1e-5, atol=1e-5)
+        assert torch.equal(torch.autograd.grad((s1 * wv).sum(), y)[0], torch.autograd.grad((s2 * wv).sum(), y)[0])
+    assert torch.equal(segment_sum(y, seg, rows, "sorted"), segment_sum(y, seg, rows, "sorted"))  # a fixed order: same bits
+    uq = torch.randperm(rows, device=dev)[: rows // 2]
+    yu = torch.randn((rows // 2, 16), device=dev, requires_grad=True)
+    assert torch.equal(segment_sum(yu, uq, rows, "unique"), torch.zeros((rows, 16), device=dev).index_copy_(0, uq, yu))
+    g1 = gather_rows(t1, i1)
+    assert torch.equal(g1, t1.index_select(0, i1))
+    tu = torch.randn((rows, 16), device=dev, requires_grad=True)
+    big = torch.randperm(rows, device=dev)[:8500]
+    wu = torch.randn((8500, 16), device=dev)
+    assert torch.equal(torch.autograd.grad((gather_rows(tu, big, unique=True) * wu).sum(), tu)[0], torch.autograd.grad((tu.index_select(0, big) * wu).sum(), tu)[0])
 
 
 @pytest.mark.gpu

@@ -158,3 +158,60 @@ def reference_smoke_test_config(artifacts_dir: str) -> dict:
         "env": dict(num_executors=50, job_arrival_cap=10, moving_delay=2000.0, mean_time_limit=2.0e7, job_arrival_rate=4.0e-5,
                     warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"),
     }
+
+
+def check_rows_ops(binding, device, n):
+    """`train_kernels.rows_op` (include/sss.h sss_rows_op) against torch's index_select / index_add_ / index_copy on the same
+    data; the gather is exact, the sums agree up to the order of the additions"""
+    import pytest
+
+    from spark_sched_sim_amd.train_kernels import ROWS_GATHER, ROWS_SCATTER, ROWS_SCATTER_ADD, ROWS_SEGMENT_SUM, ROWS_TAKE, ROWS_UPDATE, rows_op, segment_offsets
+
+    gen = torch.Generator().manual_seed(11)
+    rnd = lambda *shape: torch.randn(shape, generator=gen).to(device)  # noqa: E731
+    for width in (1, 5, 16, 21, 35, 36, 64):
+        rows = max(3, n // 3)
+        table = rnd(rows, width)
+        idx = torch.randint(0, rows, (n,), generator=gen).to(device)
+        # gather into a whole matrix and into a column slice of a wider one
+        out = torch.empty((n, width), device=device)
+        rows_op(ROWS_GATHER, idx, out, table, binding=binding)
+        assert torch.equal(out, table[idx])
+        wide = torch.full((n, width + 7), -1.0, device=device)
+        rows_op(ROWS_GATHER, idx, wide[:, 3:3 + width], table, binding=binding)
+        assert torch.equal(wide[:, 3:3 + width], table[idx]) and bool((wide[:, :3] == -1).all()) and bool((wide[:, 3 + width:] == -1).all())
+        # scatter-add, from a whole matrix and from a column slice
+        src = rnd(n, width + 4)
+        for a in (src[:, :width].contiguous(), src[:, 2:2 + width]):
+            acc = table.clone()
+            rows_op(ROWS_SCATTER_ADD, idx, a, acc, binding=binding)
+            assert torch.allclose(acc, table.clone().index_add_(0, idx, a), rtol=1e-5, atol=1e-5)
+        # the two receiver operations (ids without repeats)
+        uniq = torch.randperm(rows, generator=gen)[: max(1, rows // 2)].to(device)
+        a, h, c = rnd(uniq.numel(), width), rnd(rows, width), rnd(rows, width)
+        want = h.clone().index_copy_(0, uniq, a + c[uniq])
+        rows_op(ROWS_UPDATE, uniq, a, h, c, binding=binding)
+        assert torch.equal(h, want)
+        gh, gi = rnd(rows, width), rnd(rows, width)
+        want_a, want_gh, want_gi = gh[uniq].clone(), gh.clone().index_fill_(0, uniq, 0.0), gi.clone().index_add_(0, uniq, gh[uniq])
+        got_a = torch.empty_like(a)
+        rows_op(ROWS_TAKE, uniq, got_a, gh, gi, binding=binding)
+        assert torch.equal(got_a, want_a) and torch.equal(gh, want_gh) and torch.equal(gi, want_gi)
+        # stores to rows without repeats; sums over ranges of rows (empty segments included)
+        tab = rnd(rows, width)
+        want = tab.clone().index_copy_(0, uniq, a)
+        rows_op(ROWS_SCATTER, uniq, a, tab, binding=binding)
+        assert torch.equal(tab, want)
+        owner = torch.sort(torch.randint(0, rows, (n,), generator=gen))[0].to(device)
+        ptr = segment_offsets(owner, rows)
+        assert int(ptr[0]) == 0 and int(ptr[-1]) == n
+        for a2 in (src[:, :width].contiguous(), src[:, 2:2 + width]):
+            sums = torch.full((rows, width), 7.0, device=device)
+            rows_op(ROWS_SEGMENT_SUM, ptr, a2, sums, binding=binding)
+            assert torch.allclose(sums, torch.zeros((rows, width), device=device).index_add_(0, owner, a2), rtol=1e-5, atol=1e-5)
+    empty = torch.zeros((0,), dtype=torch.long, device=device)
+    rows_op(ROWS_GATHER, empty, torch.empty((0, 16), device=device), rnd(4, 16), binding=binding)  # nothing to do: no launch
+    with pytest.raises(ValueError):
+        rows_op(ROWS_GATHER, torch.zeros(2, dtype=torch.long, device=device), torch.empty((2, 65), device=device), rnd(4, 65), binding=binding)
+    with pytest.raises(ValueError):
+        rows_op(7, torch.zeros(2, dtype=torch.long, device=device), torch.empty((2, 16), device=device), rnd(4, 16), binding=binding)

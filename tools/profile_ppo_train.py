@@ -55,6 +55,10 @@ def main():
         torch.cuda.synchronize(); a3 = time.perf_counter()
         tr.policy.update_parameters(None)
         torch.cuda.synchronize(); a4 = time.perf_counter()
+    jg = torch.cumsum(g["obs_jobs"], 0) - g["obs_jobs"] + acts[1][mb]
+    print(json.dumps({"minibatch_edges": int(g["src"].numel()), "minibatch_jobs": int(g["job_obs"].numel()), "schedulable": int(g["stage_mask"].sum()),
+                      "mean_allowed_executor_counts": float(g["job_cap"][jg].float().mean()), "layers": int(g["obs_depth"].max()),
+                      "receivers": int(sum(int(r.numel()) for _, r in g.get("layers", [])))}))
     print(json.dumps({"minibatch_obs": int(mb.numel()), "minibatch_nodes": int(g["x"].shape[0]), "select_s": a1 - a0, "forward_loss_s": a2 - a1, "backward_s": a3 - a2, "optim_s": a4 - a3}))
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
