@@ -72,6 +72,98 @@ class Rollouts:
 ActFn = Callable[[dict[str, Any], torch.Tensor], dict[str, torch.Tensor]]
 
 
+class GraphArena:
+    """The record of a collection's observations as ONE compact graph (what `concat_graphs` of the per-step graphs gives), built
+    on the device while collecting: `append` copies the step's graph out of the env's capacity buffers (`decima_graph_on_device`)
+    behind what is there, at cursors that stay on the device, shifting its ids to arena ids (include/sss.h sss_arena_append).
+    The host never learns a step's sizes; it keeps `headroom` steps' worth of the env's capacities free beyond the last cursor
+    it has seen (`ensure`), growing the arrays geometrically when that is not the case."""
+
+    NODES, EDGES, JOBS, OBS = 0, 1, 2, 3
+    # (name, dtype, elements per row, what it has one row per, what its ids name: 0 nothing, 1 nodes, 2 jobs, 3 observations)
+    ARRAYS = (("x", torch.float32, 5, 0, 0), ("node_obs", torch.int64, 1, 0, 3), ("node_loc", torch.int64, 1, 0, 0), ("node_job", torch.int64, 1, 0, 2),
+              ("gen", torch.int32, 1, 0, 0), ("stage_mask", torch.bool, 1, 0, 0), ("sched_rank", torch.int64, 1, 0, 0), ("node_recv", torch.int32, 1, 0, 0),
+              ("src", torch.int64, 1, 1, 1), ("dst", torch.int64, 1, 1, 1), ("edge_obs", torch.int64, 1, 1, 3), ("edge_layers", torch.int32, 1, 1, 0),
+              ("job_obs", torch.int64, 1, 2, 3), ("job_cap", torch.int64, 1, 2, 0), ("job_first", torch.int64, 1, 2, 1),
+              ("obs_nodes", torch.int64, 1, 3, 0), ("obs_jobs", torch.int64, 1, 3, 0), ("obs_depth", torch.int32, 1, 3, 0))
+
+    def __init__(self, env, capacity: Sequence[int] | None = None):
+        self.env, self.dev, self.B = env, env.device, env.num_envs
+        d = env.dims
+        self.step_max = (self.B * d.node_cap, self.B * d.edge_cap, self.B * d.job_cap, self.B)  # what one step can add at most
+        self.capacity = [max(int(c), 16 * m) for c, m in zip(capacity or (0, 0, 0, 0), self.step_max)]
+        self.capacity[3] = max(self.capacity[3], 1024 * self.B)
+        self.cursor = torch.zeros(8, dtype=torch.int64, device=self.dev)
+        self.seen = [0, 0, 0, 0]   # the last cursors the host has seen
+        self.seen_steps = 0        # ... and how many steps they cover
+        self.steps = 0             # steps appended (enqueued)
+        self.buf = {name: torch.empty((self.capacity[kind], per) if per > 1 else (self.capacity[kind],), dtype=dt, device=self.dev)
+                    for name, dt, per, kind, _ in self.ARRAYS}
+        self._args = None
+
+    def _build_args(self, g):
+        from .binding import SssArenaArgs, SssArenaArray
+        a = SssArenaArgs()
+        a.n_arrays, a.n_obs = len(self.ARRAYS), self.B
+        a.totals_dev, a.cursor_dev = g["totals_dev"].data_ptr(), self.cursor.data_ptr()
+        for k in range(4):
+            a.capacity[k] = self.capacity[k]
+        a.rows_hint = 0
+        for i, (name, dt, per, kind, shift) in enumerate(self.ARRAYS):
+            src = g[name]
+            assert src.dtype == dt and src.is_contiguous(), name
+            a.arrays[i] = SssArenaArray(src.data_ptr(), self.buf[name].data_ptr(), src.element_size(), per, kind, shift)
+        self._args = (a, tuple(g[name].data_ptr() for name, *_ in self.ARRAYS) + (g["totals_dev"].data_ptr(),))
+
+    def note(self, cursors: Sequence[int], steps: int) -> None:
+        """the host has seen the cursors as they were after `steps` appended steps"""
+        self.seen, self.seen_steps = [int(c) for c in cursors[:4]], int(steps)
+
+    def ensure(self, sync) -> None:
+        """room for the next step whatever its size: the steps the host has not seen the cursors of may each have added a
+        step's maximum. Grows (after `sync()`, which must leave `note` up to date) when that bound does not fit."""
+        def short():
+            ahead = self.steps - self.seen_steps + 1
+            return [k for k in range(4) if self.seen[k] + ahead * self.step_max[k] > self.capacity[k]]
+        if not short():
+            return
+        sync()
+        for k in short():
+            new_cap = max(2 * self.capacity[k], self.seen[k] + 8 * self.step_max[k])
+            for name, dt, per, kind, _ in self.ARRAYS:
+                if kind == k:
+                    old = self.buf[name]
+                    self.buf[name] = torch.empty((new_cap, *old.shape[1:]), dtype=dt, device=self.dev)
+                    self.buf[name][: self.seen[k]] = old[: self.seen[k]]
+            self.capacity[k] = new_cap
+        self._args = None
+
+    def append(self, g: dict[str, Any], rows_hint: int = 0) -> None:
+        import ctypes
+
+        from .binding import device_of
+        key = tuple(g[name].data_ptr() for name, *_ in self.ARRAYS) + (g["totals_dev"].data_ptr(),)
+        if self._args is None or self._args[1] != key:
+            self._build_args(g)
+        a = self._args[0]
+        a.rows_hint = int(rows_hint)
+        with device_of(self.dev):
+            self.env._b.check(self.env._b.lib.sss_arena_append(ctypes.byref(a), self.env._stream()))
+        self.steps += 1
+
+    def finish(self, n_steps: int) -> dict[str, Any]:
+        """the graph of the first `n_steps` steps (call after a sync with `note` up to date for at least that many steps; the
+        steps behind them must have been empty)"""
+        cur = [int(c) for c in self.cursor[:6].tolist()]
+        if cur[5]:
+            raise RuntimeError("the graph arena overflowed (the headroom rule of GraphArena.ensure was violated)")
+        sizes = (cur[0], cur[1], cur[2], n_steps * self.B)
+        out: dict[str, Any] = {name: self.buf[name][: sizes[kind]] for name, _, _, kind, _ in self.ARRAYS}
+        out["gen"] = out["gen"].long()
+        out["n_obs"], out["n_pad"] = n_steps * self.B, self.env.dims.node_cap
+        return out
+
+
 class RolloutCollector:
     """the reference's `RolloutWorkerSync` / `RolloutWorkerAsync` loops for all envs at once.
 
@@ -84,12 +176,17 @@ class RolloutCollector:
     SSS_SKIP_ENV until the others catch up."""
 
     def __init__(self, env, mean_time_limit: float, base_seeds: Sequence[int], seed_step: int, num_executors: int,
-                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None, on_env_error: str = "raise", groups: int = 1):
+                 policy=None, act_fn: ActFn | None = None, generator: torch.Generator | None = None, on_env_error: str = "raise", groups: int = 1,
+                 record_on_device: bool = True):
         """groups: the envs are split into that many groups that take their steps alternately, each on its own HIP stream (the
         idea: while one group's step launch waits for its slowest env the other group's policy kernels have the device). The
         record and the results per env are the same as with one group; on one MI355X it is SLOWER (every launch of the policy
         pass is latency-bound and costs a half-size group as much as the whole batch: 0.88 -> 1.84 ms per row of the record
         with two groups, profiles/r03_ppo.md), so 1 is the default.
+        record_on_device: synchronous collection with the default policy sampling keeps the host out of the loop - the step's
+        graph stays in the env's capacity buffers with its sizes on the device, `GraphArena` appends it to the record there, and
+        the flags of a step are read a few steps late (the steps enqueued in between find every env frozen when the collection
+        turns out to be over). The record is the same; False reads the sizes and the flags every step (two waits per step).
         on_env_error: what to do when an env reports an error from `step` - in practice the
         reference's `[step]` assertion (spark_sched_sim.py:212-215), which valid Decima actions can
         trigger (tests/golden/stall_case.json). "raise" = the reference's behaviour (the worker
@@ -97,6 +194,8 @@ class RolloutCollector:
         rollout ends before the failing step and training goes on (`env_errors` counts them)."""
         assert on_env_error in ("raise", "truncate")
         self.groups = max(1, min(int(groups), env.num_envs))
+        self.record_on_device = bool(record_on_device)
+        self._arena_sizes = None  # the previous collection's graph sizes: the next arena's starting capacity
         self.on_env_error = on_env_error
         self.env_errors = 0
         self.env = env
@@ -173,6 +272,25 @@ class RolloutCollector:
                 st.wait_stream(main)
         acts = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(G)]
         lib = env._b.lib
+        # the loop without waits (see __init__, record_on_device)
+        fast = (self.record_on_device and not asynchronous and G == 1 and self.act_fn is None and self.policy is not None and B > 0
+                and self.policy._use_kernels() and 16 * env.dims.node_cap <= 65536)
+        LAG, R = 4, 8  # flags are read at most LAG steps late; rings of R slots for what a step leaves for the host
+        arena = None
+        if fast:
+            cuda = dev.type == "cuda"
+            pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+            cap0 = None
+            if self._arena_sizes:
+                d = env.dims
+                step_max = (B * d.node_cap, B * d.edge_cap, B * d.job_cap, B)
+                cap0 = [int(1.1 * c) + (LAG + 4) * m for c, m in zip(self._arena_sizes, step_max)]
+            arena = GraphArena(env, cap0)
+            ring_flags, ring_cur = pin(torch.zeros((R, 8), dtype=torch.int32)), pin(torch.zeros((R, 8), dtype=torch.int64))
+            ring_acts = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(R)]
+            ring_ev = [torch.cuda.Event() for _ in range(R)] if cuda else None
+        n_kept = 0  # fast: steps whose observations are part of the record
+        calls0 = getattr(self.policy, "_calls", 0) if fast else 0
         graphs: dict[tuple[int, int], dict[str, Any]] = {}
         issued = [0] * G             # steps enqueued per group
         unread: list[Any] = [None] * G  # (t, graph, stage_idx, num_exec) of the group's step whose flags have not been read yet
@@ -186,10 +304,13 @@ class RolloutCollector:
 
         def read_flags(k: int) -> None:
             """what became of group k's last step: the ONE device->host read per group and step beside the graph totals"""
-            nonlocal n_failed
             t, g, stage_idx, num_exec = unread[k]
             unread[k] = None
-            any_bad, any_done, any_left, bad_env, any_recorded = flags[t, k, :5].tolist()
+            handle_flags(k, t, g, stage_idx, num_exec, flags[t, k, :5].tolist())
+
+        def handle_flags(k: int, t: int, g, stage_idx, num_exec, vals) -> None:
+            nonlocal n_failed, n_kept
+            any_bad, any_done, any_left, bad_env, any_recorded = vals
             if any_bad:
                 n_bad = int(pending.sum()) - n_failed
                 n_failed += n_bad
@@ -210,7 +331,9 @@ class RolloutCollector:
                 if not any_recorded:
                     alive[k] = False
                     return
-            graphs[(t, k)] = g
+            if g is not None:
+                graphs[(t, k)] = g
+            n_kept = t + 1
             if asynchronous and any_done:
                 done = rec["resets"][t].view(torch.bool)
                 self._reset(mask=done if member_b[k] is None else done & member_b[k])
@@ -226,11 +349,18 @@ class RolloutCollector:
                 flags = torch.cat([flags, torch.zeros_like(flags)])
                 cap *= 2
             act_b = active.view(torch.bool) if member_b[k] is None else active.view(torch.bool) & member_b[k]
-            g = self.env.decima_graph(act_b)  # recorded for training
+            if fast:
+                arena.ensure(drain_all)
+                g = self.env.decima_graph_on_device(act_b)  # (sizes stay on the device; appended to the arena below)
+            else:
+                g = self.env.decima_graph(act_b)  # recorded for training
             a = self.act_fn(g, self.step_counts) if self.act_fn is not None else self.policy.act(g, self.generator)
+            if fast:
+                hint = g["totals_hint"].tolist()
+                arena.append(g, rows_hint=max(5 * hint[0], hint[1], hint[2], B) if hint[0] >= 0 else 0)
             sel = [a[n] if a[n].dtype == torch.int64 and a[n].is_contiguous() else a[n].to(torch.int64).contiguous() for n in ("stage_sel", "job_idx", "exec_sel")]
             lg = a["lgprob"] if a["lgprob"].dtype == torch.float32 and a["lgprob"].is_contiguous() else a["lgprob"].float().contiguous()
-            stage_idx, num_exec = acts[k]
+            stage_idx, num_exec = ring_acts[t % R] if fast else acts[k]
             c = SssCollectArgs(B, int(asynchronous), t, float(duration), env.obs_f64.data_ptr(), env.obs_i32.data_ptr(), env.obs_i32.stride(0),
                                self.tl_env.time_limit.data_ptr(), active.data_ptr(), wall.data_ptr(), elapsed.data_ptr(), self.step_counts.data_ptr(),
                                pending.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), sel[2].data_ptr(), lg.data_ptr(), stage_idx.data_ptr(), num_exec.data_ptr(),
@@ -241,11 +371,41 @@ class RolloutCollector:
             env.step_async(stage_idx, num_exec)
             with device_of(dev):
                 env._b.check(lib.sss_collect_step(ctypes.byref(c), 1, stream))
-            unread[k] = (t, g, stage_idx, num_exec)
+            if fast:  # what the host wants of this step, without waiting for it: its flags and the arena's cursors after it
+                ring_flags[t % R].copy_(flags[t, k], non_blocking=True)
+                ring_cur[t % R].copy_(arena.cursor, non_blocking=True)
+                if ring_ev is not None:
+                    ring_ev[t % R].record(torch.cuda.current_stream(dev))
+                unread[k] = None
+                late.append((t, stage_idx, num_exec))
+            else:
+                unread[k] = (t, g, stage_idx, num_exec)
             issued[k] = t + 1
 
+        late: list[Any] = []  # fast: steps enqueued whose flags have not been looked at, oldest first
+
+        def take_late() -> None:
+            """the oldest enqueued step's flags (waits for that step if it has not finished)"""
+            t, stage_idx, num_exec = late.pop(0)
+            if ring_ev is not None:
+                ring_ev[t % R].synchronize()
+            arena.note(ring_cur[t % R].tolist(), t + 1)
+            handle_flags(0, t, None, stage_idx, num_exec, ring_flags[t % R, :5].tolist())
+
+        def drain_all() -> None:
+            while late and alive[0]:
+                take_late()
+
         try:
-            while any(alive) or any(u is not None for u in unread):
+            while fast and alive[0]:
+                # look at the steps that have finished, and never run more than LAG steps ahead of the flags
+                while late and alive[0] and (len(late) >= LAG or ring_ev is None or ring_ev[late[0][0] % R].query()):
+                    take_late()
+                if alive[0]:
+                    enqueue(0)
+                    if ring_ev is None:
+                        take_late()
+            while not fast and (any(alive) or any(u is not None for u in unread)):
                 for k in range(G):
                     with (torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()):
                         if unread[k] is not None:
@@ -261,7 +421,7 @@ class RolloutCollector:
             self._pending_reset = pending.view(torch.bool)
         self._obs, self._wall = True, wall  # (_obs: the envs are inside their episodes)
         keys = sorted(graphs)
-        T = max((t for t, _ in keys), default=-1) + 1
+        T = n_kept if fast else max((t for t, _ in keys), default=-1) + 1
         out = {name: rec[name][:T] for name, _ in spec}
         obs_index = None
         if G > 1:  # observation (t, b) sits in the graph its group recorded at step t
@@ -269,7 +429,18 @@ class RolloutCollector:
             for i, (t, k) in enumerate(keys):
                 pos[t, k] = i
             obs_index = torch.from_numpy(pos[:T]).to(dev)[:, group_of] * B + torch.arange(B, device=dev)[None, :]
-        return Rollouts(graph=concat_graphs([graphs[key] for key in keys]), active=out["active"].view(torch.bool), t_before=out["t_before"], t_after=out["t_after"],
+        if fast:
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+            graph = arena.finish(T)
+            # the steps enqueued behind the last one found every env frozen, but each took a draw counter of the policy's sampling
+            # stream (decima._sample_kernels): hand them back, so that the next collection draws what it would have drawn
+            if hasattr(self.policy, "_calls"):
+                self.policy._calls = calls0 + T
+            self._arena_sizes = [int(graph["x"].shape[0]), int(graph["src"].numel()), int(graph["job_obs"].numel()), T * B]
+        else:
+            graph = concat_graphs([graphs[key] for key in keys])
+        return Rollouts(graph=graph, active=out["active"].view(torch.bool), t_before=out["t_before"], t_after=out["t_after"],
                         rewards=out["rewards"], stage_sel=out["stage_sel"], job_idx=out["job_idx"], exec_sel=out["exec_sel"],
                         lgprobs=out["lgprobs"], resets=out["resets"].view(torch.bool), stats=self._stats() if with_stats else {}, obs_index=obs_index)
 
@@ -530,7 +701,7 @@ class Trainer:
             # caching allocator then keeps asking the driver for slightly larger blocks (0.1 s per hipMalloc, 0.9 s of a 3.4 s
             # update: profiles/r04_ppo.md). Rounding request sizes up to eighths of a power of two makes the blocks reusable.
             try:
-                torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:8")
+                (getattr(torch._C, "_accelerator_setAllocatorSettings", None) or torch.cuda.memory._set_allocator_settings)("roundup_power2_divisions:8")
             except Exception:  # (an allocator backend without the option)
                 pass
         E = int(self.env_cfg["num_executors"])

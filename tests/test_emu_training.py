@@ -218,6 +218,25 @@ def test_rows_entry_point_on_the_host_backend():
     check_rows_ops(Binding(load_emu()), "cpu", n=300)
 
 
+def test_collection_recorded_on_the_device_equals_the_synchronous_one():
+    """training_util.check_record_on_device on the emulator library"""
+    from training_util import check_record_on_device
+
+    from emu_util import load_emu
+
+    check_record_on_device("cpu", load_emu(), num_envs=6)
+
+
+def test_graph_arena_grows():
+    """`GraphArena` with a starting capacity far too small for the collection: the headroom rule makes it grow (with the
+    cursors the host has seen), the record is still the one of the synchronous loop"""
+    from training_util import check_record_on_device
+
+    from emu_util import load_emu
+
+    check_record_on_device("cpu", load_emu(), num_envs=3, tiny_arena=True)
+
+
 def test_two_groups_of_envs_record_what_one_group_records():
     """`RolloutCollector(groups=2)` - the envs take their steps in two alternating groups (on two streams on the GPU), the
     flags of a group's step are read one step late - against `groups=1`: the same record per env, and every sample's

@@ -198,6 +198,16 @@ def test_message_passing_function_matches_the_tensor_op_form():
 
 
 @pytest.mark.gpu
+def test_collection_recorded_on_the_device_equals_the_synchronous_one_gpu():
+    """training_util.check_record_on_device on the GPU (events, pinned rings, flags read up to four steps late), also with an
+    arena that has to grow"""
+    from training_util import check_record_on_device
+
+    check_record_on_device("cuda:0", None, num_envs=64)
+    check_record_on_device("cuda:0", None, num_envs=8, tiny_arena=True)
+
+
+@pytest.mark.gpu
 def test_rows_kernels_match_torch_indexing():
     """`sss_rows_kernel` (csrc/sss_rows.h) against torch indexing, 16-byte and 4-byte forms, and the autograd functions built on
     it (`gather_rows`, `segment_sum`, `concat_rows`) against index_select / index_add_ / cat through autograd"""

@@ -215,3 +215,48 @@ def check_rows_ops(binding, device, n):
         rows_op(ROWS_GATHER, torch.zeros(2, dtype=torch.long, device=device), torch.empty((2, 65), device=device), rnd(4, 65), binding=binding)
     with pytest.raises(ValueError):
         rows_op(7, torch.zeros(2, dtype=torch.long, device=device), torch.empty((2, 16), device=device), rnd(4, 16), binding=binding)
+
+
+def check_record_on_device(device, lib, num_envs, tiny_arena=False):
+    """`RolloutCollector(record_on_device=True)` (the step's graph stays on the device and is appended to a `GraphArena` there,
+    flags read a few steps late) against `record_on_device=False` (sizes and flags read every step, per-step graphs concatenated
+    at the end): same policy parameters, same generator seed -> the same record, array by array, twice in a row (the second
+    collection starts from the first one's arena sizes)"""
+    import spark_sched_sim_amd.training as T
+
+    cfg = dict(num_executors=10, job_arrival_cap=8, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    dev = torch.device(device)
+    out = {}
+    old_init = T.GraphArena.__init__
+    if tiny_arena:
+        def small_init(self, env, capacity=None):
+            old_init(self, env, capacity)
+            for name, dt, per, kind, _ in self.ARRAYS:  # one step's maximum and a bit: every few steps the headroom rule fires
+                self.capacity[kind] = self.step_max[kind] + 3
+                self.buf[name] = self.buf[name][: self.capacity[kind]].clone()
+        T.GraphArena.__init__ = small_init
+    try:
+        for on_dev in (True, False):
+            env = VecSparkSchedSimEnv(cfg, num_envs, device=device, auto_reset=False, _lib=lib)
+            torch.manual_seed(1)
+            pol = DecimaPolicy(num_executors=10, **AGENT).to(dev)
+            gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
+            gen.manual_seed(99)
+            col = RolloutCollector(env, 5.0e5, list(range(21, 21 + num_envs)), seed_step=num_envs, num_executors=10, policy=pol, generator=gen,
+                                   record_on_device=on_dev)
+            out[on_dev] = [col.collect_sync(with_stats=False) for _ in range(2)]
+            assert (col._arena_sizes is not None) == on_dev  # (the loop without waits was the one that ran)
+            env.close()
+    finally:
+        T.GraphArena.__init__ = old_init
+    for ra, rb in zip(out[True], out[False]):
+        assert ra.active.shape == rb.active.shape and int(ra.active.sum()) > 20 * num_envs
+        for name in ("active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets"):
+            assert torch.equal(getattr(ra, name), getattr(rb, name)), name
+        assert set(ra.graph) >= set(rb.graph) - {"_ranges"}
+        for k, v in rb.graph.items():
+            if torch.is_tensor(v):
+                assert ra.graph[k].dtype == v.dtype and torch.equal(ra.graph[k], v), k
+            elif k in ("n_obs", "n_pad"):
+                assert ra.graph[k] == v, k
+        assert torch.equal(ra.sample_ids(), rb.sample_ids())
