@@ -275,6 +275,19 @@ class Bench:
                             events.append((e0, e1))
                         else:
                             e.step_async(act["stage_idx"], act["num_exec"])
+        elif mode == "bounded":  # launches with an event budget: an env whose step is cut goes on in the next launch (sss_step_bounded)
+            for _ in range(n_steps):
+                for e, st in zip(self.shards, self.streams):
+                    with torch.cuda.stream(st):
+                        act = e.policy_actions(self.policy)
+                        if events is not None:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(st)
+                            e.step_bounded_async(act["stage_idx"], act["num_exec"], args.bounded_events)
+                            e1.record(st)
+                            events.append((e0, e1))
+                        else:
+                            e.step_bounded_async(act["stage_idx"], act["num_exec"], args.bounded_events)
         else:
             done = 0
             while done < n_steps:
@@ -319,12 +332,12 @@ class Bench:
         avg_launch_s = (kern_ms_all / launches_all) * 1e-3
         bytes_per_launch = bytes_all / launches_all
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        kernel = "sss_step_kernel" if mode == "step" else "sss_rollout_kernel"
+        kernel = {"step": "sss_step_kernel", "bounded": "sss_step_bounded_kernel"}.get(mode, "sss_rollout_kernel")
         evps = evs_all / max(1.0, steps_all)
         return {
             "value": steps_all / dt_max,
             "ms_per_step": dt_max / steps * 1e3,
-            "launches_per_step": launches_all / self.world / steps if mode == "step" else launches_all / self.world / max(1, (steps + args.fused_chunk - 1) // args.fused_chunk),
+            "launches_per_step": launches_all / self.world / steps if mode in ("step", "bounded") else launches_all / self.world / max(1, (steps + args.fused_chunk - 1) // args.fused_chunk),
             "events_per_s": evs_all / dt_max,
             "events_per_step": evps,
             "fast_path_event_frac": fast_all / max(1.0, evs_all),
@@ -382,6 +395,31 @@ class Bench:
                 "launch_ms": float(np.mean(ms)), "what": "per-env shader ticks of single step launches; a launch ends with its slowest env"}
 
 
+BOUNDED_EVENTS = {"c2": 48, "c3": 32, "c1": 48, "e100": 32}
+
+
+def bounded_record(bench: "Bench", args, config: str, steps: int, warmup: int):
+    """the same envs stepped by launches with an event budget (include/sss.h sss_step_bounded): a launch of sss_step ends with
+    its slowest env; here an env whose step needs more than the budget continues in the next launch while the others take their
+    next steps - the envs run at their own pace, as the reference's do in their worker processes. Env-steps per second of
+    completed steps (per-env trajectories are the same bit for bit: tests/test_{emu,gpu}_bounded.py). NOT the headline `value`,
+    which stays the lock-step one."""
+    budget = BOUNDED_EVENTS.get(config, 24) if args.bounded_events is None else args.bounded_events
+    if budget <= 0:
+        return None
+    saved = args.bounded_events
+    args.bounded_events = budget
+    try:
+        k = max(steps, 200)
+        r = bench.measure("bounded", k, max(warmup, 50))
+    finally:
+        args.bounded_events = saved
+    return {"value": r["value"], "unit": "env-steps/s", "max_events_per_launch": budget, "launches": k, "ms_per_launch": r["ms_per_step"],
+            "completed_steps_per_launch_and_env": r["value"] * r["ms_per_step"] * 1e-3 / bench.B, "events_per_step": r["events_per_step"],
+            "roofline": r["roofline"],
+            "what": "policy launch + sss_step_bounded per iteration; an env's step that exceeds the budget continues in the next launch"}
+
+
 def run_ranks_myself(args) -> int:
     """--gpus N without a torch.distributed environment: N fresh rank processes (nothing here has touched the GPU)"""
     from spark_sched_sim_amd.distributed import launch_ranks
@@ -406,6 +444,8 @@ def main() -> None:
                     help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
                          "(a launch lasts as long as its slowest env; with several streams the tails overlap)")
     ap.add_argument("--single-mode", action="store_true", help="skip the second measurement in the other mode")
+    ap.add_argument("--bounded-events", type=int, default=None,
+                    help="event budget per launch of the extra `bounded_launches` record (sss_step_bounded; default: 48 at c2, 32 at c3; 0: skip the record)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of the single-core CPU leg (the all-core and config-3 legs take at most half of it each)")
     ap.add_argument("--sustained-s", type=float, default=1.2, help="a second, longer timed region in the same mode when the K timed steps last less than this (0: off)")
@@ -451,6 +491,7 @@ def main() -> None:
     other_mode = "fused" if args.mode == "step" else "step"
     secondary = None if args.single_mode else bench.measure(other_mode, args.steps, args.warmup)
     tail = bench.step_tail() if (world == 1 and args.shards == 1) else None
+    bounded = bounded_record(bench, args, args.config, args.steps, args.warmup) if world == 1 else None
 
     if world > 1:
         # the one exchange of the path: all-gather of per-env episode summaries (RCCL)
@@ -506,6 +547,8 @@ def main() -> None:
         if secondary is not None:
             # the same K batched steps through the other entry point (same per-step work, same trajectories)
             out["other_mode"] = dict(secondary, mode=other_mode)
+        if bounded is not None:
+            out["bounded_launches"] = bounded
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget)
             try:
@@ -536,6 +579,9 @@ def main() -> None:
                    "phase_ticks_per_step": r3["phase_ticks_per_step"], "roofline": s3["roofline"] if s3 is not None else r3["roofline"],
                    "roofline_k_steps": r3["roofline"], "step_tail": b3.step_tail(12),
                    "other_mode": dict(f3, mode="fused"), "mean_last_episode_return": b3.header_field("last_ep_return").mean().item()}
+            bd3 = bounded_record(b3, args, "c3", k3, w3)
+            if bd3 is not None:
+                rec["bounded_launches"] = bd3
             b3.close()
             if s3 is not None:
                 rec["sustained"] = s3

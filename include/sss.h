@@ -101,6 +101,16 @@ int sss_reset(sss_handle* h, const uint64_t* seeds_dev, const double* time_limit
 #define SSS_SKIP_ENV (-2147483647 - 1)
 int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, void* stream);
 
+/* sss_step with an event budget per launch - the reference's envs run in worker processes of their own, one step() never waits
+ * for another env's (trainers/rollout_worker.py:133-206); a launch of sss_step ends with its slowest env. Here an env whose step
+ * has taken max_events events (>= 1; batches of events are not cut, so it may overshoot by one batch) stops between two events:
+ * ready_dev[i] = 0, its outputs (observation, reward, terminated, err) are NOT written, and the next sss_step_bounded / sss_step
+ * call continues that step - its action arguments for env i are then not looked at. ready_dev[i] = 1: the step is complete, the
+ * outputs are the ones sss_step writes. SSS_SKIP_ENV envs: ready_dev[i] is left alone. Every env goes through the states and
+ * outputs it goes through under sss_step, bit for bit; only the launch in which its k-th step completes differs. */
+int sss_step_bounded(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, int max_events,
+                     uint8_t* ready_dev, void* stream);
+
 /* On-device counterparts of the reference's heuristic Scheduler plugins; they fill one action per
  * env for the next sss_step. policy: 0 = fair (RoundRobinScheduler(dynamic_partition=True),
  * schedulers/heuristics/round_robin.py:7-49), 1 = FIFO (dynamic_partition=False), 2 = the build's

@@ -133,7 +133,7 @@ class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
                 ("rows_hint", C.c_int64), ("arrays", SssArenaArray * 24)]
 
 
-EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_policy", "sss_rollout",
+EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_step_bounded", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
            "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_arena_append", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
@@ -158,6 +158,7 @@ class Binding:
         L.sss_bind_buffers.argtypes = [C.c_void_p, C.POINTER(SssBuffers)]
         L.sss_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+        L.sss_step_bounded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.sss_policy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sss_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
         L.sss_decima_graph_build.argtypes = [C.c_void_p, C.POINTER(SssDecimaGraph), C.c_void_p]

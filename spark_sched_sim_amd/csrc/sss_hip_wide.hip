@@ -15,6 +15,12 @@ int sss_wide_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* 
   hipLaunchKernelGGL(sss_reset_kernel_wide, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, seeds, tl, mask);
   return (int)hipGetLastError();
 }
+int sss_wide_launch_step_bounded(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
+                                 int budget, uint8_t* ready, void* stream) {
+  hipLaunchKernelGGL(sss_step_bounded_kernel_wide, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset,
+                     seed_stride, budget, ready);
+  return (int)hipGetLastError();
+}
 int sss_wide_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
                          void* stream) {
   hipLaunchKernelGGL(sss_step_kernel_wide, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset, seed_stride);

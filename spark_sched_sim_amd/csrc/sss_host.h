@@ -408,6 +408,19 @@ extern "C" int sss_step(sss_handle* h, const int32_t* stage_idx_dev, const int32
   return 0;
 }
 
+extern "C" int sss_step_bounded(sss_handle* h, const int32_t* stage_idx_dev, const int32_t* num_exec_dev, int auto_reset, uint64_t seed_stride, int max_events,
+                                uint8_t* ready_dev, void* stream) {
+  if (!h || !stage_idx_dev || !num_exec_dev || !ready_dev) return sss_fail(-1, "NULL argument");
+  if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");
+  if (max_events < 1) return sss_fail(-35, "sss_step_bounded: max_events must be at least 1");
+  BeDeviceGuard guard(h->device);
+  const SssKernelArgs ka = sss_args(h);
+  if (int rc = sss_is_wide(h->L.E) ? sss_wide_launch_step_bounded(ka, h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, max_events, ready_dev, stream)
+                                   : be_launch_step_bounded(ka, h->L.num_envs, stage_idx_dev, num_exec_dev, auto_reset, seed_stride, max_events, ready_dev, stream))
+    return sss_fail(-30, std::string("step launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" int sss_policy(sss_handle* h, int policy, int param, int32_t* stage_idx_dev, int32_t* num_exec_dev, void* stream) {
   if (!h || !stage_idx_dev || !num_exec_dev) return sss_fail(-1, "NULL argument");
   if (!h->bound) return sss_fail(-22, "sss_bind_buffers has not been called");

@@ -69,7 +69,7 @@ enum { EV_NONE = 0, EV_TASK_FINISHED = 2, EV_EXECUTOR_READY = 3 };
 #define POOL_NONE 0xFFFFFFFFu
 #define POOL_COMMON 0u
 
-struct SssHdr {            // 304 bytes
+struct SssHdr {            // 320 bytes
   uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
   uint32_t rng_has32, rng_u32;
   double wall_time;
@@ -107,7 +107,9 @@ struct SssHdr {            // 304 bytes
   uint64_t n_batched;      // ... of which handled by the lane-parallel batch path
   uint64_t n_rounds;       // batch rounds that committed at least one event
   uint64_t err_line;       // diagnostics: source line (csrc/sss_sim.h) of the check that set `err` last (0: none so far); survives resets
-  uint64_t pad_[1];
+  // a step cut at its event budget (sss_step_bounded): the next launch continues its event loop and takes no action
+  int32_t mid_step;        // 1: the current step's event loop has not reached its end
+  int32_t step_events;     // events of the current step so far
   // The active subgraph (which jobs, in which order, with which stages) changes only when a job arrives or
   // completes or a stage completes; the observation's edge rows are a function of it alone. graph_version counts
   // those changes, obs_* say what the edge rows in the caller's buffer were written from: an unchanged graph's
@@ -116,6 +118,11 @@ struct SssHdr {            // 304 bytes
   uint32_t obs_graph_version;  // 0: nothing written yet
   int32_t obs_n_edges;
   uint32_t obs_bind_gen;       // SssBuffers::gen of the buffer they were written to
+  // ... and what the first part of that step left in scratch for its end: the clock and the active jobs at the end of the
+  // commitment round (the reward integrates over the jobs of either list, ENV:847-874); the list itself follows the active list in HBM
+  double wall_old;
+  int32_t n_old_active;
+  int32_t pad2_;
 };
 
 // one pending event per executor at most: 16 bytes, read with a single LDS access.
@@ -292,7 +299,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->ed_cap = J_cap * max_edges_per_job;
   L->pad_ = 0;
   int64_t o = (int64_t)hot_bytes;
-  L->off_active = o, o = sss_align(o + 2 * (int64_t)J_cap, 64);
+  L->off_active = o, o = sss_align(o + 2 * 2 * (int64_t)J_cap, 64);  // active_job_ids, then the old list of a step cut at its event budget
   L->off_jobs = o, o += (int64_t)sizeof(SssJob) * J_cap;
   L->off_t_arrival = o, o += 8 * (int64_t)J_cap;
   L->off_t_completed = o, o += 8 * (int64_t)J_cap;
@@ -306,7 +313,7 @@ static inline void sss_compute_layout(SssLayout* L, int num_envs, int E, int J_c
   L->state_bytes = L->env_stride * num_envs;
 }
 
-static_assert(sizeof(SssHdr) == 304, "SssHdr must be 304 bytes");
+static_assert(sizeof(SssHdr) == 320, "SssHdr must be 320 bytes");
 static_assert(sizeof(SssHot) % 16 == 0, "SssHot is copied with 16-byte accesses");
 static_assert(sizeof(SssJob) == 64, "SssJob must be one 64-byte line");
 static_assert(sizeof(SssStage) == 8 && sizeof(SssPoolHdr) == 16, "packed records");

@@ -61,6 +61,7 @@ struct alignas(16) SssScratch {
   int32_t m_n_active, m_src_job;  // mailbox for find_schedulable_all
   int32_t n_old_active;
   int32_t events_this_step;
+  int32_t events_at_launch;       // ... of which taken by earlier launches (a step cut at its event budget, sss_step_bounded)
   int32_t pending_free;           // job whose cache slot is to be released (-1: none)
   int32_t pinned_job;             // job of the event being handled: its cache slot is not given away
   int32_t sel_job, sel_stage;     // the stage an action names (select_stage_wave -> take_action)
@@ -4460,7 +4461,9 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
   return 0;
 }
 
-SSS_DEV void resume_simulation() {
+// budget > 0: the loop also ends (returns true) at the top of a round once the step has taken that many events - everything is
+// in the env's state there, the next launch goes on from it (do_step)
+SSS_DEV bool resume_simulation(int budget = 0) {
   PROF3(26);
   int lane = wave_lane();
   FastCtx f;
@@ -4488,6 +4491,7 @@ SSS_DEV void resume_simulation() {
       // cannot have been scheduled ahead of. Found on the GPU with the wide instantiation (every round is of that kind there; the
       // emulator's lanes run one after the other and cannot show it); at wavefront scope the point costs no instruction.
       wave_sync();
+      if (budget > 0 && g_sc.events_this_step - g_sc.events_at_launch >= budget) return true;  // (wave-uniform: an LDS word behind the ordering point)
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
       if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {
@@ -4531,14 +4535,14 @@ SSS_DEV void resume_simulation() {
         H.n_sched = 0;
       }
       wave_sync();
-      return;
+      return false;
     }
     // f_scan: _find_schedulable_stages() with the whole wave
     int n = find_schedulable_all();
     if (n > 0) {
       if (lane == 0) H.n_sched = n;
       wave_sync();
-      return;
+      return false;
     }
     publish_idle_mask();
     if (lane == 0) {
@@ -4568,11 +4572,11 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     double last_ep_return = H.last_ep_return, last_ep_wall = H.last_ep_wall;
     uint64_t prof[5];
     for (int i = 0; i < 5; i++) prof[i] = H.prof[i];
-    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds, pad0_keep = H.err_line, pad1_keep = H.pad_[0];
+    uint64_t n_fast_keep = H.n_fast, n_batched_keep = H.n_batched, n_rounds_keep = H.n_rounds, pad0_keep = H.err_line;
     SssHdr z = {};
     H = z;
     for (int i = 0; i < 5; i++) H.prof[i] = prof[i];
-    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep, H.err_line = pad0_keep, H.pad_[0] = pad1_keep;
+    H.n_fast = n_fast_keep, H.n_batched = n_batched_keep, H.n_rounds = n_rounds_keep, H.err_line = pad0_keep;
     H.n_steps = n_steps, H.n_events = n_events, H.model_bytes = model_bytes;
     H.dur_head = dur_head, H.dur_n = dur_n, H.episodes = episodes;
     H.last_ep_steps = last_ep_steps, H.last_ep_return = last_ep_return, H.last_ep_wall = last_ep_wall;
@@ -4692,16 +4696,45 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
   wave_sync();
 }
 
-// ENV:188-221. `reward` is valid on lane 0 (and uniform).
-SSS_DEV double do_step(int stage_idx, int num_exec) {
+SSS_DEV double step_reward(uint64_t t1, uint64_t t2);
+// A step whose event loop was cut at its budget (H.mid_step): the scratch the first part of the step left for its end comes
+// back from the header and from behind the active list in HBM; the action arguments of this launch are not looked at.
+SSS_DEV void step_continue() {
+  const int lane = wave_lane();
+  for (int a = lane; a < g_hot.h.n_old_active; a += 64) lds_old_active()[a] = g_c.active_g[g_c.J_cap + a];
+  if (lane == 0) {
+    g_sc.f_round_continues = 0, g_sc.f_fulfil = 0, g_sc.idle_valid = 0;
+    g_sc.events_this_step = H.step_events, g_sc.events_at_launch = H.step_events;
+    g_sc.wall_old = H.wall_old, g_sc.n_old_active = H.n_old_active;
+    g_sc.old_version = g_sc.active_version, g_sc.jobset_valid = 0;
+    H.mid_step = 0;
+  }
+  wave_sync();
+}
+SSS_DEV void step_yield() {
+  const int lane = wave_lane();
+  for (int a = lane; a < g_sc.n_old_active; a += 64) g_c.active_g[g_c.J_cap + a] = lds_old_active()[a];
+  if (lane == 0) H.mid_step = 1, H.step_events = g_sc.events_this_step, H.wall_old = g_sc.wall_old, H.n_old_active = g_sc.n_old_active;
+  wave_sync();
+}
+
+// ENV:188-221. `reward` is valid on lane 0 (and uniform). budget > 0 (sss_step_bounded): at most about that many events per
+// launch - *yielded is set when the step's event loop has not reached its end (no reward, no observation yet; the next
+// launch continues it).
+SSS_DEV double do_step(int stage_idx, int num_exec, int budget = 0, bool* yielded = nullptr) {
   PROF3(28);
   int lane = wave_lane();
   uint64_t t0 = wave_clock();
+  const bool go_on = wave_ballot(g_hot.h.mid_step != 0) != 0;  // (the ballot: every lane has read the header before lane 0 rewrites it)
+  uint64_t t1 = t0;
+  if (go_on) {
+    step_continue();
+  } else {
   publish_idle_mask();  // for fulfil_build_list, should the round end with this action (nothing below moves an executor before it)
   select_stage_wave(stage_idx);
   if (lane == 0) {
     g_sc.f_round_continues = 1, g_sc.f_fulfil = 0;
-    g_sc.events_this_step = 0;
+    g_sc.events_this_step = 0, g_sc.events_at_launch = 0;
     H.last_reward = 0.0;
     if (H.need_reset || H.terminated) {
       H.err = SSS_ERR_NEED_RESET;
@@ -4739,7 +4772,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
   }
   if (lane == 0 && H.err && H.err != SSS_ERR_ACTION_SPACE && H.err != SSS_ERR_STAGE_IDX && H.err != SSS_ERR_TOO_MANY) H.need_reset = 1;
   wave_sync();
-  uint64_t t1 = wave_clock();
+  t1 = wave_clock();
   if (lane == 0) H.prof[1] += t1 - t0;
   if (wave_ballot(g_sc.f_round_continues || g_hot.h.err) != 0) return 0.0;  // same round: reward 0 (ENV:191-193)
   for (int a = lane; a < g_hot.h.n_active; a += 64) {  // ENV:203 selected_stages.clear(); active jobs at the round's end
@@ -4748,9 +4781,19 @@ SSS_DEV double do_step(int stage_idx, int num_exec) {
     lds_old_active()[a] = (uint16_t)j;
   }
   wave_sync();
-  resume_simulation();
-  uint64_t t2 = wave_clock();
-  // reward = -job_time (ENV:208-209); `duration == 0.0` short-circuits to -0.0 (ENV:850-852)
+  }
+  if (resume_simulation(budget)) {
+    step_yield();
+    *yielded = true;
+    return 0.0;
+  }
+  return step_reward(t1, wave_clock());
+}
+
+// the end of a step: reward = -job_time (ENV:208-209), termination, the stall check
+SSS_DEV double step_reward(uint64_t t1, uint64_t t2) {
+  const int lane = wave_lane();
+  // `duration == 0.0` short-circuits to -0.0 (ENV:850-852)
   if (lane == 0) {
     g_sc.f_need_jobtime = 0;
     if (!H.err && H.wall_time - g_sc.wall_old != 0.0) {
@@ -4803,23 +4846,37 @@ SSS_KERNEL void SSS_KNAME(sss_reset_kernel)(SssKernelArgs a, const uint64_t* see
 
 // one step() per env; with auto_reset != 0 an env that is terminated at entry starts its next
 // episode instead (seed += seed_stride), like a vector env in "next-step" autoreset mode
-SSS_KERNEL void SSS_KNAME(sss_step_kernel)(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
+SSS_DEV void step_env(const SssKernelArgs& a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride, int budget, uint8_t* ready) {
   int env = wave_env();
   if (stage_idx[env] == SSS_SKIP_ENV) return;  // wave-uniform: the env is not touched at all
   uint8_t* base = (uint8_t*)a.B.state + (size_t)env * a.L.env_stride;
   ctx_init();
   env_begin(base);
   double reward = 0.0;
+  bool yielded = false;
   // the ballot doubles as the barrier between "all lanes read the header" and lane 0 rewriting it
   bool start_next_episode = wave_ballot(auto_reset && g_hot.h.terminated && !g_hot.h.err) != 0;
   if (start_next_episode) {
     do_reset(a.L, g_hot.h.seed + seed_stride, g_hot.h.time_limit);
   } else {
-    reward = do_step(stage_idx[env], num_exec[env]);
+    reward = do_step(stage_idx[env], num_exec[env], budget, &yielded);
   }
-  write_observation(a.L, a.B, env, reward);
+  if (!yielded) write_observation(a.L, a.B, env, reward);  // (a step that goes on in the next launch has no observation yet)
+  if (ready && wave_lane() == 0) ready[env] = yielded ? 0 : 1;
   env_end(base);
   prof3_flush();
+}
+SSS_KERNEL void SSS_KNAME(sss_step_kernel)(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride) {
+  step_env(a, stage_idx, num_exec, auto_reset, seed_stride, 0, nullptr);
+}
+// sss_step_bounded: the same with an event budget per launch. A launch of sss_step_kernel ends with its slowest env - one with
+// 170 events in its step where the mean is 21 (profiles/r04_bench.md) - while the other waves' SIMDs idle. Here an env whose step
+// has taken `budget` events stops at the top of its next round (mid_step in its header, ready[env] = 0), the launch ends, and the
+// next launch continues that step (its action arguments are not looked at) while the other envs take their next steps. Every
+// env's trajectory is the one sss_step_kernel produces; what changes is which launch an env's k-th step ends in.
+SSS_KERNEL void SSS_KNAME(sss_step_bounded_kernel)(SssKernelArgs a, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
+                                                   int budget, uint8_t* ready) {
+  step_env(a, stage_idx, num_exec, auto_reset, seed_stride, budget, ready);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@
 int sss_wide_hot_bytes();         // sizeof(SssHot) with SSS_MAX_EXEC = 128
 int sss_wide_static_lds_bytes();  // SSS_STATIC_LDS_BYTES of that instantiation
 int sss_wide_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* seeds, const double* tl, const uint8_t* mask, void* stream);
+int sss_wide_launch_step_bounded(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
+                                 int budget, uint8_t* ready, void* stream);
 int sss_wide_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride, void* stream);
 int sss_wide_launch_policy(const SssKernelArgs& a, int num_envs, int policy, int param, int32_t* stage_idx, int32_t* num_exec, void* stream);
 int sss_wide_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream);

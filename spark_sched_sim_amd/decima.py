@@ -767,7 +767,8 @@ class DecimaPolicy(nn.Module):
         if want_scores:
             out["stage_scores"] = torch.full((B, d.node_cap), float("-inf"), dtype=torch.float32, device=dev)
             out["exec_scores"] = torch.full((B, self.num_executors), float("-inf"), dtype=torch.float32, device=dev)
-        act8 = active.to(torch.uint8).contiguous() if active is not None else None
+        from .vec_env import _mask_u8
+        act8 = _mask_u8(active)
         a = SssDecimaPolicyArgs(act8.data_ptr() if act8 is not None else None, 200.0, 1e5, self._packed[2],
                                 w["prep"].data_ptr(), w["msg"].data_ptr(), w["update"].data_ptr(), w["dag"].data_ptr(), w["glob"].data_ptr(),
                                 w["stage"].data_ptr(), w["exec"].data_ptr(), ws["node"].data_ptr(), ws["job"].data_ptr(),

@@ -373,7 +373,7 @@ class RolloutCollector:
                 env._b.check(lib.sss_collect_step(ctypes.byref(c), 1, stream))
             if fast:  # what the host wants of this step, without waiting for it: its flags and the arena's cursors after it
                 ring_flags[t % R].copy_(flags[t, k], non_blocking=True)
-                ring_cur[t % R].copy_(arena.cursor, non_blocking=True)
+                ring_cur[t % R].copy_(arena.cursor, non_blocking=True)  # (ring_cur[.., 4] = steps appended: which step the cursors are of)
                 if ring_ev is not None:
                     ring_ev[t % R].record(torch.cuda.current_stream(dev))
                 unread[k] = None

@@ -29,6 +29,15 @@ class BatchedObs(dict):
     """
 
 
+def _mask_u8(mask: torch.Tensor | None) -> torch.Tensor | None:
+    """an env mask as the u8 array the kernels read: a view when it already is one byte per env (bool / uint8, contiguous)"""
+    if mask is None:
+        return None
+    if mask.is_contiguous() and mask.dtype in (torch.bool, torch.uint8):
+        return mask.view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
 class VecSparkSchedSimEnv:
     """`num_envs` reference environments in one object.
 
@@ -163,6 +172,23 @@ class VecSparkSchedSimEnv:
         self._b.check(self._b.lib.sss_step(self._h, stage_idx.data_ptr(), num_exec.data_ptr(), int(self.auto_reset),
                                            self.seed_stride, self._stream()))
 
+    def step_bounded_async(self, stage_idx: torch.Tensor, num_exec: torch.Tensor, max_events: int, ready: torch.Tensor | None = None) -> torch.Tensor:
+        """`step_async` with an event budget per launch (include/sss.h sss_step_bounded): an env whose step needs more than
+        `max_events` events is cut between two events and goes on in the next call (its action entries are then ignored).
+        Returns `ready` u8[B] (the env's buffer unless one is given): 1 = the env's step is complete and its outputs are
+        current, 0 = it continues - its observation / reward / flags are still the previous ones. Envs run at their own
+        pace, as the reference's envs do in their worker processes; each env's trajectory is the one `step` gives."""
+        assert stage_idx.dtype == torch.int32 and num_exec.dtype == torch.int32
+        assert stage_idx.device == self.device and stage_idx.is_contiguous() and num_exec.is_contiguous()
+        if ready is None:
+            if getattr(self, "_ready", None) is None:
+                self._ready = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+            ready = self._ready
+        assert ready.dtype == torch.uint8 and ready.is_contiguous() and ready.numel() == self.num_envs
+        self._b.check(self._b.lib.sss_step_bounded(self._h, stage_idx.data_ptr(), num_exec.data_ptr(), int(self.auto_reset), self.seed_stride, int(max_events),
+                                                   ready.data_ptr(), self._stream()))
+        return ready
+
     def step(self, actions):
         """reference `step(action)` (spark_sched_sim.py:188-221), batched.
         `actions`: {"stage_idx": i32[B], "num_exec": i32[B]} (tensors on the env's device).
@@ -223,7 +249,7 @@ class VecSparkSchedSimEnv:
                 "layer_cnt": e(32, torch.int32, B), "sched_list": e(Mc, torch.int64),
                 "scan": e(2, torch.int64, 4, B), "tot": e(4, torch.int64), "layer_totals": torch.zeros(32, dtype=torch.int64, device=dev),
                 "recv": e(Mc * max(D, 1), torch.int64), "hint": hint.pin_memory() if dev.type == "cuda" else hint, "epoch": 0}
-        act8 = active.to(torch.uint8).contiguous() if active is not None else None
+        act8 = _mask_u8(active)
         scan, tot = ws["scan"], ws["tot"]
         with device_of(dev):
             self._b.check(self._b.lib.sss_prefix_rows(self.obs_i32.data_ptr(), 1, self.obs_i32.stride(0), act8.data_ptr() if act8 is not None else None, 4, B,
@@ -270,7 +296,7 @@ class VecSparkSchedSimEnv:
         # per-env counts (n_nodes, n_edges, n_jobs; 0 for inactive envs), their exclusive prefix sums and totals:
         # one small kernel over the obs_i32 rows in place (include/sss.h sss_prefix_rows) instead of a handful of
         # tensor ops; the totals are the one device->host sync
-        act8 = active.to(torch.uint8).contiguous() if active is not None else None
+        act8 = _mask_u8(active)
         # (rows of the scan: n_nodes, n_edges, n_jobs, n_sched = columns 0..3 of obs_i32)
         scan = torch.empty((2, 4, B), dtype=torch.int64, device=dev)
         tot = torch.empty(4, dtype=torch.int64, device=dev)

@@ -38,6 +38,12 @@ static int be_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t*
   emu::launch(num_envs, [&]() { sss_reset_kernel(a, seeds, tl, mask); });
   return 0;
 }
+static int be_launch_step_bounded(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
+                                  int budget, uint8_t* ready, void*) {
+  emu::g_kernargs = &a;
+  emu::launch(num_envs, [&]() { sss_step_bounded_kernel(a, stage_idx, num_exec, auto_reset, seed_stride, budget, ready); });
+  return 0;
+}
 static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride, void*) {
   emu::g_kernargs = &a;
   emu::launch(num_envs, [&]() { sss_step_kernel(a, stage_idx, num_exec, auto_reset, seed_stride); });

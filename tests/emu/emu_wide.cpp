@@ -25,6 +25,12 @@ int sss_wide_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* 
   emu::launch(num_envs, [&]() { sss_reset_kernel_wide(a, seeds, tl, mask); });
   return 0;
 }
+int sss_wide_launch_step_bounded(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
+                                 int budget, uint8_t* ready, void*) {
+  emu::g_kernargs = &a;
+  emu::launch(num_envs, [&]() { sss_step_bounded_kernel_wide(a, stage_idx, num_exec, auto_reset, seed_stride, budget, ready); });
+  return 0;
+}
 int sss_wide_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride, void*) {
   emu::g_kernargs = &a;
   emu::launch(num_envs, [&]() { sss_step_kernel_wide(a, stage_idx, num_exec, auto_reset, seed_stride); });

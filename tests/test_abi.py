@@ -69,7 +69,7 @@ def test_header_offsets_match_layout(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
     got = {l.split()[0]: int(l.split()[1]) for l in out.splitlines()}
     assert got.pop("prof") == HDR_PROF  # the profiling counters VecSparkSchedSimEnv.counters() reads
-    assert got.pop("sizeof") == 304
+    assert got.pop("sizeof") == 320
     assert got == HDR_OFF
 
 

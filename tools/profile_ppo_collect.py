@@ -21,20 +21,22 @@ def main():
     ap.add_argument("--duration", type=float, default=1.5e6, help="simulated ms per env and collection")
     ap.add_argument("--rows", type=int, default=25)
     ap.add_argument("--groups", type=int, default=1)
+    ap.add_argument("--sync", action="store_true", help="synchronous rollouts (one episode per env: the reference's decima_tpch.yaml) instead")
     a = ap.parse_args()
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=a.sequences, num_rollouts=a.rollouts, seed=42, checkpointing_freq=10 ** 9, num_epochs=3,
                  num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4),
-                 max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo", rollout_duration=a.duration, collector_groups=a.groups)
+                 max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo", collector_groups=a.groups, **({} if a.sync else {"rollout_duration": a.duration}))
     env = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
     tr = Trainer(AGENT, env, train, device="cuda:0")
     tr.policy.eval()
     col = tr.collector
-    col.collect_async(a.duration, with_stats=False)  # warm-up (also moves every env into its episode)
+    run = (lambda: col.collect_sync(with_stats=False)) if a.sync else (lambda: col.collect_async(a.duration, with_stats=False))
+    run()  # warm-up (async: also moves every env into its episode)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         t0 = time.perf_counter()
-        ro = col.collect_async(a.duration, with_stats=False)
+        ro = run()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
     iters, n = int(ro.active.shape[0]), int(ro.active.sum())
