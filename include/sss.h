@@ -507,6 +507,35 @@ typedef struct sss_arena_args {
 } sss_arena_args;
 int sss_arena_append(const sss_arena_args* a, void* stream);
 
+/* What the trainer computes from the collected rollouts before the PPO epochs, over [T][B] records (row = step, column = env;
+ * active_dev u8[T][B] marks the rows an env recorded - a prefix of its column), all f64, row-major, on the CURRENT device:
+ *   sss_discounted_returns   R_k = r_k + exp(-beta * 1e-3 * (t_after_k - t_before_k)) * R_{k+1} per env from its last row
+ *                            (trainers/utils/returns_calculator.py:67-76); out = 0 on rows that are not active
+ *   sss_sequence_baselines   envs g*R .. g*R+R-1 are the rollouts of one job sequence: out[t][b] = mean over the sequence's
+ *                            rollouts j of numpy.interp(times[t][b], times[:n_j][j], values[:n_j][j]) (trainers/utils/baselines.py:
+ *                            12-37, trainer.py:206-207); n_dev i64[B] = recorded rows per env; skip_empty != 0: rollouts with
+ *                            n = 0 are left out of the mean. The arithmetic is numpy's, operation by operation. */
+typedef struct sss_returns_args {
+  int64_t T, B;
+  const uint8_t* active_dev;
+  const double* t_before_dev;
+  const double* t_after_dev;
+  const double* rewards_dev;
+  double beta;
+  double* out_dev;
+} sss_returns_args;
+typedef struct sss_baseline_args {
+  int64_t T, B;
+  int32_t R, skip_empty;
+  const uint8_t* active_dev;
+  const double* times_dev;
+  const double* values_dev;
+  const int64_t* n_dev;
+  double* out_dev;
+} sss_baseline_args;
+int sss_discounted_returns(const sss_returns_args* a, void* stream);
+int sss_sequence_baselines(const sss_baseline_args* a, void* stream);
+
 /* Row gathers / scatters of the PPO update (what PyG's message passing, the score networks' `torch.cat([x[idx], h[idx], ..])`
  * inputs and the per-job / per-observation sums run as index_select / index_add_ under autograd in the reference:
  * schedulers/decima/scheduler.py:209-232, :246-283, :289-318, :337-385). `a` is the list side (row i, leading dimension ld_a

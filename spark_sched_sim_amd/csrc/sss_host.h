@@ -707,6 +707,28 @@ extern "C" int sss_arena_append(const sss_arena_args* a, void* stream) {
   return 0;
 }
 
+#include "sss_returns.h"
+static int be_launch_returns(const SssReturnsArgs& a, void* stream);
+static int be_launch_baselines(const SssBaselineArgs& a, void* stream);
+extern "C" int sss_discounted_returns(const sss_returns_args* a, void* stream) {
+  if (!a || !a->active_dev || !a->t_before_dev || !a->t_after_dev || !a->rewards_dev || !a->out_dev) return sss_fail(-1, "NULL argument");
+  if (a->T < 0 || a->B < 0) return sss_fail(-36, "sss_discounted_returns: negative size");
+  SssReturnsArgs r;
+  r.T = a->T, r.B = a->B, r.active = a->active_dev, r.t_before = a->t_before_dev, r.t_after = a->t_after_dev, r.rewards = a->rewards_dev, r.beta = a->beta, r.out = a->out_dev;
+  if (r.T == 0 || r.B == 0) return 0;
+  if (int rc = be_launch_returns(r, stream)) return sss_fail(-30, std::string("returns launch failed: ") + be_error(rc));
+  return 0;
+}
+extern "C" int sss_sequence_baselines(const sss_baseline_args* a, void* stream) {
+  if (!a || !a->active_dev || !a->times_dev || !a->values_dev || !a->n_dev || !a->out_dev) return sss_fail(-1, "NULL argument");
+  if (a->T < 0 || a->B < 0 || a->R < 1 || a->B % a->R != 0) return sss_fail(-36, "sss_sequence_baselines: B must be a multiple of R >= 1");
+  SssBaselineArgs r;
+  r.T = a->T, r.B = a->B, r.R = a->R, r.skip_empty = a->skip_empty, r.active = a->active_dev, r.times = a->times_dev, r.values = a->values_dev, r.n = a->n_dev, r.out = a->out_dev;
+  if (r.T == 0 || r.B == 0) return 0;
+  if (int rc = be_launch_baselines(r, stream)) return sss_fail(-30, std::string("baselines launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
   if (!a || !a->a_dev || !a->b_dev || (a->n > 0 && !a->idx_dev)) return sss_fail(-1, "NULL argument");
   if (a->op < 0 || a->op > 5) return sss_fail(-33, "sss_rows_op: unknown operation");

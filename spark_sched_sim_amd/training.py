@@ -456,9 +456,36 @@ class RolloutCollector:
 
 # ---- returns (trainers/utils/returns_calculator.py) -----------------------------------------------
 
-def discounted_returns(ro: Rollouts, beta: float) -> torch.Tensor:
+def _record_kernels(ro: Rollouts, binding=None):
+    """the binding to run the [T, B] record kernels with (include/sss.h sss_discounted_returns / sss_sequence_baselines): the
+    library when the record is on a GPU - no fallback there - or the one a caller passes (tests: the emulator's host backend)"""
+    if binding is not None:
+        return binding
+    if ro.active.is_cuda:
+        from .train_kernels import _binding
+        return _binding()
+    return None
+
+
+def _c64(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if t.dtype == torch.float64 else t.double().contiguous()
+
+
+def discounted_returns(ro: Rollouts, beta: float, binding=None) -> torch.Tensor:
     """R_k = r_k + exp(-beta * 1e-3 * dt_k) * R_{k+1} per rollout (returns_calculator.py:67-76); f64[T,B]"""
     T, B = ro.active.shape
+    b = _record_kernels(ro, binding)
+    if b is not None and T > 0 and B > 0:  # one kernel, a thread per env (the loop below: T x 5 launches, 0.30 s at BASELINE config 5)
+        import ctypes
+
+        from .binding import SssReturnsArgs, device_of
+        dev = ro.active.device
+        act, tb, ta, rw = ro.active.contiguous().view(torch.uint8), _c64(ro.t_before), _c64(ro.t_after), _c64(ro.rewards)
+        out = torch.empty((T, B), dtype=torch.float64, device=dev)
+        a = SssReturnsArgs(T, B, act.data_ptr(), tb.data_ptr(), ta.data_ptr(), rw.data_ptr(), float(beta), out.data_ptr())
+        with device_of(dev):
+            b.check(b.lib.sss_discounted_returns(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+        return out
     dt = ro.t_after - ro.t_before
     out = torch.zeros_like(ro.rewards)
     R = torch.zeros(B, dtype=torch.float64, device=ro.rewards.device)
@@ -521,13 +548,26 @@ def _interp(x: torch.Tensor, xp: torch.Tensor, fp: torch.Tensor, n: torch.Tensor
     return torch.where(exact, y0, v)
 
 
-def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, num_rollouts: int) -> torch.Tensor:
+def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, num_rollouts: int, binding=None) -> torch.Tensor:
     """for each group of `num_rollouts` consecutive envs (the rollouts of one job sequence) the mean
     over the group's rollouts of their piecewise-linear value curves, evaluated at each rollout's own
     step times (baselines.py:12-37; times = `wall_times[:-1]`, trainer.py:206-207). f64[T,B]"""
     T, B = ro.active.shape
     assert B == num_sequences * num_rollouts
     G, R = num_sequences, num_rollouts
+    b = _record_kernels(ro, binding)
+    if b is not None and T > 0 and B > 0:  # one kernel, a thread per (step, env) query (below: ~20 operations on [G, R, R, T] tensors)
+        import ctypes
+
+        from .binding import SssBaselineArgs, device_of
+        dev = ro.active.device
+        act, ts, ys = ro.active.contiguous().view(torch.uint8), _c64(ro.t_before), _c64(values)
+        n = ro.active.sum(0).to(torch.int64).contiguous()
+        out = torch.empty((T, B), dtype=torch.float64, device=dev)
+        a = SssBaselineArgs(T, B, R, int(not bool((n > 0).all())), act.data_ptr(), ts.data_ptr(), ys.data_ptr(), n.data_ptr(), out.data_ptr())
+        with device_of(dev):
+            b.check(b.lib.sss_sequence_baselines(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+        return out
     ts = ro.t_before.t().reshape(G, R, T)
     ys = values.t().reshape(G, R, T)
     n = ro.active.sum(0).reshape(G, R)

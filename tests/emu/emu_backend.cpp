@@ -79,6 +79,17 @@ static int be_launch_rows(const SssRowsArgs& r, void*) {
     for (int j = 0; j < r.width; j++) sss_rows_element(r, i, j, [](float* p, float v) { *p += v; });
   return 0;
 }
+// sss_discounted_returns / sss_sequence_baselines on the host: the per-env / per-query functions of sss_returns.h in plain loops
+#include "sss_returns.h"
+static int be_launch_returns(const SssReturnsArgs& a, void*) {
+  for (int64_t b = 0; b < a.B; b++) returns_env(a, b);
+  return 0;
+}
+static int be_launch_baselines(const SssBaselineArgs& a, void*) {
+  for (int64_t t = 0; t < a.T; t++)
+    for (int64_t b = 0; b < a.B; b++) baseline_query(a, t, b);
+  return 0;
+}
 // sss_arena_append on the host
 #include "sss_arena.h"
 static int be_launch_arena(const SssArenaArgs& a, int64_t, void*) {

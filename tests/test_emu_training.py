@@ -237,6 +237,17 @@ def test_graph_arena_grows():
     check_record_on_device("cpu", load_emu(), num_envs=3, tiny_arena=True)
 
 
+def test_record_kernels_on_the_host_backend():
+    """include/sss.h sss_discounted_returns / sss_sequence_baselines through the emulator library's host loops against the
+    tensor-op forms (training_util.check_record_kernels)"""
+    from training_util import check_record_kernels
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+
+    check_record_kernels(Binding(load_emu()), "cpu")
+
+
 def test_two_groups_of_envs_record_what_one_group_records():
     """`RolloutCollector(groups=2)` - the envs take their steps in two alternating groups (on two streams on the GPU), the
     flags of a group's step are read one step late - against `groups=1`: the same record per env, and every sample's

@@ -208,6 +208,14 @@ def test_collection_recorded_on_the_device_equals_the_synchronous_one_gpu():
 
 
 @pytest.mark.gpu
+def test_record_kernels_match_the_tensor_op_forms():
+    """sss_returns_kernel / sss_baseline_kernel (csrc/sss_returns.h) against the tensor-op forms, bit for bit"""
+    from training_util import check_record_kernels
+
+    check_record_kernels(None, "cuda:0")
+
+
+@pytest.mark.gpu
 def test_rows_kernels_match_torch_indexing():
     """`sss_rows_kernel` (csrc/sss_rows.h) against torch indexing, 16-byte and 4-byte forms, and the autograd functions built on
     it (`gather_rows`, `segment_sum`, `concat_rows`) against index_select / index_add_ / cat through autograd"""

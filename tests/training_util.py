@@ -260,3 +260,49 @@ def check_record_on_device(device, lib, num_envs, tiny_arena=False):
             elif k in ("n_obs", "n_pad"):
                 assert ra.graph[k] == v, k
         assert torch.equal(ra.sample_ids(), rb.sample_ids())
+
+
+def check_record_kernels(binding, device):
+    """`sss_discounted_returns` / `sss_sequence_baselines` against the tensor-op forms of training.discounted_returns /
+    sequence_baselines on a random record: envs with different lengths (one of them empty -> the mean skips it), repeated step
+    times (zero-length steps: duplicate knots of the value curves), with and without empty rollouts. Bit for bit on the GPU
+    (same exp, same operation order); the emulator's host loops use libm's exp (1e-12 relative)."""
+    from spark_sched_sim_amd.training import Rollouts
+
+    gen = torch.Generator().manual_seed(0)
+    for T, B, R in ((37, 12, 4), (200, 64, 4), (5, 3, 1)):
+        n = torch.randint(0, T + 1, (B,), generator=gen)
+        n[min(3, B - 1)] = 0
+        dt = torch.rand((T, B), generator=gen, dtype=torch.float64) * 5e4
+        dt[torch.rand((T, B), generator=gen) < 0.2] = 0.0
+        ta = torch.cumsum(dt, 0)
+        tb = torch.cat([torch.zeros((1, B), dtype=torch.float64), ta[:-1]])  # non-decreasing, repeats where dt = 0
+        rw = -torch.rand((T, B), generator=gen, dtype=torch.float64) * 1e4
+        z = torch.zeros((T, B), dtype=torch.long)
+        for drop_empty in (False, True):
+            nn = torch.where(n == 0, torch.ones_like(n), n) if drop_empty else n
+            a = (torch.arange(T)[:, None] < nn[None, :]).to(device)
+            ro = Rollouts(graph={}, active=a, t_before=tb.to(device) * a, t_after=ta.to(device) * a, rewards=rw.to(device) * a, stage_sel=z, job_idx=z, exec_sel=z,
+                          lgprobs=z.float(), resets=z.bool())
+            ref = Rollouts(**{**ro.__dict__, "active": a.cpu(), "t_before": ro.t_before.cpu(), "t_after": ro.t_after.cpu(), "rewards": ro.rewards.cpu()})
+            r_ref = T_discounted(ref)
+            r_got = __import__("spark_sched_sim_amd.training", fromlist=["x"]).discounted_returns(ro, 5e-3, binding=binding)
+            assert torch.allclose(r_got.cpu(), r_ref, rtol=1e-12, atol=1e-9), float((r_got.cpu() - r_ref).abs().max())
+            b_ref = sequence_baselines(ref, r_ref, B // R, R)
+            b_got = sequence_baselines(ro, r_ref.to(device), B // R, R, binding=binding)
+            assert torch.equal(b_got.cpu(), b_ref), float((b_got.cpu() - b_ref).abs().max())
+            if device != "cpu":
+                r_dev = T_discounted(ro)   # the same loop as tensor operations on the GPU: the same exp
+                assert torch.equal(r_got, r_dev)
+
+
+def T_discounted(ro):
+    """training.discounted_returns' tensor-op loop, whatever device the record is on (returns_calculator.py:67-76)"""
+    T, B = ro.active.shape
+    dt = ro.t_after - ro.t_before
+    out = torch.zeros_like(ro.rewards)
+    R = torch.zeros(B, dtype=torch.float64, device=ro.rewards.device)
+    for k in range(T - 1, -1, -1):
+        R = torch.where(ro.active[k], ro.rewards[k] + torch.exp(-5e-3 * 1e-3 * dt[k]) * R, R)
+        out[k] = R
+    return out * ro.active

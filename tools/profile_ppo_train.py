@@ -39,7 +39,12 @@ def main():
     tr.policy.train()
     # pieces of one minibatch
     ppo = tr.ppo
-    returns, baselines = ppo.preprocess(ro)
+    torch.cuda.synchronize(); p0 = time.perf_counter()
+    returns = ppo.diff(ro) if ppo.diff is not None else __import__("spark_sched_sim_amd.training", fromlist=["x"]).discounted_returns(ro, ppo.beta)
+    torch.cuda.synchronize(); p1 = time.perf_counter()
+    baselines = __import__("spark_sched_sim_amd.training", fromlist=["x"]).sequence_baselines(ro, returns, ppo.num_sequences, ppo.num_rollouts)
+    torch.cuda.synchronize(); p2 = time.perf_counter()
+    print(json.dumps({"returns_s": p1 - p0, "baselines_s": p2 - p1, "rows": int(ro.active.shape[0])}))
     ids = ro.sample_ids()
     advgs = ro.flat(returns - baselines)
     acts = [ro.flat(ro.stage_sel), ro.flat(ro.job_idx), ro.flat(ro.exec_sel)]
