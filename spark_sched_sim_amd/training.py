@@ -151,13 +151,16 @@ class GraphArena:
             self.env._b.check(self.env._b.lib.sss_arena_append(ctypes.byref(a), self.env._stream()))
         self.steps += 1
 
-    def finish(self, n_steps: int) -> dict[str, Any]:
-        """the graph of the first `n_steps` steps (call after a sync with `note` up to date for at least that many steps; the
-        steps behind them must have been empty)"""
+    def finish(self, n_steps: int, sizes: Sequence[int] | None = None) -> dict[str, Any]:
+        """the graph of the first `n_steps` steps: `sizes` = the cursors (nodes, edges, jobs) as they were after that many steps
+        (`note`), default: everything appended - the steps behind them are dropped"""
         cur = [int(c) for c in self.cursor[:6].tolist()]
         if cur[5]:
             raise RuntimeError("the graph arena overflowed (the headroom rule of GraphArena.ensure was violated)")
-        sizes = (cur[0], cur[1], cur[2], n_steps * self.B)
+        if sizes is None:
+            sizes = cur[:3]
+        assert all(0 <= int(s) <= c for s, c in zip(sizes[:3], cur[:3])) and n_steps <= cur[4]
+        sizes = (int(sizes[0]), int(sizes[1]), int(sizes[2]), n_steps * self.B)
         out: dict[str, Any] = {name: self.buf[name][: sizes[kind]] for name, _, _, kind, _ in self.ARRAYS}
         out["gen"] = out["gen"].long()
         out["n_obs"], out["n_pad"] = n_steps * self.B, self.env.dims.node_cap
@@ -289,7 +292,7 @@ class RolloutCollector:
             ring_flags, ring_cur = pin(torch.zeros((R, 8), dtype=torch.int32)), pin(torch.zeros((R, 8), dtype=torch.int64))
             ring_acts = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(R)]
             ring_ev = [torch.cuda.Event() for _ in range(R)] if cuda else None
-        n_kept = 0  # fast: steps whose observations are part of the record
+        n_kept, kept_sizes = 0, [0, 0, 0, 0]  # fast: steps whose observations are part of the record, the arena's cursors after them
         calls0 = getattr(self.policy, "_calls", 0) if fast else 0
         graphs: dict[tuple[int, int], dict[str, Any]] = {}
         issued = [0] * G             # steps enqueued per group
@@ -309,7 +312,7 @@ class RolloutCollector:
             handle_flags(k, t, g, stage_idx, num_exec, flags[t, k, :5].tolist())
 
         def handle_flags(k: int, t: int, g, stage_idx, num_exec, vals) -> None:
-            nonlocal n_failed, n_kept
+            nonlocal n_failed, n_kept, kept_sizes
             any_bad, any_done, any_left, bad_env, any_recorded = vals
             if any_bad:
                 n_bad = int(pending.sum()) - n_failed
@@ -334,6 +337,8 @@ class RolloutCollector:
             if g is not None:
                 graphs[(t, k)] = g
             n_kept = t + 1
+            if arena is not None:
+                kept_sizes = list(arena.seen)  # (take_late has just noted the cursors after this step)
             if asynchronous and any_done:
                 done = rec["resets"][t].view(torch.bool)
                 self._reset(mask=done if member_b[k] is None else done & member_b[k])
@@ -432,7 +437,7 @@ class RolloutCollector:
         if fast:
             if dev.type == "cuda":
                 torch.cuda.current_stream(dev).synchronize()
-            graph = arena.finish(T)
+            graph = arena.finish(T, kept_sizes)  # (a last step that failed for every env left is dropped, like the steps enqueued behind the end)
             # the steps enqueued behind the last one found every env frozen, but each took a draw counter of the policy's sampling
             # stream (decima._sample_kernels): hand them back, so that the next collection draws what it would have drawn
             if hasattr(self.policy, "_calls"):
