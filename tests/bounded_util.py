@@ -21,7 +21,7 @@ def check_bounded_steps(device, lib, cfg, seeds, policy, n_steps, budgets, pack=
     reward, wall time, flags - bit for bit), whatever the budget; after `n_steps` completed steps per env the env states are the
     same bytes (timers, batch counters and the scratch a cut step parks in the state aside). Returns launches per budget."""
     B = len(seeds)
-    kw = dict(device=device, auto_reset=False, _lib=lib)
+    kw = dict(device=device, auto_reset=True, _lib=lib)  # (an env whose episode ends starts its next one: a launch like any other)
     if pack is not None:
         kw["pack"] = pack
     ref = VecSparkSchedSimEnv(cfg, B, **kw)
