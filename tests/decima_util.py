@@ -228,3 +228,40 @@ def check_on_device_step_equals_the_synchronous_one(device, lib=None, n_envs=6, 
         _, _, _, _, info = env.step(act_b)
         assert not info["err"].any(), t
     env.close()
+
+
+def check_reference_style_episode(device, lib=None, max_steps=None):
+    """the single-env harness of the reference (examples.py:84-102) with the Decima plugin:
+    env_wrapper_cls(env) + schedule(obs) sampling through `random.choices` under a fixed
+    `random.seed` reproduces the recorded reference episode action for action (scores agree to
+    ~1e-6, so a draw landing that close to a CDF boundary could differ; none does in this episode)"""
+    import os.path as osp
+    import random
+
+    import numpy as np
+    import torch
+
+    HERE = osp.dirname(osp.abspath(__file__))
+    from golden_util import bits
+    from spark_sched_sim_amd import SparkSchedSimEnv, make_scheduler
+
+    g = np.load(osp.join(HERE, "golden", "decima_episode.npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    cfg["num_executors"], cfg["job_arrival_cap"] = int(cfg["num_executors"]), int(cfg["job_arrival_cap"])
+    sched = make_scheduler(dict(AGENT, agent_cls="DecimaScheduler", num_executors=cfg["num_executors"]))
+    sched.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")})
+    sched.eval()
+    env = sched.env_wrapper_cls(SparkSchedSimEnv(cfg, device=device, _lib=lib))
+    random.seed(int(g["py_seed"]))
+    obs, _ = env.reset(seed=int(g["seed"]), options=None)
+    terminated = truncated = False
+    t = 0
+    while not (terminated or truncated) and (max_steps is None or t < max_steps):
+        action, info = sched.schedule(obs)
+        assert [action["stage_idx"], action["job_idx"], action["num_exec"]] == g["actions"][t].tolist(), t
+        assert abs(float(info["lgprob"]) - float(g["lgprobs"][t])) < 1e-4, t
+        obs, reward, terminated, truncated, einfo = env.step(action)
+        assert bits(float(reward)) == bits(float(g["rewards"][t])) and bits(float(einfo["wall_time"])) == bits(float(g["wall_times"][t])), t
+        t += 1
+    assert t == (len(g["actions"]) if max_steps is None else min(max_steps, len(g["actions"])))
+    env.close()

@@ -9,6 +9,14 @@ from decima_util import AGENT, check_decima_fixture
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.gpu
+def test_reference_style_decima_episode_gpu():
+    """decima_util.check_reference_style_episode on the GPU: the whole recorded reference episode, action for action"""
+    from decima_util import check_reference_style_episode
+
+    check_reference_style_episode("cuda:0")
+
+
 @pytest.mark.parametrize("name,n_steps", [("decima_c1", 90), ("decima_e50", 90)])
 def test_decima_features_and_scores_match_reference_gpu(name, n_steps):
     check_decima_fixture(name, "cuda:0", None, n_steps)
