@@ -145,7 +145,7 @@ class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_step_bounded", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -185,6 +185,10 @@ class Binding:
         L.sss_mlp_supported.argtypes = [C.c_int] * 5
         L.sss_mlp_forward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
         L.sss_mlp_backward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
+        L.sss_mlp_wgrad_scratch.argtypes = [C.c_int]
+        L.sss_mlp_wgrad_scratch.restype = C.c_int64
+        L.sss_mlp_backward_wgrad.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p, C.c_void_p]
+        L.sss_mlp_wgrad_finish.argtypes = [C.c_int] + [C.c_void_p] * 8
         L.sss_discounted_returns.argtypes = [C.POINTER(SssReturnsArgs), C.c_void_p]
         L.sss_sequence_baselines.argtypes = [C.POINTER(SssBaselineArgs), C.c_void_p]
         L.sss_arena_append.argtypes = [C.POINTER(SssArenaArgs), C.c_void_p]

@@ -741,6 +741,38 @@ extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
   return 0;
 }
 
+#ifndef SSS_MLPW_SLOTS
+#define SSS_MLPW_SLOTS 2048
+#endif
+static bool sss_mlpw_ok(int in_dim) { return in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16; }
+extern "C" int64_t sss_mlp_wgrad_scratch(int in_dim) {
+  return sss_mlpw_ok(in_dim) ? (int64_t)SSS_MLPW_SLOTS * ((16 * 16 + 16) + (16 * 32 + 16) + (32 * in_dim + 32)) : 0;
+}
+extern "C" int sss_mlp_backward_wgrad(const sss_mlp_args* a, float* acc_dev, void* stream) {
+  if (!a || !a->w_dev || !a->a1_dev || !a->a2_dev || !a->dy_dev || !a->x_dev || !acc_dev) return sss_fail(-1, "NULL argument");
+  if (a->rows < 0) return sss_fail(-31, "sss_mlp: negative row count");
+  if (!(a->h1 == 32 && a->h2 == 16 && a->out_dim == 16 && a->act == 0 && sss_mlpw_ok(a->in_dim)))
+    return sss_fail(-31, "sss_mlp_backward_wgrad: (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs only");
+  if (int rc = be_launch_mlp_bwdw(sss_mlp_args_of(a), acc_dev, stream)) return sss_fail(-30, std::string("mlp backward launch failed: ") + be_error(rc));
+  return 0;
+}
+extern "C" int sss_mlp_wgrad_finish(int in_dim, const float* acc_dev, float* gw1_dev, float* gb1_dev, float* gw2_dev, float* gb2_dev, float* gw3_dev, float* gb3_dev,
+                                    void* stream) {
+  if (!acc_dev || !gw1_dev || !gb1_dev || !gw2_dev || !gb2_dev || !gw3_dev || !gb3_dev) return sss_fail(-1, "NULL argument");
+  if (!sss_mlpw_ok(in_dim)) return sss_fail(-31, "sss_mlp_wgrad_finish: not one of the GNN-shaped MLPs");
+  const float* l3 = acc_dev;
+  const float* l2 = l3 + (size_t)SSS_MLPW_SLOTS * (16 * 16 + 16);
+  const float* l1 = l2 + (size_t)SSS_MLPW_SLOTS * (16 * 32 + 16);
+  const struct { const float* part; int N, M; float* gw; float* gb; } job[3] = {{l3, 16, 16, gw3_dev, gb3_dev}, {l2, 16, 32, gw2_dev, gb2_dev}, {l1, 32, in_dim, gw1_dev, gb1_dev}};
+  for (int k = 0; k < 3; k++) {
+    SssWgradArgs r;
+    r.x = nullptr, r.dy = nullptr, r.K = 0, r.ldx = 0, r.ldy = 0, r.M = job[k].M, r.N = job[k].N, r.partial = const_cast<float*>(job[k].part), r.n_partials = SSS_MLPW_SLOTS;
+    r.gw = job[k].gw, r.gb = job[k].gb;
+    if (int rc = be_launch_wgrad_reduce(r, stream)) return sss_fail(-30, std::string("wgrad reduce launch failed: ") + be_error(rc));
+  }
+  return 0;
+}
+
 extern "C" void sss_destroy(sss_handle* h) {
   if (!h) return;
   BeDeviceGuard guard(h->device);

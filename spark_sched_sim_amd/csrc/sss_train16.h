@@ -290,6 +290,157 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwd_kernel(SssMlpArgs a) {
   }
 }
 
+// ---- backward with the weight gradients in the same pass (GNN-shaped MLPs) -------------------------------------------------
+// The separate weight-gradient launches (sss_train.h) read x, a1, a2, dy and the g1 / g2 this kernel had just written: 256 floats
+// per row of a 16-32-16-16 MLP over both kernels, a fifth of an update's device time (profiles/r04_ppo.md). Here the tile's
+// g2 / g1 go through a per-wave LDS tile into the weight-gradient operand layout (lane (i, q): element i of row 4 s + q), the
+// stored activations and the input are read a second time in that layout (the lines are in L1 from the first read), and twenty
+// more v_mfma_f32_16x16x4_f32 per tile accumulate dW3 = dY^T A2, dW2 = G2^T A1, dW1 = G1^T X and the three bias sums in
+// registers: x 16 + a1 32 + a2 16 + dy 16 floats in, dx 16 out - g1 and g2 never reach HBM. The four waves of a workgroup add
+// their accumulators in LDS (wave order) and the workgroup ADDS the result to its slot of the partial arrays (one slot per
+// workgroup, zeroed by the caller before the first call of a group: the layers of the message passing share them); a fixed-order
+// sum over the slots (sss_wgrad_reduce_kernel) finishes. Same inputs, same bits.
+#define SSS_MLPW_SLOTS 2048
+struct SssMlpWgradAcc {  // per-workgroup slots: [SLOTS][N * M + N] per Linear
+  float* l3;  // 16 x 16 + 16
+  float* l2;  // 16 x 32 + 16
+  float* l1;  // 32 x IN + 32
+};
+template <int IN>
+__global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, SssMlpWgradAcc acc) {
+  constexpr int U = (IN + 15) / 16;
+  constexpr int NT = 3 + 2 * U;  // accumulator tiles: dW3, dW2 (two column tiles), dW1 (two row tiles x U column tiles)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const float* W1 = a.w;
+  const float* W2T = W1 + 32 * IN + 32;
+  const float* W3 = W2T + 32 * 16 + 16;
+  float t3[4], t2[2][4], t1[U][2][4];
+  for (int r = 0; r < 4; r++) t3[r] = W3[(4 * q + r) * 16 + i];
+  for (int tp = 0; tp < 2; tp++)
+    for (int r = 0; r < 4; r++) t2[tp][r] = W2T[(16 * tp + i) * 16 + 4 * q + r];
+  for (int u = 0; u < U; u++)
+    for (int t = 0; t < 2; t++)
+      for (int r = 0; r < 4; r++) t1[u][t][r] = 16 * u + i < IN ? W1[(16 * t + 4 * q + r) * IN + 16 * u + i] : 0.0f;
+  __shared__ __attribute__((aligned(16))) float tr[4][16 * 48];  // per wave: [row][g2 (16) | g1 (32)] of the tile
+  __shared__ float red[NT * 256 + 64];
+  float* T = tr[wave];
+  const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  mfma_f4 w3a = zero, w2a[2] = {zero, zero}, w1a[2][U];
+  for (int t = 0; t < 2; t++)
+    for (int u = 0; u < U; u++) w1a[t][u] = zero;
+  float b3s = 0.0f, b2s = 0.0f, b1s[2] = {0.0f, 0.0f};
+  const int64_t n_tiles = (a.rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + i;
+    const bool valid = row < a.rows;
+    const mfma_f4 dy = valid ? *(const mfma_f4*)(a.dy + row * 16 + 4 * q) : zero;
+    const mfma_f4 a2 = valid ? *(const mfma_f4*)(a.a2 + row * 16 + 4 * q) : zero;
+    const mfma_f4 a10 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 4 * q) : zero;
+    const mfma_f4 a11 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) : zero;
+    mfma_f4 g2 = zero;
+    g2 = mfma16(t3[0], dy.x, g2), g2 = mfma16(t3[1], dy.y, g2), g2 = mfma16(t3[2], dy.z, g2), g2 = mfma16(t3[3], dy.w, g2);
+    g2 = leaky4_grad(g2, a2, a.slope);
+    mfma_f4 g10 = zero, g11 = zero;
+    g10 = mfma16(t2[0][0], g2.x, g10), g11 = mfma16(t2[1][0], g2.x, g11);
+    g10 = mfma16(t2[0][1], g2.y, g10), g11 = mfma16(t2[1][1], g2.y, g11);
+    g10 = mfma16(t2[0][2], g2.z, g10), g11 = mfma16(t2[1][2], g2.z, g11);
+    g10 = mfma16(t2[0][3], g2.w, g10), g11 = mfma16(t2[1][3], g2.w, g11);
+    g10 = leaky4_grad(g10, a10, a.slope), g11 = leaky4_grad(g11, a11, a.slope);
+    // (rows behind the end: dy = 0 -> g2 = g1 = 0, they add nothing below)
+    *(mfma_f4*)(T + i * 48 + 4 * q) = g2, *(mfma_f4*)(T + i * 48 + 16 + 4 * q) = g10, *(mfma_f4*)(T + i * 48 + 32 + 4 * q) = g11;
+    if (a.dx) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        mfma_f4 dx = zero;
+        dx = mfma16(t1[u][0][0], g10.x, dx), dx = mfma16(t1[u][0][1], g10.y, dx), dx = mfma16(t1[u][0][2], g10.z, dx), dx = mfma16(t1[u][0][3], g10.w, dx);
+        dx = mfma16(t1[u][1][0], g11.x, dx), dx = mfma16(t1[u][1][1], g11.y, dx), dx = mfma16(t1[u][1][2], g11.z, dx), dx = mfma16(t1[u][1][3], g11.w, dx);
+        if (valid) {
+          float* o = a.dx + row * IN + 16 * u + 4 * q;
+          if (16 * u + 4 * q + 0 < IN) o[0] = dx.x;
+          if (16 * u + 4 * q + 1 < IN) o[1] = dx.y;
+          if (16 * u + 4 * q + 2 < IN) o[2] = dx.z;
+          if (16 * u + 4 * q + 3 < IN) o[3] = dx.w;
+        }
+      }
+    }
+    wave_sync_local();
+    // the weight gradients: K-step s = rows 4 s + q of the tile; A operand = the gradient's element i of that row, B = the input's
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const int r = 4 * s4 + q;
+      const int64_t grow = tile * 16 + r;
+      const bool ok = grow < a.rows;
+      const float A3 = ok ? a.dy[grow * 16 + i] : 0.0f, B3 = ok ? a.a2[grow * 16 + i] : 0.0f;
+      w3a = __builtin_amdgcn_mfma_f32_16x16x4f32(A3, B3, w3a, 0, 0, 0), b3s += A3;
+      const float A2 = T[r * 48 + i];
+      const float B20 = ok ? a.a1[grow * 32 + i] : 0.0f, B21 = ok ? a.a1[grow * 32 + 16 + i] : 0.0f;
+      w2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, B20, w2a[0], 0, 0, 0), w2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, B21, w2a[1], 0, 0, 0), b2s += A2;
+      const float A10 = T[r * 48 + 16 + i], A11 = T[r * 48 + 32 + i];
+      b1s[0] += A10, b1s[1] += A11;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float B1 = (ok && 16 * u + i < IN) ? a.x[grow * IN + 16 * u + i] : 0.0f;
+        w1a[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A10, B1, w1a[0][u], 0, 0, 0), w1a[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A11, B1, w1a[1][u], 0, 0, 0);
+      }
+    }
+    wave_sync_local();  // (the next tile's stores to T come after these reads)
+  }
+  // the four waves add their accumulators in LDS (wave order); tiles 0: dW3, 1..2: dW2, 3..: dW1[t][u]; then the bias sums
+  for (int turn = 0; turn < 4; turn++) {
+    if (wave == turn) {
+      auto put = [&](int tile_id, const mfma_f4& v) {
+        float* p0 = &red[(tile_id * 4) * 64 + lane];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) p0[k * 64] = turn == 0 ? vv[k] : p0[k * 64] + vv[k];
+      };
+      put(0, w3a), put(1, w2a[0]), put(2, w2a[1]);
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < U; u++) put(3 + t * U + u, w1a[t][u]);
+      float sb[4] = {b3s, b2s, b1s[0], b1s[1]};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sb[k] += __shfl_xor(sb[k], 16, 64);
+        sb[k] += __shfl_xor(sb[k], 32, 64);
+        if (q == 0) {
+          float* p0 = &red[NT * 256 + k * 16 + i];
+          *p0 = turn == 0 ? sb[k] : *p0 + sb[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // red[(tile * 4 + v) * 64 + l] = D[4 (l / 16) + v][l % 16] of the tile -> the slot's [N][M] arrays
+  float* o3 = acc.l3 + (size_t)blockIdx.x * (16 * 16 + 16);
+  float* o2 = acc.l2 + (size_t)blockIdx.x * (16 * 32 + 16);
+  float* o1 = acc.l1 + (size_t)blockIdx.x * (32 * IN + 32);
+  for (int e = threadIdx.x; e < NT * 256; e += 256) {
+    const int tile_id = e >> 8, v = (e >> 6) & 3, l = e & 63;
+    const int n = 4 * (l >> 4) + v, m = l & 15;
+    if (tile_id == 0) o3[n * 16 + m] += red[e];
+    else if (tile_id < 3) o2[n * 32 + 16 * (tile_id - 1) + m] += red[e];
+    else {
+      const int t = (tile_id - 3) / U, u = (tile_id - 3) % U;
+      if (16 * u + m < IN) o1[(16 * t + n) * IN + 16 * u + m] += red[e];
+    }
+  }
+  if (threadIdx.x < 16) o3[16 * 16 + threadIdx.x] += red[NT * 256 + threadIdx.x];
+  else if (threadIdx.x < 32) o2[16 * 32 + threadIdx.x - 16] += red[NT * 256 + threadIdx.x];
+  else if (threadIdx.x < 64) o1[32 * IN + threadIdx.x - 32] += red[NT * 256 + threadIdx.x];
+}
+
+template <int IN>
+static int mlp_mfma_bwdw_launch(const SssMlpArgs& a, const SssMlpWgradAcc& acc, void* stream) {
+  if (a.rows <= 0) return 0;
+  const int64_t wgs = (a.rows + 63) / 64;
+  const unsigned grid = (unsigned)(wgs < SSS_MLPW_SLOTS ? wgs : SSS_MLPW_SLOTS);
+  hipLaunchKernelGGL(sss_mlp_mfma_bwdw_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
+  return (int)hipGetLastError();
+}
+
 template <int IN>
 static int mlp_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
   if (a.rows <= 0) return 0;
@@ -433,6 +584,19 @@ static int mlp_head_mfma_launch(const SssMlpArgs& a, bool backward, void* stream
 }
 
 // the MLP shapes of the published architecture (config/decima_tpch.yaml:66-78); anything else: -1 (the caller keeps autograd)
+// backward + weight gradients of a GNN-shaped MLP (acc: SSS_MLPW_SLOTS slots per Linear, see sss_mlp_mfma_bwdw_kernel)
+static int be_launch_mlp_bwdw(const SssMlpArgs& a, float* acc, void* stream) {
+  SssMlpWgradAcc w;
+  w.l3 = acc, w.l2 = w.l3 + (size_t)SSS_MLPW_SLOTS * (16 * 16 + 16), w.l1 = w.l2 + (size_t)SSS_MLPW_SLOTS * (16 * 32 + 16);
+  if (a.in_dim == GNN_NF) return mlp_mfma_bwdw_launch<GNN_NF>(a, w, stream);
+  if (a.in_dim == 16) return mlp_mfma_bwdw_launch<16>(a, w, stream);
+  if (a.in_dim == GNN_NF + 16) return mlp_mfma_bwdw_launch<GNN_NF + 16>(a, w, stream);
+  return -1;
+}
+static int be_launch_wgrad_reduce(const SssWgradArgs& a, void* stream) {
+  hipLaunchKernelGGL(sss_wgrad_reduce_kernel, dim3((unsigned)((a.N * a.M + a.N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 static int be_launch_mlp(const SssMlpArgs& a, int backward, void* stream) {
   const bool gnn = a.h1 == 32 && a.h2 == 16 && a.out_dim == 16 && a.act == 0;
   const bool head = a.h1 == 64 && a.h2 == 64 && a.out_dim == 1 && a.act == 1;

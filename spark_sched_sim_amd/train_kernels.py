@@ -284,6 +284,49 @@ def mlp_backward(dy: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: t
     return g1, g2, dx
 
 
+FUSED_WGRAD = True  # the GNN-shaped MLPs' backward pass with the parameter gradients in the same kernel (sss_mlp_backward_wgrad)
+
+
+def mlp_wgrad_acc(in_dim: int, dev, binding=None) -> torch.Tensor | None:
+    """a zeroed accumulator for `mlp_backward_wgrad` calls whose parameter gradients belong together, or None when the shape has
+    no fused kernel"""
+    b = binding if binding is not None else _binding()
+    n = int(b.lib.sss_mlp_wgrad_scratch(in_dim))
+    return torch.zeros(n, dtype=torch.float32, device=dev) if n > 0 else None
+
+
+def mlp_backward_wgrad(dy: torch.Tensor, x: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: torch.Tensor, dims, slope: float, acc: torch.Tensor,
+                       want_dx: bool = True, binding=None):
+    """`sss_mlp_backward_wgrad`: dx f32[rows, IN] | None for dy f32[rows, 16]; the six parameter gradients are added to `acc`"""
+    import ctypes
+
+    from .binding import device_of
+    b = binding if binding is not None else _binding()
+    rows, dev = a1.shape[0], a1.device
+    dy = dy.contiguous()
+    assert dy.shape == (rows, dims[3]) and x.shape == (rows, dims[0]) and x.is_contiguous() and dy.dtype == x.dtype == torch.float32
+    dx = torch.empty((rows, dims[0]), dtype=torch.float32, device=dev) if want_dx else None
+    if rows == 0:
+        return dx
+    a = _mlp_args(dims, 0, slope, rows, packed, x=x, a1=a1, a2=a2, dy=dy, dx=dx)
+    with device_of(dev):
+        b.check(b.lib.sss_mlp_backward_wgrad(ctypes.byref(a), acc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+    return dx
+
+
+def mlp_wgrad_finish(dims, acc: torch.Tensor, binding=None):
+    """(gw1, gb1, gw2, gb2, gw3, gb3) from an accumulator: the per-workgroup slots added in a fixed order"""
+    from .binding import device_of
+    b = binding if binding is not None else _binding()
+    dev = acc.device
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    gw1, gb1, gw2, gb2, gw3, gb3 = f(dims[1], dims[0]), f(dims[1]), f(dims[2], dims[1]), f(dims[2]), f(dims[3], dims[2]), f(dims[3])
+    with device_of(dev):
+        b.check(b.lib.sss_mlp_wgrad_finish(dims[0], acc.data_ptr(), gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+    return gw1, gb1, gw2, gb2, gw3, gb3
+
+
 class _MlpFn(torch.autograd.Function):
     """y = W3 act(W2 act(W1 x + b1) + b2) + b3 for x f32[rows, IN]; saves x and the two hidden activations"""
 
@@ -299,6 +342,10 @@ class _MlpFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, a1, a2, packed = ctx.saved_tensors
         dy = dy.contiguous()
+        acc = mlp_wgrad_acc(ctx.dims[0], dy.device) if (FUSED_WGRAD and ctx.act == 0 and tuple(ctx.dims[1:]) == (32, 16, 16)) else None
+        if acc is not None:  # one kernel: dx and the six parameter gradients (g1 / g2 never leave the chip)
+            dx = mlp_backward_wgrad(dy, x, a1, a2, packed, ctx.dims, ctx.slope, acc, want_dx=ctx.needs_input_grad[0])
+            return (dx, *mlp_wgrad_finish(ctx.dims, acc), None, None, None)
         g1, g2, dx = mlp_backward(dy, a1, a2, packed, ctx.dims, ctx.act, ctx.slope, want_dx=ctx.needs_input_grad[0])
         gw3, gb3 = linear_wgrad(a2, dy)
         gw2, gb2 = linear_wgrad(a1, g2)
@@ -400,8 +447,11 @@ class _MessagePassFn(torch.autograd.Function):
         layers, slope, D = ctx.layers, ctx.slope, _MessagePassFn.DIMS
         dev = gh_in.device
         f = lambda t: torch.empty_like(t)  # noqa: E731
-        mdy, mg1, mg2 = f(mx), f(ma1), f(ma2)
-        udy, ug1, ug2 = f(ux), f(ua1), f(ua2)
+        acc_m = mlp_wgrad_acc(16, dev) if FUSED_WGRAD else None
+        acc_u = mlp_wgrad_acc(16, dev) if FUSED_WGRAD else None
+        fused = acc_m is not None and acc_u is not None
+        mdy, udy = f(mx), f(ux)
+        mg1, mg2, ug1, ug2 = (None,) * 4 if fused else (f(ma1), f(ma2), f(ua1), f(ua2))
         gh = gh_in.contiguous().clone()  # gradient w.r.t. the embeddings as they were before the layer being undone
         g_init = torch.zeros_like(gh)
         eo, ro = int(mx.shape[0]), int(ux.shape[0])
@@ -413,11 +463,19 @@ class _MessagePassFn(torch.autograd.Function):
             g_new = udy[ro:ro + n_r]
             # g_new = gh[recv]; gh[recv] = 0 (the receivers' previous embeddings were overwritten); g_init[recv] += g_new
             rows_op(ROWS_TAKE, recv, g_new, gh, g_init)
-            _, _, g_agg = mlp_backward(g_new, ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, 0, slope, g1=ug1[ro:ro + n_r], g2=ug2[ro:ro + n_r])
+            if fused:  # the parameter gradients of every layer add up in the two accumulators
+                g_agg = mlp_backward_wgrad(g_new, ux[ro:ro + n_r], ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, slope, acc_u)
+            else:
+                _, _, g_agg = mlp_backward(g_new, ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, 0, slope, g1=ug1[ro:ro + n_r], g2=ug2[ro:ro + n_r])
             g_msg = mdy[eo:eo + n_e]
             rows_op(ROWS_GATHER, pos, g_msg, g_agg)
-            _, _, g_xs = mlp_backward(g_msg, ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, 0, slope, g1=mg1[eo:eo + n_e], g2=mg2[eo:eo + n_e])
+            if fused:
+                g_xs = mlp_backward_wgrad(g_msg, mx[eo:eo + n_e], ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, slope, acc_m)
+            else:
+                _, _, g_xs = mlp_backward(g_msg, ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, 0, slope, g1=mg1[eo:eo + n_e], g2=mg2[eo:eo + n_e])
             rows_op(ROWS_SCATTER_ADD, child, g_xs, gh)
+        if fused:
+            return (g_init, gh, None, None, None, None) + tuple(mlp_wgrad_finish(D, acc_m)) + tuple(mlp_wgrad_finish(D, acc_u))
         grads = []
         for x, a1, a2, dy, g1, g2 in ((mx, ma1, ma2, mdy, mg1, mg2), (ux, ua1, ua2, udy, ug1, ug2)):
             if x.shape[0] == 0:

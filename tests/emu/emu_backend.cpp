@@ -169,6 +169,43 @@ static int be_launch_mlp(const SssMlpArgs& a, int backward, void*) {
   return 0;
 }
 
+// sss_mlp_backward_wgrad / sss_mlp_wgrad_finish on the host: be_launch_mlp's backward arithmetic, the parameter gradients added to slot 0
+static int be_launch_mlp_bwdw(const SssMlpArgs& a0, float* acc, void*) {
+  const int IN = a0.in_dim, H1 = a0.h1, H2 = a0.h2, OUT = a0.out_dim;
+  std::vector<float> g1((size_t)std::max<int64_t>(a0.rows, 1) * H1), g2((size_t)std::max<int64_t>(a0.rows, 1) * H2);
+  SssMlpArgs a = a0;
+  a.g1 = g1.data(), a.g2 = g2.data();
+  if (int rc = be_launch_mlp(a, 1, nullptr)) return rc;
+  float* l3 = acc;
+  float* l2 = l3 + (size_t)2048 * (OUT * H2 + OUT);
+  float* l1 = l2 + (size_t)2048 * (H2 * H1 + H2);
+  for (int64_t r = 0; r < a.rows; r++) {
+    for (int o = 0; o < OUT; o++) {
+      for (int m = 0; m < H2; m++) l3[o * H2 + m] += a.dy[r * OUT + o] * a.a2[r * H2 + m];
+      l3[OUT * H2 + o] += a.dy[r * OUT + o];
+    }
+    for (int m = 0; m < H2; m++) {
+      for (int j = 0; j < H1; j++) l2[m * H1 + j] += g2[r * H2 + m] * a.a1[r * H1 + j];
+      l2[H2 * H1 + m] += g2[r * H2 + m];
+    }
+    for (int j = 0; j < H1; j++) {
+      for (int c = 0; c < IN; c++) l1[j * IN + c] += g1[r * H1 + j] * a.x[r * IN + c];
+      l1[H1 * IN + j] += g1[r * H1 + j];
+    }
+  }
+  return 0;
+}
+static int be_launch_wgrad_reduce(const SssWgradArgs& a, void*) {
+  const int n_out = a.N * a.M + a.N;
+  for (int i = 0; i < n_out; i++) {
+    float s = 0.0f;
+    for (int p = 0; p < a.n_partials; p++) s += a.partial[(size_t)p * n_out + i];
+    if (i < a.N * a.M) a.gw[i] = s;
+    else if (a.gb) a.gb[i - a.N * a.M] = s;
+  }
+  return 0;
+}
+
 static int be_launch_prefix_rows(const SssPrefixArgs& a, void*) {
   int64_t part[1];
   for (int r = 0; r < a.n_rows; r++) prefix_row(a, r, 0, 1, part, [] {});

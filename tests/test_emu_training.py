@@ -206,6 +206,39 @@ def test_mlp_entry_points_on_the_host_backend():
         mlp_forward(torch.zeros((4, 7)), torch.zeros(2000), (7, 32, 16, 16), 0, 0.2, binding=b)
 
 
+def test_fused_backward_entry_points_on_the_host_backend():
+    """include/sss.h sss_mlp_backward_wgrad / sss_mlp_wgrad_finish through the emulator library's host loops against autograd on
+    the same MLP, with the parameter gradients of two calls adding up in one accumulator (what the layers of the message passing
+    do): the argument plumbing of train_kernels.mlp_wgrad_acc / mlp_backward_wgrad / mlp_wgrad_finish and the shape filter"""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+    from spark_sched_sim_amd.decima import make_mlp
+    from spark_sched_sim_amd.train_kernels import mlp_backward_wgrad, mlp_forward, mlp_wgrad_acc, mlp_wgrad_finish, pack_mlp
+
+    b = Binding(load_emu())
+    torch.manual_seed(6)
+    for in_dim in (5, 16, 21):
+        dims = (in_dim, 32, 16, 16)
+        mlp = make_mlp(in_dim, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2))
+        packed = pack_mlp(mlp[0], mlp[2], mlp[4])
+        acc = mlp_wgrad_acc(in_dim, "cpu", binding=b)
+        xs = [torch.randn((n, in_dim), requires_grad=True) for n in (37, 5)]
+        for x in xs:
+            y = mlp(x)
+            dy = torch.randn_like(y)
+            y.backward(dy)
+            a1, a2, _ = mlp_forward(x.detach(), packed, dims, 0, 0.2, binding=b)
+            dx = mlp_backward_wgrad(dy, x.detach(), a1, a2, packed, dims, 0.2, acc, binding=b)
+            assert torch.allclose(dx, x.grad, rtol=1e-4, atol=1e-5)
+        got = mlp_wgrad_finish(dims, acc, binding=b)
+        want = (mlp[0].weight.grad, mlp[0].bias.grad, mlp[2].weight.grad, mlp[2].bias.grad, mlp[4].weight.grad, mlp[4].bias.grad)
+        for g_, w_ in zip(got, want):
+            assert g_.shape == w_.shape and torch.allclose(g_, w_, rtol=1e-4, atol=1e-4)
+    assert mlp_wgrad_acc(53, "cpu", binding=b) is None
+
+
 def test_rows_entry_point_on_the_host_backend():
     """include/sss.h sss_rows_op through the emulator library's host implementation against torch indexing: the argument
     plumbing of spark_sched_sim_amd.train_kernels.rows_op (the four operations, a list side that is a column slice, widths that
