@@ -174,6 +174,20 @@ def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
     return g["layers"]
 
 
+def _take(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """`t[idx]` along the first axis; large gathers of 4-byte-multiple rows on the GPU go through the row kernel (include/sss.h
+    sss_rows_op GATHER moves bits, whatever the dtype: the library's index kernel ran at a tenth of its rate, profiles/r04_ppo.md)"""
+    row_bytes = t.element_size() * (t[0].numel() if t.dim() > 1 else 1) if t.numel() else 0
+    if not (t.is_cuda and idx.numel() >= 8192 and t.is_contiguous() and row_bytes % 4 == 0 and 4 <= row_bytes <= 256 and t.dtype != torch.bool):
+        return t[idx]
+    from .train_kernels import ROWS_GATHER, rows_op
+    w = row_bytes // 4
+    src = t.view(-1).view(torch.float32).view(t.shape[0], w)
+    out = torch.empty((idx.numel(), *t.shape[1:]), dtype=t.dtype, device=t.device)
+    rows_op(ROWS_GATHER, idx, out.view(-1).view(torch.float32).view(idx.numel(), w), src)
+    return out
+
+
 def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, Any]:
     """the sub-batch made of observations `obs_idx` (i64[k], in that order) of a compact graph,
     re-labelled - a PPO minibatch out of a `GraphArena`"""
@@ -213,14 +227,15 @@ def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, A
     node_new[kn] = torch.arange(kn.numel(), device=dev)
     job_new = torch.full((g["job_obs"].numel(),), -1, dtype=torch.long, device=dev)
     job_new[kj] = torch.arange(kj.numel(), device=dev)
-    return {"x": g["x"][kn], "node_obs": new_of_old[g["node_obs"][kn]], "node_loc": g["node_loc"][kn],
-            "node_job": job_new[g["node_job"][kn]], "gen": g["gen"][kn], "stage_mask": g["stage_mask"][kn],
-            "sched_rank": g["sched_rank"][kn], "n_pad": g["n_pad"],
-            "src": node_new[g["src"][ke]], "dst": node_new[g["dst"][ke]], "edge_obs": new_of_old[g["edge_obs"][ke]],
-            "job_obs": new_of_old[g["job_obs"][kj]], "job_cap": g["job_cap"][kj], "job_first": node_new[g["job_first"][kj]],
+    T = _take
+    return {"x": T(g["x"], kn), "node_obs": T(new_of_old, T(g["node_obs"], kn)), "node_loc": T(g["node_loc"], kn),
+            "node_job": T(job_new, T(g["node_job"], kn)), "gen": T(g["gen"], kn), "stage_mask": g["stage_mask"][kn],
+            "sched_rank": T(g["sched_rank"], kn), "n_pad": g["n_pad"],
+            "src": T(node_new, T(g["src"], ke)), "dst": T(node_new, T(g["dst"], ke)), "edge_obs": T(new_of_old, T(g["edge_obs"], ke)),
+            "job_obs": T(new_of_old, T(g["job_obs"], kj)), "job_cap": T(g["job_cap"], kj), "job_first": T(node_new, T(g["job_first"], kj)),
             "n_obs": int(obs_idx.numel()), "obs_nodes": g["obs_nodes"][obs_idx], "obs_jobs": g["obs_jobs"][obs_idx],
             "obs_depth": g["obs_depth"][obs_idx],
-            **({"edge_layers": g["edge_layers"][ke], "node_recv": g["node_recv"][kn]} if "edge_layers" in g else {})}
+            **({"edge_layers": T(g["edge_layers"], ke), "node_recv": T(g["node_recv"], kn)} if "edge_layers" in g else {})}
 
 
 def concat_graphs(gs: list[dict[str, Any]]) -> dict[str, Any]:

@@ -208,6 +208,26 @@ def test_collection_recorded_on_the_device_equals_the_synchronous_one_gpu():
 
 
 @pytest.mark.gpu
+def test_take_moves_rows_of_any_dtype():
+    """decima._take (the minibatch cut of `select_observations` on the row gather kernel) against tensor indexing: int64 / int32 /
+    float rows, NaN and negative-zero bit patterns included"""
+    from spark_sched_sim_amd.decima import _take
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(2)
+    n, k = 50_000, 20_011
+    idx = torch.randint(0, n, (k,), device=dev, generator=gen)
+    x = torch.randn((n, 5), device=dev, generator=gen)
+    x[::7, 2] = float("nan")
+    x[1::7, 3] = -0.0
+    for t in (x, torch.randint(-2 ** 62, 2 ** 62, (n,), device=dev, generator=gen), torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), device=dev, generator=gen).int(),
+              torch.randn((n, 16), device=dev, generator=gen), torch.rand(n, device=dev, generator=gen) < 0.5):
+        got, want = _take(t, idx), t[idx]
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert torch.equal(got.view(torch.uint8).reshape(-1) if got.dtype != torch.bool else got, want.view(torch.uint8).reshape(-1) if want.dtype != torch.bool else want)
+
+
+@pytest.mark.gpu
 def test_fused_backward_with_weight_gradients():
     """sss_mlp_mfma_bwdw_kernel (backward + the six parameter gradients in one pass, csrc/sss_train16.h) against fp64 autograd for
     the three GNN-shaped MLPs: row counts that are not multiples of 16 / 64 and exceed one grid pass, two calls adding up in one
