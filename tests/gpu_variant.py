@@ -16,7 +16,9 @@ VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
             "thr63": ("-DSSS_MIN_RELEASED_BATCH=6", "-DSSS_MIN_ARRIVAL_BATCH=3"), "arr1": ("-DSSS_MIN_ARRIVAL_BATCH=1",),
             "nolean": ("-DSSS_NO_LEAN",), "syncwg": ("-DSSS_SYNC_WORKGROUP",), "pair17": ("-DSSS_PAIR_MIN_E=17",), "w3": ("-DSSS_WAVES_PER_SIMD=3",), "w2": ("-DSSS_WAVES_PER_SIMD=2",), "oplane": ("-DSSS_OPAQUE_LANE",), "mlicm": ("-mllvm", "-disable-machine-licm=false"),
             # csrc/sss_rows.h: the atomic additions with 16 bytes per lane (A/B timing, tools/debug/rows_time.py)
-            "vecatom": ("-DSSS_ROWS_VEC_ATOMICS=1",)}
+            "vecatom": ("-DSSS_ROWS_VEC_ATOMICS=1",),
+            # job-cache slots at large job capacities (csrc/sss_layout.h; A/B timing at small env counts, profiles/r04_bench.md section 9)
+            "slots16": ("-DSSS_FALLBACK_SLOTS=16",), "slots24": ("-DSSS_FALLBACK_SLOTS=24",), "slots32": ("-DSSS_FALLBACK_SLOTS=32",), "slots48": ("-DSSS_FALLBACK_SLOTS=48",)}
 
 
 def variant_path(name: str) -> str:
