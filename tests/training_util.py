@@ -286,7 +286,7 @@ def check_record_kernels(binding, device):
                           lgprobs=z.float(), resets=z.bool())
             ref = Rollouts(**{**ro.__dict__, "active": a.cpu(), "t_before": ro.t_before.cpu(), "t_after": ro.t_after.cpu(), "rewards": ro.rewards.cpu()})
             r_ref = T_discounted(ref)
-            r_got = __import__("spark_sched_sim_amd.training", fromlist=["x"]).discounted_returns(ro, 5e-3, binding=binding)
+            r_got = discounted_returns(ro, 5e-3, binding=binding)
             assert torch.allclose(r_got.cpu(), r_ref, rtol=1e-12, atol=1e-9), float((r_got.cpu() - r_ref).abs().max())
             b_ref = sequence_baselines(ref, r_ref, B // R, R)
             b_got = sequence_baselines(ro, r_ref.to(device), B // R, R, binding=binding)

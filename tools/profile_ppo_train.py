@@ -11,7 +11,7 @@ import time
 import torch
 
 sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
-from spark_sched_sim_amd.training import Trainer, ppo_loss, select_observations  # noqa: E402
+from spark_sched_sim_amd.training import Trainer, discounted_returns, ppo_loss, select_observations, sequence_baselines  # noqa: E402
 from bench_ppo import AGENT  # noqa: E402
 
 
@@ -40,9 +40,9 @@ def main():
     # pieces of one minibatch
     ppo = tr.ppo
     torch.cuda.synchronize(); p0 = time.perf_counter()
-    returns = ppo.diff(ro) if ppo.diff is not None else __import__("spark_sched_sim_amd.training", fromlist=["x"]).discounted_returns(ro, ppo.beta)
+    returns = ppo.diff(ro) if ppo.diff is not None else discounted_returns(ro, ppo.beta)
     torch.cuda.synchronize(); p1 = time.perf_counter()
-    baselines = __import__("spark_sched_sim_amd.training", fromlist=["x"]).sequence_baselines(ro, returns, ppo.num_sequences, ppo.num_rollouts)
+    baselines = sequence_baselines(ro, returns, ppo.num_sequences, ppo.num_rollouts)
     torch.cuda.synchronize(); p2 = time.perf_counter()
     print(json.dumps({"returns_s": p1 - p0, "baselines_s": p2 - p1, "rows": int(ro.active.shape[0])}))
     ids = ro.sample_ids()
