@@ -196,6 +196,25 @@ typedef struct sss_decima_lists {
 } sss_decima_lists;
 int sss_decima_layer_lists(int num_envs, const sss_decima_lists* a, void* stream);
 
+/* The DAG layers' index lists of a batch graph from its per-edge / per-node layer masks (sss_decima_graph_build's edge_layers /
+ * node_recv; the reference's `edge_masks[l]` as index lists, decima/utils.py:249-267): for every bit l < n_layers the ascending
+ * positions e with bit l of bits_dev[e] set - what torch.nonzero over (bits >> l) & 1 returns, for all layers in two launches.
+ *   pass 0: cnt_dev[c * n_layers + l] (i32[n_chunks][n_layers]) = such positions in chunk c = [c * chunk, (c + 1) * chunk);
+ *           chunk a multiple of 64, n_chunks = ceil(n / chunk). The caller scans the counts along the chunks (sss_prefix_rows with
+ *           src_row_stride 1, src_col_stride n_layers) into off_dev i64[n_layers][n_chunks] and reads the totals;
+ *   pass 1: out_dev[base[l] + off_dev[l][c] + rank] = e  (base[l]: where layer l's list starts in out_dev; host values). */
+typedef struct sss_bit_list_args {
+  const int32_t* bits_dev;
+  int64_t n;
+  int32_t n_layers, chunk;
+  int32_t n_chunks, phase; /* phase: 0 = count, 1 = write ("pass" above) */
+  int32_t* cnt_dev;
+  const int64_t* off_dev;
+  int64_t base[32];
+  int64_t* out_dev;
+} sss_bit_list_args;
+int sss_bit_lists(const sss_bit_list_args* a, void* stream);
+
 /* Exclusive prefix sums and totals of n_rows rows of n_cols non-negative counts, one launch (the offsets the two
  * kernels above are fed: per-env node / edge / job offsets of the compact graph, per-env offsets into each DAG
  * layer's receiver list; what utils.collate_obsns does with torch.cumsum on the host, decima/utils.py:117-204).

@@ -124,6 +124,11 @@ class SssRowsArgs(C.Structure):  # include/sss.h sss_rows_args
                 ("c_dev", C.c_void_p)]
 
 
+class SssBitListArgs(C.Structure):  # include/sss.h sss_bit_list_args
+    _fields_ = [("bits_dev", C.c_void_p), ("n", C.c_int64), ("n_layers", C.c_int32), ("chunk", C.c_int32), ("n_chunks", C.c_int32), ("phase", C.c_int32),
+                ("cnt_dev", C.c_void_p), ("off_dev", C.c_void_p), ("base", C.c_int64 * 32), ("out_dev", C.c_void_p)]
+
+
 class SssReturnsArgs(C.Structure):  # include/sss.h sss_returns_args
     _fields_ = [("T", C.c_int64), ("B", C.c_int64), ("active_dev", C.c_void_p), ("t_before_dev", C.c_void_p), ("t_after_dev", C.c_void_p), ("rewards_dev", C.c_void_p),
                 ("beta", C.c_double), ("out_dev", C.c_void_p)]
@@ -145,7 +150,7 @@ class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_step_bounded", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 
 
@@ -191,6 +196,7 @@ class Binding:
         L.sss_mlp_wgrad_finish.argtypes = [C.c_int] + [C.c_void_p] * 8
         L.sss_discounted_returns.argtypes = [C.POINTER(SssReturnsArgs), C.c_void_p]
         L.sss_sequence_baselines.argtypes = [C.POINTER(SssBaselineArgs), C.c_void_p]
+        L.sss_bit_lists.argtypes = [C.POINTER(SssBitListArgs), C.c_void_p]
         L.sss_arena_append.argtypes = [C.POINTER(SssArenaArgs), C.c_void_p]
         L.sss_rows_op.argtypes = [C.POINTER(SssRowsArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p

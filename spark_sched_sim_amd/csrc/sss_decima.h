@@ -206,6 +206,43 @@ SSS_KERNEL void sss_decima_lists_kernel(int num_envs, SssDecimaListArgs d) {
   }
 }
 
+// sss_bit_lists (include/sss.h): for every bit l < n_layers the ascending list of the positions e with bit l of bits[e] set - the
+// DAG layers' edge lists and receiver lists of a batch graph from its per-edge / per-node layer masks (what torch.nonzero over
+// (mask >> l) & 1 returns, layer after layer: decima/utils.py:249-267's edge_masks as index lists). One wave per chunk of
+// `chunk` consecutive positions; pass 0 counts (cnt[chunk][l]), the caller scans the counts (sss_prefix_rows), pass 1 writes
+// out[base[l] + off[l][chunk] + rank inside the chunk].
+struct SssBitListArgs {
+  const int32_t* bits;
+  int64_t n;
+  int32_t n_layers, chunk;  // chunk: a multiple of 64
+  int32_t n_chunks, pass;
+  int32_t* cnt;             // [n_chunks][n_layers]
+  const int64_t* off;       // [n_layers][n_chunks]
+  int64_t base[32];
+  int64_t* out;
+};
+SSS_KERNEL void sss_bit_lists_kernel(SssBitListArgs a) {
+  const int c = wave_env(), lane = wave_lane();
+  const uint64_t lt = bit64(lane) - 1;
+  const int64_t e0 = (int64_t)c * a.chunk;
+  uint32_t run = 0;  // lane l: positions with bit l seen so far in this chunk
+  for (int i0 = 0; i0 < a.chunk; i0 += 64) {
+    const int64_t e = e0 + i0 + lane;
+    const uint32_t v = e < a.n ? (uint32_t)a.bits[e] : 0u;
+    if (wave_ballot(v != 0) == 0) continue;
+    for (int l = 0; l < a.n_layers; l++) {
+      const bool on = (v >> l) & 1u;
+      const uint64_t bal = wave_ballot(on);
+      if (a.pass == 1 && bal) {
+        const uint32_t before = wave_readlane_u32(run, l);
+        if (on) a.out[a.base[l] + a.off[(size_t)l * a.n_chunks + c] + before + popc64(bal & lt)] = e;
+      }
+      if (lane == l) run += (uint32_t)popc64(bal);
+    }
+  }
+  if (a.pass == 0 && lane < a.n_layers) a.cnt[(size_t)c * a.n_layers + lane] = (int32_t)run;
+}
+
 // sss_prefix_rows (include/sss.h): one row's exclusive prefix sums, `tid` of `nt` cooperating threads; `part` is
 // scratch for nt partial sums shared by them; `sync` orders the phases.
 struct SssPrefixArgs {

@@ -73,6 +73,10 @@ static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, cons
   return (int)hipGetLastError();
 }
 
+static int be_launch_bit_lists(const SssBitListArgs& a, void* stream) {
+  hipLaunchKernelGGL(sss_bit_lists_kernel, dim3((unsigned)a.n_chunks), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void* stream) {
   hipLaunchKernelGGL(sss_decima_lists_kernel, dim3(num_envs), dim3(64), 0, (hipStream_t)stream, num_envs, d);
   return (int)hipGetLastError();

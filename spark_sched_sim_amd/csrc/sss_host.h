@@ -729,6 +729,20 @@ extern "C" int sss_sequence_baselines(const sss_baseline_args* a, void* stream) 
   return 0;
 }
 
+extern "C" int sss_bit_lists(const sss_bit_list_args* a, void* stream) {
+  if (!a || !a->bits_dev) return sss_fail(-1, "NULL argument");
+  if (a->n < 0 || a->n_layers < 1 || a->n_layers > 32 || a->chunk < 64 || a->chunk % 64 != 0 || a->n_chunks != (int)((a->n + a->chunk - 1) / a->chunk) ||
+      (a->phase != 0 && a->phase != 1))
+    return sss_fail(-37, "sss_bit_lists: 1..32 layers, chunk a multiple of 64, n_chunks = ceil(n / chunk), pass 0 or 1");
+  if (a->phase == 0 ? !a->cnt_dev : (!a->off_dev || !a->out_dev)) return sss_fail(-1, "NULL argument");
+  if (a->n_chunks == 0) return 0;
+  SssBitListArgs r;
+  r.bits = a->bits_dev, r.n = a->n, r.n_layers = a->n_layers, r.chunk = a->chunk, r.n_chunks = a->n_chunks, r.pass = a->phase, r.cnt = a->cnt_dev, r.off = a->off_dev, r.out = a->out_dev;
+  for (int l = 0; l < 32; l++) r.base[l] = a->base[l];
+  if (int rc = be_launch_bit_lists(r, stream)) return sss_fail(-30, std::string("bit lists launch failed: ") + be_error(rc));
+  return 0;
+}
+
 extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
   if (!a || !a->a_dev || !a->b_dev || (a->n > 0 && !a->idx_dev)) return sss_fail(-1, "NULL argument");
   if (a->op < 0 || a->op > 5) return sss_fail(-33, "sss_rows_op: unknown operation");

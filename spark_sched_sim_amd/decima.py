@@ -147,6 +147,41 @@ def compact_graph(f: dict[str, torch.Tensor]) -> dict[str, Any]:
             "obs_nodes": n_nodes, "obs_jobs": f["job_valid"].sum(1), "obs_depth": f["depth"]}
 
 
+def bit_lists(bits: torch.Tensor, n_layers: int, binding=None) -> list[torch.Tensor]:
+    """[positions e with bit l of bits[e] set, ascending, for l < n_layers] for an int32 mask array - `((bits >> l) & 1).nonzero()`
+    for all layers in three launches and ONE device->host read (include/sss.h sss_bit_lists + sss_prefix_rows) instead of a
+    `nonzero` with its read per layer"""
+    import ctypes
+
+    from .binding import SssBitListArgs, device_of
+    if binding is None:
+        from .train_kernels import _binding
+        binding = _binding()
+    dev, n = bits.device, int(bits.numel())
+    assert bits.dtype == torch.int32 and bits.is_contiguous() and 1 <= n_layers <= 32
+    if n == 0:
+        return [torch.zeros(0, dtype=torch.int64, device=dev) for _ in range(n_layers)]
+    chunk = 2048
+    n_chunks = (n + chunk - 1) // chunk
+    cnt = torch.empty((n_chunks, n_layers), dtype=torch.int32, device=dev)
+    off = torch.empty((n_layers, n_chunks), dtype=torch.int64, device=dev)
+    tot = torch.empty(n_layers, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    a = SssBitListArgs(bits.data_ptr(), n, n_layers, chunk, n_chunks, 0, cnt.data_ptr(), None, (ctypes.c_int64 * 32)(), None)
+    with device_of(dev):
+        binding.check(binding.lib.sss_bit_lists(ctypes.byref(a), stream))
+        binding.check(binding.lib.sss_prefix_rows(cnt.data_ptr(), 1, n_layers, None, n_layers, n_chunks, off.data_ptr(), None, tot.data_ptr(), stream))
+    sizes = [int(v) for v in tot.tolist()]  # (the one read)
+    out = torch.empty(max(sum(sizes), 1), dtype=torch.int64, device=dev)
+    base, run = (ctypes.c_int64 * 32)(), 0
+    for l, k in enumerate(sizes):
+        base[l], run = run, run + k
+    a.phase, a.off_dev, a.out_dev, a.base = 1, off.data_ptr(), out.data_ptr(), base
+    with device_of(dev):
+        binding.check(binding.lib.sss_bit_lists(ctypes.byref(a), stream))
+    return [out[base[l]: base[l] + sizes[l]] for l in range(n_layers)]
+
+
 def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
     """for every DAG layer l (decima/utils.py:249-267): (ids of the edges whose two ends lie in
     (generation l) U (its successors) - the reference's `edge_masks[l]` as an index list, ids of the
@@ -155,8 +190,11 @@ def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
         # the graph kernel (include/sss.h sss_decima_graph_build) already marked every edge / node
         # with the layers it belongs to: one bit test + nonzero per layer
         depth = int(g["obs_depth"].max()) if g["x"].shape[0] else 0
-        g["layers"] = [(((g["edge_layers"] >> lvl) & 1).nonzero(as_tuple=True)[0], ((g["node_recv"] >> lvl) & 1).nonzero(as_tuple=True)[0])
-                       for lvl in range(depth)]
+        el, nr = g["edge_layers"], g["node_recv"]
+        if el.is_cuda and 1 <= depth <= 32 and el.numel() >= 8192 and el.dtype == nr.dtype == torch.int32:
+            g["layers"] = list(zip(bit_lists(el.contiguous(), depth), bit_lists(nr.contiguous(), depth)))  # two reads instead of 2 x depth
+        else:
+            g["layers"] = [(((el >> lvl) & 1).nonzero(as_tuple=True)[0], ((nr >> lvl) & 1).nonzero(as_tuple=True)[0]) for lvl in range(depth)]
         return g["layers"]
     if "layers" not in g:
         gen, src, dst = g["gen"], g["src"], g["dst"]

@@ -211,6 +211,10 @@ static int be_launch_prefix_rows(const SssPrefixArgs& a, void*) {
   for (int r = 0; r < a.n_rows; r++) prefix_row(a, r, 0, 1, part, [] {});
   return 0;
 }
+static int be_launch_bit_lists(const SssBitListArgs& a, void*) {
+  emu::launch(a.n_chunks, [&]() { sss_bit_lists_kernel(a); });
+  return 0;
+}
 static int be_launch_decima_lists(int num_envs, const SssDecimaListArgs& d, void*) {
   emu::launch(num_envs, [&]() { sss_decima_lists_kernel(num_envs, d); });
   return 0;

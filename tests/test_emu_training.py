@@ -270,6 +270,16 @@ def test_graph_arena_grows():
     check_record_on_device("cpu", load_emu(), num_envs=3, tiny_arena=True)
 
 
+def test_bit_lists_under_the_emulator():
+    """the layer-list kernel (csrc/sss_decima.h sss_bit_lists_kernel, a wave per chunk) under the wave emulator against nonzero"""
+    from training_util import check_bit_lists
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+
+    check_bit_lists(Binding(load_emu()), "cpu")
+
+
 def test_record_kernels_on_the_host_backend():
     """include/sss.h sss_discounted_returns / sss_sequence_baselines through the emulator library's host loops against the
     tensor-op forms (training_util.check_record_kernels)"""

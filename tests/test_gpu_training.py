@@ -208,6 +208,30 @@ def test_collection_recorded_on_the_device_equals_the_synchronous_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bit_lists_match_nonzero():
+    """sss_bit_lists_kernel on the GPU against nonzero (training_util.check_bit_lists), and `graph_layers` of a recorded graph
+    built with it against the per-layer nonzero form"""
+    from training_util import check_bit_lists
+
+    from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
+    from spark_sched_sim_amd.decima import graph_layers
+
+    check_bit_lists(None, "cuda:0")
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 512, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
+    env.reset(seed=3)
+    env.rollout("fair", 120)
+    g = env.decima_graph(None)
+    assert g["edge_layers"].numel() >= 8192
+    got = graph_layers(dict(g))
+    depth = int(g["obs_depth"].max())
+    assert len(got) == depth >= 3
+    for lvl, (e, recv) in enumerate(got):
+        assert torch.equal(e, ((g["edge_layers"] >> lvl) & 1).nonzero(as_tuple=True)[0]) and torch.equal(recv, ((g["node_recv"] >> lvl) & 1).nonzero(as_tuple=True)[0])
+    env.close()
+
+
+@pytest.mark.gpu
 def test_take_moves_rows_of_any_dtype():
     """decima._take (the minibatch cut of `select_observations` on the row gather kernel) against tensor indexing: int64 / int32 /
     float rows, NaN and negative-zero bit patterns included"""
