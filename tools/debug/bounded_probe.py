@@ -15,7 +15,7 @@ from spark_sched_sim_amd.vec_env import HDR_OFF, HDR_PROF  # noqa: E402
 
 config, budget = sys.argv[1], int(sys.argv[2])
 cfg = bench.CONFIGS[config]
-B = 4096
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 e = VecSparkSchedSimEnv(cfg, B, device="cuda:0", pack=workload.default_pack(), auto_reset=True, seed_stride=B)
 e.reset(seed=0)
 left = bench.PREROLL_STEPS[config]
