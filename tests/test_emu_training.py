@@ -260,6 +260,15 @@ def test_collection_recorded_on_the_device_equals_the_synchronous_one():
     check_record_on_device("cpu", load_emu(), num_envs=6)
 
 
+def test_collection_recorded_on_the_device_with_a_failing_env():
+    """training_util.check_record_on_device_with_a_failing_env on the emulator library"""
+    from training_util import check_record_on_device_with_a_failing_env
+
+    from emu_util import load_emu
+
+    check_record_on_device_with_a_failing_env("cpu", load_emu())
+
+
 def test_graph_arena_grows():
     """`GraphArena` with a starting capacity far too small for the collection: the headroom rule makes it grow (with the
     cursors the host has seen), the record is still the one of the synchronous loop"""

@@ -208,6 +208,14 @@ def test_collection_recorded_on_the_device_equals_the_synchronous_one_gpu():
 
 
 @pytest.mark.gpu
+def test_collection_recorded_on_the_device_with_a_failing_env_gpu():
+    """training_util.check_record_on_device_with_a_failing_env on the GPU: the error flag of the failing step is read late"""
+    from training_util import check_record_on_device_with_a_failing_env
+
+    check_record_on_device_with_a_failing_env("cuda:0", None, num_envs=32)
+
+
+@pytest.mark.gpu
 def test_bit_lists_match_nonzero():
     """sss_bit_lists_kernel on the GPU against nonzero (training_util.check_bit_lists), and `graph_layers` of a recorded graph
     built with it against the per-layer nonzero form"""

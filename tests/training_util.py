@@ -323,3 +323,55 @@ def check_bit_lists(binding, device):
         for l in range(L):
             want = ((bits >> l) & 1).nonzero(as_tuple=True)[0]
             assert got[l].dtype == torch.int64 and torch.equal(got[l], want), (n, L, l)
+
+
+def check_record_on_device_with_a_failing_env(device, lib, num_envs=6):
+    """an env that reports an error in the middle of a collection (its sampled action is corrupted: a stage index outside the
+    schedulable stages) - `on_env_error="truncate"`: the env leaves the collection, the record is the same with and without
+    `record_on_device` (flags read late or not); `"raise"`: both raise, naming the env and its step"""
+    import pytest
+
+    cfg = dict(num_executors=10, job_arrival_cap=8, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    dev = torch.device(device)
+    bad_env, bad_step = 2, 9
+
+    def collector(on_dev, mode):
+        env = VecSparkSchedSimEnv(cfg, num_envs, device=device, auto_reset=False, _lib=lib)
+        torch.manual_seed(1)
+        pol = DecimaPolicy(num_executors=10, **AGENT).to(dev)
+        gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
+        gen.manual_seed(5)
+        col = RolloutCollector(env, 5.0e5, list(range(31, 31 + num_envs)), seed_step=num_envs, num_executors=10, policy=pol, generator=gen,
+                               record_on_device=on_dev, on_env_error=mode)
+        act, calls = pol.act, [0]
+
+        def corrupted(g, generator=None):
+            a = act(g, generator)
+            if calls[0] == bad_step:
+                a["stage_sel"][bad_env] = 10_000
+                if "env_stage_idx" in a:
+                    a["env_stage_idx"][bad_env] = 10_000
+            calls[0] += 1
+            return a
+        pol.act = corrupted
+        return env, col
+
+    out = {}
+    for on_dev in (True, False):
+        env, col = collector(on_dev, "truncate")
+        out[on_dev] = col.collect_sync(with_stats=False)
+        assert col.env_errors == 1 and (col._arena_sizes is not None) == on_dev
+        env.close()
+    ra, rb = out[True], out[False]
+    assert int(ra.active[:, bad_env].sum()) == bad_step  # the failing step is not recorded, the env sits out the rest
+    for name in ("active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets"):
+        assert torch.equal(getattr(ra, name), getattr(rb, name)), name
+    for k, v in rb.graph.items():
+        if torch.is_tensor(v):
+            assert torch.equal(ra.graph[k], v), k
+    for on_dev in (True, False):
+        env, col = collector(on_dev, "raise")
+        with pytest.raises(RuntimeError) as ei:
+            col.collect_sync(with_stats=False)
+        assert f"env {bad_env} " in str(ei.value) and f"rollout step {bad_step}" in str(ei.value)
+        env.close()
