@@ -49,7 +49,14 @@ def check_bounded_steps(device, lib, cfg, seeds, policy, n_steps, budgets, pack=
             a = env.policy_actions(policy)
             frozen = torch.from_numpy(count >= n_steps).to(env.device)
             stage_idx = torch.where(frozen, torch.full_like(a["stage_idx"], SKIP), a["stage_idx"]).contiguous()
-            ready = env.step_bounded_async(stage_idx, a["num_exec"], budget).cpu().numpy().astype(bool)
+            if budget == "mixed":  # a different budget every launch, and every fifth launch a plain step() (it finishes cut steps too)
+                if n_launch % 5 == 4:
+                    env.step_async(stage_idx, a["num_exec"])
+                    ready = np.ones(B, dtype=bool)
+                else:
+                    ready = env.step_bounded_async(stage_idx, a["num_exec"], (n_launch * 7) % 23 + 1).cpu().numpy().astype(bool)
+            else:
+                ready = env.step_bounded_async(stage_idx, a["num_exec"], budget).cpu().numpy().astype(bool)
             n_launch += 1
             got = {k: _rows(env, k) for k in OUT}
             for b in np.nonzero(~frozen.cpu().numpy())[0]:

@@ -16,10 +16,11 @@ def pack():
 
 
 @pytest.mark.parametrize("cfg,policy,seeds,n_steps,budgets", [(C2, "fair", [1, 2, 3], 120, (1, 7, 64)), (E50, "fair", [4, 5], 60, (3, 16)),
-                                                               (E50, "hash", [6], 80, (5,)), (E100, "fair", [7], 40, (4, 40))])
+                                                               (E50, "hash", [6], 80, (5,)), (E100, "fair", [7], 40, (4, 40)),
+                                                               (E50, "fair", [8, 9], 60, ("mixed",))])
 def test_bounded_steps_leave_what_steps_leave(cfg, policy, seeds, n_steps, budgets, pack):
     launches = check_bounded_steps("cpu", load_emu(), cfg, seeds, policy, n_steps, budgets, pack=pack)
-    small = min(budgets)
+    small = min(budgets, key=lambda b: 0 if b == "mixed" else b)
     assert launches[small][1] > 0, "no step was cut at the smallest budget: the test did not exercise the continuation"
     assert launches[small][0] > n_steps
 
