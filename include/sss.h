@@ -297,7 +297,8 @@ int sss_gnn_launch(int kind, const sss_gnn_args* args, void* stream);
  * uniform stream keyed by (rng_seed, rng_counter, env, candidate): pass a new rng_counter per call.
  * Outputs per env: stage_idx / num_exec (for sss_step; stage_idx -1 when nothing is schedulable),
  * Decima's action tuple (stage_sel, job_idx, exec_sel) and its log-probability; optional dense
- * scores (stage_scores_dev f32[num_envs][node_cap], exec_scores_dev f32[num_envs][E]; -inf = masked). */
+ * scores (stage_scores_dev f32[num_envs][node_cap], exec_scores_dev f32[num_envs][E]; -inf = masked).
+ * Any executor count the simulator takes (1..128: an executor count sits on lane c & 63, two per lane beyond 64). */
 typedef struct sss_decima_policy_args {
   const uint8_t* active_dev; /* u8[num_envs] or NULL */
   float num_tasks_scale, work_scale, slope;
@@ -327,7 +328,7 @@ int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* a, void* stre
  * sss_gnn_launch pipeline, one wavefront per observation, same Gumbel-max stream as sss_decima_policy.
  * which = 0: stage draw from stage_scores_dev (f32[n_obs][n_pad], -inf = masked) -> job_gid_dev (the
  * idx0 of the EXEC launch), stage_idx / stage_sel / job_idx, lgprob, any_stage. which = 1: executor
- * count draw from exec_scores_dev (f32[n_obs][E]) -> num_exec / exec_sel, lgprob += . */
+ * count draw from exec_scores_dev (f32[n_obs][E], any E >= 1: lanes stride over the counts) -> num_exec / exec_sel, lgprob += . */
 typedef struct sss_decima_sample_args {
   int64_t n_pad;
   int num_executors;

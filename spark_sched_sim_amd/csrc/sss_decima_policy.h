@@ -313,29 +313,40 @@ SSS_DEV void decima_policy_wave(const SssLayout& L, const SssBuffers& B, int E, 
     cap = gap < ncommit ? gap : ncommit;
     if (a_sel == src_idx) cap = ncommit;
   }
-  float esc = -__builtin_inff();
-  if (lane < E) {
+  // executor count c lives on lane c & 63, slot c >> 6 (up to 128 executors: two counts per lane)
+  float esc[2] = {-__builtin_inff(), -__builtin_inff()};
+  float ekey = -__builtin_inff(), ebest = -__builtin_inff(), emax = -__builtin_inff();
+  uint32_t ebest_c = (uint32_t)lane;
+  for (int q = 0; q < 2; q++) {
+    int c = lane + 64 * q;
+    if (c >= E) break;
     float x[GNN_DF + 2 * F + 1], h2[64];
     gnn_load<GNN_DF>(NS + (size_t)dag_ptr[a_sel] * DP_NODE_FLOATS + DP_X, x);
     gnn_load<F>(JS + (size_t)a_sel * DP_JOB_FLOATS, x + GNN_DF);
     GNN_UNROLL for (int k = 0; k < F; k++) x[GNN_DF + F + k] = hglob[k];
-    x[GNN_DF + 2 * F] = (float)lane / (float)E;
+    x[GNN_DF + 2 * F] = (float)c / (float)E;
     gnn_hidden<GNN_DF + 2 * F + 1, 64, 64, 1>(d.w_exec, x, h2, 0.0f);
     float v0 = 0.0f;
     gnn_out<GNN_DF + 2 * F + 1, 64, 64, 1>(d.w_exec, h2, 1.0f, [&](int, float v) { v0 = v; });
-    if (lane < cap) esc = v0;
-    if (d.exec_scores) d.exec_scores[(size_t)env * E + lane] = esc;
+    if (c < cap) esc[q] = v0;
+    if (d.exec_scores) d.exec_scores[(size_t)env * E + c] = esc[q];
+    if (esc[q] != -__builtin_inff()) {
+      float key = esc[q] + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)c, 1);
+      if (key > ekey) ekey = key, ebest = esc[q], ebest_c = (uint32_t)c;
+      if (esc[q] > emax) emax = esc[q];
+    }
   }
-  bool ok = esc != -__builtin_inff();
-  float ekey = ok ? esc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)lane, 1) : -__builtin_inff();
+  bool ok = emax != -__builtin_inff();
   uint32_t csel;
-  dp_wave_argmax(ekey, (uint32_t)lane, kmax, csel);
+  dp_wave_argmax(ekey, ebest_c, kmax, csel);
   bool any_exec = wave_ballot(ok) != 0;
   float EM, ES = 0.0f, esel = 0.0f;
-  dp_wave_argmax(esc, 0, EM, dummy_i);
+  dp_wave_argmax(emax, 0, EM, dummy_i);
   if (any_exec) {
-    ES = wave_sum_f32(ok ? expf(esc - EM) : 0.0f);
-    dp_wave_argmax((uint32_t)lane == csel ? esc : -__builtin_inff(), 0, esel, dummy_i);
+    float part = 0.0f;
+    for (int q = 0; q < 2; q++) part += esc[q] != -__builtin_inff() ? expf(esc[q] - EM) : 0.0f;
+    ES = wave_sum_f32(part);
+    dp_wave_argmax(ok && ebest_c == csel ? ebest : -__builtin_inff(), 0, esel, dummy_i);
   } else {
     csel = 0;
   }
@@ -414,16 +425,30 @@ SSS_KERNEL void sss_decima_sample_stage_kernel(SssDecimaSampleArgs d) {
 SSS_KERNEL void sss_decima_sample_exec_kernel(SssDecimaSampleArgs d) {
   int env = wave_env(), lane = wave_lane();
   bool live = d.any_stage[env] != 0;
-  float esc = live && lane < d.E ? d.exec_scores[(size_t)env * d.E + lane] : -__builtin_inff();
-  bool ok = esc != -__builtin_inff();
-  float ekey = ok ? esc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)lane, 1) : -__builtin_inff();
+  const float* row = d.exec_scores + (size_t)env * d.E;
+  // lanes stride over the executor counts (any E); with E <= 64 every lane holds one count as before
+  float ekey = -__builtin_inff(), ebest = -__builtin_inff(), emax = -__builtin_inff();
+  uint32_t ebest_c = (uint32_t)lane;
+  for (int c = lane; live && c < d.E; c += 64) {
+    float esc = row[c];
+    if (esc == -__builtin_inff()) continue;
+    float key = esc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)c, 1);
+    if (key > ekey) ekey = key, ebest = esc, ebest_c = (uint32_t)c;
+    if (esc > emax) emax = esc;
+  }
+  bool ok = emax != -__builtin_inff();
   float kmax, EM, esel;
   uint32_t csel, dummy_i;
-  dp_wave_argmax(ekey, (uint32_t)lane, kmax, csel);
+  dp_wave_argmax(ekey, ebest_c, kmax, csel);
   bool any_exec = wave_ballot(ok) != 0;
-  dp_wave_argmax(esc, 0, EM, dummy_i);
-  float ES = wave_sum_f32(ok ? expf(esc - EM) : 0.0f);
-  dp_wave_argmax(ok && (uint32_t)lane == csel ? esc : -__builtin_inff(), 0, esel, dummy_i);
+  dp_wave_argmax(emax, 0, EM, dummy_i);
+  float part = 0.0f;
+  for (int c = lane; ok && c < d.E; c += 64) {
+    float esc = row[c];
+    part += esc != -__builtin_inff() ? expf(esc - EM) : 0.0f;
+  }
+  float ES = wave_sum_f32(part);
+  dp_wave_argmax(ok && ebest_c == csel ? ebest : -__builtin_inff(), 0, esel, dummy_i);
   if (lane == 0) {
     if (!any_exec) csel = 0;
     d.exec_sel[env] = csel, d.num_exec[env] = (int32_t)csel + 1;

@@ -490,7 +490,7 @@ extern "C" int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* g,
       !g->exec_sel_dev || !g->lgprob_dev)
     return sss_fail(-1, "NULL argument");
   if ((int64_t)20 * h->L.n_cap + 64 > 65536 || h->L.n_cap > 65535) return sss_fail(-25, "node capacity too large for the Decima policy kernel's LDS working set");
-  if (h->cfg.num_executors > 64) return sss_fail(-28, "num_executors must be <= 64");
+  if (h->cfg.num_executors > 128) return sss_fail(-28, "num_executors must be <= 128");
   SssDecimaPolicyArgs d;
   d.active = g->active_dev, d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale, d.slope = g->slope;
   d.w_prep = g->w_prep_dev, d.w_msg = g->w_msg_dev, d.w_upd = g->w_upd_dev, d.w_dag = g->w_dag_dev, d.w_glob = g->w_glob_dev;
@@ -504,7 +504,7 @@ extern "C" int sss_decima_policy(sss_handle* h, const sss_decima_policy_args* g,
 
 extern "C" int sss_decima_sample(int n_obs, int which, const sss_decima_sample_args* g, void* stream) {
   if (!g || n_obs < 1 || (which != 0 && which != 1)) return sss_fail(-1, "bad argument");
-  if (g->num_executors < 1 || g->num_executors > 64) return sss_fail(-28, "num_executors must be 1..64");
+  if (g->num_executors < 1) return sss_fail(-28, "num_executors must be >= 1");
   SssDecimaSampleArgs d;
   d.n_pad = g->n_pad, d.E = g->num_executors, d.rng_seed = g->rng_seed, d.rng_counter = g->rng_counter;
   d.stage_scores = g->stage_scores_dev, d.exec_scores = g->exec_scores_dev, d.obs_nodes = g->obs_nodes_dev, d.obs_node_off = g->obs_node_off_dev;

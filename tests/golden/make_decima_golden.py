@@ -39,6 +39,9 @@ CFGS = {
                        warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"), [3, 4]),
     "decima_e50": (dict(num_executors=50, job_arrival_cap=12, job_arrival_rate=8.0e-5, moving_delay=2000.0,
                         warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"), [5]),
+    # more than 64 executors: executor-count scores / exec_mask of 100 entries per job, the simulator's wide instantiation
+    "decima_e100": (dict(num_executors=100, job_arrival_cap=12, job_arrival_rate=1.2e-4, moving_delay=2000.0,
+                         warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"), [6]),
 }
 AGENT = dict(embed_dim=16,
              gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(inplace=True, negative_slope=0.2)),

@@ -9,7 +9,7 @@ from decima_util import check_decima_fixture
 from emu_util import load_emu
 
 
-@pytest.mark.parametrize("name,n_steps", [("decima_c1", 50), ("decima_e50", 40)])
+@pytest.mark.parametrize("name,n_steps", [("decima_c1", 50), ("decima_e50", 40), ("decima_e100", 30)])
 def test_decima_features_and_scores_match_reference(name, n_steps):
     check_decima_fixture(name, "cpu", load_emu(), n_steps)
 
@@ -36,6 +36,35 @@ def test_sampled_actions_are_always_valid():
         assert not info["err"].any()
     assert int(env.header_field("n_steps").sum()) == 6 * 150
     env.close()
+
+
+def test_decima_in_the_loop_beyond_64_executors():
+    """100 and 128 executors (two executor counts per lane in the sampling kernels; round 4 raised `sss error -28` here):
+    sampled actions through the pipeline AND through the one-launch policy kernel drive the wide simulator without a rejected
+    action and executor counts above 64 do get drawn (scores of the two paths against each other and against the reference:
+    the decima_e100 fixture above)"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    for E, steps in ((100, 60), (128, 40)):
+        cfg = dict(num_executors=E, job_arrival_cap=10, job_arrival_rate=1.5e-4, moving_delay=2000.0, warmup_delay=1000.0)
+        env = VecSparkSchedSimEnv(cfg, 4, device="cpu", auto_reset=True, _lib=load_emu())
+        torch.manual_seed(E)
+        policy = DecimaPolicy(num_executors=E, **AGENT).eval()
+        gen = torch.Generator().manual_seed(5)
+        env.reset(seed=300)
+        most = 0
+        for t in range(steps):
+            act, aux = policy.schedule_env(env, generator=gen, one_launch=(t % 3 == 2))
+            assert torch.isfinite(aux["lgprob"]).all()
+            most = max(most, int(act["num_exec"].max()))
+            _, _, _, _, info = env.step(act)
+            assert not info["err"].any()
+        assert most > 64, most  # (an empty cluster at the start: the first decisions can hand out nearly all executors)
+        env.close()
 
 
 def test_graph_kernel_lists_and_one_call_encoder():

@@ -45,6 +45,23 @@ def test_trainer_runs_and_checkpoints(tmp_path):
     tr.close()
 
 
+def test_trainer_iteration_at_100_executors(tmp_path):
+    """the trainer with more than 64 executors (wide simulator, executor head over 100 counts): one iteration, parameters move"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd.training import Trainer
+
+    env = dict(num_executors=100, job_arrival_cap=5, job_arrival_rate=1.5e-4, moving_delay=1500.0, warmup_delay=500.0, mean_time_limit=2.0e5)
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), env, dict(TRAIN, num_iterations=1, artifacts_dir=str(tmp_path)), device="cpu", _lib=load_emu())
+    before = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    hist = tr.train(verbose=False)
+    assert len(hist) == 1 and hist[0]["samples"] > 0
+    assert torch.isfinite(torch.tensor([hist[0]["policy loss"], hist[0]["entropy"], hist[0]["approx kl div"]])).all()
+    assert any(not torch.equal(v, before[k]) for k, v in tr.policy.state_dict().items())
+    tr.close()
+
+
 def test_train(tmp_path):
     """the reference's one integration test (reference test/test_train.py:5-7): load the YAML,
     `make_trainer(cfg).train()`, pass if nothing raises - same configuration, on the batched env"""

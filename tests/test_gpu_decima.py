@@ -17,7 +17,7 @@ def test_reference_style_decima_episode_gpu():
     check_reference_style_episode("cuda:0")
 
 
-@pytest.mark.parametrize("name,n_steps", [("decima_c1", 90), ("decima_e50", 90)])
+@pytest.mark.parametrize("name,n_steps", [("decima_c1", 90), ("decima_e50", 90), ("decima_e100", 90)])
 def test_decima_features_and_scores_match_reference_gpu(name, n_steps):
     check_decima_fixture(name, "cuda:0", None, n_steps)
 
@@ -47,7 +47,9 @@ def test_decima_in_the_loop_256_envs():
     (dict(num_executors=3, job_arrival_cap=20, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0), 24, 300),
     (dict(num_executors=12, job_arrival_cap=40, job_arrival_rate=1.0e-4, moving_delay=0.0, warmup_delay=0.0), 24, 300),
     (dict(num_executors=64, job_arrival_cap=60, job_arrival_rate=2.0e-4, moving_delay=2000.0, warmup_delay=1000.0), 24, 300),
-], ids=["c2", "c3", "three_exec", "zero_delays", "sixty_four_exec"])
+    (dict(num_executors=100, job_arrival_cap=60, job_arrival_rate=2.0e-4, moving_delay=2000.0, warmup_delay=1000.0), 24, 300),
+    (dict(num_executors=128, job_arrival_cap=40, job_arrival_rate=3.0e-4, moving_delay=2000.0, warmup_delay=1000.0), 16, 250),
+], ids=["c2", "c3", "three_exec", "zero_delays", "sixty_four_exec", "e100", "e128"])
 def test_simulator_under_decima_actions_matches_oracle(cfg, B, T, pack):
     """the step kernel under the action distribution a GNN policy produces (many executors per
     decision, any stage of any job, ...): envs driven by sampled Decima actions; every env's
@@ -125,9 +127,10 @@ def test_graph_kernel_at_c3_sizing_matches_tensor_ops():
     env.close()
 
 
-@pytest.mark.parametrize("E,J,rate", [(1, 6, 1.0e-4), (2, 12, 1.0e-4), (17, 40, 1.0e-4), (64, 60, 2.0e-4)])
+@pytest.mark.parametrize("E,J,rate", [(1, 6, 1.0e-4), (2, 12, 1.0e-4), (17, 40, 1.0e-4), (64, 60, 2.0e-4), (65, 60, 2.0e-4), (100, 60, 2.0e-4), (128, 60, 3.0e-4)])
 def test_decima_pipeline_at_executor_count_extremes(E, J, rate):
-    """1, 2, 17 and 64 executors: 64 envs stepped by sampled Decima actions for 150 steps without a
+    """1, 2, 17, 64 executors and - two executor counts per lane in the sampling kernels, the simulator's wide
+    instantiation - 65, 100, 128: 64 envs stepped by sampled Decima actions for 150 steps without a
     rejected action (only the reference's own `[step]` stall may appear), the kernel forward equal
     to the tensor-op forward, and the one-launch policy kernel consistent with the pipeline's scores"""
     from decima_util import SCORE_ATOL

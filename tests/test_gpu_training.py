@@ -33,6 +33,29 @@ def test_trainer_two_iterations_gpu(tmp_path):
     tr.close()
 
 
+def test_trainer_iteration_at_100_executors_gpu(tmp_path):
+    """one PPO iteration with more than 64 executors (the reference's Decima is parameterised by num_executors throughout,
+    schedulers/decima/scheduler.py:24,41,326-385): sampled actions on the wide simulator, the executor head over 100 counts,
+    the update; the record made on the device equals the synchronous one at this size too"""
+    from decima_util import AGENT
+    from spark_sched_sim_amd.training import Trainer
+    from training_util import check_record_on_device
+
+    train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=2, num_rollouts=3, seed=7, checkpointing_freq=50,
+                 num_epochs=2, num_batches=4, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3,
+                 opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir=str(tmp_path))
+    env = dict(num_executors=100, job_arrival_cap=12, job_arrival_rate=1.2e-4, moving_delay=2000.0, warmup_delay=1000.0,
+               mean_time_limit=6.0e5)
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), env, train, device="cuda:0")
+    before = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    hist = tr.train(verbose=False)
+    assert len(hist) == 1 and hist[0]["samples"] > 0
+    assert torch.isfinite(torch.tensor([hist[0]["policy loss"], hist[0]["entropy"], hist[0]["approx kl div"]])).all()
+    assert any(not torch.equal(v, before[k]) for k, v in tr.policy.state_dict().items())
+    tr.close()
+    check_record_on_device("cuda:0", None, 6, num_executors=100)
+
+
 def test_train_gpu(tmp_path):
     """reference test/test_train.py:5-7 on the GPU"""
     from spark_sched_sim_amd.training import make_trainer

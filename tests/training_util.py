@@ -217,14 +217,14 @@ def check_rows_ops(binding, device, n):
         rows_op(7, torch.zeros(2, dtype=torch.long, device=device), torch.empty((2, 16), device=device), rnd(4, 16), binding=binding)
 
 
-def check_record_on_device(device, lib, num_envs, tiny_arena=False):
+def check_record_on_device(device, lib, num_envs, tiny_arena=False, num_executors=10):
     """`RolloutCollector(record_on_device=True)` (the step's graph stays on the device and is appended to a `GraphArena` there,
     flags read a few steps late) against `record_on_device=False` (sizes and flags read every step, per-step graphs concatenated
     at the end): same policy parameters, same generator seed -> the same record, array by array, twice in a row (the second
     collection starts from the first one's arena sizes)"""
     import spark_sched_sim_amd.training as T
 
-    cfg = dict(num_executors=10, job_arrival_cap=8, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    cfg = dict(num_executors=num_executors, job_arrival_cap=8, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
     dev = torch.device(device)
     out = {}
     old_init = T.GraphArena.__init__
@@ -239,10 +239,10 @@ def check_record_on_device(device, lib, num_envs, tiny_arena=False):
         for on_dev in (True, False):
             env = VecSparkSchedSimEnv(cfg, num_envs, device=device, auto_reset=False, _lib=lib)
             torch.manual_seed(1)
-            pol = DecimaPolicy(num_executors=10, **AGENT).to(dev)
+            pol = DecimaPolicy(num_executors=num_executors, **AGENT).to(dev)
             gen = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
             gen.manual_seed(99)
-            col = RolloutCollector(env, 5.0e5, list(range(21, 21 + num_envs)), seed_step=num_envs, num_executors=10, policy=pol, generator=gen,
+            col = RolloutCollector(env, 5.0e5, list(range(21, 21 + num_envs)), seed_step=num_envs, num_executors=num_executors, policy=pol, generator=gen,
                                    record_on_device=on_dev)
             out[on_dev] = [col.collect_sync(with_stats=False) for _ in range(2)]
             assert (col._arena_sizes is not None) == on_dev  # (the loop without waits was the one that ran)
