@@ -211,6 +211,50 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
             "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
 
 
+def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
+    """extra, not the headline: one GPU's share of BASELINE config 5 (reference trainers/trainer.py:85-162, trainers/ppo.py:51-138 with
+    config/decima_tpch.yaml's hyper-parameters) - 256 job sequences x 4 rollouts = 1024 envs, 50 executors, 200 jobs: every env
+    runs a whole episode under sampled Decima actions (synchronous collection, the record built on the device), then the PPO
+    epochs run on the recorded compact graph. One warm-up iteration, one timed (the shape of tools/bench_ppo.py)."""
+    import torch
+
+    from spark_sched_sim_amd.training import Trainer
+
+    agent = dict(agent_cls="DecimaScheduler", embed_dim=16, gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(negative_slope=0.2)),
+                 policy_mlp_kwargs=dict(hid_dims=[64, 64], act_cls="Tanh"))
+    train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=sequences, num_rollouts=rollouts, seed=42, checkpointing_freq=10 ** 9, num_epochs=3,
+                 num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4),
+                 max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo_bench")
+    env = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    tr = Trainer(agent, env, train, device=str(dev))
+    rec = None
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.policy.eval()
+        ro = tr.collector.collect_sync(with_stats=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr.policy.train()
+        learn = tr.ppo.train_on_rollouts(ro)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n = int(ro.active.sum())
+        rec = {"envs": sequences * rollouts, "samples": n, "longest_rollout": int(ro.active.shape[0]), "collect_s": t1 - t0, "train_s": t2 - t1,
+               "iteration_s": t2 - t0, "collect_env_steps_per_s": n / (t1 - t0), "graph_nodes": int(ro.graph["x"].shape[0]),
+               **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in learn.items()}}
+        del ro
+    rec["peak_memory_allocated_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
+    rec["peak_memory_reserved_gb"] = torch.cuda.max_memory_reserved(dev) / 1e9
+    rec["what"] = ("one rank's share of BASELINE config 5 (PPO, decima_tpch.yaml): whole episodes of 1024 envs under sampled Decima actions, then 3 epochs x 10 "
+                   "minibatches; second of two iterations")
+    tr.close()
+    torch.cuda.empty_cache()
+    return rec
+
+
 class Bench:
     """one rank's share of one configuration: B envs (optionally in sub-batches on their own streams)"""
 
@@ -439,6 +483,7 @@ def main() -> None:
     ap.add_argument("--fused-chunk", type=int, default=50)
     ap.add_argument("--preroll", type=int, default=None, help="fused steps every env runs before anything is timed (default: a few episodes)")
     ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the extra PPO-iteration record (one rank's share of BASELINE config 5; N=1, c2 only)")
     ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE config 3 record (N=1, --config c2 only)")
     ap.add_argument("--shards", type=int, default=1,
                     help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
@@ -600,6 +645,11 @@ def main() -> None:
                 out["decima_in_loop"] = decima_in_loop(cfg, B, dev, pack)
             except Exception as e:
                 out["decima_in_loop"] = {"error": repr(e)}
+        if world == 1 and not args.no_ppo and args.config == "c2":
+            try:  # SURVEY 8(f) next-3 / BASELINE config 5 at one rank's share; never let it take the bench line down
+                out["ppo_config5_share"] = ppo_config5_share(dev)
+            except Exception as e:
+                out["ppo_config5_share"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

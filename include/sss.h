@@ -542,7 +542,8 @@ int sss_arena_append(const sss_arena_args* a, void* stream);
  *   sss_sequence_baselines   envs g*R .. g*R+R-1 are the rollouts of one job sequence: out[t][b] = mean over the sequence's
  *                            rollouts j of numpy.interp(times[t][b], times[:n_j][j], values[:n_j][j]) (trainers/utils/baselines.py:
  *                            12-37, trainer.py:206-207); n_dev i64[B] = recorded rows per env; skip_empty != 0: rollouts with
- *                            n = 0 are left out of the mean. The arithmetic is numpy's, operation by operation. */
+ *                            n = 0 are left out of the mean. The arithmetic is numpy's, operation by operation - the mean's sum in
+ *                            numpy's pairwise order (sequential below 8 rollouts, eight partial sums from 8 on, halved above 128). */
 typedef struct sss_returns_args {
   int64_t T, B;
   const uint8_t* active_dev;

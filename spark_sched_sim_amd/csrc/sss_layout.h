@@ -13,7 +13,8 @@
 // One lane per executor up to 64 executors: event slots, batch ranking, fast runs, executor-pool set images in registers.
 // 65..128 executors (the reference takes any num_executors, spark_sched_sim.py:37; its level table reaches 100,
 // tpch.py:237-262) run on a second instantiation of the same source compiled with -DSSS_WIDE (csrc/sss_hip_wide.hip):
-// two executors per lane in the queue's pop and the staging loops, every event through the one-at-a-time handlers.
+// two executors per lane - in the queue's pop and the staging loops both, in the lane-parallel event machinery the one whose
+// event comes first (sss_sim.h: lane_event).
 #ifdef SSS_WIDE
 #define SSS_MAX_EXEC 128
 #else
@@ -25,9 +26,10 @@
 #define SSS_JOBSET_SLOTS 2048  // CPython table for <= 1228 distinct small ints
 #define SSS_MAX_LEVELS 16
 // bytes of a scratch set image built from scratch (no dummies) or by set.copy(): <= 63 small ints at any resize fit 256 slots
-// (CPython grows to > 4 * used, copies to > 2 * used); 128 ints: 512 slots
+// (CPython grows to > 4 * used, copies to > 2 * used); 128 ints: 512 slots. The two areas are also where pool tables are staged
+// (pool_pair_*): up to 256 bytes each below 64 executors, up to 1024 bytes (a pool that held all 128 executors) in the wide instantiation
 #ifdef SSS_WIDE
-#define SSS_SET_TABLE 512
+#define SSS_SET_TABLE 1024
 #else
 #define SSS_SET_TABLE 256
 #endif

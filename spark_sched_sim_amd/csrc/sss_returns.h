@@ -6,7 +6,8 @@
 // over the [T, B] record of `RolloutCollector` (row = step, column = env; `active` marks the rows an env recorded: a prefix of its
 // column). As tensor operations these were a Python loop over T (7 441 rows at BASELINE config 5: 0.30 s) and twenty operations on
 // [sequences, R, R, T] tensors (0.25 s) - a fifth of an update. One thread per env (returns: the recurrence is sequential in k,
-// the loads are not) and one per (step, env) query (baselines); the arithmetic is the tensor form's, operation by operation.
+// the loads are not) and one per (step, env) query (baselines); the arithmetic is the tensor form's, operation by operation - the
+// mean over a sequence's rollouts in numpy's own summation order (baseline_pairwise).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -66,17 +67,44 @@ SSS_ANY double baseline_interp(const SssBaselineArgs& a, int64_t col, double x) 
   const double slope = (y1 - y0) / (x1 - x0);
   return slope * (x - x0) + y0;
 }
+// one term of a sequence's mean: rollout j's curve at x (an empty rollout contributes 0 with skip_empty)
+SSS_ANY double baseline_term(const SssBaselineArgs& a, int64_t g0, int j, double x) {
+  const double y = baseline_interp(a, g0 + j, x);
+  return a.skip_empty ? y * (a.n[g0 + j] > 0 ? 1.0 : 0.0) : y;
+}
+// The sum of terms [lo, lo + n) in the order numpy's add.reduce takes over a float64 axis - what `y_hat.mean()` does
+// (baselines.py:33; numpy/core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum): fewer than 8 terms one after the other from
+// 0.0; up to 128 terms eight strided partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail; above that the
+// range is halved (the first half rounded down to a multiple of 8). With fewer than 8 rollouts per sequence (decima_tpch.yaml: 4)
+// this is the plain running sum. Pinned against numpy itself in tests/test_emu_training.py.
+SSS_ANY double baseline_pairwise(const SssBaselineArgs& a, int64_t g0, double x, int lo, int n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; i++) res = res + baseline_term(a, g0, lo + i, x);
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = baseline_term(a, g0, lo + k, x);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; k++) r[k] = r[k] + baseline_term(a, g0, lo + i + k, x);
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + baseline_term(a, g0, lo + i, x);
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return baseline_pairwise(a, g0, x, lo, n2) + baseline_pairwise(a, g0, x, lo + n2, n - n2);
+}
 SSS_ANY void baseline_query(const SssBaselineArgs& a, int64_t t, int64_t b) {
   const int64_t g0 = (b / a.R) * a.R;
   const double x = a.times[t * a.B + b];
-  double acc = 0.0, cnt = 0.0;
-  for (int j = 0; j < a.R; j++) {
-    const double y = baseline_interp(a, g0 + j, x);
-    if (a.skip_empty) {
-      const double has = a.n[g0 + j] > 0 ? 1.0 : 0.0;
-      acc = acc + y * has, cnt = cnt + has;
-    } else
-      acc = acc + y;
+  const double acc = baseline_pairwise(a, g0, x, 0, a.R);
+  double cnt = (double)a.R;
+  if (a.skip_empty) {
+    cnt = 0.0;
+    for (int j = 0; j < a.R; j++) cnt = cnt + (a.n[g0 + j] > 0 ? 1.0 : 0.0);
   }
   const double mean = a.skip_empty ? acc / (cnt < 1.0 ? 1.0 : cnt) : acc / (double)a.R;
   a.out[t * a.B + b] = mean * (a.active[t * a.B + b] ? 1.0 : 0.0);

@@ -20,14 +20,15 @@
 // No oracle code is used here: this is an independent implementation on different data
 // structures (bit masks, flat slot arrays, fixed-capacity set images); tests compare the two.
 #pragma once
-// -DSSS_WIDE: the instantiation for 65..128 executors (csrc/sss_hip_wide.hip, tests/emu/emu_wide.cpp). Two executors per lane
-// where lanes stand for executors outside the event chain (the queue's pop, staging at launch boundaries, episode
-// initialisation); the lane-parallel event machinery - fast runs, event batches, chunked fulfilment, all written for one lane per
-// executor - is compiled out (SSS_NO_BATCH): every event goes through the one-at-a-time handlers, which are the reference's
-// control flow restated and do not care how many executors there are. Same results, by the same parity tests; slower per event.
-#if defined(SSS_WIDE) && !defined(SSS_NO_BATCH)
-#define SSS_NO_BATCH 1
-#endif
+// -DSSS_WIDE: the instantiation for 65..128 executors (csrc/sss_hip_wide.hip, tests/emu/emu_wide.cpp): 128-entry executor arrays,
+// job.local_executors kept as a count, set images of up to 1024 slots, and TWO EXECUTORS PER LANE wherever lanes stand for
+// executors. Outside the event chain (the queue's pop, staging at launch boundaries, episode initialisation) a lane simply handles
+// both. In the lane-parallel event machinery - fast runs, event batches - a lane speaks for the one of its two executors whose
+// pending event comes first (lane_event); the other one's event is an outsider that bounds the window like any event of another
+// kind. That costs window length, never correctness: a window may always be cut short, and the event that cut it is its lane's
+// first event in the next round. The wave-uniform single-event paths, chunked fulfilment and the pair staging take executor ids
+// and list positions, not lanes, and only needed their tables and masks widened. -DSSS_NO_BATCH (either instantiation): every
+// event through the one-at-a-time handlers - the reference's control flow restated - for the byte-identity tests.
 #ifdef SSS_WIDE
 #define SSS_KNAME(name) name##_wide
 #else
@@ -70,6 +71,9 @@ struct alignas(16) SssScratch {
   uint32_t idle_key;
   int32_t idle_valid;
   uint64_t idle_mask;
+#ifdef SSS_WIDE
+  uint64_t idle_mask_hi;          // ... executors 64..127
+#endif
   int32_t jobset_mask, f_need_jobtime;
   // the set image of (old active list + active list) only changes when a job arrives or completes:
   // versions of the two lists it was built from (valid within one launch)
@@ -261,12 +265,62 @@ SSS_DEV int local_count(uint64_t m) { return (int)m; }
 SSS_DEV uint64_t local_with(uint64_t m, int) { return m + 1; }
 SSS_DEV uint64_t local_without(uint64_t m, int) { return m - 1; }
 SSS_DEV bool local_has(uint64_t m, int) { return m != 0; }
+// several lanes at once (event batches); the count lives in the low word and never carries or borrows out of it
+SSS_DEV void local_atomic_attach(SssJob* jp, int) { lane_atomic_add_u32((uint32_t*)&jp->local_mask, 1u); }
+SSS_DEV void local_atomic_detach(SssJob* jp, int) { lane_atomic_add_u32((uint32_t*)&jp->local_mask, 0u - 1u); }
+// a group of executors that leaves a job together (lane 0): gathered one by one, taken off the job's record at once
+struct LocalGroup { uint32_t n; };
+SSS_DEV LocalGroup local_group() { return LocalGroup{0u}; }
+SSS_DEV void local_group_add(LocalGroup& g, int) { g.n++; }
+SSS_DEV void local_group_detach(SssJob* jp, const LocalGroup& g) {
+  CHECK(jp->local_mask >= g.n);
+  jp->local_mask -= g.n;
+}
 #else
 SSS_DEV int local_count(uint64_t m) { return popc64(m); }
 SSS_DEV uint64_t local_with(uint64_t m, int e) { return m | bit64(e); }
 SSS_DEV uint64_t local_without(uint64_t m, int e) { return m & ~bit64(e); }
 SSS_DEV bool local_has(uint64_t m, int e) { return (m & bit64(e)) != 0; }
+SSS_DEV void local_atomic_attach(SssJob* jp, int e) { lane_atomic_or_u64(&jp->local_mask, bit64(e)); }
+SSS_DEV void local_atomic_detach(SssJob* jp, int e) { lane_atomic_and_u64(&jp->local_mask, ~bit64(e)); }
+struct LocalGroup { uint64_t m; };
+SSS_DEV LocalGroup local_group() { return LocalGroup{0ull}; }
+SSS_DEV void local_group_add(LocalGroup& g, int e) { g.m |= bit64(e); }
+SSS_DEV void local_group_detach(SssJob* jp, const LocalGroup& g) {
+  CHECK((jp->local_mask & g.m) == g.m);
+  jp->local_mask &= ~g.m;
+}
 #endif
+
+// ---- executors per lane ----
+// Where lanes stand for executors: one each up to 64 executors; in the wide instantiation lane l holds executors l and l + 64
+// (slots beyond num_executors are empty: t = +inf, EV_NONE).
+#ifdef SSS_WIDE
+#define SSS_EPL 2
+#else
+#define SSS_EPL 1
+#endif
+SSS_DEV int head_lane(int ex) { return ex & 63; }  // the lane that speaks for executor `ex`
+// The pending event a lane speaks for in the lane-parallel event machinery, its executor, and - wide - the time of the lane's
+// OTHER event, which takes no part: it bounds every window like an event of another kind (t_alt = +inf when there is none,
+// and always with one executor per lane).
+struct LaneEvent {
+  SssEvSlot sl;
+  int ex;
+  double t_alt;
+};
+SSS_DEV LaneEvent lane_event(int lane) {
+  LaneEvent le;
+#ifdef SSS_WIDE
+  const SssEvSlot a = g_hot.ev[lane], b = g_hot.ev[lane + 64];
+  const bool b_first = b.t < a.t || (b.t == a.t && b.seq < a.seq);  // heapq's order (EVQ:35); empty slots hold +inf
+  le.sl = b_first ? b : a, le.ex = b_first ? lane + 64 : lane, le.t_alt = b_first ? a.t : b.t;
+#else
+  le.sl = g_hot.ev[lane], le.ex = lane, le.t_alt = __builtin_inf();
+#endif
+  return le;
+}
+SSS_DEV double min_f64(double a, double b) { return b < a ? b : a; }
 
 // ------------------------------------------------------------------------------------------
 // numpy Generator(PCG64) stream (lane 0). Restates numpy/random: SeedSequence, pcg64 XSL-RR,
@@ -752,14 +806,29 @@ SSS_DEV void pool_close(uint32_t key, const SetImg<uint8_t>& s) {
 // instead of dependent HBM ones - and it goes back the same way. pool_stage_in (all lanes) .. lane-0 section
 // on the image it returns .. wave_sync .. pool_stage_out (all lanes). The staging area is setA + setB.
 SSS_DEV uint8_t* pool_table_hbm(uint32_t key) { return g_c.pool_tab + (size_t)pool_index(key) * sss_pool_table_bytes(g_c.E); }
+// one access per lane moves a whole pool table between HBM and LDS: 8 bytes each up to 64 executors (tables of at most 512
+// bytes), 16 bytes in the wide instantiation (at most 1024)
+#ifdef SSS_WIDE
+typedef uint4 tabword_t;
+SSS_DEV tabword_t tabword_zero() { return mk_u4(0u, 0u, 0u, 0u); }
+#else
+typedef uint2 tabword_t;
+SSS_DEV tabword_t tabword_zero() { return mk_u2(0u, 0u); }
+#endif
+SSS_DEV bool tabword_in(int lane) { return (uint32_t)lane * (uint32_t)sizeof(tabword_t) < (uint32_t)sss_pool_table_bytes(g_c.E); }
+// whether two pool tables fit the two staging areas side by side (pool_pair_*): not with exactly 64 executors (512-byte tables
+// against 256-byte areas); the wide instantiation's areas hold its largest table
+#ifdef SSS_WIDE
+SSS_DEV bool pair_staging_fits(int) { return true; }
+#else
+SSS_DEV bool pair_staging_fits(int E) { return E < 64; }
+#endif
 SSS_DEV SetImg<uint8_t> pool_stage_in(uint32_t key) {
   const int lane = wave_lane();
   const uint4 rec = *(const uint4*)(g_c.pool_hdr + pool_index(key));
   const uint32_t bytes = sss_pool_table_bytes(g_c.E);
-#ifndef SSS_WIDE  // (staged images belong to the event batches: not part of the wide instantiation)
-  static_assert(2 * SSS_SET_TABLE <= 64 * 8, "one 8-byte access per lane moves a whole table");
-#endif
-  if ((uint32_t)lane * 8 < bytes) ((uint2*)g_sc.setA)[lane] = ((const uint2*)pool_table_hbm(key))[lane];
+  static_assert(2 * SSS_SET_TABLE >= 64 * sizeof(tabword_t), "a staged table lies in setA (+ setB, which follows it)");
+  if (tabword_in(lane)) ((tabword_t*)g_sc.setA)[lane] = ((const tabword_t*)pool_table_hbm(key))[lane];
   SetImg<uint8_t> s;
   s.mask = rec.x & 0xFFFFu, s.fill = rec.x >> 16, s.used = rec.y & 0xFFFFu, s.finger = 0, s.aux = rec.y >> 16;
   s.big = g_sc.setA, s.big_wide = false, s.small = g_sc.pool8;
@@ -776,7 +845,7 @@ SSS_DEV void pool_stage_out(uint32_t key, const SetImg<uint8_t>& s) {
   const int lane = wave_lane();
   // the whole area goes back, not just the slots in use: the HBM copy then is byte for byte what the
   // one-operation-at-a-time code would have left (it works in place), dead slots included
-  if ((uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E)) ((uint2*)pool_table_hbm(key))[lane] = ((const uint2*)g_sc.setA)[lane];
+  if (tabword_in(lane)) ((tabword_t*)pool_table_hbm(key))[lane] = ((const tabword_t*)g_sc.setA)[lane];
   if (lane == 0) pool_close(key, s);
   wave_sync();
 }
@@ -986,6 +1055,41 @@ SSS_DEV uint32_t trk_peek_commitment(uint32_t src) {
   return dst;
 }
 
+// the same with the whole wave (all lanes, the same arguments on every lane; `on` = false: no hit): the first-inserted live entry of
+// source `src` - among those to the common pool only, with `only_common` - found with one ballot over the list, one entry per lane
+// (two in the wide instantiation: the list has one entry per executor at most). ci = -1: none.
+struct CommitHit {
+  int ci;
+  uint32_t dst;
+  int num;
+};
+SSS_DEV CommitHit commit_first_wave(uint32_t src, bool only_common, bool on, int n_commits) {
+  const int lane = wave_lane();
+  bool mine = on && lane < n_commits && g_hot.c_src[lane] == src && (!only_common || g_hot.c_dst[lane] == POOL_COMMON);
+  uint32_t seq = g_hot.c_seq[lane], dst = g_hot.c_dst[lane];
+  int num = g_hot.c_n[lane], idx = lane;
+#ifdef SSS_WIDE
+  {
+    const int l2 = lane + 64;
+    const bool mine2 = on && l2 < n_commits && g_hot.c_src[l2] == src && (!only_common || g_hot.c_dst[l2] == POOL_COMMON);
+    const uint32_t seq2 = g_hot.c_seq[l2];
+    if (mine2 && (!mine || seq2 < seq)) seq = seq2, dst = g_hot.c_dst[l2], num = g_hot.c_n[l2], idx = l2;
+    mine = mine || mine2;
+  }
+#endif
+  CommitHit h;
+  h.ci = -1, h.dst = POOL_NONE, h.num = 0;
+  const uint64_t cm = wave_ballot(mine);
+  if (cm == 0) return h;
+  int wl = ctz64_nz(cm);
+  if (cm & (cm - 1)) {
+    const uint32_t best = wave_min_u32(mine ? seq : 0xFFFFFFFFu);
+    wl = ctz64_nz(wave_ballot(mine && seq == best));
+  }
+  h.ci = (int)wave_readlane_u32((uint32_t)idx, wl), h.dst = wave_readlane_u32(dst, wl), h.num = (int)wave_readlane_u32((uint32_t)num, wl);
+  return h;
+}
+
 // ---- 8-slot set images held in a register (mask == 7: LINEAR_PROBES never applies, i + 9 > mask) ----
 SSS_DEV uint32_t t8_get(uint64_t t, uint32_t i) { return (uint32_t)(t >> (8 * i)) & 0xFFu; }
 SSS_DEV uint64_t t8_set(uint64_t t, uint32_t i, uint32_t v) { return (t & ~(0xFFull << (8 * i))) | ((uint64_t)v << (8 * i)); }
@@ -1036,20 +1140,20 @@ SSS_DEV bool set8_add(uint64_t& t, uint32_t& fill, uint32_t& used, uint32_t key)
 // pool_pair_flush.
 // ------------------------------------------------------------------------------------------
 struct PoolPairRegs {
-  uint4 rec_a, rec_b;  // the two 16-byte records
-  uint2 tab_a, tab_b;  // this lane's 8 bytes of either table
+  uint4 rec_a, rec_b;      // the two 16-byte records
+  tabword_t tab_a, tab_b;  // this lane's bytes of either table
 };
 SSS_DEV PoolPairRegs pool_pair_fetch(uint32_t key_a, uint32_t key_b, bool has_b) {
   const int lane = wave_lane();
   PoolPairRegs r;
   r.rec_a = *(const uint4*)(g_c.pool_hdr + pool_index(key_a));
   r.rec_b = mk_u4(7u, 0u, 0u, 0u);
-  r.tab_a = mk_u2(0u, 0u), r.tab_b = r.tab_a;
-  const bool in = (uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E);
-  if (in) r.tab_a = ((const uint2*)pool_table_hbm(key_a))[lane];
+  r.tab_a = tabword_zero(), r.tab_b = r.tab_a;
+  const bool in = tabword_in(lane);
+  if (in) r.tab_a = ((const tabword_t*)pool_table_hbm(key_a))[lane];
   if (has_b) {
     r.rec_b = *(const uint4*)(g_c.pool_hdr + pool_index(key_b));
-    if (in) r.tab_b = ((const uint2*)pool_table_hbm(key_b))[lane];
+    if (in) r.tab_b = ((const tabword_t*)pool_table_hbm(key_b))[lane];
   }
   return r;
 }
@@ -1073,10 +1177,10 @@ SSS_DEV PairImg pool_pair_image(const uint4 rec, uint8_t* area, uint8_t* small8)
 // (ends with a barrier: the tables beyond 8 slots are in LDS)
 SSS_DEV void pool_pair_stage(const PoolPairRegs& r, bool has_b, PairImg& a, PairImg& b) {
   const int lane = wave_lane();
-  const bool in = (uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E);
-  if (in) ((uint2*)g_sc.setA)[lane] = r.tab_a;
+  const bool in = tabword_in(lane);
+  if (in) ((tabword_t*)g_sc.setA)[lane] = r.tab_a;
   a = pool_pair_image(r.rec_a, g_sc.setA, g_sc.pool8);
-  if (has_b && in) ((uint2*)g_sc.setB)[lane] = r.tab_b;
+  if (has_b && in) ((tabword_t*)g_sc.setB)[lane] = r.tab_b;
   b = pool_pair_image(r.rec_b, g_sc.setB, g_sc.pool8b);
   wave_sync();
 }
@@ -1111,7 +1215,7 @@ SSS_DEV bool pair_remove(PairImg& p, uint32_t key) {  // set_remove (all lanes)
 }
 // n members leave the pool at once (all lanes): list[from .. to) are their ids. Removals commute - a removal leaves a dummy, no
 // probe chain changes - so on a staged table every member's own lane finds and marks its slot (the table is in LDS: the lanes'
-// probe loops run side by side); an 8-slot image in the register is walked by every lane alike. Fewer than 64 members.
+// probe loops run side by side); an 8-slot image in the register is walked by every lane alike.
 SSS_DEV void pair_remove_many(PairImg& p, const uint8_t* list, int from, int to) {
   const int n = to - from;
   if (p.s.mask == 7) {
@@ -1121,10 +1225,9 @@ SSS_DEV void pair_remove_many(PairImg& p, const uint8_t* list, int from, int to)
     }
     return;
   }
-  const int lane = wave_lane();
-  if (lane < n) {
+  for (int q0 = wave_lane(); q0 < n; q0 += 64) {  // (more than 64 members: the wide instantiation)
     uint8_t* const tab = p.s.big;
-    const uint32_t key = list[from + lane], mask = p.s.mask;
+    const uint32_t key = list[from + q0], mask = p.s.mask;
     uint32_t i = key & mask, perturb = key;
     bool done = false;
     for (int guard = 0; guard < 64 && !done; guard++) {
@@ -1147,8 +1250,8 @@ SSS_DEV void pair_remove_many(PairImg& p, const uint8_t* list, int from, int to)
 // one-operation-at-a-time code leaves, dead slots included.
 SSS_DEV void pool_pair_flush_one(uint32_t key, const PairImg& p) {
   const int lane = wave_lane();
-  if ((p.mask_before != 7 || p.s.mask != 7) && (uint32_t)lane * 8 < (uint32_t)sss_pool_table_bytes(g_c.E))
-    ((uint2*)pool_table_hbm(key))[lane] = ((const uint2*)p.s.big)[lane];
+  if ((p.mask_before != 7 || p.s.mask != 7) && tabword_in(lane))
+    ((tabword_t*)pool_table_hbm(key))[lane] = ((const tabword_t*)p.s.big)[lane];
   if (lane == 0) {
     const uint32_t w0 = p.s.mask | (p.s.fill << 16), w1 = (p.s.used & 0xFFFFu) | (p.s.aux << 16);
     const bool small = p.s.mask == 7;  // (larger tables live in the overflow area; the inline bytes are kept clean)
@@ -1461,12 +1564,13 @@ SSS_DEV void move_idle_executor(uint32_t src, int e) {
 // set(id for id in pool.copy() if not executing) into sc->setB (ENV:714-728)
 // all lanes: which executors sit idle in the source pool (a pool's members are the executors located in it)
 SSS_DEV void publish_idle_mask() {
-#ifdef SSS_WIDE  // (a 64-bit mask of executors: the pool's copy is walked instead, get_idle_source_executors)
-  return;
-#endif
   int lane = wave_lane();
   uint32_t key = g_hot.h.curr_source;
   uint64_t m = wave_ballot(lane < g_c.E && key != POOL_NONE && g_hot.ex_loc[lane] == key && !g_hot.ex_executing[lane]);
+#ifdef SSS_WIDE
+  uint64_t mh = wave_ballot(lane + 64 < g_c.E && key != POOL_NONE && g_hot.ex_loc[lane + 64] == key && !g_hot.ex_executing[lane + 64]);
+  if (lane == 0) g_sc.idle_mask_hi = mh;
+#endif
   if (lane == 0) g_sc.idle_key = key, g_sc.idle_mask = m, g_sc.idle_valid = 1;
 }
 SSS_DEV SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
@@ -1481,21 +1585,29 @@ SSS_DEV SetImg<uint8_t> get_idle_source_executors(uint32_t key) {
     // (one add into a fresh 8-slot table) - the usual case when executors are released one at a time
     uint64_t m = g_sc.idle_mask;
     g_sc.idle_valid = 0;
-    if ((m & (m - 1)) == 0) {
-      if (m) {
-        int e = ctz64(m);
+#ifdef SSS_WIDE
+    const uint64_t mh = g_sc.idle_mask_hi;
+#else
+    const uint64_t mh = 0;
+#endif
+    const uint32_t n_idle = (uint32_t)(popc64(m) + popc64(mh));
+    if (n_idle <= 1) {
+      if (n_idle) {
+        int e = m ? ctz64(m) : 64 + ctz64(mh);
         out.tab[e & 7] = (uint8_t)(e + 2);
         out.fill = out.used = 1;
       }
       return out;
     }
     // 19 or more: whatever order they are added in, the set grows 8 -> 32 (5th key) -> 128 slots (19th key,
-    // set_table_resize(76)), where every executor id sits in its home slot: the image is the same for every order
-    const uint32_t n_idle = (uint32_t)popc64(m);
+    // set_table_resize(76)) - and on to 512 slots with the 77th (set_table_resize(308)) - where every executor id sits in
+    // its home slot: the image is the same for every order
     if (n_idle >= 19) {
-      for (int i = 0; i < 128 / 8; i++) ((uint2*)out.tab)[i] = mk_u2(0u, 0u);
+      const int slots = n_idle >= 77 ? 512 : 128;
+      for (int i = 0; i < slots / 8; i++) ((uint2*)out.tab)[i] = mk_u2(0u, 0u);
       for (uint64_t r = m; r; r &= r - 1) out.tab[ctz64(r)] = (uint8_t)(ctz64(r) + 2);
-      out.mask = 127, out.fill = out.used = n_idle;
+      for (uint64_t r = mh; r; r &= r - 1) out.tab[64 + ctz64(r)] = (uint8_t)(64 + ctz64(r) + 2);
+      out.mask = (uint32_t)slots - 1, out.fill = out.used = n_idle;
       return out;
     }
   }
@@ -1744,7 +1856,7 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
   int4 da = mk_i4(0, 0, 0, 0), db = da;
   bool open = false;
   if (active && type == FI_EXEC && !bad) {
-    n_local = popc64(local) - popc64(m_send_att & below);
+    n_local = local_count(local) - popc64(m_send_att & below);
     if (n_local <= 0 || n_local > g_c.E)
       bad = true;
     else {
@@ -1752,8 +1864,8 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
       open = li != ri;
       const int mode = exts < 0 ? 0 : (exts == s ? 1 : 2);
       const int32_t* eff = g_c.pk.eff;
-      da = *(const int4*)(eff + (((size_t)gs * 8 + li) * 3 + mode) * 4);
-      db = open ? *(const int4*)(eff + (((size_t)gs * 8 + ri) * 3 + mode) * 4) : da;
+      da = *(const int4*)eff_row(eff, gs, li, mode);
+      db = open ? *(const int4*)eff_row(eff, gs, ri, mode) : da;
       bad = (da.y & LENW_LEN) <= 1 || (db.y & LENW_LEN) <= 1;
     }
   }
@@ -1840,7 +1952,9 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
       g_hot.ex_loc[e] = POOL_NONE;
       if (exj >= 0) {
         g_hot.ex_job[e] = -1, g_hot.ex_task_stage[e] = -1;  // JOB:86-89
+#ifndef SSS_WIDE  // (the wide instantiation keeps a count: popc64(m_send_att) below)
         lane_atomic_or_u64(&g_sc.fi_detach, bit64(e));
+#endif
       }
     }
     g_sc.fi_type[idx] = (uint8_t)type;
@@ -1894,7 +2008,11 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
     if (src_job >= 0) {
       const int n_send_all = popc64(m_send);
       if (n_send_all) add_supply(src_job, -n_send_all);
+#ifdef SSS_WIDE
+      if (m_send_att) (*jobp(src_job)).local_mask -= (uint64_t)popc64(m_send_att);
+#else
       if (g_sc.fi_detach) (*jobp(src_job)).local_mask &= ~g_sc.fi_detach;
+#endif
     }
     g_sc.fi_detach = 0;
   }
@@ -1963,8 +2081,6 @@ SSS_DEV bool fulfil_common_wave(int from, int to) {
   // ---- reads ----
   const uint32_t src = g_hot.h.curr_source;
   const int n_commits = g_hot.h.n_commits;
-  const bool c_mine = lane < n_commits && g_hot.c_src[lane] == src && g_hot.c_dst[lane] == POOL_COMMON;
-  const int c_num = g_hot.c_n[lane];
   const int j = key_job(src), s = key_stage(src);
   bool moves = false, is_sat = false;
   SssJob* jp = nullptr;
@@ -1974,13 +2090,13 @@ SSS_DEV bool fulfil_common_wave(int from, int to) {
     moves = s >= 0 || is_sat;                          // ENV:766-769: a job's pool keeps its executors while the job has work
   }
   const uint32_t dstp = is_sat ? POOL_COMMON : key_job_pool(j);
-  const uint64_t cm = wave_ballot(c_mine);
-  if (wave_ballot(!(n > 0 && src != POOL_NONE && g_c.E < 64 && cm != 0 && (cm & (cm - 1)) == 0)) != 0) return false;
-  const int ci = ctz64_nz(cm);
-  const int c_left = (int)wave_readlane_u32((uint32_t)c_num, ci) - n;
+  const CommitHit hit = commit_first_wave(src, true, n > 0 && src != POOL_NONE && pair_staging_fits(g_c.E), n_commits);  // (a source has one entry per destination)
+  if (hit.ci < 0) return false;
+  const int ci = hit.ci;
+  const int c_left = hit.num - n;
   if (wave_ballot(c_left < 0) != 0) return false;
   // ---- from here on the items are consumed ----
-  uint64_t moved_m = 0;
+  LocalGroup moved = local_group();
   if (moves) {
     const PoolPairRegs pr = pool_pair_fetch(src, dstp, true);
     PairImg so, sn;
@@ -1988,7 +2104,7 @@ SSS_DEV bool fulfil_common_wave(int from, int to) {
     pair_remove_many(so, g_sc.fi_e, from, to);  // TRK:188-222, the removals (they commute: every member's own lane)
     for (int i = from; i < to; i++) {  // ... the additions, in item order (wave-uniform: every lane reads the list)
       const uint32_t e = g_sc.fi_e[i];
-      moved_m |= bit64((int)e);
+      local_group_add(moved, (int)e);
       pair_add(sn, e);
     }
     so.s.aux -= (uint32_t)n;  // the source's outgoing commitments (TRK:159-176)
@@ -2019,10 +2135,7 @@ SSS_DEV bool fulfil_common_wave(int from, int to) {
         g_hot.ex_loc[e] = dstp;
         if (dstp == POOL_COMMON) g_hot.ex_job[e] = -1, g_hot.ex_task_stage[e] = -1;  // JOB:86-89
       }
-      if (dstp == POOL_COMMON) {
-        CHECK((jp->local_mask & moved_m) == moved_m);
-        jp->local_mask &= ~moved_m;
-      }
+      if (dstp == POOL_COMMON) local_group_detach(jp, moved);
     }
   }
   wave_sync();
@@ -2424,7 +2537,11 @@ SSS_DEV int fast_run(const FastCtx& f) {
   PROF3_SEC_BEGIN;
   const int lane = wave_lane();
   // ---- everything that is read from shared state is read before the first collective ----
-  SssEvSlot sl = g_hot.ev[lane];  // t = +inf beyond the executors and for executors without an event
+  // this lane's event (t = +inf beyond the executors and for executors without one) and its executor; wide: the earlier of the
+  // lane's two - the other one stops the window like any event of another kind (t_alt)
+  const LaneEvent le = lane_event(lane);
+  SssEvSlot sl = le.sl;
+  const int ex = le.ex;
   const uint32_t counter = g_hot.h.counter;
   uint32_t h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
   int pos = g_sc.rng_pos;
@@ -2433,7 +2550,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
   const uint32_t info = sl.info;
   const uint32_t slot = info_slot(info);
   const int s = info_stage(info);
-  bool elig = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
+  bool elig = ex < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
   int rem = 0, mc = 0, off_l = 0, off_r = 0;
   uint32_t len_l = 1, len_r = 1;
   uint64_t thr = 1ull << 53;
@@ -2443,10 +2560,10 @@ SSS_DEV int fast_run(const FastCtx& f) {
     const SssJob* jp = f.cjobs + slot;
     const uint64_t local = jp->local_mask;
     const int gs = jp->gs_base + s;
-    const int n_local = popc64(local);
+    const int n_local = local_count(local);
     int li, ri;
     executor_interval(n_local, li, ri);
-    SssExDesc xd = f.exdesc[lane];
+    SssExDesc xd = f.exdesc[ex];
     bool xd_new = false;
     if (!(xd.gs == gs && xd.li == li && xd.ri == ri)) exdesc_fetch(f, xd, gs, li, ri), xd_new = true;
     // the level threshold of an open interval rides with the entry (it is a function of the job's executor count alone): one
@@ -2455,7 +2572,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
       const uint64_t t = g_c.pk.lvl_thr[n_local];
       xd.thr_n = (int16_t)n_local, xd.thr_lo = (uint32_t)t, xd.thr_hi = (uint32_t)(t >> 32), xd_new = true;
     }
-    if (xd_new) f.exdesc[lane] = xd;  // an entry is only ever used with its own executor's events
+    if (xd_new) f.exdesc[ex] = xd;  // an entry is only ever used with its own executor's events
     rem = st.remaining, mc = (int)st.moving_to + (int)st.commit_to;
     // lists with one entry draw nothing, empty ones fail, the idle-executor fallback adds warmup_delay
     // (TPCH:88-106): all of those go one at a time
@@ -2471,7 +2588,8 @@ SSS_DEV int fast_run(const FastCtx& f) {
   const uint32_t counter0 = wave_lane0_u32(counter);
   h0 = wave_lane0_u32(h0), u32_0 = wave_lane0_u32(u32_0), pos = (int)wave_lane0_u32((uint32_t)pos);
   // ---- the window and the ranks in it ----
-  double t_stop = f.E <= 16 ? wave_min_f64_nonneg_row0(elig ? __builtin_inf() : sl.t) : wave_min_f64_nonneg(elig ? __builtin_inf() : sl.t);
+  const double t_out = min_f64(elig ? __builtin_inf() : sl.t, le.t_alt);  // what this lane holds that is not part of the run
+  double t_stop = f.E <= 16 ? wave_min_f64_nonneg_row0(t_out) : wave_min_f64_nonneg(t_out);
   {
     const double na = wave_lane0_f64(next_arr_l);
     t_stop = na < t_stop ? na : t_stop;
@@ -2634,7 +2752,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
 #undef SSS_EXP_DUR
   if (total > 0) {
     const bool won = sl.seq != seq0, touched = elig && rem != rem0;  // (push counters only grow)
-    if (won) g_hot.ev[lane].t = sl.t, g_hot.ev[lane].seq = sl.seq;
+    if (won) g_hot.ev[ex].t = sl.t, g_hot.ev[ex].seq = sl.seq;
     SssJob* jp = f.cjobs + (touched ? slot : 0);
     if (touched) {  // (the lanes of one stage hold the same values)
       f.cstages[slot * f.SP + s].remaining = (int16_t)rem;
@@ -2808,7 +2926,9 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   PROF3_SEC_BEGIN;
   const int lane = wave_lane();
   // ---- reads ----
-  const SssEvSlot sl = g_hot.ev[lane];
+  const LaneEvent le = lane_event(lane);  // (wide: the earlier of the lane's two events; the other one bounds the window, t_alt)
+  const SssEvSlot sl = le.sl;
+  const int ex = le.ex, hl = head_lane(head);
   const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
   const int pos = g_sc.rng_pos;
   const int n_commits = g_hot.h.n_commits;
@@ -2816,21 +2936,21 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   const uint32_t info = sl.info;
   const uint32_t slot = info_slot(info);
   const int s = info_stage(info), j = info_job(info);
-  const bool tfc = lane < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
+  const bool tfc = ex < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
   SssStage st_old = {0, 0, 0, 0};
   if (tfc) st_old = f.cstages[slot * f.SP + s];
   // an executor whose departure does not complete its stage (that one changes the frontier: general path).
   // With a source pool set, an executor entering it would become committable (ENV:331-338, TRK:107-113): such a
   // member goes the general way (below). Leaving the source takes one of its commitments along: no change.
   const uint32_t source = g_hot.h.curr_source;
-  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.ex_job[lane] == j;
+  bool cand = tfc && st_old.remaining == 0 && st_old.executing >= 2 && g_hot.ex_job[ex] == j;
   {
-    const double kq = cand ? __builtin_inf() : sl.t;
+    const double kq = min_f64(cand ? __builtin_inf() : sl.t, le.t_alt);
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
     // none or too few (a single one goes the wave-uniform single-event way, lean_released), or not the head
-    if (popc64(pre) < SSS_MIN_RELEASED_BATCH || !((pre >> head) & 1ull)) { STAT(64, 1); return 0; }
+    if (popc64(pre) < SSS_MIN_RELEASED_BATCH || !((pre >> hl) & 1ull)) { STAT(64, 1); return 0; }
   }
   PROF3_SEC(1);
   // the commitment its pool would serve first (TRK:178-183: the first-inserted one of that source)
@@ -2848,7 +2968,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   const bool freed = cand && c_idx < 0;
   cand = cand && (freed || dst != sp);
   // the head of the queue has to be a member: whenever it turns out not to be one, the round is over
-  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(65, 1); return 0; }
+  if (!((wave_ballot(cand) >> hl) & 1ull)) { STAT(65, 1); return 0; }
   PROF3_SEC(2);
   const int j2 = key_job(dst), s2 = key_stage(dst);
   int type = RL_START;
@@ -2872,21 +2992,22 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       cand = st_new.remaining > 0;  // else: backup scheduling (ENV:784-797)
       type = j2 != j ? RL_SEND : ((jp->frontier_mask & bit64(s2)) ? RL_START : RL_PARK);
       if (cand && type == RL_START) {  // TPCH:75-106: the executor's last task was on another stage of the job
-        n_local = popc64(jp->local_mask);
+        n_local = local_count(jp->local_mask);
         executor_interval(n_local, li, ri);
         open = li != ri;
         const int gs2 = jp->gs_base + s2;
-        da = *(const int4*)(f.eff + (((size_t)gs2 * 8 + li) * 3 + 2) * 4);
-        db = open ? *(const int4*)(f.eff + (((size_t)gs2 * 8 + ri) * 3 + 2) * 4) : da;
+        da = *(const int4*)eff_row(f.eff, gs2, li, 2);
+        db = open ? *(const int4*)eff_row(f.eff, gs2, ri, 2) : da;
         cand = n_local > 0 && (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
       }
     }
   }
-  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(66, 1); return 0; }
+  if (!((wave_ballot(cand) >> hl) & 1ull)) { STAT(66, 1); return 0; }
   if (wave_ballot(cand && freed) != 0) {
     // executors idling in a stage's pool would move along with a freed one (ENV:714-728): there are none between events
-    const bool idle_in_stage = lane < f.E && !g_hot.ex_executing[lane] && g_hot.ex_loc[lane] != POOL_NONE && g_hot.ex_loc[lane] != POOL_COMMON &&
-                               key_stage(g_hot.ex_loc[lane]) >= 0;
+    bool idle_in_stage = false;
+    for (int x = lane; x < f.E; x += 64)
+      idle_in_stage = idle_in_stage || (!g_hot.ex_executing[x] && g_hot.ex_loc[x] != POOL_NONE && g_hot.ex_loc[x] != POOL_COMMON && key_stage(g_hot.ex_loc[x]) >= 0);
     if (wave_ballot(idle_in_stage) != 0 || any_schedulable_without_source()) cand = cand && !freed;
   }
   const bool start = type == RL_START, pusher = type == RL_START || type == RL_SEND;
@@ -2896,11 +3017,11 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // the pool the member enters
   const uint32_t enters = start ? dst : (type == RL_SEND ? POOL_NONE : ((type == RL_IDLE_COMMON || type == RL_FREE_COMMON) ? POOL_COMMON : key_job_pool(j)));
   cand = cand && (freed || source == POOL_NONE || enters != source);
-  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(67, 1); return 0; }
+  if (!((wave_ballot(cand) >> hl) & 1ull)) { STAT(67, 1); return 0; }
   PROF3_SEC(3);
   // when the event a member pushes can come at the earliest
   const double push_lb = start ? (double)(da.z < db.z ? da.z : db.z) : (type == RL_SEND ? g_c.P.moving_delay : __builtin_inf());
-  const double key = cand ? sl.t + push_lb : sl.t;
+  const double key = min_f64(cand ? sl.t + push_lb : sl.t, le.t_alt);
   double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
@@ -2987,7 +3108,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   if (V) {
     SssJob* jp = f.cjobs + slot;
     lane_atomic_add_u32((uint32_t*)(f.cstages + slot * f.SP + s), 0u - (1u << 16));  // executing-- (STG:60-62)
-    g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = (uint8_t)type;
+    g_sc.fi_e[rank] = (uint8_t)ex, g_sc.fi_type[rank] = (uint8_t)type;
     g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = freed ? (uint8_t)RL_NO_COMMITMENT : (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best;
     g_sc.fc_dst[rank] = enters;
     if (start) {
@@ -2995,34 +3116,34 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       if (dd.y >> 30) dur += g_c.P.warmup_delay;
       lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - 1u);          // commitments to the new stage: one fewer (TRK:159-176)
       lane_atomic_add_u32((uint32_t*)sp_new, (1u << 16) - 1u);      // remaining--, executing++ (STG:53-58)
-      g_hot.ev[lane].t = sl.t + dur;
-      g_hot.ev[lane].seq = counter0 + rank_p;
-      g_hot.ev[lane].info = ev_info(EV_TASK_FINISHED, j, s2, slot);
-      g_hot.ex_task_stage[lane] = (int8_t)s2, g_hot.ex_loc[lane] = dst;
+      g_hot.ev[ex].t = sl.t + dur;
+      g_hot.ev[ex].seq = counter0 + rank_p;
+      g_hot.ev[ex].info = ev_info(EV_TASK_FINISHED, j, s2, slot);
+      g_hot.ex_task_stage[ex] = (int8_t)s2, g_hot.ex_loc[ex] = dst;
       if (cb_take + 1 == ct_take) {  // the new stage's last starter of the batch
         f.cdur[slot * f.SP + s2] = (float)dur;
         if ((int)st_new.remaining - (int)ct_take == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
       }
     } else if (type == RL_SEND) {
       lane_atomic_add_u32((uint32_t*)sp_new + 1, 0xFFFFu);           // commit_to--, moving_to++ (the borrow of the low half is the carry into the high one)
-      g_hot.ev[lane].t = sl.t + g_c.P.moving_delay;
-      g_hot.ev[lane].seq = counter0 + rank_p;
-      g_hot.ev[lane].info = ev_info(EV_EXECUTOR_READY, j2, s2, (uint32_t)lds_slot_of()[j2]);
-      g_hot.ex_executing[lane] = 0, g_hot.ex_loc[lane] = POOL_NONE;
+      g_hot.ev[ex].t = sl.t + g_c.P.moving_delay;
+      g_hot.ev[ex].seq = counter0 + rank_p;
+      g_hot.ev[ex].info = ev_info(EV_EXECUTOR_READY, j2, s2, (uint32_t)lds_slot_of()[j2]);
+      g_hot.ex_executing[ex] = 0, g_hot.ex_loc[ex] = POOL_NONE;
       lane_atomic_add_u32((uint32_t*)&jp->supply, 0u - 1u);          // the old job's executor count (TRK:218-221)
     } else {
       if (type == RL_PARK) {
         lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - 1u);
-        g_hot.ex_task_stage[lane] = -1;  // ENV:808-813
+        g_hot.ex_task_stage[ex] = -1;  // ENV:808-813
       }
-      g_hot.ev[lane].t = __builtin_inf();
-      g_hot.ev[lane].info = EV_NONE;
-      if (freed) g_hot.ex_task_stage[lane] = -1;  // executor.task = None (ENV:655-656)
-      g_hot.ex_executing[lane] = 0, g_hot.ex_loc[lane] = enters;
+      g_hot.ev[ex].t = __builtin_inf();
+      g_hot.ev[ex].info = EV_NONE;
+      if (freed) g_hot.ex_task_stage[ex] = -1;  // executor.task = None (ENV:655-656)
+      g_hot.ex_executing[ex] = 0, g_hot.ex_loc[ex] = enters;
     }
     if (detach) {  // JOB:86-89
-      lane_atomic_and_u64(&jp->local_mask, ~bit64(lane));
-      g_hot.ex_job[lane] = -1, g_hot.ex_task_stage[lane] = -1;
+      local_atomic_detach(jp, ex);
+      g_hot.ex_job[ex] = -1, g_hot.ex_task_stage[ex] = -1;
     }
     if (rank == n - 1) {
       SssHdr& h = g_hot.h;
@@ -3045,13 +3166,13 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // The usual batch: executors of ONE stage that finish close together - they leave the same pool, take the same commitment
   // (the pool's first-inserted one) and go the same way. One entry of the commitment list shrinks by n, the two pool images
   // come in with one round trip (pool_pair_*: n removals, n additions in rank order), the cache-slot references move in one go.
-  const uint32_t sp_h = wave_readlane_u32(sp, head), en_h = wave_readlane_u32(enters, head);
-  const int type_h = (int)wave_readlane_u32((uint32_t)type, head);
-  const bool uniform = f.E >= SSS_PAIR_MIN_E && f.E < 64 && wave_ballot(V && (sp != sp_h || enters != en_h || type != type_h)) == 0;
+  const uint32_t sp_h = wave_readlane_u32(sp, hl), en_h = wave_readlane_u32(enters, hl);
+  const int type_h = (int)wave_readlane_u32((uint32_t)type, hl);
+  const bool uniform = f.E >= SSS_PAIR_MIN_E && pair_staging_fits(f.E) && wave_ballot(V && (sp != sp_h || enters != en_h || type != type_h)) == 0;
   if (uniform) {
-    const bool freed_h = wave_readlane_u32(freed ? 1u : 0u, head) != 0;
-    const int ci_h = (int)wave_readlane_u32((uint32_t)c_idx, head);
-    const uint32_t slot_h = wave_readlane_u32(slot, head);
+    const bool freed_h = wave_readlane_u32(freed ? 1u : 0u, hl) != 0;
+    const int ci_h = (int)wave_readlane_u32((uint32_t)c_idx, hl);
+    const uint32_t slot_h = wave_readlane_u32(slot, hl);
     const PoolPairRegs pr = pool_pair_fetch(sp_h, en_h, en_h != POOL_NONE);
     if (lane == 0) {
       if (!freed_h) {  // TRK:159-176, n times: dict.pop when the entry is used up (swap-remove, the order lives in c_seq)
@@ -3123,7 +3244,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // member before it (in rank) shares that pool.
   bool deferred = false;
   if (V) {
-    pool_leave_table(sp, (uint32_t)lane);
+    pool_leave_table(sp, (uint32_t)ex);
     if (cb_old == 0) pool_leave_many(sp, n);
     const uint32_t nkey = g_sc.fc_dst[rank];
     bool lead = nkey != POOL_NONE;
@@ -3231,7 +3352,9 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   PROF3_SEC_BEGIN;
   const int lane = wave_lane();
   // ---- reads ----
-  const SssEvSlot sl = g_hot.ev[lane];
+  const LaneEvent le = lane_event(lane);  // (wide: the earlier of the lane's two events; the other one bounds the window, t_alt)
+  const SssEvSlot sl = le.sl;
+  const int ex = le.ex, hl = head_lane(head);
   const uint32_t counter0 = g_hot.h.counter, h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
   const int pos = g_sc.rng_pos;
   const double next_arr = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
@@ -3239,13 +3362,13 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   const uint32_t slot = info_slot(info);
   const int s = info_stage(info), j = info_job(info);
   const uint32_t source = g_hot.h.curr_source;
-  bool cand = lane < f.E && info_kind(info) == EV_EXECUTOR_READY && slot != INFO_SLOT_NONE;
+  bool cand = ex < f.E && info_kind(info) == EV_EXECUTOR_READY && slot != INFO_SLOT_NONE;
   {
-    const double kq = cand ? __builtin_inf() : sl.t;
+    const double kq = min_f64(cand ? __builtin_inf() : sl.t, le.t_alt);
     const double t_other = f.E <= 16 ? wave_min_f64_nonneg_row0(kq) : wave_min_f64_nonneg(kq);
     const double t_stop = next_arr < t_other ? next_arr : t_other;
     const uint64_t pre = wave_ballot(cand && sl.t < t_stop);
-    if (popc64(pre) < SSS_MIN_ARRIVAL_BATCH || !((pre >> head) & 1ull)) { STAT(80, 1); return 0; }  // none, too few (lean_arrival), or not the head
+    if (popc64(pre) < SSS_MIN_ARRIVAL_BATCH || !((pre >> hl) & 1ull)) { STAT(80, 1); return 0; }  // none, too few (lean_arrival), or not the head
   }
   PROF3_ASEC(1);
   SssStage st = {0, 0, 0, 0};
@@ -3255,16 +3378,16 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   if (cand) {
     st = f.cstages[slot * f.SP + s];
     gs = jpc->gs_base + s;
-    n_base = popc64(jpc->local_mask);
+    n_base = local_count(jpc->local_mask);
     type = (jpc->frontier_mask & bit64(s)) ? AR_START : AR_PARK;
     // with a source pool set, an executor that stays in it would become committable (ENV:331-338): general path
     cand = st.remaining > 0 && st.moving_to > 0 && (source == POOL_NONE || source != (type == AR_START ? key_stage_pool(j, s) : key_job_pool(j)));
     if (type == AR_START) push_lb = (double)f.eff[(((size_t)gs * 8 + 0) * 3 + 0) * 4 + 3];
   }
   const bool start = type == AR_START;
-  if (!((wave_ballot(cand) >> head) & 1ull)) { STAT(81, 1); return 0; }  // the head of the queue has to be a member
+  if (!((wave_ballot(cand) >> hl) & 1ull)) { STAT(81, 1); return 0; }  // the head of the queue has to be a member
   PROF3_ASEC(2);
-  const double key = cand ? sl.t + push_lb : sl.t;
+  const double key = min_f64(cand ? sl.t + push_lb : sl.t, le.t_alt);
   double M = f.E <= 16 ? wave_min_f64_nonneg_row0(key) : wave_min_f64_nonneg(key);
   if (next_arr < M) M = next_arr;
   bool V = cand && sl.t < M;
@@ -3292,8 +3415,8 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   int4 da = mk_i4(0, 0, 0, 0), db = da;
   bool drawable = true;
   if (V && start) {
-    da = *(const int4*)(f.eff + (((size_t)gs * 8 + li) * 3 + 0) * 4);
-    db = open ? *(const int4*)(f.eff + (((size_t)gs * 8 + ri) * 3 + 0) * 4) : da;
+    da = *(const int4*)eff_row(f.eff, gs, li, 0);
+    db = open ? *(const int4*)eff_row(f.eff, gs, ri, 0) : da;
     drawable = n_local <= f.E && (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
   }
   const uint32_t nmax = (uint32_t)(64 - pos) >> 1;
@@ -3350,28 +3473,28 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   if (V) {
     SssJob* jp = f.cjobs + slot;
     SssStage* stp = f.cstages + slot * f.SP + s;
-    lane_atomic_or_u64(&jp->local_mask, bit64(lane));  // JOB:81-84
-    g_hot.ex_job[lane] = (int16_t)j;
+    local_atomic_attach(jp, ex);  // JOB:81-84
+    g_hot.ex_job[ex] = (int16_t)j;
     lane_atomic_add_u32((uint32_t*)stp + 1, 0u - (1u << 16));  // moving_to-- (TRK:185-187)
-    g_sc.fi_e[rank] = (uint8_t)lane, g_sc.fi_type[rank] = (uint8_t)type;
+    g_sc.fi_e[rank] = (uint8_t)ex, g_sc.fi_type[rank] = (uint8_t)type;
     g_sc.rl_old[rank] = jkey;
     g_sc.fc_dst[rank] = start ? skey : POOL_NONE;  // the pool it enters after the job's
     if (start) {
       double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
       if (dd.y >> 30) dur += g_c.P.warmup_delay;
       lane_atomic_add_u32((uint32_t*)stp, (1u << 16) - 1u);  // remaining--, executing++ (STG:53-58)
-      g_hot.ev[lane].t = sl.t + dur;
-      g_hot.ev[lane].seq = counter0 + rank_x;
-      g_hot.ev[lane].info = ev_info(EV_TASK_FINISHED, j, s, slot);
-      g_hot.ex_task_stage[lane] = (int8_t)s, g_hot.ex_executing[lane] = 1, g_hot.ex_loc[lane] = skey;
+      g_hot.ev[ex].t = sl.t + dur;
+      g_hot.ev[ex].seq = counter0 + rank_x;
+      g_hot.ev[ex].info = ev_info(EV_TASK_FINISHED, j, s, slot);
+      g_hot.ex_task_stage[ex] = (int8_t)s, g_hot.ex_executing[ex] = 1, g_hot.ex_loc[ex] = skey;
       if (cb_take + 1 == ct_take) {  // the stage's last starter of the batch
         f.cdur[slot * f.SP + s] = (float)dur;
         if ((int)st.remaining - (int)ct_take == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
       }
     } else {
-      g_hot.ev[lane].t = __builtin_inf();
-      g_hot.ev[lane].info = EV_NONE;
-      g_hot.ex_task_stage[lane] = -1, g_hot.ex_loc[lane] = jkey;
+      g_hot.ev[ex].t = __builtin_inf();
+      g_hot.ev[ex].info = EV_NONE;
+      g_hot.ex_task_stage[ex] = -1, g_hot.ex_loc[ex] = jkey;
     }
     if (rank == n - 1) {
       SssHdr& h = g_hot.h;
@@ -3393,7 +3516,7 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
   bool def_job = false, def_stage = false;
   // every member arrives at the same stage (executors of one fulfilment; a single member): the job's pool and the stage's are
   // the only two images involved - both through the pair staging, one HBM round trip for the batch (fewer than 64 executors)
-  const bool one_stage = f.E >= SSS_PAIR_MIN_E && f.E < 64 && wave_ballot(V && same_stage != vm) == 0;
+  const bool one_stage = f.E >= SSS_PAIR_MIN_E && pair_staging_fits(f.E) && wave_ballot(V && same_stage != vm) == 0;
   if (one_stage) {
     const int l0 = ctz64_nz(vm);
     const uint32_t jk = wave_readlane_u32(jkey, l0), sk = wave_readlane_u32(skey, l0);
@@ -3486,21 +3609,14 @@ SSS_DEV int lean_released(const FastCtx& f, int ex, double t_ev, uint32_t info) 
   const uint32_t counter0 = g_hot.h.counter;
   uint32_t h0 = g_hot.h.rng_has32, u32_0 = g_hot.h.rng_u32;
   const uint32_t sp = key_stage_pool(j, s);
-  const bool mine = st_old.remaining == 0 && st_old.executing >= 2 && g_hot.ex_job[ex] == j && f.E < 64;  // (64 executors: two 512-byte tables)
-  const bool c_mine = mine && lane < n_commits && g_hot.c_src[lane] == sp;
-  const uint32_t c_seq = g_hot.c_seq[lane], c_dst = g_hot.c_dst[lane];
-  const int c_num = g_hot.c_n[lane];
+  const bool mine = st_old.remaining == 0 && st_old.executing >= 2 && g_hot.ex_job[ex] == j && pair_staging_fits(f.E);  // (64 executors: two 512-byte tables)
   // the commitment its pool serves first (TRK:178-183: the first-inserted entry of that source)
-  const uint64_t cm = wave_ballot(c_mine);
-  STAT(120, 1), STAT(121, cm == 0);
-  if (cm == 0) return 0;
-  int ci = ctz64_nz(cm);
-  if (cm & (cm - 1)) {
-    const uint32_t best = wave_min_u32(c_mine ? c_seq : 0xFFFFFFFFu);
-    ci = ctz64_nz(wave_ballot(c_mine && c_seq == best));
-  }
-  const uint32_t dst = wave_readlane_u32(c_dst, ci);
-  const int c_left = (int)wave_readlane_u32((uint32_t)c_num, ci) - 1;
+  const CommitHit hit = commit_first_wave(sp, false, mine, n_commits);
+  STAT(120, 1), STAT(121, hit.ci < 0);
+  if (hit.ci < 0) return 0;
+  const int ci = hit.ci;
+  const uint32_t dst = hit.dst;
+  const int c_left = hit.num - 1;
   SssJob* const jp = f.cjobs + slot;
   const bool job_sat = (int)jp->sat_count == (int)jp->n_stages;  // JOB:53-55
   const int j2 = key_job(dst), s2 = key_stage(dst);  // the stage the commitment names (-1, -1: the common pool)
@@ -3566,13 +3682,13 @@ SSS_DEV int lean_released(const FastCtx& f, int ex, double t_ev, uint32_t info) 
   int n_local = 0, li = 0, ri = 0;
   int4 da = mk_i4(0, 0, 0, 0), db = da;
   if (start) {  // TPCH:75-106: the executor's last task was on another stage of the job ("first_wave" mode)
-    n_local = popc64(jp->local_mask);
+    n_local = local_count(jp->local_mask);
     ok = n_local > 0 && n_local <= f.E && ts != s;
     if (ok) {
       executor_interval(n_local, li, ri);
       const int gs2 = jp->gs_base + ts;
-      da = *(const int4*)(f.eff + (((size_t)gs2 * 8 + li) * 3 + 2) * 4);
-      db = li != ri ? *(const int4*)(f.eff + (((size_t)gs2 * 8 + ri) * 3 + 2) * 4) : da;
+      da = *(const int4*)eff_row(f.eff, gs2, li, 2);
+      db = li != ri ? *(const int4*)eff_row(f.eff, gs2, ri, 2) : da;
       ok = (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;  // lists that draw nothing / fail: one at a time
     }
   }
@@ -3674,7 +3790,7 @@ SSS_DEV int lean_released(const FastCtx& f, int ex, double t_ev, uint32_t info) 
     if (type == RL_START) g_hot.ex_task_stage[ex] = (int8_t)ts;
     if (type == RL_PARK) g_hot.ex_task_stage[ex] = -1;  // ENV:808-813
     if (type == RL_SEND || type == RL_IDLE_COMMON) {      // JOB:86-89
-      jp->local_mask &= ~bit64(ex);
+      jp->local_mask = local_without(jp->local_mask, ex);
       g_hot.ex_job[ex] = -1, g_hot.ex_task_stage[ex] = -1;
     }
     // its event slot and the cache-slot references of the events' jobs
@@ -3725,8 +3841,8 @@ SSS_DEV int lean_arrival(const FastCtx& f, int ex, double t_ev, uint32_t info) {
   const uint32_t jkey = key_job_pool(j), skey = key_stage_pool(j, s);
   const PoolPairRegs pr = pool_pair_fetch(jkey, skey, start);  // (asked for right away: its round trip overlaps the descriptors')
   // with a source pool set, an executor that stays in it would become committable (ENV:331-338): general path
-  bool ok = f.E < 64 && st.remaining > 0 && st.moving_to > 0 && g_hot.ex_task_stage[ex] < 0 && (source == POOL_NONE || source != (start ? skey : jkey));
-  const int n_local = popc64(local) + 1;  // JOB:81-84: the executor is attached before it draws
+  bool ok = pair_staging_fits(f.E) && st.remaining > 0 && st.moving_to > 0 && g_hot.ex_task_stage[ex] < 0 && (source == POOL_NONE || source != (start ? skey : jkey));
+  const int n_local = local_count(local) + 1;  // JOB:81-84: the executor is attached before it draws
   int li = 0, ri = 0;
   int4 da = mk_i4(0, 0, 0, 0), db = da;
   if (ok && start) {
@@ -3734,8 +3850,8 @@ SSS_DEV int lean_arrival(const FastCtx& f, int ex, double t_ev, uint32_t info) {
     if (ok) {
       executor_interval(n_local, li, ri);
       const int gs = jp->gs_base + s;
-      da = *(const int4*)(f.eff + (((size_t)gs * 8 + li) * 3 + 0) * 4);
-      db = li != ri ? *(const int4*)(f.eff + (((size_t)gs * 8 + ri) * 3 + 0) * 4) : da;
+      da = *(const int4*)eff_row(f.eff, gs, li, 0);
+      db = li != ri ? *(const int4*)eff_row(f.eff, gs, ri, 0) : da;
       ok = (da.y & LENW_LEN) > 1 && (db.y & LENW_LEN) > 1;
     }
   }
@@ -3786,7 +3902,7 @@ SSS_DEV int lean_arrival(const FastCtx& f, int ex, double t_ev, uint32_t info) {
     h.wall_time = t_ev;
     h.n_events += 1, h.n_batched += 1, h.n_rounds += 1;
     g_sc.events_this_step += 1;
-    jp->local_mask = local | bit64(ex);  // JOB:81-84
+    jp->local_mask = local_with(local, ex);  // JOB:81-84
     g_hot.ex_job[ex] = (int16_t)j;
     SssStage t2 = st;
     t2.moving_to = (int16_t)(t2.moving_to - 1);  // TRK:185-187
@@ -3834,7 +3950,7 @@ SSS_DEV void preflush_completing_job(const FastCtx& f, uint32_t info) {
   const int s = info_stage(info), j = info_job(info);
   const SssStage st = f.cstages[slot * f.SP + s];
   const SssJob* jp = f.cjobs + slot;
-  const bool completes = st.remaining == 0 && st.executing == 1 && jp->active_mask == bit64(s) && (int)jp->sat_count == (int)jp->n_stages && f.E < 64;
+  const bool completes = st.remaining == 0 && st.executing == 1 && jp->active_mask == bit64(s) && (int)jp->sat_count == (int)jp->n_stages && pair_staging_fits(f.E);
   if (wave_ballot(completes) == 0) return;
   PROF3(40);
   const uint32_t jkey = key_job_pool(j);
@@ -3853,11 +3969,11 @@ SSS_DEV void preflush_completing_job(const FastCtx& f, uint32_t info) {
   const PoolPairRegs pr = pool_pair_fetch(jkey, POOL_COMMON, true);
   PairImg so, sn;
   pool_pair_stage(pr, true, so, sn);
-  uint64_t moved_m = 0;
+  LocalGroup moved = local_group();
   pair_remove_many(so, g_sc.fi_e, 0, m);
   for (int i = 0; i < m; i++) {
     const uint32_t e = g_sc.fi_e[i];
-    moved_m |= bit64((int)e);
+    local_group_add(moved, (int)e);
     pair_add(sn, e);
   }
   wave_sync();
@@ -3865,8 +3981,7 @@ SSS_DEV void preflush_completing_job(const FastCtx& f, uint32_t info) {
   pool_pair_flush_one(POOL_COMMON, sn);
   if (lane == 0) {
     SssJob* jw = f.cjobs + slot;
-    CHECK((jw->local_mask & moved_m) == moved_m);
-    jw->local_mask &= ~moved_m;  // JOB:86-89
+    local_group_detach(jw, moved);  // JOB:86-89
     for (int i = 0; i < m; i++) {
       const int e = g_sc.fi_e[i];
       g_hot.ex_loc[e] = POOL_COMMON, g_hot.ex_job[e] = -1, g_hot.ex_task_stage[e] = -1;
@@ -4077,57 +4192,59 @@ SSS_DEV void env_begin(const uint8_t* base) {
   wave_sync();
   int A = g_hot.h.n_active;
   for (int i = lane; i < A; i += 64) lds_active()[i] = g_c.active_g[i];
-#ifdef SSS_WIDE
-  // the jobs of the pending events get the cache slots, in executor order (lane 0: cache_acquire brings the records in)
-  if (lane == 0) {
-    g_sc.free_slots = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
-    g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
-    g_sc.events_this_step = 0;
-    g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
-    g_sc.rng_pos = 64;
-    for (int x = 0; x < g_c.E; x++) {
-      const uint32_t info = g_hot.ev[x].info;
-      if (info_kind(info) == EV_NONE) continue;
-      const int k = cache_acquire(info_job(info));
-      if (k == SLOT_NONE) continue;
-      lds_slot_ref()[k]++;
-      g_hot.ev[x].info = info_with_slot(info, (uint32_t)k);
-    }
-  }
-  wave_sync();
-  return;
-#endif
   {
     // The jobs of the pending events get the cache slots - the jobs with the most pending events first (ties: lowest
     // executor), so that a burst of executors travelling to one job, or many executors working on one job, never
-    // finds its job without a slot because single events of other jobs were met first. One lane per executor:
-    // same[job] counts and the "first executor of its job" flag come from a readlane sweep over the executors, the
-    // rank of a job among the jobs from a second sweep. The events learn the slot their job got for this launch.
-    const uint32_t info = g_hot.ev[lane].info;  // lanes beyond the executors hold EV_NONE
-    const bool has = info_kind(info) != EV_NONE;
-    const int j = has ? info_job(info) : -1 - lane;
+    // finds its job without a slot because single events of other jobs were met first. One lane per executor (two
+    // executors per lane in the wide instantiation: x = lane + 64 h): same[job] counts and the "first executor of its
+    // job" flag come from a readlane sweep over the executors, the rank of a job among the jobs from a second sweep.
+    // The events learn the slot their job got for this launch.
+    uint32_t info[SSS_EPL], cnt[SSS_EPL], key[SSS_EPL], rank[SSS_EPL];
+    bool has[SSS_EPL], first[SSS_EPL];
+    int j[SSS_EPL];
+    uint64_t m[SSS_EPL];
+    for (int h = 0; h < SSS_EPL; h++) {
+      const int x = lane + 64 * h;
+      info[h] = g_hot.ev[x].info;  // slots beyond the executors hold EV_NONE
+      has[h] = info_kind(info[h]) != EV_NONE;
+      j[h] = has[h] ? info_job(info[h]) : -1 - x;
+      cnt[h] = 0, first[h] = false, rank[h] = 0;
+      m[h] = wave_ballot(has[h]);
+    }
     // (one pass per DISTINCT job with an event, not per executor: at 50 executors a third of the iterations)
-    uint32_t cnt = 0;
-    bool first = false;
-    for (uint64_t m = wave_ballot(has); m;) {
-      const int l = ctz64_nz(m);
-      const int jl = (int)wave_readlane_u32((uint32_t)j, l);
-      const uint64_t same = wave_ballot(has && j == jl);
-      if (has && j == jl) cnt = (uint32_t)popc64(same), first = lane == l;  // (l is the lowest executor of its job)
-      m &= ~same;
+    for (;;) {
+      int h0 = -1, l = 0, jl = 0;  // the lowest executor that is still to be counted: l + 64 h0 (it is the lowest executor of its job)
+      for (int h = SSS_EPL - 1; h >= 0; h--)  // (constant indices once unrolled: the arrays stay in registers)
+        if (m[h]) h0 = h, l = ctz64_nz(m[h]), jl = (int)wave_readlane_u32((uint32_t)j[h], l);
+      if (h0 < 0) break;
+      uint64_t same[SSS_EPL];
+      uint32_t total = 0;
+      for (int h = 0; h < SSS_EPL; h++) same[h] = wave_ballot(has[h] && j[h] == jl), total += (uint32_t)popc64(same[h]);
+      for (int h = 0; h < SSS_EPL; h++) {
+        if (has[h] && j[h] == jl) cnt[h] = total, first[h] = h == h0 && lane == l;
+        m[h] &= ~same[h];
+      }
     }
-    const uint32_t key = first ? ((cnt << 8) | (uint32_t)(63 - lane)) : 0u;  // more events first, then the lower executor
-    uint32_t rank = 0;
-    for (uint64_t m = wave_ballot(first); m; m &= m - 1) rank += wave_readlane_u32(key, ctz64_nz(m)) > key ? 1u : 0u;
-    const int nK = (int)popc64(wave_ballot(first));
+    int nK = 0;
+    for (int h = 0; h < SSS_EPL; h++) {
+      key[h] = first[h] ? ((cnt[h] << 8) | (uint32_t)(64 * SSS_EPL - 1 - (lane + 64 * h))) : 0u;  // more events first, then the lower executor
+      nK += popc64(wave_ballot(first[h]));
+    }
+    for (int h2 = 0; h2 < SSS_EPL; h2++)
+      for (uint64_t fm = wave_ballot(first[h2]); fm; fm &= fm - 1) {
+        const uint32_t kq = wave_readlane_u32(key[h2], ctz64_nz(fm));
+        for (int h = 0; h < SSS_EPL; h++) rank[h] += kq > key[h] ? 1u : 0u;
+      }
     const int n_used = nK < g_c.P.n_slots ? nK : g_c.P.n_slots;
-    if (first && (int)rank < g_c.P.n_slots) {
-      lds_slot_of()[j] = (uint8_t)rank;
-      lds_slot_job()[rank] = (uint16_t)j;
-      lds_slot_ref()[rank] = (uint8_t)cnt;
-    }
+    for (int h = 0; h < SSS_EPL; h++)
+      if (first[h] && (int)rank[h] < g_c.P.n_slots) {
+        lds_slot_of()[j[h]] = (uint8_t)rank[h];
+        lds_slot_job()[rank[h]] = (uint16_t)j[h];
+        lds_slot_ref()[rank[h]] = (uint8_t)cnt[h];
+      }
     wave_sync();
-    if (has) g_hot.ev[lane].info = info_with_slot(info, (uint32_t)lds_slot_of()[j]);
+    for (int h = 0; h < SSS_EPL; h++)
+      if (has[h]) g_hot.ev[lane + 64 * h].info = info_with_slot(info[h], (uint32_t)lds_slot_of()[j[h]]);
     if (lane == 0) {
       uint64_t all = g_c.P.n_slots >= 64 ? ~0ull : (bit64(g_c.P.n_slots) - 1);
       uint64_t used = n_used >= 64 ? ~0ull : (bit64(n_used) - 1);

@@ -182,6 +182,17 @@ def bit_lists(bits: torch.Tensor, n_layers: int, binding=None) -> list[torch.Ten
     return [out[base[l]: base[l] + sizes[l]] for l in range(n_layers)]
 
 
+def edges_grouped_by_source(g: dict[str, Any]) -> bool:
+    """whether `src` is non-decreasing, i.e. every node's out-edges are consecutive - what the segment sums of the kernel message
+    passing rely on. True by construction for graphs written by the graph kernel (they carry each node's out-edge range,
+    `out_start`); checked once (one device->host read) and remembered for any other graph - a reference-format observation
+    may list its `edge_links` in any order."""
+    if "_src_sorted" not in g:
+        src = g["src"]
+        g["_src_sorted"] = "out_start" in g or src.numel() < 2 or bool((src[1:] >= src[:-1]).all())
+    return g["_src_sorted"]
+
+
 def graph_layers(g: dict[str, Any]) -> list[torch.Tensor]:
     """for every DAG layer l (decima/utils.py:249-267): (ids of the edges whose two ends lie in
     (generation l) U (its successors) - the reference's `edge_masks[l]` as an index list, ids of the
@@ -356,8 +367,10 @@ class _NodeEncoder(nn.Module):
         is_parent = torch.zeros(M, dtype=torch.bool, device=x.device).index_fill_(0, src, True)
         leaf = (~is_parent).nonzero(as_tuple=True)[0]
         h = segment_sum(self.mlp_update(gather_rows(h_init, leaf, unique=True)), leaf, M, "unique")
-        if self._kernel_message_passing(h_init):
-            # one autograd node for the whole loop, both MLPs on the MLP kernels (train_kernels._MessagePassFn)
+        if self._kernel_message_passing(h_init) and edges_grouped_by_source(g):
+            # one autograd node for the whole loop, both MLPs on the MLP kernels (train_kernels._MessagePassFn): a receiver's
+            # messages are summed as a RANGE of the layer's edge rows - which they are when the edges are stored source node by
+            # source node (every graph built here; checked once per graph for graphs from elsewhere, else the form below)
             from .train_kernels import message_passing
             plan = [(dst[e], torch.searchsorted(recv, src[e]), recv) for e, recv in reversed(layers)]
             h = message_passing(h_init, h, plan, self.mlp_msg, self.mlp_update)
@@ -630,10 +643,10 @@ class DecimaPolicy(nn.Module):
         sc = pool.get((dev, stream))
         need = 1 if on_dev else max(M * D, 1)  # (a capacity graph always comes with the graph kernel's own lists)
         if sc is None or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
-            hint = torch.full((32,), -1, dtype=torch.int64)  # (unknown until the first pass's lengths have come back)
+            from .vec_env import LateHint  # (list sizes unknown until the first pass's lengths have come back: -1)
             sc = pool[(dev, stream)] = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
                                       "env_off": torch.empty(32 * B, dtype=torch.int64, device=dev), "tot": torch.empty(32, dtype=torch.int64, device=dev),
-                                      "hint": hint.pin_memory() if dev.type == "cuda" else hint}
+                                      "hint": LateHint(32, dev)}
         p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731  (a batch without edges: dst / edge_layers empty)
         # the graph kernel's own lists, if this graph is still the last one its env built on this stream (else: scan + list kernel here)
         ls, epoch = g.get("_layer_lists", (None, -1))
@@ -644,12 +657,12 @@ class DecimaPolicy(nn.Module):
                              p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
                              p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
                              # the list sizes of the PREVIOUS pass, copied back without waiting (whatever is there: they only size grids)
-                             (ctypes.c_int64 * 32)(*sc["hint"].tolist()),
+                             (ctypes.c_int64 * 32)(*sc["hint"].read().tolist()),
                              g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None,
                              int(g["totals_hint"][0]) if on_dev else 0, int(g["totals_hint"][2]) if on_dev else 0)
         with device_of(dev):
             self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
-        sc["hint"].copy_(tot_t, non_blocking=True)
+        sc["hint"].post(tot_t)
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()

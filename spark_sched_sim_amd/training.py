@@ -293,6 +293,7 @@ class RolloutCollector:
             ring_acts = [(torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(R)]
             ring_ev = [torch.cuda.Event() for _ in range(R)] if cuda else None
         n_kept, kept_sizes = 0, [0, 0, 0, 0]  # fast: steps whose observations are part of the record, the arena's cursors after them
+        n_lockstep = 0  # steps a loop that reads every step's flags before issuing the next would have issued (a dropped last step included)
         calls0 = getattr(self.policy, "_calls", 0) if fast else 0
         graphs: dict[tuple[int, int], dict[str, Any]] = {}
         issued = [0] * G             # steps enqueued per group
@@ -312,8 +313,9 @@ class RolloutCollector:
             handle_flags(k, t, g, stage_idx, num_exec, flags[t, k, :5].tolist())
 
         def handle_flags(k: int, t: int, g, stage_idx, num_exec, vals) -> None:
-            nonlocal n_failed, n_kept, kept_sizes
+            nonlocal n_failed, n_kept, kept_sizes, n_lockstep
             any_bad, any_done, any_left, bad_env, any_recorded = vals
+            n_lockstep = t + 1
             if any_bad:
                 n_bad = int(pending.sum()) - n_failed
                 n_failed += n_bad
@@ -439,9 +441,11 @@ class RolloutCollector:
                 torch.cuda.current_stream(dev).synchronize()
             graph = arena.finish(T, kept_sizes)  # (a last step that failed for every env left is dropped, like the steps enqueued behind the end)
             # the steps enqueued behind the last one found every env frozen, but each took a draw counter of the policy's sampling
-            # stream (decima._sample_kernels): hand them back, so that the next collection draws what it would have drawn
+            # stream (decima._sample_kernels): hand them back, so that the next collection draws what it would have drawn - the loop
+            # that waits for every step's flags has issued n_lockstep steps (a last step that failed for every env left took its
+            # counter too, although it is not part of the record)
             if hasattr(self.policy, "_calls"):
-                self.policy._calls = calls0 + T
+                self.policy._calls = calls0 + n_lockstep
             self._arena_sizes = [int(graph["x"].shape[0]), int(graph["src"].numel()), int(graph["job_obs"].numel()), T * B]
         else:
             graph = concat_graphs([graphs[key] for key in keys])
@@ -553,6 +557,33 @@ def _interp(x: torch.Tensor, xp: torch.Tensor, fp: torch.Tensor, n: torch.Tensor
     return torch.where(exact, y0, v)
 
 
+def numpy_sum_order(terms: list) -> Any:
+    """the sum of `terms` (tensors, or floats) in the order numpy's `add.reduce` takes over a float64 axis - what `y_hat.mean()`
+    does in baselines.py:33 (numpy's DOUBLE_pairwise_sum): fewer than 8 terms one after the other from 0.0; up to 128 terms eight
+    strided partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail; above that the range is halved (the
+    first half rounded down to a multiple of 8). tests/test_emu_training.py checks it against numpy itself."""
+    n = len(terms)
+    if n < 8:
+        res = torch.zeros_like(terms[0]) if n and torch.is_tensor(terms[0]) else 0.0
+        for t in terms:
+            res = res + t
+        return res
+    if n <= 128:
+        r = list(terms[:8])
+        i = 8
+        while i < n - (n % 8):
+            for k in range(8):
+                r[k] = r[k] + terms[i + k]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for t in terms[i:]:
+            res = res + t
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return numpy_sum_order(terms[:n2]) + numpy_sum_order(terms[n2:])
+
+
 def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, num_rollouts: int, binding=None) -> torch.Tensor:
     """for each group of `num_rollouts` consecutive envs (the rollouts of one job sequence) the mean
     over the group's rollouts of their piecewise-linear value curves, evaluated at each rollout's own
@@ -581,16 +612,12 @@ def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, n
     fp = ys[:, None, :, :].expand(G, R, R, T)
     nn = n[:, None, :].expand(G, R, R)
     y_hat = _interp(x.contiguous(), xp.contiguous(), fp.contiguous(), nn.contiguous())
-    acc = torch.zeros((G, R, T), dtype=torch.float64, device=values.device)
-    if bool((n > 0).all()):
-        for j in range(R):
-            acc = acc + y_hat[:, :, j, :]
-        return (acc / R).reshape(B, T).t() * ro.active
+    if bool((n > 0).all()):  # (the mean over the sequence's rollouts in numpy's summation order)
+        return (numpy_sum_order([y_hat[:, :, j, :] for j in range(R)]) / R).reshape(B, T).t() * ro.active
     # some rollout recorded nothing (its env failed on its first step, on_env_error="truncate"):
     # it has no curve and is left out of its group's mean
     has = (n > 0).to(torch.float64)
-    for j in range(R):
-        acc = acc + y_hat[:, :, j, :] * has[:, None, j, None]
+    acc = numpy_sum_order([y_hat[:, :, j, :] * has[:, None, j, None] for j in range(R)])
     return (acc / has.sum(1).clamp(min=1)[:, None, None]).reshape(B, T).t() * ro.active
 
 

@@ -38,6 +38,38 @@ def _mask_u8(mask: torch.Tensor | None) -> torch.Tensor | None:
     return mask.to(torch.uint8).contiguous()
 
 
+class LateHint:
+    """A few device integers read back WITHOUT waiting for them: `post(t)` enqueues a copy of `t` to pinned host memory on the current
+    stream, `read()` returns the most recent copy that has COMPLETED (all `fill` until one has) - two host buffers taken in turn,
+    each with an event recorded behind its copy, so that a buffer is never read while a copy into it may be in flight (a plain
+    pinned tensor read while the previous call's non_blocking copy was still running gave torn / half-old values). The values only
+    size grids and work buffers: late ones are fine, undefined ones are not. CPU tensors: the copy is synchronous."""
+
+    def __init__(self, n: int, device: torch.device, fill: int = -1):
+        self.cuda = device.type == "cuda"
+        self.fill = torch.full((n,), fill, dtype=torch.int64)
+        bufs = [torch.full((n,), fill, dtype=torch.int64) for _ in range(2)]
+        self.bufs = [b.pin_memory() for b in bufs] if self.cuda else bufs
+        self.events = [torch.cuda.Event() for _ in range(2)] if self.cuda else None
+        self.posted = [False, False]
+        self.last = 1
+
+    def read(self) -> torch.Tensor:
+        for k in (self.last, 1 - self.last):
+            if self.posted[k] and (not self.cuda or self.events[k].query()):
+                return self.bufs[k].clone()
+        return self.fill.clone()
+
+    def post(self, t: torch.Tensor) -> None:
+        k = 1 - self.last
+        if self.cuda and self.posted[k] and not self.events[k].query():
+            return  # (the copy before last has not even finished: the host is far ahead - skip this one rather than wait)
+        self.bufs[k].copy_(t, non_blocking=True)
+        if self.cuda:
+            self.events[k].record(torch.cuda.current_stream(t.device))
+        self.posted[k], self.last = True, k
+
+
 class VecSparkSchedSimEnv:
     """`num_envs` reference environments in one object.
 
@@ -239,7 +271,6 @@ class VecSparkSchedSimEnv:
         if ws is None:
             Mc, Ec, Jc = B * d.node_cap, B * d.edge_cap, B * d.job_cap
             e = lambda n, dt, *tail: torch.empty((max(n, 1), *tail), dtype=dt, device=dev)  # noqa: E731
-            hint = torch.full((4,), -1, dtype=torch.int64)
             ws = self._dg_dev = {
                 "x": e(Mc, torch.float32, 5), "node_obs": e(Mc, torch.int64), "node_loc": e(Mc, torch.int64), "node_job": e(Mc, torch.int64),
                 "sched_rank": e(Mc, torch.int64), "gen": e(Mc, torch.int32), "node_recv": e(Mc, torch.int32), "stage_mask": e(Mc, torch.bool),
@@ -248,7 +279,7 @@ class VecSparkSchedSimEnv:
                 "job_nodes": e(Jc, torch.int64), "out_start": e(Mc, torch.int64), "out_deg": e(Mc, torch.int32),
                 "layer_cnt": e(32, torch.int32, B), "sched_list": e(Mc, torch.int64),
                 "scan": e(2, torch.int64, 4, B), "tot": e(4, torch.int64), "layer_totals": torch.zeros(32, dtype=torch.int64, device=dev),
-                "recv": e(Mc * max(D, 1), torch.int64), "hint": hint.pin_memory() if dev.type == "cuda" else hint, "epoch": 0}
+                "recv": e(Mc * max(D, 1), torch.int64), "hint": LateHint(4, dev), "epoch": 0}
         act8 = _mask_u8(active)
         scan, tot = ws["scan"], ws["tot"]
         with device_of(dev):
@@ -269,8 +300,8 @@ class VecSparkSchedSimEnv:
         g["n_obs"], g["n_pad"], g["max_depth"] = B, d.node_cap, D
         g["layer_totals"], g["_layer_lists"] = ws["layer_totals"], ({"recv": ws["recv"], "stride": stride, "epoch": ws["epoch"]}, ws["epoch"])
         g["obs_nodes"], g["obs_jobs"], g["obs_node_off"], g["obs_job_off"] = cnt_t[0], cnt_t[2], off[0], off[2]
-        g["totals_dev"], g["totals_hint"] = tot, ws["hint"].clone()  # (M, Ed, J, S); the hint: whatever has arrived of the previous call's
-        ws["hint"].copy_(tot, non_blocking=True)
+        g["totals_dev"], g["totals_hint"] = tot, ws["hint"].read()  # (M, Ed, J, S); the hint: the latest earlier call's totals that have arrived (-1: none yet)
+        ws["hint"].post(tot)
         g["_keepalive"], g["_binding"] = (off, act8), self._b
         return g
 

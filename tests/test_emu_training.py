@@ -343,3 +343,19 @@ def test_two_groups_of_envs_record_what_one_group_records():
         for ra, rb in zip(one[0], two[0]):
             assert ra.keys() == rb.keys() and all((ra[k] == rb[k]).all() and ra[k].shape == rb[k].shape for k in ra)
         assert one[1].numel() > 50 and all(torch.equal(a, b) for a, b in zip(one[1:], two[1:]))
+
+
+def test_sum_order_of_the_baseline_mean_is_numpys():
+    """`training.numpy_sum_order` (and with it `baseline_pairwise` of csrc/sss_returns.h, which the record-kernel test compares with
+    it bit for bit) against numpy itself: `y_hat.mean()` over a strided column, as baselines.py:33 takes it - sequential below 8
+    rollouts per sequence, pairwise with eight partial sums from 8 on, halved above 128"""
+    import numpy as np
+
+    from spark_sched_sim_amd.training import numpy_sum_order
+
+    rng = np.random.default_rng(5)
+    for R in (1, 2, 3, 4, 7, 8, 9, 10, 16, 17, 33, 128, 129, 130, 140, 300):
+        for _ in range(40):
+            M = rng.standard_normal((R, 13)) * 10.0 ** rng.integers(-3, 6)
+            for col in M.T[:4]:
+                assert np.float64(numpy_sum_order([np.float64(v) for v in col])) / R == col.mean(), R

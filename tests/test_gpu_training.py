@@ -217,6 +217,21 @@ def test_message_passing_function_matches_the_tensor_op_form():
     for k in out[True][1]:
         a, b = out[True][1][k], out[False][1][k]
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * max(1.0, float(b.abs().max()))), (k, float((a - b).abs().max()), float(b.abs().max()))
+    # the same graph with its edges listed in another order (a reference-format observation may do that): a receiver's messages
+    # are no longer a range of rows - the encoder notices (decima.edges_grouped_by_source) and sums them the order-free way
+    from spark_sched_sim_amd.decima import edges_grouped_by_source
+    perm = torch.randperm(g["src"].numel(), device=dev)
+    gs = {k: v for k, v in g.items() if k in ("x", "node_obs", "node_loc", "n_pad", "node_job", "sched_rank", "gen", "stage_mask", "job_obs", "job_cap",
+                                               "job_first", "n_obs", "obs_nodes", "obs_jobs", "obs_depth")}
+    gs.update(src=g["src"][perm].contiguous(), dst=g["dst"][perm].contiguous(), edge_obs=g["edge_obs"][perm].contiguous())
+    assert edges_grouped_by_source(g) and not edges_grouped_by_source(gs)
+    pol.zero_grad()
+    h = enc(gs, per_obs_skip=False)
+    (h * w).sum().backward()
+    assert torch.allclose(h.detach(), out[False][0], rtol=1e-4, atol=2e-5)
+    for k, p_ in enc.named_parameters():
+        b = out[False][1][k]
+        assert torch.allclose(p_.grad, b, rtol=2e-3, atol=2e-3 * max(1.0, float(b.abs().max()))), k
     env.close()
 
 

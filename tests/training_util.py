@@ -270,7 +270,7 @@ def check_record_kernels(binding, device):
     from spark_sched_sim_amd.training import Rollouts
 
     gen = torch.Generator().manual_seed(0)
-    for T, B, R in ((37, 12, 4), (200, 64, 4), (5, 3, 1)):
+    for T, B, R in ((37, 12, 4), (200, 64, 4), (5, 3, 1), (23, 16, 8), (19, 27, 9), (11, 140, 140)):  # (R >= 8: numpy's pairwise order)
         n = torch.randint(0, T + 1, (B,), generator=gen)
         n[min(3, B - 1)] = 0
         dt = torch.rand((T, B), generator=gen, dtype=torch.float64) * 5e4
@@ -375,3 +375,23 @@ def check_record_on_device_with_a_failing_env(device, lib, num_envs=6):
             col.collect_sync(with_stats=False)
         assert f"env {bad_env} " in str(ei.value) and f"rollout step {bad_step}" in str(ei.value)
         env.close()
+    # the LAST step of a collection fails for every env that is left (one env, its action corrupted): the step is dropped from the
+    # record, but it took a counter of the policy's sampling stream - with the flags read late as well, so that the collection
+    # AFTER it draws the same samples either way
+    num_envs_saved, num_envs = num_envs, 1
+    bad_env = 0
+    two = {}
+    for on_dev in (True, False):
+        env, col = collector(on_dev, "truncate")
+        first = col.collect_sync(with_stats=False)
+        calls_after = col.policy._calls
+        second = col.collect_sync(with_stats=False)
+        two[on_dev] = (first, calls_after, second)
+        assert int(first.active.sum()) == bad_step and col.env_errors == 1
+        env.close()
+    assert two[True][1] == two[False][1] == bad_step + 1
+    for ra, rb in ((two[True][0], two[False][0]), (two[True][2], two[False][2])):
+        for name in ("active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs"):
+            assert torch.equal(getattr(ra, name), getattr(rb, name)), name
+    assert int(two[True][2].active.sum()) > 0
+    num_envs = num_envs_saved

@@ -8,6 +8,7 @@ from emu_util import load_emu
 from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
 CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
        "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair"),
+       "e100": (dict(num_executors=100, job_arrival_cap=200, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair"),
        "e50": (dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
