@@ -25,19 +25,21 @@ def sources() -> list[str]:
 
 
 OUT = osp.join(CSRC, "libsss_hip.so")
-# translation units: the C ABI + every kernel for up to 64 executors, and the wide instantiation of the simulator kernels
-# (65..128 executors: the same sss_sim.h with -DSSS_WIDE, csrc/sss_wide.h)
-UNITS = ["sss_hip.hip", "sss_hip_wide.hip"]
+# translation units: the C ABI with every kernel but the simulator's own, and the simulator kernels (sss_sim.h) - up to 64 executors, and
+# the wide instantiation (65..128 executors: the same source with -DSSS_WIDE, csrc/sss_wide.h)
+UNITS = ["sss_hip.hip", "sss_hip_sim.hip", "sss_hip_wide.hip"]
 
 # -ffp-contract=off: f64 event times / rewards must round exactly as the reference's do (no FMA fusion)
-# -mllvm -disable-machine-licm: the simulator kernels are one function each (everything is inlined: the launch context lives in
-#   the kernel-argument segment) whose event loop spans tens of thousands of instructions; machine LICM hoists dozens of cheap
-#   per-lane values (lane masks, LDS addresses) out of that loop and the register allocator then spills them across it: 272 /
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
+# -mllvm -disable-machine-licm, for the two simulator units ONLY: a simulator kernel is one function (everything is inlined: the launch
+#   context lives in the kernel-argument segment) whose event loop spans tens of thousands of instructions; machine LICM hoists dozens of
+#   cheap per-lane values (lane masks, LDS addresses) out of that loop and the register allocator then spills them across it: 272 /
 #   640 bytes of scratch per lane in sss_step_kernel / sss_rollout_kernel against 32 / 48 without the pass - 16 KB of spill stores
-#   per env-step, three times the HBM write traffic, fused C2 -8 % (profiles/r04_bench.md section 4). The GNN / MLP kernels do not
-#   care (Decima step 0.605 -> 0.599 ms).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm",
-         "-Wall", "-Wno-unused-function", "-I", CSRC]
+#   per env-step, three times the HBM write traffic, fused C2 -8 % (profiles/r04_bench.md section 4). It is a compiler-internal
+#   switch, so it stays off the other kernels, and tests/test_abi.py::test_simulator_kernels_do_not_spill holds the kernels' scratch
+#   sizes (tools/isa_counts.py) to what it buys: a toolchain that ignores or renames the flag fails that test instead of silently
+#   bringing the spills back.
+UNIT_FLAGS = {"sss_hip_sim.hip": ["-mllvm", "-disable-machine-licm"], "sss_hip_wide.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def hipcc() -> str:
@@ -64,7 +66,7 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, extra_flag
 
         def compile_unit(unit: str) -> str:
             obj = osp.join(objdir, osp.splitext(unit)[0] + ".o")
-            cmd = [cc] + FLAGS + list(extra_flags) + ["-c", "-o", obj, osp.join(CSRC, unit)]
+            cmd = [cc] + FLAGS + UNIT_FLAGS.get(unit, []) + list(extra_flags) + ["-c", "-o", obj, osp.join(CSRC, unit)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True, cwd=CSRC)

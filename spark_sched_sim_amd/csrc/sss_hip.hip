@@ -1,10 +1,14 @@
-// sss_hip.hip - gfx950 build of the simulator: kernels (sss_sim.h) + the C ABI (sss_host.h) on
-// the HIP runtime. Built by __graft_entry__.build() / spark_sched_sim_amd/build.py with
+// sss_hip.hip - gfx950 build of the C ABI (sss_host.h) on the HIP runtime and of every kernel but the simulator's own (those:
+// sss_hip_sim.hip / sss_hip_wide.hip): the Decima graph / policy / GNN kernels, the record and training kernels. Built by __graft_entry__.build() / spark_sched_sim_amd/build.py with
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 // (-ffp-contract=off: the f64 arithmetic must round exactly like the reference's; no FMA fusion).
 #include <hip/hip_runtime.h>
 
-#include "sss_sim.h"
+#include "../../include/sss.h"
+#include "sss_layout.h"
+#include "sss_narrow.h"
+#include "sss_wide.h"
+#include <wave_rt.h>
 #include "sss_decima.h"
 #include "sss_gnn.h"
 #include "sss_decima_policy.h"
@@ -43,29 +47,23 @@ static void be_free(void* p) {
 }
 static int be_h2d(void* dst, const void* src, size_t n) { return (int)hipMemcpy(dst, src, n, hipMemcpyHostToDevice); }
 
+// the simulator kernels themselves are two translation units of their own (sss_hip_sim.hip: up to 64 executors; sss_hip_wide.hip: 65..128)
 static int be_launch_reset(const SssKernelArgs& a, int num_envs, const uint64_t* seeds, const double* tl, const uint8_t* mask, void* stream) {
-  hipLaunchKernelGGL(sss_reset_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, seeds, tl, mask);
-  return (int)hipGetLastError();
+  return sss_narrow_launch_reset(a, num_envs, seeds, tl, mask, stream);
 }
 static int be_launch_step_bounded(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
                                   int budget, uint8_t* ready, void* stream) {
-  hipLaunchKernelGGL(sss_step_bounded_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset, seed_stride,
-                     budget, ready);
-  return (int)hipGetLastError();
+  return sss_narrow_launch_step_bounded(a, num_envs, stage_idx, num_exec, auto_reset, seed_stride, budget, ready, stream);
 }
 static int be_launch_step(const SssKernelArgs& a, int num_envs, const int32_t* stage_idx, const int32_t* num_exec, int auto_reset, uint64_t seed_stride,
                           void* stream) {
-  hipLaunchKernelGGL(sss_step_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, stage_idx, num_exec, auto_reset, seed_stride);
-  return (int)hipGetLastError();
+  return sss_narrow_launch_step(a, num_envs, stage_idx, num_exec, auto_reset, seed_stride, stream);
 }
-
 static int be_launch_policy(const SssKernelArgs& a, int num_envs, int policy, int param, int32_t* stage_idx, int32_t* num_exec, void* stream) {
-  hipLaunchKernelGGL(sss_policy_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, policy, param, stage_idx, num_exec);
-  return (int)hipGetLastError();
+  return sss_narrow_launch_policy(a, num_envs, policy, param, stage_idx, num_exec, stream);
 }
 static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, int param, int n_steps, int auto_reset, uint64_t seed_stride, void* stream) {
-  hipLaunchKernelGGL(sss_rollout_kernel, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, policy, param, n_steps, auto_reset, seed_stride);
-  return (int)hipGetLastError();
+  return sss_narrow_launch_rollout(a, num_envs, policy, param, n_steps, auto_reset, seed_stride, stream);
 }
 
 static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void* stream) {
@@ -247,14 +245,3 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
 }
 
 #include "sss_host.h"
-
-#ifdef SSS_EVPROF3  // timing builds only (tools/debug/evprof3.sh): reads and clears the scoped profiler's table
-extern "C" int sss_debug_prof(unsigned long long* out64) {
-  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
-  static const unsigned long long zeros[96] = {0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
-}
-extern "C" int sss_debug_prof_min(unsigned long long min_step_ticks) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3_min), &min_step_ticks, sizeof(min_step_ticks)) == hipSuccess ? 0 : -1;
-}
-#endif

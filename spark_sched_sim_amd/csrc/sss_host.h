@@ -1,7 +1,7 @@
 // sss_host.h - host side of the C ABI (include/sss.h): argument checking, layout, constant
 // upload, kernel launches. The including translation unit supplies the five be_* primitives
 // (spark_sched_sim_amd/csrc/sss_hip.hip: HIP runtime; tests/emu/emu_backend.cpp: the CPU wave
-// emulator used by the test-suite) and includes sss_sim.h for SssKernelArgs.
+// emulator used by the test-suite); the simulator kernels' launchers come from sss_narrow.h / sss_wide.h.
 #pragma once
 #include <math.h>
 #include <stdio.h>
@@ -15,11 +15,12 @@
 #include "sss_layout.h"
 #include "sss_train.h"
 #include "sss_rows.h"
+#include "sss_narrow.h"
 #include "sss_wide.h"
 
 // envs with more than 64 executors run on the wide instantiation of the kernels (sss_wide.h)
 static bool sss_is_wide(int num_executors) { return num_executors > 64; }
-static int sss_hot_bytes(int num_executors) { return sss_is_wide(num_executors) ? sss_wide_hot_bytes() : (int)sizeof(SssHot); }
+static int sss_hot_bytes(int num_executors) { return sss_is_wide(num_executors) ? sss_wide_hot_bytes() : sss_narrow_hot_bytes(); }
 
 static thread_local std::string g_sss_err;
 static int sss_fail(int code, const std::string& msg) {
@@ -329,7 +330,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
       if (levels[l] == exec_levels[i]) P.lvl_of[i] = (int8_t)l;
   }
   P.max_edges = ph.max_edges_per_job;
-  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, h->L.E, sss_is_wide(h->L.E) ? sss_wide_static_lds_bytes() : SSS_STATIC_LDS_BYTES)) {
+  if (sss_compute_lds_pool(&P, h->L.J_cap, h->L.SP, h->L.E, sss_is_wide(h->L.E) ? sss_wide_static_lds_bytes() : sss_narrow_static_lds_bytes())) {
     sss_destroy(h);
     return sss_fail(-12, "LDS working set does not fit");
   }

@@ -256,7 +256,6 @@ SSS_DEV int pool_index(uint32_t k) {
   if (s < 0) return 1 + j;
   return 1 + g_c.J_cap + j * g_c.SP + s;
 }
-SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
 
 // job.local_executors (JOB:81-89) is only ever counted (TPCH:217, the executor-level key). Up to 64 executors it is kept as a
 // bit mask (the event batches update it with lane masks); the wide instantiation keeps the count itself in the same field.

@@ -181,6 +181,7 @@ SSS_DEV uint64_t wave_clock() { return (uint64_t)clock64(); }
 template <class T>
 SSS_DEV void nt_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
+SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
 SSS_DEV int popc64(uint64_t x) { return __popcll(x); }
 SSS_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
 SSS_DEV int ctz64_nz(uint64_t x) { return __builtin_ctzll(x); }  // x != 0

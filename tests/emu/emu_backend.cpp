@@ -22,6 +22,10 @@ extern "C" { long long sss_batch_stats[128]; }
 #include "sss_decima_policy.h"
 #include "zig_tables.inc"
 
+#include "sss_narrow.h"
+int sss_narrow_hot_bytes() { return (int)sizeof(SssHot); }
+int sss_narrow_static_lds_bytes() { return SSS_STATIC_LDS_BYTES; }
+
 static int be_set_device(int) { return 0; }
 struct BeDeviceGuard {
   explicit BeDeviceGuard(int) {}

@@ -135,6 +135,7 @@ SSS_DEV uint64_t wave_clock() { return 0; }
 template <class T>
 SSS_DEV void nt_store(T* p, T v) { *p = v; }
 SSS_DEV uint64_t mul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+SSS_DEV uint64_t bit64(int i) { return 1ull << i; }
 SSS_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
 SSS_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : -1; }
 SSS_DEV int ctz64_nz(uint64_t x) { if (!x) __builtin_trap(); return __builtin_ctzll(x); }

@@ -29,6 +29,27 @@ def test_exports_match_header(hip_lib):
         assert hasattr(hip_lib, sym), sym
 
 
+def test_simulator_kernels_do_not_spill(hip_lib):
+    """The simulator units are compiled with machine LICM off (spark_sched_sim_amd/build.py: with the pass on, 32 loop-invariant
+    register pairs are hoisted out of the event loop and spilled across it - 272 / 640 bytes of scratch per lane in the step /
+    rollout kernels, 16 KB of spill stores per env-step). That is a compiler-internal switch: should a toolchain stop honouring it,
+    this fails instead of the spills silently coming back. Scratch per lane and vector-register spills of the built library's
+    kernels, read from its code objects (tools/isa_counts.py kernel_metadata); the 4-waves-per-SIMD register budget with them."""
+    import sys
+
+    from spark_sched_sim_amd import build
+
+    sys.path.insert(0, osp.join(ROOT, "tools"))
+    from isa_counts import kernel_metadata
+
+    md = kernel_metadata(build.build())
+    for kernel, scratch_max in (("sss_step_kernel", 64), ("sss_step_bounded_kernel", 64), ("sss_rollout_kernel", 96), ("sss_reset_kernel", 0),
+                                ("sss_step_kernel_wide", 64), ("sss_step_bounded_kernel_wide", 64), ("sss_rollout_kernel_wide", 96), ("sss_reset_kernel_wide", 0)):
+        k = md[kernel]
+        assert k["private_segment_fixed_size"] <= scratch_max, (kernel, k)
+        assert k["vgpr_spill_count"] <= 8 and k["vgpr_count"] <= 128, (kernel, k)
+
+
 def test_query_dims_and_validation(hip_lib, pack):
     from spark_sched_sim_amd.binding import Binding, SssCfg
 
