@@ -34,3 +34,14 @@ int sss_wide_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, in
   hipLaunchKernelGGL(sss_rollout_kernel_wide, dim3(num_envs), dim3(64), (size_t)a.P.pool_bytes, (hipStream_t)stream, a, policy, param, n_steps, auto_reset, seed_stride);
   return (int)hipGetLastError();
 }
+
+#ifdef SSS_EVPROF3  // timing builds only (tools/debug/evprof3.py): the scoped profiler's table of THIS instantiation
+extern "C" int sss_debug_prof_wide(unsigned long long* out64) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
+  static const unsigned long long zeros[96] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
+}
+extern "C" int sss_debug_prof_min_wide(unsigned long long min_step_ticks) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof3_min), &min_step_ticks, sizeof(min_step_ticks)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -624,16 +624,22 @@ def sequence_baselines(ro: Rollouts, values: torch.Tensor, num_sequences: int, n
 # ---- PPO (trainers/ppo.py) ----------------------------------------------------------------------------
 
 def ppo_loss(policy, g: dict[str, Any], stage_sel, job_idx, exec_sel, advantages: torch.Tensor, old_lgprobs: torch.Tensor,
-             clip_range: float, entropy_coeff: float):
-    """the CLIP loss of ppo.py:104-138 on one minibatch (a compact graph + per-observation vectors)"""
+             clip_range: float, entropy_coeff: float, adv_stats: tuple[float, float] | None = None, weight: float = 1.0):
+    """the CLIP loss of ppo.py:104-138 on one minibatch (a compact graph + per-observation vectors).
+    Several ranks, each holding a part of the minibatch: `adv_stats` = (mean, std) of the WHOLE minibatch's advantages (ppo.py:113-116
+    normalises over the minibatch - the reference has one learner and every sample in it) and `weight` = this rank's share of the
+    minibatch x number of ranks, so that the ranks' AVERAGED gradients are the gradient of the whole minibatch's mean loss."""
     res = policy.evaluate_actions(g, stage_sel, job_idx, exec_sel)
     advgs = advantages.float()
-    advgs = (advgs - advgs.mean()) / (advgs.std() + EPS)
+    mean, std = (advgs.mean(), advgs.std()) if adv_stats is None else adv_stats
+    advgs = (advgs - mean) / (std + EPS)
     log_ratio = res["lgprobs"] - old_lgprobs
     ratio = log_ratio.exp()
     policy_loss = -torch.min(advgs * ratio, advgs * torch.clamp(ratio, 1 - clip_range, 1 + clip_range)).mean()
     entropy_loss = -res["entropies"].mean()
     loss = policy_loss + entropy_coeff * entropy_loss
+    if weight != 1.0:
+        loss = loss * weight
     with torch.no_grad():
         approx_kl = ((ratio - 1) - log_ratio).mean()
     return loss, {"policy_loss": policy_loss.detach(), "entropy_loss": entropy_loss.detach(), "approx_kl_div": approx_kl}
@@ -687,17 +693,37 @@ class PPO:
             # single process: the reference's DataLoader batches (size n // num_batches + 1, ppo.py:66-71).
             # several ranks: exactly num_batches chunks everywhere, so that the collectives line up
             chunks = torch.tensor_split(perm, self.num_batches) if dist else [perm[s: s + bs] for s in range(0, n, bs)]
-            for mb in chunks:
-                usable = mb.numel() >= 2  # a single sample has no advantage std (the reference would fail on it)
+            whole = None
+            if dist:
+                # A minibatch is the ranks' chunks TOGETHER, as if one learner held every sample (the reference's does: the workers'
+                # rollouts are gathered into one process, trainer.py:113-121, ppo.py:51-138): its advantages are normalised with the
+                # mean / std over all ranks' chunks and every rank's loss counts by its share of the samples. One all-reduce per
+                # epoch carries the sums of all its minibatches: (count, sum, sum of squares) each, f64.
+                a64 = advgs.double()
+                whole = torch.stack([torch.stack([torch.tensor(float(mb.numel()), dtype=torch.float64, device=ids.device), a64[mb].sum(), (a64[mb] ** 2).sum()])
+                                     for mb in chunks])
+                dist.all_reduce(whole)
+                whole = whole.cpu()
+            for ci, mb in enumerate(chunks):
+                stats, weight = None, 1.0
+                if dist:
+                    N, S1, S2 = (float(v) for v in whole[ci])
+                    usable = mb.numel() >= 1 and N >= 2  # (a single sample in the whole minibatch has no advantage std)
+                    if usable:
+                        mean = S1 / N
+                        stats = (mean, max(0.0, (S2 - N * mean * mean) / (N - 1)) ** 0.5)  # (torch.std: the unbiased estimate)
+                        weight = mb.numel() * dist.get_world_size() / N
+                else:
+                    usable = mb.numel() >= 2  # a single sample has no advantage std (the reference would fail on it)
                 if usable:
                     g = select_observations(ro.graph, ids[mb])
                     loss, info = ppo_loss(self.policy, g, acts[0][mb], acts[1][mb], acts[2][mb], advgs[mb], old_lg[mb],
-                                          self.clip_range, self.entropy_coeff)
+                                          self.clip_range, self.entropy_coeff, stats, weight)
                     kl = info["approx_kl_div"]
                 else:
                     loss, info, kl = None, None, torch.zeros((), device=ids.device)
-                if dist:
-                    stat = torch.stack([kl.float(), torch.ones_like(kl.float()) * usable])
+                if dist:  # the early-stop test looks at the whole minibatch's mean KL (ppo.py:89-93)
+                    stat = torch.stack([kl.float() * (mb.numel() if usable else 0), torch.ones_like(kl.float()) * (mb.numel() if usable else 0)])
                     dist.all_reduce(stat)
                     kl = stat[0] / stat[1].clamp(min=1)
                 elif not usable:

@@ -10,9 +10,26 @@ from spark_sched_sim_amd import VecSparkSchedSimEnv
 from spark_sched_sim_amd.digest import digest_words
 
 
+SKIP = -2147483648  # stage_idx of an env that takes no part in a launch (include/sss.h)
+
+
+def step_in_bounded_launches(env, stage_idx: torch.Tensor, num_exec: torch.Tensor, bounded, launch_no: list) -> None:
+    """one step of every env through `sss_step_bounded` only (include/sss.h): launches with an event budget until every env's step
+    is complete; an env that is done sits the remaining launches out. `bounded`: the budget, or "mixed" - another one every launch."""
+    done = torch.zeros(env.num_envs, dtype=torch.bool, device=env.device)
+    while not bool(done.all()):
+        budget = (launch_no[0] * 7) % 23 + 1 if bounded == "mixed" else int(bounded)
+        launch_no[0] += 1
+        si = torch.where(done, torch.full_like(stage_idx, SKIP), stage_idx).contiguous()
+        ready = env.step_bounded_async(si, num_exec, budget).bool()
+        done = done | ready
+        assert launch_no[0] < 10 ** 7
+
+
 def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs_steps: int = 0, max_steps: int | None = None,
-                  reward_rtol: float = 0.0, rewards_out: list | None = None):
-    """one env per seed, all stepped together; returns a list of mismatch descriptions"""
+                  reward_rtol: float = 0.0, rewards_out: list | None = None, bounded=None):
+    """one env per seed, all stepped together; returns a list of mismatch descriptions. `bounded`: every step is taken through
+    the bounded entry point (`sss_step_bounded`, an event budget per launch) instead of `sss_step`"""
     g = Golden(name)
     pack = g.pack(pack)
     seeds = list(seeds)
@@ -40,6 +57,7 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
             bad.append(f"{name} seed {s}: job durations differ")
 
     i = 0
+    launch_no = [0]
     while True:
         oi = env.obs_i32.cpu().numpy()
         of = env.obs_f64.cpu().numpy()
@@ -98,7 +116,10 @@ def replay_golden(name: str, seeds, pack: bytes, device: str, lib=None, full_obs
             st = g.ep(s, "stage_idx")
             if alive[k] and i + 1 < len(st):
                 si[k], ne_[k] = int(st[i + 1]), int(g.ep(s, "num_exec")[i + 1])
-        env.step({"stage_idx": si.to(env.device), "num_exec": ne_.to(env.device)})
+        if bounded is None:
+            env.step({"stage_idx": si.to(env.device), "num_exec": ne_.to(env.device)})
+        else:
+            step_in_bounded_launches(env, si.to(env.device), ne_.to(env.device), bounded, launch_no)
         i += 1
     env.close()
     return bad

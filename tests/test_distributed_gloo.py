@@ -158,6 +158,88 @@ def test_two_rank_ppo_every_epoch_permutes_all_samples(tmp_path):
         assert torch.equal(three["sd"][k], other["sd"][k]), k
 
 
+def _record_grads(policy, store: list):
+    """wraps `policy.update_parameters` so that the gradients every optimiser step sees are kept (after the ranks' all-reduce)"""
+    real = policy.update_parameters
+
+    def spy(loss=None):
+        store.append({k: p.grad.detach().clone() for k, p in policy.named_parameters() if p.grad is not None})
+        return real(loss)
+    policy.update_parameters = spy
+
+
+def _ppo_halves_worker(rank: int, world: int, port: int, out_dir: str):
+    """rank r trains on the rollouts of job sequence r of a record made by ONE process (columns 2r, 2r + 1 of it)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    from decima_util import AGENT
+    from spark_sched_sim_amd.decima import DecimaPolicy
+    from spark_sched_sim_amd.training import PPO, Rollouts
+
+    blob = torch.load(os.path.join(out_dir, "record.pt"))
+    full = Rollouts(**blob["ro"])
+    T, B = full.active.shape
+    cols = torch.arange(2 * rank, 2 * rank + 2)
+    ids = (torch.arange(T)[:, None] * B + torch.arange(B)[None, :])[:, cols]
+    part = Rollouts(graph=full.graph, obs_index=ids, **{k: getattr(full, k)[:, cols] for k in
+                    ("active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")})
+    pol = DecimaPolicy(num_executors=ENV["num_executors"], **AGENT, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5)
+    pol.load_state_dict(blob["sd"])
+    grads = []
+    _record_grads(pol, grads)
+    pol.train()
+    PPO(pol, dict(blob["train"], num_sequences=1), generator=torch.Generator().manual_seed(rank)).train_on_rollouts(part)
+    torch.save({"grads": grads, "sd": pol.state_dict()}, os.path.join(out_dir, f"half{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ppo_update_equals_the_one_rank_update_on_the_union(tmp_path):
+    """The reference has ONE learner: the workers' rollouts are gathered into it (trainers/trainer.py:113-121) and every minibatch's
+    advantages are normalised over the whole minibatch (trainers/ppo.py:113-116). With one learner per rank each holds a part of
+    every minibatch: the ranks exchange the minibatch's advantage sums and weigh their losses by their share of it, so that the
+    averaged gradient is the gradient the single learner computes. Checked on a record made by one process (2 job sequences x 2
+    rollouts): the gradients of the optimiser steps of (a) one process training on all of it and (b) two gloo ranks training on one
+    sequence's rollouts each agree to float32 round-off (rtol 2e-4 of the largest entry: different summation order; the ranks'
+    chunks of a minibatch hold the same samples as the single learner's minibatch when there is one minibatch per epoch), and
+    so do the parameters after the steps whose gradients are not ~0 in any entry (Adam's first steps are sign-like)."""
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    from decima_util import AGENT
+    from emu_util import load_emu
+    from spark_sched_sim_amd.training import PPO, Trainer
+
+    train = dict(TRAIN, num_iterations=1, num_sequences=2, num_rollouts=2, num_epochs=2, num_batches=1)
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), ENV, dict(train, artifacts_dir=str(tmp_path / "a")), device="cpu", _lib=load_emu())
+    tr.policy.eval()
+    ro = tr.collector.collect_sync(with_stats=False)
+    assert int(ro.active.sum()) > 20 and ro.active.shape[1] == 4
+    sd = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    fields = {k: getattr(ro, k) for k in ("graph", "active", "t_before", "t_after", "rewards", "stage_sel", "job_idx", "exec_sel", "lgprobs", "resets")}
+    fields["graph"] = {k: v for k, v in ro.graph.items() if torch.is_tensor(v) or isinstance(v, (int, float))}
+    torch.save({"ro": fields, "sd": sd, "train": train}, str(tmp_path / "record.pt"))
+    one = []
+    _record_grads(tr.policy, one)
+    tr.policy.train()
+    PPO(tr.policy, train, generator=torch.Generator().manual_seed(5)).train_on_rollouts(ro)
+    sd_one = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    tr.close()
+    mp.spawn(_ppo_halves_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    h0, h1 = torch.load(str(tmp_path / "half0.pt")), torch.load(str(tmp_path / "half1.pt"))
+    assert len(one) == len(h0["grads"]) == len(h1["grads"]) == 2  # (two epochs x one minibatch)
+    g1, g2 = one[0], h0["grads"][0]
+    scale = max(float(v.abs().max()) for v in g1.values())  # (entries whose true gradient is 0 - the last bias of a softmax's scores - are noise)
+    for k in g1:  # first optimiser step: same parameters on both sides
+        assert torch.allclose(g1[k], g2[k], rtol=0.0, atol=2e-4 * scale), (k, float((g1[k] - g2[k]).abs().max()), scale)
+        assert torch.equal(h0["grads"][0][k], h1["grads"][0][k]), k
+    for k in sd_one:  # after both steps (the second one's gradients follow from the first one's parameters)
+        assert torch.equal(h0["sd"][k], h1["sd"][k]), k
+        assert torch.allclose(sd_one[k], h0["sd"][k], rtol=0.0, atol=2.5 * 2 * 3.0e-4), k  # (bounded by two sign-like Adam steps)
+    close = sum(int(torch.isclose(sd_one[k], h0["sd"][k], rtol=0.0, atol=1e-5).sum()) for k in sd_one)
+    total = sum(v.numel() for v in sd_one.values())
+    assert close >= 0.97 * total, (close, total)
+
+
 # ---- self-starting ranks (bench.py --gpus N with no outer launcher) ----------------------------------
 
 _RANK_SCRIPT = """

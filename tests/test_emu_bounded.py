@@ -36,3 +36,13 @@ def test_bounded_step_rejects_bad_arguments(pack):
     with pytest.raises(ValueError):
         env.step_bounded_async(a["stage_idx"], a["num_exec"], 0)
     env.close()
+
+
+@pytest.mark.parametrize("name,seeds,budget,max_steps", [("c1_fair", [1234, 3], 3, 200), ("c1_hash", [100], "mixed", 250), ("e100_fair", [0], 5, 120)])
+def test_bounded_entry_point_against_the_reference_recordings(name, seeds, budget, max_steps, pack):
+    """the golden trajectories recorded from the reference, every step taken through `sss_step_bounded` alone (no `sss_step` in
+    between): rewards, wall times, flags and observation digests of every completed step, bit for bit"""
+    from replay_util import replay_golden
+
+    bad = replay_golden(name, seeds, pack, device="cpu", lib=load_emu(), full_obs_steps=10, max_steps=max_steps, bounded=budget)
+    assert not bad, "\n".join(bad[:10])

@@ -1,5 +1,5 @@
 """debug: scoped profile of the lane-0 procedures (library built with -DSSS_EVPROF3 by evprof3.sh)"""
-import ctypes as C, sys, os.path as osp
+import ctypes as C, sys, os, os.path as osp
 ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
 sys.path[:0] = [ROOT]
 import torch
@@ -15,8 +15,9 @@ NAMES = {0: "batch_released_events", 1: "trk_add_commitment", 2: "trk_remove_com
          28: "do_step", 29: "run_policy", 30: "fast_run (per EVENT)", 31: "handle_popped", 32: "lean_released", 33: "fulfil_run", 34: "select_stage_wave",
          35: "fulfil_chunk", 36: "fulfil_order_commitments", 37: "pop_event_wave", 38: "lean_arrival", 39: "fulfil_common_wave", 40: "preflush_completing_job"}
 CFG = {"c2": (dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash"),
-       "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
-import os
+       "c3": (dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair"),
+       "e100": (dict(num_executors=100, job_arrival_cap=200, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair")}
+N_ENVS = int(os.environ.get("SSS_ENVS", "4096"))
 if os.environ.get("SSS_SECTIONS"):
     NAMES.update({1: "rel: reads .. first exit", 2: "rel: commitment scan", 3: "rel: classify", 4: "rel: window + ranking", 5: "rel: draws + lane commit", 6: "rel: lane-0 commitments",
                   7: "rel: per-lane pool records", 8: "rel: pools_staged", 9: "rel: sched clear", 10: "rel: sat bits", 11: "rel: send cache_acquire"})
@@ -36,14 +37,16 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
 # third argument: only record step launches of envs whose do_step took at least that many ticks (the tail of step mode)
 min_ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 lib.sss_debug_prof_min.argtypes = [C.c_ulonglong]
+lib.sss_debug_prof_min_wide.argtypes = [C.c_ulonglong]
 for name in sys.argv[1].split(","):
     cfg, pol = CFG[name]
-    env = VecSparkSchedSimEnv(cfg, 4096, device="cuda:0", pack=workload.default_pack(), auto_reset=True, _lib=lib)
+    prof, prof_min = (lib.sss_debug_prof_wide, lib.sss_debug_prof_min_wide) if cfg["num_executors"] > 64 else (lib.sss_debug_prof, lib.sss_debug_prof_min)
+    env = VecSparkSchedSimEnv(cfg, N_ENVS, device="cuda:0", pack=workload.default_pack(), auto_reset=True, _lib=lib)
     env.reset(seed=0)
     env.rollout(pol, 600)
     torch.cuda.synchronize()
-    lib.sss_debug_prof(buf)
-    lib.sss_debug_prof_min(min_ticks)
+    prof(buf)
+    prof_min(min_ticks)
     c0 = env.counters()
     if mode == "fused":
         for _ in range(6):
@@ -52,9 +55,9 @@ for name in sys.argv[1].split(","):
         for _ in range(300):
             env.step(env.policy_actions(pol))
     torch.cuda.synchronize()
-    lib.sss_debug_prof(buf)
+    prof(buf)
     c1 = env.counters()
-    lib.sss_debug_prof_min(0)
+    prof_min(0)
     steps = c1["n_steps"] - c0["n_steps"]; evs = c1["n_events"] - c0["n_events"]
     if min_ticks:
         steps = buf[2 * 28 + 1]  # per recorded (slow) step
