@@ -194,7 +194,7 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
         t0 = time.perf_counter()
         for _ in range(n):
             act, _ = policy.schedule_env(env, generator=gen)
-            env.step(act)
+            env.step_async(act["stage_idx"], act["num_exec"])  # (observations, rewards, flags: the env's buffers, read in place by the next pass)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 

@@ -78,7 +78,8 @@ struct alignas(16) SssScratch {
   // the set image of (old active list + active list) only changes when a job arrives or completes:
   // versions of the two lists it was built from (valid within one launch)
   uint32_t active_version, old_version, jobset_old_v, jobset_new_v;
-  int32_t jobset_valid, pad1_;
+  int32_t jobset_valid;
+  int32_t active_dirty;           // the ordered active-job list has changed since it was staged in (env_end writes it back only then)
   uint64_t free_slots;            // bit k set <=> cache slot k is free
   double wall_old;
   uint32_t fc_dst[SSS_MAX_EXEC];  // snapshot of the source's commitments (fulfill_commitments_from_source)
@@ -814,6 +815,13 @@ SSS_DEV tabword_t tabword_zero() { return mk_u4(0u, 0u, 0u, 0u); }
 typedef uint2 tabword_t;
 SSS_DEV tabword_t tabword_zero() { return mk_u2(0u, 0u); }
 #endif
+SSS_DEV bool tabword_differs(const tabword_t& a, const tabword_t& b) {
+#ifdef SSS_WIDE
+  return a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+#else
+  return a.x != b.x || a.y != b.y;
+#endif
+}
 SSS_DEV bool tabword_in(int lane) { return (uint32_t)lane * (uint32_t)sizeof(tabword_t) < (uint32_t)sss_pool_table_bytes(g_c.E); }
 // whether two pool tables fit the two staging areas side by side (pool_pair_*): not with exactly 64 executors (512-byte tables
 // against 256-byte areas); the wide instantiation's areas hold its largest table
@@ -822,12 +830,14 @@ SSS_DEV bool pair_staging_fits(int) { return true; }
 #else
 SSS_DEV bool pair_staging_fits(int E) { return E < 64; }
 #endif
-SSS_DEV SetImg<uint8_t> pool_stage_in(uint32_t key) {
+// `fetched`: this lane's bytes of the table as they are in HBM - pool_stage_out stores a lane's bytes only if they have changed
+SSS_DEV SetImg<uint8_t> pool_stage_in(uint32_t key, tabword_t& fetched) {
   const int lane = wave_lane();
   const uint4 rec = *(const uint4*)(g_c.pool_hdr + pool_index(key));
   const uint32_t bytes = sss_pool_table_bytes(g_c.E);
   static_assert(2 * SSS_SET_TABLE >= 64 * sizeof(tabword_t), "a staged table lies in setA (+ setB, which follows it)");
-  if (tabword_in(lane)) ((tabword_t*)g_sc.setA)[lane] = ((const tabword_t*)pool_table_hbm(key))[lane];
+  fetched = tabword_zero();
+  if (tabword_in(lane)) fetched = ((const tabword_t*)pool_table_hbm(key))[lane], ((tabword_t*)g_sc.setA)[lane] = fetched;
   SetImg<uint8_t> s;
   s.mask = rec.x & 0xFFFFu, s.fill = rec.x >> 16, s.used = rec.y & 0xFFFFu, s.finger = 0, s.aux = rec.y >> 16;
   s.big = g_sc.setA, s.big_wide = false, s.small = g_sc.pool8;
@@ -840,11 +850,15 @@ SSS_DEV SetImg<uint8_t> pool_stage_in(uint32_t key) {
   return s;
 }
 // `s`: lane 0's image after its operations (the other lanes' copies are stale)
-SSS_DEV void pool_stage_out(uint32_t key, const SetImg<uint8_t>& s) {
+SSS_DEV void pool_stage_out(uint32_t key, const SetImg<uint8_t>& s, const tabword_t& fetched) {
   const int lane = wave_lane();
-  // the whole area goes back, not just the slots in use: the HBM copy then is byte for byte what the
-  // one-operation-at-a-time code would have left (it works in place), dead slots included
-  if (tabword_in(lane)) ((tabword_t*)pool_table_hbm(key))[lane] = ((const tabword_t*)g_sc.setA)[lane];
+  // every word of the area that differs from what was fetched goes back, not just the slots in use: the HBM copy then is byte for
+  // byte what the one-operation-at-a-time code would have left (it works in place), dead slots included - and a table in which
+  // one byte changed costs one store, not its whole area
+  if (tabword_in(lane)) {
+    const tabword_t now = ((const tabword_t*)g_sc.setA)[lane];
+    if (tabword_differs(now, fetched)) ((tabword_t*)pool_table_hbm(key))[lane] = now;
+  }
   if (lane == 0) pool_close(key, s);
   wave_sync();
 }
@@ -1163,6 +1177,7 @@ struct PairImg {
   SetImg<uint8_t> s;
   uint64_t t8;
   uint32_t mask_before;  // the record's mask when it was fetched
+  tabword_t fetched;     // this lane's bytes of the table area as they are in HBM
 };
 SSS_DEV PairImg pool_pair_image(const uint4 rec, uint8_t* area, uint8_t* small8) {
   PairImg p;
@@ -1179,8 +1194,10 @@ SSS_DEV void pool_pair_stage(const PoolPairRegs& r, bool has_b, PairImg& a, Pair
   const bool in = tabword_in(lane);
   if (in) ((tabword_t*)g_sc.setA)[lane] = r.tab_a;
   a = pool_pair_image(r.rec_a, g_sc.setA, g_sc.pool8);
+  a.fetched = r.tab_a;
   if (has_b && in) ((tabword_t*)g_sc.setB)[lane] = r.tab_b;
   b = pool_pair_image(r.rec_b, g_sc.setB, g_sc.pool8b);
+  b.fetched = r.tab_b;
   wave_sync();
 }
 // the image has just been through a resize on lane 0 (its header is in step again): an 8-slot result goes to the register
@@ -1245,12 +1262,15 @@ SSS_DEV void pair_remove_many(PairImg& p, const uint8_t* list, int from, int to)
   wave_sync();
 }
 // one image back to HBM: the record, and the table area unless the image had 8 slots before and has 8 slots now (the
-// area then holds what was fetched). Like pool_stage_out the whole area goes back, so that the HBM bytes are what the
-// one-operation-at-a-time code leaves, dead slots included.
+// area then holds what was fetched). Like pool_stage_out every word of the area that has changed goes back, so that the HBM bytes
+// are what the one-operation-at-a-time code leaves, dead slots included (round 4 stored the whole area: 256 bytes where one byte
+// had changed, +3.7 MB per config-2 step launch).
 SSS_DEV void pool_pair_flush_one(uint32_t key, const PairImg& p) {
   const int lane = wave_lane();
-  if ((p.mask_before != 7 || p.s.mask != 7) && tabword_in(lane))
-    ((tabword_t*)pool_table_hbm(key))[lane] = ((const tabword_t*)p.s.big)[lane];
+  if ((p.mask_before != 7 || p.s.mask != 7) && tabword_in(lane)) {
+    const tabword_t now = ((const tabword_t*)p.s.big)[lane];
+    if (tabword_differs(now, p.fetched)) ((tabword_t*)pool_table_hbm(key))[lane] = now;
+  }
   if (lane == 0) {
     const uint32_t w0 = p.s.mask | (p.s.fill << 16), w1 = (p.s.used & 0xFFFFu) | (p.s.aux << 16);
     const bool small = p.s.mask == 7;  // (larger tables live in the overflow area; the inline bytes are kept clean)
@@ -1979,7 +1999,8 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
   wave_sync();
   const uint32_t src_jpool = src_job >= 0 ? key_job_pool(src_job) : POOL_NONE;
   if (staged_src) {
-    SetImg<uint8_t> sset = pool_stage_in(src);
+    tabword_t src_words;
+    SetImg<uint8_t> sset = pool_stage_in(src, src_words);
     for (int i = c0; i < c0 + n; i++) {  // (every lane: the operations run on the whole wave, staged_add / staged_remove)
       bool was = staged_remove(sset, (uint32_t)g_sc.fi_e[i]);
       CHECK(was);
@@ -1987,7 +2008,7 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
     }
     sset.aux -= (uint32_t)n;
     wave_sync();
-    pool_stage_out(src, sset);
+    pool_stage_out(src, sset, src_words);
   }
   if (lane == 0) {
     // the source pool's record: n executors and n commitments fewer
@@ -2024,10 +2045,11 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
     while (i1 < c0 + n && g_sc.fi_k[i1] == kk) n_ex += g_sc.fi_type[i1] == FI_EXEC, n_pk += g_sc.fi_type[i1] == FI_PARK, i1++;
     const uint32_t into = n_ex ? d : key_job_pool(key_job(d));
     if ((n_ex || n_pk) && into != src) {
-      SetImg<uint8_t> dset = pool_stage_in(into);
+      tabword_t into_words;
+      SetImg<uint8_t> dset = pool_stage_in(into, into_words);
       for (int q = i; q < i1; q++) staged_add(dset, (uint32_t)g_sc.fi_e[q]);
       wave_sync();
-      pool_stage_out(into, dset);
+      pool_stage_out(into, dset, into_words);
     }
     i = i1;
   }
@@ -2262,7 +2284,7 @@ SSS_DEV int cache_acquire(int j) {  // HBM -> LDS if the job has no slot yet; re
 SSS_DEV void handle_job_arrival(int j) {  // ENV:428-438 (pools were created empty at reset)
   lds_active()[H.n_active] = (uint16_t)j;
   H.n_active++;
-  g_sc.active_version++;
+  g_sc.active_version++, g_sc.active_dirty = 1;
   H.graph_version++;
   if (g_c.pool_hdr[0].used > 0) H.curr_source = POOL_COMMON;
 }
@@ -2295,7 +2317,7 @@ SSS_DEV void process_job_completion(int j) {  // ENV:682-697
   (*jobp(j)).completion_order = (int16_t)H.n_completed;
   H.n_completed++;
   g_sc.pending_free = j;  // its cache slot is written back once the handler has returned
-  g_sc.active_version++;
+  g_sc.active_version++, g_sc.active_dirty = 1;
   H.graph_version++;
   g_c.t_completed[j] = H.wall_time;
   double dur = H.wall_time - g_c.t_arrival[j];
@@ -2883,7 +2905,8 @@ SSS_DEV void pools_staged(uint64_t dm, uint32_t n, uint32_t mykey, bool parks) {
     const int l = ctz64_nz(dm);
     dm &= dm - 1;
     const uint32_t key = wave_readlane_u32(mykey, l);
-    SetImg<uint8_t> sn = pool_stage_in(key);
+    tabword_t key_words;
+    SetImg<uint8_t> sn = pool_stage_in(key, key_words);
     for (uint32_t q = 0; q < n; q++) {  // (wave-uniform: the lists are read by every lane)
       const uint32_t e = g_sc.fi_e[q];
       if (MODE == STAGED_ENTER) {
@@ -2896,7 +2919,7 @@ SSS_DEV void pools_staged(uint64_t dm, uint32_t n, uint32_t mykey, bool parks) {
       }
     }
     wave_sync();
-    pool_stage_out(key, sn);
+    pool_stage_out(key, sn, key_words);
   }
 }
 
@@ -4250,7 +4273,7 @@ SSS_DEV void env_begin(const uint8_t* base) {
       g_sc.free_slots = all & ~used;
       g_sc.pending_free = -1, g_sc.pinned_job = -1, g_sc.idle_valid = 0, g_sc.fi_detach = 0;
       g_sc.events_this_step = 0;
-      g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0;
+      g_sc.active_version = 0, g_sc.old_version = 0, g_sc.jobset_valid = 0, g_sc.active_dirty = 0;
       g_sc.rng_pos = 64;  // the HBM image holds the generator's state itself, nothing is buffered yet
     }
   }
@@ -4323,7 +4346,8 @@ SSS_DEV void env_end(uint8_t* base) {
     else
       ((uint64_t*)(g_c.durations + j * g_c.SP))[w - 8 - g_c.SP] = ((const uint64_t*)(lds_cdur() + k * g_c.SP))[w - 8 - g_c.SP];
   }
-  for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
+  if (g_sc.active_dirty)  // (wave-uniform: read behind the ordering point above)
+    for (int i = lane; i < A; i += 64) g_c.active_g[i] = lds_active()[i];
   for (int x = lane; x < g_c.E; x += 64) {  // the HBM image of an event does not name an LDS slot
     uint32_t info = g_hot.ev[x].info;
     if (info_kind(info) != EV_NONE) g_hot.ev[x].info = info_with_slot(info, INFO_SLOT_NONE);
@@ -4332,10 +4356,11 @@ SSS_DEV void env_end(uint8_t* base) {
   {
     SssHot* g = (SssHot*)base;
     if (lane < (int)(sizeof(SssHdr) / 16)) ((uint4*)&g->h)[lane] = ((const uint4*)&g_hot.h)[lane];
+    const int n_commits = g_hot.h.n_commits;  // entries behind the live ones are never read again: they stay what they are in HBM
     for (int x = lane; x < g_c.E; x += 64) {
       g->ev[x] = g_hot.ev[x], g->ex_loc[x] = g_hot.ex_loc[x], g->ex_job[x] = g_hot.ex_job[x];
       g->ex_task_stage[x] = g_hot.ex_task_stage[x], g->ex_executing[x] = g_hot.ex_executing[x];
-      g->c_src[x] = g_hot.c_src[x], g->c_dst[x] = g_hot.c_dst[x], g->c_seq[x] = g_hot.c_seq[x], g->c_n[x] = g_hot.c_n[x];
+      if (x < n_commits) g->c_src[x] = g_hot.c_src[x], g->c_dst[x] = g_hot.c_dst[x], g->c_seq[x] = g_hot.c_seq[x], g->c_n[x] = g_hot.c_n[x];
     }
   }
 }

@@ -558,16 +558,34 @@ class DecimaPolicy(nn.Module):
         self._plist = None
         return super()._apply(fn, *args, **kwargs)
 
-    def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, n_rows_dev: torch.Tensor | None = None, **ptrs) -> None:
-        """`n_rows_dev`: i64[1] on the device holding the real row count (`n_rows` is then a grid-size guess)"""
+    def _launch(self, kind: str, n_rows: int, w: torch.Tensor, layer: int = 0, n_pad: int = 0, n_rows_dev: torch.Tensor | None = None, _stream: int | None = None,
+                **ptrs) -> None:
+        """`n_rows_dev`: i64[1] on the device holding the real row count (`n_rows` is then a grid-size guess). `_stream`: the stream
+        handle, when the caller has looked it up already (and made `w`'s device current).
+
+        Filling a ctypes structure of 30 pointers costs more host time than the launch itself, and an inference loop passes the
+        same buffers step after step: the structures are kept, keyed by the pointer values (another buffer anywhere -> another
+        structure), and only the row count is written per call."""
         import ctypes
 
         from .binding import GNN_KINDS, SssGnnArgs, device_of
-        a = SssGnnArgs()
-        a.n_rows, a.w_dev, a.slope, a.num_executors, a.layer, a.n_pad = int(n_rows), w.data_ptr(), self._packed[2], self.num_executors, layer, n_pad
-        a.n_rows_dev = n_rows_dev.data_ptr() if n_rows_dev is not None else None
-        for k, t in ptrs.items():
-            setattr(a, k + "_dev", t.data_ptr() if t is not None and t.numel() else None)
+        names = tuple(ptrs)
+        vals = tuple(t.data_ptr() if t is not None and t.numel() else None for t in ptrs.values())
+        key = (kind, layer, n_pad, w.data_ptr(), n_rows_dev.data_ptr() if n_rows_dev is not None else None, self._packed[2], names, vals)
+        cache = self.__dict__.setdefault("_launch_args", {})
+        a = cache.get(key)
+        if a is None:
+            if len(cache) > 256:  # (graphs that come and go, e.g. training minibatches: do not grow without bound)
+                cache.clear()
+            a = cache[key] = SssGnnArgs()
+            a.w_dev, a.slope, a.num_executors, a.layer, a.n_pad = w.data_ptr(), self._packed[2], self.num_executors, layer, n_pad
+            a.n_rows_dev = key[4]
+            for k, v in zip(names, vals):
+                setattr(a, k + "_dev", v)
+        a.n_rows = int(n_rows)
+        if _stream is not None:
+            self._kb.check(self._kb.lib.sss_gnn_launch(GNN_KINDS[kind], ctypes.byref(a), _stream))
+            return
         dev = w.device
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         with device_of(dev):  # (no handle in this entry point: it launches on the current device)
@@ -586,7 +604,7 @@ class DecimaPolicy(nn.Module):
         return torch.nonzero_static(mask, size=mask.numel(), fill_value=-1)[:, 0]
 
     @torch.no_grad()
-    def _encode_kernels(self, g: dict[str, Any]) -> dict[str, torch.Tensor]:
+    def _encode_kernels(self, g: dict[str, Any], _stream: int | None = None) -> dict[str, torch.Tensor]:
         """`encode(g, per_obs_skip=True)` on the fused kernels. Re-packs the parameters if they changed
         since the last call (the other kernel stages of the same `act` reuse that packing)."""
         w = self._packed_weights()
@@ -594,7 +612,7 @@ class DecimaPolicy(nn.Module):
         dev = x.device
         M, J, B = x.shape[0], g["job_obs"].numel(), g["n_obs"]
         if "max_depth" in g and "layer_cnt" in g and 0 <= g["max_depth"] <= 32:
-            return self._encode_one_call(g, w)
+            return self._encode_one_call(g, w, _stream)
         h_init = torch.empty((M, 16), dtype=torch.float32, device=dev)
         self._launch("prep", M, w["prep"], x=x, out=h_init)
         h = torch.empty_like(h_init)
@@ -618,7 +636,7 @@ class DecimaPolicy(nn.Module):
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()
-    def _encode_one_call(self, g: dict[str, Any], w: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+    def _encode_one_call(self, g: dict[str, Any], w: dict[str, torch.Tensor], _stream: int | None = None) -> dict[str, torch.Tensor]:
         """the encoder through `sss_gnn_encode` (include/sss.h): every launch of the pass enqueued by one call, the layers'
         list sizes stay on the device - no device->host round trip between the graph kernel and the scores"""
         import ctypes
@@ -628,7 +646,7 @@ class DecimaPolicy(nn.Module):
         dev = x.device
         M, J, B, D = x.shape[0], g["job_obs"].numel(), g["n_obs"], int(g["max_depth"])
         on_dev = "totals_dev" in g  # a capacity graph (env.decima_graph_on_device): M, J are capacities, the totals live on the device
-        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        stream = _stream if _stream is not None else (torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
         f32 = lambda n: torch.empty((n, 16), dtype=torch.float32, device=dev)  # noqa: E731
         if on_dev:  # work buffers at capacity, kept per stream (no allocation per step)
             hb = self.__dict__.setdefault("_enc_cap", {})
@@ -652,21 +670,34 @@ class DecimaPolicy(nn.Module):
         ls, epoch = g.get("_layer_lists", (None, -1))
         fresh = ls is not None and ls["epoch"] == epoch and ls["recv"].device == dev and ls["stride"] >= M
         tot_t, recv_t, stride = (g["layer_totals"], ls["recv"], ls["stride"]) if fresh else (sc["tot"], sc["recv"], 0)
-        a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
-                             p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
-                             p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
-                             p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
-                             # the list sizes of the PREVIOUS pass, copied back without waiting (whatever is there: they only size grids)
-                             (ctypes.c_int64 * 32)(*sc["hint"].read().tolist()),
-                             g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None,
-                             int(g["totals_hint"][0]) if on_dev else 0, int(g["totals_hint"][2]) if on_dev else 0)
-        with device_of(dev):
+        # (the structure is kept per set of buffers - an inference loop passes the same ones step after step; filling its 40
+        # fields costs more host time than the launches it describes)
+        key = (M, J, B, D, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
+               recv_t.numel(), stride, g["obs_nodes"].data_ptr(), g["totals_dev"].data_ptr() if on_dev else 0)
+        kept = sc.get("args")
+        if kept is None or kept[0] != key:
+            a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
+                                 p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
+                                 p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
+                                 p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
+                                 (ctypes.c_int64 * 32)(),
+                                 g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None, 0, 0)
+            sc["args"] = kept = (key, a, (w, x, h_init, h, tmp, h_dag, h_glob))  # (the tensors: kept alive with the pointers)
+        a = kept[1]
+        # the list sizes of an EARLIER pass, copied back without waiting (the latest that have arrived: they only size grids)
+        a.layer_rows_hint[:] = sc["hint"].read().tolist()
+        if on_dev:
+            a.n_nodes_hint, a.n_jobs_hint = int(g["totals_hint"][0]), int(g["totals_hint"][2])
+        if _stream is not None:
             self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
+        else:
+            with device_of(dev):
+                self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
         sc["hint"].post(tot_t)
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()
-    def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor]) -> torch.Tensor:
+    def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], _stream: int | None = None) -> torch.Tensor:
         """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
         M = g["x"].shape[0]
         rows_dev = None
@@ -686,40 +717,60 @@ class DecimaPolicy(nn.Module):
                 rows, idx0, exact = g["sched_list"].numel(), g["sched_list"], 1
             else:
                 rows, idx0, exact = M, self._index_list(g["stage_mask"]), 0
-        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, n_rows_dev=rows_dev, w16=self._packed[1].get("stage16"), w2_16=self._packed[1].get("stage_mfma"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
+        self._launch("stage", rows, self._packed[1]["stage"], layer=exact, n_rows_dev=rows_dev, _stream=_stream, w16=self._packed[1].get("stage16"), w2_16=self._packed[1].get("stage_mfma"), n_pad=g["n_pad"], x=g["x"], h=h["node"], h_dag=h["dag"],
                      h_glob=h["glob"], out=out, idx0=idx0, node_job=g["node_job"], node_obs=g["node_obs"], node_loc=g["node_loc"])
         return out
 
     @torch.no_grad()
     def _sample_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], padded: torch.Tensor, generator: torch.Generator | None,
-                        scores_out: dict | None = None) -> dict[str, torch.Tensor]:
+                        scores_out: dict | None = None, _stream: int | None = None) -> dict[str, torch.Tensor]:
         """both draws on the device (include/sss.h sss_decima_sample): stage draw -> executor scores
         of the chosen stage's job -> executor-count draw; Gumbel-max over a counter-based stream
-        (seed = the generator's, counter = number of calls so far)"""
+        (seed = the generator's, counter = number of calls so far).
+        On a capacity graph (`env.decima_graph_on_device`: act-and-forget inference, its buffers are overwritten by the next
+        call anyway) the result tensors and the argument structure are kept and reused from call to call as well."""
         import ctypes
 
         from .binding import SssDecimaSampleArgs, device_of
         B, E, dev = g["n_obs"], self.num_executors, padded.device
         self._calls = getattr(self, "_calls", 0) + 1
-        i64 = lambda: torch.empty(B, dtype=torch.int64, device=dev)  # noqa: E731
-        out = {"stage_sel": i64(), "job_idx": i64(), "exec_sel": i64(), "lgprob": torch.empty(B, dtype=torch.float32, device=dev),
-               "any_stage": torch.empty(B, dtype=torch.bool, device=dev)}
-        job_gid = i64()
-        stage_idx = torch.empty(B, dtype=torch.int32, device=dev)
-        num_exec = torch.empty(B, dtype=torch.int32, device=dev)
-        es = torch.empty((B, E), dtype=torch.float32, device=dev)
-        a = SssDecimaSampleArgs(g["n_pad"], E, (generator.initial_seed() if generator is not None else 0) & (2 ** 64 - 1), self._calls,
-                                padded.data_ptr(), es.data_ptr(), g["obs_nodes"].data_ptr(), g["obs_node_off"].data_ptr(),
-                                g["obs_job_off"].data_ptr(), g["sched_rank"].data_ptr(), g["node_job"].data_ptr(), job_gid.data_ptr(),
-                                stage_idx.data_ptr(), num_exec.data_ptr(), out["stage_sel"].data_ptr(), out["job_idx"].data_ptr(),
-                                out["exec_sel"].data_ptr(), out["lgprob"].data_ptr(), out["any_stage"].data_ptr())
-        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        with device_of(dev):
+        seed = (generator.initial_seed() if generator is not None else 0) & (2 ** 64 - 1)
+        key = (B, E, g["n_pad"], padded.data_ptr(), g["obs_nodes"].data_ptr(), g["obs_node_off"].data_ptr(), g["obs_job_off"].data_ptr(), g["sched_rank"].data_ptr(),
+               g["node_job"].data_ptr())
+        kept = self.__dict__.get("_sample_ws") if "totals_dev" in g else None
+        if kept is None or kept[0] != key:
+            i64 = lambda: torch.empty(B, dtype=torch.int64, device=dev)  # noqa: E731
+            out = {"stage_sel": i64(), "job_idx": i64(), "exec_sel": i64(), "lgprob": torch.empty(B, dtype=torch.float32, device=dev),
+                   "any_stage": torch.empty(B, dtype=torch.bool, device=dev)}
+            job_gid = i64()
+            stage_idx = torch.empty(B, dtype=torch.int32, device=dev)
+            num_exec = torch.empty(B, dtype=torch.int32, device=dev)
+            es = torch.empty((B, E), dtype=torch.float32, device=dev)
+            a = SssDecimaSampleArgs(g["n_pad"], E, seed, self._calls,
+                                    padded.data_ptr(), es.data_ptr(), g["obs_nodes"].data_ptr(), g["obs_node_off"].data_ptr(),
+                                    g["obs_job_off"].data_ptr(), g["sched_rank"].data_ptr(), g["node_job"].data_ptr(), job_gid.data_ptr(),
+                                    stage_idx.data_ptr(), num_exec.data_ptr(), out["stage_sel"].data_ptr(), out["job_idx"].data_ptr(),
+                                    out["exec_sel"].data_ptr(), out["lgprob"].data_ptr(), out["any_stage"].data_ptr())
+            kept = (key, out, job_gid, stage_idx, num_exec, es, a)
+            if "totals_dev" in g:
+                self._sample_ws = kept
+        _, out, job_gid, stage_idx, num_exec, es, a = kept
+        out = dict(out)
+        a.rng_seed, a.rng_counter = seed, self._calls
+        if _stream is not None:  # (the caller has made the device current)
+            stream = _stream
             self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
-        self._launch("exec", B * E, self._packed[1]["exec"], w16=self._packed[1].get("exec16"), w2_16=self._packed[1].get("exec_mfma"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
+        else:
+            stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+            with device_of(dev):
+                self._kb.check(self._kb.lib.sss_decima_sample(B, 0, ctypes.byref(a), stream))
+        self._launch("exec", B * E, self._packed[1]["exec"], _stream=_stream, w16=self._packed[1].get("exec16"), w2_16=self._packed[1].get("exec_mfma"), x=g["x"], h_dag=h["dag"], h_glob=h["glob"], out=es,
                      idx0=job_gid, job_obs=g["job_obs"], job_first=g["job_first"], job_cap=g["job_cap"])
-        with device_of(dev):
+        if _stream is not None:
             self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
+        else:
+            with device_of(dev):
+                self._kb.check(self._kb.lib.sss_decima_sample(B, 1, ctypes.byref(a), stream))
         out["env_stage_idx"], out["env_num_exec"] = stage_idx, num_exec
         out["rng"] = (a.rng_seed, a.rng_counter)
         if scores_out is not None:
@@ -779,8 +830,13 @@ class DecimaPolicy(nn.Module):
         B, N = g["n_obs"], g["n_pad"]
         M, J = g["x"].shape[0], g["job_obs"].numel()
         if self._use_kernels(g) and M > 0 and J > 0:
-            h = self._encode_kernels(g)
-            return self._sample_kernels(g, h, self._stage_scores_kernels(g, h), generator)
+            # (the stream handle and the current device are looked up once for the pass's seven library calls)
+            from .binding import device_of
+            dev = g["x"].device
+            with device_of(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+                h = self._encode_kernels(g, stream)
+                return self._sample_kernels(g, h, self._stage_scores_kernels(g, h, stream), generator, _stream=stream)
         # tensor-op path (other architectures, graphs built without the graph kernel)
         h = self.encode(g)
         s, idx = self.stage_scores(g, h)

@@ -77,8 +77,17 @@ def check_bounded_steps(device, lib, cfg, seeds, policy, n_steps, budgets, pack=
         # entries of the active list behind n_active are leftovers of longer lists (a cut step parks its list as it is then)
         n_act = np.ascontiguousarray(state[:, HDR_OFF["n_active"]: HDR_OFF["n_active"] + 4]).view(np.int32).ravel()
         assert np.array_equal(n_act, np.ascontiguousarray(state_ref[:, HDR_OFF["n_active"]: HDR_OFF["n_active"] + 4]).view(np.int32).ravel())
+        # entries of the commitment list behind the live ones are dead (never read again, written back only while live: which bytes
+        # they hold follows from where launches ended); hot block: header, then ev[ME] (16 B), ex_loc (4), ex_job (2),
+        # ex_task_stage (1), ex_executing (1), c_src (4), c_dst (4), c_seq (4), c_n (2), ME = 64 or 128 executor entries
+        ME = 128 if cfg["num_executors"] > 64 else 64
+        n_com = np.ascontiguousarray(state[:, HDR_OFF["n_commits"]: HDR_OFF["n_commits"] + 4]).view(np.int32).ravel()
+        assert np.array_equal(n_com, np.ascontiguousarray(state_ref[:, HDR_OFF["n_commits"]: HDR_OFF["n_commits"] + 4]).view(np.int32).ravel())
+        c0 = d.hdr_bytes + ME * (16 + 4 + 2 + 1 + 1)
         for b in range(B):
             diff[b, d.off_active + 2 * int(n_act[b]): d.off_active + 2 * n_slots] = False
+            for base, w in ((c0, 4), (c0 + 4 * ME, 4), (c0 + 8 * ME, 4), (c0 + 12 * ME, 2)):
+                diff[b, base + w * int(n_com[b]): base + w * ME] = False
         assert not diff.any(), (budget, np.nonzero(diff.any(0))[0][:10])
         launches[budget] = (n_launch, n_cut)
         env.close()
