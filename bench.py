@@ -270,7 +270,11 @@ class Bench:
         Bs = B // S
         self.pack = workload.default_pack()
         # env i of shard s of rank r: seed (r*S + s)*Bs + i = its global env id (placement invariant)
-        self.shards = [VecSparkSchedSimEnv(self.cfg, Bs, device=dev, pack=self.pack, auto_reset=True, seed_stride=B * world) for _ in range(S)]
+        lib = None
+        if getattr(args, "lib", None):  # an A/B test build of the library (tests/gpu_variant.py), never the default
+            from spark_sched_sim_amd.binding import load_library
+            lib = load_library(osp.abspath(args.lib))
+        self.shards = [VecSparkSchedSimEnv(self.cfg, Bs, device=dev, pack=self.pack, auto_reset=True, seed_stride=B * world, _lib=lib) for _ in range(S)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
         for k, e in enumerate(self.shards):
             e.reset(seed=(rank * S + k) * Bs)
@@ -484,6 +488,8 @@ def main() -> None:
     ap.add_argument("--preroll", type=int, default=None, help="fused steps every env runs before anything is timed (default: a few episodes)")
     ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the extra PPO-iteration record (one rank's share of BASELINE config 5; N=1, c2 only)")
+    ap.add_argument("--lib", default=None, help="path of a test build of the library to measure instead of the product (A/B timing; tests/gpu_variant.py builds them)")
+    ap.add_argument("--no-e100", action="store_true", help="skip the 100-executor record (the wide instantiation; N=1, --config c2 only)")
     ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE config 3 record (N=1, --config c2 only)")
     ap.add_argument("--shards", type=int, default=1,
                     help="split the rank's envs into this many independently stepped sub-batches, one HIP stream each "
@@ -639,6 +645,26 @@ def main() -> None:
             out["c3"] = rec
         except Exception as e:
             out["c3"] = {"error": repr(e)}
+    # more than 64 executors (the wide instantiation of the kernels, csrc/sss_hip_wide.hip) next to the headline (N = 1): 100 executors,
+    # 200 jobs, step mode at 1024 and at 4096 envs, with the C oracle on all host cores beside it
+    if world == 1 and args.config == "c2" and not args.no_e100 and args.shards == 1:
+        try:
+            rec = {"what": "100 executors, 200 TPC-H-format jobs (job_arrival_rate 8e-05/ms), on-device 'fair' policy, auto-reset, steady state; step mode "
+                           "(sss_policy + sss_step per batched step); the wide instantiation: two executors per lane"}
+            ke, we = max(10, min(args.steps, 200)), max(5, min(args.warmup, 50))
+            for Be in (1024, 4096):
+                be = Bench(args, "e100", DEFAULT_POLICY["e100"], Be, dev, rank, world)
+                re_ = be.measure("step", ke, we)
+                fe = be.measure("fused", ke, we)
+                rec[f"envs_{Be}"] = {"value": re_["value"], "unit": "env-steps/s", "ms_per_step": re_["ms_per_step"], "events_per_step": re_["events_per_step"],
+                                     "batched_event_frac": re_["batched_event_frac"], "roofline": re_["roofline"], "step_tail": be.step_tail(8),
+                                     "fused": {"value": fe["value"], "ms_per_step": fe["ms_per_step"]}}
+                be.close()
+            if not args.no_cpu_baseline:
+                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["e100"], "fair", min(4.0, args.cpu_budget / 2))
+            out["e100"] = rec
+        except Exception as e:
+            out["e100"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_decima and args.config == "c2":
             try:  # SURVEY 8(f) next-1 on the same env sizing; never let it take the bench line down

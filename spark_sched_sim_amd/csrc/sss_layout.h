@@ -274,7 +274,7 @@ static inline int sss_compute_lds_pool(SssParams* P, int J_cap, int SP, int E, i
   int budget = SSS_LDS_BUDGET - static_bytes;
   int n = (budget - o) / per_slot;
   // Large job capacities (BASELINE config 3: 200 jobs -> 4.2 KB of lists and maps): the 16-workgroups/CU target
-  // is given up rather than the cache - but not by much. Measured at C3 on MI355X (tools/debug/slots_sweep.sh,
+  // is given up rather than the cache - but not by much. Measured at C3 on MI355X (profiles/r02_bench.md: `-DSSS_FALLBACK_SLOTS=n` test builds,
   // env-steps/s step / fused): 6 slots 8.3 / 24.8 M, 8: 9.1 / 23.6, 10: 9.5 / 24.0, 14: 9.4 / 23.4, 16: 9.4 / 23.2,
   // 24: 9.0 / 21.3, 32: 8.8 / 20.3, 48: 8.4 / 18.8 - occupancy is worth more than cache coverage beyond ~10 jobs.
 #ifndef SSS_FALLBACK_SLOTS

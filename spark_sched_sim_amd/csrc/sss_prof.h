@@ -1,7 +1,7 @@
-// sss_prof.h - the scoped profiler of the timing builds (tools/debug/evprof3.sh: -DSSS_EVPROF3). In the product build
+// sss_prof.h - the scoped profiler of the timing builds (tools/debug/evprof3.py: -DSSS_EVPROF3). In the product build
 // every macro below expands to nothing; sss_sim.h only carries the one-line PROF3(id) scope markers.
 #pragma once
-// -DSSS_EVPROF3 (tools/debug/evprof3.sh): inclusive shader-clock ticks and call counts of the lane-0
+// -DSSS_EVPROF3 (tools/debug/evprof3.py): inclusive shader-clock ticks and call counts of the lane-0
 // procedures, in a device-global table read back through sss_debug_prof (timing builds only)
 #ifdef SSS_EVPROF3
 __device__ unsigned long long g_prof3[96];  // 48 scopes x (ticks, calls)

@@ -360,7 +360,7 @@ class KernelMLP(nn.Sequential):
     # The two policy heads (53 / 36 -> 64 -> 64 -> 1, Tanh) go through the kernels as well since they run on the matrix cores
     # (csrc/sss_train16.h sss_mlp_head_mfma_*: 600 k rows forward + backward 0.77 / 0.65 ms against 1.46 / 1.28 ms for the three
     # library GEMMs with the MFMA weight-gradient kernel; their 16-lanes-per-row form was LDS-bound and slower, 2.50 / 1.54 ms).
-    # The GNN's 32 / 16-wide MLPs: 2.5 M rows forward + backward ~0.9 ms against 2.1 - 2.3 ms (tools/debug/mlp_time.py).
+    # The GNN's 32 / 16-wide MLPs: 2.5 M rows forward + backward ~0.9 ms against 2.1 - 2.3 ms (profiles/r03_ppo.md).
     FUSE_WIDE = True
 
     def _fused_spec(self):

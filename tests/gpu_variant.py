@@ -11,7 +11,7 @@ VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
             # timing builds for tools/debug/evprof3.py (scoped profiler of the lane-0 procedures, csrc/sss_prof.h)
             "evprof3": ("-DSSS_EVPROF3",), "evprof3b": ("-DSSS_EVPROF3", "-DSSS_EVPROF3B"), "evprof3c": ("-DSSS_EVPROF3", "-DSSS_EVPROF3C"),
             "evprof3d": ("-DSSS_EVPROF3", "-DSSS_EVPROF3D"),
-            # batch-size thresholds of the event loop (A/B timing: copied over the product library on the GPU box by hand)
+            # batch-size thresholds of the event loop (A/B timing: `bench.py --lib tests/_build/libsss_hip_<name>.so`)
             "thr22": ("-DSSS_MIN_RELEASED_BATCH=2", "-DSSS_MIN_ARRIVAL_BATCH=2"), "thr32": ("-DSSS_MIN_RELEASED_BATCH=3", "-DSSS_MIN_ARRIVAL_BATCH=2"),
             "thr63": ("-DSSS_MIN_RELEASED_BATCH=6", "-DSSS_MIN_ARRIVAL_BATCH=3"), "arr1": ("-DSSS_MIN_ARRIVAL_BATCH=1",),
             "nolean": ("-DSSS_NO_LEAN",), "syncwg": ("-DSSS_SYNC_WORKGROUP",), "pair17": ("-DSSS_PAIR_MIN_E=17",), "w3": ("-DSSS_WAVES_PER_SIMD=3",), "w2": ("-DSSS_WAVES_PER_SIMD=2",), "oplane": ("-DSSS_OPAQUE_LANE",), "mlicm": ("-mllvm", "-disable-machine-licm=false"),

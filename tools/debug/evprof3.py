@@ -1,4 +1,4 @@
-"""debug: scoped profile of the lane-0 procedures (library built with -DSSS_EVPROF3 by evprof3.sh)"""
+"""debug: scoped profile of the lane-0 procedures (the -DSSS_EVPROF3 test build: python tests/gpu_variant.py evprof3 ahead of the gpurun call)"""
 import ctypes as C, sys, os, os.path as osp
 ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
 sys.path[:0] = [ROOT]
