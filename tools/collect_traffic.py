@@ -97,7 +97,7 @@ def main():
     for config, envs in (("c2", 4096), ("c3", 4096)):
         for mode, kernel in (("step", "sss_step_kernel"), ("fused", "sss_rollout_kernel")):
             cmd = ["python3", "bench.py", "--config", config, "--envs", str(envs), "--mode", mode, "--single-mode",
-                   "--no-cpu-baseline", "--no-decima", "--no-c3", "--steps", "200", "--warmup", "50"]
+                   "--no-cpu-baseline", "--no-decima", "--no-c3", "--no-ppo", "--no-e100", "--steps", "200", "--warmup", "50"]
             # the regime the counters are collected in (steady state: bench.py pre-rolls every env), from an unprofiled run
             line = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT).stdout.strip().splitlines()[-1]
             ref = json.loads(line)

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/pmc
 rocprofv3 --list-avail 2>/dev/null | grep -i -E "icache|ifetch|SQ_WAIT_INST|SQ_INSTS_(VALU|SALU|LDS|SMEM|VMEM)|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_ACTIVE_INST|SQ_INST_CYCLES|SQ_WAIT_ANY|SQ_WAVES" | head -60 > gpurun_out/pmc/avail.txt
 for grp in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_BUSY_CYCLES" "SQ_IFETCH SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc/$tag -o t -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-decima --no-c3 --single-mode --preroll 300 > /dev/null 2> gpurun_out/pmc/$tag.err
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc/$tag -o t -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-decima --no-c3 --no-ppo --no-e100 --single-mode --preroll 300 > /dev/null 2> gpurun_out/pmc/$tag.err
 done
 python3 - <<'PY'
 import csv, glob, collections
