@@ -26,6 +26,13 @@ CASES = [
     ("e33_zero_delays_hash0", dict(num_executors=33, job_arrival_cap=80, job_arrival_rate=1.0e-4, moving_delay=0.0, warmup_delay=0.0), "hash", 1, 30000),
     ("burst_fair", dict(num_executors=20, job_arrival_cap=120, job_arrival_rate=4.0e-4, moving_delay=500.0, warmup_delay=100.0), "fair", 0, 30000),
     ("e100_fair_wide", dict(num_executors=100, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 12000),
+    # round 5: the wide instantiation's lane-parallel event machinery (two executors per lane: csrc/sss_sim.h lane_event) - random
+    # actions (backup scheduling, sends, parks), every lane with two executors, zero delays, 65 executors (one lane with two)
+    ("e100_hash0_wide", dict(num_executors=100, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "hash", 1, 12000),
+    ("e128_fair_wide", dict(num_executors=128, job_arrival_cap=80, job_arrival_rate=2.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 10000),
+    ("e128_hash0_wide", dict(num_executors=128, job_arrival_cap=60, job_arrival_rate=2.0e-4, moving_delay=500.0, warmup_delay=100.0), "hash", 1, 10000),
+    ("e65_fair_wide", dict(num_executors=65, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 12000),
+    ("e90_zero_delays_hash0_wide", dict(num_executors=90, job_arrival_cap=80, job_arrival_rate=1.5e-4, moving_delay=0.0, warmup_delay=0.0), "hash", 1, 10000),
 ]
 
 
@@ -34,10 +41,13 @@ def bits(x):
 
 
 def main():
-    stride = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # every stride-th env is replayed on the oracle (usage: soak_verify.py [stride])
+    stride = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # every stride-th env is replayed on the oracle (usage: soak_verify.py [stride] [case name part])
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
     pack = workload.default_pack()
     B, base = 4096, 777
     for name, cfg, policy, pid, steps in CASES:
+        if only not in name:
+            continue
         env = VecSparkSchedSimEnv(cfg, B, device="cuda:0", pack=pack, auto_reset=True)
         env.reset(seed=base)
         for _ in range(steps // 1000):
