@@ -674,7 +674,7 @@ class DecimaPolicy(nn.Module):
         # fields costs more host time than the launches it describes)
         key = (M, J, B, D, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
                recv_t.numel(), stride, g["obs_nodes"].data_ptr(), g["totals_dev"].data_ptr() if on_dev else 0)
-        kept = sc.get("args")
+        kept = sc.get("args") if on_dev else None  # (graphs with exact sizes bring new buffers every call: nothing to keep, and nothing kept alive)
         if kept is None or kept[0] != key:
             a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
                                  p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
@@ -682,7 +682,9 @@ class DecimaPolicy(nn.Module):
                                  p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
                                  (ctypes.c_int64 * 32)(),
                                  g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None, 0, 0)
-            sc["args"] = kept = (key, a, (w, x, h_init, h, tmp, h_dag, h_glob))  # (the tensors: kept alive with the pointers)
+            kept = (key, a, (w, x, h_init, h, tmp, h_dag, h_glob))  # (the tensors: kept alive with the pointers)
+            if on_dev:
+                sc["args"] = kept
         a = kept[1]
         # the list sizes of an EARLIER pass, copied back without waiting (the latest that have arrived: they only size grids)
         a.layer_rows_hint[:] = sc["hint"].read().tolist()
