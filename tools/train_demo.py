@@ -27,11 +27,13 @@ def main():
     ap.add_argument("--rollouts", type=int, default=4)
     ap.add_argument("--lr", type=float, default=3.0e-4)
     ap.add_argument("--on-env-error", default="truncate", choices=["raise", "truncate"])
+    ap.add_argument("--executors", type=int, default=10, help="more than 64: the simulator's wide instantiation, executor-count draws over two counts per lane")
+    ap.add_argument("--jobs", type=int, default=30)
     a = ap.parse_args()
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=a.sequences, num_rollouts=a.rollouts, seed=42,
                  checkpointing_freq=10 ** 9, num_epochs=3, num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04,
                  beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=a.lr), max_grad_norm=0.5, artifacts_dir="/tmp/sss_demo", on_env_error=a.on_env_error)
-    env = dict(num_executors=10, job_arrival_cap=30, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0,
+    env = dict(num_executors=a.executors, job_arrival_cap=a.jobs, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0,
                mean_time_limit=2.0e7)
     tr = Trainer(AGENT, env, train, device="cuda:0")
     for it in range(a.iterations):
