@@ -367,10 +367,7 @@ typedef struct sss_gnn_encode_args {
   int64_t n_nodes, n_jobs;
   int32_t n_obs, max_depth;
   float slope;
-  int32_t layers_mode; /* the DAG layers: 1 = one launch per layer over the layer's receiving nodes of all observations; 2 = ONE launch,
-                          a wave per observation walking its layers (message passing never leaves an observation; the same
-                          arithmetic per node - bit-identical embeddings - and no start-up / drain per layer; needs none of the
-                          lists); 0 = the library chooses (2 from 256 observations on) */
+  int32_t pad_;
   const float* w_prep_dev;
   const float* w_update_dev;
   const float* w_msg_dev;

@@ -24,19 +24,6 @@ SSS_DEV mfma_f4 leaky4(mfma_f4 v, float slope) {
   return o;
 }
 
-#ifdef GNN_OBS_PROF  // timing build (tests/gpu_variant.py obsprof, tools/debug/layers_obs_prof.py): shader cycles per section, summed over waves
-__device__ unsigned long long g_obs_prof[16];
-#define OBS_T(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long var = clock64()
-struct ObsProf { unsigned long long v[16] = {0}; };  // a wave's own sums, added to the table once at the end
-#define OBS_ADD(i, val) (P.v[i] += (unsigned long long)(val))
-#define OBS_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; i_++) if (i_ != 1 && P.v[i_]) atomicAdd(&g_obs_prof[i_], P.v[i_]); atomicMax(&g_obs_prof[1], P.v[0]); } } while (0)
-#else
-struct ObsProf {};
-#define OBS_T(var) ((void)0)
-#define OBS_ADD(i, val) ((void)0)
-#define OBS_FLUSH() ((void)0)
-#endif
-
 // the A operands and bias registers of one 16 -> 32 -> 16 -> 16 MLP for lane l (i = l & 15, q = l >> 4)
 struct MfmaGnnMlp {
   float a1[2][4];  // [t'][r]  W1[16 t' + i][4 q + r]
@@ -138,13 +125,67 @@ SSS_DEV void gnn_layer_mfma_rows(const SssGnnArgs& a, const MfmaGnnMlp& msg, con
     *(mfma_f4*)(nxt + n * 16 + 4 * q) = hi + y;
   }
 }
+// The same tile with its loads batched - what a wave of a layer launch waits for is the chain of dependent loads, so three
+// round trips instead of three per out-edge slot: (a) everything that depends on the row's node alone, (b) the layer bits and
+// end points of up to four out-edge slots at once, (c) the children's receiver bits together with BOTH copies of their
+// embeddings (the right one is picked when the bits are there). Needs node_recv; same arithmetic in the same order -
+// bit-identical embeddings. 18.7 -> 14.7 us per launch at 4096 envs (profiles/r05_layers_per_observation.txt, which also has
+// the measured dead end: all layers in one launch with a wave per observation).
+SSS_DEV void gnn_layer_mfma_rows_batched(const SssGnnArgs& a, const MfmaGnnMlp& msg, const MfmaGnnMlp& upd, int64_t n, int layer, int lane) {
+  const int q = lane >> 4;
+  const uint32_t above = layer >= 31 ? 0u : ~((2u << layer) - 1u);
+  const bool valid = n >= 0;
+  const int64_t nn = valid ? n : 0;
+  const int64_t e0 = a.out_start[nn];
+  const int deg = valid ? a.out_deg[nn] : 0;
+  const uint32_t rv = (uint32_t)a.node_recv[nn];
+  const mfma_f4 hi = *(const mfma_f4*)(a.h_init + nn * 16 + 4 * q);
+  mfma_f4 acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  float used = 0.0f;
+  for (int k0 = 0; __builtin_amdgcn_ballot_w64(k0 < deg) != 0; k0 += 4) {
+    bool use[4];
+    int64_t c[4];
+    uint32_t el[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool in = k0 + u < deg;
+      const int64_t e = in ? e0 + k0 + u : 0;
+      el[u] = in ? a.edge_layers[e] : 0u;
+      c[u] = in ? a.dst[e] : nn;
+    }
+    uint32_t rc[4];
+    mfma_f4 xh[4], xt[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      use[u] = (el[u] >> layer) & 1u;
+      if (!use[u]) c[u] = nn;  // (a row of this observation: both copies readable, nothing of it used)
+      rc[u] = (uint32_t)a.node_recv[c[u]];
+      xh[u] = *(const mfma_f4*)(a.h + c[u] * 16 + 4 * q);
+      xt[u] = *(const mfma_f4*)(a.tmp + c[u] * 16 + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (__builtin_amdgcn_ballot_w64(use[u]) == 0) continue;  // (no row of the tile has such an edge: nothing would be added)
+      const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      const mfma_f4 x = use[u] ? ((__builtin_popcount(rc[u] & above) & 1) ? xt[u] : xh[u]) : zero;
+      const mfma_f4 h2 = msg.hidden(x, a.slope);
+      if (use[u]) acc += h2, used += 1.0f;
+    }
+  }
+  const mfma_f4 agg = msg.out(acc, used);
+  const mfma_f4 y = upd.out(upd.hidden(agg, a.slope), 1.0f);
+  if (valid) {
+    float* nxt = (__builtin_popcount(rv & above) & 1) ? a.h : a.tmp;
+    *(mfma_f4*)(nxt + n * 16 + 4 * q) = hi + y;
+  }
+}
+
 // One tile: rows idx0[first + j], j < count (count <= 16), of DAG layer `layer`.
-SSS_DEV void gnn_layer_mfma_rows_obs(const SssGnnArgs& a, const MfmaGnnMlp& msg, const MfmaGnnMlp& upd, int64_t n, int layer, int lane, ObsProf& P);
 SSS_DEV void gnn_layer_mfma_tile(const SssGnnArgs& a, const MfmaGnnMlp& msg, const MfmaGnnMlp& upd, const int64_t* idx0, int64_t first, int count, int layer,
-                                  int lane, ObsProf& P) {
+                                  int lane) {
   const int j = lane & 15;
   const int64_t n = j < count ? idx0[first + j] : -1;
-  if (a.node_recv) gnn_layer_mfma_rows_obs(a, msg, upd, n, layer, lane, P);  // (the same arithmetic with the loads of a tile batched)
+  if (a.node_recv) gnn_layer_mfma_rows_batched(a, msg, upd, n, layer, lane);  // (the same arithmetic with the loads of a tile batched)
   else gnn_layer_mfma_rows(a, msg, upd, n, layer, lane);
 }
 
@@ -159,13 +200,12 @@ __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   MfmaGnnMlp msg, upd;
-  ObsProf P;
   msg.load(a.w, lane), upd.load(a.w2, lane);
   if (a.n_rows_dev) a.n_rows = *a.n_rows_dev;  // (the row count of a step without a host round trip)
   const int64_t n_tiles = (a.n_rows + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t left = a.n_rows - tile * 16;
-    gnn_layer_mfma_tile(a, msg, upd, a.idx0, tile * 16, left < 16 ? (int)left : 16, a.layer, lane, P);
+    gnn_layer_mfma_tile(a, msg, upd, a.idx0, tile * 16, left < 16 ? (int)left : 16, a.layer, lane);
   }
 }
 
@@ -174,174 +214,6 @@ static int gnn_layer_mfma_launch(const SssGnnArgs& a, void* stream) {
   const int64_t wgs = (a.n_rows + 63) / 64;  // four tiles of 16 rows per workgroup and pass
   const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
   hipLaunchKernelGGL(sss_gnn_layer_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-// ALL the DAG layers of a pass in ONE launch, one wave per OBSERVATION. Message passing never leaves an observation (edges join
-// nodes of one job), so the only ordering the layers need is inside an observation - which a wave has for free: no launch
-// boundary, no device-wide barrier between layers. A row's arithmetic does not depend on which rows share its tile, so the
-// embeddings are bit-identical to the launch-by-launch path. The embeddings stay in global memory (`h` / `tmp` alternate per
-// update exactly as above); a wave reads back what it wrote itself, ordered by a workgroup-scope fence between layers.
-//
-// What the wave waits for is the chain of dependent loads of a tile, nine layers deep, so the tile procedure here has three
-// round trips where the per-layer launch has three per out-edge slot: (a) everything that depends on the row's node alone,
-// (b) the layer bits and end points of up to four out-edge slots at once, (c) the children's receiver bits together with BOTH
-// copies of their embeddings (the right one is picked when the bits are there). The receiving nodes of each layer are
-// compacted over the whole observation first (one pass over its receiver bits, 16-bit positions in LDS, the lists' lengths from
-// the graph kernel's per-observation counts): ~13 receivers of a 200-node observation make one tile per layer, not one per
-// 64-node chunk.
-#define GNN_OBS_LIST_CAP 3072  // list entries (node, layer) per observation kept in LDS; a larger observation compacts chunk by chunk
-SSS_DEV void gnn_layer_mfma_rows_obs(const SssGnnArgs& a, const MfmaGnnMlp& msg, const MfmaGnnMlp& upd, int64_t n, int layer, int lane, ObsProf& P) {
-  const int q = lane >> 4;
-  const uint32_t above = layer >= 31 ? 0u : ~((2u << layer) - 1u);
-  const bool valid = n >= 0;
-  OBS_T(t0);
-  const int64_t nn = valid ? n : 0;
-  const int64_t e0 = a.out_start[nn];
-  const int deg = valid ? a.out_deg[nn] : 0;
-  const uint32_t rv = (uint32_t)a.node_recv[nn];
-  const mfma_f4 hi = *(const mfma_f4*)(a.h_init + nn * 16 + 4 * q);
-  mfma_f4 acc = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-  float used = 0.0f;
-  OBS_T(t1);
-  OBS_ADD(4, t1 - t0);
-  for (int k0 = 0; __builtin_amdgcn_ballot_w64(k0 < deg) != 0; k0 += 4) {
-    OBS_T(t1b);
-    bool use[4];
-    int64_t c[4];
-    uint32_t el[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const bool in = k0 + u < deg;
-      const int64_t e = in ? e0 + k0 + u : 0;
-      el[u] = in ? a.edge_layers[e] : 0u;
-      c[u] = in ? a.dst[e] : nn;
-    }
-    OBS_T(t2);
-    uint32_t rc[4];
-    mfma_f4 xh[4], xt[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      use[u] = (el[u] >> layer) & 1u;
-      if (!use[u]) c[u] = nn;  // (a row of this observation: both copies readable, nothing of it used)
-      rc[u] = (uint32_t)a.node_recv[c[u]];
-      xh[u] = *(const mfma_f4*)(a.h + c[u] * 16 + 4 * q);
-      xt[u] = *(const mfma_f4*)(a.tmp + c[u] * 16 + 4 * q);
-    }
-    OBS_T(t3);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (__builtin_amdgcn_ballot_w64(use[u]) == 0) continue;  // (no row of the tile has such an edge: nothing would be added)
-      const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
-      const mfma_f4 x = use[u] ? ((__builtin_popcount(rc[u] & above) & 1) ? xt[u] : xh[u]) : zero;
-      const mfma_f4 h2 = msg.hidden(x, a.slope);
-      if (use[u]) acc += h2, used += 1.0f;
-      OBS_ADD(12, 1);
-    }
-    OBS_T(t4);
-    OBS_ADD(5, t2 - t1b); OBS_ADD(6, t3 - t2); OBS_ADD(7, t4 - t3); OBS_ADD(13, 1);
-  }
-  OBS_T(t5);
-  const mfma_f4 agg = msg.out(acc, used);
-  const mfma_f4 y = upd.out(upd.hidden(agg, a.slope), 1.0f);
-  if (valid) {
-    float* nxt = (__builtin_popcount(rv & above) & 1) ? a.h : a.tmp;
-    *(mfma_f4*)(nxt + n * 16 + 4 * q) = hi + y;
-  }
-  OBS_T(t6);
-  OBS_ADD(8, t6 - t5); OBS_ADD(10, 1);
-}
-
-__global__ __launch_bounds__(256) void sss_gnn_layers_obs_kernel(SssGnnArgs a, const int64_t* __restrict__ obs_node_off, const int64_t* __restrict__ obs_nodes,
-                                                                 const int32_t* __restrict__ layer_cnt, int n_obs, int max_depth) {
-  __shared__ uint16_t lists[4][GNN_OBS_LIST_CAP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int obs = (int)blockIdx.x * 4 + wave;
-  if (obs >= n_obs) return;
-  ObsProf P;
-  OBS_T(k0);
-  const int cnt = (int)obs_nodes[obs];
-  if (cnt == 0) return;
-  const int64_t n0 = obs_node_off[obs];
-  // lane l: length and start of layer l's list
-  const int len = lane < max_depth ? layer_cnt[(size_t)lane * n_obs + obs] : 0;
-  int off = len;
-  for (int s = 1; s < 32; s <<= 1) {
-    const int t = __shfl_up(off, s);
-    if (lane >= s) off += t;
-  }
-  const int total = __shfl(off, 31);
-  off -= len;
-  if (total == 0) return;
-  MfmaGnnMlp msg, upd;
-  msg.load(a.w, lane), upd.load(a.w2, lane);
-  OBS_T(k1);
-  OBS_ADD(2, k1 - k0);
-  const uint64_t lt = (1ull << lane) - 1ull;
-  const uint32_t depth_mask = max_depth < 32 ? (1u << max_depth) - 1u : ~0u;  // (the per-layer launches stop at max_depth as well)
-  if (total <= GNN_OBS_LIST_CAP && cnt <= 65536) {
-    uint16_t* list = lists[wave];
-    int run = off;
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-      const uint32_t rv = c0 + lane < cnt ? (uint32_t)a.node_recv[n0 + c0 + lane] & depth_mask : 0u;
-      if (__builtin_amdgcn_ballot_w64(rv != 0) == 0) continue;
-      for (int l = 0; l < max_depth; l++) {
-        const bool on = (rv >> l) & 1u;
-        const uint64_t m = __builtin_amdgcn_ballot_w64(on);
-        if (m == 0) continue;
-        const int base = __builtin_amdgcn_readlane(run, l);
-        if (on) list[base + __builtin_popcountll(m & lt)] = (uint16_t)(c0 + lane);
-        if (lane == l) run += __builtin_popcountll(m);
-      }
-    }
-    __threadfence_block();
-    OBS_T(k2);
-    OBS_ADD(3, k2 - k1);
-    for (int l = max_depth - 1; l >= 0; l--) {
-      const int c = __builtin_amdgcn_readlane(len, l);
-      if (c == 0) continue;
-      const int o = __builtin_amdgcn_readlane(off, l);
-      for (int t = 0; 16 * t < c; t++) {
-        const int r = 16 * t + (lane & 15);
-        gnn_layer_mfma_rows_obs(a, msg, upd, r < c ? n0 + list[o + r] : -1, l, lane, P);
-      }
-      OBS_T(f0);
-      __threadfence_block();  // the next layer reads what this one wrote (same wave, other lanes)
-      OBS_T(f1);
-      OBS_ADD(9, f1 - f0);
-    }
-    OBS_T(k3);
-    OBS_ADD(0, k3 - k0); OBS_ADD(11, 1); OBS_FLUSH();
-    return;
-  }
-  // an observation whose lists do not fit: the receiving nodes of a layer compacted chunk by chunk (one ballot + one ds_permute)
-  uint32_t layers = 0;
-  for (int l = 0; l < max_depth; l++)
-    if (__builtin_amdgcn_readlane(len, l)) layers |= 1u << l;
-  while (layers) {
-    const int l = 31 - __builtin_clz(layers);
-    layers &= ~(1u << l);
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-      const bool on = c0 + lane < cnt && (((uint32_t)a.node_recv[n0 + c0 + lane] >> l) & 1u);
-      const uint64_t m = __builtin_amdgcn_ballot_w64(on);
-      if (m == 0) continue;
-      const int n_on = __builtin_popcountll(m);
-      // lane r < n_on receives the chunk position of the chunk's r-th receiving node (a permutation of the lanes: the others go behind)
-      const int to = on ? __builtin_popcountll(m & lt) : n_on + __builtin_popcountll(~m & lt);
-      const int sel = __builtin_amdgcn_ds_permute(to << 2, lane);
-      for (int t = 0; 16 * t < n_on; t++) {
-        const int r = 16 * t + (lane & 15);
-        const int pos = __shfl(sel, r);
-        gnn_layer_mfma_rows_obs(a, msg, upd, r < n_on ? n0 + c0 + pos : -1, l, lane, P);
-      }
-    }
-    __threadfence_block();
-  }
-}
-static int gnn_layers_obs_launch(const SssGnnArgs& a, const int64_t* obs_node_off, const int64_t* obs_nodes, const int32_t* layer_cnt, int n_obs, int max_depth,
-                                 void* stream) {
-  hipLaunchKernelGGL(sss_gnn_layers_obs_kernel, dim3((unsigned)((n_obs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, obs_node_off, obs_nodes, layer_cnt, n_obs,
-                     max_depth);
   return (int)hipGetLastError();
 }
 

@@ -20,7 +20,6 @@
 #include <stdlib.h>
 #include "zig_tables.inc"
 
-#define BE_UNAVAILABLE (-1000)
 static int be_set_device(int device) { return (int)hipSetDevice(device); }
 // launches of a handle go to the handle's device whatever the caller's current device is, and leave
 // the caller's current device as it was
@@ -244,20 +243,5 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
   }
   return -1;
 }
-
-// all DAG layers of a pass in one launch (sss_gnn_mfma.h); BE_UNAVAILABLE: this build has no such kernel
-static int be_launch_gnn_layers_obs(const SssGnnArgs& a, const int64_t* obs_node_off, const int64_t* obs_nodes, const int32_t* layer_cnt, int n_obs, int max_depth,
-                                    void* stream) {
-  if (kVectorForms) return BE_UNAVAILABLE;
-  return gnn_layers_obs_launch(a, obs_node_off, obs_nodes, layer_cnt, n_obs, max_depth, stream);
-}
-
-#ifdef GNN_OBS_PROF  // timing build only: reads and clears the per-section cycle counts of sss_gnn_layers_obs_kernel
-extern "C" int sss_debug_obs_prof(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_obs_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-  static const unsigned long long zeros[16] = {0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_obs_prof), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 #include "sss_host.h"

@@ -672,12 +672,11 @@ class DecimaPolicy(nn.Module):
         tot_t, recv_t, stride = (g["layer_totals"], ls["recv"], ls["stride"]) if fresh else (sc["tot"], sc["recv"], 0)
         # (the structure is kept per set of buffers - an inference loop passes the same ones step after step; filling its 40
         # fields costs more host time than the launches it describes)
-        mode = int(getattr(self, "_layers_mode", 0))  # (include/sss.h sss_gnn_encode_args.layers_mode; 0: the library chooses)
-        key = (M, J, B, D, mode, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
+        key = (M, J, B, D, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
                recv_t.numel(), stride, g["obs_nodes"].data_ptr(), g["totals_dev"].data_ptr() if on_dev else 0)
         kept = sc.get("args") if on_dev else None  # (graphs with exact sizes bring new buffers every call: nothing to keep, and nothing kept alive)
         if kept is None or kept[0] != key:
-            a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), mode, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
+            a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
                                  p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
                                  p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
                                  p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,

@@ -8,8 +8,6 @@ import os.path as osp
 
 HERE = osp.dirname(osp.abspath(__file__))
 VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
-            # shader cycles per section of the one-launch DAG layers (csrc/sss_gnn_mfma.h; tools/debug/layers_obs_prof.py)
-            "obsprof": ("-DGNN_OBS_PROF",),
             # timing builds for tools/debug/evprof3.py (scoped profiler of the lane-0 procedures, csrc/sss_prof.h)
             "evprof3": ("-DSSS_EVPROF3",), "evprof3b": ("-DSSS_EVPROF3", "-DSSS_EVPROF3B"), "evprof3c": ("-DSSS_EVPROF3", "-DSSS_EVPROF3C"),
             "evprof3d": ("-DSSS_EVPROF3", "-DSSS_EVPROF3D"),
