@@ -391,9 +391,12 @@ SSS_KERNEL void sss_decima_sample_stage_kernel(SssDecimaSampleArgs d) {
   const float* row = d.stage_scores + (size_t)env * d.n_pad;
   float best_key = -__builtin_inff(), best_score = 0.0f, m_run = -__builtin_inff(), s_run = 0.0f;
   uint32_t best_i = 0x7FFFFFFFu;
+  const int64_t* rank = d.sched_rank + d.obs_node_off[env];
   for (int i = lane; i < n; i += 64) {
     float sc = row[i];
-    if (sc == -__builtin_inff()) continue;
+    // (a slot that is not a schedulable stage holds -inf - or, in a score matrix that is refilled without being cleared, whatever an
+    // earlier pass left there: the stage's rank decides as well)
+    if (rank[i] < 0 || sc == -__builtin_inff()) continue;
     float key = sc + dp_gumbel(d.rng_seed, d.rng_counter, env, (uint32_t)i, 0);
     if (key > best_key) best_key = key, best_i = (uint32_t)i, best_score = sc;
     float m_new = sc > m_run ? sc : m_run;

@@ -281,6 +281,52 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
   }
 }
 
+// DAGSUM / GLOBSUM with 16 lanes per row: lane g sums feature g of the segment's hidden vectors (the rows of a job's nodes / an
+// observation's jobs are contiguous: each step reads one 64-byte row) in the order of sss_gnn.h's loop, then takes output g of
+// the last Linear with gnn_dot's four accumulators - the additions in the same order as the one-thread-per-row form (whose
+// compiled multiply-adds may be fused differently: last-bit differences), eight rows of the segment in flight per step.
+template <int KIND>
+__global__ __launch_bounds__(256) void sss_gnn_sum16_kernel(SssGnnArgs a) {
+  constexpr int IN = KIND == GNN_DAGSUM ? GNN_NF + 16 : 16;
+  const int g = threadIdx.x & 15;
+  const float* W3 = a.w + 32 * IN + 32 + 16 * 32 + 16;
+  float w[16];
+  static_for<16>([&](auto ic) { w[decltype(ic)::value] = W3[g * 16 + decltype(ic)::value]; });
+  const float b3 = W3[256 + g];
+  const int64_t rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  float* out = KIND == GNN_DAGSUM ? a.h_dag : a.h_glob;
+  for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (int64_t)gridDim.x * 16) {
+    const int64_t first = KIND == GNN_DAGSUM ? a.job_first[r] : a.obs_job_off[r], cnt = KIND == GNN_DAGSUM ? a.job_nodes[r] : a.obs_jobs[r];
+    float acc = 0.0f;
+    const float* __restrict__ src = a.tmp + first * 16 + g;
+    int64_t n = 0;
+    for (; n + 8 <= cnt; n += 8) {  // eight rows in flight, added in order
+      float t[8];
+      static_for<8>([&](auto uc) { t[decltype(uc)::value] = src[(n + decltype(uc)::value) * 16]; });
+      static_for<8>([&](auto uc) { acc += t[decltype(uc)::value]; });
+    }
+    {
+      float t[8];
+      static_for<8>([&](auto uc) { t[decltype(uc)::value] = n + decltype(uc)::value < cnt ? src[(n + decltype(uc)::value) * 16] : 0.0f; });
+      static_for<8>([&](auto uc) { if (n + decltype(uc)::value < cnt) acc += t[decltype(uc)::value]; });
+    }
+    float a0 = b3 * (float)cnt, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    static_for<4>([&](auto kc) {
+      constexpr int i = 4 * decltype(kc)::value;
+      a0 = __builtin_fmaf(w[i], row_bcast<i>(acc), a0), a1 = __builtin_fmaf(w[i + 1], row_bcast<i + 1>(acc), a1);
+      a2 = __builtin_fmaf(w[i + 2], row_bcast<i + 2>(acc), a2), a3 = __builtin_fmaf(w[i + 3], row_bcast<i + 3>(acc), a3);
+    });
+    out[r * 16 + g] = (a0 + a1) + (a2 + a3);
+  }
+}
+template <int KIND>
+static int gnn_sum16_launch(const SssGnnArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  const int64_t wgs = (a.n_rows + 15) / 16;
+  hipLaunchKernelGGL(sss_gnn_sum16_kernel<KIND>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 template <int KIND>
 constexpr int gnn16_lds_floats() {
   return KIND == GNN_LAYER ? 2 * MlpGnn::TOTAL : KIND == GNN_PREP ? MlpPrep::TOTAL : KIND == GNN_DAGHID ? MlpDag::TOTAL

@@ -126,9 +126,40 @@ static int be_launch_decima_sample(int n_obs, int which, const SssDecimaSampleAr
 #include "sss_gnn_mfma.h"
 #include "sss_train16.h"
 
-__global__ __launch_bounds__(256) void sss_prefix_rows_kernel(SssPrefixArgs a) {
-  __shared__ int64_t part[256];
-  prefix_row(a, (int)blockIdx.x, (int)threadIdx.x, 256, part, [] { __syncthreads(); });
+// one workgroup per row (sss_decima.h prefix_row is the emulator's form of the same thing): a contiguous run of columns per
+// thread, the threads' sums scanned inside each wave by shuffles and across the waves through LDS
+#define SSS_PREFIX_THREADS 1024  // (a row is one workgroup: the more threads, the fewer dependent rounds of loads per thread)
+__global__ __launch_bounds__(SSS_PREFIX_THREADS) void sss_prefix_rows_kernel(SssPrefixArgs a) {
+  __shared__ int64_t wave_tot[SSS_PREFIX_THREADS / 64];
+  const int row = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (a.n_cols + SSS_PREFIX_THREADS - 1) / SSS_PREFIX_THREADS;
+  const int c0 = tid * per, c1 = c0 + per < a.n_cols ? c0 + per : a.n_cols;
+  // (the loads unconditional and eight in flight: a masked-out column is read and dropped - a load behind the mask test waits for it)
+  auto at = [&](int c) -> int64_t {
+    const int32_t v = a.src[row * a.row_stride + c * a.col_stride];
+    const uint8_t m = a.mask ? a.mask[c] : (uint8_t)1;
+    return m ? (int64_t)v : 0;
+  };
+  int64_t sum = 0;
+#pragma unroll 8
+  for (int c = c0; c < c1; c++) sum += at(c);
+  int64_t incl = sum;
+  for (int s = 1; s < 64; s <<= 1) {
+    const int64_t t = __shfl_up(incl, s);
+    if (lane >= s) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int64_t base = incl - sum;
+  for (int w = 0; w < wave; w++) base += wave_tot[w];
+  if (tid == SSS_PREFIX_THREADS - 1) a.totals[row] = base + sum;
+#pragma unroll 8
+  for (int c = c0; c < c1; c++) {
+    const int64_t v = at(c);
+    a.off[(int64_t)row * a.n_cols + c] = base;
+    if (a.cnt) a.cnt[(int64_t)row * a.n_cols + c] = v;
+    base += v;
+  }
 }
 template <int NT>
 static void be_launch_wgrad_nt(const SssWgradArgs& a, int mt, dim3 grid, hipStream_t st) {
@@ -183,7 +214,7 @@ static int be_launch_collect(const SssCollectArgs& a, int phase, void* stream) {
 }
 
 static int be_launch_prefix_rows(const SssPrefixArgs& a, void* stream) {
-  hipLaunchKernelGGL(sss_prefix_rows_kernel, dim3((unsigned)a.n_rows), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sss_prefix_rows_kernel, dim3((unsigned)a.n_rows), dim3(SSS_PREFIX_THREADS), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -235,11 +266,12 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
     case GNN_SINK: return gnn_launch_kind<GNN_SINK>(a, stream);
     case GNN_DAGHID: return kVectorForms ? gnn_launch_kind<GNN_DAGHID>(a, stream) : gnn_rows_mfma_launch<GNN_DAGHID>(a, stream);
     case GNN_GLOBHID: return kVectorForms ? gnn_launch_kind<GNN_GLOBHID>(a, stream) : gnn_rows_mfma_launch<GNN_GLOBHID>(a, stream);
-    // copies and range sums: one thread per row (sss_gnn.h)
+    // copies: one thread per row (sss_gnn.h)
     case GNN_COMMIT: return gnn_launch_kind<GNN_COMMIT>(a, stream);
     case GNN_MERGE: return gnn_launch_kind<GNN_MERGE>(a, stream);
-    case GNN_DAGSUM: return gnn_launch_kind<GNN_DAGSUM>(a, stream);
-    case GNN_GLOBSUM: return gnn_launch_kind<GNN_GLOBSUM>(a, stream);
+    // range sums + the last Linear: 16 lanes per row (sss_gnn16.h), the same additions in the same order
+    case GNN_DAGSUM: return kVectorForms ? gnn_launch_kind<GNN_DAGSUM>(a, stream) : gnn_sum16_launch<GNN_DAGSUM>(a, stream);
+    case GNN_GLOBSUM: return kVectorForms ? gnn_launch_kind<GNN_GLOBSUM>(a, stream) : gnn_sum16_launch<GNN_GLOBSUM>(a, stream);
   }
   return -1;
 }

@@ -699,8 +699,11 @@ class DecimaPolicy(nn.Module):
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()
-    def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], _stream: int | None = None) -> torch.Tensor:
-        """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage"""
+    def _stage_scores_kernels(self, g: dict[str, Any], h: dict[str, torch.Tensor], _stream: int | None = None, for_draw_only: bool = False) -> torch.Tensor:
+        """f32[n_obs, n_pad] stage scores, -inf where the slot is not a schedulable stage.
+        `for_draw_only`: the matrix goes to `_sample_kernels` and nowhere else - on a capacity graph the kept matrix is then refilled
+        without the -inf pass over all of it (the draw skips the slots that are not schedulable stages by their rank; what an earlier
+        pass left in them is never read)"""
         M = g["x"].shape[0]
         rows_dev = None
         if "totals_dev" in g:  # capacity graph: the number of schedulable nodes is on the device; the score matrix is kept and refilled
@@ -708,8 +711,8 @@ class DecimaPolicy(nn.Module):
             key = (g["x"].device, g["n_obs"], g["n_pad"])
             if key not in ob:
                 ob.clear()
-                ob[key] = torch.empty((g["n_obs"], g["n_pad"]), dtype=torch.float32, device=g["x"].device)
-            out = ob[key].fill_(float("-inf"))
+                ob[key] = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
+            out = ob[key] if for_draw_only else ob[key].fill_(float("-inf"))
             hint = int(g["totals_hint"][3])
             rows, idx0, exact, rows_dev = (hint + hint // 4 + 64 if hint > 0 else g["sched_list"].numel()), g["sched_list"], 1, g["totals_dev"][3:4]
             rows = min(rows, g["sched_list"].numel())
@@ -838,7 +841,7 @@ class DecimaPolicy(nn.Module):
             with device_of(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
                 h = self._encode_kernels(g, stream)
-                return self._sample_kernels(g, h, self._stage_scores_kernels(g, h, stream), generator, _stream=stream)
+                return self._sample_kernels(g, h, self._stage_scores_kernels(g, h, stream, for_draw_only=True), generator, _stream=stream)
         # tensor-op path (other architectures, graphs built without the graph kernel)
         h = self.encode(g)
         s, idx = self.stage_scores(g, h)

@@ -284,6 +284,16 @@ for name, cfg, n_env, steps in (("c2", dict(num_executors=10, job_arrival_cap=50
     es = pol._exec_scores_kernels(g, h, jobs)
     for k, v in (("node", h["node"]), ("dag", h["dag"]), ("glob", h["glob"]), ("stage", s), ("exec", es)):
         out[name + "_" + k] = v.cpu().numpy()
+    # the range sums on their own, on the same random hidden vectors in both builds: 16 lanes per row (sss_gnn16.h
+    # sss_gnn_sum16_kernel) against one thread per row (sss_gnn.h) - the additions in the same order (multiply-adds may be fused differently)
+    w = pol._packed_weights()
+    gen = torch.Generator().manual_seed(11)
+    M, J, B = g["x"].shape[0], g["job_obs"].numel(), g["n_obs"]
+    tmp = torch.randn((max(M, J), 16), generator=gen).cuda()
+    hd, hg = torch.empty((J, 16), device="cuda:0"), torch.empty((B, 16), device="cuda:0")
+    pol._launch("dagsum", J, w["dag"], tmp=tmp, h_dag=hd, job_first=g["job_first"], job_nodes=g["job_nodes"])
+    pol._launch("globsum", B, w["glob"], tmp=tmp, h_glob=hg, obs_job_off=g["obs_job_off"], obs_jobs=g["obs_jobs"])
+    out[name + "_dagsum_alone"], out[name + "_globsum_alone"] = hd.cpu().numpy(), hg.cpu().numpy()
     env.close()
 np.savez(sys.argv[1], **out)
 '''
@@ -295,10 +305,13 @@ np.savez(sys.argv[1], **out)
         path = str(tmp_path / (tag + ".npz"))
         subprocess.run([sys.executable, "-c", script, path, root, os.path.join(root, "tests")] + extra, check=True, timeout=900)
         res[tag] = dict(np.load(path))
-    assert res["mfma"].keys() == res["valu"].keys() and len(res["mfma"]) == 10
+    assert res["mfma"].keys() == res["valu"].keys() and len(res["mfma"]) == 14
     for k, a in res["mfma"].items():
         b = res["valu"][k]
         assert a.shape == b.shape and a.size > 0
+        if k.endswith("_alone"):
+            assert np.abs(a - b).max() <= 2e-6 * max(1.0, float(np.abs(b).max())), (k, float(np.abs(a - b).max()))
+            continue
         fin = np.isfinite(b)
         assert (np.isfinite(a) == fin).all(), k  # (-inf marks slots that are not schedulable / executor counts beyond the cap)
         assert np.abs(a[fin] - b[fin]).max() <= 2e-5 * max(1.0, float(np.abs(b[fin]).max())), (k, float(np.abs(a[fin] - b[fin]).max()))
