@@ -171,11 +171,14 @@ typedef struct sss_decima_graph {
    * env in node order - the row list of the stage-score launch (sss_gnn_launch STAGE), with no padding */
   const int64_t* sched_off_dev;
   int64_t* sched_list_dev;
-  /* optional (all or none): the layers' lists of receiving nodes written by this launch itself - layer l's list at
-   * recv_lists_dev[l * recv_stride ..] (recv_stride >= the total node count), its length in layer_totals_dev[l] (i64[32], ZERO
-   * on entry). Envs reserve their share of a list with a fetch-add, so the order of the envs inside a list is not fixed (the
-   * layer launches treat rows independently). sss_gnn_encode takes them as they are (recv_stride there): no scan, no list
-   * kernel */
+  /* optional (all or none): the layers' lists of receiving nodes written by this launch itself. An env reserves its share of
+   * a list with a fetch-add on a counter it shares with its BLOCK of envs only - SSS_LIST_SETS = 32 blocks of
+   * q = ceil(num_envs / 32) consecutive envs (4096 envs adding to the same addresses: 35 us of a 78 us launch,
+   * profiles/r05_graph_kernel.txt) - so layer l's list is up to 32 dense pieces: block s's piece starts at
+   * recv_lists_dev[l * recv_stride + node_off_dev[s * q]] and has layer_totals_dev[l * 32 + s] entries (i64[32][32], ZERO on
+   * entry; recv_stride >= the total node count; a block's receivers are among its own nodes, so pieces never overlap). The
+   * order of the envs inside a piece is not fixed (the layer launches treat rows independently). sss_gnn_encode takes the
+   * pieces as they are (recv_stride there): no scan, no list kernel */
   int64_t* layer_totals_dev;
   int64_t* recv_lists_dev;
   int64_t recv_stride;
@@ -400,8 +403,9 @@ typedef struct sss_gnn_encode_args {
   int64_t* recv_dev;
   int64_t recv_cap;
   int64_t recv_stride;         /* 0: this call builds the lists (scan + list kernel into env_off_dev / layer_totals_dev / recv_dev);
-                                  > 0: sss_decima_graph_build wrote them - layer l at recv_dev[l * recv_stride ..], lengths in
-                                  layer_totals_dev (env_off_dev unused, may be NULL) */
+                                  > 0: sss_decima_graph_build wrote them - layer l's pieces at recv_dev[l * recv_stride ..], their
+                                  lengths in layer_totals_dev (then i64[32][32], see sss_decima_graph; env_off_dev unused, may be
+                                  NULL) */
   int64_t layer_rows_hint[32]; /* host values: roughly how many nodes layer l updates (e.g. layer_totals of the previous step,
                                   read back lazily); only sizes the launch grids - every row is processed whatever it says.
                                   -1: no idea (the grid is sized by n_nodes) */

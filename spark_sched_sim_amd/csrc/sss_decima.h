@@ -7,11 +7,12 @@
 // exec_supplies, the scalar block) plus the env's offsets into the flat outputs (exclusive prefix
 // sums of the per-env counts, computed by the caller); nothing of the simulator state is touched,
 // so the kernel is a pure function of the observation. LDS: 16 bytes per node slot
-// (generation, layer-membership bits / first out-edge, receiver bits, end of the out-edge range).
+// (generation, layer-membership bits / first out-edge, receiver bits, end of the out-edge range) + 8 per job slot (first node, supply).
 //
 // Included by sss_hip.hip (gfx950) and tests/emu/emu_backend.cpp (CPU wave emulator) after sss_sim.h.
 #pragma once
 
+#define SSS_LIST_SETS 32  // blocks of envs with their own list counters (sss_decima_graph_kernel)
 struct SssDecimaArgs {
   const uint8_t* active;  // u8[B] or null
   const int64_t *node_off, *job_off, *edge_off;
@@ -30,9 +31,13 @@ struct SssDecimaArgs {
   int32_t* layer_cnt;   // i32[32][B]: number of receiving nodes of DAG layer l in env b
   const int64_t* sched_off;  // nullable, i64[B]: exclusive prefix of the envs' schedulable-stage counts ...
   int64_t* sched_list;       // ... and where the flat ids of the schedulable nodes go, env by env in node order
-  // nullable: the layers' lists of receiving nodes written by this kernel itself - layer l's list is recv_lists[l * recv_stride ..]
-  // (recv_stride >= total node count), its length layer_totals[l] (i64[32], ZERO on entry): an env reserves its share of a list
-  // with one fetch-add, so the order of the envs inside a list varies from launch to launch (the layer launches do not care)
+  // nullable: the layers' lists of receiving nodes written by this kernel itself. An env reserves its share of a list with one
+  // fetch-add - on a counter it shares with its BLOCK of envs only (SSS_LIST_SETS blocks of consecutive envs): 4096 envs adding to
+  // the same 9 addresses were 35 us of a 78 us launch (same-address atomics retire one at a time, ~6 ns each;
+  // profiles/r05_graph_kernel.txt). Layer l's list is therefore up to SSS_LIST_SETS dense pieces: block s's piece starts at
+  // recv_lists[l * recv_stride + node_off[first env of s]] (a block's receivers are among its own nodes: the pieces cannot
+  // overlap) and has layer_totals[l * SSS_LIST_SETS + s] entries (i64[32][SSS_LIST_SETS], ZERO on entry); the order of the
+  // envs inside a piece varies from launch to launch (the layer launches do not care)
   int64_t* layer_totals;
   int64_t* recv_lists;
   int64_t recv_stride;
@@ -71,33 +76,51 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   uint32_t* memb = (uint32_t*)(g_dec_lds + (size_t)4 * L.n_cap);
   uint32_t* recv = (uint32_t*)(g_dec_lds + (size_t)8 * L.n_cap);
   int32_t* oend = (int32_t*)(g_dec_lds + (size_t)12 * L.n_cap);
+  // the env's job table next to them: every node looks its job up (a binary search over dag_ptr - in global memory that was four
+  // dependent round trips per 64 nodes)
+  int32_t* jp = (int32_t*)(g_dec_lds + (size_t)16 * L.n_cap);
+  int32_t* js = jp + (L.J_cap + 1);
   for (int i = lane; i < n; i += 64) gen[i] = 0, recv[i] = 0, oend[i] = 0;
+  for (int a = lane; a <= A; a += 64) jp[a] = dag_ptr[a], js[a] = a < A ? sup[a] : 0;
+  // the first 256 edges stay in registers (end points packed 16 + 16 bits: node slots are below 4096), the rest is re-read from the
+  // observation where a phase needs it: the relaxation below walks the edge list once per DAG level, and re-reading it from
+  // global memory every time was a third of the kernel (~45 dependent round trips per env at ~250 edges)
+  uint32_t ev[4];
+  for (int k = 0; k < 4; k++) {
+    const int e = 64 * k + lane;
+    ev[k] = e < ne ? ((uint32_t)el[2 * e] | ((uint32_t)el[2 * e + 1] << 16)) : 0u;
+  }
+  auto for_edges = [&](auto f) {
+    for (int k = 0; k < 4; k++) {
+      const int e = 64 * k + lane;
+      if (e < ne) f(e, (int)(ev[k] & 0xFFFFu), (int)(ev[k] >> 16));
+    }
+    for (int e = 256 + lane; e < ne; e += 64) f(e, el[2 * e], el[2 * e + 1]);
+  };
   wave_sync();
   // topological generations of the active subgraph (nx.topological_generations, utils.py:246-247):
   // longest-path relaxation over the edge list until nothing moves
   for (int it = 0; it <= n; it++) {
     bool moved = false;
-    for (int e = lane; e < ne; e += 64) {
-      int u = el[2 * e], v = el[2 * e + 1];
+    for_edges([&](int, int u, int v) {
       int gu = gen[u] + 1;
       if (gen[v] < gu) lane_atomic_max_i32(&gen[v], gu), moved = true;
-    }
+    });
     wave_sync();
     if (!wave_ballot(moved)) break;
   }
   // membership bits: bit l of memb[i] <=> node i is in (generation l) U succ(generation l)
   for (int i = lane; i < n; i += 64) memb[i] = 1u << gen[i];
   wave_sync();
-  for (int e = lane; e < ne; e += 64) lane_atomic_or_u32(&memb[el[2 * e + 1]], 1u << gen[el[2 * e]]);
+  for_edges([&](int, int u, int v) { lane_atomic_or_u32(&memb[v], 1u << gen[u]); });
   wave_sync();
   // edges: global endpoints, the layers whose mask holds the edge (both ends in the layer's node set)
-  for (int e = lane; e < ne; e += 64) {
-    int u = el[2 * e], v = el[2 * e + 1];
+  for_edges([&](int e, int u, int v) {
     uint32_t lay = memb[u] & memb[v];
     d.src[e0 + e] = n0 + u, d.dst[e0 + e] = n0 + v, d.edge_obs[e0 + e] = env;
     d.edge_layers[e0 + e] = lay;
     lane_atomic_or_u32(&recv[u], lay);
-  }
+  });
   wave_sync();
   // out-edge range of every node: edge_links is ordered by (job, source, destination)
   // (spark_sched_sim.py:249-258 + utils.subgraph keep the template's row-major edge order), so a
@@ -105,20 +128,36 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   int32_t* ostart = (int32_t*)memb;
   for (int i = lane; i < n; i += 64) ostart[i] = 0;
   wave_sync();
-  for (int e = lane; e < ne; e += 64) {
-    int u = el[2 * e];
-    if (e == 0 || el[2 * (e - 1)] != u) ostart[u] = e;
-    if (e == ne - 1 || el[2 * (e + 1)] != u) oend[u] = e + 1;
+  {
+    // (the neighbours of a register-resident edge come from the neighbouring lanes; wave-uniform: every lane takes part)
+    uint32_t prev_last = 0;
+    for (int k = 0; k < 4 && 64 * k < ne; k++) {
+      const int e = 64 * k + lane;
+      const uint32_t left = wave_bcast_u32(ev[k], (lane + 63) & 63), right = wave_bcast_u32(ev[k], (lane + 1) & 63);
+      const uint32_t next_first = k < 3 ? wave_bcast_u32(ev[k + 1], 0) : (256 < ne ? (uint32_t)el[2 * 256] : 0u);
+      if (e < ne) {
+        const int u = (int)(ev[k] & 0xFFFFu);
+        const int pu = lane > 0 ? (int)(left & 0xFFFFu) : (int)(prev_last & 0xFFFFu), nu = lane < 63 ? (int)(right & 0xFFFFu) : (int)(next_first & 0xFFFFu);
+        if (e == 0 || pu != u) ostart[u] = e;
+        if (e == ne - 1 || nu != u) oend[u] = e + 1;
+      }
+      prev_last = wave_bcast_u32(ev[k], 63);
+    }
+    for (int e = 256 + lane; e < ne; e += 64) {
+      int u = el[2 * e];
+      if (el[2 * (e - 1)] != u) ostart[u] = e;
+      if (e == ne - 1 || el[2 * (e + 1)] != u) oend[u] = e + 1;
+    }
   }
   wave_sync();
   // jobs: executor cap (env_wrapper.py:72-82), first node
   for (int a = lane; a < A; a += 64) {
-    int gap = E - sup[a];
+    int gap = E - js[a];
     if (gap < 0) gap = 0;
     int cap = gap < ncommit ? gap : ncommit;
     if (a == src_idx) cap = ncommit;
-    d.job_obs[j0 + a] = env, d.job_cap[j0 + a] = cap, d.job_first[j0 + a] = n0 + dag_ptr[a];
-    d.job_nodes[j0 + a] = dag_ptr[a + 1] - dag_ptr[a];
+    d.job_obs[j0 + a] = env, d.job_cap[j0 + a] = cap, d.job_first[j0 + a] = n0 + jp[a];
+    d.job_nodes[j0 + a] = jp[a + 1] - jp[a];
   }
   // nodes: features (env_wrapper.py:110-143), job, schedulable rank, generation
   uint32_t run = 0, depth = 0;
@@ -128,13 +167,13 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
     bool sched = false;
     if (i < n) {
       // job slot of node i: last a with dag_ptr[a] <= i
-      int lo = 0, hi = A;  // invariant: dag_ptr[lo] <= i < dag_ptr[hi]
+      int lo = 0, hi = A;  // invariant: jp[lo] <= i < jp[hi]  (jp: the env's dag_ptr in LDS)
       while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
-        if (dag_ptr[mid] <= i) lo = mid; else hi = mid;
+        if (jp[mid] <= i) lo = mid; else hi = mid;
       }
       int a = lo;
-      int supply = sup[a];
+      int supply = js[a];
       int gap = E - supply;
       if (gap < 0) gap = 0;
       int cap = gap < ncommit ? gap : ncommit;
@@ -171,10 +210,12 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   }
   if (lane < 32) d.layer_cnt[(size_t)lane * L.num_envs + env] = (int32_t)cnt;
   if (d.recv_lists) {
+    const int q = (L.num_envs + SSS_LIST_SETS - 1) / SSS_LIST_SETS, set = env / q;  // this env's block of envs
+    const int64_t set_n0 = d.node_off[set * q];
     int64_t base = 0;
-    if (lane < 32 && cnt) base = global_fetch_add_i64(d.layer_totals + lane, (int64_t)cnt);
+    if (lane < 32 && cnt) base = global_fetch_add_i64(d.layer_totals + lane * SSS_LIST_SETS + set, (int64_t)cnt);
     for (uint32_t l = 0; l < depth; l++) {
-      int64_t pos = (int64_t)l * d.recv_stride + (int64_t)wave_readlane_u64((uint64_t)base, (int)l);
+      int64_t pos = (int64_t)l * d.recv_stride + set_n0 + (int64_t)wave_readlane_u64((uint64_t)base, (int)l);
       for (int i0 = 0; i0 < n; i0 += 64) {
         const bool on = i0 + lane < n && ((recv[i0 + lane] >> l) & 1u);
         const uint64_t bal = wave_ballot(on);

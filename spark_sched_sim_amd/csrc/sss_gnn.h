@@ -68,6 +68,11 @@ struct SssGnnArgs {
                                 // after the lists of the layers below it (no host round trip for the list sizes); n_rows is then
                                 // an upper bound that sizes the grid
   int64_t idx0_stride;          // ... with layer_totals: > 0 = layer l's list starts at idx0[l * idx0_stride] (the graph kernel's lists)
+  // LAYER with the graph kernel's lists (sss_decima.h SssDecimaArgs::recv_lists): the layer's list is one dense piece per block of
+  // `list_q` consecutive observations - block s's piece starts at idx0[l * idx0_stride + seg_off[s * list_q]] and has
+  // layer_totals[l * SSS_LIST_SETS + s] rows (layer_totals is then i64[32][SSS_LIST_SETS]); list_q = 0: one dense list
+  const int64_t* seg_off;       // i64[n_seg] first node of every observation
+  int32_t n_seg, list_q;
   float slope;          // LeakyReLU negative slope (GNN MLPs)
   int E;                // EXEC: number of executors
   int layer;            // LAYER

@@ -146,6 +146,42 @@ SSS_DEV float hidden16_of(const float* m, float x, int g, float slope) {  // 16 
   return h[0];
 }
 
+// the pieces of a layer's list (sss_gnn.h list_q): lane s < 32 holds piece s - its length, its number of 16-row tiles, the running
+// tile count up to and including it, its first row in idx0; `total` = tiles of the layer
+struct GnnListPieces {
+  int64_t len, start;
+  int tiles, incl, total;
+  SSS_DEV void load(const SssGnnArgs& a, int lane) {
+    const int n_sets = (a.n_seg + a.list_q - 1) / a.list_q;
+    const bool mine = lane < n_sets && lane < SSS_LIST_SETS;
+    len = mine ? a.layer_totals[(int64_t)a.layer * SSS_LIST_SETS + lane] : 0;
+    start = (int64_t)a.layer * a.idx0_stride + (mine ? a.seg_off[(int64_t)lane * a.list_q] : 0);
+    tiles = (int)((len + 15) >> 4), incl = tiles;
+    for (int s = 1; s < 32; s <<= 1) {
+      const int t = __shfl_up(incl, s);
+      if ((lane & 31) >= s) incl += t;
+    }
+    total = __shfl(incl, 31);
+  }
+  // the same for a tile number the whole wave agrees on: one ballot, the piece's entries through scalar registers
+  SSS_DEV void tile_uniform(int t, int lane, int64_t& first, int& count) const {
+    const int s = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < SSS_LIST_SETS && incl <= t));  // pieces that end before tile t
+    const int local = t - (__builtin_amdgcn_readlane(incl, s) - __builtin_amdgcn_readlane(tiles, s));
+    const int64_t len_s = ((int64_t)__builtin_amdgcn_readlane((int)(len >> 32), s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)len, s);
+    const int64_t start_s = ((int64_t)__builtin_amdgcn_readlane((int)(start >> 32), s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)start, s);
+    const int64_t left = len_s - 16 * (int64_t)local;
+    first = start_s + 16 * (int64_t)local, count = left < 16 ? (int)left : 16;
+  }
+  // tile t of the layer: its first row in idx0 and its number of rows (any lane may ask for any tile)
+  SSS_DEV void tile(int t, int64_t& first, int& count) const {
+    int s = 0;
+    for (int k = 0; k < SSS_LIST_SETS; k++) s += __shfl(incl, k) <= t ? 1 : 0;  // pieces that end before tile t
+    const int local = t - (__shfl(incl, s) - __shfl(tiles, s));
+    const int64_t left = __shfl(len, s) - 16 * (int64_t)local;
+    first = __shfl(start, s) + 16 * (int64_t)local, count = left < 16 ? (int)left : 16;
+  }
+};
+
 // rows of a launch: 16 per workgroup of 256 threads at a time, looping; parameters staged once per workgroup
 #define GNN16_ROWS(r) for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4), r##_end = a.n_rows_dev ? *a.n_rows_dev : a.n_rows; r < r##_end; r += (int64_t)gridDim.x * 16)
 
@@ -156,7 +192,12 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
   const int g = threadIdx.x & 15;
   if (KIND == GNN_LAYER) {
     // tmp[r] = h_init[r] + update( sum over r's out-edges e in DAG layer l of msg(h[dst_e]) )
-    if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode): most workgroups of a sparse layer leave here
+    GnnListPieces pc;  // the graph kernel's lists (sss_gnn.h list_q): a dense piece per block of observations, walked tile by tile
+    if (a.list_q) {
+      pc.load(a, threadIdx.x & 63);
+      a.n_rows = 16 * (int64_t)pc.total;
+      if ((int64_t)blockIdx.x * 16 >= a.n_rows) return;
+    } else if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode): most workgroups of a sparse layer leave here
       int64_t off = (int64_t)a.layer * a.idx0_stride;
       if (a.idx0_stride == 0)
         for (int l = 0; l < a.layer; l++) off += a.layer_totals[l];
@@ -177,7 +218,14 @@ __global__ __launch_bounds__(256) void sss_gnn16_kernel(SssGnnArgs a) {
     const float* msg = w_lds;
     const float* upd = w_lds + MlpGnn::TOTAL;
     GNN16_ROWS(r) {
-      const int64_t n = a.idx0[r];
+      int64_t n;
+      if (a.list_q) {
+        int64_t first;
+        int count;
+        pc.tile((int)(r >> 4), first, count);
+        n = (int)(r & 15) < count ? a.idx0[first + (r & 15)] : -1;
+      } else
+        n = a.idx0[r];
       if (n < 0) continue;  // (whole rows: the 16 lanes of a row always agree)
       const int64_t e0 = a.out_start[n];
       const int deg = a.out_deg[n];

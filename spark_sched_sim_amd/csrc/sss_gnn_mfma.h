@@ -190,6 +190,21 @@ SSS_DEV void gnn_layer_mfma_tile(const SssGnnArgs& a, const MfmaGnnMlp& msg, con
 }
 
 __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
+  if (a.list_q) {  // the graph kernel's lists: a dense piece per block of observations
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    GnnListPieces pc;
+    pc.load(a, lane);
+    if ((int)blockIdx.x * 4 + wave >= pc.total) return;  // (before the parameters are fetched)
+    MfmaGnnMlp msg, upd;
+    msg.load(a.w, lane), upd.load(a.w2, lane);
+    for (int t = (int)blockIdx.x * 4 + wave; t < pc.total; t += (int)gridDim.x * 4) {
+      int64_t first;
+      int count;
+      pc.tile_uniform(t, lane, first, count);
+      gnn_layer_mfma_tile(a, msg, upd, a.idx0, first, count, a.layer, lane);
+    }
+    return;
+  }
   if (a.layer_totals) {  // list length and position from the device (sss_gnn_encode)
     int64_t off = (int64_t)a.layer * a.idx0_stride;
     if (a.idx0_stride == 0)

@@ -454,7 +454,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
       !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev ||
       !g->job_nodes_dev || !g->out_start_dev || !g->out_deg_dev || !g->layer_cnt_dev)
     return sss_fail(-1, "NULL argument");
-  if ((int64_t)16 * h->L.n_cap > 65536) return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
+  if ((int64_t)16 * h->L.n_cap + (int64_t)8 * (h->L.J_cap + 1) > 65536 || h->L.n_cap > 65535)
+    return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
   SssDecimaArgs d;
   d.active = g->active_dev, d.node_off = g->node_off_dev, d.job_off = g->job_off_dev, d.edge_off = g->edge_off_dev;
   d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale;
@@ -539,6 +540,7 @@ extern "C" int sss_gnn_launch(int kind, const sss_gnn_args* g, void* stream) {
   a.job_obs = g->job_obs_dev, a.job_first = g->job_first_dev, a.job_cap = g->job_cap_dev, a.job_nodes = g->job_nodes_dev;
   a.obs_job_off = g->obs_job_off_dev, a.obs_jobs = g->obs_jobs_dev;
   a.w16 = g->w16_dev, a.w2_16 = g->w2_16_dev, a.node_recv = g->node_recv_dev, a.layer_totals = nullptr, a.idx0_stride = 0;
+  a.seg_off = nullptr, a.n_seg = 0, a.list_q = 0;
   a.n_rows_dev = kind == GNN_LAYER ? nullptr : g->n_rows_dev;
   if (a.n_rows_dev && a.n_rows < 1) a.n_rows = 1;  // (the count is on the device: n_rows is a grid-size guess)
   if (kind == GNN_MERGE && !g->node_recv_dev) return sss_fail(-1, "NULL argument");
@@ -596,6 +598,8 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   a.out = nullptr;
   // the layers, deepest first (scheduler.py:209-211): embeddings alternate between h and tmp per update (sss_gnn.h)
   a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev, a.idx0_stride = g->recv_stride;
+  if (g->recv_stride)  // the graph kernel's lists: a dense piece per block of observations (sss_decima.h SSS_LIST_SETS)
+    a.seg_off = g->obs_node_off_dev, a.n_seg = g->n_obs, a.list_q = (g->n_obs + SSS_LIST_SETS - 1) / SSS_LIST_SETS;
   a.w2 = g->w_update_dev, a.w16 = g->w_msg16_dev, a.w2_16 = g->w_update16_dev;
   for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
     a.layer = lvl;
@@ -605,6 +609,7 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
     if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
   }
   a.idx0 = nullptr, a.layer_totals = nullptr, a.idx0_stride = 0, a.w2 = nullptr, a.w16 = nullptr, a.w2_16 = nullptr, a.layer = 0;
+  a.seg_off = nullptr, a.n_seg = 0, a.list_q = 0;
   if (int rc = run(GNN_DAGHID, rows_nodes, g->w_dag_dev, g->n_nodes_dev)) return fail("gnn", rc);  // (brings the embeddings left in tmp home: MERGE)
   a.node_recv = nullptr;
   if (int rc = run(GNN_DAGSUM, rows_jobs, g->w_dag_dev, g->n_jobs_dev)) return fail("gnn", rc);

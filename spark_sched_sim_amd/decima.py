@@ -642,6 +642,7 @@ class DecimaPolicy(nn.Module):
         import ctypes
 
         from .binding import SssGnnEncodeArgs, device_of
+        from .vec_env import LateHint  # (list sizes unknown until the first pass's lengths have come back: -1)
         x = g["x"]
         dev = x.device
         M, J, B, D = x.shape[0], g["job_obs"].numel(), g["n_obs"], int(g["max_depth"])
@@ -661,7 +662,6 @@ class DecimaPolicy(nn.Module):
         sc = pool.get((dev, stream))
         need = 1 if on_dev else max(M * D, 1)  # (a capacity graph always comes with the graph kernel's own lists)
         if sc is None or sc["recv"].numel() < need or sc["env_off"].numel() < 32 * B:
-            from .vec_env import LateHint  # (list sizes unknown until the first pass's lengths have come back: -1)
             sc = pool[(dev, stream)] = {"recv": torch.empty(max(2 * need, 1 << 16), dtype=torch.int64, device=dev),
                                       "env_off": torch.empty(32 * B, dtype=torch.int64, device=dev), "tot": torch.zeros(32, dtype=torch.int64, device=dev),
                                       "hint": LateHint(32, dev)}
@@ -686,8 +686,13 @@ class DecimaPolicy(nn.Module):
             if on_dev:
                 sc["args"] = kept
         a = kept[1]
-        # the list sizes of an EARLIER pass, copied back without waiting (the latest that have arrived: they only size grids)
-        a.layer_rows_hint[:] = sc["hint"].read().tolist()
+        # the list sizes of an EARLIER pass, copied back without waiting (the latest that have arrived: they only size grids);
+        # the graph kernel's lists come in pieces per block of envs (i64[32][32] lengths: a layer's rows are the sum over its pieces)
+        if fresh and "hint_pieces" not in sc:
+            sc["hint_pieces"] = LateHint(32 * 32, dev)
+        hint = sc["hint_pieces"] if fresh else sc["hint"]
+        hv = hint.read()
+        a.layer_rows_hint[:] = (hv.view(32, 32).clamp(min=0).sum(1) if hv[0] >= 0 else hv[:32]).tolist() if fresh else hv.tolist()
         if on_dev:
             a.n_nodes_hint, a.n_jobs_hint = int(g["totals_hint"][0]), int(g["totals_hint"][2])
         if _stream is not None:
@@ -695,7 +700,7 @@ class DecimaPolicy(nn.Module):
         else:
             with device_of(dev):
                 self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
-        sc["hint"].post(tot_t)
+        hint.post(tot_t)
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()

@@ -265,7 +265,7 @@ class VecSparkSchedSimEnv:
         without waiting (pinned memory) - grid sizes only. For act-and-forget inference (`DecimaPolicy.schedule_env`): the buffers are
         overwritten by the next call; graphs that are kept (rollout recording, training) use `decima_graph`."""
         B, dev, d = self.num_envs, self.device, self.dims
-        assert 16 * d.node_cap <= 65536, "the graph kernel's LDS working set does not fit this node capacity"
+        assert 16 * d.node_cap + 8 * (d.job_cap + 1) <= 65536, "the graph kernel's LDS working set does not fit this node capacity"
         D = self.max_dag_depth
         ws = getattr(self, "_dg_dev", None)
         if ws is None:
@@ -278,7 +278,7 @@ class VecSparkSchedSimEnv:
                 "job_obs": e(Jc, torch.int64), "job_cap": e(Jc, torch.int64), "job_first": e(Jc, torch.int64), "obs_depth": e(B, torch.int32),
                 "job_nodes": e(Jc, torch.int64), "out_start": e(Mc, torch.int64), "out_deg": e(Mc, torch.int32),
                 "layer_cnt": e(32, torch.int32, B), "sched_list": e(Mc, torch.int64),
-                "scan": e(2, torch.int64, 4, B), "tot": e(4, torch.int64), "layer_totals": torch.zeros(32, dtype=torch.int64, device=dev),
+                "scan": e(2, torch.int64, 4, B), "tot": e(4, torch.int64), "layer_totals": torch.zeros(32 * 32, dtype=torch.int64, device=dev),  # (i64[32][32]: a counter per layer and block of envs)
                 "recv": e(Mc * max(D, 1), torch.int64), "hint": LateHint(4, dev), "epoch": 0}
         act8 = _mask_u8(active)
         scan, tot = ws["scan"], ws["tot"]
@@ -327,7 +327,7 @@ class VecSparkSchedSimEnv:
         overwritten by the next such call) - for act-and-forget inference loops; graphs that are
         kept (rollout recording) must use the default."""
         B, dev = self.num_envs, self.device
-        if 16 * self.dims.node_cap > 65536:
+        if 16 * self.dims.node_cap + 8 * (self.dims.job_cap + 1) > 65536:
             # the kernel's per-node LDS working set does not fit: same graph from tensor ops on the device
             from .decima import compact_graph, decima_observation
             f = decima_observation(self._obs(), self.num_executors, self.dims.stage_stride, int(num_tasks_scale), work_scale)
@@ -379,7 +379,7 @@ class VecSparkSchedSimEnv:
             ls = self._layer_scratch[skey] = {"recv": torch.empty(max(2 * M, 1 << 14) * max(D, 1), dtype=torch.int64, device=dev), "epoch": 0}
         ls["epoch"] += 1
         ls["stride"] = ls["recv"].numel() // max(D, 1)
-        layer_totals = torch.zeros(32, dtype=torch.int64, device=dev)
+        layer_totals = torch.zeros(32 * 32, dtype=torch.int64, device=dev)  # (i64[32][32]: a counter per layer and block of envs)
         a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",

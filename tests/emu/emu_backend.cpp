@@ -247,6 +247,16 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
     case GNN_SINK: return gnn_run_kind<GNN_SINK>(a);
     case GNN_LAYER: {
       SssGnnArgs b = a;
+      if (b.list_q) {  // the graph kernel's lists (sss_gnn.h list_q): a dense piece per block of observations, piece after piece
+        const int n_sets = (b.n_seg + b.list_q - 1) / b.list_q;
+        for (int s = 0; s < n_sets && s < SSS_LIST_SETS; s++) {
+          SssGnnArgs c = b;
+          c.list_q = 0, c.layer_totals = nullptr, c.n_rows_dev = nullptr;
+          c.n_rows = b.layer_totals[(int64_t)b.layer * SSS_LIST_SETS + s], c.idx0 = b.idx0 + (int64_t)b.layer * b.idx0_stride + b.seg_off[(int64_t)s * b.list_q];
+          if (int rc = gnn_run_kind<GNN_LAYER>(c)) return rc;
+        }
+        return 0;
+      }
       if (b.layer_totals) {  // (the gfx950 kernel reads the list's length and position from the device, sss_gnn16.h)
         int64_t off = (int64_t)b.layer * b.idx0_stride;
         if (b.idx0_stride == 0)
