@@ -182,6 +182,10 @@ typedef struct sss_decima_graph {
   int64_t* layer_totals_dev;
   int64_t* recv_lists_dev;
   int64_t recv_stride;
+  /* optional: ANOTHER set of list counters (i64[32][32]) that this launch sets to zero - a caller that builds a graph per step
+   * keeps two sets and passes them in turn (this step's zeroed by the previous launch, the previous step's - its consumers are
+   * behind this launch in the stream - cleared now), which saves the clearing launch in between */
+  int64_t* layer_totals_clear_dev;
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
 

@@ -43,7 +43,7 @@ class SssDecimaGraph(C.Structure):
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
                 ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p), ("sched_off_dev", C.c_void_p), ("sched_list_dev", C.c_void_p),
-                ("layer_totals_dev", C.c_void_p), ("recv_lists_dev", C.c_void_p), ("recv_stride", C.c_int64)]
+                ("layer_totals_dev", C.c_void_p), ("recv_lists_dev", C.c_void_p), ("recv_stride", C.c_int64), ("layer_totals_clear_dev", C.c_void_p)]
 
 
 class SssDecimaLists(C.Structure):

@@ -40,6 +40,7 @@ struct SssDecimaArgs {
   // envs inside a piece varies from launch to launch (the layer launches do not care)
   int64_t* layer_totals;
   int64_t* recv_lists;
+  int64_t* layer_totals_clear;  // nullable: another set of counters, zeroed by this launch (the caller's next launch reserves on it)
   int64_t recv_stride;
 };
 
@@ -61,6 +62,8 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   const int32_t* oi = B.obs_i32 + (size_t)env * SSS_OBS_I32;
   bool on = d.active == nullptr || d.active[env] != 0;
   int n = on ? oi[OBS_N_NODES] : 0, ne = on ? oi[OBS_N_EDGES] : 0, A = on ? oi[OBS_N_JOBS] : 0;
+  if (d.layer_totals_clear)
+    for (int i = env * 64 + lane; i < 32 * SSS_LIST_SETS; i += L.num_envs * 64) d.layer_totals_clear[i] = 0;
   if (n == 0) {  // wave-uniform
     if (lane == 0) d.obs_depth[env] = 0;
     if (lane < 32) d.layer_cnt[(size_t)lane * L.num_envs + env] = 0;

@@ -317,7 +317,20 @@ __global__ __launch_bounds__(256) void sss_gnn_head_mfma_kernel(SssGnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float w_lds[];
   if (a.w2_16) {  // the host has the images ready (decima.py `_mfma_head_image`, the layout of MfmaHead::stage): a straight copy
     static_assert(H::TOTAL % 4 == 0, "images are copied 16 bytes at a time");
-    for (int t = threadIdx.x; t < H::TOTAL / 4; t += 256) ((float4*)w_lds)[t] = ((const float4*)a.w2_16)[t];
+    // (all of a thread's loads first, then its LDS writes: written as one loop the compiler waits for every load before the next
+    // is issued - eight to nine dependent round trips at the head of every workgroup)
+    constexpr int N4 = H::TOTAL / 4, IT = (N4 + 255) / 256;
+    float4 img[IT];
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = (int)threadIdx.x + 256 * i;
+      img[i] = ((const float4*)a.w2_16)[t < N4 ? t : N4 - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = (int)threadIdx.x + 256 * i;
+      if (t < N4) ((float4*)w_lds)[t] = img[i];
+    }
   } else
     H::stage(w_lds, a.w, IN, threadIdx.x, 256, [](int u, int f) {
       if (KIND == GNN_STAGE) return u == 0 ? GNN_NF + f : u == 1 ? GNN_NF + 16 + f : u == 2 ? GNN_NF + 32 + f : (f < GNN_NF ? f : -1);
@@ -374,7 +387,7 @@ static int gnn_head_mfma_launch(const SssGnnArgs& a, void* stream) {
   if (a.n_rows <= 0) return 0;
   constexpr int U = KIND == GNN_STAGE ? 4 : 3;
   const int64_t wgs = (a.n_rows + 63) / 64;
-  const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);  // (33 KB of LDS images per workgroup, staged once and reused over its tiles)
+  const unsigned grid = (unsigned)(wgs < 1024 ? wgs : 1024);  // (33 KB of LDS images per workgroup, staged once and reused over its tiles: four workgroups per CU)
   hipLaunchKernelGGL(sss_gnn_head_mfma_kernel<KIND>, dim3(grid), dim3(256), (size_t)MfmaHead<U>::TOTAL * sizeof(float), (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -466,6 +466,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   d.job_nodes = g->job_nodes_dev, d.out_start = g->out_start_dev, d.out_deg = g->out_deg_dev, d.layer_cnt = g->layer_cnt_dev;
   d.sched_off = g->sched_off_dev, d.sched_list = g->sched_off_dev ? g->sched_list_dev : nullptr;
   d.layer_totals = g->layer_totals_dev, d.recv_lists = g->layer_totals_dev ? g->recv_lists_dev : nullptr, d.recv_stride = g->recv_stride;
+  d.layer_totals_clear = g->layer_totals_clear_dev;
+  if (g->layer_totals_clear_dev && g->layer_totals_clear_dev == g->layer_totals_dev) return sss_fail(-1, "layer_totals_clear_dev must be another set of counters than layer_totals_dev");
   if (g->layer_totals_dev && (!g->recv_lists_dev || g->recv_stride < 1)) return sss_fail(-1, "NULL argument");
   if (g->sched_off_dev && !g->sched_list_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));

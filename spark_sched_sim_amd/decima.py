@@ -674,8 +674,11 @@ class DecimaPolicy(nn.Module):
         # fields costs more host time than the launches it describes)
         key = (M, J, B, D, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
                recv_t.numel(), stride, g["obs_nodes"].data_ptr(), g["totals_dev"].data_ptr() if on_dev else 0)
-        kept = sc.get("args") if on_dev else None  # (graphs with exact sizes bring new buffers every call: nothing to keep, and nothing kept alive)
-        if kept is None or kept[0] != key:
+        # (graphs with exact sizes bring new buffers every call: nothing to keep, and nothing kept alive; a capacity graph alternates
+        # between two sets of list counters: two structures)
+        memo = sc.setdefault("args", {}) if on_dev else None
+        kept = memo.get(key) if on_dev else None
+        if kept is None:
             a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
                                  p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
                                  p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
@@ -684,14 +687,17 @@ class DecimaPolicy(nn.Module):
                                  g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None, 0, 0)
             kept = (key, a, (w, x, h_init, h, tmp, h_dag, h_glob))  # (the tensors: kept alive with the pointers)
             if on_dev:
-                sc["args"] = kept
+                if len(memo) >= 4:
+                    memo.clear()
+                memo[key] = kept
         a = kept[1]
         # the list sizes of an EARLIER pass, copied back without waiting (the latest that have arrived: they only size grids);
         # the graph kernel's lists come in pieces per block of envs (i64[32][32] lengths: a layer's rows are the sum over its pieces)
-        if fresh and "hint_pieces" not in sc:
+        own_hint = not (fresh and "layer_hint" in g)  # (a capacity graph brings the piece lengths with its totals: one read-back for both)
+        if fresh and own_hint and "hint_pieces" not in sc:
             sc["hint_pieces"] = LateHint(32 * 32, dev)
-        hint = sc["hint_pieces"] if fresh else sc["hint"]
-        hv = hint.read()
+        hint = sc.get("hint_pieces") if fresh else sc["hint"]
+        hv = hint.read() if own_hint else g["layer_hint"]
         a.layer_rows_hint[:] = (hv.view(32, 32).clamp(min=0).sum(1) if hv[0] >= 0 else hv[:32]).tolist() if fresh else hv.tolist()
         if on_dev:
             a.n_nodes_hint, a.n_jobs_hint = int(g["totals_hint"][0]), int(g["totals_hint"][2])
@@ -700,7 +706,8 @@ class DecimaPolicy(nn.Module):
         else:
             with device_of(dev):
                 self._kb.check(self._kb.lib.sss_gnn_encode(ctypes.byref(a), stream))
-        hint.post(tot_t)
+        if own_hint:
+            hint.post(tot_t)
         return {"node": h, "dag": h_dag, "glob": h_glob}
 
     @torch.no_grad()

@@ -52,22 +52,27 @@ class LateHint:
         self.bufs = [b.pin_memory() for b in bufs] if self.cuda else bufs
         self.events = [torch.cuda.Event() for _ in range(2)] if self.cuda else None
         self.posted = [False, False]
+        self.tags = [None, None]
         self.last = 1
 
     def read(self) -> torch.Tensor:
+        return self.read_tagged()[0]
+
+    def read_tagged(self):
+        """(values, the `tag` their `post` was given); (fill, None) until a copy has completed"""
         for k in (self.last, 1 - self.last):
             if self.posted[k] and (not self.cuda or self.events[k].query()):
-                return self.bufs[k].clone()
-        return self.fill.clone()
+                return self.bufs[k].clone(), self.tags[k]
+        return self.fill.clone(), None
 
-    def post(self, t: torch.Tensor) -> None:
+    def post(self, t: torch.Tensor, tag=None) -> None:
         k = 1 - self.last
         if self.cuda and self.posted[k] and not self.events[k].query():
             return  # (the copy before last has not even finished: the host is far ahead - skip this one rather than wait)
         self.bufs[k].copy_(t, non_blocking=True)
         if self.cuda:
             self.events[k].record(torch.cuda.current_stream(t.device))
-        self.posted[k], self.last = True, k
+        self.posted[k], self.last, self.tags[k] = True, k, tag
 
 
 class VecSparkSchedSimEnv:
@@ -278,8 +283,13 @@ class VecSparkSchedSimEnv:
                 "job_obs": e(Jc, torch.int64), "job_cap": e(Jc, torch.int64), "job_first": e(Jc, torch.int64), "obs_depth": e(B, torch.int32),
                 "job_nodes": e(Jc, torch.int64), "out_start": e(Mc, torch.int64), "out_deg": e(Mc, torch.int32),
                 "layer_cnt": e(32, torch.int32, B), "sched_list": e(Mc, torch.int64),
-                "scan": e(2, torch.int64, 4, B), "tot": e(4, torch.int64), "layer_totals": torch.zeros(32 * 32, dtype=torch.int64, device=dev),  # (i64[32][32]: a counter per layer and block of envs)
-                "recv": e(Mc * max(D, 1), torch.int64), "hint": LateHint(4, dev), "epoch": 0}
+                "scan": e(2, torch.int64, 4, B),
+                # two sets of list counters (i64[32][32] each: a counter per layer and block of envs) used in turn - a launch reserves on
+                # one and clears the other - with the graph's four totals between them: [set 0 | totals | set 1], so that the totals and
+                # the current set are one contiguous piece for the read-back of the grid-size hints
+                "pp": torch.zeros(1024 + 4 + 1024, dtype=torch.int64, device=dev),
+                "recv": e(Mc * max(D, 1), torch.int64), "hint": LateHint(1028, dev), "epoch": 0}
+            ws["tot"] = ws["pp"][1024:1028]
         act8 = _mask_u8(active)
         scan, tot = ws["scan"], ws["tot"]
         stream = self._stream()
@@ -294,11 +304,10 @@ class VecSparkSchedSimEnv:
                                float(num_tasks_scale), float(work_scale), *(ws[k].data_ptr() for k in (
                                    "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
                                    "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
-                               off[3].data_ptr(), ws["sched_list"].data_ptr(), ws["layer_totals"].data_ptr(), ws["recv"].data_ptr(), stride)
+                               off[3].data_ptr(), ws["sched_list"].data_ptr(), None, ws["recv"].data_ptr(), stride, None)
             g0 = {k: ws[k] for k in ("x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst", "edge_obs",
                                      "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt", "sched_list")}
             g0["n_obs"], g0["n_pad"], g0["max_depth"] = B, d.node_cap, D
-            g0["layer_totals"] = ws["layer_totals"]
             g0["obs_nodes"], g0["obs_jobs"], g0["obs_node_off"], g0["obs_job_off"] = cnt_t[0], cnt_t[2], off[0], off[2]
             g0["totals_dev"], g0["_binding"] = tot, self._b
             ptrs = (self.obs_i32.data_ptr(), self.obs_i32.stride(0), scan[0].data_ptr(), scan[1].data_ptr(), tot.data_ptr())
@@ -307,13 +316,18 @@ class VecSparkSchedSimEnv:
         a.active_dev = mask_ptr
         with device_of(dev):
             self._b.check(self._b.lib.sss_prefix_rows(ptrs[0], 1, ptrs[1], mask_ptr, 4, B, ptrs[2], ptrs[3], ptrs[4], stream))
-            ws["layer_totals"].zero_()
             ws["epoch"] += 1
+            par, pp = ws["epoch"] & 1, ws["pp"]
+            sets = (pp[0:1024], pp[1028:2052])
+            a.layer_totals_dev, a.layer_totals_clear_dev = sets[par].data_ptr(), sets[1 - par].data_ptr()
             self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), stream))
             g = dict(g0)
+            g["layer_totals"] = sets[par]
             g["_layer_lists"] = ({"recv": ws["recv"], "stride": stride, "epoch": ws["epoch"]}, ws["epoch"])
-            g["totals_hint"] = ws["hint"].read()  # (M, Ed, J, S): the latest earlier call's totals that have arrived (-1: none yet)
-            ws["hint"].post(tot)
+            # the latest earlier call's numbers that have arrived: totals (M, Ed, J, S) and the lists' piece lengths (-1: none yet)
+            hv, tag = ws["hint"].read_tagged()
+            g["totals_hint"], g["layer_hint"] = (hv[:4], hv[:1024]) if tag is None else (hv[1024:1028], hv[:1024]) if tag == 0 else (hv[:4], hv[4:1028])
+            ws["hint"].post(pp[0:1028] if par == 0 else pp[1024:2052], tag=par)
         g["_keepalive"] = (off, act8)
         return g
 
@@ -384,7 +398,7 @@ class VecSparkSchedSimEnv:
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
                                "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
-                           off[3].data_ptr(), buf["sched_list"].data_ptr(), layer_totals.data_ptr(), ls["recv"].data_ptr(), ls["stride"])
+                           off[3].data_ptr(), buf["sched_list"].data_ptr(), layer_totals.data_ptr(), ls["recv"].data_ptr(), ls["stride"], None)
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
         g["max_depth"] = self.max_dag_depth
