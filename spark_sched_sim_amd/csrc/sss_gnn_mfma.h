@@ -387,7 +387,7 @@ static int gnn_head_mfma_launch(const SssGnnArgs& a, void* stream) {
   if (a.n_rows <= 0) return 0;
   constexpr int U = KIND == GNN_STAGE ? 4 : 3;
   const int64_t wgs = (a.n_rows + 63) / 64;
-  const unsigned grid = (unsigned)(wgs < 1024 ? wgs : 1024);  // (33 KB of LDS images per workgroup, staged once and reused over its tiles: four workgroups per CU)
+  const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);  // (33 KB of LDS images per workgroup, staged once and reused over its tiles; 1024 workgroups: no faster)
   hipLaunchKernelGGL(sss_gnn_head_mfma_kernel<KIND>, dim3(grid), dim3(256), (size_t)MfmaHead<U>::TOTAL * sizeof(float), (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
