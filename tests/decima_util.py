@@ -135,6 +135,7 @@ def compare_graphs(kg, cg, f):
     from spark_sched_sim_amd import VecSparkSchedSimEnv
     lists = VecSparkSchedSimEnv.decima_layer_lists(kg)
     assert len(lists) == len(layers) and all(torch.equal(a, r) for a, (_, r) in zip(lists, layers))
+    check_list_pieces(kg, [r for _, r in layers])
     # out-edge ranges: every edge lies in its source's range, ranges tile the edge list
     deg = torch.zeros(kg["x"].shape[0], dtype=torch.long, device=kg["x"].device).index_add_(0, kg["src"], torch.ones_like(kg["src"]))
     assert torch.equal(kg["out_deg"].long(), deg)
@@ -142,6 +143,57 @@ def compare_graphs(kg, cg, f):
     assert bool(((e_ids >= kg["out_start"][kg["src"]]) & (e_ids < kg["out_start"][kg["src"]] + deg[kg["src"]])).all())
     cnt = torch.zeros(kg["job_obs"].numel(), dtype=torch.long, device=deg.device).index_add_(0, kg["node_job"], torch.ones_like(kg["node_job"]))
     assert torch.equal(kg["job_nodes"], cnt)
+
+
+def check_list_pieces(kg, receivers):
+    """the graph kernel's own lists of receiving nodes (include/sss.h sss_decima_graph: per layer a dense piece per block of
+    q = ceil(num_envs / 32) consecutive envs, lengths in layer_totals[l][s], piece s of layer l at
+    recv[l * stride + node_off[s * q]]) hold exactly the layer's receivers: every piece lies inside its block's node range and
+    the pieces of a layer together are the layer's receivers, each once"""
+    ls, epoch = kg["_layer_lists"]
+    assert ls["epoch"] == epoch, "the lists belong to a later graph of this env"
+    B, stride, recv = kg["n_obs"], ls["stride"], ls["recv"]
+    tot = kg["layer_totals"].view(32, 32).cpu()
+    off = kg["obs_node_off"].cpu()
+    M = kg["x"].shape[0] if "totals_dev" not in kg else int(kg["totals_dev"][0])
+    q = (B + 31) // 32
+    n_sets = (B + q - 1) // q
+    assert int(tot[len(receivers):].sum()) == 0 and int(tot[:, n_sets:].sum()) == 0
+    for l, want in enumerate(receivers):
+        got = []
+        for s in range(n_sets):
+            lo = int(off[s * q])
+            hi = int(off[(s + 1) * q]) if (s + 1) * q < B else M
+            n = int(tot[l, s])
+            piece = recv[l * stride + lo: l * stride + lo + n]
+            assert n <= hi - lo and bool(((piece >= lo) & (piece < hi)).all()), (l, s)
+            got.append(piece)
+        got = torch.cat(got) if got else recv[:0]
+        assert torch.equal(torch.sort(got)[0], torch.sort(want)[0]), l
+
+
+def check_pieces_on_device(device, lib=None, n_envs=6, steps=40, cfg=None):
+    """`env.decima_graph_on_device` (capacity buffers, two sets of list counters used in turn - a launch clears the other set) over
+    several consecutive calls, with and without inactive envs: every call's list pieces hold that call's receivers"""
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+
+    cfg = cfg or dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, n_envs, device=device, auto_reset=True, _lib=lib)
+    env.reset(seed=21)
+    gen = torch.Generator().manual_seed(5)
+    seen = 0
+    for call in range(5):
+        env.rollout("fair", steps)
+        active = None if call % 2 == 0 else (torch.rand(n_envs, generator=gen) < 0.7).to(device)
+        g = env.decima_graph_on_device(active)
+        M = int(g["totals_dev"][0])
+        recv_bits = g["node_recv"][:M].long()
+        D = int(g["max_depth"])
+        assert not bool((recv_bits >> D).any())
+        check_list_pieces(g, [((recv_bits >> l) & 1).nonzero(as_tuple=True)[0] for l in range(D)])
+        seen += M
+    assert seen > 0
+    env.close()
 
 
 def _gumbel(seed, counter, env, idx, draw):

@@ -288,3 +288,11 @@ def test_kernel_weight_images_are_the_documented_permutations():
         # every input column of the first Linear appears exactly once among the K-steps (no feature dropped or doubled)
         used = sorted(c for row in cols for c in row if c >= 0)
         assert used == list(range(W1.shape[1])), name
+
+
+def test_list_pieces_of_the_graph_on_the_device():
+    """decima_util.check_pieces_on_device on the emulator (6 envs: a block per env; 70 envs: blocks of three, the last one short)"""
+    from decima_util import check_pieces_on_device
+
+    check_pieces_on_device("cpu", load_emu(), n_envs=6, steps=40)
+    check_pieces_on_device("cpu", load_emu(), n_envs=70, steps=25)

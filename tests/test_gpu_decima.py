@@ -328,3 +328,12 @@ def test_decima_step_without_host_round_trip_equals_the_synchronous_one(cfg, n_e
     from decima_util import check_on_device_step_equals_the_synchronous_one
 
     check_on_device_step_equals_the_synchronous_one("cuda:0", None, n_envs=n_envs, steps=steps, cfg=cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_envs", [1, 37, 300, 1024])
+def test_list_pieces_of_the_graph_on_the_device(n_envs):
+    """decima_util.check_pieces_on_device on the GPU: blocks of 1 / 2 / 10 / 32 envs per list counter"""
+    from decima_util import check_pieces_on_device
+
+    check_pieces_on_device("cuda:0", n_envs=n_envs, steps=120)
