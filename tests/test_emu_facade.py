@@ -182,3 +182,24 @@ def test_edge_rows_are_rewritten_after_a_rebind(pack):
         assert int(env.edge_links[k, 0, 0]) in (-9, int(snap2[k, 0, 0]))  # kept (skipped) or rewritten (graph changed back to equal rows)
     env.close()
     assert good.shape == snap.shape and n_edges.numel() == 2
+
+
+def test_late_hint_returns_the_latest_completed_copy_with_its_tag():
+    """vec_env.LateHint on CPU tensors (copies are synchronous there): nothing posted -> the fill value and no tag; afterwards the latest
+    post with the tag it was given - `decima_graph_on_device` tags a read-back with the set of list counters it belongs to"""
+    import torch
+    from spark_sched_sim_amd.vec_env import LateHint
+
+    h = LateHint(4, torch.device("cpu"))
+    v, tag = h.read_tagged()
+    assert v.tolist() == [-1] * 4 and tag is None and h.read().tolist() == [-1] * 4
+    h.post(torch.tensor([1, 2, 3, 4]), tag=1)
+    v, tag = h.read_tagged()
+    assert v.tolist() == [1, 2, 3, 4] and tag == 1
+    src = torch.tensor([5, 6, 7, 8])
+    h.post(src, tag=0)
+    src[0] = 99  # (the hint holds a copy)
+    v, tag = h.read_tagged()
+    assert v.tolist() == [5, 6, 7, 8] and tag == 0
+    v[1] = 0  # (and hands out copies)
+    assert h.read().tolist() == [5, 6, 7, 8]
