@@ -369,6 +369,11 @@ __global__ __launch_bounds__(256) void sss_gnn_head_mfma_kernel(SssGnnArgs a) {
       const int64_t b = valid ? r / a.E : 0;
       const int c = (int)(r - b * a.E);
       const int64_t jj = a.idx0[b];
+      // a tile whose rows are all executor counts beyond their job's cap (a job allows ~7 of 50 counts at config 5): -inf, no network
+      if (__builtin_amdgcn_ballot_w64(valid && c < a.job_cap[jj]) == 0) {
+        if (valid && q == 0) a.out[r] = -__builtin_inff();
+        continue;
+      }
       x[0] = valid ? *(const mfma_f4*)(a.h_dag + jj * 16 + 4 * q) : zero;
       x[1] = valid ? *(const mfma_f4*)(a.h_glob + a.job_obs[jj] * 16 + 4 * q) : zero;
       x[2] = zero;
