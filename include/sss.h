@@ -175,14 +175,15 @@ typedef struct sss_decima_graph {
    * a list with a fetch-add on a counter it shares with its BLOCK of envs only - SSS_LIST_SETS = 32 blocks of
    * q = ceil(num_envs / 32) consecutive envs (4096 envs adding to the same addresses: 35 us of a 78 us launch,
    * profiles/r05_graph_kernel.txt) - so layer l's list is up to 32 dense pieces: block s's piece starts at
-   * recv_lists_dev[l * recv_stride + node_off_dev[s * q]] and has layer_totals_dev[l * 32 + s] entries (i64[32][32], ZERO on
-   * entry; recv_stride >= the total node count; a block's receivers are among its own nodes, so pieces never overlap). The
+   * recv_lists_dev[l * recv_stride + node_off_dev[s * q]] and has layer_totals_dev[l * 32 + s] entries (i64[33][32], ZERO on
+   * entry; recv_stride >= the total node count; a block's receivers are among its own nodes, so pieces never overlap; row 32
+   * receives the largest node count of an env of block s - sss_gnn_encode_args.max_obs_nodes_hint is made of it). The
    * order of the envs inside a piece is not fixed (the layer launches treat rows independently). sss_gnn_encode takes the
    * pieces as they are (recv_stride there): no scan, no list kernel */
   int64_t* layer_totals_dev;
   int64_t* recv_lists_dev;
   int64_t recv_stride;
-  /* optional: ANOTHER set of list counters (i64[32][32]) that this launch sets to zero - a caller that builds a graph per step
+  /* optional: ANOTHER set of list counters (i64[33][32]) that this launch sets to zero - a caller that builds a graph per step
    * keeps two sets and passes them in turn (this step's zeroed by the previous launch, the previous step's - its consumers are
    * behind this launch in the stream - cleared now), which saves the clearing launch in between */
   int64_t* layer_totals_clear_dev;
@@ -374,7 +375,11 @@ typedef struct sss_gnn_encode_args {
   int64_t n_nodes, n_jobs;
   int32_t n_obs, max_depth;
   float slope;
-  int32_t pad_;
+  int32_t layers_mode; /* the DAG layers: 1 = a launch per layer over the layer's receiving nodes of all observations; 2 = ONE launch,
+                          a wave per observation walking its own layers (message passing never leaves an observation; the same
+                          arithmetic per node - bit-identical embeddings; needs none of the lists); 0 = the library chooses: 2 for
+                          batches of small observations (64 observations or more, max_obs_nodes_hint small: see there), where nine
+                          launches at the launch floor cost more than a wave walking a handful of tiles alone, else 1 */
   const float* w_prep_dev;
   const float* w_update_dev;
   const float* w_msg_dev;
@@ -408,7 +413,7 @@ typedef struct sss_gnn_encode_args {
   int64_t recv_cap;
   int64_t recv_stride;         /* 0: this call builds the lists (scan + list kernel into env_off_dev / layer_totals_dev / recv_dev);
                                   > 0: sss_decima_graph_build wrote them - layer l's pieces at recv_dev[l * recv_stride ..], their
-                                  lengths in layer_totals_dev (then i64[32][32], see sss_decima_graph; env_off_dev unused, may be
+                                  lengths in layer_totals_dev (then i64[33][32], see sss_decima_graph; env_off_dev unused, may be
                                   NULL) */
   int64_t layer_rows_hint[32]; /* host values: roughly how many nodes layer l updates (e.g. layer_totals of the previous step,
                                   read back lazily); only sizes the launch grids - every row is processed whatever it says.
@@ -419,6 +424,10 @@ typedef struct sss_gnn_encode_args {
   const int64_t* n_nodes_dev;
   const int64_t* n_jobs_dev;
   int64_t n_nodes_hint, n_jobs_hint; /* with the pointers: roughly the real totals (grid sizes); <= 0: use the capacities */
+  int64_t max_obs_nodes_hint;        /* roughly the node count of the LARGEST observation (e.g. row 32 of an earlier pass's
+                                        sss_decima_graph counters, read back lazily); <= 0: unknown. layers_mode 0 takes the one
+                                        launch while it is at most 192 (up to 2048 observations) / 64 (more): that launch ends
+                                        with its largest observation */
 } sss_gnn_encode_args;
 int sss_gnn_encode(const sss_gnn_encode_args* a, void* stream);
 

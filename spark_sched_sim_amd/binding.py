@@ -95,12 +95,12 @@ ERROR_NAMES = {
 }
 
 class SssGnnEncodeArgs(C.Structure):  # include/sss.h sss_gnn_encode_args
-    _fields_ = ([("n_nodes", C.c_int64), ("n_jobs", C.c_int64), ("n_obs", C.c_int32), ("max_depth", C.c_int32), ("slope", C.c_float), ("pad_", C.c_int32)]
+    _fields_ = ([("n_nodes", C.c_int64), ("n_jobs", C.c_int64), ("n_obs", C.c_int32), ("max_depth", C.c_int32), ("slope", C.c_float), ("layers_mode", C.c_int32)]
                 + [(k + "_dev", C.c_void_p) for k in ("w_prep", "w_update", "w_msg", "w_dag", "w_glob", "w_msg16", "w_update16", "x", "out_deg", "obs_depth", "node_obs", "dst",
                                                       "out_start", "edge_layers", "node_recv", "job_first", "job_nodes", "obs_job_off", "obs_jobs", "obs_node_off",
                                                       "obs_nodes", "layer_cnt", "h_init", "h", "tmp", "h_dag", "h_glob", "env_off", "layer_totals", "recv")]
                 + [("recv_cap", C.c_int64), ("recv_stride", C.c_int64), ("layer_rows_hint", C.c_int64 * 32),
-                   ("n_nodes_dev", C.c_void_p), ("n_jobs_dev", C.c_void_p), ("n_nodes_hint", C.c_int64), ("n_jobs_hint", C.c_int64)])
+                   ("n_nodes_dev", C.c_void_p), ("n_jobs_dev", C.c_void_p), ("n_nodes_hint", C.c_int64), ("n_jobs_hint", C.c_int64), ("max_obs_nodes_hint", C.c_int64)])
 
 
 class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args

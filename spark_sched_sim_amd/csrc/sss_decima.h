@@ -36,8 +36,9 @@ struct SssDecimaArgs {
   // the same 9 addresses were 35 us of a 78 us launch (same-address atomics retire one at a time, ~6 ns each;
   // profiles/r05_graph_kernel.txt). Layer l's list is therefore up to SSS_LIST_SETS dense pieces: block s's piece starts at
   // recv_lists[l * recv_stride + node_off[first env of s]] (a block's receivers are among its own nodes: the pieces cannot
-  // overlap) and has layer_totals[l * SSS_LIST_SETS + s] entries (i64[32][SSS_LIST_SETS], ZERO on entry); the order of the
-  // envs inside a piece varies from launch to launch (the layer launches do not care)
+  // overlap) and has layer_totals[l * SSS_LIST_SETS + s] entries (i64[33][SSS_LIST_SETS], ZERO on entry; row 32: the largest node
+  // count of an env of the block - what decides between a launch per layer and one launch, sss_host.h); the order of the envs
+  // inside a piece varies from launch to launch (the layer launches do not care)
   int64_t* layer_totals;
   int64_t* recv_lists;
   int64_t* layer_totals_clear;  // nullable: another set of counters, zeroed by this launch (the caller's next launch reserves on it)
@@ -63,7 +64,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   bool on = d.active == nullptr || d.active[env] != 0;
   int n = on ? oi[OBS_N_NODES] : 0, ne = on ? oi[OBS_N_EDGES] : 0, A = on ? oi[OBS_N_JOBS] : 0;
   if (d.layer_totals_clear)
-    for (int i = env * 64 + lane; i < 32 * SSS_LIST_SETS; i += L.num_envs * 64) d.layer_totals_clear[i] = 0;
+    for (int i = env * 64 + lane; i < 33 * SSS_LIST_SETS; i += L.num_envs * 64) d.layer_totals_clear[i] = 0;
   if (n == 0) {  // wave-uniform
     if (lane == 0) d.obs_depth[env] = 0;
     if (lane < 32) d.layer_cnt[(size_t)lane * L.num_envs + env] = 0;
@@ -215,6 +216,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   if (d.recv_lists) {
     const int q = (L.num_envs + SSS_LIST_SETS - 1) / SSS_LIST_SETS, set = env / q;  // this env's block of envs
     const int64_t set_n0 = d.node_off[set * q];
+    if (lane == 0) global_atomic_max_i64(d.layer_totals + 32 * SSS_LIST_SETS + set, (int64_t)n);  // row 32: the block's largest observation
     int64_t base = 0;
     if (lane < 32 && cnt) base = global_fetch_add_i64(d.layer_totals + lane * SSS_LIST_SETS + set, (int64_t)cnt);
     for (uint32_t l = 0; l < depth; l++) {

@@ -232,6 +232,99 @@ static int gnn_layer_mfma_launch(const SssGnnArgs& a, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ALL the DAG layers of a pass in ONE launch, one wave per OBSERVATION - for batches of SMALL observations. Message passing never
+// leaves an observation (edges join nodes of one job), so the only ordering the layers need is inside an observation, which a wave
+// has for free: no launch boundary between layers. A row's arithmetic does not depend on which rows share its tile, so the embeddings
+// are bit-identical to the launch-per-layer path; they stay in global memory (`h` / `tmp` alternate per update exactly as above),
+// a wave reads back what it wrote itself, ordered by a workgroup-scope fence between layers. The receiving nodes of each layer are
+// compacted over the whole observation first (one pass over its receiver bits, 16-bit positions in LDS, lengths from the graph
+// kernel's per-observation counts). The wave walks its tiles alone, ~5 us each, and the launch ends with its largest observation:
+// at ~40 nodes per observation (a PPO collection at config 5: 1024 envs, nine launches of ~8 us each, all at the launch floor)
+// that is a third of the nine launches; at ~200 nodes per observation (config 2 in steady state, 17 tiles per wave) it is slower
+// than they are (profiles/r05_layers_per_observation.txt) - sss_gnn_encode chooses by the nodes per observation.
+#define GNN_OBS_LIST_CAP 1024  // list entries (node, layer) per observation kept in LDS; a larger observation compacts chunk by chunk
+__global__ __launch_bounds__(256) void sss_gnn_layers_obs_kernel(SssGnnArgs a, const int64_t* __restrict__ obs_node_off, const int64_t* __restrict__ obs_nodes,
+                                                                 const int32_t* __restrict__ layer_cnt, int n_obs, int max_depth) {
+  __shared__ uint16_t lists[4][GNN_OBS_LIST_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obs = (int)blockIdx.x * 4 + wave;
+  if (obs >= n_obs) return;
+  const int cnt = (int)obs_nodes[obs];
+  if (cnt == 0) return;
+  const int64_t n0 = obs_node_off[obs];
+  // lane l: length and start of layer l's list
+  const int len = lane < max_depth ? layer_cnt[(size_t)lane * n_obs + obs] : 0;
+  int off = len;
+  for (int s = 1; s < 32; s <<= 1) {
+    const int t = __shfl_up(off, s);
+    if (lane >= s) off += t;
+  }
+  const int total = __shfl(off, 31);
+  off -= len;
+  if (total == 0) return;
+  MfmaGnnMlp msg, upd;
+  msg.load(a.w, lane), upd.load(a.w2, lane);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t depth_mask = max_depth < 32 ? (1u << max_depth) - 1u : ~0u;  // (the per-layer launches stop at max_depth as well)
+  if (total <= GNN_OBS_LIST_CAP && cnt <= 65536) {
+    uint16_t* list = lists[wave];
+    int run = off;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      const uint32_t rv = c0 + lane < cnt ? (uint32_t)a.node_recv[n0 + c0 + lane] & depth_mask : 0u;
+      if (__builtin_amdgcn_ballot_w64(rv != 0) == 0) continue;
+      for (int l = 0; l < max_depth; l++) {
+        const bool on = (rv >> l) & 1u;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+        if (m == 0) continue;
+        const int base = __builtin_amdgcn_readlane(run, l);
+        if (on) list[base + __builtin_popcountll(m & lt)] = (uint16_t)(c0 + lane);
+        if (lane == l) run += __builtin_popcountll(m);
+      }
+    }
+    __threadfence_block();
+    for (int l = max_depth - 1; l >= 0; l--) {
+      const int c = __builtin_amdgcn_readlane(len, l);
+      if (c == 0) continue;
+      const int o = __builtin_amdgcn_readlane(off, l);
+      for (int t = 0; 16 * t < c; t++) {
+        const int r = 16 * t + (lane & 15);
+        gnn_layer_mfma_rows_batched(a, msg, upd, r < c ? n0 + list[o + r] : -1, l, lane);
+      }
+      __threadfence_block();  // the next layer reads what this one wrote (same wave, other lanes)
+    }
+    return;
+  }
+  // an observation whose lists do not fit: the receiving nodes of a layer compacted chunk by chunk (one ballot + one ds_permute)
+  uint32_t layers = 0;
+  for (int l = 0; l < max_depth; l++)
+    if (__builtin_amdgcn_readlane(len, l)) layers |= 1u << l;
+  while (layers) {
+    const int l = 31 - __builtin_clz(layers);
+    layers &= ~(1u << l);
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      const bool on = c0 + lane < cnt && (((uint32_t)a.node_recv[n0 + c0 + lane] >> l) & 1u);
+      const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+      if (m == 0) continue;
+      const int n_on = __builtin_popcountll(m);
+      // lane r < n_on receives the chunk position of the chunk's r-th receiving node (a permutation of the lanes: the others go behind)
+      const int to = on ? __builtin_popcountll(m & lt) : n_on + __builtin_popcountll(~m & lt);
+      const int sel = __builtin_amdgcn_ds_permute(to << 2, lane);
+      for (int t = 0; 16 * t < n_on; t++) {
+        const int r = 16 * t + (lane & 15);
+        const int pos = __shfl(sel, r);
+        gnn_layer_mfma_rows_batched(a, msg, upd, r < n_on ? n0 + c0 + pos : -1, l, lane);
+      }
+    }
+    __threadfence_block();
+  }
+}
+static int gnn_layers_obs_launch(const SssGnnArgs& a, const int64_t* obs_node_off, const int64_t* obs_nodes, const int32_t* layer_cnt, int n_obs, int max_depth,
+                                 void* stream) {
+  hipLaunchKernelGGL(sss_gnn_layers_obs_kernel, dim3((unsigned)((n_obs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, obs_node_off, obs_nodes, layer_cnt, n_obs,
+                     max_depth);
+  return (int)hipGetLastError();
+}
+
 // tanh(v) = 1 - 2 / (1 + e^(2v)) on the transcendental unit (v_exp_f32, v_rcp_f32): absolute error ~1e-7, saturates
 // correctly at both ends; the library tanhf costs ~40 instructions, and a tile of a policy head needs 32 per lane
 SSS_DEV float fast_tanh(float v) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * v)); }

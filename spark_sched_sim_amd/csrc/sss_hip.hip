@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "zig_tables.inc"
 
+#define BE_UNAVAILABLE (-1000)
 static int be_set_device(int device) { return (int)hipSetDevice(device); }
 // launches of a handle go to the handle's device whatever the caller's current device is, and leave
 // the caller's current device as it was
@@ -274,6 +275,13 @@ static int be_launch_gnn(int kind, const SssGnnArgs& a, void* stream) {
     case GNN_GLOBSUM: return kVectorForms ? gnn_launch_kind<GNN_GLOBSUM>(a, stream) : gnn_sum16_launch<GNN_GLOBSUM>(a, stream);
   }
   return -1;
+}
+
+// all DAG layers of a pass in one launch, a wave per observation (sss_gnn_mfma.h); BE_UNAVAILABLE: this build has no such kernel
+static int be_launch_gnn_layers_obs(const SssGnnArgs& a, const int64_t* obs_node_off, const int64_t* obs_nodes, const int32_t* layer_cnt, int n_obs, int max_depth,
+                                    void* stream) {
+  if (kVectorForms) return BE_UNAVAILABLE;
+  return gnn_layers_obs_launch(a, obs_node_off, obs_nodes, layer_cnt, n_obs, max_depth, stream);
 }
 
 #include "sss_host.h"

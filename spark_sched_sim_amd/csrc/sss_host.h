@@ -572,20 +572,32 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   auto guess = [](int64_t hint, int64_t cap) { int64_t v = hint > 0 ? hint + hint / 4 + 64 : cap; return v > cap ? cap : (v < 1 ? 1 : v); };
   const int64_t rows_nodes = on_dev ? guess(g->n_nodes_hint, g->n_nodes) : g->n_nodes, rows_jobs = on_dev ? guess(g->n_jobs_hint, g->n_jobs) : g->n_jobs;
   auto fail = [](const char* what, int rc) { return sss_fail(-30, std::string(what) + " launch failed: " + be_error(rc)); };
-  // lengths of the layers' lists of receiving nodes, their per-env offsets, the lists
+  // the DAG layers: a launch per layer over the layer's receiving nodes of all observations, or ONE launch with a wave per
+  // observation (layers_mode; 0: by the size of the observations - a wave walks its observation's tiles alone, which beats nine
+  // launches at the launch floor only while observations are small: sss_gnn_mfma.h)
+  if (g->layers_mode < 0 || g->layers_mode > 2) return sss_fail(-33, "sss_gnn_encode: layers_mode is 0 (the library chooses), 1 (a launch per layer) or 2 (one launch)");
+  // (the one launch ends with its LARGEST observation; measured against nine launches per pass, profiles/r05_layers_per_observation.txt:
+  // at 1024 observations it wins up to ~300 nodes in the largest one (a wave per SIMD), at 4096 - two waves per SIMD, twice the
+  // matrix-core work per SIMD - only while every observation is small)
+  const int64_t one_launch_max = g->n_obs <= 2048 ? 192 : 64;
+  bool one_launch = g->max_depth > 0 && (g->layers_mode == 2 || (g->layers_mode == 0 && g->n_obs >= 64 && g->max_obs_nodes_hint > 0 && g->max_obs_nodes_hint <= one_launch_max));
+  // lengths of the layers' lists of receiving nodes, their per-env offsets, the lists (only the launches per layer need them)
   // (recv_stride != 0: sss_decima_graph_build has written the lists and their lengths already - recv_lists_dev / layer_totals_dev)
-  SssPrefixArgs p;
-  p.src = g->layer_cnt_dev, p.row_stride = g->n_obs, p.col_stride = 1, p.mask = nullptr, p.n_rows = 32, p.n_cols = g->n_obs;
-  p.off = g->env_off_dev, p.cnt = nullptr, p.totals = g->layer_totals_dev;
-  if (g->recv_stride == 0)
+  auto build_lists = [&]() -> int {
+    if (g->recv_stride != 0) return 0;
+    SssPrefixArgs p;
+    p.src = g->layer_cnt_dev, p.row_stride = g->n_obs, p.col_stride = 1, p.mask = nullptr, p.n_rows = 32, p.n_cols = g->n_obs;
+    p.off = g->env_off_dev, p.cnt = nullptr, p.totals = g->layer_totals_dev;
     if (int rc = be_launch_prefix_rows(p, stream)) return fail("prefix", rc);
-  if (g->max_depth > 0 && g->recv_stride == 0) {
-    SssDecimaListArgs d;
-    d.node_off = g->obs_node_off_dev, d.obs_nodes = g->obs_nodes_dev, d.node_recv = (const uint32_t*)g->node_recv_dev, d.env_off = g->env_off_dev;
-    for (int l = 0; l < 32; l++) d.layer_base[l] = 0;
-    d.recv = g->recv_dev, d.n_layers = g->max_depth, d.totals = g->layer_totals_dev;
-    if (int rc = be_launch_decima_lists(g->n_obs, d, stream)) return fail("decima lists", rc);
-  }
+    if (g->max_depth > 0) {
+      SssDecimaListArgs d;
+      d.node_off = g->obs_node_off_dev, d.obs_nodes = g->obs_nodes_dev, d.node_recv = (const uint32_t*)g->node_recv_dev, d.env_off = g->env_off_dev;
+      for (int l = 0; l < 32; l++) d.layer_base[l] = 0;
+      d.recv = g->recv_dev, d.n_layers = g->max_depth, d.totals = g->layer_totals_dev;
+      if (int rc = be_launch_decima_lists(g->n_obs, d, stream)) return fail("decima lists", rc);
+    }
+    return 0;
+  };
   SssGnnArgs a;
   memset(&a, 0, sizeof a);
   a.slope = g->slope, a.x = g->x_dev, a.h_init = g->h_init_dev, a.h = g->h_dev, a.tmp = g->tmp_dev, a.h_dag = g->h_dag_dev, a.h_glob = g->h_glob_dev;
@@ -599,16 +611,26 @@ extern "C" int sss_gnn_encode(const sss_gnn_encode_args* g, void* stream) {
   if (int rc = run(GNN_PREP, rows_nodes, g->w_prep_dev, g->n_nodes_dev)) return fail("gnn", rc);
   a.out = nullptr;
   // the layers, deepest first (scheduler.py:209-211): embeddings alternate between h and tmp per update (sss_gnn.h)
-  a.node_recv = g->node_recv_dev, a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev, a.idx0_stride = g->recv_stride;
-  if (g->recv_stride)  // the graph kernel's lists: a dense piece per block of observations (sss_decima.h SSS_LIST_SETS)
-    a.seg_off = g->obs_node_off_dev, a.n_seg = g->n_obs, a.list_q = (g->n_obs + SSS_LIST_SETS - 1) / SSS_LIST_SETS;
-  a.w2 = g->w_update_dev, a.w16 = g->w_msg16_dev, a.w2_16 = g->w_update16_dev;
-  for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
-    a.layer = lvl;
-    // (n_rows only sizes the grid here: the kernel reads the list's length itself and strides over all of it)
-    int64_t rows = g->layer_rows_hint[lvl] >= 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : rows_nodes;
-    if (rows > g->n_nodes) rows = g->n_nodes;
-    if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
+  a.node_recv = g->node_recv_dev, a.w2 = g->w_update_dev;
+  if (one_launch) {
+    a.w = g->w_msg_dev;
+    const int rc = be_launch_gnn_layers_obs(a, g->obs_node_off_dev, g->obs_nodes_dev, g->layer_cnt_dev, g->n_obs, g->max_depth, stream);
+    if (rc == BE_UNAVAILABLE) one_launch = false;  // (a build without the kernel: the launches per layer below)
+    else if (rc) return fail("gnn", rc);
+  }
+  if (!one_launch) {
+    if (int rc = build_lists()) return rc;
+    a.idx0 = g->recv_dev, a.layer_totals = g->layer_totals_dev, a.idx0_stride = g->recv_stride;
+    if (g->recv_stride)  // the graph kernel's lists: a dense piece per block of observations (sss_decima.h SSS_LIST_SETS)
+      a.seg_off = g->obs_node_off_dev, a.n_seg = g->n_obs, a.list_q = (g->n_obs + SSS_LIST_SETS - 1) / SSS_LIST_SETS;
+    a.w16 = g->w_msg16_dev, a.w2_16 = g->w_update16_dev;
+    for (int lvl = g->max_depth - 1; lvl >= 0; lvl--) {
+      a.layer = lvl;
+      // (n_rows only sizes the grid here: the kernel reads the list's length itself and strides over all of it)
+      int64_t rows = g->layer_rows_hint[lvl] >= 0 ? g->layer_rows_hint[lvl] + g->layer_rows_hint[lvl] / 4 + 64 : rows_nodes;
+      if (rows > g->n_nodes) rows = g->n_nodes;
+      if (int rc = run(GNN_LAYER, rows, g->w_msg_dev)) return fail("gnn", rc);
+    }
   }
   a.idx0 = nullptr, a.layer_totals = nullptr, a.idx0_stride = 0, a.w2 = nullptr, a.w16 = nullptr, a.w2_16 = nullptr, a.layer = 0;
   a.seg_off = nullptr, a.n_seg = 0, a.list_q = 0;

@@ -24,6 +24,9 @@ NUM_NODE_FEATURES = 5  # env_wrapper.py:9
 NUM_DAG_FEATURES = 3   # scheduler.py:33
 
 
+_NO_HINT = [-1] * 32  # sss_gnn_encode_args.layer_rows_hint: no idea (the launch is sized by the node count)
+
+
 def decima_observation(obs, num_executors: int, max_depth: int, num_tasks_scale: int = 200, work_scale: float = 1e5,
                        edge_masks: bool = False) -> dict[str, torch.Tensor]:
     """`DecimaObsWrapper.observation` for every env of a `BatchedObs`, padded per env.
@@ -672,19 +675,20 @@ class DecimaPolicy(nn.Module):
         tot_t, recv_t, stride = (g["layer_totals"], ls["recv"], ls["stride"]) if fresh else (sc["tot"], sc["recv"], 0)
         # (the structure is kept per set of buffers - an inference loop passes the same ones step after step; filling its 40
         # fields costs more host time than the launches it describes)
-        key = (M, J, B, D, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
+        mode = int(getattr(self, "_layers_mode", 0))  # (include/sss.h sss_gnn_encode_args.layers_mode; 0: the library chooses)
+        key = (M, J, B, D, mode, id(w), x.data_ptr(), g["out_deg"].data_ptr(), g["dst"].data_ptr() if g["dst"].numel() else 0, h.data_ptr(), tot_t.data_ptr(), recv_t.data_ptr(),
                recv_t.numel(), stride, g["obs_nodes"].data_ptr(), g["totals_dev"].data_ptr() if on_dev else 0)
         # (graphs with exact sizes bring new buffers every call: nothing to keep, and nothing kept alive; a capacity graph alternates
         # between two sets of list counters: two structures)
         memo = sc.setdefault("args", {}) if on_dev else None
         kept = memo.get(key) if on_dev else None
         if kept is None:
-            a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), 0, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
+            a = SssGnnEncodeArgs(M, J, B, D, float(self._packed[2]), mode, p(w["prep"]), p(w["update"]), p(w["msg"]), p(w["dag"]), p(w["glob"]), p(w.get("msg16")), p(w.get("update16")),
                                  p(x), p(g["out_deg"]), p(g["obs_depth"]), p(g["node_obs"]), p(g["dst"]), p(g["out_start"]), p(g["edge_layers"]), p(g["node_recv"]),
                                  p(g["job_first"]), p(g["job_nodes"]), p(g["obs_job_off"]), p(g["obs_jobs"]), p(g["obs_node_off"]), p(g["obs_nodes"]), p(g["layer_cnt"]),
                                  p(h_init), p(h), p(tmp), p(h_dag), p(h_glob), p(sc["env_off"]), p(tot_t), p(recv_t), recv_t.numel(), stride,
                                  (ctypes.c_int64 * 32)(),
-                                 g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None, 0, 0)
+                                 g["totals_dev"][0:1].data_ptr() if on_dev else None, g["totals_dev"][2:3].data_ptr() if on_dev else None, 0, 0, 0)
             kept = (key, a, (w, x, h_init, h, tmp, h_dag, h_glob))  # (the tensors: kept alive with the pointers)
             if on_dev:
                 if len(memo) >= 4:
@@ -695,10 +699,17 @@ class DecimaPolicy(nn.Module):
         # the graph kernel's lists come in pieces per block of envs (i64[32][32] lengths: a layer's rows are the sum over its pieces)
         own_hint = not (fresh and "layer_hint" in g)  # (a capacity graph brings the piece lengths with its totals: one read-back for both)
         if fresh and own_hint and "hint_pieces" not in sc:
-            sc["hint_pieces"] = LateHint(32 * 32, dev)
+            sc["hint_pieces"] = LateHint(33 * 32, dev)
         hint = sc.get("hint_pieces") if fresh else sc["hint"]
         hv = hint.read() if own_hint else g["layer_hint"]
-        a.layer_rows_hint[:] = (hv.view(32, 32).clamp(min=0).sum(1) if hv[0] >= 0 else hv[:32]).tolist() if fresh else hv.tolist()
+        if fresh and hv[0] >= 0:  # (i64[33][32]: piece lengths per layer and block of envs; row 32: the blocks' largest observation)
+            # (a capacity graph's layer launches keep the grid their node capacity gives them: sized by the read-back lengths - a few
+            # steps old - the Decima step at 4096 envs was 14 us SLOWER, profiles/r05_hints.txt; the read-back decides the layers' mode)
+            a.layer_rows_hint[:] = _NO_HINT if on_dev else hv[:1024].view(32, 32).sum(1).tolist()
+            a.max_obs_nodes_hint = int(hv[1024:].max())
+        else:
+            a.layer_rows_hint[:] = hv[:32].tolist()
+            a.max_obs_nodes_hint = 0
         if on_dev:
             a.n_nodes_hint, a.n_jobs_hint = int(g["totals_hint"][0]), int(g["totals_hint"][2])
         if _stream is not None:
@@ -949,7 +960,7 @@ class DecimaPolicy(nn.Module):
             return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
         # no device->host round trip when the graph kernel and the GNN kernels can do the whole step (the graph's totals stay on
         # the device); else the graph with exact sizes (one read-back of its totals)
-        on_dev = host_sync is False or (host_sync is None and self._use_kernels() and 16 * env.dims.node_cap <= 65536)
+        on_dev = host_sync is False or (host_sync is None and self._use_kernels() and 16 * env.dims.node_cap + 8 * (env.dims.job_cap + 1) <= 65536)
         a = self.act(env.decima_graph_on_device(active) if on_dev else env.decima_graph(active, reuse_buffers=True), generator)
         return self.env_actions(a), a
 

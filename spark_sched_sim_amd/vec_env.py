@@ -59,11 +59,15 @@ class LateHint:
         return self.read_tagged()[0]
 
     def read_tagged(self):
-        """(values, the `tag` their `post` was given); (fill, None) until a copy has completed"""
+        """(values, the `tag` their `post` was given); (fill, None) until a copy has completed. With the host several steps ahead of
+        the device BOTH buffers can be waiting for their copies: the values of the last completed one are kept and returned again
+        (returning the fill value then sized every grid by its capacity for as long as the host stayed ahead)"""
         for k in (self.last, 1 - self.last):
             if self.posted[k] and (not self.cuda or self.events[k].query()):
-                return self.bufs[k].clone(), self.tags[k]
-        return self.fill.clone(), None
+                self.kept = (self.bufs[k].clone(), self.tags[k])
+                break
+        kept = getattr(self, "kept", None)
+        return (kept[0].clone(), kept[1]) if kept is not None else (self.fill.clone(), None)
 
     def post(self, t: torch.Tensor, tag=None) -> None:
         k = 1 - self.last
@@ -284,12 +288,12 @@ class VecSparkSchedSimEnv:
                 "job_nodes": e(Jc, torch.int64), "out_start": e(Mc, torch.int64), "out_deg": e(Mc, torch.int32),
                 "layer_cnt": e(32, torch.int32, B), "sched_list": e(Mc, torch.int64),
                 "scan": e(2, torch.int64, 4, B),
-                # two sets of list counters (i64[32][32] each: a counter per layer and block of envs) used in turn - a launch reserves on
+                # two sets of list counters (i64[33][32] each: a counter per layer and block of envs + the blocks' largest observation) used in turn - a launch reserves on
                 # one and clears the other - with the graph's four totals between them: [set 0 | totals | set 1], so that the totals and
                 # the current set are one contiguous piece for the read-back of the grid-size hints
-                "pp": torch.zeros(1024 + 4 + 1024, dtype=torch.int64, device=dev),
-                "recv": e(Mc * max(D, 1), torch.int64), "hint": LateHint(1028, dev), "epoch": 0}
-            ws["tot"] = ws["pp"][1024:1028]
+                "pp": torch.zeros(1056 + 4 + 1056, dtype=torch.int64, device=dev),
+                "recv": e(Mc * max(D, 1), torch.int64), "hint": LateHint(1060, dev), "epoch": 0}
+            ws["tot"] = ws["pp"][1056:1060]
         act8 = _mask_u8(active)
         scan, tot = ws["scan"], ws["tot"]
         stream = self._stream()
@@ -318,7 +322,7 @@ class VecSparkSchedSimEnv:
             self._b.check(self._b.lib.sss_prefix_rows(ptrs[0], 1, ptrs[1], mask_ptr, 4, B, ptrs[2], ptrs[3], ptrs[4], stream))
             ws["epoch"] += 1
             par, pp = ws["epoch"] & 1, ws["pp"]
-            sets = (pp[0:1024], pp[1028:2052])
+            sets = (pp[0:1056], pp[1060:2116])
             a.layer_totals_dev, a.layer_totals_clear_dev = sets[par].data_ptr(), sets[1 - par].data_ptr()
             self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), stream))
             g = dict(g0)
@@ -326,8 +330,8 @@ class VecSparkSchedSimEnv:
             g["_layer_lists"] = ({"recv": ws["recv"], "stride": stride, "epoch": ws["epoch"]}, ws["epoch"])
             # the latest earlier call's numbers that have arrived: totals (M, Ed, J, S) and the lists' piece lengths (-1: none yet)
             hv, tag = ws["hint"].read_tagged()
-            g["totals_hint"], g["layer_hint"] = (hv[:4], hv[:1024]) if tag is None else (hv[1024:1028], hv[:1024]) if tag == 0 else (hv[:4], hv[4:1028])
-            ws["hint"].post(pp[0:1028] if par == 0 else pp[1024:2052], tag=par)
+            g["totals_hint"], g["layer_hint"] = (hv[:4], hv[:1056]) if tag is None else (hv[1056:1060], hv[:1056]) if tag == 0 else (hv[:4], hv[4:1060])
+            ws["hint"].post(pp[0:1060] if par == 0 else pp[1056:2116], tag=par)
         g["_keepalive"] = (off, act8)
         return g
 
@@ -393,7 +397,7 @@ class VecSparkSchedSimEnv:
             ls = self._layer_scratch[skey] = {"recv": torch.empty(max(2 * M, 1 << 14) * max(D, 1), dtype=torch.int64, device=dev), "epoch": 0}
         ls["epoch"] += 1
         ls["stride"] = ls["recv"].numel() // max(D, 1)
-        layer_totals = torch.zeros(32 * 32, dtype=torch.int64, device=dev)  # (i64[32][32]: a counter per layer and block of envs)
+        layer_totals = torch.zeros(33 * 32, dtype=torch.int64, device=dev)  # (i64[33][32]: a counter per layer and block of envs, the blocks' largest observation)
         a = SssDecimaGraph(act8.data_ptr() if act8 is not None else None, off[0].data_ptr(), off[2].data_ptr(), off[1].data_ptr(),
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",

@@ -153,12 +153,14 @@ def check_list_pieces(kg, receivers):
     ls, epoch = kg["_layer_lists"]
     assert ls["epoch"] == epoch, "the lists belong to a later graph of this env"
     B, stride, recv = kg["n_obs"], ls["stride"], ls["recv"]
-    tot = kg["layer_totals"].view(32, 32).cpu()
+    tot = kg["layer_totals"].view(33, 32).cpu()
     off = kg["obs_node_off"].cpu()
     M = kg["x"].shape[0] if "totals_dev" not in kg else int(kg["totals_dev"][0])
     q = (B + 31) // 32
     n_sets = (B + q - 1) // q
-    assert int(tot[len(receivers):].sum()) == 0 and int(tot[:, n_sets:].sum()) == 0
+    assert int(tot[len(receivers):32].sum()) == 0 and int(tot[:, n_sets:].sum()) == 0
+    nodes = kg["obs_nodes"].cpu()  # row 32: the largest observation of every block of envs
+    assert tot[32, :n_sets].tolist() == [int(nodes[s * q: (s + 1) * q].max()) for s in range(n_sets)]
     for l, want in enumerate(receivers):
         got = []
         for s in range(n_sets):

@@ -241,6 +241,8 @@ static int gnn_run_kind(const SssGnnArgs& a) {
   for (int64_t r = 0; r < rows; r++) gnn_row<KIND>(a, r, a.w, a.w2);
   return 0;
 }
+#define BE_UNAVAILABLE (-1000)
+static int be_launch_gnn_layers_obs(const SssGnnArgs&, const int64_t*, const int64_t*, const int32_t*, int, int, void*) { return BE_UNAVAILABLE; }  // (matrix-core kernel: gfx950 only)
 static int be_launch_gnn(int kind, const SssGnnArgs& a, void*) {
   switch (kind) {
     case GNN_PREP: return gnn_run_kind<GNN_PREP>(a);

@@ -337,3 +337,34 @@ def test_list_pieces_of_the_graph_on_the_device(n_envs):
     from decima_util import check_pieces_on_device
 
     check_pieces_on_device("cuda:0", n_envs=n_envs, steps=120)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_envs,steps", [(300, 25), (96, 400), (1024, 60)])
+def test_layers_in_one_launch_equal_the_launches_per_layer(n_envs, steps):
+    """include/sss.h sss_gnn_encode_args.layers_mode: all DAG layers in one launch with a wave per observation (2) against a launch
+    per layer (1) on the same live observations - small ones early in the episodes, a few hundred nodes later, exact-size graphs
+    and the env's capacity graphs: the three encoder outputs are bit-identical (a row's arithmetic does not depend on which rows share
+    its tile); the library's own choice (0) is one of the two"""
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, n_envs, device="cuda:0", auto_reset=True)
+    torch.manual_seed(3)
+    policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval().bind_kernels(env._b)
+    env.reset(seed=9)
+    env.rollout("fair", steps)
+    for make in (env.decima_graph, env.decima_graph_on_device):
+        outs = {}
+        for mode in (1, 2, 0):
+            g = make()
+            policy._layers_mode = mode
+            h = policy._encode_kernels(g)
+            M, J = (int(g["totals_dev"][0]), int(g["totals_dev"][2])) if "totals_dev" in g else (g["x"].shape[0], g["job_obs"].numel())
+            outs[mode] = (h["node"][:M].clone(), h["dag"][:J].clone(), h["glob"].clone())
+        assert outs[1][0].shape[0] > n_envs
+        for mode in (2, 0):
+            for a, b, name in zip(outs[1], outs[mode], ("node embeddings", "job summaries", "observation summaries")):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (make.__name__, mode, name)
+    env.close()
