@@ -14,12 +14,18 @@ torch.manual_seed(0)
 pol = DecimaPolicy(num_executors=10, **agent).to(dev).eval()
 gen = torch.Generator(device=dev).manual_seed(1)
 env.reset(seed=0)
+import os
+SPIN = float(os.environ.get("SSS_SPIN_US", "0")) * 1e-6  # (extra host time per step: is the host on the critical path?)
 def run(n):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
         act, _ = pol.schedule_env(env, generator=gen)
         env.step_async(act["stage_idx"], act["num_exec"])
+        if SPIN:
+            t1 = time.perf_counter() + SPIN
+            while time.perf_counter() < t1:
+                pass
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 run(20)
