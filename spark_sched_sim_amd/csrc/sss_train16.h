@@ -445,7 +445,11 @@ template <int IN>
 static int mlp_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
   if (a.rows <= 0) return 0;
   const int64_t wgs = (a.rows + 63) / 64;
-  const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);
+  // (one resident set of workgroups striding over the tiles, as the inference launches: sss_gnn_mfma.h gnn_resident_workgroups)
+  static const int64_t cap_f = gnn_resident_workgroups((const void*)sss_mlp_mfma_fwd_kernel<IN>, 256, 0);
+  static const int64_t cap_b = gnn_resident_workgroups((const void*)sss_mlp_mfma_bwd_kernel<IN>, 256, 0);
+  const int64_t cap = backward ? cap_b : cap_f;
+  const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
   if (backward)
     hipLaunchKernelGGL(sss_mlp_mfma_bwd_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else
