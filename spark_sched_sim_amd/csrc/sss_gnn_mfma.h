@@ -189,7 +189,7 @@ SSS_DEV void gnn_layer_mfma_tile(const SssGnnArgs& a, const MfmaGnnMlp& msg, con
   else gnn_layer_mfma_rows(a, msg, upd, n, layer, lane);
 }
 
-__global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
   if (a.list_q) {  // the graph kernel's lists: a dense piece per block of observations
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     GnnListPieces pc;
@@ -197,11 +197,24 @@ __global__ __launch_bounds__(256) void sss_gnn_layer_mfma_kernel(SssGnnArgs a) {
     if ((int)blockIdx.x * 4 + wave >= pc.total) return;  // (before the parameters are fetched)
     MfmaGnnMlp msg, upd;
     msg.load(a.w, lane), upd.load(a.w2, lane);
-    for (int t = (int)blockIdx.x * 4 + wave; t < pc.total; t += (int)gridDim.x * 4) {
-      int64_t first;
-      int count;
-      pc.tile_uniform(t, lane, first, count);
-      gnn_layer_mfma_tile(a, msg, upd, a.idx0, first, count, a.layer, lane);
+    // (the next tile's row ids are asked for before this tile is worked on: one of a tile's four dependent round trips less; also
+    // fetching ahead what depends on the next rows' nodes alone was slower again - 0.5495 -> 0.5558 ms per step)
+    const int j = lane & 15, step = (int)gridDim.x * 4;
+    int64_t first;
+    int count;
+    int t = (int)blockIdx.x * 4 + wave;
+    pc.tile_uniform(t, lane, first, count);
+    int64_t n = j < count ? a.idx0[first + j] : -1;
+    while (true) {
+      const int t_next = t + step;
+      int64_t n_next = -1;
+      if (t_next < pc.total) {
+        pc.tile_uniform(t_next, lane, first, count);
+        if (j < count) n_next = a.idx0[first + j];
+      }
+      gnn_layer_mfma_rows_batched(a, msg, upd, n, a.layer, lane);
+      if (t_next >= pc.total) break;
+      t = t_next, n = n_next;
     }
     return;
   }
@@ -532,6 +545,7 @@ __global__ __launch_bounds__(256) void sss_gnn_rows_mfma_kernel(SssGnnArgs a) {
   if (KIND == GNN_GLOBHID) m0.load(a.w, lane);
   if (a.n_rows_dev) a.n_rows = *a.n_rows_dev;  // (the row count of a step without a host round trip)
   const int64_t n_tiles = (a.n_rows + 15) / 16;
+  // (asking for the NEXT tile's inputs before this tile's matrix-core work was tried: 0.5495 -> 0.5533 ms per step, more registers)
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t n = tile * 16 + j;
     const bool valid = n < a.n_rows;
