@@ -1,5 +1,6 @@
-"""debug: time of the Decima graph kernel alone (prefix + graph build on live observations), optionally on a timing build that
-ends the kernel after a phase (tests/gpu_variant.py gstop<k>). usage: python tools/debug/graph_time.py [envs] [c2|c3] [variant ...]"""
+"""debug: time of the Decima graph kernel alone (offsets scan + graph build on live observations), on the product library or on test
+builds of it (names from tests/gpu_variant.py VARIANTS; profiles/r05_graph_kernel.txt was made with builds that ended the kernel after a
+phase). usage: python tools/debug/graph_time.py [envs] [c2|c3] [product|variant ...]"""
 import sys, os.path as osp
 ROOT = osp.dirname(osp.dirname(osp.dirname(osp.abspath(__file__))))
 sys.path[:0] = [ROOT, osp.join(ROOT, "tests")]
