@@ -6,8 +6,8 @@
 // One wavefront per env. Inputs are the env's own observation rows (nodes, edge_links, dag_ptr,
 // exec_supplies, the scalar block) plus the env's offsets into the flat outputs (exclusive prefix
 // sums of the per-env counts, computed by the caller); nothing of the simulator state is touched,
-// so the kernel is a pure function of the observation. LDS: 16 bytes per node slot
-// (generation, layer-membership bits / first out-edge, receiver bits, end of the out-edge range) + 8 per job slot (first node, supply).
+// so the kernel is a pure function of the observation. LDS: 8 bytes per node slot
+// (generation + receiver bits; layer-membership bits, then the out-edge range) + 8 per job slot (first node, supply).
 //
 // Included by sss_hip.hip (gfx950) and tests/emu/emu_backend.cpp (CPU wave emulator) after sss_sim.h.
 #pragma once
@@ -76,15 +76,17 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   const int32_t* dag_ptr = B.dag_ptr + (size_t)env * (L.J_cap + 1);
   const int32_t* sup = B.exec_supplies + (size_t)env * L.J_cap;
   int64_t n0 = d.node_off[env], j0 = d.job_off[env], e0 = d.edge_off[env];
-  int32_t* gen = (int32_t*)g_dec_lds;
-  uint32_t* memb = (uint32_t*)(g_dec_lds + (size_t)4 * L.n_cap);
-  uint32_t* recv = (uint32_t*)(g_dec_lds + (size_t)8 * L.n_cap);
-  int32_t* oend = (int32_t*)(g_dec_lds + (size_t)12 * L.n_cap);
+  // two words per node slot (LDS decides how many envs a CU holds at once - at 200 jobs x 18 stage slots four words were 57.6 KB,
+  // two envs per CU):  gr = generation in bits 0..7 (alone while the relaxation runs: its atomic max sees a plain integer), then the
+  // receiver bits from bit 8 up (at most 24 layers: the host checks the stage slots per job);  mb = the layer-membership bits, then
+  // the node's out-edge range as two 16-bit halves (first edge | end << 16: edge slots are below 65536)
+  uint32_t* gr = (uint32_t*)g_dec_lds;
+  uint32_t* mb = gr + L.n_cap;
   // the env's job table next to them: every node looks its job up (a binary search over dag_ptr - in global memory that was four
   // dependent round trips per 64 nodes)
-  int32_t* jp = (int32_t*)(g_dec_lds + (size_t)16 * L.n_cap);
+  int32_t* jp = (int32_t*)(g_dec_lds + (size_t)8 * L.n_cap);
   int32_t* js = jp + (L.J_cap + 1);
-  for (int i = lane; i < n; i += 64) gen[i] = 0, recv[i] = 0, oend[i] = 0;
+  for (int i = lane; i < n; i += 64) gr[i] = 0, mb[i] = 0;
   for (int a = lane; a <= A; a += 64) jp[a] = dag_ptr[a], js[a] = a < A ? sup[a] : 0;
   // the first 256 edges stay in registers (end points packed 16 + 16 bits: node slots are below 4096), the rest is re-read from the
   // observation where a phase needs it: the relaxation below walks the edge list once per DAG level, and re-reading it from
@@ -107,30 +109,30 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   for (int it = 0; it <= n; it++) {
     bool moved = false;
     for_edges([&](int, int u, int v) {
-      int gu = gen[u] + 1;
-      if (gen[v] < gu) lane_atomic_max_i32(&gen[v], gu), moved = true;
+      int gu = (int)gr[u] + 1;
+      if ((int)gr[v] < gu) lane_atomic_max_i32((int32_t*)&gr[v], gu), moved = true;
     });
     wave_sync();
     if (!wave_ballot(moved)) break;
   }
   // membership bits: bit l of memb[i] <=> node i is in (generation l) U succ(generation l)
-  for (int i = lane; i < n; i += 64) memb[i] = 1u << gen[i];
+  for (int i = lane; i < n; i += 64) mb[i] = 1u << gr[i];
   wave_sync();
-  for_edges([&](int, int u, int v) { lane_atomic_or_u32(&memb[v], 1u << gen[u]); });
+  for_edges([&](int, int u, int v) { lane_atomic_or_u32(&mb[v], 1u << gr[u]); });
   wave_sync();
   // edges: global endpoints, the layers whose mask holds the edge (both ends in the layer's node set)
   for_edges([&](int e, int u, int v) {
-    uint32_t lay = memb[u] & memb[v];
+    uint32_t lay = mb[u] & mb[v];
     d.src[e0 + e] = n0 + u, d.dst[e0 + e] = n0 + v, d.edge_obs[e0 + e] = env;
     d.edge_layers[e0 + e] = lay;
-    lane_atomic_or_u32(&recv[u], lay);
+    lane_atomic_or_u32(&gr[u], lay << 8);  // (nobody reads a generation in this phase; from here on it is gr & 0xFF)
   });
   wave_sync();
   // out-edge range of every node: edge_links is ordered by (job, source, destination)
   // (spark_sched_sim.py:249-258 + utils.subgraph keep the template's row-major edge order), so a
-  // node's out-edges are contiguous; `memb` is done and becomes the range start
-  int32_t* ostart = (int32_t*)memb;
-  for (int i = lane; i < n; i += 64) ostart[i] = 0;
+  // node's out-edges are contiguous; the membership bits are done and their words become the ranges (two 16-bit halves)
+  uint16_t* rng = (uint16_t*)mb;  // rng[2 u] = first out-edge of u, rng[2 u + 1] = one past its last (0: none)
+  for (int i = lane; i < n; i += 64) mb[i] = 0;
   wave_sync();
   {
     // (the neighbours of a register-resident edge come from the neighbouring lanes; wave-uniform: every lane takes part)
@@ -142,15 +144,15 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
       if (e < ne) {
         const int u = (int)(ev[k] & 0xFFFFu);
         const int pu = lane > 0 ? (int)(left & 0xFFFFu) : (int)(prev_last & 0xFFFFu), nu = lane < 63 ? (int)(right & 0xFFFFu) : (int)(next_first & 0xFFFFu);
-        if (e == 0 || pu != u) ostart[u] = e;
-        if (e == ne - 1 || nu != u) oend[u] = e + 1;
+        if (e == 0 || pu != u) rng[2 * u] = (uint16_t)e;
+        if (e == ne - 1 || nu != u) rng[2 * u + 1] = (uint16_t)(e + 1);
       }
       prev_last = wave_bcast_u32(ev[k], 63);
     }
     for (int e = 256 + lane; e < ne; e += 64) {
       int u = el[2 * e];
-      if (el[2 * (e - 1)] != u) ostart[u] = e;
-      if (e == ne - 1 || el[2 * (e + 1)] != u) oend[u] = e + 1;
+      if (el[2 * (e - 1)] != u) rng[2 * u] = (uint16_t)e;
+      if (e == ne - 1 || el[2 * (e + 1)] != u) rng[2 * u + 1] = (uint16_t)(e + 1);
     }
   }
   wave_sync();
@@ -191,10 +193,11 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
       x[3] = rem / d.num_tasks_scale;
       x[4] = rem * dur / d.work_scale;
       d.node_obs[n0 + i] = env, d.node_loc[n0 + i] = i, d.node_job[n0 + i] = j0 + a;
-      d.gen[n0 + i] = gen[i], d.node_recv[n0 + i] = recv[i], d.stage_mask[n0 + i] = sched;
-      int deg = oend[i] > 0 ? oend[i] - ostart[i] : 0;
-      d.out_start[n0 + i] = e0 + ostart[i], d.out_deg[n0 + i] = deg;
-      if ((uint32_t)gen[i] > depth) depth = (uint32_t)gen[i];
+      const uint32_t g_i = gr[i] & 0xFFu, first = mb[i] & 0xFFFFu, end = mb[i] >> 16;
+      d.gen[n0 + i] = (int32_t)g_i, d.node_recv[n0 + i] = gr[i] >> 8, d.stage_mask[n0 + i] = sched;
+      int deg = end > 0 ? (int)(end - first) : 0;
+      d.out_start[n0 + i] = e0 + first, d.out_deg[n0 + i] = deg;
+      if (g_i > depth) depth = g_i;
     }
     uint64_t bal = wave_ballot(sched);
     if (i < n) d.sched_rank[n0 + i] = sched ? (int64_t)(run + popc64(bal & lt)) : -1;
@@ -206,7 +209,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   // receiving nodes per layer (lane l counts layer l): sizes the per-layer lists / launches
   uint32_t cnt = 0;
   for (int i0 = 0; i0 < n; i0 += 64) {
-    uint32_t rv = i0 + lane < n ? recv[i0 + lane] : 0u;
+    uint32_t rv = i0 + lane < n ? gr[i0 + lane] >> 8 : 0u;
     for (uint32_t l = 0; l < depth; l++) {
       uint64_t bal = wave_ballot((rv >> l) & 1u);
       if ((uint32_t)lane == l) cnt += (uint32_t)popc64(bal);
@@ -222,7 +225,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
     for (uint32_t l = 0; l < depth; l++) {
       int64_t pos = (int64_t)l * d.recv_stride + set_n0 + (int64_t)wave_readlane_u64((uint64_t)base, (int)l);
       for (int i0 = 0; i0 < n; i0 += 64) {
-        const bool on = i0 + lane < n && ((recv[i0 + lane] >> l) & 1u);
+        const bool on = i0 + lane < n && ((gr[i0 + lane] >> (8 + l)) & 1u);
         const uint64_t bal = wave_ballot(on);
         if (on) d.recv_lists[pos + popc64(bal & lt)] = n0 + i0 + lane;
         pos += popc64(bal);

@@ -68,7 +68,7 @@ static int be_launch_rollout(const SssKernelArgs& a, int num_envs, int policy, i
 }
 
 static int be_launch_decima(const SssLayout& L, const SssBuffers& B, int E, const SssDecimaArgs& d, void* stream) {
-  hipLaunchKernelGGL(sss_decima_graph_kernel, dim3(L.num_envs), dim3(64), (size_t)16 * L.n_cap + (size_t)8 * (L.J_cap + 1), (hipStream_t)stream, L, B, E, d);
+  hipLaunchKernelGGL(sss_decima_graph_kernel, dim3(L.num_envs), dim3(64), (size_t)8 * L.n_cap + (size_t)8 * (L.J_cap + 1), (hipStream_t)stream, L, B, E, d);
   return (int)hipGetLastError();
 }
 

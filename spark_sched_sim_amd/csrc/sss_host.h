@@ -454,8 +454,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
       !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev ||
       !g->job_nodes_dev || !g->out_start_dev || !g->out_deg_dev || !g->layer_cnt_dev)
     return sss_fail(-1, "NULL argument");
-  if ((int64_t)16 * h->L.n_cap + (int64_t)8 * (h->L.J_cap + 1) > 65536 || h->L.n_cap > 65535)
-    return sss_fail(-25, "node capacity too large for the Decima graph kernel's LDS working set");
+  if ((int64_t)8 * h->L.n_cap + (int64_t)8 * (h->L.J_cap + 1) > 65536 || h->L.n_cap > 65535 || h->L.ed_cap > 65535 || h->L.SP > 24)
+    return sss_fail(-25, "node / edge capacity or stage slots per job too large for the Decima graph kernel's LDS working set");
   SssDecimaArgs d;
   d.active = g->active_dev, d.node_off = g->node_off_dev, d.job_off = g->job_off_dev, d.edge_off = g->edge_off_dev;
   d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale;

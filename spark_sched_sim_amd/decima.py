@@ -960,7 +960,7 @@ class DecimaPolicy(nn.Module):
             return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
         # no device->host round trip when the graph kernel and the GNN kernels can do the whole step (the graph's totals stay on
         # the device); else the graph with exact sizes (one read-back of its totals)
-        on_dev = host_sync is False or (host_sync is None and self._use_kernels() and 16 * env.dims.node_cap + 8 * (env.dims.job_cap + 1) <= 65536)
+        on_dev = host_sync is False or (host_sync is None and self._use_kernels() and env.graph_kernel_fits)
         a = self.act(env.decima_graph_on_device(active) if on_dev else env.decima_graph(active, reuse_buffers=True), generator)
         return self.env_actions(a), a
 

@@ -277,7 +277,7 @@ class RolloutCollector:
         lib = env._b.lib
         # the loop without waits (see __init__, record_on_device)
         fast = (self.record_on_device and not asynchronous and G == 1 and self.act_fn is None and self.policy is not None and B > 0
-                and self.policy._use_kernels() and 16 * env.dims.node_cap <= 65536)
+                and self.policy._use_kernels() and env.graph_kernel_fits)
         LAG, R = 4, 8  # flags are read at most LAG steps late; rings of R slots for what a step leaves for the host
         arena = None
         if fast:

@@ -274,7 +274,7 @@ class VecSparkSchedSimEnv:
         without waiting (pinned memory) - grid sizes only. For act-and-forget inference (`DecimaPolicy.schedule_env`): the buffers are
         overwritten by the next call; graphs that are kept (rollout recording, training) use `decima_graph`."""
         B, dev, d = self.num_envs, self.device, self.dims
-        assert 16 * d.node_cap + 8 * (d.job_cap + 1) <= 65536, "the graph kernel's LDS working set does not fit this node capacity"
+        assert self.graph_kernel_fits, "the graph kernel's LDS working set does not fit this node capacity"
         D = self.max_dag_depth
         ws = getattr(self, "_dg_dev", None)
         if ws is None:
@@ -335,6 +335,13 @@ class VecSparkSchedSimEnv:
         g["_keepalive"] = (off, act8)
         return g
 
+    @property
+    def graph_kernel_fits(self) -> bool:
+        """whether include/sss.h sss_decima_graph_build takes this env's capacities (its per-env LDS working set: 8 bytes per node
+        slot + 8 per job slot; 16-bit node / edge slots; at most 24 DAG layers) - else the graph comes from tensor ops"""
+        d = self.dims
+        return 8 * d.node_cap + 8 * (d.job_cap + 1) <= 65536 and d.node_cap <= 65535 and d.edge_cap <= 65535 and d.stage_stride <= 24
+
     def decima_graph(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5,
                      reuse_buffers: bool = False) -> dict[str, Any]:
         """the current observations of all envs (or of those with `active[b]` True) as Decima's
@@ -345,7 +352,7 @@ class VecSparkSchedSimEnv:
         overwritten by the next such call) - for act-and-forget inference loops; graphs that are
         kept (rollout recording) must use the default."""
         B, dev = self.num_envs, self.device
-        if 16 * self.dims.node_cap + 8 * (self.dims.job_cap + 1) > 65536:
+        if not self.graph_kernel_fits:
             # the kernel's per-node LDS working set does not fit: same graph from tensor ops on the device
             from .decima import compact_graph, decima_observation
             f = decima_observation(self._obs(), self.num_executors, self.dims.stage_stride, int(num_tasks_scale), work_scale)

@@ -113,17 +113,17 @@ def test_reference_style_decima_episode():
 
 
 def test_large_node_capacity_falls_back_to_tensor_op_graph():
-    """job capacity 300 -> 5400 node slots: beyond the graph kernel's LDS working set; the same
-    compact graph then comes from tensor ops and the policy runs its tensor-op forward"""
+    """job capacity 500 -> 9000 node slots: beyond the graph kernel's LDS working set (8 bytes per node slot + 8 per job slot in
+    64 KB); the same compact graph then comes from tensor ops and the policy runs its tensor-op forward"""
     import torch
 
     from decima_util import AGENT
     from spark_sched_sim_amd import VecSparkSchedSimEnv
     from spark_sched_sim_amd.decima import DecimaPolicy
 
-    cfg = dict(num_executors=8, job_arrival_cap=300, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0)
+    cfg = dict(num_executors=8, job_arrival_cap=500, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0)
     env = VecSparkSchedSimEnv(cfg, 3, device="cpu", _lib=load_emu())
-    assert 16 * env.dims.node_cap > 65536
+    assert 8 * env.dims.node_cap > 65536 and not env.graph_kernel_fits
     torch.manual_seed(1)
     policy = DecimaPolicy(num_executors=8, **AGENT).eval()
     gen = torch.Generator().manual_seed(2)
