@@ -266,7 +266,9 @@ static int gnn_layer_mfma_launch(const SssGnnArgs& a, void* stream) {
 // at ~40 nodes per observation (a PPO collection at config 5: 1024 envs, nine launches of ~8 us each, all at the launch floor)
 // that is a third of the nine launches; at ~200 nodes per observation (config 2 in steady state, 17 tiles per wave) it is slower
 // than they are (profiles/r05_layers_per_observation.txt) - sss_gnn_encode chooses by the nodes per observation.
+#ifndef GNN_OBS_LIST_CAP  // (a test build sets it low to reach the chunk-by-chunk path: tests/gpu_variant.py obscap64)
 #define GNN_OBS_LIST_CAP 1024  // list entries (node, layer) per observation kept in LDS; a larger observation compacts chunk by chunk
+#endif
 __global__ __launch_bounds__(256) void sss_gnn_layers_obs_kernel(SssGnnArgs a, const int64_t* __restrict__ obs_node_off, const int64_t* __restrict__ obs_nodes,
                                                                  const int32_t* __restrict__ layer_cnt, int n_obs, int max_depth) {
   __shared__ uint16_t lists[4][GNN_OBS_LIST_CAP];

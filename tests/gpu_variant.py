@@ -8,6 +8,9 @@ import os.path as osp
 
 HERE = osp.dirname(osp.abspath(__file__))
 VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
+            # the one-launch DAG layers (csrc/sss_gnn_mfma.h) with room for 64 list entries per observation: larger observations take
+            # the chunk-by-chunk path
+            "obscap64": ("-DGNN_OBS_LIST_CAP=64",),
             # timing builds for tools/debug/evprof3.py (scoped profiler of the lane-0 procedures, csrc/sss_prof.h)
             "evprof3": ("-DSSS_EVPROF3",), "evprof3b": ("-DSSS_EVPROF3", "-DSSS_EVPROF3B"), "evprof3c": ("-DSSS_EVPROF3", "-DSSS_EVPROF3C"),
             "evprof3d": ("-DSSS_EVPROF3", "-DSSS_EVPROF3D"),

@@ -340,8 +340,8 @@ def test_list_pieces_of_the_graph_on_the_device(n_envs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_envs,steps", [(300, 25), (96, 400), (1024, 60)])
-def test_layers_in_one_launch_equal_the_launches_per_layer(n_envs, steps):
+@pytest.mark.parametrize("n_envs,steps,variant", [(300, 25, None), (96, 400, None), (1024, 60, None), (96, 400, "obscap64")])
+def test_layers_in_one_launch_equal_the_launches_per_layer(n_envs, steps, variant):
     """include/sss.h sss_gnn_encode_args.layers_mode: all DAG layers in one launch with a wave per observation (2) against a launch
     per layer (1) on the same live observations - small ones early in the episodes, a few hundred nodes later, exact-size graphs
     and the env's capacity graphs: the three encoder outputs are bit-identical (a row's arithmetic does not depend on which rows share
@@ -349,8 +349,12 @@ def test_layers_in_one_launch_equal_the_launches_per_layer(n_envs, steps):
     from spark_sched_sim_amd import VecSparkSchedSimEnv
     from spark_sched_sim_amd.decima import DecimaPolicy
 
+    lib = None
+    if variant is not None:  # (a test build of the library: observations with more than 64 list entries take the kernel's chunk-by-chunk path)
+        from gpu_variant import load_variant
+        lib = load_variant(variant)
     cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
-    env = VecSparkSchedSimEnv(cfg, n_envs, device="cuda:0", auto_reset=True)
+    env = VecSparkSchedSimEnv(cfg, n_envs, device="cuda:0", auto_reset=True, _lib=lib)
     torch.manual_seed(3)
     policy = DecimaPolicy(num_executors=10, **AGENT).to("cuda:0").eval().bind_kernels(env._b)
     env.reset(seed=9)
