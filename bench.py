@@ -310,12 +310,13 @@ class Bench:
     def run(self, mode: str, n_steps: int, events=None):
         # every shard issues its own chain of launches on its own stream; chains are independent
         torch, args = self.torch, self.args
+        every = max(1, int(getattr(args, "event_every", 1)))  # HIP events around every `every`-th launch of the timed region
         if mode == "step":
-            for _ in range(n_steps):
+            for i in range(n_steps):
                 for e, st in zip(self.shards, self.streams):
                     with torch.cuda.stream(st):
                         act = e.policy_actions(self.policy)
-                        if events is not None:
+                        if events is not None and i % every == 0:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record(st)
                             e.step_async(act["stage_idx"], act["num_exec"])
@@ -324,11 +325,11 @@ class Bench:
                         else:
                             e.step_async(act["stage_idx"], act["num_exec"])
         elif mode == "bounded":  # launches with an event budget: an env whose step is cut goes on in the next launch (sss_step_bounded)
-            for _ in range(n_steps):
+            for i in range(n_steps):
                 for e, st in zip(self.shards, self.streams):
                     with torch.cuda.stream(st):
                         act = e.policy_actions(self.policy)
-                        if events is not None:
+                        if events is not None and i % every == 0:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record(st)
                             e.step_bounded_async(act["stage_idx"], act["num_exec"], args.bounded_events)
@@ -375,9 +376,11 @@ class Bench:
             import torch.distributed as dist
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        steps_all, evs_all, bytes_all, kern_ms_all, launches_all, fast_all, batched_all, rounds_all = tot.cpu().tolist()
+        steps_all, evs_all, bytes_all, kern_ms_all, timed_launches_all, fast_all, batched_all, rounds_all = tot.cpu().tolist()
         dt_max = tmax.item()
-        avg_launch_s = (kern_ms_all / launches_all) * 1e-3
+        avg_launch_s = (kern_ms_all / timed_launches_all) * 1e-3  # (over the launches that carry events: every --event-every-th step launch)
+        # all launches of the timed region: one per shard and batched step in the step / bounded modes; every fused launch carries events
+        launches_all = float(steps * len(self.shards) * self.world) if mode in ("step", "bounded") else timed_launches_all
         bytes_per_launch = bytes_all / launches_all
         achieved = bytes_per_launch / avg_launch_s / 1e9
         kernel = {"step": "sss_step_kernel", "bounded": "sss_step_bounded_kernel"}.get(mode, "sss_rollout_kernel")
@@ -404,7 +407,8 @@ class Bench:
                 # process, so the PMC passes are separate runs of this kernel / config (tools/collect_traffic.py)
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this kernel and config, same events per step within 15 %; null if none)",
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
-                "kernel_time_frac_of_wall": (kern_ms_all / self.world) * 1e-3 / dt_max,
+                "kernel_time_frac_of_wall": avg_launch_s * (launches_all / self.world / len(self.shards)) / dt_max,
+                "launches_with_events": timed_launches_all / self.world,
             },
         }
 
@@ -488,6 +492,8 @@ def main() -> None:
     ap.add_argument("--preroll", type=int, default=None, help="fused steps every env runs before anything is timed (default: a few episodes)")
     ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the extra PPO-iteration record (one rank's share of BASELINE config 5; N=1, c2 only)")
+    ap.add_argument("--event-every", type=int, default=8, help="HIP events (the roofline's launch durations) around every N-th step launch of the timed region: "
+                    "an event pair per launch costs the stream ~5 us per step (profiles/r05_bench.md section 5), 3 %% of a config-2 step")
     ap.add_argument("--lib", default=None, help="path of a test build of the library to measure instead of the product (A/B timing; tests/gpu_variant.py builds them)")
     ap.add_argument("--no-e100", action="store_true", help="skip the 100-executor record (the wide instantiation; N=1, --config c2 only)")
     ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE config 3 record (N=1, --config c2 only)")
@@ -587,11 +593,11 @@ def main() -> None:
             "mean_last_episode_return": mean_return,
             # the roofline figures of the line are the SUSTAINED window's when there is one (>= --sustained-s of stepping in the
             # same mode): K = 20 timed steps are 3-4 ms and carry whatever bytes per launch those 20 steps happened to have
-            "roofline": dict(sustained["roofline"], window=f"{sustained['steps']} batched steps (the `sustained` record)") if sustained is not None
-                        else dict(primary["roofline"], window=f"the K = {args.steps} timed steps"),
+            "roofline": dict(sustained["roofline"], window=f"{sustained['steps']} batched steps (the `sustained` record; HIP events around every {args.event_every}th launch)") if sustained is not None
+                        else dict(primary["roofline"], window=f"the K = {args.steps} timed steps (HIP events around every {args.event_every}th launch)"),
         }
         if sustained is not None:
-            out["roofline_k_steps"] = dict(primary["roofline"], window=f"the K = {args.steps} timed steps of `value`")
+            out["roofline_k_steps"] = dict(primary["roofline"], window=f"the K = {args.steps} timed steps of `value` (HIP events around every {args.event_every}th launch)")
             out["sustained"] = sustained
         if tail is not None:
             out["step_tail"] = tail
