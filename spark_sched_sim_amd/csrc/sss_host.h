@@ -59,6 +59,23 @@ static int sss_pack_parse(const uint8_t* p, size_t n, SssPackHost* v) {
   for (int t = 0; t < v->T; t++) me = eo[t + 1] - eo[t] > me ? eo[t + 1] - eo[t] : me;
   v->max_edges_per_job = me;
   if (me > 255) return -1;
+  // Fields the pack carries narrower than the reference's Python objects (workload.py refuses what does not fit when it
+  // builds a pack; a pack from anywhere else is looked at again here): a task count or duration that wrapped shows up
+  // negative, list descriptors must stay inside the duration pool.
+  if ((size_t)v->sec_len[3] < sizeof(int32_t) * (size_t)v->total_stages || (size_t)v->sec_len[11] < sizeof(int32_t) * (size_t)v->total_durations ||
+      (size_t)v->sec_len[10] < sizeof(int32_t) * (size_t)v->total_stages * 3 * (size_t)v->L * 2)
+    return -1;
+  const int32_t* nt = (const int32_t*)(p + v->sec_off[3]);
+  for (int i = 0; i < v->total_stages; i++)
+    if (nt[i] < 0) return -2;
+  const int32_t* du = (const int32_t*)(p + v->sec_off[11]);
+  for (int i = 0; i < v->total_durations; i++)
+    if (du[i] < 0) return -3;
+  const int32_t* de = (const int32_t*)(p + v->sec_off[10]);
+  for (int64_t i = 0; i < (int64_t)v->total_stages * 3 * v->L; i++) {
+    const int64_t off = de[2 * i], len = de[2 * i + 1];
+    if (len > 0 && (off < 0 || len >= (1 << 30) || off + len > v->total_durations)) return -4;
+  }
   return 0;
 }
 
@@ -80,7 +97,11 @@ struct sss_handle {
 
 static int sss_validate(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, SssPackHost* ph, int* J_cap) {
   if (!cfg) return sss_fail(-1, "cfg is NULL");
-  if (sss_pack_parse((const uint8_t*)pack, pack_bytes, ph)) return sss_fail(-2, "workload pack is malformed (expected SSSPACK2, n_queries x n_sizes templates, <= 64 stages/job, <= 255 edges/job)");
+  if (int prc = sss_pack_parse((const uint8_t*)pack, pack_bytes, ph))
+    return sss_fail(-2, prc == -2   ? "workload pack: a stage has a negative task count (a count beyond int32 wrapped when the pack was written)"
+                        : prc == -3 ? "workload pack: negative task duration (a duration beyond int32 milliseconds wrapped when the pack was written, or the trace set holds one)"
+                        : prc == -4 ? "workload pack: a duration list descriptor points outside the duration pool or holds 2^30 or more entries"
+                                    : "workload pack is malformed (expected SSSPACK2, n_queries x n_sizes templates, <= 64 stages/job, <= 255 edges/job, <= 16 executor levels)");
   if (num_envs < 1) return sss_fail(-3, "num_envs must be >= 1");
   if (cfg->num_executors < 1 || cfg->num_executors > SSS_MAX_EXEC_ANY) return sss_fail(-4, "num_executors must be in [1, 128]");
   int cap = cfg->job_arrival_cap > 0 ? cfg->job_arrival_cap : 0;

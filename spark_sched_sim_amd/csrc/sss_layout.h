@@ -168,9 +168,18 @@ struct SssJob {            // 64 bytes, one cache line
   int32_t gs_base;         // first stage row of the template in the pack (identifies the template)
 };
 
-struct SssStage {          // 8 bytes
-  int16_t remaining, executing, commit_to, moving_to;
+// 8 bytes, read and written as one access. `remaining` is a stage's task count (any int the reference's Python ints hold that fits
+// 31 bits: tpch.py:185-187 is a list length); the other three count executors and are bounded by num_executors <= 128.
+// Lane-parallel commits add to the record as words: word 0 = remaining, word 1 = executing | commit_to << 16 | moving_to << 24.
+struct alignas(8) SssStage {
+  int32_t remaining;
+  int16_t executing;
+  uint8_t commit_to, moving_to;
 };
+#define STG_W1_EXECUTING 1u
+#define STG_W1_COMMIT_TO (1u << 16)
+#define STG_W1_MOVING_TO (1u << 24)
+static_assert(SSS_MAX_EXEC_ANY <= 255, "commit_to / moving_to are bytes");
 
 struct SssPoolHdr {        // 16 bytes: CPython set header + outgoing commitment count + the table while it has 8 slots
   uint16_t mask, fill, used;

@@ -1021,7 +1021,7 @@ SSS_DEV void trk_add_commitment(int n, uint32_t dst) {  // TRK:148-157, 226-238
   int dj = key_job(dst), ds = key_stage(dst);
   if (ds >= 0) {
     const JobView v = jobview(dj);
-    v.st[ds].commit_to = (int16_t)(v.st[ds].commit_to + n);
+    v.st[ds].commit_to = (uint8_t)(v.st[ds].commit_to + n);
     update_sat(v, ds);
   }
   if (dj != key_job(src)) add_supply(dj, n);
@@ -1047,7 +1047,7 @@ SSS_DEV uint32_t trk_remove_commitment(int e, uint32_t dst) {
     const JobView v = jobview(dj);
     const int c = (int)v.st[ds].commit_to - 1;
     CHECK(c >= 0);
-    v.st[ds].commit_to = (int16_t)c;
+    v.st[ds].commit_to = (uint8_t)c;
     update_sat(v, ds);
   }
   if (hot.c_n[i] == 0) {  // dict.pop(dst): swap-remove, order lives in c_seq
@@ -1334,7 +1334,7 @@ SSS_DEV void trk_move_executor_to_pool(int e, uint32_t new_pool, bool send) {  /
   CHECK(nj >= 0 && ns >= 0);  // "can only send executors to stages"
   {
     const JobView v = jobview(nj);
-    v.st[ns].moving_to = (int16_t)(v.st[ns].moving_to + 1);
+    v.st[ns].moving_to = (uint8_t)(v.st[ns].moving_to + 1);
     update_sat(v, ns);
     const int sup = (int)v.job->supply + 1;  // add_supply(nj, 1)
     v.job->supply = (int16_t)sup;
@@ -1541,7 +1541,7 @@ SSS_DEV void execute_next_task(int e, int j, int s) {  // ENV:584-615
   const JobView v = jobview(j);  // (valid up to push_event, which may hand the job a cache slot)
   SssStage st = v.st[s];
   CHECK(st.remaining > 0 && g_hot.ex_job[e] == j && !g_hot.ex_executing[e]);
-  st.remaining = (int16_t)(st.remaining - 1);  // STG:53-58
+  st.remaining = (st.remaining - 1);  // STG:53-58
   st.executing = (int16_t)(st.executing + 1);
   v.st[s] = st;
   if (st.remaining == 0) v.job->sat_count = (int16_t)(v.job->sat_count + 1);
@@ -1978,8 +1978,8 @@ SSS_DEV int fulfil_chunk(int c0, int n, int& serial_end) {
     }
     g_sc.fi_type[idx] = (uint8_t)type;
     if ((run & ~(below | bit64(lane))) == 0) {  // last item of its commitment: the stage's counters (TRK:159-176,188-222; STG:53-58)
-      st.remaining = (int16_t)(st.remaining - n_exec_run), st.executing = (int16_t)(st.executing + n_exec_run);
-      st.commit_to = (int16_t)(st.commit_to - n_run), st.moving_to = (int16_t)(st.moving_to + n_send_run);
+      st.remaining = st.remaining - n_exec_run, st.executing = (int16_t)(st.executing + n_exec_run);
+      st.commit_to = (uint8_t)(st.commit_to - n_run), st.moving_to = (uint8_t)(st.moving_to + n_send_run);
       *sp = st;
       if (n_exec_run && st.remaining == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
       // executor demand = remaining - (moving_to + commit_to) is what it was unless executors were parked
@@ -2297,7 +2297,7 @@ SSS_DEV void handle_executor_arrival(int e, int j, int s) {  // ENV:440-450
   g_hot.ex_job[e] = (int16_t)j;
   const int mv = (int)v.st[s].moving_to - 1;  // TRK:185-187
   CHECK(mv >= 0);
-  v.st[s].moving_to = (int16_t)mv;
+  v.st[s].moving_to = (uint8_t)mv;
   update_sat(v, s);
   trk_move_executor_to_pool(e, key_job_pool(j), false);
   move_executor_to_stage(e, j, s);
@@ -2481,7 +2481,7 @@ SSS_DEV int fast_body(const FastCtx& f, int ex, double t_ev, int j, int s, int s
   SssExDesc xd = f.exdesc[ex];
   if (st.remaining <= 0) return 0;
   g_hot.h.wall_time = t_ev;
-  st.remaining = (int16_t)(st.remaining - 1);
+  st.remaining = st.remaining - 1;
   int demand = (int)st.remaining - ((int)st.moving_to + (int)st.commit_to);
   if (st.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);  // stage just became saturated (ENV:595-597)
   if (demand <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));  // fire-and-forget: nothing below waits for the old mask
@@ -2776,7 +2776,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
     if (won) g_hot.ev[ex].t = sl.t, g_hot.ev[ex].seq = sl.seq;
     SssJob* jp = f.cjobs + (touched ? slot : 0);
     if (touched) {  // (the lanes of one stage hold the same values)
-      f.cstages[slot * f.SP + s].remaining = (int16_t)rem;
+      f.cstages[slot * f.SP + s].remaining = rem;
       f.cdur[slot * f.SP + s] = (float)lastdur;
       if (rem - mc <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));  // executor demand <= 0 (ENV:566-582)
     }
@@ -3129,15 +3129,15 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
   // ---- commit ----
   if (V) {
     SssJob* jp = f.cjobs + slot;
-    lane_atomic_add_u32((uint32_t*)(f.cstages + slot * f.SP + s), 0u - (1u << 16));  // executing-- (STG:60-62)
+    lane_atomic_add_u32((uint32_t*)(f.cstages + slot * f.SP + s) + 1, 0u - STG_W1_EXECUTING);  // executing-- (STG:60-62)
     g_sc.fi_e[rank] = (uint8_t)ex, g_sc.fi_type[rank] = (uint8_t)type;
     g_sc.rl_old[rank] = sp, g_sc.rl_idx[rank] = freed ? (uint8_t)RL_NO_COMMITMENT : (uint8_t)c_idx, g_sc.rl_seq[rank] = c_best;
     g_sc.fc_dst[rank] = enters;
     if (start) {
       double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
       if (dd.y >> 30) dur += g_c.P.warmup_delay;
-      lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - 1u);          // commitments to the new stage: one fewer (TRK:159-176)
-      lane_atomic_add_u32((uint32_t*)sp_new, (1u << 16) - 1u);      // remaining--, executing++ (STG:53-58)
+      // commitments to the new stage: one fewer (TRK:159-176); remaining--, executing++ (STG:53-58): one 64-bit addition, no field underflows
+      lane_atomic_add_u64((uint64_t*)sp_new, ((uint64_t)(STG_W1_EXECUTING - STG_W1_COMMIT_TO) << 32) - 1ull);
       g_hot.ev[ex].t = sl.t + dur;
       g_hot.ev[ex].seq = counter0 + rank_p;
       g_hot.ev[ex].info = ev_info(EV_TASK_FINISHED, j, s2, slot);
@@ -3147,7 +3147,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
         if ((int)st_new.remaining - (int)ct_take == 0) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (ENV:595-597)
       }
     } else if (type == RL_SEND) {
-      lane_atomic_add_u32((uint32_t*)sp_new + 1, 0xFFFFu);           // commit_to--, moving_to++ (the borrow of the low half is the carry into the high one)
+      lane_atomic_add_u32((uint32_t*)sp_new + 1, STG_W1_MOVING_TO - STG_W1_COMMIT_TO);  // commit_to--, moving_to++
       g_hot.ev[ex].t = sl.t + g_c.P.moving_delay;
       g_hot.ev[ex].seq = counter0 + rank_p;
       g_hot.ev[ex].info = ev_info(EV_EXECUTOR_READY, j2, s2, (uint32_t)lds_slot_of()[j2]);
@@ -3155,7 +3155,7 @@ SSS_DEV int batch_released_events(const FastCtx& f, int head) {
       lane_atomic_add_u32((uint32_t*)&jp->supply, 0u - 1u);          // the old job's executor count (TRK:218-221)
     } else {
       if (type == RL_PARK) {
-        lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - 1u);
+        lane_atomic_add_u32((uint32_t*)sp_new + 1, 0u - STG_W1_COMMIT_TO);
         g_hot.ex_task_stage[ex] = -1;  // ENV:808-813
       }
       g_hot.ev[ex].t = __builtin_inf();
@@ -3497,14 +3497,14 @@ SSS_DEV int batch_arrival_events(const FastCtx& f, int head) {
     SssStage* stp = f.cstages + slot * f.SP + s;
     local_atomic_attach(jp, ex);  // JOB:81-84
     g_hot.ex_job[ex] = (int16_t)j;
-    lane_atomic_add_u32((uint32_t*)stp + 1, 0u - (1u << 16));  // moving_to-- (TRK:185-187)
+    lane_atomic_add_u32((uint32_t*)stp + 1, 0u - STG_W1_MOVING_TO);  // moving_to-- (TRK:185-187)
     g_sc.fi_e[rank] = (uint8_t)ex, g_sc.fi_type[rank] = (uint8_t)type;
     g_sc.rl_old[rank] = jkey;
     g_sc.fc_dst[rank] = start ? skey : POOL_NONE;  // the pool it enters after the job's
     if (start) {
       double dur = (double)f.durations[dd.x + (int)(mm >> 32)];
       if (dd.y >> 30) dur += g_c.P.warmup_delay;
-      lane_atomic_add_u32((uint32_t*)stp, (1u << 16) - 1u);  // remaining--, executing++ (STG:53-58)
+      lane_atomic_add_u64((uint64_t*)stp, ((uint64_t)STG_W1_EXECUTING << 32) - 1ull);  // remaining--, executing++ (STG:53-58)
       g_hot.ev[ex].t = sl.t + dur;
       g_hot.ev[ex].seq = counter0 + rank_x;
       g_hot.ev[ex].info = ev_info(EV_TASK_FINISHED, j, s, slot);
@@ -3779,7 +3779,7 @@ SSS_DEV int lean_released(const FastCtx& f, int ex, double t_ev, uint32_t info) 
       const JobView v = jobview(j2);
       const int c = (int)v.st[s2].commit_to - 1;
       CHECK(c >= 0);
-      v.st[s2].commit_to = (int16_t)c;
+      v.st[s2].commit_to = (uint8_t)c;
       update_sat(v, s2);
       if (j2 != j) v.job->supply = (int16_t)(v.job->supply - 1);
     }
@@ -3790,13 +3790,13 @@ SSS_DEV int lean_released(const FastCtx& f, int ex, double t_ev, uint32_t info) 
       SssJob* jpt = f.cjobs + tslot;
       SssStage t2 = *spt;
       if (type == RL_START) {
-        t2.remaining = (int16_t)(t2.remaining - 1), t2.executing = (int16_t)(t2.executing + 1);  // STG:53-58
+        t2.remaining = t2.remaining - 1, t2.executing = (int16_t)(t2.executing + 1);  // STG:53-58
         if (t2.remaining == 0) jpt->sat_count = (int16_t)(jpt->sat_count + 1);  // ENV:595-597
         f.cdur[slot * f.SP + ts] = (float)dur;  // ENV:604
         new_t = t_ev + dur, new_info = ev_info(EV_TASK_FINISHED, j, ts, slot);
         g_sc.rng_pos = pos, h.rng_has32 = h0, h.rng_u32 = u32_0;
       } else if (type == RL_SEND) {
-        t2.moving_to = (int16_t)(t2.moving_to + 1);        // TRK:206-216
+        t2.moving_to = (uint8_t)(t2.moving_to + 1);        // TRK:206-216
         jpt->supply = (int16_t)(jpt->supply + 1);          // the new job's executor count ...
         jp->supply = (int16_t)(jp->supply - 1);            // ... and the old one's (TRK:218-221)
         new_t = t_ev + g_c.P.moving_delay, new_info = ev_info(EV_EXECUTOR_READY, tj, ts, tslot);
@@ -3927,10 +3927,10 @@ SSS_DEV int lean_arrival(const FastCtx& f, int ex, double t_ev, uint32_t info) {
     jp->local_mask = local_with(local, ex);  // JOB:81-84
     g_hot.ex_job[ex] = (int16_t)j;
     SssStage t2 = st;
-    t2.moving_to = (int16_t)(t2.moving_to - 1);  // TRK:185-187
+    t2.moving_to = (uint8_t)(t2.moving_to - 1);  // TRK:185-187
     SssEvSlot sl = g_hot.ev[ex];
     if (start) {
-      t2.remaining = (int16_t)(t2.remaining - 1), t2.executing = (int16_t)(t2.executing + 1);  // STG:53-58
+      t2.remaining = t2.remaining - 1, t2.executing = (int16_t)(t2.executing + 1);  // STG:53-58
       if (t2.remaining == 0) jp->sat_count = (int16_t)(jp->sat_count + 1);                      // ENV:595-597
       f.cdur[slot * f.SP + s] = (float)dur;                                                     // ENV:604
       sl.t = t_ev + dur, sl.seq = counter0, sl.info = ev_info(EV_TASK_FINISHED, j, s, slot);
@@ -4088,7 +4088,7 @@ SSS_DEV void write_observation(const SssLayout& L, const SssBuffers& B, int env,
   // four rows per lane at a time, every load of the four issued before the first store (one round trip to HBM per
   // 256 rows instead of one per 64)
   for (int i0 = lane; i0 < A * SPn; i0 += 64 * 4) {
-    int16_t remaining[4];
+    int32_t remaining[4];
     float recent[4];
     uint64_t act[4], sched[4];
     int nst[4];
@@ -4804,7 +4804,7 @@ SSS_DEV void do_reset(const SssLayout& L, uint64_t seed, double time_limit) {
     SssStage st = {0, 0, 0, 0};
     float d = 0.0f;
     if (s < (int)job.n_stages) {
-      st.remaining = (int16_t)g_c.pk.stage_num_tasks[job.gs_base + s];
+      st.remaining = g_c.pk.stage_num_tasks[job.gs_base + s];
       d = (float)g_c.pk.stage_rough[job.gs_base + s];
     }
     g_c.stages[i] = st;

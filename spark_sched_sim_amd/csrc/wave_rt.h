@@ -157,6 +157,7 @@ SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned lo
 SSS_DEV void lane_atomic_and_u64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 SSS_DEV void lane_atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+SSS_DEV void lane_atomic_add_u64(uint64_t* p, uint64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 // a counter in global memory shared by the waves of a launch: returns the value before the addition
 SSS_DEV int64_t global_fetch_add_i64(int64_t* p, int64_t v) { return (int64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 SSS_DEV void global_atomic_max_i64(int64_t* p, int64_t v) { atomicMax((long long*)p, (long long)v); }

@@ -46,6 +46,17 @@ PACK_MAGIC = b"SSSPACK2"
 _SIZE_SCALE = {"2g": 1, "5g": 2, "10g": 4, "20g": 8, "50g": 20, "80g": 32, "100g": 40}
 _LEVELS = [2, 5, 10, 20, 40, 50, 60, 80, 100]
 
+# Trace-set regimes of the synthetic generator (`make_raw_workload(profile=...)`). "default" is the frozen set every round-1..5
+# fixture was recorded on (2-18 stages, parents among the 6 nearest predecessors, <= ~220 tasks per stage, 2.7 MB
+# pack). "deep" is shaped like what a real TPC-H trace set is expected to look like: DAGs of up to 40 stages whose parents sit
+# anywhere upstream (in-degree <= 6), 4 .. 3000 tasks per stage growing with the input size, the executor levels the sampler's
+# interval table actually produces (tpch.py:238: no level 2), task durations from 50 ms to 40 s - a pack of tens of MB (past the
+# aggregate L2) with long runs of task completions per scheduling decision. Same corner-case rotation as the default.
+PROFILES = {
+    "default": dict(stages=(2, 19), max_in=3, parent_window=6, tasks=(1, 12), tasks_div=2, base=(200, 4000), levels=_LEVELS),
+    "deep": dict(stages=(4, 41), max_in=6, parent_window=None, tasks=(4, 76), tasks_div=1, base=(50, 20000), levels=_LEVELS[1:]),
+}
+
 
 def template_index(query_num: int, size_idx: int, n_sizes: int = len(QUERY_SIZES)) -> int:
     """template id used by the pack: query-major. `query_num` is 1-based as in
@@ -75,19 +86,19 @@ def trace_set_shape(raw: dict) -> tuple[list[str], int]:
 # --------------------------------------------------------------------------
 
 
-def _make_dag(rng: np.random.Generator, n: int) -> np.ndarray:
-    """random DAG on n >= 2 stages, edges u < v, in-degree <= 3, >= 1 edge
-    (the reference's `_reset_edge_links` cannot handle an edge-less job,
+def _make_dag(rng: np.random.Generator, n: int, max_in: int = 3, parent_window: int | None = 6) -> np.ndarray:
+    """random DAG on n >= 2 stages, edges u < v, in-degree <= max_in (parents among the `parent_window` nearest
+    predecessors; None: any predecessor), >= 1 edge (the reference's `_reset_edge_links` cannot handle an edge-less job,
     spark_sched_sim.py:254)."""
     adj = np.zeros((n, n), dtype=np.int64)
     for v in range(1, n):
-        max_par = min(v, 3)
+        max_par = min(v, max_in)
         # sources are allowed (k = 0) but get rarer further down the DAG
         k = int(rng.integers(0, max_par + 1))
         if k == 0 and rng.random() < 0.7:
             k = 1
         if k:
-            lo = max(0, v - 6)
+            lo = 0 if parent_window is None else max(0, v - parent_window)
             cand = np.arange(lo, v)
             k = min(k, cand.size)
             par = rng.choice(cand, size=k, replace=False)
@@ -98,7 +109,7 @@ def _make_dag(rng: np.random.Generator, n: int) -> np.ndarray:
 
 
 def _make_stage_durations(
-    rng: np.random.Generator, scale: int, variant: int
+    rng: np.random.Generator, scale: int, variant: int, prof: dict | None = None
 ) -> dict[str, dict[int, list[int]]]:
     """one stage's `{wave: {level: [ms, ...]}}` dict.
 
@@ -112,10 +123,11 @@ def _make_stage_durations(
       4 -> empty fresh list at some level (ValueError fallback + warmup)
       5 -> keys inserted in descending order (first key != smallest)
     """
-    num_tasks = max(1, int(rng.integers(1, 12)) * scale // 2)
-    base = int(rng.integers(200, 4000))
+    prof = PROFILES["default"] if prof is None else prof
+    num_tasks = max(1, int(rng.integers(*prof["tasks"])) * scale // prof["tasks_div"])
+    base = int(rng.integers(*prof["base"]))
 
-    levels = list(_LEVELS)
+    levels = list(prof["levels"])
     if variant == 1:
         levels = levels[: int(rng.integers(3, 6))]
     if variant == 5:
@@ -151,21 +163,24 @@ def _make_stage_durations(
     return {"fresh_durations": fresh, "first_wave": first, "rest_wave": rest}
 
 
-def make_raw_workload(seed: int = DEFAULT_SEED, query_sizes: list[str] | None = None, num_queries: int = NUM_QUERIES) -> dict[tuple[str, int], tuple[np.ndarray, dict]]:
+def make_raw_workload(seed: int = DEFAULT_SEED, query_sizes: list[str] | None = None, num_queries: int = NUM_QUERIES,
+                      profile: str = "default") -> dict[tuple[str, int], tuple[np.ndarray, dict]]:
     """-> {(size, query_num): (adj_mat int64[S,S], {stage: {wave: {level: [int]}}})}; by default the reference's grid of
-    7 sizes x 22 queries (the frozen set the fixtures were recorded on); other grids for tests of other trace-set shapes"""
+    7 sizes x 22 queries (the frozen set the fixtures were recorded on); other grids for tests of other trace-set shapes;
+    `profile`: the regime of DAG shapes / task counts / durations (PROFILES)"""
+    prof = PROFILES[profile]
     rng = np.random.default_rng(seed)
     raw: dict[tuple[str, int], tuple[np.ndarray, dict]] = {}
     query_sizes = list(QUERY_SIZES) if query_sizes is None else list(query_sizes)
     for q in range(1, num_queries + 1):
-        n_stages = int(rng.integers(2, 19))
-        adj = _make_dag(rng, n_stages)
+        n_stages = int(rng.integers(*prof["stages"]))
+        adj = _make_dag(rng, n_stages, prof["max_in"], prof["parent_window"])
         for size in query_sizes:
             scale = _SIZE_SCALE[size]
             td = {}
             for s in range(n_stages):
                 variant = int(rng.integers(0, 8))
-                td[s] = _make_stage_durations(rng, scale, variant)
+                td[s] = _make_stage_durations(rng, scale, variant, prof)
             raw[(size, q)] = (adj.copy(), td)
     return raw
 
@@ -234,6 +249,23 @@ def _template_constants(adj: np.ndarray, td: dict) -> dict[str, Any]:
     return {"n": n, "stages": stages, "edges": list(zip(us.tolist(), vs.tolist()))}
 
 
+def _is_dag(n: int, edges: list[tuple[int, int]]) -> bool:
+    indeg = [0] * n
+    for _, v in edges:
+        indeg[v] += 1
+    todo = [v for v in range(n) if indeg[v] == 0]
+    seen = 0
+    while todo:
+        u = todo.pop()
+        seen += 1
+        for a, b in edges:
+            if a == u:
+                indeg[b] -= 1
+                if indeg[b] == 0:
+                    todo.append(b)
+    return seen == n
+
+
 # --------------------------------------------------------------------------
 # pack
 # --------------------------------------------------------------------------
@@ -254,9 +286,46 @@ _SECTIONS = (
 )
 
 
+MAX_STAGES_PER_JOB = 64       # stage bit masks are 64 bits (csrc/sss_layout.h: SSS_MAX_STAGES)
+MAX_EDGES_PER_JOB = 255       # SssJob.n_edges is a byte
+MAX_LEVELS = 16               # csrc/sss_layout.h: SSS_MAX_LEVELS
+MAX_INT32 = 2 ** 31 - 1       # task counts, durations (ms), list offsets and lengths are carried as int32
+
+
+def _duration_array(lst, where: str) -> np.ndarray:
+    """one duration list as the int32 array the pack carries - or a ValueError naming the list. The reference takes whatever
+    numbers the trace files hold (tpch.py:208-214 `np_random.choice(list)`; event times are Python floats); the pack narrows
+    them to int32 milliseconds, so everything that does not survive that narrowing unchanged is refused HERE rather than
+    truncated: non-integer values (1234.5), values >= 2^31, NaN / inf, negative durations (the batched event paths bound the
+    time of events that do not exist yet from below with the lists' minima), non-numeric entries."""
+    a = np.asarray(lst)
+    if a.ndim != 1:
+        raise ValueError(f"{where}: expected a flat list of durations, got shape {a.shape}")
+    if a.size == 0:
+        return np.zeros(0, dtype=np.int32)
+    if a.dtype.kind == "b" or a.dtype.kind not in "iuf":
+        raise ValueError(f"{where}: durations must be numbers, got dtype {a.dtype}")
+    if a.dtype.kind == "f":
+        if not np.all(np.isfinite(a)):
+            raise ValueError(f"{where}: non-finite task duration")
+        frac = a != np.rint(a)
+        if frac.any():
+            raise ValueError(f"{where}: task duration {a[frac][0]!r} is not a whole number of milliseconds "
+                             "(the pack carries int32 ms; rescale the trace set instead of letting it truncate)")
+    if (a < 0).any():
+        raise ValueError(f"{where}: negative task duration {a[a < 0][0]!r}")
+    if (a > MAX_INT32).any():
+        raise ValueError(f"{where}: task duration {a[a > MAX_INT32][0]!r} does not fit int32 milliseconds (max {MAX_INT32})")
+    return a.astype(np.int32)
+
+
 def build_pack_arrays(raw: dict, query_sizes: list[str] | None = None, num_queries: int | None = None) -> dict[str, np.ndarray]:
     """`query_sizes` / `num_queries`: the sampler's QUERY_SIZES / NUM_QUERIES (tpch.py:14-15: `integers(NUM_QUERIES)`,
-    `choice(QUERY_SIZES)` index the templates); by default whatever grid `raw` holds (the reference's 7 x 22 for its own data)"""
+    `choice(QUERY_SIZES)` index the templates); by default whatever grid `raw` holds (the reference's 7 x 22 for its own data).
+
+    Every field the pack carries narrower than the reference's Python objects is checked here and a ValueError names the
+    offending template / stage / list (DESIGN.md section 8 lists the limits); `sss_create` checks what can still be seen in the
+    serialized pack again."""
     if query_sizes is None or num_queries is None:
         found_sizes, found_q = trace_set_shape(raw)
         query_sizes = found_sizes if query_sizes is None else list(query_sizes)
@@ -268,7 +337,10 @@ def build_pack_arrays(raw: dict, query_sizes: list[str] | None = None, num_queri
                 level_set.update(st[w].keys())
     levels = sorted(level_set)
     L = len(levels)
-    assert L <= 32, "first_keymask is 32 bits"
+    if L > MAX_LEVELS:
+        raise ValueError(f"trace set uses {L} distinct executor levels {levels}; at most {MAX_LEVELS} are supported")
+    if any((not isinstance(e, (int, np.integer))) or isinstance(e, bool) or e < 0 or e > MAX_INT32 for e in levels):
+        raise ValueError(f"executor levels must be non-negative ints, got {levels}")
     lvl_idx = {e: i for i, e in enumerate(levels)}
 
     tmpl_stage_off = [0]
@@ -282,10 +354,24 @@ def build_pack_arrays(raw: dict, query_sizes: list[str] | None = None, num_queri
     for q in range(1, num_queries + 1):
         for size in query_sizes:
             adj, td = raw[(size, q)]
-            tc = _template_constants(np.asarray(adj), td)
-            n = tc["n"]
-            assert 1 <= n <= 64, "stage bit masks are 64 bits"
-            assert tc["edges"], "every template needs >= 1 edge (spark_sched_sim.py:254)"
+            name = f"template (size {size!r}, query {q})"
+            adj = np.asarray(adj)
+            n = adj.shape[0] if adj.ndim == 2 else -1
+            if adj.ndim != 2 or adj.shape != (n, n) or len(td) != n:
+                raise ValueError(f"{name}: adjacency matrix {adj.shape} does not match its {len(td)} stages")
+            if not 1 <= n <= MAX_STAGES_PER_JOB:
+                raise ValueError(f"{name}: {n} stages; 1 .. {MAX_STAGES_PER_JOB} per job are supported (stage bit masks are 64 bits)")
+            for s_, st_ in td.items():  # (before anything is computed from the lists: the cleaning pass and the rough mean)
+                for w_ in WAVES:
+                    for e_, lst_ in st_[w_].items():
+                        _duration_array(lst_, f"{name} stage {s_} {w_}[{e_}]")
+            tc = _template_constants(adj, td)
+            if not tc["edges"]:
+                raise ValueError(f"{name}: no edge - the reference cannot run an edge-less job either (spark_sched_sim.py:254 np.vstack([]))")
+            if len(tc["edges"]) > MAX_EDGES_PER_JOB:
+                raise ValueError(f"{name}: {len(tc['edges'])} edges; at most {MAX_EDGES_PER_JOB} per job are supported")
+            if any(u >= v for u, v in tc["edges"]) and not _is_dag(n, tc["edges"]):
+                raise ValueError(f"{name}: the stage graph has a cycle")
             pm = [0] * n
             cm = [0] * n
             for u, v in tc["edges"]:
@@ -293,6 +379,8 @@ def build_pack_arrays(raw: dict, query_sizes: list[str] | None = None, num_queri
                 cm[u] |= 1 << v
             edges += tc["edges"]
             for s, st in enumerate(tc["stages"]):
+                if not 0 <= st["num_tasks"] <= MAX_INT32:
+                    raise ValueError(f"{name} stage {s}: {st['num_tasks']} tasks do not fit the int32 task counter")
                 num_tasks.append(st["num_tasks"])
                 rough.append(st["rough"])
                 pmask.append(pm[s])
@@ -310,10 +398,14 @@ def build_pack_arrays(raw: dict, query_sizes: list[str] | None = None, num_queri
                     for e, lst in wave.items():
                         key = id(lst)
                         if key not in seen:  # inherited lists share storage
-                            arr = np.asarray(lst, dtype=np.int32)
+                            arr = _duration_array(lst, f"{name} stage {s} {WAVES[w]}[{e}]")
+                            if arr.size >= 1 << 30:
+                                raise ValueError(f"{name} stage {s} {WAVES[w]}[{e}]: {arr.size} durations in one list (max 2^30 - 1)")
                             seen[key] = (dur_off, arr.size)
                             dur_chunks.append(arr)
                             dur_off += arr.size
+                            if dur_off > MAX_INT32:
+                                raise ValueError(f"trace set holds more than {MAX_INT32} durations (list offsets are int32)")
                         d[w, lvl_idx[e]] = seen[key]
                 desc_rows.append(d)
             tmpl_stage_off.append(len(num_tasks))
@@ -428,7 +520,7 @@ def pack_digest(pack: bytes) -> str:
     return hashlib.sha256(pack).hexdigest()
 
 
-_CACHE: dict[int, bytes] = {}
+_CACHE: dict = {}
 
 
 def default_pack(seed: int = DEFAULT_SEED) -> bytes:
@@ -436,6 +528,14 @@ def default_pack(seed: int = DEFAULT_SEED) -> bytes:
     if seed not in _CACHE:
         _CACHE[seed] = build_pack(seed=seed)
     return _CACHE[seed]
+
+
+def profile_pack(profile: str = "default", seed: int = DEFAULT_SEED, query_sizes: list[str] | None = None, num_queries: int = NUM_QUERIES) -> bytes:
+    """the pack of the synthetic trace set of a generator profile (PROFILES), cached per process"""
+    key = (profile, seed, tuple(query_sizes) if query_sizes is not None else None, num_queries)
+    if key not in _CACHE:
+        _CACHE[key] = default_pack(seed) if key == ("default", seed, None, NUM_QUERIES) else build_pack(make_raw_workload(seed, query_sizes, num_queries, profile=profile))
+    return _CACHE[key]
 
 
 def pack_from_reference_layout(root: str, query_sizes: list[str] | None = None, num_queries: int | None = None) -> bytes:

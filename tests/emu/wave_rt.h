@@ -121,6 +121,7 @@ SSS_DEV void lane_atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
 SSS_DEV void lane_atomic_and_u64(uint64_t* p, uint64_t v) { *p &= v; }
 SSS_DEV void lane_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 SSS_DEV void lane_atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
+SSS_DEV void lane_atomic_add_u64(uint64_t* p, uint64_t v) { *p += v; }
 // a counter in global memory shared by the waves of a launch: returns the value before the addition
 SSS_DEV int64_t global_fetch_add_i64(int64_t* p, int64_t v) { int64_t o = *p; *p = o + v; return o; }  // (waves run one at a time)
 SSS_DEV void global_atomic_max_i64(int64_t* p, int64_t v) { if (*p < v) *p = v; }  // (waves run one at a time)

@@ -55,7 +55,9 @@ E100 = dict(num_executors=100, job_arrival_cap=40, job_arrival_rate=1.0e-4, movi
 E120 = dict(num_executors=120, job_arrival_cap=6, job_arrival_rate=2.0e-5, moving_delay=2000.0,
             warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler")
 
-# name -> (env_cfg, policy, seeds, reset options)
+DEEP = (list(workload.QUERY_SIZES), workload.NUM_QUERIES, workload.DEFAULT_SEED, "deep")
+
+# name -> (env_cfg, policy, seeds, reset options[, (query sizes, number of queries, generator seed[, generator profile])])
 SETS = {
     "c1_fair": (C1, "fair", [1234] + list(range(20)), None),
     "c1_hash": (C1, "hash", list(range(100, 112)), None),
@@ -77,6 +79,15 @@ SETS = {
     # QUERY_SIZES / NUM_QUERIES (tpch.py:14-15); here those two module constants are set on the imported module
     "q5s2_fair": (dict(C1, job_arrival_cap=25), "fair", [0, 1, 2], None, (["2g", "10g"], 5, 77)),
     "q5s2_hash": (dict(C1, job_arrival_cap=25), "hash", [3, 4], None, (["2g", "10g"], 5, 77)),
+    # the "deep" trace regime (workload.PROFILES: up to 40 stages, in-degree <= 6 over all predecessors, 4 .. 3000 tasks per stage,
+    # no executor level 2, durations 50 ms .. 40 s; a 60 MB pack): long runs of task completions per decision, parents far upstream
+    "deep_c1_fair": (C1, "fair", [0, 1], None, DEEP),
+    "deep_c1_hash": (C1, "hash", [2], None, DEEP),
+    "deep_c1_fifo": (dict(C1, job_arrival_cap=30), "fifo", [3], None, DEEP),
+    "deep_e50_fair": (dict(C3, job_arrival_cap=100), "fair", [0], None, DEEP),
+    "deep_e50_hash": (dict(C3, job_arrival_cap=60), "hash", [1], None, DEEP),
+    "deep_e100_fair": (E100, "fair", [0], None, DEEP),
+    "deep_e100_hash": (E100, "hash", [1], None, DEEP),
 }
 
 
@@ -210,8 +221,9 @@ def main(argv):
     for name in names:
         env_cfg, policy, seeds, options = SETS[name][:4]
         shape = SETS[name][4] if len(SETS[name]) > 4 else None
-        sizes, n_queries, raw_seed = shape if shape else (list(workload.QUERY_SIZES), workload.NUM_QUERIES, workload.DEFAULT_SEED)
-        raw = workload.make_raw_workload(raw_seed, sizes, n_queries)
+        sizes, n_queries, raw_seed = shape[:3] if shape else (list(workload.QUERY_SIZES), workload.NUM_QUERIES, workload.DEFAULT_SEED)
+        profile = shape[3] if shape and len(shape) > 3 else "default"
+        raw = workload.make_raw_workload(raw_seed, sizes, n_queries, profile=profile)
         pack = workload.build_pack(raw)
         with tempfile.TemporaryDirectory() as tmp:
             workload.write_reference_layout(raw, tmp)
@@ -239,6 +251,8 @@ def main(argv):
         blob["pack_sha256"] = np.asarray(workload.pack_digest(pack))
         if shape:  # what tests/golden_util.py needs to rebuild the set's pack
             blob["trace_sizes"], blob["trace_queries"], blob["trace_seed"] = np.asarray(sizes), np.int64(n_queries), np.int64(raw_seed)
+            if profile != "default":
+                blob["trace_profile"] = np.asarray(profile)
         blob["cfg_keys"] = np.asarray(sorted(k for k in env_cfg if k != "data_sampler_cls"))
         blob["cfg_vals"] = np.asarray(
             [np.nan if env_cfg[k] is None else float(env_cfg[k]) for k in sorted(env_cfg) if k != "data_sampler_cls"],

@@ -8,6 +8,8 @@ import numpy as np
 GOLDEN_DIR = osp.join(osp.dirname(osp.abspath(__file__)), "golden")
 ALL_SETS = ["tiny_hash", "tiny_fair_tlimit", "c1_fair", "c1_hash", "c1_fifo", "c3_fair", "c3_hash",
             "testyaml_fair", "bige_hash", "e100_fair", "e100_hash", "e120_hash", "q5s2_fair", "q5s2_hash"]
+# recorded on the "deep" trace regime (workload.PROFILES["deep"], a 60 MB pack)
+DEEP_SETS = ["deep_c1_fair", "deep_c1_hash", "deep_c1_fifo", "deep_e50_fair", "deep_e50_hash", "deep_e100_fair", "deep_e100_hash"]
 
 
 _PACKS: dict = {}
@@ -32,13 +34,14 @@ class Golden:
 
     def pack(self, default: bytes) -> bytes:
         """the workload pack the set was recorded on: the frozen default, or - sets that name a trace-set shape (make_golden.py:
-        q5s2_*) - the pack of that many sizes x queries from that generator seed"""
+        q5s2_*, deep_*) - the pack of that many sizes x queries from that generator seed and profile"""
         if "trace_sizes" not in self.z:
             return default
         from spark_sched_sim_amd import workload
-        key = (tuple(str(x) for x in self.z["trace_sizes"]), int(self.z["trace_queries"]), int(self.z["trace_seed"]))
+        profile = str(self.z["trace_profile"]) if "trace_profile" in self.z else "default"
+        key = (tuple(str(x) for x in self.z["trace_sizes"]), int(self.z["trace_queries"]), int(self.z["trace_seed"]), profile)
         if key not in _PACKS:
-            _PACKS[key] = workload.build_pack(workload.make_raw_workload(key[2], list(key[0]), key[1]))
+            _PACKS[key] = workload.profile_pack(profile, key[2], list(key[0]), key[1])
         return _PACKS[key]
 
     def ep(self, seed: int, key: str):

@@ -23,6 +23,14 @@ CASES = [
     ("e120_hash", [0, 1, 2, 3], None),
     ("q5s2_fair", [0, 1, 2], None),   # a trace set of 5 queries x 2 sizes
     ("q5s2_hash", [3, 4], None),
+    # the "deep" trace regime (a 60 MB pack: <= 40 stages, in-degree <= 6, <= 3000 tasks per stage), whole episodes
+    ("deep_c1_fair", [0, 1], None),
+    ("deep_c1_hash", [2], None),
+    ("deep_c1_fifo", [3], None),
+    ("deep_e50_fair", [0], None),
+    ("deep_e50_hash", [1], None),
+    ("deep_e100_fair", [0], None),
+    ("deep_e100_hash", [1], None),
 ]
 
 

@@ -6,7 +6,7 @@ reference's error behaviour ("[step]" assertion)."""
 import numpy as np
 import pytest
 
-from golden_util import ALL_SETS, Golden, bits
+from golden_util import ALL_SETS, DEEP_SETS, Golden, bits
 from oracle_binding import OracleEnv
 from spark_sched_sim_amd import workload
 from spark_sched_sim_amd.digest import digest_words
@@ -57,7 +57,7 @@ def replay(env: OracleEnv, g: Golden, seed: int, check_full: bool = True):
     assert int(env.info().num_completed) == int(g.ep(seed, "num_completed"))
 
 
-@pytest.mark.parametrize("name", ALL_SETS + ["c1_fair_beta"])
+@pytest.mark.parametrize("name", ALL_SETS + ["c1_fair_beta"] + DEEP_SETS)
 def test_oracle_matches_reference_trajectories(name, pack):
     g = Golden(name)
     pack = g.pack(pack)
