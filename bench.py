@@ -52,7 +52,7 @@ PREROLL_STEPS = {"c2": 1500, "c3": 6000, "e100": 6000}  # a few episodes each (a
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(cfg: dict, policy: str, budget_s: float) -> dict:
+def cpu_baseline(cfg: dict, policy: str, budget_s: float, pack_profile: str = "default") -> dict:
     """the C oracle (a port of the reference env, bit-identical trajectories) on ONE host core,
     same workload, whole episodes until ~budget_s of CPU time is spent"""
     import ctypes as C
@@ -61,7 +61,7 @@ def cpu_baseline(cfg: dict, policy: str, budget_s: float) -> dict:
     from oracle_binding import OracleEnv
     from spark_sched_sim_amd import workload
 
-    env = OracleEnv(workload.default_pack(), cfg)
+    env = OracleEnv(workload.profile_pack(pack_profile), cfg)
     pol = {"fair": 0, "hash": 1}[policy]
     steps, eps = 0, 0
     t0 = time.perf_counter()
@@ -83,9 +83,9 @@ sys.path[:0] = [{root!r}, {tests!r}]
 from oracle_binding import OracleEnv
 from spark_sched_sim_amd import workload
 cfg, pol, budget, wid = json.loads(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
-env = OracleEnv(workload.default_pack(), cfg)
+env = OracleEnv(workload.profile_pack(sys.argv[5]), cfg)
 steps = eps = 0
-t0 = time.perf_counter()
+t0 = time.perf_counter()   # (the pack is built before the clock starts)
 while time.perf_counter() - t0 < budget:
     r = C.c_double()
     steps += max(0, env.lib.sso_run_episode(env.h, 20000 + 1000 * wid + eps, pol, 10**9, C.byref(r)))
@@ -127,7 +127,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float) -> dict:
+def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float, pack_profile: str = "default") -> dict:
     """the reference's own parallelism model (one process per env, trainers/trainer.py:264-293)
     with the C oracle: one child process per host core (plain subprocesses that never touch the GPU)"""
     import subprocess
@@ -135,7 +135,7 @@ def cpu_baseline_all_cores(cfg: dict, policy: str, budget_s: float) -> dict:
     n = usable_cores()
     code = _CPU_WORKER.format(root=ROOT, tests=osp.join(ROOT, "tests"))
     pol = {"fair": 0, "hash": 1}[policy]
-    procs = [subprocess.Popen([sys.executable, "-c", code, json.dumps(cfg), str(pol), str(budget_s), str(w)],
+    procs = [subprocess.Popen([sys.executable, "-c", code, json.dumps(cfg), str(pol), str(budget_s), str(w), pack_profile],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for w in range(n)]
     res = []
     for p in procs:
@@ -258,7 +258,7 @@ def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
 class Bench:
     """one rank's share of one configuration: B envs (optionally in sub-batches on their own streams)"""
 
-    def __init__(self, args, config: str, policy: str, B: int, dev, rank: int, world: int):
+    def __init__(self, args, config: str, policy: str, B: int, dev, rank: int, world: int, pack_profile: str | None = None):
         import torch
 
         from spark_sched_sim_amd import VecSparkSchedSimEnv, workload
@@ -268,7 +268,8 @@ class Bench:
         S = max(1, args.shards)
         assert B % S == 0, "--envs must be divisible by --shards"
         Bs = B // S
-        self.pack = workload.default_pack()
+        self.pack_profile = pack_profile or getattr(args, "pack", "default")
+        self.pack = workload.profile_pack(self.pack_profile)
         # env i of shard s of rank r: seed (r*S + s)*Bs + i = its global env id (placement invariant)
         lib = None
         if getattr(args, "lib", None):  # an A/B test build of the library (tests/gpu_variant.py), never the default
@@ -279,7 +280,7 @@ class Bench:
         for k, e in enumerate(self.shards):
             e.reset(seed=(rank * S + k) * Bs)
         # steady state: every env a few episodes in, all phases of an episode present in the batch
-        left = PREROLL_STEPS[config] if args.preroll is None else args.preroll
+        left = (PREROLL_STEPS[config] * (2 if self.pack_profile == "deep" else 1)) if args.preroll is None else args.preroll
         while left > 0:
             n = min(500, left)
             for e in self.shards:
@@ -472,6 +473,33 @@ def bounded_record(bench: "Bench", args, config: str, steps: int, warmup: int):
             "what": "policy launch + sss_step_bounded per iteration; an env's step that exceeds the budget continues in the next launch"}
 
 
+def deep_record(args, B: int, dev, rank: int, world: int) -> dict:
+    """extra, not the headline: the same entry points on the second synthetic trace regime (workload.PROFILES["deep"]: DAGs of up to 40
+    stages with parents anywhere upstream, 4 .. 3000 tasks per stage, durations 50 ms .. 40 s - a 60 MB pack, past the aggregate L2, with
+    hundreds of task completions per scheduling decision), which the reference-recorded `deep_*` goldens pin (tests/golden/). C2 and
+    C3 sizing: step mode (sss_policy + sss_step per batched step) and the fused rollout, each with its roofline; the C oracle on all host
+    cores beside them on the same pack."""
+    out: dict = {"pack": "deep", "what": "BASELINE config 2 / 3 sizing on the 'deep' trace regime (<= 40 stages, in-degree <= 6 over all predecessors, <= 3000 tasks "
+                                          "per stage, 60 MB pack); on-device policies, auto-reset, every env past its first episodes"}
+    for config in ("c2", "c3"):
+        try:
+            b = Bench(args, config, DEFAULT_POLICY[config], B, dev, rank, world, pack_profile="deep")
+            k, w = max(10, min(args.steps, 200)), max(5, min(args.warmup, 30))
+            r = b.measure("step", k, w)
+            f = b.measure("fused", k, w)
+            rec = {"value": r["value"], "unit": "env-steps/s", "ms_per_step": r["ms_per_step"], "steps": k, "events_per_step": r["events_per_step"], "events_per_s": r["events_per_s"],
+                   "fast_path_event_frac": r["fast_path_event_frac"], "batched_event_frac": r["batched_event_frac"], "roofline": r["roofline"],
+                   "step_tail": b.step_tail(8), "fused": {"value": f["value"], "ms_per_step": f["ms_per_step"], "events_per_s": f["events_per_s"], "roofline": f["roofline"]},
+                   "mean_last_episode_return": b.header_field("last_ep_return").mean().item(), "envs_in_error_state": int((b.shards[0].obs_i32[:, 7] != 0).sum())}
+            b.close()
+            if not args.no_cpu_baseline:
+                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS[config], DEFAULT_POLICY[config], min(4.0, args.cpu_budget / 2), "deep")
+            out[config] = rec
+        except Exception as e:  # never let the extra record take the bench line down
+            out[config] = {"error": repr(e)}
+    return out
+
+
 def run_ranks_myself(args) -> int:
     """--gpus N without a torch.distributed environment: N fresh rank processes (nothing here has touched the GPU)"""
     from spark_sched_sim_amd.distributed import launch_ranks
@@ -490,6 +518,10 @@ def main() -> None:
     ap.add_argument("--mode", default="step", choices=["step", "fused"])
     ap.add_argument("--fused-chunk", type=int, default=50)
     ap.add_argument("--preroll", type=int, default=None, help="fused steps every env runs before anything is timed (default: a few episodes)")
+    ap.add_argument("--pack", default="default", choices=["default", "deep"],
+                    help="synthetic trace regime (spark_sched_sim_amd/workload.py PROFILES): 'default' = the frozen 2.7 MB set of SURVEY 8(d); 'deep' = "
+                         "<= 40 stages, in-degree <= 6, <= 3000 tasks per stage, a 60 MB pack")
+    ap.add_argument("--no-deep", action="store_true", help="skip the extra record on the 'deep' trace regime (N=1, --config c2 --pack default only)")
     ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the extra PPO-iteration record (one rank's share of BASELINE config 5; N=1, c2 only)")
     ap.add_argument("--event-every", type=int, default=8, help="HIP events (the roofline's launch durations) around every N-th step launch of the timed region: "
@@ -567,7 +599,7 @@ def main() -> None:
     out = None
     if rank == 0:
         workload = (f"{B} envs/GPU x ({cfg['num_executors']} executors, {cfg['job_arrival_cap']} TPC-H-format jobs, job_arrival_rate {cfg['job_arrival_rate']}/ms, "
-                    f"synthetic frozen trace set), on-device '{policy}' policy, auto-reset, steady state (every env several episodes in), "
+                    f"synthetic frozen trace set{'' if args.pack == 'default' else ' of the ' + repr(args.pack) + ' regime'}), on-device '{policy}' policy, auto-reset, steady state (every env several episodes in), "
                     f"mode={args.mode} ({'sss_policy + sss_step per batched step' if args.mode == 'step' else 'sss_rollout, ' + str(args.fused_chunk) + ' steps per launch'})")
         out = {
             "metric": "env-steps/sec at 4096 batched envs (TPC-H, 10 exec)" if (args.config == "c2" and B == 4096) else f"env-steps/sec at {B} batched envs ({args.config})",
@@ -607,18 +639,20 @@ def main() -> None:
         if bounded is not None:
             out["bounded_launches"] = bounded
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(cfg, policy, args.cpu_budget, args.pack)
             try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(4.0, args.cpu_budget / 2))
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(4.0, args.cpu_budget / 2), args.pack)
             except Exception as e:  # never let the extra baseline take the bench line down
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
-            ref_py = reference_python_baseline(args.config)
+            ref_py = reference_python_baseline(args.config) if args.pack == "default" else None
             if ref_py is not None:
                 out["cpu_baseline_reference_python"] = ref_py
     pack = bench.pack
     bench.close()
 
     # BASELINE config 3 next to the headline (N = 1): same measurements, its own roofline and CPU baseline
+    if world == 1 and args.config == "c2" and not args.no_deep and args.shards == 1 and args.pack == "default":
+        out["deep"] = deep_record(args, B, dev, rank, world)
     if world == 1 and args.config == "c2" and not args.no_c3 and args.shards == 1:
         try:
             b3 = Bench(args, "c3", DEFAULT_POLICY["c3"], B, dev, rank, world)
@@ -643,9 +677,9 @@ def main() -> None:
             if s3 is not None:
                 rec["sustained"] = s3
             if not args.no_cpu_baseline:
-                rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2))
-                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2))
-                ref_py = reference_python_baseline("c3")
+                rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2), args.pack)
+                rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2), args.pack)
+                ref_py = reference_python_baseline("c3") if args.pack == "default" else None
                 if ref_py is not None:
                     rec["cpu_baseline_reference_python"] = ref_py
             out["c3"] = rec

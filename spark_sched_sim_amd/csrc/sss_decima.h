@@ -78,7 +78,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   int64_t n0 = d.node_off[env], j0 = d.job_off[env], e0 = d.edge_off[env];
   // two words per node slot (LDS decides how many envs a CU holds at once - at 200 jobs x 18 stage slots four words were 57.6 KB,
   // two envs per CU):  gr = generation in bits 0..7 (alone while the relaxation runs: its atomic max sees a plain integer), then the
-  // receiver bits from bit 8 up (at most 24 layers: the host checks the stage slots per job);  mb = the layer-membership bits, then
+  // receiver bits from bit 8 up (at most 24 layers: the host checks the longest path of the workload's job templates);  mb = the layer-membership bits, then
   // the node's out-edge range as two 16-bit halves (first edge | end << 16: edge slots are below 65536)
   uint32_t* gr = (uint32_t*)g_dec_lds;
   uint32_t* mb = gr + L.n_cap;
@@ -88,7 +88,7 @@ SSS_KERNEL void sss_decima_graph_kernel(SssLayout L, SssBuffers B, int E, SssDec
   int32_t* js = jp + (L.J_cap + 1);
   for (int i = lane; i < n; i += 64) gr[i] = 0, mb[i] = 0;
   for (int a = lane; a <= A; a += 64) jp[a] = dag_ptr[a], js[a] = a < A ? sup[a] : 0;
-  // the first 256 edges stay in registers (end points packed 16 + 16 bits: node slots are below 4096), the rest is re-read from the
+  // the first 256 edges stay in registers (end points packed 16 + 16 bits: node slots are below 65536), the rest is re-read from the
   // observation where a phase needs it: the relaxation below walks the edge list once per DAG level, and re-reading it from
   // global memory every time was a third of the kernel (~45 dependent round trips per env at ~250 edges)
   uint32_t ev[4];

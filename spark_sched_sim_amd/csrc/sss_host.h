@@ -79,9 +79,34 @@ static int sss_pack_parse(const uint8_t* p, size_t n, SssPackHost* v) {
   return 0;
 }
 
+// the longest path (in edges) of any template's stage DAG: what bounds the DAG layers (topological generations beyond the first,
+// decima/utils.py:246-267) of any observation of this workload (workload.py: pack_max_depth)
+static int sss_pack_max_depth(const uint8_t* p, const SssPackHost& v) {
+  const int32_t* so = (const int32_t*)(p + v.sec_off[1]);
+  const int32_t* eo = (const int32_t*)(p + v.sec_off[2]);
+  const int32_t* ed = (const int32_t*)(p + v.sec_off[9]);
+  int best = 0;
+  for (int t = 0; t < v.T; t++) {
+    const int n = so[t + 1] - so[t];
+    if (n < 1 || n > SSS_MAX_STAGES) continue;
+    int dist[SSS_MAX_STAGES] = {0};
+    for (int it = 0; it < n; it++) {  // longest-path relaxation; a DAG of n stages settles within n sweeps
+      bool moved = false;
+      for (int e = eo[t]; e < eo[t + 1]; e++) {
+        const int u = ed[2 * e], w = ed[2 * e + 1];
+        if (u >= 0 && u < n && w >= 0 && w < n && dist[w] < dist[u] + 1) dist[w] = dist[u] + 1, moved = true;
+      }
+      if (!moved) break;
+    }
+    for (int i = 0; i < n; i++) best = dist[i] > best ? dist[i] : best;
+  }
+  return best;
+}
+
 struct sss_handle {
   sss_cfg cfg;
   SssPackHost ph;
+  int max_dag_depth;
   SssLayout L;
   SssBuffers B;
   bool bound;
@@ -299,6 +324,7 @@ extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_byte
   if (int rc = be_set_device(device)) return sss_fail(-10, "cannot select device " + std::to_string(device) + ": " + be_error(rc));
   sss_handle* h = new sss_handle();
   h->cfg = *cfg, h->ph = ph, h->device = device, h->bound = false;
+  h->max_dag_depth = sss_pack_max_depth((const uint8_t*)pack, ph);
   sss_compute_layout(&h->L, num_envs, cfg->num_executors, J_cap, ph.s_max, ph.L, ph.max_edges_per_job, sss_hot_bytes(cfg->num_executors));
   memset(&h->B, 0, sizeof(h->B));
 
@@ -475,8 +501,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
       !g->edge_layers_dev || !g->job_obs_dev || !g->job_cap_dev || !g->job_first_dev || !g->obs_depth_dev ||
       !g->job_nodes_dev || !g->out_start_dev || !g->out_deg_dev || !g->layer_cnt_dev)
     return sss_fail(-1, "NULL argument");
-  if ((int64_t)8 * h->L.n_cap + (int64_t)8 * (h->L.J_cap + 1) > 65536 || h->L.n_cap > 65535 || h->L.ed_cap > 65535 || h->L.SP > 24)
-    return sss_fail(-25, "node / edge capacity or stage slots per job too large for the Decima graph kernel's LDS working set");
+  if ((int64_t)8 * h->L.n_cap + (int64_t)8 * (h->L.J_cap + 1) > 65536 || h->L.n_cap > 65535 || h->L.ed_cap > 65535 || h->max_dag_depth > 24)
+    return sss_fail(-25, "node / edge capacity too large for the Decima graph kernel's LDS working set, or a job template deeper than 24 DAG layers");
   SssDecimaArgs d;
   d.active = g->active_dev, d.node_off = g->node_off_dev, d.job_off = g->job_off_dev, d.edge_off = g->edge_off_dev;
   d.num_tasks_scale = g->num_tasks_scale, d.work_scale = g->work_scale;

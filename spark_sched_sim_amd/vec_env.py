@@ -338,9 +338,10 @@ class VecSparkSchedSimEnv:
     @property
     def graph_kernel_fits(self) -> bool:
         """whether include/sss.h sss_decima_graph_build takes this env's capacities (its per-env LDS working set: 8 bytes per node
-        slot + 8 per job slot; 16-bit node / edge slots; at most 24 DAG layers) - else the graph comes from tensor ops"""
+        slot + 8 per job slot; 16-bit node / edge slots; job templates of at most 24 DAG layers = longest path in edges) - else the
+        graph comes from tensor ops"""
         d = self.dims
-        return 8 * d.node_cap + 8 * (d.job_cap + 1) <= 65536 and d.node_cap <= 65535 and d.edge_cap <= 65535 and d.stage_stride <= 24
+        return 8 * d.node_cap + 8 * (d.job_cap + 1) <= 65536 and d.node_cap <= 65535 and d.edge_cap <= 65535 and self.max_dag_depth <= 24
 
     def decima_graph(self, active: torch.Tensor | None = None, num_tasks_scale: float = 200.0, work_scale: float = 1e5,
                      reuse_buffers: bool = False) -> dict[str, Any]:
@@ -355,6 +356,12 @@ class VecSparkSchedSimEnv:
         if not self.graph_kernel_fits:
             # the kernel's per-node LDS working set does not fit: same graph from tensor ops on the device
             from .decima import compact_graph, decima_observation
+            if not getattr(self, "_warned_graph_fallback", False):
+                import warnings
+                self._warned_graph_fallback = True
+                warnings.warn(f"Decima graph kernel not usable for this env (node capacity {self.dims.node_cap}, edge capacity {self.dims.edge_cap}, "
+                              f"deepest job template {self.max_dag_depth} DAG layers; limits: 8 B x nodes + 8 B x jobs <= 64 KB of LDS, 65535 slots, 24 layers): "
+                              "observations are transformed by tensor ops instead (same results, several times slower per step)", RuntimeWarning, stacklevel=2)
             f = decima_observation(self._obs(), self.num_executors, self.dims.stage_stride, int(num_tasks_scale), work_scale)
             if active is not None:
                 for k in ("node_valid", "job_valid", "edge_valid", "stage_mask"):

@@ -22,7 +22,9 @@ def check_decima_fixture(name, device, lib, n_steps):
     cfg["job_arrival_cap"] = int(cfg["job_arrival_cap"])
     seeds = [int(s) for s in g["seeds"]]
     E = cfg["num_executors"]
-    env = VecSparkSchedSimEnv(cfg, len(seeds), device=device, _lib=lib)
+    from spark_sched_sim_amd import workload
+    pack = workload.profile_pack(str(g["trace_profile"])) if "trace_profile" in g.files else None  # (None: the frozen default pack)
+    env = VecSparkSchedSimEnv(cfg, len(seeds), device=device, _lib=lib, pack=pack)
     dev = env.device
     policy = DecimaPolicy(num_executors=E, **AGENT)
     policy.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")})
@@ -50,7 +52,8 @@ def check_decima_fixture(name, device, lib, n_steps):
             assert policy._use_kernels()
             hk = policy._encode_kernels(kg)
             for k in ("node", "dag", "glob"):
-                assert float((hk[k] - h[k]).abs().max()) <= SCORE_ATOL, (t, k)
+                # (embeddings are sums over up to ~40 nodes per job, ~1000 per observation: round-off scales with their magnitude)
+                assert float((hk[k] - h[k]).abs().max()) <= SCORE_ATOL * max(1.0, float(h[k].abs().max())), (t, k)
             sk = policy._stage_scores_kernels(kg, hk)
             assert torch.equal(torch.isfinite(sk), torch.isfinite(ss)), t
             assert float((sk - ss)[torch.isfinite(ss)].abs().max()) <= SCORE_ATOL, t

@@ -42,6 +42,9 @@ CFGS = {
     # more than 64 executors: executor-count scores / exec_mask of 100 entries per job, the simulator's wide instantiation
     "decima_e100": (dict(num_executors=100, job_arrival_cap=12, job_arrival_rate=1.2e-4, moving_delay=2000.0,
                          warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"), [6]),
+    # the "deep" trace regime (workload.PROFILES: DAGs of up to 40 stages and 12 layers, in-degree <= 6, thousands of tasks per stage)
+    "decima_deep": (dict(num_executors=10, job_arrival_cap=30, job_arrival_rate=4.0e-5, moving_delay=2000.0,
+                         warmup_delay=1000.0, data_sampler_cls="TPCHDataSampler"), [7, 8], "deep"),
 }
 AGENT = dict(embed_dim=16,
              gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(inplace=True, negative_slope=0.2)),
@@ -49,19 +52,30 @@ AGENT = dict(embed_dim=16,
 
 
 def main(argv):
-    raw = workload.make_raw_workload()
-    with tempfile.TemporaryDirectory() as tmp:
+    cwd0 = os.getcwd()
+    for profile in sorted({(c[2] if len(c) > 2 else "default") for c in CFGS.values()}):
+        names = [n for n, c in CFGS.items() if (c[2] if len(c) > 2 else "default") == profile and (not argv or n in argv)]
+        if names:
+            with tempfile.TemporaryDirectory() as tmp:
+                try:
+                    record(names, profile, tmp)
+                finally:
+                    os.chdir(cwd0)
+
+
+def record(names, profile, tmp):
+    raw = workload.make_raw_workload(profile=profile)
+    if True:
         workload.write_reference_layout(raw, tmp)
-        os.chdir(tmp)
+        os.chdir(tmp)  # the reference reads data/tpch relative to cwd (tpch.py:48,119)
         import gymnasium as gym
         import spark_sched_sim  # noqa: F401
         from schedulers.decima import utils as dutils
         from schedulers.decima.env_wrapper import DecimaEnvWrapper
         from schedulers.decima.scheduler import DecimaScheduler
 
-        for name, (env_cfg, seeds) in CFGS.items():
-            if argv and name not in argv:
-                continue
+        for name in names:
+            env_cfg, seeds = CFGS[name][:2]
             torch.manual_seed(1234)
             sched = DecimaScheduler(num_executors=env_cfg["num_executors"], **AGENT)
             # give the biases (zeroed by the reference's constructor) some life
@@ -72,6 +86,8 @@ def main(argv):
             sched.eval()
             blob = {f"w_{k}": v.numpy() for k, v in sched.state_dict().items()}
             blob["seeds"] = np.asarray(seeds)
+            if profile != "default":
+                blob["trace_profile"] = np.asarray(profile)
             blob["cfg_keys"] = np.asarray(sorted(k for k in env_cfg if k != "data_sampler_cls"))
             blob["cfg_vals"] = np.asarray([float(env_cfg[k]) for k in sorted(env_cfg) if k != "data_sampler_cls"])
             for seed in seeds:

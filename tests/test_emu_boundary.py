@@ -91,13 +91,15 @@ def test_template_offenders_are_refused_with_the_template_named(offender, match,
 
 
 def _big_stage_raw(n_tasks: int = 40000):
-    """every template's first stage with `n_tasks` tasks (beyond what a 16-bit counter holds)"""
+    """every template's first stage with `n_tasks` tasks (beyond what a 16-bit counter holds). The stage's task count is that of
+    the first key (tpch.py:185-187); the other levels share one long rest_wave list"""
     raw = small_raw()
+    big = np.random.default_rng(5).integers(20, 60, size=n_tasks).tolist()
     for key in raw:
         st = raw[key][1][0]
-        rng = np.random.default_rng(5)
+        e0 = next(iter(st["first_wave"]))
         for e in st["first_wave"]:
-            st["rest_wave"][e] = rng.integers(20, 60, size=n_tasks - len(st["first_wave"][e])).tolist()
+            st["rest_wave"][e] = big[: n_tasks - len(st["first_wave"][e0])] if e == e0 else big
     return raw
 
 
@@ -111,7 +113,7 @@ def test_a_stage_with_40000_tasks_is_exact(pack):
     nodes = env.nodes.cpu().numpy()
     assert nodes[..., 0].max() == 40000.0 and nodes[..., 0].min() >= 0.0 and int(env.obs_i32[:, 7].abs().sum()) == 0
     env.close()
-    bad = lockstep_vs_oracle(big, CFG, [0, 1, 2, 3], 60, device="cpu", lib=load_emu())
+    bad = lockstep_vs_oracle(big, CFG, [0, 1], 25, device="cpu", lib=load_emu())
     assert not bad, "\n".join(bad[:8])
 
 

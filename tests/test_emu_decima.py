@@ -9,7 +9,7 @@ from decima_util import check_decima_fixture
 from emu_util import load_emu
 
 
-@pytest.mark.parametrize("name,n_steps", [("decima_c1", 50), ("decima_e50", 40), ("decima_e100", 30)])
+@pytest.mark.parametrize("name,n_steps", [("decima_c1", 50), ("decima_e50", 40), ("decima_e100", 30), ("decima_deep", 30)])
 def test_decima_features_and_scores_match_reference(name, n_steps):
     check_decima_fixture(name, "cpu", load_emu(), n_steps)
 

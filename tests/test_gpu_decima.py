@@ -17,7 +17,7 @@ def test_reference_style_decima_episode_gpu():
     check_reference_style_episode("cuda:0")
 
 
-@pytest.mark.parametrize("name,n_steps", [("decima_c1", 90), ("decima_e50", 90), ("decima_e100", 90)])
+@pytest.mark.parametrize("name,n_steps", [("decima_c1", 90), ("decima_e50", 90), ("decima_e100", 90), ("decima_deep", 90)])
 def test_decima_features_and_scores_match_reference_gpu(name, n_steps):
     check_decima_fixture(name, "cuda:0", None, n_steps)
 
