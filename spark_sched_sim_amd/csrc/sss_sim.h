@@ -2569,18 +2569,31 @@ SSS_DEV int fast_run(const FastCtx& f) {
   const double next_arr_l = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
   uint64_t rngv = g_sc.rng_buf[lane];  // raw output `lane` of the buffer (those from rng_pos on are unconsumed)
   const uint32_t info = sl.info;
-  const uint32_t slot = info_slot(info);
-  const int s = info_stage(info);
-  bool elig = ex < f.E && info_kind(info) == EV_TASK_FINISHED && slot != INFO_SLOT_NONE;
+  const int s = info_stage(info), j = info_job(info);
+  bool elig = ex < f.E && info_kind(info) == EV_TASK_FINISHED;
+  // the job's records: its LDS cache slot, else - more jobs with pending events than slots - the HBM copy, read here once per run and
+  // written back at its end (an event pushed while its job had no slot does not name one; the job may have got one since)
+  uint32_t slot = info_slot(info);
+  if (elig && slot == INFO_SLOT_NONE) {
+    const uint32_t k = f.slot_of[j];
+    slot = k != SLOT_NONE ? k : INFO_SLOT_NONE;
+  }
+  const bool cached = slot != INFO_SLOT_NONE;
   int rem = 0, mc = 0, off_l = 0, off_r = 0;
   uint32_t len_l = 1, len_r = 1;
   uint64_t thr = 1ull << 53;
   uint32_t open_v = 0;  // all ones: the executor-level interval is open (the draw takes random() first)
   if (elig) {
-    const SssStage st = f.cstages[slot * f.SP + s];
-    const SssJob* jp = f.cjobs + slot;
-    const uint64_t local = jp->local_mask;
-    const int gs = jp->gs_base + s;
+    SssStage st;
+    uint64_t local;
+    int gs;
+    if (cached) {
+      const SssJob* jp = f.cjobs + slot;
+      st = f.cstages[slot * f.SP + s], local = jp->local_mask, gs = jp->gs_base + s;
+    } else {
+      const SssJob* jp = g_c.jobs + j;
+      st = g_c.stages[j * f.SP + s], local = jp->local_mask, gs = jp->gs_base + s;
+    }
     const int n_local = local_count(local);
     int li, ri;
     executor_interval(n_local, li, ri);
@@ -2603,7 +2616,7 @@ SSS_DEV int fast_run(const FastCtx& f) {
       if (li != ri) thr = (uint64_t)xd.thr_lo | ((uint64_t)xd.thr_hi << 32), open_v = 0xFFFFFFFFu;
     }
   }
-  const uint32_t tag = info >> 8;  // (job, slot, stage)
+  const uint32_t tag = ((uint32_t)j << 6) | (uint32_t)s;  // (job, stage): the lanes of one stage, whatever slot their event words name
   PROF3_FSEC(1);
   // wave-uniform values the loop keeps on the scalar unit
   const uint32_t counter0 = wave_lane0_u32(counter);
@@ -2774,17 +2787,25 @@ SSS_DEV int fast_run(const FastCtx& f) {
   if (total > 0) {
     const bool won = sl.seq != seq0, touched = elig && rem != rem0;  // (push counters only grow)
     if (won) g_hot.ev[ex].t = sl.t, g_hot.ev[ex].seq = sl.seq;
-    SssJob* jp = f.cjobs + (touched ? slot : 0);
     if (touched) {  // (the lanes of one stage hold the same values)
-      f.cstages[slot * f.SP + s].remaining = rem;
-      f.cdur[slot * f.SP + s] = (float)lastdur;
-      if (rem - mc <= 0) lane_atomic_or_u64(&jp->sat_mask, bit64(s));  // executor demand <= 0 (ENV:566-582)
+      if (cached) {
+        f.cstages[slot * f.SP + s].remaining = rem;
+        f.cdur[slot * f.SP + s] = (float)lastdur;
+        if (rem - mc <= 0) lane_atomic_or_u64(&f.cjobs[slot].sat_mask, bit64(s));  // executor demand <= 0 (ENV:566-582)
+      } else {
+        g_c.stages[j * f.SP + s].remaining = rem;
+        g_c.durations[j * f.SP + s] = (float)lastdur;
+        if (rem - mc <= 0) lane_atomic_or_u64(&g_c.jobs[j].sat_mask, bit64(s));
+      }
     }
     // a stage whose last task was started in this run is saturated from now on (ENV:595-597): once per stage
     for (uint64_t zm = wave_ballot(touched && rem == 0); zm;) {
       const int l = ctz64_nz(zm);
       const uint32_t tl = wave_readlane_u32(tag, l);
-      if (lane == l) lane_atomic_add_u32((uint32_t*)&jp->supply, 1u << 16);  // sat_count++ (upper half of the word)
+      if (lane == l) {  // sat_count++ (upper half of the word)
+        if (cached) lane_atomic_add_u32((uint32_t*)&f.cjobs[slot].supply, 1u << 16);
+        else lane_atomic_add_u32((uint32_t*)&g_c.jobs[j].supply, 1u << 16);
+      }
       zm &= ~wave_ballot(touched && tag == tl);
     }
     if (lane == 0) {
@@ -4635,14 +4656,19 @@ SSS_DEV bool resume_simulation(int budget = 0) {
       if (budget > 0 && g_sc.events_this_step - g_sc.events_at_launch >= budget) return true;  // (wave-uniform: an LDS word behind the ordering point)
       double next_arrival_t = g_hot.h.next_arrival < g_hot.h.J ? g_hot.h.next_arrival_t : __builtin_inf();
       int ex = pop_event_wave(next_arrival_t, t_win, info_win);
-      if (ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE) {
+      const bool head_cached = ex >= 0 && info_slot(info_win) != INFO_SLOT_NONE;
+      if (head_cached || (ex >= 0 && info_kind(info_win) == EV_TASK_FINISHED)) {
         int handled = 0;
         // tasks left in its stage: a run of such events (fast_run produces the randomness it needs itself); when it
         // ends, the head of the queue is something else. None left: a batch of released executors. Those and the
         // batches of arriving executors want `rng_need` raw outputs buffered
         const bool tf = info_kind(info_win) == EV_TASK_FINISHED;
-        const bool tasks_left = tf && f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0;
-        if (tasks_left) {
+        const bool tasks_left = tf && head_cached && f.cstages[info_slot(info_win) * f.SP + info_stage(info_win)].remaining > 0;
+        if (!head_cached) {
+          // a task completion of a job without a cache slot (more jobs with pending events than slots): the run looks at the job's
+          // HBM records itself and declines (0: nothing touched) when the stage has no task left; the batches below want slots
+          handled = fast_run(f);
+        } else if (tasks_left) {
           handled = fast_run(f);
         } else {
 #ifndef SSS_NO_BATCH

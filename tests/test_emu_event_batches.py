@@ -103,6 +103,37 @@ def test_batches_equal_one_event_at_a_time(cfg, policy, seeds, chunk, n_launches
         e.close()
 
 
+# more jobs with pending events than LDS cache slots (10 at this sizing): the "deep" trace regime (jobs of up to 40 stages with
+# thousands of tasks stay active for a long time) with the fair policy spreading 50 executors over ~40 active jobs
+DEEP_E50 = dict(num_executors=50, job_arrival_cap=40, job_arrival_rate=1.0e-3, moving_delay=2000.0, warmup_delay=1000.0)
+
+
+@pytest.mark.parametrize("policy,seeds,chunk,n_launches", [("fair", [0, 1], 41, 8), ("hash", [2], 29, 8)])
+def test_runs_over_jobs_without_a_cache_slot_equal_one_event_at_a_time(policy, seeds, chunk, n_launches):
+    """fast_run takes the task completions of jobs that have no LDS cache slot too (their records are read from and written back to
+    HBM once per run): byte-identical env state to the one-at-a-time build, and nearly every such event goes through runs"""
+    from spark_sched_sim_amd import workload
+
+    pack = workload.profile_pack("deep")
+    envs = [VecSparkSchedSimEnv(DEEP_E50, len(seeds), device="cpu", pack=pack, _lib=load_emu(v)) for v in ("", "_nobatch")]
+    for e in envs:
+        e.reset(seed=seeds)
+    skip = slice(256, 272)  # SssHdr::n_batched, n_rounds: the only fields that may differ
+    for it in range(n_launches):
+        for e in envs:
+            e.rollout(policy, chunk)
+        a, b = (e._env_view.numpy().copy() for e in envs)
+        a[:, skip] = 0
+        b[:, skip] = 0
+        assert np.array_equal(a, b), f"launch {it}: env state differs"
+        for name in ("nodes", "edge_links", "dag_ptr", "exec_supplies", "obs_i32", "obs_f64"):
+            assert np.array_equal(getattr(envs[0], name).numpy(), getattr(envs[1], name).numpy()), (it, name)
+    c = envs[0].counters()
+    assert c["n_batched_events"] > 0.9 * c["n_fast_events"] > 0, c   # (about 0.3 while runs stopped at the first event of a job without a slot)
+    for e in envs:
+        e.close()
+
+
 def test_jump_table_is_numpys_advance():
     """sss_host.h sss_build_pcg_jump through its test export: state_{n+k} = A_k * state_n + C_k * inc"""
     lib = load_emu()
