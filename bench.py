@@ -44,7 +44,7 @@ CONFIGS = {
     "c2": dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
     "c3": dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
     # not a BASELINE config: config 3's sizing at the top of the reference's executor-level table (tpch.py:238) - more than
-    # 64 executors run on the wide instantiation of the kernels (csrc/sss_hip_wide.hip: every event one at a time)
+    # 64 executors run on the wide instantiation of the kernels (csrc/sss_hip_wide.hip: two executors per lane)
     "e100": dict(num_executors=100, job_arrival_cap=200, job_arrival_rate=8.0e-5, moving_delay=2000.0, warmup_delay=1000.0),
 }
 DEFAULT_POLICY = {"c2": "hash", "c3": "fair", "e100": "fair"}
@@ -524,8 +524,9 @@ def main() -> None:
     ap.add_argument("--no-deep", action="store_true", help="skip the extra record on the 'deep' trace regime (N=1, --config c2 --pack default only)")
     ap.add_argument("--no-decima", action="store_true", help="skip the extra Decima-in-the-loop measurement (N=1, c2 only)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the extra PPO-iteration record (one rank's share of BASELINE config 5; N=1, c2 only)")
-    ap.add_argument("--event-every", type=int, default=8, help="HIP events (the roofline's launch durations) around every N-th step launch of the timed region: "
-                    "an event pair per launch costs the stream ~5 us per step (profiles/r05_bench.md section 5), 3 %% of a config-2 step")
+    ap.add_argument("--event-every", type=int, default=None, help="HIP events (the roofline's launch durations) around every N-th step launch of the timed region: "
+                    "an event pair per launch costs the stream ~5 us per step (profiles/r05_bench.md section 5), 3 %% of a config-2 step. Default: every 8th, "
+                    "more often for short regions so that at least ~8 launches of the K timed steps carry events (K = 20: every 2nd)")
     ap.add_argument("--lib", default=None, help="path of a test build of the library to measure instead of the product (A/B timing; tests/gpu_variant.py builds them)")
     ap.add_argument("--no-e100", action="store_true", help="skip the 100-executor record (the wide instantiation; N=1, --config c2 only)")
     ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE config 3 record (N=1, --config c2 only)")
@@ -541,6 +542,8 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); 'gloo' only for plumbing tests")
     ap.add_argument("--device-index", type=int, default=None, help="override LOCAL_RANK -> device mapping (plumbing tests on one GPU)")
     args = ap.parse_args()
+    if args.event_every is None:
+        args.event_every = max(1, min(8, args.steps // 8))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(run_ranks_myself(args))

@@ -187,8 +187,18 @@ typedef struct sss_decima_graph {
    * keeps two sets and passes them in turn (this step's zeroed by the previous launch, the previous step's - its consumers are
    * behind this launch in the stream - cleared now), which saves the clearing launch in between */
   int64_t* layer_totals_clear_dev;
+  /* number of i64 entries behind layer_totals_dev (and behind layer_totals_clear_dev): must be 33 * 32 = 1056 whenever either is
+   * passed. The counters grew from i64[32] to i64[33][32] in round 5; a caller built against the older layout now gets -1 and a
+   * message instead of fetch-adds past the end of its 32-entry buffer. */
+  int64_t layer_totals_len;
 } sss_decima_graph;
 int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, void* stream);
+
+/* sizeof() of an argument structure of this header as the LIBRARY was compiled with ("sss_cfg", "sss_decima_graph", ...; -1: unknown
+ * name): a binding checks its mirrors against it once (spark_sched_sim_amd/binding.py: check_abi; tests/test_abi.py), so that a
+ * stale binding fails loudly instead of handing the library a structure of another layout. No reference counterpart (the reference
+ * has no native boundary). */
+int sss_abi_sizeof(const char* struct_name);
 
 /* The nodes each DAG layer updates, as index lists (what nonzero((node_recv >> l) & 1) returns), for
  * all layers in one launch: layer l's list starts at recv_dev[layer_base[l]]; env_off_dev = exclusive

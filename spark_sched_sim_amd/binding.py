@@ -43,7 +43,8 @@ class SssDecimaGraph(C.Structure):
                 ("edge_obs_dev", C.c_void_p), ("edge_layers_dev", C.c_void_p), ("job_obs_dev", C.c_void_p), ("job_cap_dev", C.c_void_p),
                 ("job_first_dev", C.c_void_p), ("obs_depth_dev", C.c_void_p), ("job_nodes_dev", C.c_void_p), ("out_start_dev", C.c_void_p),
                 ("out_deg_dev", C.c_void_p), ("layer_cnt_dev", C.c_void_p), ("sched_off_dev", C.c_void_p), ("sched_list_dev", C.c_void_p),
-                ("layer_totals_dev", C.c_void_p), ("recv_lists_dev", C.c_void_p), ("recv_stride", C.c_int64), ("layer_totals_clear_dev", C.c_void_p)]
+                ("layer_totals_dev", C.c_void_p), ("recv_lists_dev", C.c_void_p), ("recv_stride", C.c_int64), ("layer_totals_clear_dev", C.c_void_p),
+                ("layer_totals_len", C.c_int64)]
 
 
 class SssDecimaLists(C.Structure):
@@ -150,8 +151,14 @@ class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_step_bounded", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy", "sss_abi_sizeof"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
+# the argument structures of include/sss.h and their mirrors here (Binding.check_abi)
+ABI_STRUCTS = {"sss_cfg": SssCfg, "sss_dims": SssDims, "sss_buffers": SssBuffers, "sss_decima_graph": SssDecimaGraph, "sss_decima_lists": SssDecimaLists,
+               "sss_bit_list_args": SssBitListArgs, "sss_gnn_args": SssGnnArgs, "sss_decima_policy_args": SssDecimaPolicyArgs,
+               "sss_decima_sample_args": SssDecimaSampleArgs, "sss_gnn_encode_args": SssGnnEncodeArgs, "sss_collect_args": SssCollectArgs,
+               "sss_mlp_args": SssMlpArgs, "sss_arena_array": SssArenaArray, "sss_arena_args": SssArenaArgs, "sss_returns_args": SssReturnsArgs,
+               "sss_baseline_args": SssBaselineArgs, "sss_rows_args": SssRowsArgs}
 
 
 def load_library(path: str | None = None) -> C.CDLL:
@@ -201,6 +208,16 @@ class Binding:
         L.sss_rows_op.argtypes = [C.POINTER(SssRowsArgs), C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
+        L.sss_abi_sizeof.argtypes = [C.c_char_p]
+        self.check_abi()
+
+    def check_abi(self) -> None:
+        """every ctypes mirror above has the size the library was compiled with (include/sss.h sss_abi_sizeof): a binding and a
+        library of different rounds fail here, not inside a kernel"""
+        bad = [(name, C.sizeof(cls), self.lib.sss_abi_sizeof(name.encode())) for name, cls in ABI_STRUCTS.items()
+               if C.sizeof(cls) != self.lib.sss_abi_sizeof(name.encode())]
+        if bad:
+            raise RuntimeError("binding / library mismatch (struct, sizeof in binding.py, sizeof in the library): " + ", ".join(map(str, bad)))
 
     def check(self, rc: int) -> None:
         if rc != 0:

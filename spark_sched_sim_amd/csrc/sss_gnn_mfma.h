@@ -238,19 +238,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 }
 
 // how many workgroups of a kernel the device holds at once (occupancy x CUs) - the grid of a launch whose waves stride over tiles;
-// `fallback` if the runtime will not say
-static int64_t gnn_resident_workgroups(const void* kernel, int threads, size_t lds, int64_t fallback = 1024) {
+// `fallback` if the runtime will not say. Cached per launch site AND per device (a process may drive several GPUs: the answer of the
+// device that happened to be current at the first launch is not the answer for the others), and a failed query is not cached (the
+// optimum is sharp - 768 workgroups for the layers, profiles/r05_hints.txt - so a remembered fallback would be a silent slow-down for
+// the life of the process).
+struct GnnGridCap {
+  int64_t per_device[16] = {0};  // 0: not known yet
+};
+static int64_t gnn_resident_workgroups(GnnGridCap& cache, const void* kernel, int threads, size_t lds, int64_t fallback = 1024) {
   int per_cu = 0, dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fallback;
+  const bool slot = dev >= 0 && dev < 16;
+  if (slot) {
+    const int64_t known = __atomic_load_n(&cache.per_device[dev], __ATOMIC_RELAXED);
+    if (known > 0) return known;
+  }
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) return fallback;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return fallback;
-  return (int64_t)per_cu * cus;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return fallback;
+  const int64_t n = (int64_t)per_cu * cus;
+  if (slot) __atomic_store_n(&cache.per_device[dev], n, __ATOMIC_RELAXED);
+  return n;
 }
 static int gnn_layer_mfma_launch(const SssGnnArgs& a, void* stream) {
   if (a.n_rows <= 0) return 0;
   const int64_t wgs = (a.n_rows + 63) / 64;  // four tiles of 16 rows per workgroup and pass
   // at most ONE resident set of workgroups, each wave striding over its tiles with the parameters loaded once: measured at 4096 envs
   // (profiles/r05_hints.txt) 768 workgroups - exactly what fits at this kernel's register count - beat 512 and 1024 as well as 2048
-  static const int64_t cap = gnn_resident_workgroups((const void*)sss_gnn_layer_mfma_kernel, 256, 0);
+  static GnnGridCap cache;
+  const int64_t cap = gnn_resident_workgroups(cache, (const void*)sss_gnn_layer_mfma_kernel, 256, 0);
   const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
   hipLaunchKernelGGL(sss_gnn_layer_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
@@ -512,7 +527,8 @@ static int gnn_head_mfma_launch(const SssGnnArgs& a, void* stream) {
   constexpr int U = KIND == GNN_STAGE ? 4 : 3;
   const int64_t wgs = (a.n_rows + 63) / 64;
   // (33 KB of LDS images per workgroup, staged once and reused over its tiles: one resident set of workgroups)
-  static const int64_t hcap = gnn_resident_workgroups((const void*)sss_gnn_head_mfma_kernel<KIND>, 256, (size_t)MfmaHead<U>::TOTAL * sizeof(float));
+  static GnnGridCap cache;
+  const int64_t hcap = gnn_resident_workgroups(cache, (const void*)sss_gnn_head_mfma_kernel<KIND>, 256, (size_t)MfmaHead<U>::TOTAL * sizeof(float));
   const unsigned grid = (unsigned)(wgs < hcap ? wgs : hcap);
   hipLaunchKernelGGL(sss_gnn_head_mfma_kernel<KIND>, dim3(grid), dim3(256), (size_t)MfmaHead<U>::TOTAL * sizeof(float), (hipStream_t)stream, a);
   return (int)hipGetLastError();
@@ -585,7 +601,8 @@ template <int KIND>
 static int gnn_rows_mfma_launch(const SssGnnArgs& a, void* stream) {
   if (a.n_rows <= 0) return 0;
   const int64_t wgs = (a.n_rows + 63) / 64;
-  static const int64_t cap = gnn_resident_workgroups((const void*)sss_gnn_rows_mfma_kernel<KIND>, 256, 0);  // (one resident set, as for the layers)
+  static GnnGridCap cache;
+  const int64_t cap = gnn_resident_workgroups(cache, (const void*)sss_gnn_rows_mfma_kernel<KIND>, 256, 0);  // (one resident set, as for the layers)
   const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
   hipLaunchKernelGGL(sss_gnn_rows_mfma_kernel<KIND>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();

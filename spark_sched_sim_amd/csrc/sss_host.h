@@ -315,6 +315,18 @@ static std::vector<uint8_t> sss_build_common_pool(int E) {
 
 extern "C" const char* sss_last_error(void) { return g_sss_err.c_str(); }
 
+extern "C" int sss_abi_sizeof(const char* name) {
+  if (!name) return -1;
+#define SSS_ABI_SIZE(T) \
+  if (!strcmp(name, #T)) return (int)sizeof(T);
+  SSS_ABI_SIZE(sss_cfg) SSS_ABI_SIZE(sss_dims) SSS_ABI_SIZE(sss_buffers) SSS_ABI_SIZE(sss_decima_graph) SSS_ABI_SIZE(sss_decima_lists)
+  SSS_ABI_SIZE(sss_bit_list_args) SSS_ABI_SIZE(sss_gnn_args) SSS_ABI_SIZE(sss_decima_policy_args) SSS_ABI_SIZE(sss_decima_sample_args)
+  SSS_ABI_SIZE(sss_gnn_encode_args) SSS_ABI_SIZE(sss_collect_args) SSS_ABI_SIZE(sss_mlp_args) SSS_ABI_SIZE(sss_arena_array)
+  SSS_ABI_SIZE(sss_arena_args) SSS_ABI_SIZE(sss_returns_args) SSS_ABI_SIZE(sss_baseline_args) SSS_ABI_SIZE(sss_rows_args)
+#undef SSS_ABI_SIZE
+  return -1;
+}
+
 extern "C" int sss_create(const sss_cfg* cfg, const void* pack, size_t pack_bytes, int num_envs, int device, sss_handle** out) {
   SssPackHost ph;
   int J_cap;
@@ -515,6 +527,8 @@ extern "C" int sss_decima_graph_build(sss_handle* h, const sss_decima_graph* g, 
   d.layer_totals = g->layer_totals_dev, d.recv_lists = g->layer_totals_dev ? g->recv_lists_dev : nullptr, d.recv_stride = g->recv_stride;
   d.layer_totals_clear = g->layer_totals_clear_dev;
   if (g->layer_totals_clear_dev && g->layer_totals_clear_dev == g->layer_totals_dev) return sss_fail(-1, "layer_totals_clear_dev must be another set of counters than layer_totals_dev");
+  if ((g->layer_totals_dev || g->layer_totals_clear_dev) && g->layer_totals_len != 33 * SSS_LIST_SETS)
+    return sss_fail(-1, "layer_totals_len must be 33 * 32: the list counters are i64[33][32] (a binding built against the i64[32] layout?)");
   if (g->layer_totals_dev && (!g->recv_lists_dev || g->recv_stride < 1)) return sss_fail(-1, "NULL argument");
   if (g->sched_off_dev && !g->sched_list_dev) return sss_fail(-1, "NULL argument");
   if (int rc = be_launch_decima(h->L, h->B, h->cfg.num_executors, d, stream)) return sss_fail(-30, std::string("decima graph launch failed: ") + be_error(rc));

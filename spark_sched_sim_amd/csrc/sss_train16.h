@@ -446,8 +446,9 @@ static int mlp_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
   if (a.rows <= 0) return 0;
   const int64_t wgs = (a.rows + 63) / 64;
   // (one resident set of workgroups striding over the tiles, as the inference launches: sss_gnn_mfma.h gnn_resident_workgroups)
-  static const int64_t cap_f = gnn_resident_workgroups((const void*)sss_mlp_mfma_fwd_kernel<IN>, 256, 0);
-  static const int64_t cap_b = gnn_resident_workgroups((const void*)sss_mlp_mfma_bwd_kernel<IN>, 256, 0);
+  static GnnGridCap cache_f, cache_b;
+  const int64_t cap_f = gnn_resident_workgroups(cache_f, (const void*)sss_mlp_mfma_fwd_kernel<IN>, 256, 0);
+  const int64_t cap_b = gnn_resident_workgroups(cache_b, (const void*)sss_mlp_mfma_bwd_kernel<IN>, 256, 0);
   const int64_t cap = backward ? cap_b : cap_f;
   const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
   if (backward)

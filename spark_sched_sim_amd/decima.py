@@ -736,6 +736,7 @@ class DecimaPolicy(nn.Module):
                 ob.clear()
                 ob[key] = torch.full((g["n_obs"], g["n_pad"]), float("-inf"), dtype=torch.float32, device=g["x"].device)
             out = ob[key] if for_draw_only else ob[key].fill_(float("-inf"))
+            out._sss_not_cleared = bool(for_draw_only)  # (read by _sample_kernels: such a matrix must not be handed out as scores)
             hint = int(g["totals_hint"][3])
             rows, idx0, exact, rows_dev = (hint + hint // 4 + 64 if hint > 0 else g["sched_list"].numel()), g["sched_list"], 1, g["totals_dev"][3:4]
             rows = min(rows, g["sched_list"].numel())
@@ -802,6 +803,9 @@ class DecimaPolicy(nn.Module):
         out["env_stage_idx"], out["env_num_exec"] = stage_idx, num_exec
         out["rng"] = (a.rng_seed, a.rng_counter)
         if scores_out is not None:
+            # (a capacity graph's kept score matrix is refilled without its -inf pass when it only feeds the draw - `for_draw_only` -
+            # and then holds stale finite scores in slots that are not schedulable stages: never hand that one out)
+            assert not getattr(padded, "_sss_not_cleared", False), "stage scores were computed for the draw only (stale entries outside the schedulable stages)"
             scores_out["stage_scores"], scores_out["exec_scores"] = padded, es
         return out
 
@@ -848,23 +852,31 @@ class DecimaPolicy(nn.Module):
         return torch.full((k, E), float("-inf"), dtype=s.dtype, device=dev).index_put((owner, count), s)
 
     @torch.no_grad()
-    def act(self, g: dict[str, Any], generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:
+    def act(self, g: dict[str, Any], generator: torch.Generator | None = None, greedy: bool = False, fresh_outputs: bool = False) -> dict[str, torch.Tensor]:
         """samples one Decima action per observation of a compact graph (scheduler.py:71-99): a stage
         from softmax(stage scores), then an executor count from softmax(exec scores of that stage's
         job). Returns the reference's action tuple entries `stage_sel` (index among the observation's
         schedulable stages = the env's `stage_idx`), `job_idx` (job slot), `exec_sel` (executor
         count - 1), `lgprob`, and `any_stage` (False where nothing is schedulable; the other entries
-        are then meaningless)."""
+        are then meaningless).
+
+        OWNERSHIP of the result: on a capacity graph (`env.decima_graph_on_device()`, which `schedule_env` uses by default) the
+        returned tensors - `stage_sel`, `job_idx`, `exec_sel`, `lgprob`, `any_stage`, `env_stage_idx`, `env_num_exec` - are work space
+        the policy keeps and the NEXT call on a graph of the same shape overwrites, like the observation buffers `env.step`
+        returns. Consume them before the next call (the in-tree collector copies them on the stream) or pass
+        `fresh_outputs=True` to get copies you own. Graphs with exact sizes (`env.decima_graph()`) return fresh tensors.
+        `greedy`: the most probable stage and executor count instead of a draw (evaluation; tensor-op path)."""
         B, N = g["n_obs"], g["n_pad"]
         M, J = g["x"].shape[0], g["job_obs"].numel()
-        if self._use_kernels(g) and M > 0 and J > 0:
+        if self._use_kernels(g) and M > 0 and J > 0 and not greedy:
             # (the stream handle and the current device are looked up once for the pass's seven library calls)
             from .binding import device_of
             dev = g["x"].device
             with device_of(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
                 h = self._encode_kernels(g, stream)
-                return self._sample_kernels(g, h, self._stage_scores_kernels(g, h, stream, for_draw_only=True), generator, _stream=stream)
+                out = self._sample_kernels(g, h, self._stage_scores_kernels(g, h, stream, for_draw_only=True), generator, _stream=stream)
+            return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in out.items()} if fresh_outputs else out
         # tensor-op path (other architectures, graphs built without the graph kernel)
         h = self.encode(g)
         s, idx = self.stage_scores(g, h)
@@ -872,7 +884,7 @@ class DecimaPolicy(nn.Module):
         padded[g["node_obs"][idx], g["node_loc"][idx]] = s
         any_stage = torch.isfinite(padded).any(1)
         p = torch.softmax(torch.where(any_stage[:, None], padded, torch.zeros_like(padded)), 1)
-        col = torch.multinomial(p, 1, generator=generator)[:, 0]
+        col = p.argmax(1) if greedy else torch.multinomial(p, 1, generator=generator)[:, 0]
         node = (_excl_cumsum(g["obs_nodes"]) + col).clamp(max=max(M - 1, 0))
         if M == 0:
             z = torch.zeros(B, dtype=torch.long, device=padded.device)
@@ -883,7 +895,7 @@ class DecimaPolicy(nn.Module):
         es = self.exec_scores(g, h, job_gid.clamp(min=0, max=max(J - 1, 0)))
         any_exec = torch.isfinite(es).any(1) & any_stage
         pe = torch.softmax(torch.where(any_exec[:, None], es, torch.zeros_like(es)), 1)
-        k = torch.multinomial(pe, 1, generator=generator)[:, 0]
+        k = pe.argmax(1) if greedy else torch.multinomial(pe, 1, generator=generator)[:, 0]
         lg = torch.log(p.gather(1, col[:, None])[:, 0]) + torch.log(pe.gather(1, k[:, None])[:, 0])
         return {"stage_sel": stage_sel, "job_idx": job_slot, "exec_sel": k, "lgprob": lg, "any_stage": any_stage}
 
@@ -945,23 +957,30 @@ class DecimaPolicy(nn.Module):
 
     @torch.no_grad()
     def schedule_env(self, env, generator: torch.Generator | None = None, active: torch.Tensor | None = None, one_launch: bool = False,
-                     host_sync: bool | None = None):
+                     host_sync: bool | None = None, greedy: bool = False, fresh_outputs: bool = False):
         """Decima in the loop on a `VecSparkSchedSimEnv`: one sampled action per env. Default: the
         graph kernel + the row-parallel GNN kernels + `act` (rows of ALL envs share every launch, so
         the lanes stay full). `one_launch=True` uses the per-env policy kernel (`act_env`; its draw
         counter advances on every call, `generator` only supplies the seed): no host sync and one
         launch, but each env's phases run serially inside one wavefront - on one MI355X it ties the
         pipeline up to ~1024 envs and is 2x slower at 4096 (profiles/r01_decima.md).
-        Returns (actions for `env.step`, the `act` dict)."""
+        Returns (actions for `env.step`, the `act` dict).
+
+        OWNERSHIP: by default both are views of work space that the next `schedule_env` / `act` call on this policy overwrites (see
+        `act`): hand the actions to `env.step` and read `aux["lgprob"]` etc. before calling again, or pass `fresh_outputs=True` for
+        tensors you may keep (a rollout recorder of your own, logging). `greedy`: arg-max actions instead of sampled ones."""
         if getattr(self, "_kb", None) is None:
             self.bind_kernels(env._b)
+        if greedy:
+            a = self.act(env.decima_graph(active), generator, greedy=True)
+            return self.env_actions(a), a
         if one_launch:
             self._calls = getattr(self, "_calls", 0) + 1
             return self.act_env(env, self._calls, seed=generator.initial_seed() if generator is not None else 0, active=active)
         # no device->host round trip when the graph kernel and the GNN kernels can do the whole step (the graph's totals stay on
         # the device); else the graph with exact sizes (one read-back of its totals)
         on_dev = host_sync is False or (host_sync is None and self._use_kernels() and env.graph_kernel_fits)
-        a = self.act(env.decima_graph_on_device(active) if on_dev else env.decima_graph(active, reuse_buffers=True), generator)
+        a = self.act(env.decima_graph_on_device(active) if on_dev else env.decima_graph(active, reuse_buffers=True), generator, fresh_outputs=fresh_outputs)
         return self.env_actions(a), a
 
     @torch.no_grad()

@@ -308,7 +308,7 @@ class VecSparkSchedSimEnv:
                                float(num_tasks_scale), float(work_scale), *(ws[k].data_ptr() for k in (
                                    "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
                                    "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
-                               off[3].data_ptr(), ws["sched_list"].data_ptr(), None, ws["recv"].data_ptr(), stride, None)
+                               off[3].data_ptr(), ws["sched_list"].data_ptr(), None, ws["recv"].data_ptr(), stride, None, 33 * 32)
             g0 = {k: ws[k] for k in ("x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst", "edge_obs",
                                      "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt", "sched_list")}
             g0["n_obs"], g0["n_pad"], g0["max_depth"] = B, d.node_cap, D
@@ -416,7 +416,7 @@ class VecSparkSchedSimEnv:
                            float(num_tasks_scale), float(work_scale), *(buf[k].data_ptr() for k in (
                                "x", "node_obs", "node_loc", "node_job", "sched_rank", "gen", "node_recv", "stage_mask", "src", "dst",
                                "edge_obs", "edge_layers", "job_obs", "job_cap", "job_first", "obs_depth", "job_nodes", "out_start", "out_deg", "layer_cnt")),
-                           off[3].data_ptr(), buf["sched_list"].data_ptr(), layer_totals.data_ptr(), ls["recv"].data_ptr(), ls["stride"], None)
+                           off[3].data_ptr(), buf["sched_list"].data_ptr(), layer_totals.data_ptr(), ls["recv"].data_ptr(), ls["stride"], None, 33 * 32)
         self._b.check(self._b.lib.sss_decima_graph_build(self._h, C.byref(a), self._stream()))
         g["n_obs"], g["n_pad"] = B, self.dims.node_cap
         g["max_depth"] = self.max_dag_depth

@@ -29,6 +29,33 @@ def test_exports_match_header(hip_lib):
         assert hasattr(hip_lib, sym), sym
 
 
+def test_binding_mirrors_have_the_library_sizes(hip_lib):
+    """every ctypes mirror of an argument structure (binding.py) is as large as the structure the library was compiled with
+    (include/sss.h sss_abi_sizeof) and as the header compiled with gcc says - a stale binding fails at load time (Binding.check_abi),
+    not inside a kernel (round 5 grew sss_decima_graph's list counters from i64[32] to i64[33][32] without any such guard)"""
+    from spark_sched_sim_amd.binding import ABI_STRUCTS, Binding
+
+    hip_lib.sss_abi_sizeof.argtypes = [C.c_char_p]
+    header = open(osp.join(ROOT, "include", "sss.h")).read()
+    assert set(re.findall(r"^} (sss_[a-z_]+);", header, re.M)) == set(ABI_STRUCTS)   # every structure of the header has a mirror
+    for name, cls in ABI_STRUCTS.items():
+        assert hip_lib.sss_abi_sizeof(name.encode()) == C.sizeof(cls), name
+    assert hip_lib.sss_abi_sizeof(b"no_such_struct") == -1
+    Binding(hip_lib)   # (check_abi runs in the constructor)
+
+    class Stale(C.Structure):   # the round-5 layout of sss_decima_graph: one field short
+        _fields_ = ABI_STRUCTS["sss_decima_graph"]._fields_[:-1]
+
+    import spark_sched_sim_amd.binding as bnd
+    keep = bnd.ABI_STRUCTS["sss_decima_graph"]
+    bnd.ABI_STRUCTS["sss_decima_graph"] = Stale
+    try:
+        with pytest.raises(RuntimeError, match="binding / library mismatch"):
+            Binding(hip_lib)
+    finally:
+        bnd.ABI_STRUCTS["sss_decima_graph"] = keep
+
+
 def test_simulator_kernels_do_not_spill(hip_lib):
     """The simulator units are compiled with machine LICM off (spark_sched_sim_amd/build.py: with the pass on, 32 loop-invariant
     register pairs are hoisted out of the event loop and spilled across it - 272 / 640 bytes of scratch per lane in the step /

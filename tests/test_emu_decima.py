@@ -38,6 +38,86 @@ def test_sampled_actions_are_always_valid():
     env.close()
 
 
+def test_schedule_env_results_are_work_space_unless_fresh_outputs_is_asked_for():
+    """the ownership contract of `schedule_env` / `act` (their docstrings): on the default path the returned tensors are the policy's
+    work space, overwritten by the next call; `fresh_outputs=True` returns tensors the caller may keep"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 5, device="cpu", auto_reset=True, _lib=load_emu())
+    torch.manual_seed(3)
+    policy = DecimaPolicy(num_executors=10, **AGENT).eval()
+    gen = torch.Generator().manual_seed(5)
+    env.reset(seed=40)
+    kept = []
+    for fresh in (False, False, True, True):
+        act, aux = policy.schedule_env(env, generator=gen, fresh_outputs=fresh)
+        kept.append((fresh, act, aux, {k: v.clone() for k, v in list(act.items()) + [("lgprob", aux["lgprob"])]}))
+        env.step(act)
+    (_, a0, x0, c0), (_, a1, x1, c1), (_, a2, x2, c2), (_, a3, x3, c3) = kept
+    assert a0["stage_idx"].data_ptr() == a1["stage_idx"].data_ptr() and x0["lgprob"].data_ptr() == x1["lgprob"].data_ptr()   # work space: aliased
+    assert len({a1["stage_idx"].data_ptr(), a2["stage_idx"].data_ptr(), a3["stage_idx"].data_ptr()}) == 3
+    for act, aux, copy in ((a2, x2, c2), (a3, x3, c3)):   # held across later calls: still what they were
+        assert torch.equal(act["stage_idx"], copy["stage_idx"]) and torch.equal(act["num_exec"], copy["num_exec"]) and torch.equal(aux["lgprob"], copy["lgprob"])
+    assert not torch.equal(x0["lgprob"], c0["lgprob"])   # (the first result's buffer now holds a later step's values)
+    env.close()
+
+
+def test_greedy_actions_are_the_arg_max_of_the_scores():
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    cfg = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 4, device="cpu", auto_reset=True, _lib=load_emu())
+    torch.manual_seed(3)
+    policy = DecimaPolicy(num_executors=10, **AGENT).eval()
+    env.reset(seed=70)
+    for _ in range(25):
+        act, aux = policy.schedule_env(env, greedy=True)
+        g = env.decima_graph()
+        h = policy.encode(g)
+        s, idx = policy.stage_scores(g, h)
+        for b in range(4):
+            mine = g["node_obs"][idx] == b
+            assert int(act["stage_idx"][b]) == int(s[mine].argmax())   # index among the observation's schedulable stages
+        obs, r, term, trunc, info = env.step(act)
+        assert not info["err"].any()
+    env.close()
+
+
+def test_graph_build_refuses_list_counters_of_another_length():
+    """include/sss.h sss_decima_graph.layer_totals_len: the i64[33][32] counters must be announced as such"""
+    import ctypes as C
+
+    import torch
+
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    import spark_sched_sim_amd.vec_env as ve
+
+    cfg = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 3, device="cpu", _lib=load_emu())
+    env.reset(seed=1)
+    env.decima_graph()   # fine
+    real = ve.SssDecimaGraph
+
+    def stale(*a):   # a caller built against the round-4 layout: 32 counters
+        return real(*a[:-1], 32)
+    ve.SssDecimaGraph = stale
+    try:
+        with pytest.raises(ValueError, match="layer_totals_len"):
+            env.decima_graph()
+    finally:
+        ve.SssDecimaGraph = real
+    env.close()
+
+
 def test_decima_in_the_loop_beyond_64_executors():
     """100 and 128 executors (two executor counts per lane in the sampling kernels; round 4 raised `sss error -28` here):
     sampled actions through the pipeline AND through the one-launch policy kernel drive the wide simulator without a rejected

@@ -1,5 +1,6 @@
 """More than 64 executors: the WIDE instantiation of the kernel source (csrc/sss_sim.h compiled with SSS_WIDE - two executors per
-lane in the queue's pop and the staging loops, 128-entry executor arrays, every event through the one-at-a-time handlers;
+lane in the queue's pop and the staging loops, 128-entry executor arrays; in the lane-parallel event machinery a lane speaks for the
+one of its two executors whose event comes first, csrc/sss_sim.h lane_event;
 tests/emu/emu_wide.cpp here, csrc/sss_hip_wide.hip on gfx950) under the CPU wave emulator, through the real C ABI, against the C
 oracle step by step. The reference takes any `num_executors` (spark_sched_sim.py:37) and its level table reaches 100
 (tpch.py:237-262); beyond 100 the interval table has the quirks of tpch.py:258-260 (rows 101 .. cap-1 are (100, 100), row cap
