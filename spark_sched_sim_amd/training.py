@@ -770,7 +770,8 @@ class Trainer:
     iteration moves the per-rollout statistics (trainer.py:113-121's Pipe gather)."""
 
     def __init__(self, agent_cfg: dict[str, Any], env_cfg: dict[str, Any], train_cfg: dict[str, Any],
-                 device: str | torch.device | None = None, _lib=None):
+                 device: str | torch.device | None = None, _lib=None, pack: bytes | None = None):
+        """`pack`: the workload pack the envs run on (None: the frozen default trace set)"""
         import torch.distributed as dist
 
         from .decima import DecimaPolicy
@@ -808,7 +809,7 @@ class Trainer:
                                    max_grad_norm=train_cfg.get("max_grad_norm"), **kw).to(dev)
         B = self.num_sequences * self.num_rollouts
         sim_cfg = {k: v for k, v in self.env_cfg.items() if k not in ("mean_time_limit", "dataset")}
-        self.env = VecSparkSchedSimEnv(sim_cfg, B, device=dev, _lib=_lib)
+        self.env = VecSparkSchedSimEnv(sim_cfg, B, device=dev, _lib=_lib, pack=pack)
         total_sequences = self.num_sequences * self.world
         seq_ids = self.rank * self.num_sequences + np.arange(self.num_sequences)
         base_seeds = np.repeat(self.seed + seq_ids, self.num_rollouts)  # trainer.py:264-266
