@@ -169,17 +169,35 @@ def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float
     return None
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (the pass computes in exact fp32)
+
+
+def reference_decima_baseline(key: str):
+    """the reference's own Decima code timed in the BUILD CONTAINER (tools/time_reference_decima.py; it cannot travel to the GPU box):
+    the committed record profiles/reference_python.json, quoted with its hardware - never something timed in this run"""
+    try:
+        rec = json.load(open(osp.join(ROOT, "profiles", "reference_python.json")))[key]
+    except Exception:
+        return None
+    return rec
+
+
 def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int = 20, steady_after: int = 600, steady_steps: int = 1200) -> dict:
     """extra, not the headline: the same B envs with a sampled Decima action (GNN policy, random-init
     weights of the published architecture) for every env on every step - graph kernel, GNN kernels,
     sampling kernels, sss_step (spark_sched_sim_amd/decima.py). Two windows: steps 20..120 after the reset (the window
     the earlier rounds quote: every env early in its first episode) and `steady`: 1200 steps after 600 - two episode
     lengths under this policy; the envs stay roughly in phase, so the cost of a step swings with the phase of the episode
-    (0.63 .. 0.89 ms, tools/debug/decima_windows.py) and only an average over episodes is a stable figure."""
+    (0.63 .. 0.89 ms, tools/debug/decima_windows.py) and only an average over episodes is a stable figure.
+
+    `roofline`: the Decima pass (everything between two sss_step launches) priced against the dense fp32 MFMA peak - its HBM
+    bytes are two orders of magnitude below what 8 TB/s moves in the same time, so the matrix cores are the binding roofline
+    (DESIGN.md section 6): algorithmic flops of a pass (decima.algorithmic_cost: MLP rows x 2 * weights) / the pass's duration,
+    HIP events around every 8th pass of the steady window. `cpu_baseline`: the reference's DecimaScheduler.schedule + env.step."""
     import torch
 
     from spark_sched_sim_amd import VecSparkSchedSimEnv
-    from spark_sched_sim_amd.decima import DecimaPolicy
+    from spark_sched_sim_amd.decima import DecimaPolicy, algorithmic_cost
 
     agent = dict(embed_dim=16, gnn_mlp_kwargs=dict(hid_dims=[32, 16], act_cls="LeakyReLU", act_kwargs=dict(negative_slope=0.2)),
                  policy_mlp_kwargs=dict(hid_dims=[64, 64], act_cls="Tanh"))
@@ -189,12 +207,21 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
     gen = torch.Generator(device=dev).manual_seed(1)
     env.reset(seed=0)
 
-    def run(n: int) -> float:
+    def run(n: int, events=None) -> float:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n):
-            act, _ = policy.schedule_env(env, generator=gen)
-            env.step_async(act["stage_idx"], act["num_exec"])  # (observations, rewards, flags: the env's buffers, read in place by the next pass)
+        for i in range(n):
+            if events is not None and i % 8 == 0:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                act, _ = policy.schedule_env(env, generator=gen)
+                e1.record()
+                env.step_async(act["stage_idx"], act["num_exec"])
+                e2.record()
+                events.append((e0, e1, e2))
+            else:
+                act, _ = policy.schedule_env(env, generator=gen)
+                env.step_async(act["stage_idx"], act["num_exec"])  # (observations, rewards, flags: the env's buffers, read in place by the next pass)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
@@ -202,13 +229,34 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
     dt = run(steps)
     run(max(0, steady_after - warmup - steps))
     nodes = int(env.obs_i32[:, 0].sum())
-    dts = run(steady_steps)
+    events: list = []
+    dts = run(steady_steps, events)
+    pass_ms = sum(a.elapsed_time(b) for a, b, _ in events) / len(events)
+    step_ms = sum(b.elapsed_time(c) for _, b, c in events) / len(events)
+    # the work of a pass on the observations the window ended on: rows of each MLP from the graph kernel's own output
+    act, aux = policy.schedule_env(env, generator=gen, fresh_outputs=True)
+    g = env.decima_graph()
+    gid = (g["obs_job_off"] + aux["job_idx"]).clamp(0, max(0, g["job_cap"].numel() - 1))
+    exec_rows = int((g["job_cap"][gid].clamp(0, cfg["num_executors"]) * aux["any_stage"]).sum())
+    cost = algorithmic_cost(g, exec_rows)
+    achieved = cost["flops"] / (pass_ms * 1e-3) / 1e12
     err = int((env.obs_i32[:, 7] != 0).sum())
     env.close()
-    return {"value": B * steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "envs_in_error_state": err,
-            "steady": {"value": B * steady_steps / dts, "ms_per_step": 1e3 * dts / steady_steps, "steps": steady_steps, "after_steps": steady_after,
-                       "active_nodes_per_env": nodes / B},
-            "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
+    ref = reference_decima_baseline("decima_c1")
+    out = {"value": B * steps / dt, "unit": "env-steps/s", "envs": B, "ms_per_step": 1e3 * dt / steps, "steps": steps, "envs_in_error_state": err,
+           "steady": {"value": B * steady_steps / dts, "ms_per_step": 1e3 * dts / steady_steps, "steps": steady_steps, "after_steps": steady_after,
+                      "active_nodes_per_env": nodes / B, "decima_pass_ms": pass_ms, "sss_step_ms": step_ms},
+           "roofline": {"bound": "mfma", "kernel": "the Decima pass: sss_decima_graph_kernel + sss_gnn_*_mfma kernels + sss_decima_sample kernels (dominant: sss_gnn_layer_mfma_kernel, one launch per DAG layer)",
+                        "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "dtype": "f32",
+                        "flops_per_pass": cost["flops"], "mlp_rows_per_pass": cost["rows"], "avg_pass_ms": pass_ms, "passes_with_events": len(events),
+                        "hbm_bytes_per_pass_algorithmic": cost["bytes_inference"], "hbm_frac_if_it_were_the_bound": cost["bytes_inference"] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None},
+           "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
+    if ref is not None:
+        out["cpu_baseline"] = {"value": ref["env_steps_per_s"], "unit": "env-steps/s", "cores": 1, "kind": "reference", "sample": f"{ref['episodes']} episodes / {ref['steps']} steps: {ref['what']}",
+                               "schedule_share_of_time": ref["schedule_share_of_time"], "hardware": ref["hardware"], "measured_in_this_run": False,
+                               "source": "profiles/reference_python.json decima_c1 (tools/time_reference_decima.py)"}
+    return out
 
 
 def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
@@ -245,6 +293,31 @@ def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
         rec = {"envs": sequences * rollouts, "samples": n, "longest_rollout": int(ro.active.shape[0]), "collect_s": t1 - t0, "train_s": t2 - t1,
                "iteration_s": t2 - t0, "collect_env_steps_per_s": n / (t1 - t0), "graph_nodes": int(ro.graph["x"].shape[0]),
                **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in learn.items()}}
+        if it == 1:
+            # the algorithmic work of the iteration from its own record (decima.algorithmic_cost): one forward pass over every recorded
+            # observation = what the collection's policy passes computed; an optimiser step over a minibatch is forward + backward
+            # (input and weight gradients) = 3 x its forward flops, `minibatches` of `num_batches` per epoch were taken
+            from spark_sched_sim_amd.decima import algorithmic_cost
+            g = ro.graph
+            gid = (g["obs_job_off"][ro.sample_ids()] + ro.flat(ro.job_idx)).clamp(0, max(0, g["job_cap"].numel() - 1))
+            cost = algorithmic_cost(g, int(g["job_cap"][gid].clamp(0, env["num_executors"]).sum()))
+            mbs = int(learn.get("minibatches", train["num_epochs"] * train["num_batches"]))
+            train_flops = 3.0 * cost["flops"] * mbs / train["num_batches"]
+            train_bytes = cost["bytes_training"] * mbs / train["num_batches"]
+            rec["train_roofline"] = {"bound": "mfma", "kernel": "the PPO update: sss_mlp_mfma_{fwd,bwd,bwdw} / sss_mlp_head_mfma_* kernels + row gather / segment-sum kernels + autograd glue",
+                                     "achieved": train_flops / (t2 - t1) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": train_flops / (t2 - t1) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                     "dtype": "f32", "flops": train_flops, "flops_forward_whole_record": cost["flops"], "minibatches": mbs, "mlp_rows_whole_record": cost["rows"],
+                                     "hbm_bytes_algorithmic": train_bytes, "hbm_frac_if_it_were_the_bound": train_bytes / (t2 - t1) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                     "samples_x_epochs_per_s": n * mbs / train["num_batches"] / (t2 - t1)}
+            rec["collect_roofline"] = {"bound": "mfma", "kernel": "the collection's Decima passes (one per step over the active envs)", "achieved": cost["flops"] / (t1 - t0) / 1e12,
+                                       "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": cost["flops"] / (t1 - t0) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "flops": cost["flops"],
+                                       "note": "the collection is latency-bound: ~7500 dependent steps of graph + GNN + sampling + sss_step launches over <= 1024 envs (DESIGN.md section 9.2)"}
+            ref = reference_decima_baseline("ppo_config5")
+            if ref is not None:
+                rec["cpu_baseline"] = {"collect": {"value": ref["collect_env_steps_per_s_one_core"], "unit": "env-steps/s", "cores": 1},
+                                       "train": {"value": ref["train_samples_per_s"], "unit": "samples x epochs / s", "cores": ref["train_threads"]},
+                                       "kind": "reference", "sample": f"{ref['rollouts']} rollouts / {ref['samples']} samples: {ref['what']}", "hardware": ref["hardware"],
+                                       "measured_in_this_run": False, "source": "profiles/reference_python.json ppo_config5 (tools/time_reference_decima.py)"}
         del ro
     rec["peak_memory_allocated_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
     rec["peak_memory_reserved_gb"] = torch.cuda.max_memory_reserved(dev) / 1e9
@@ -714,6 +787,10 @@ def main() -> None:
                 out["decima_in_loop"] = decima_in_loop(cfg, B, dev, pack)
             except Exception as e:
                 out["decima_in_loop"] = {"error": repr(e)}
+            try:  # BASELINE config 4 is 8192 envs over 8 GPUs: one rank's share
+                out["decima_in_loop_1024"] = decima_in_loop(cfg, 1024, dev, pack)
+            except Exception as e:
+                out["decima_in_loop_1024"] = {"error": repr(e)}
         if world == 1 and not args.no_ppo and args.config == "c2":
             try:  # SURVEY 8(f) next-3 / BASELINE config 5 at one rank's share; never let it take the bench line down
                 out["ppo_config5_share"] = ppo_config5_share(dev)

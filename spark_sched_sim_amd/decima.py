@@ -314,6 +314,36 @@ def concat_graphs(gs: list[dict[str, Any]]) -> dict[str, Any]:
     return out
 
 
+# (in, hidden 1, hidden 2, out) of the seven MLPs of the published architecture (config/decima_tpch.yaml:68-78: embed 16, GNN MLPs
+# [32, 16], policy MLPs [64, 64]); a row of an MLP costs 2 * (in * h1 + h1 * h2 + h2 * out) flops
+MLP_DIMS = {"prep": (NUM_NODE_FEATURES, 32, 16, 16), "msg": (16, 32, 16, 16), "update": (16, 32, 16, 16), "dag": (NUM_NODE_FEATURES + 16, 32, 16, 16),
+            "glob": (16, 32, 16, 16), "stage": (NUM_NODE_FEATURES + 3 * 16, 64, 64, 1), "exec": (NUM_DAG_FEATURES + 2 * 16 + 1, 64, 64, 1)}
+
+
+def _popcount_sum(t: torch.Tensor, bits: int = 32) -> int:
+    return int(sum(int(((t >> b) & 1).sum()) for b in range(bits))) if t.numel() else 0
+
+
+def algorithmic_cost(g: dict[str, Any], exec_rows: int) -> dict[str, Any]:
+    """Algorithmic work of ONE forward pass of the published Decima architecture over the observations of compact graph `g`
+    (scheduler.py:142-385) - what bench.py prices `decima_in_loop` and `ppo_config5_share` against:
+
+      rows    MLP evaluations the pass needs: prep and dag once per active node; msg once per (edge, DAG layer whose mask holds the
+              edge) and update once per (receiving node, layer) (scheduler.py:196-241); glob once per active job; stage once per
+              schedulable node; exec once per allowed (job, executor count) pair of the chosen jobs (`exec_rows`, given by the caller)
+      flops   sum over rows of 2 * (in * h1 + h1 * h2 + h2 * out): the matrix products only (activations, sums, softmax not counted)
+      bytes_inference   HBM bytes when nothing but inputs and outputs of each MLP touch memory: 4 B * (in + out) per row
+      bytes_training    forward + backward with every MLP's activations stored once and read once, gradients of the same size
+                        written and read: 12 B * (in + h1 + h2 + out) per row
+    A training step (forward + backward: input and weight gradients) is 3 x the forward flops."""
+    rows = {"prep": int(g["x"].shape[0]), "dag": int(g["x"].shape[0]), "glob": int(g["job_obs"].numel()), "stage": int(g["stage_mask"].sum()),
+            "exec": int(exec_rows), "msg": _popcount_sum(g["edge_layers"]) if "edge_layers" in g else 0,
+            "update": _popcount_sum(g["node_recv"]) if "node_recv" in g else 0}
+    flops = sum(n * 2 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[3]) for k, n in rows.items() for d in (MLP_DIMS[k],))
+    return {"rows": rows, "flops": float(flops), "bytes_inference": float(sum(n * 4 * (MLP_DIMS[k][0] + MLP_DIMS[k][3]) for k, n in rows.items())),
+            "bytes_training": float(sum(n * 12 * sum(MLP_DIMS[k]) for k, n in rows.items()))}
+
+
 def make_mlp(input_dim: int, hid_dims: list[int], output_dim: int, act_cls: str, act_kwargs: dict[str, Any] | None = None) -> nn.Sequential:
     """Linear / activation stack with the reference's layer numbering (decima/utils.py:44-64)"""
     act = getattr(torch.nn.modules.activation, act_cls)

@@ -755,7 +755,8 @@ class PPO:
                         p.grad.copy_(flat[off: off + k].view_as(p))
                         off += k
                 self.policy.update_parameters(None)
-        return {"policy loss": abs(float(np.mean(pol))), "entropy": abs(float(np.mean(ent))), "approx kl div": abs(float(np.mean(kls)))}
+        # (`minibatches`: optimiser steps taken - fewer than epochs x batches when the KL test stopped the epochs, ppo.py:89-93)
+        return {"policy loss": abs(float(np.mean(pol))), "entropy": abs(float(np.mean(ent))), "approx kl div": abs(float(np.mean(kls))), "minibatches": len(pol)}
 
 
 class Trainer:
