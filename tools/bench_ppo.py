@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--device-index", type=int, default=None)
     ap.add_argument("--collector-groups", type=int, default=1)
+    ap.add_argument("--no-train", action="store_true", help="collections only (for a rocprofv3 kernel trace of the collection alone: tools/profile_ppo_rocprof.sh)")
     a = ap.parse_args()
     import os
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # BASELINE config 5: `python tools/bench_ppo.py --gpus 8 --sequences 256 --rollouts 4`
@@ -61,7 +62,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         tr.policy.train()
-        learn = tr.ppo.train_on_rollouts(ro)
+        learn = {} if a.no_train else tr.ppo.train_on_rollouts(ro)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         n = int(ro.active.sum())
