@@ -299,7 +299,8 @@ def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
             # (input and weight gradients) = 3 x its forward flops, `minibatches` of `num_batches` per epoch were taken
             from spark_sched_sim_amd.decima import algorithmic_cost
             g = ro.graph
-            gid = (g["obs_job_off"][ro.sample_ids()] + ro.flat(ro.job_idx)).clamp(0, max(0, g["job_cap"].numel() - 1))
+            job_off = torch.cumsum(g["obs_jobs"], 0) - g["obs_jobs"]
+            gid = (job_off[ro.sample_ids()] + ro.flat(ro.job_idx)).clamp(0, max(0, g["job_cap"].numel() - 1))
             cost = algorithmic_cost(g, int(g["job_cap"][gid].clamp(0, env["num_executors"]).sum()))
             mbs = int(learn.get("minibatches", train["num_epochs"] * train["num_batches"]))
             train_flops = 3.0 * cost["flops"] * mbs / train["num_batches"]
