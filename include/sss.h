@@ -526,10 +526,16 @@ typedef struct sss_mlp_args {
   float* dx_dev;       /* backward, nullable */
 } sss_mlp_args;
 int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act);
+/* 1: for the (in_dim) -> 32 -> 16 -> 16 LeakyReLU MLP sss_mlp_forward may be called with a1_dev == a2_dev == NULL (the hidden
+ * activations are not stored) and sss_mlp_backward_wgrad with the same two NULL: it then computes them again from x_dev - same
+ * instructions, same bits as the stored ones. Stored activations are two thirds of these kernels' memory traffic and 48 floats
+ * per row of the update's memory (what autograd keeps alive for nn.Sequential in the reference, ppo.py:104-138). 0: this build keeps them. */
+int sss_mlp_recompute_supported(int in_dim);
 int sss_mlp_forward(const sss_mlp_args* a, void* stream);
 int sss_mlp_backward(const sss_mlp_args* a, void* stream);
 /* sss_mlp_backward with the six parameter gradients in the same pass, for the (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs:
- * x_dev, a1_dev, a2_dev, dy_dev in, dx_dev out (nullable); g1 / g2 are not written. The weight / bias gradients are ADDED to
+ * x_dev, a1_dev, a2_dev (both NULL: recomputed from x_dev, see sss_mlp_recompute_supported), dy_dev in, dx_dev out (nullable); g1 / g2 are
+ * not written. The weight / bias gradients are ADDED to
  * per-workgroup slots of acc_dev (f32[sss_mlp_wgrad_scratch(in_dim)], zeroed by the caller before the first call of a group of
  * calls whose gradients belong together - the layers of the message passing); sss_mlp_wgrad_finish adds the slots in a fixed
  * order into gw1 [32][in_dim], gb1 [32], gw2 [16][32], gb2 [16], gw3 [16][16], gb3 [16]. Same inputs, same bits. */

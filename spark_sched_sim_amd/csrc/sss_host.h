@@ -748,8 +748,13 @@ extern "C" int sss_collect_step(const sss_collect_args* c, int phase, void* stre
   return 0;
 }
 
+static int be_mlp_recompute_supported(int in_dim);
+extern "C" int sss_mlp_recompute_supported(int in_dim) { return be_mlp_recompute_supported(in_dim); }
 static int sss_mlp_check(const sss_mlp_args* a, bool backward) {
-  if (!a || !a->w_dev || !a->a1_dev || !a->a2_dev) return sss_fail(-1, "NULL argument");
+  if (!a || !a->w_dev) return sss_fail(-1, "NULL argument");
+  // the forward pass of a GNN-shaped MLP may leave the hidden activations out (both NULL): sss_mlp_backward_wgrad then recomputes them
+  const bool no_hidden = !a->a1_dev && !a->a2_dev && !backward && a->h1 == 32 && a->h2 == 16 && a->out_dim == 16 && a->act == 0 && be_mlp_recompute_supported(a->in_dim);
+  if (!no_hidden && (!a->a1_dev || !a->a2_dev)) return sss_fail(-1, "NULL argument");
   if (a->rows < 0) return sss_fail(-31, "sss_mlp: negative row count");
   if (backward ? (!a->dy_dev || !a->g1_dev || !a->g2_dev) : (!a->x_dev || !a->y_dev)) return sss_fail(-1, "NULL argument");
   return 0;
@@ -854,7 +859,9 @@ extern "C" int64_t sss_mlp_wgrad_scratch(int in_dim) {
   return sss_mlpw_ok(in_dim) ? (int64_t)SSS_MLPW_SLOTS * ((16 * 16 + 16) + (16 * 32 + 16) + (32 * in_dim + 32)) : 0;
 }
 extern "C" int sss_mlp_backward_wgrad(const sss_mlp_args* a, float* acc_dev, void* stream) {
-  if (!a || !a->w_dev || !a->a1_dev || !a->a2_dev || !a->dy_dev || !a->x_dev || !acc_dev) return sss_fail(-1, "NULL argument");
+  if (!a || !a->w_dev || !a->dy_dev || !a->x_dev || !acc_dev) return sss_fail(-1, "NULL argument");
+  if (!a->a1_dev != !a->a2_dev) return sss_fail(-1, "sss_mlp_backward_wgrad: a1_dev and a2_dev are given together or not at all");
+  if (!a->a1_dev && !be_mlp_recompute_supported(a->in_dim)) return sss_fail(-31, "sss_mlp_backward_wgrad: this build cannot recompute the hidden activations (a1_dev / a2_dev required)");
   if (a->rows < 0) return sss_fail(-31, "sss_mlp: negative row count");
   if (!(a->h1 == 32 && a->h2 == 16 && a->out_dim == 16 && a->act == 0 && sss_mlpw_ok(a->in_dim)))
     return sss_fail(-31, "sss_mlp_backward_wgrad: (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs only");

@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_fwd_kernel(SssMlpArgs a) {
     const mfma_f4 h2 = leaky4(e0 + e1, a.slope);
     const mfma_f4 y = m.out(h2, 1.0f);
     if (valid) {
-      *(mfma_f4*)(a.a1 + row * 32 + 4 * q) = d0, *(mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) = d1;
-      *(mfma_f4*)(a.a2 + row * 16 + 4 * q) = h2;
+      if (a.a1) {  // (NULL: the caller's backward pass recomputes the hidden activations from x - sss_mlp_mfma_bwdw_kernel<IN, true>)
+        *(mfma_f4*)(a.a1 + row * 32 + 4 * q) = d0, *(mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) = d1;
+        *(mfma_f4*)(a.a2 + row * 16 + 4 * q) = h2;
+      }
       *(mfma_f4*)(a.y + row * 16 + 4 * q) = y;
     }
   }
@@ -306,12 +308,30 @@ struct SssMlpWgradAcc {  // per-workgroup slots: [SLOTS][N * M + N] per Linear
   float* l2;  // 16 x 32 + 16
   float* l1;  // 32 x IN + 32
 };
-template <int IN>
+// RECOMPUTE: the two hidden activations are not read but computed again from x (the forward chain of sss_mlp_mfma_fwd_kernel, the
+// same instructions in the same order: the same bits) - a forward pass that did not store them wrote 16 instead of 64 floats per
+// row, and this pass reads x 16 + dy 16 instead of 80 floats per row: the stored activations were two thirds of the update's MLP
+// traffic, which is what bounds these kernels (profiles/r06_ppo.md), and 48 floats per MLP row of the update's peak memory. The
+// recomputed tiles come out in the layout the chain below wants (lane (i, q): neurons 4 q .. 4 q + 3 of row i) and go through the
+// per-wave LDS tile into the weight-gradient operand layout like g1 / g2 do.
+template <int IN, bool RECOMPUTE = false>
 __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, SssMlpWgradAcc acc) {
   constexpr int U = (IN + 15) / 16;
   constexpr int NT = 3 + 2 * U;  // accumulator tiles: dW3, dW2 (two column tiles), dW1 (two row tiles x U column tiles)
+  constexpr int TS = RECOMPUTE ? 112 : 48;  // floats per row of the LDS tile (112 = 16 mod 32: rows r, r + 1 of a half-wave's read sit on different banks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
+  MfmaGnnMlp fw;       // (RECOMPUTE only) the forward chain's operands
+  float fs1[2][4];     // ... second input segment (IN > 16)
+  if (RECOMPUTE) {
+    fw.load(a.w, lane, IN, 0, IN < 16 ? IN : 16);
+    if (U > 1) {
+      MfmaGnnMlp m2;
+      m2.load(a.w, lane, IN, 16, IN - 16);
+      for (int t = 0; t < 2; t++)
+        for (int r = 0; r < 4; r++) fs1[t][r] = m2.a1[t][r];
+    }
+  }
   const float* W1 = a.w;
   const float* W2T = W1 + 32 * IN + 32;
   const float* W3 = W2T + 32 * 16 + 16;
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
   for (int u = 0; u < U; u++)
     for (int t = 0; t < 2; t++)
       for (int r = 0; r < 4; r++) t1[u][t][r] = 16 * u + i < IN ? W1[(16 * t + 4 * q + r) * IN + 16 * u + i] : 0.0f;
-  __shared__ __attribute__((aligned(16))) float tr[4][16 * 48];  // per wave: [row][g2 (16) | g1 (32)] of the tile
+  __shared__ __attribute__((aligned(16))) float tr[4][16 * TS];  // per wave: [row][g2 (16) | g1 (32) | RECOMPUTE: a2 (16) | a1 (32)] of the tile
   __shared__ float red[NT * 256 + 64];
   float* T = tr[wave];
   const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -335,9 +355,43 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
     const int64_t row = tile * 16 + i;
     const bool valid = row < a.rows;
     const mfma_f4 dy = valid ? *(const mfma_f4*)(a.dy + row * 16 + 4 * q) : zero;
-    const mfma_f4 a2 = valid ? *(const mfma_f4*)(a.a2 + row * 16 + 4 * q) : zero;
-    const mfma_f4 a10 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 4 * q) : zero;
-    const mfma_f4 a11 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) : zero;
+    mfma_f4 a2, a10, a11;
+    if (RECOMPUTE) {
+      // the forward pass again, exactly as sss_mlp_mfma_fwd_kernel runs it
+      mfma_f4 x0 = zero, x1 = zero;
+      if (valid) {
+        const float* xr = a.x + row * IN;
+        float v[4];
+        for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? xr[4 * q + r] : 0.0f;
+        x0 = mfma_f4{v[0], v[1], v[2], v[3]};
+        if (U > 1) {
+          for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? xr[16 + 4 * q + r] : 0.0f;
+          x1 = mfma_f4{v[0], v[1], v[2], v[3]};
+        }
+      }
+      mfma_f4 d0 = fw.b1[0], d1 = fw.b1[1];
+      d0 = mfma16(fw.a1[0][0], x0.x, d0), d1 = mfma16(fw.a1[1][0], x0.x, d1);
+      d0 = mfma16(fw.a1[0][1], x0.y, d0), d1 = mfma16(fw.a1[1][1], x0.y, d1);
+      d0 = mfma16(fw.a1[0][2], x0.z, d0), d1 = mfma16(fw.a1[1][2], x0.z, d1);
+      d0 = mfma16(fw.a1[0][3], x0.w, d0), d1 = mfma16(fw.a1[1][3], x0.w, d1);
+      if (U > 1) {
+        d0 = mfma16(fs1[0][0], x1.x, d0), d1 = mfma16(fs1[1][0], x1.x, d1);
+        d0 = mfma16(fs1[0][1], x1.y, d0), d1 = mfma16(fs1[1][1], x1.y, d1);
+        d0 = mfma16(fs1[0][2], x1.z, d0), d1 = mfma16(fs1[1][2], x1.z, d1);
+        d0 = mfma16(fs1[0][3], x1.w, d0), d1 = mfma16(fs1[1][3], x1.w, d1);
+      }
+      d0 = leaky4(d0, a.slope), d1 = leaky4(d1, a.slope);
+      mfma_f4 e0 = fw.b2, e1 = zero;
+      e0 = mfma16(fw.a2[0][0], d0.x, e0), e1 = mfma16(fw.a2[1][0], d1.x, e1);
+      e0 = mfma16(fw.a2[0][1], d0.y, e0), e1 = mfma16(fw.a2[1][1], d1.y, e1);
+      e0 = mfma16(fw.a2[0][2], d0.z, e0), e1 = mfma16(fw.a2[1][2], d1.z, e1);
+      e0 = mfma16(fw.a2[0][3], d0.w, e0), e1 = mfma16(fw.a2[1][3], d1.w, e1);
+      a2 = leaky4(e0 + e1, a.slope), a10 = d0, a11 = d1;
+    } else {
+      a2 = valid ? *(const mfma_f4*)(a.a2 + row * 16 + 4 * q) : zero;
+      a10 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 4 * q) : zero;
+      a11 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) : zero;
+    }
     mfma_f4 g2 = zero;
     g2 = mfma16(t3[0], dy.x, g2), g2 = mfma16(t3[1], dy.y, g2), g2 = mfma16(t3[2], dy.z, g2), g2 = mfma16(t3[3], dy.w, g2);
     g2 = leaky4_grad(g2, a2, a.slope);
@@ -348,7 +402,8 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
     g10 = mfma16(t2[0][3], g2.w, g10), g11 = mfma16(t2[1][3], g2.w, g11);
     g10 = leaky4_grad(g10, a10, a.slope), g11 = leaky4_grad(g11, a11, a.slope);
     // (rows behind the end: dy = 0 -> g2 = g1 = 0, they add nothing below)
-    *(mfma_f4*)(T + i * 48 + 4 * q) = g2, *(mfma_f4*)(T + i * 48 + 16 + 4 * q) = g10, *(mfma_f4*)(T + i * 48 + 32 + 4 * q) = g11;
+    *(mfma_f4*)(T + i * TS + 4 * q) = g2, *(mfma_f4*)(T + i * TS + 16 + 4 * q) = g10, *(mfma_f4*)(T + i * TS + 32 + 4 * q) = g11;
+    if (RECOMPUTE) *(mfma_f4*)(T + i * TS + 48 + 4 * q) = a2, *(mfma_f4*)(T + i * TS + 64 + 4 * q) = a10, *(mfma_f4*)(T + i * TS + 80 + 4 * q) = a11;
     if (a.dx) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -371,12 +426,13 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
       const int r = 4 * s4 + q;
       const int64_t grow = tile * 16 + r;
       const bool ok = grow < a.rows;
-      const float A3 = ok ? a.dy[grow * 16 + i] : 0.0f, B3 = ok ? a.a2[grow * 16 + i] : 0.0f;
+      // (RECOMPUTE: a row behind the end has dy = g = 0, so whatever its recomputed activations are multiplies zero)
+      const float A3 = ok ? a.dy[grow * 16 + i] : 0.0f, B3 = RECOMPUTE ? T[r * TS + 48 + i] : (ok ? a.a2[grow * 16 + i] : 0.0f);
       w3a = __builtin_amdgcn_mfma_f32_16x16x4f32(A3, B3, w3a, 0, 0, 0), b3s += A3;
-      const float A2 = T[r * 48 + i];
-      const float B20 = ok ? a.a1[grow * 32 + i] : 0.0f, B21 = ok ? a.a1[grow * 32 + 16 + i] : 0.0f;
+      const float A2 = T[r * TS + i];
+      const float B20 = RECOMPUTE ? T[r * TS + 64 + i] : (ok ? a.a1[grow * 32 + i] : 0.0f), B21 = RECOMPUTE ? T[r * TS + 80 + i] : (ok ? a.a1[grow * 32 + 16 + i] : 0.0f);
       w2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, B20, w2a[0], 0, 0, 0), w2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, B21, w2a[1], 0, 0, 0), b2s += A2;
-      const float A10 = T[r * 48 + 16 + i], A11 = T[r * 48 + 32 + i];
+      const float A10 = T[r * TS + 16 + i], A11 = T[r * TS + 32 + i];
       b1s[0] += A10, b1s[1] += A11;
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -437,7 +493,10 @@ static int mlp_mfma_bwdw_launch(const SssMlpArgs& a, const SssMlpWgradAcc& acc, 
   if (a.rows <= 0) return 0;
   const int64_t wgs = (a.rows + 63) / 64;
   const unsigned grid = (unsigned)(wgs < SSS_MLPW_SLOTS ? wgs : SSS_MLPW_SLOTS);
-  hipLaunchKernelGGL(sss_mlp_mfma_bwdw_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
+  if (!a.a1)  // the forward pass did not store the hidden activations: recompute them from x
+    hipLaunchKernelGGL((sss_mlp_mfma_bwdw_kernel<IN, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
+  else
+    hipLaunchKernelGGL((sss_mlp_mfma_bwdw_kernel<IN, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
   return (int)hipGetLastError();
 }
 
@@ -597,6 +656,15 @@ static int be_launch_mlp_bwdw(const SssMlpArgs& a, float* acc, void* stream) {
   if (a.in_dim == 16) return mlp_mfma_bwdw_launch<16>(a, w, stream);
   if (a.in_dim == GNN_NF + 16) return mlp_mfma_bwdw_launch<GNN_NF + 16>(a, w, stream);
   return -1;
+}
+// whether sss_mlp_forward may skip storing the hidden activations of this GNN-shaped MLP and sss_mlp_backward_wgrad recomputes them
+static int be_mlp_recompute_supported(int in_dim) {
+#ifdef SSS_TEST_VECTOR_FORMS
+  (void)in_dim;
+  return 0;  // (the 16-lanes-per-row comparison kernels keep the stored-activation form)
+#else
+  return in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16;
+#endif
 }
 static int be_launch_wgrad_reduce(const SssWgradArgs& a, void* stream) {
   hipLaunchKernelGGL(sss_wgrad_reduce_kernel, dim3((unsigned)((a.N * a.M + a.N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);

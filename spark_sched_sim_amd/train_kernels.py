@@ -249,16 +249,34 @@ def _out(t, rows, width, dev):
     return t
 
 
-def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None, a1=None, a2=None, y=None):
+_RECOMPUTE: dict = {}
+
+
+def mlp_recompute(in_dim: int, binding=None) -> bool:
+    """whether the library evaluates the (in_dim) -> 32 -> 16 -> 16 MLP without storing its hidden activations and recomputes them
+    in `mlp_backward_wgrad` (include/sss.h sss_mlp_recompute_supported)"""
+    b = binding if binding is not None else _binding()
+    key = (id(b.lib), in_dim)
+    if key not in _RECOMPUTE:
+        _RECOMPUTE[key] = bool(RECOMPUTE_HIDDEN and FUSED_WGRAD and b.lib.sss_mlp_recompute_supported(in_dim))
+    return _RECOMPUTE[key]
+
+
+def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None, a1=None, a2=None, y=None, keep_hidden: bool = True):
     """(a1 f32[rows, H1], a2 f32[rows, H2], y f32[rows, OUT]) of `sss_mlp_forward` for x f32[rows, IN] (contiguous); written
-    into the tensors given, or into new ones"""
+    into the tensors given, or into new ones. `keep_hidden=False` (only where `mlp_recompute` says so): a1 / a2 are not stored
+    (returned as None) - the backward pass computes them again"""
     import ctypes
 
     from .binding import device_of
     b = binding if binding is not None else _binding()
     rows, dev = x.shape[0], x.device
     assert x.dim() == 2 and x.shape[1] == dims[0] and x.is_contiguous() and x.dtype == torch.float32
-    a1, a2, y = _out(a1, rows, dims[1], dev), _out(a2, rows, dims[2], dev), _out(y, rows, dims[3], dev)
+    if keep_hidden:
+        a1, a2 = _out(a1, rows, dims[1], dev), _out(a2, rows, dims[2], dev)
+    else:
+        assert a1 is None and a2 is None
+    y = _out(y, rows, dims[3], dev)
     a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, y=y)
     with device_of(dev):
         b.check(b.lib.sss_mlp_forward(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
@@ -285,6 +303,10 @@ def mlp_backward(dy: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: t
 
 
 FUSED_WGRAD = True  # the GNN-shaped MLPs' backward pass with the parameter gradients in the same kernel (sss_mlp_backward_wgrad)
+# ... and without stored hidden activations: the forward kernels write y only, the backward kernel recomputes a1 / a2 from x on the
+# matrix cores (bit-identical). The kernels are bound by exactly that traffic (profiles/r06_ppo.md), and the stored activations were
+# ~25 GB of a config-5 minibatch's peak memory.
+RECOMPUTE_HIDDEN = True
 
 
 def mlp_wgrad_acc(in_dim: int, dev, binding=None) -> torch.Tensor | None:
@@ -302,9 +324,10 @@ def mlp_backward_wgrad(dy: torch.Tensor, x: torch.Tensor, a1: torch.Tensor, a2: 
 
     from .binding import device_of
     b = binding if binding is not None else _binding()
-    rows, dev = a1.shape[0], a1.device
+    rows, dev = x.shape[0], x.device   # (a1 / a2 None: recomputed from x by the kernel)
     dy = dy.contiguous()
     assert dy.shape == (rows, dims[3]) and x.shape == (rows, dims[0]) and x.is_contiguous() and dy.dtype == x.dtype == torch.float32
+    assert (a1 is None) == (a2 is None)
     dx = torch.empty((rows, dims[0]), dtype=torch.float32, device=dev) if want_dx else None
     if rows == 0:
         return dx
@@ -333,14 +356,21 @@ class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, packed, act, slope):
         dims = (w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0])
-        a1, a2, y = mlp_forward(x, packed, dims, act, slope)
-        ctx.save_for_backward(x, a1, a2, packed)
+        ctx.recompute = act == 0 and tuple(dims[1:]) == (32, 16, 16) and mlp_recompute(dims[0])
+        a1, a2, y = mlp_forward(x, packed, dims, act, slope, keep_hidden=not ctx.recompute)
+        if ctx.recompute:
+            ctx.save_for_backward(x, packed)
+        else:
+            ctx.save_for_backward(x, a1, a2, packed)
         ctx.dims, ctx.act, ctx.slope = dims, act, slope
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, a1, a2, packed = ctx.saved_tensors
+        if ctx.recompute:
+            (x, packed), a1, a2 = ctx.saved_tensors, None, None
+        else:
+            x, a1, a2, packed = ctx.saved_tensors
         dy = dy.contiguous()
         acc = mlp_wgrad_acc(ctx.dims[0], dy.device) if (FUSED_WGRAD and ctx.act == 0 and tuple(ctx.dims[1:]) == (32, 16, 16)) else None
         if acc is not None:  # one kernel: dx and the six parameter gradients (g1 / g2 never leave the chip)
@@ -418,8 +448,10 @@ class _MessagePassFn(torch.autograd.Function):
         ne = sum(int(c.numel()) for c, _, _ in layers)
         nr = sum(int(r.numel()) for _, _, r in layers)
         f = lambda n, w: torch.empty((n, w), dtype=torch.float32, device=dev)  # noqa: E731
-        mx, ma1, ma2 = f(ne, 16), f(ne, 32), f(ne, 16)  # message MLP: inputs and hidden activations of every edge, layer after layer
-        ux, ua1, ua2 = f(nr, 16), f(nr, 32), f(nr, 16)  # update MLP: the same per receiving node
+        keep = not mlp_recompute(16)  # (else the backward kernels recompute the hidden activations from mx / ux)
+        mx, ma1, ma2 = f(ne, 16), f(ne, 32) if keep else None, f(ne, 16) if keep else None  # message MLP: inputs (and hidden activations) of every edge, layer after layer
+        ux, ua1, ua2 = f(nr, 16), f(nr, 32) if keep else None, f(nr, 16) if keep else None  # update MLP: the same per receiving node
+        sl = lambda t, lo, n: t[lo:lo + n] if t is not None else None  # noqa: E731
         h = h0.clone()
         h_init = h_init.contiguous()
         eo = ro = 0
@@ -429,21 +461,28 @@ class _MessagePassFn(torch.autograd.Function):
                 continue
             xs = mx[eo:eo + n_e]
             rows_op(ROWS_GATHER, child, xs, h)
-            _, _, my = mlp_forward(xs, packed_msg, D, 0, slope, a1=ma1[eo:eo + n_e], a2=ma2[eo:eo + n_e])
+            _, _, my = mlp_forward(xs, packed_msg, D, 0, slope, a1=sl(ma1, eo, n_e), a2=sl(ma2, eo, n_e), keep_hidden=keep)
             agg = ux[ro:ro + n_r]
             # the layer's edges are listed receiver by receiver (graph_layers: edge ids ascending, edges stored source node by
             # source node), so a receiver's messages are a range of rows: summed in order, no atomics
             rows_op(ROWS_SEGMENT_SUM, segment_offsets(pos, n_r), my, agg)
-            _, _, uy = mlp_forward(agg, packed_upd, D, 0, slope, a1=ua1[ro:ro + n_r], a2=ua2[ro:ro + n_r])
+            _, _, uy = mlp_forward(agg, packed_upd, D, 0, slope, a1=sl(ua1, ro, n_r), a2=sl(ua2, ro, n_r), keep_hidden=keep)
             rows_op(ROWS_UPDATE, recv, uy, h, h_init)  # h[recv] = uy + h_init[recv] (every read of the layer came before this write)
             eo, ro = eo + n_e, ro + n_r
-        ctx.layers, ctx.slope = layers, slope
-        ctx.save_for_backward(mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd)
+        ctx.layers, ctx.slope, ctx.keep = layers, slope, keep
+        if keep:
+            ctx.save_for_backward(mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd)
+        else:
+            ctx.save_for_backward(mx, ux, packed_msg, packed_upd)
         return h
 
     @staticmethod
     def backward(ctx, gh_in):
-        mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd = ctx.saved_tensors
+        if ctx.keep:
+            mx, ma1, ma2, ux, ua1, ua2, packed_msg, packed_upd = ctx.saved_tensors
+        else:
+            (mx, ux, packed_msg, packed_upd), ma1, ma2, ua1, ua2 = ctx.saved_tensors, None, None, None, None
+        sl = lambda t, lo, n: t[lo:lo + n] if t is not None else None  # noqa: E731
         layers, slope, D = ctx.layers, ctx.slope, _MessagePassFn.DIMS
         dev = gh_in.device
         f = lambda t: torch.empty_like(t)  # noqa: E731
@@ -451,6 +490,7 @@ class _MessagePassFn(torch.autograd.Function):
         acc_u = mlp_wgrad_acc(16, dev) if FUSED_WGRAD else None
         fused = acc_m is not None and acc_u is not None
         mdy, udy = f(mx), f(ux)
+        assert fused or ctx.keep
         mg1, mg2, ug1, ug2 = (None,) * 4 if fused else (f(ma1), f(ma2), f(ua1), f(ua2))
         gh = gh_in.contiguous().clone()  # gradient w.r.t. the embeddings as they were before the layer being undone
         g_init = torch.zeros_like(gh)
@@ -464,13 +504,13 @@ class _MessagePassFn(torch.autograd.Function):
             # g_new = gh[recv]; gh[recv] = 0 (the receivers' previous embeddings were overwritten); g_init[recv] += g_new
             rows_op(ROWS_TAKE, recv, g_new, gh, g_init)
             if fused:  # the parameter gradients of every layer add up in the two accumulators
-                g_agg = mlp_backward_wgrad(g_new, ux[ro:ro + n_r], ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, slope, acc_u)
+                g_agg = mlp_backward_wgrad(g_new, ux[ro:ro + n_r], sl(ua1, ro, n_r), sl(ua2, ro, n_r), packed_upd, D, slope, acc_u)
             else:
                 _, _, g_agg = mlp_backward(g_new, ua1[ro:ro + n_r], ua2[ro:ro + n_r], packed_upd, D, 0, slope, g1=ug1[ro:ro + n_r], g2=ug2[ro:ro + n_r])
             g_msg = mdy[eo:eo + n_e]
             rows_op(ROWS_GATHER, pos, g_msg, g_agg)
             if fused:
-                g_xs = mlp_backward_wgrad(g_msg, mx[eo:eo + n_e], ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, slope, acc_m)
+                g_xs = mlp_backward_wgrad(g_msg, mx[eo:eo + n_e], sl(ma1, eo, n_e), sl(ma2, eo, n_e), packed_msg, D, slope, acc_m)
             else:
                 _, _, g_xs = mlp_backward(g_msg, ma1[eo:eo + n_e], ma2[eo:eo + n_e], packed_msg, D, 0, slope, g1=mg1[eo:eo + n_e], g2=mg2[eo:eo + n_e])
             rows_op(ROWS_SCATTER_ADD, child, g_xs, gh)

@@ -113,7 +113,7 @@ def test_a_stage_with_40000_tasks_is_exact(pack):
     nodes = env.nodes.cpu().numpy()
     assert nodes[..., 0].max() == 40000.0 and nodes[..., 0].min() >= 0.0 and int(env.obs_i32[:, 7].abs().sum()) == 0
     env.close()
-    bad = lockstep_vs_oracle(big, CFG, [0, 1], 25, device="cpu", lib=load_emu())
+    bad = lockstep_vs_oracle(big, CFG, [0], 20, device="cpu", lib=load_emu())
     assert not bad, "\n".join(bad[:8])
 
 

@@ -108,7 +108,7 @@ def test_batches_equal_one_event_at_a_time(cfg, policy, seeds, chunk, n_launches
 DEEP_E50 = dict(num_executors=50, job_arrival_cap=40, job_arrival_rate=1.0e-3, moving_delay=2000.0, warmup_delay=1000.0)
 
 
-@pytest.mark.parametrize("policy,seeds,chunk,n_launches", [("fair", [0, 1], 41, 8), ("hash", [2], 29, 8)])
+@pytest.mark.parametrize("policy,seeds,chunk,n_launches", [("fair", [0, 1], 41, 5), ("hash", [2], 29, 5)])
 def test_runs_over_jobs_without_a_cache_slot_equal_one_event_at_a_time(policy, seeds, chunk, n_launches):
     """fast_run takes the task completions of jobs that have no LDS cache slot too (their records are read from and written back to
     HBM once per run): byte-identical env state to the one-at-a-time build, and nearly every such event goes through runs"""

@@ -24,13 +24,13 @@ CASES = [
     ("e120_hash", [0, 1, 2, 3], None),   # 120 executors on <= 6 jobs: more than 100 local executors, and all 120 (tpch.py:258-260)
     # the "deep" trace regime (workload.PROFILES: <= 40 stages, in-degree <= 6 over all predecessors, <= 3000 tasks per stage, a 60 MB
     # pack): reference recordings at 10 / 50 / 100 executors; the whole episodes run in tests/test_gpu_parity.py
-    ("deep_c1_fair", [0, 1], 300),
-    ("deep_c1_hash", [2], 300),
-    ("deep_c1_fifo", [3], 300),
-    ("deep_e50_fair", [0], 300),
-    ("deep_e50_hash", [1], 300),
-    ("deep_e100_fair", [0], 300),
-    ("deep_e100_hash", [1], 300),
+    ("deep_c1_fair", [0], 150),
+    ("deep_c1_hash", [2], 150),
+    ("deep_c1_fifo", [3], 150),
+    ("deep_e50_fair", [0], 150),
+    ("deep_e50_hash", [1], 150),
+    ("deep_e100_fair", [0], 150),
+    ("deep_e100_hash", [1], 150),
 ]
 
 

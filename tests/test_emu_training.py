@@ -256,6 +256,34 @@ def test_fused_backward_entry_points_on_the_host_backend():
     assert mlp_wgrad_acc(53, "cpu", binding=b) is None
 
 
+def test_recompute_entry_points_on_the_host_backend():
+    """include/sss.h sss_mlp_recompute_supported: sss_mlp_forward without a1 / a2 and sss_mlp_backward_wgrad recomputing them -
+    the same numbers as with stored activations (argument plumbing; the gfx950 kernels' bit identity is a -m gpu test)"""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+    from spark_sched_sim_amd.decima import make_mlp
+    from spark_sched_sim_amd.train_kernels import mlp_backward_wgrad, mlp_forward, mlp_recompute, mlp_wgrad_acc, mlp_wgrad_finish, pack_mlp
+
+    b = Binding(load_emu())
+    torch.manual_seed(16)
+    assert not b.lib.sss_mlp_recompute_supported(53)
+    for in_dim in (5, 16, 21):
+        assert mlp_recompute(in_dim, binding=b)
+        dims = (in_dim, 32, 16, 16)
+        mlp = make_mlp(in_dim, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2))
+        packed = pack_mlp(mlp[0], mlp[2], mlp[4])
+        x, dy = torch.randn((41, in_dim)), torch.randn((41, 16))
+        a1, a2, y = mlp_forward(x, packed, dims, 0, 0.2, binding=b)
+        n1, n2, y2 = mlp_forward(x, packed, dims, 0, 0.2, binding=b, keep_hidden=False)
+        assert n1 is None and n2 is None and torch.equal(y, y2)
+        acc_s, acc_r = mlp_wgrad_acc(in_dim, "cpu", binding=b), mlp_wgrad_acc(in_dim, "cpu", binding=b)
+        assert torch.equal(mlp_backward_wgrad(dy, x, a1, a2, packed, dims, 0.2, acc_s, binding=b), mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_r, binding=b))
+        for g_s, g_r in zip(mlp_wgrad_finish(dims, acc_s, binding=b), mlp_wgrad_finish(dims, acc_r, binding=b)):
+            assert torch.equal(g_s, g_r)
+
+
 def test_rows_entry_point_on_the_host_backend():
     """include/sss.h sss_rows_op through the emulator library's host implementation against torch indexing: the argument
     plumbing of spark_sched_sim_amd.train_kernels.rows_op (the four operations, a list side that is a column slice, widths that

@@ -339,6 +339,38 @@ def test_fused_backward_with_weight_gradients():
 
 
 @pytest.mark.gpu
+def test_recomputed_hidden_activations_give_the_stored_forms_bits():
+    """sss_mlp_mfma_bwdw_kernel<IN, true>: a forward pass that stores no hidden activations (a1 / a2 NULL) and a backward pass that
+    computes them again from x - dx and the six parameter gradients must be BIT-identical to the stored-activation form, y too"""
+    from spark_sched_sim_amd.decima import make_mlp
+    from spark_sched_sim_amd.train_kernels import mlp_backward_wgrad, mlp_forward, mlp_recompute, mlp_wgrad_acc, mlp_wgrad_finish, pack_mlp
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    for in_dim in (5, 16, 21):
+        assert mlp_recompute(in_dim)
+        dims = (in_dim, 32, 16, 16)
+        mlp = make_mlp(in_dim, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2)).to(dev)
+        with torch.no_grad():
+            for lin in (mlp[0], mlp[2], mlp[4]):
+                lin.bias.normal_(0.0, 0.1)
+        packed = pack_mlp(mlp[0], mlp[2], mlp[4])
+        acc_s, acc_r = mlp_wgrad_acc(in_dim, dev), mlp_wgrad_acc(in_dim, dev)
+        for n in (300_007, 1_037, 15):
+            gen = torch.Generator(device=dev).manual_seed(300 + n)
+            x = torch.randn((n, in_dim), device=dev, generator=gen)
+            dy = torch.randn((n, 16), device=dev, generator=gen)
+            a1, a2, y = mlp_forward(x, packed, dims, 0, 0.2)
+            n1, n2, y2 = mlp_forward(x, packed, dims, 0, 0.2, keep_hidden=False)
+            assert n1 is None and n2 is None and torch.equal(y, y2)
+            dx_s = mlp_backward_wgrad(dy, x, a1, a2, packed, dims, 0.2, acc_s)
+            dx_r = mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_r)
+            assert torch.equal(dx_s, dx_r), (in_dim, n)
+        for g_s, g_r in zip(mlp_wgrad_finish(dims, acc_s), mlp_wgrad_finish(dims, acc_r)):
+            assert torch.equal(g_s, g_r), in_dim
+
+
+@pytest.mark.gpu
 def test_record_kernels_match_the_tensor_op_forms():
     """sss_returns_kernel / sss_baseline_kernel (csrc/sss_returns.h) against the tensor-op forms, bit for bit"""
     from training_util import check_record_kernels
