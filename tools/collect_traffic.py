@@ -94,16 +94,18 @@ def main():
     if "--calib-only" in sys.argv:
         return
     recs = []
-    for config, envs in (("c2", 4096), ("c3", 4096)):
+    packs = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--packs=")]
+    packs = packs[0].split(",") if packs else ["default"]   # (--packs=default,deep: also the 'deep' trace regime, workload.PROFILES)
+    for pack, config, envs in [(pk, c, 4096) for pk in packs for c in ("c2", "c3")]:
         for mode, kernel in (("step", "sss_step_kernel"), ("fused", "sss_rollout_kernel")):
-            cmd = ["python3", "bench.py", "--config", config, "--envs", str(envs), "--mode", mode, "--single-mode",
+            cmd = ["python3", "bench.py", "--config", config, "--envs", str(envs), "--mode", mode, "--single-mode", "--pack", pack, "--no-deep",
                    "--no-cpu-baseline", "--no-decima", "--no-c3", "--no-ppo", "--no-e100", "--steps", "200", "--warmup", "50"]
             # the regime the counters are collected in (steady state: bench.py pre-rolls every env), from an unprofiled run
             line = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT).stdout.strip().splitlines()[-1]
             ref = json.loads(line)
             per = {}
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals = pmc_run(counter, f"{config}_{mode}", cmd)
+                vals = pmc_run(counter, f"{pack}_{config}_{mode}", cmd)
                 v = vals.get(kernel, [])
                 if mode == "fused":  # only the timed launches (200 steps in chunks of 50); the pre-roll launches are longer
                     v = v[-4:]
@@ -116,7 +118,7 @@ def main():
             # (a whole L2 line), i.e. for narrow reads the counter already is at or above the bytes moved, while a wide
             # coalesced stream is reported at half. The kernels mix both, so the truth lies between the two figures.
             hbm_lo = (per["FETCH_SIZE"] * 1.0 + per["WRITE_SIZE"] * f_write) * 1024.0
-            recs.append({"kernel": kernel, "config": config, "envs": envs, "mode": mode,
+            recs.append({"kernel": kernel, "config": config, "envs": envs, "mode": mode, "pack": pack,
                          "fetch_size_kib_raw": per["FETCH_SIZE"], "write_size_kib_raw": per["WRITE_SIZE"],
                          "calibration": {"fetch_factor": f_fetch, "write_factor": f_write,
                                          "how": "256 MiB torch copy_ kernel in the same rocprofv3 setup (upper bound for this kernel: see hbm_bytes_per_launch_lo)"},
