@@ -527,7 +527,7 @@ SSS_KERNEL void SSS_KNAME(sss_rollout_kernel)(SssKernelArgs a, int policy, int p
     } else {
       int si, ne;
       run_policy(policy, param, si, ne);
-      reward = do_step(si, ne);
+      reward = do_step<true>(si, ne);
     }
     write_observation(a.L, a.B, env, reward);
     wave_sync();

@@ -424,6 +424,7 @@ SSS_DEV int handle_popped(const FastCtx& f, int ex, double t_win, uint32_t info_
 
 // budget > 0: the loop also ends (returns true) at the top of a round once the step has taken that many events - everything is
 // in the env's state there, the next launch goes on from it (do_step)
+template <bool FUSED = false>  // (FUSED: the rollout kernel's instantiation - fast_run<true>)
 SSS_DEV bool resume_simulation(int budget = 0) {
   PROF3(26);
   int lane = wave_lane();
@@ -466,9 +467,9 @@ SSS_DEV bool resume_simulation(int budget = 0) {
         if (!head_cached) {
           // a task completion of a job without a cache slot (more jobs with pending events than slots): the run looks at the job's
           // HBM records itself and declines (0: nothing touched) when the stage has no task left; the batches below want slots
-          handled = fast_run(f);
+          handled = fast_run<FUSED>(f);
         } else if (tasks_left) {
-          handled = fast_run(f);
+          handled = fast_run<FUSED>(f);
         } else {
 #ifndef SSS_NO_BATCH
           if (64 - g_sc.rng_pos < rng_need) {
@@ -687,6 +688,7 @@ SSS_DEV void step_yield() {
 // ENV:188-221. `reward` is valid on lane 0 (and uniform). budget > 0 (sss_step_bounded): at most about that many events per
 // launch - *yielded is set when the step's event loop has not reached its end (no reward, no observation yet; the next
 // launch continues it).
+template <bool FUSED = false>
 SSS_DEV double do_step(int stage_idx, int num_exec, int budget = 0, bool* yielded = nullptr) {
   PROF3(28);
   int lane = wave_lane();
@@ -748,7 +750,7 @@ SSS_DEV double do_step(int stage_idx, int num_exec, int budget = 0, bool* yielde
   }
   wave_sync();
   }
-  if (resume_simulation(budget)) {
+  if (resume_simulation<FUSED>(budget)) {
     step_yield();
     *yielded = true;
     return 0.0;

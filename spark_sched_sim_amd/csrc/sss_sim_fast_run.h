@@ -30,6 +30,9 @@
 // Returns the number of events handled (0: none, nothing modified).
 // ------------------------------------------------------------------------------------------
 #define FR_OUT 0x40000000u  // rank of a lane whose event is not in the window (never counts down to the head's rank, 1)
+// HEAD_ONLY: which lanes read their candidate duration from the pool (see SSS_EXP_DUR below) - the fused rollout kernel's
+// instantiation, where every wave is busy all the time and the memory pipeline is what a run waits for
+template <bool HEAD_ONLY = false>
 SSS_DEV int fast_run(const FastCtx& f) {
   UTRACE("fast_run");
 #ifdef SSS_NO_BATCH  // debugging aid: every event goes through the one-at-a-time path
@@ -155,10 +158,24 @@ SSS_DEV int fast_run(const FastCtx& f) {
     /* draw passes Lemire's test at the first attempt */                                                                  \
     okm = elig_m & wave_ballot(sl.t < t_stop) & wave_ballot(rem > 0) & wave_ballot((uint32_t)mm >= len);                  \
   } while (0)
+  // Which lanes read their candidate duration from the pool. Only the head's (rank 1: the ranks are up to date whenever a draw is
+  // computed) is ever used; with every lane loading, an event of a 50-executor env touches ~50 lines scattered over the env's
+  // duration lists - 2.3 GB of fetches per config-3 launch on the 60 MB "deep" pack (rocprofv3 FETCH_SIZE, profiles/r06_bench.md).
+  // Letting the other lanes read entry 0 instead (one compare and one select: two lines per load instruction) puts the rank
+  // update of the previous event's commit in front of the load's address - the load no longer issues as early as it can, which
+  // a lock-step launch pays for (its slowest env's chain: -5 % at config 2, -11 % on the deep pack) and the fused rollout, where
+  // all waves are busy and the memory pipeline is the resource, gains from (+26 % at config 3 sizing on the deep pack, +2-3 %
+  // elsewhere): HEAD_ONLY is the rollout kernel's instantiation (profiles/r06_bench.md section 4: also the exec-mask form).
 #ifdef SSS_EXP_NOLOAD  /* timing experiment only (wrong durations): what the load from the duration pool costs */
 #define SSS_EXP_DUR(i) (int32_t)(((i) & 1023u) + 100u)
-#else
+#elif defined(SSS_FAST_LOAD_PRED)
+#define SSS_EXP_DUR(i) (rank == 1u ? *(const int32_t*)(dur_base + (size_t)((i) << 2)) : 0)
+#elif defined(SSS_FAST_LOAD_SEL)
+#define SSS_EXP_DUR(i) (*(const int32_t*)(dur_base + (size_t)((rank == 1u ? (i) : 0u) << 2)))
+#elif defined(SSS_FAST_LOAD_ALL)
 #define SSS_EXP_DUR(i) (*(const int32_t*)(dur_base + (size_t)((i) << 2)))
+#else
+#define SSS_EXP_DUR(i) (*(const int32_t*)(dur_base + (size_t)(((!HEAD_ONLY || rank == 1u) ? (i) : 0u) << 2)))
 #endif
   // the head of the queue commits (registers only): lane w takes its new time and push counter
 #define SSS_FAST_COMMIT(w)                                                                                                \

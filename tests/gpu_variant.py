@@ -17,6 +17,10 @@ VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
             # batch-size thresholds of the event loop (A/B timing: `bench.py --lib tests/_build/libsss_hip_<name>.so`)
             "thr22": ("-DSSS_MIN_RELEASED_BATCH=2", "-DSSS_MIN_ARRIVAL_BATCH=2"), "thr32": ("-DSSS_MIN_RELEASED_BATCH=3", "-DSSS_MIN_ARRIVAL_BATCH=2"),
             "thr63": ("-DSSS_MIN_RELEASED_BATCH=6", "-DSSS_MIN_ARRIVAL_BATCH=3"), "arr1": ("-DSSS_MIN_ARRIVAL_BATCH=1",),
+            # timing only (wrong durations): the fast run without its load from the duration pool - what that load costs per event
+            "noload": ("-DSSS_EXP_NOLOAD",),
+            # A/B timing: which lanes of a fast run load their candidate duration (csrc/sss_sim_fast_run.h SSS_EXP_DUR)
+            "loadpred": ("-DSSS_FAST_LOAD_PRED",), "loadsel": ("-DSSS_FAST_LOAD_SEL",), "loadall": ("-DSSS_FAST_LOAD_ALL",),
             "nolean": ("-DSSS_NO_LEAN",), "syncwg": ("-DSSS_SYNC_WORKGROUP",), "pair17": ("-DSSS_PAIR_MIN_E=17",), "w3": ("-DSSS_WAVES_PER_SIMD=3",), "w2": ("-DSSS_WAVES_PER_SIMD=2",), "oplane": ("-DSSS_OPAQUE_LANE",), "mlicm": ("-mllvm", "-disable-machine-licm=false"),
             # csrc/sss_rows.h: the atomic additions with 16 bytes per lane (A/B timing, tools/debug/rows_time.py)
             "vecatom": ("-DSSS_ROWS_VEC_ATOMICS=1",),
