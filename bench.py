@@ -94,12 +94,14 @@ print(json.dumps([steps, time.perf_counter() - t0]))
 """
 
 
-def reference_python_baseline(config: str):
+def reference_python_baseline(config: str, profile: str = "default"):
     """the reference Python env itself, timed in the BUILD CONTAINER by tools/time_reference.py (it cannot travel to the GPU box:
     /root/reference does not exist there) - the committed record profiles/reference_python.json, quoted with its hardware"""
     path = osp.join(ROOT, "profiles", "reference_python.json")
     try:
         rec = json.load(open(path))
+        if profile != "default":
+            rec = rec[profile]  # (the same measurement on another synthetic trace regime: tools/time_reference.py --deep)
         c = rec["configs"][{"c2": "c1", "c3": "c3"}[config]]  # (KeyError for other configs: no record)
         return {"value": c["one_core"]["env_only"], "unit": "env-steps/s", "cores": 1, "kind": "reference",
                 "all_cores": {"value": c["all_cores"]["env_only"], "processes": c["all_cores"]["processes"]},
@@ -170,6 +172,17 @@ def measured_traffic(kernel: str, config: str, envs: int, events_per_step: float
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (the pass computes in exact fp32)
+
+
+def binding_roofline(flops: float, hbm_bytes: float, seconds: float) -> dict:
+    """the roofline record of a pass that is priced both ways: algorithmic flops against the dense fp32 MFMA peak and algorithmic
+    HBM bytes against 8 TB/s - `bound` / `achieved` / `peak` / `frac` are those of the LARGER fraction (the roofline that binds),
+    the other one rides along"""
+    tf, gbs = flops / seconds / 1e12, hbm_bytes / seconds / 1e9
+    m = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+    h = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    first, second = (m, h) if m["frac"] >= h["frac"] else (h, m)
+    return dict(first, other_roofline=second)
 
 
 def reference_decima_baseline(key: str):
@@ -246,11 +259,10 @@ def decima_in_loop(cfg: dict, B: int, dev, pack, steps: int = 100, warmup: int =
     out = {"value": B * steps / dt, "unit": "env-steps/s", "envs": B, "ms_per_step": 1e3 * dt / steps, "steps": steps, "envs_in_error_state": err,
            "steady": {"value": B * steady_steps / dts, "ms_per_step": 1e3 * dts / steady_steps, "steps": steady_steps, "after_steps": steady_after,
                       "active_nodes_per_env": nodes / B, "decima_pass_ms": pass_ms, "sss_step_ms": step_ms},
-           "roofline": {"bound": "mfma", "kernel": "the Decima pass: sss_decima_graph_kernel + sss_gnn_*_mfma kernels + sss_decima_sample kernels (dominant: sss_gnn_layer_mfma_kernel, one launch per DAG layer)",
-                        "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "dtype": "f32",
-                        "flops_per_pass": cost["flops"], "mlp_rows_per_pass": cost["rows"], "avg_pass_ms": pass_ms, "passes_with_events": len(events),
-                        "hbm_bytes_per_pass_algorithmic": cost["bytes_inference"], "hbm_frac_if_it_were_the_bound": cost["bytes_inference"] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None},
+           "roofline": dict(binding_roofline(cost["flops"], cost["bytes_inference"], pass_ms * 1e-3),
+                            kernel="the Decima pass: sss_decima_graph_kernel + sss_gnn_*_mfma kernels + sss_decima_sample kernels (dominant: sss_gnn_layer_mfma_kernel, one launch per DAG layer)",
+                            dtype="f32", flops_per_pass=cost["flops"], mlp_rows_per_pass=cost["rows"], avg_pass_ms=pass_ms, passes_with_events=len(events),
+                            hbm_bytes_per_pass_algorithmic=cost["bytes_inference"], traffic=None),
            "what": "every env gets a sampled Decima action every step (graph + GNN + sampling kernels, then sss_step)"}
     if ref is not None:
         out["cpu_baseline"] = {"value": ref["env_steps_per_s"], "unit": "env-steps/s", "cores": 1, "kind": "reference", "sample": f"{ref['episodes']} episodes / {ref['steps']} steps: {ref['what']}",
@@ -305,11 +317,12 @@ def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
             mbs = int(learn.get("minibatches", train["num_epochs"] * train["num_batches"]))
             train_flops = 3.0 * cost["flops"] * mbs / train["num_batches"]
             train_bytes = cost["bytes_training"] * mbs / train["num_batches"]
-            rec["train_roofline"] = {"bound": "mfma", "kernel": "the PPO update: sss_mlp_mfma_{fwd,bwd,bwdw} / sss_mlp_head_mfma_* kernels + row gather / segment-sum kernels + autograd glue",
-                                     "achieved": train_flops / (t2 - t1) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": train_flops / (t2 - t1) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                     "dtype": "f32", "flops": train_flops, "flops_forward_whole_record": cost["flops"], "minibatches": mbs, "mlp_rows_whole_record": cost["rows"],
-                                     "hbm_bytes_algorithmic": train_bytes, "hbm_frac_if_it_were_the_bound": train_bytes / (t2 - t1) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                     "samples_x_epochs_per_s": n * mbs / train["num_batches"] / (t2 - t1)}
+            rec["train_roofline"] = dict(binding_roofline(train_flops, train_bytes, t2 - t1),
+                                         kernel="the PPO update: sss_mlp_mfma_{fwd,bwdw} / sss_mlp_head_mfma_* kernels + row gather / segment-sum kernels + autograd glue",
+                                         dtype="f32", flops=train_flops, flops_forward_whole_record=cost["flops"], minibatches=mbs, mlp_rows_whole_record=cost["rows"],
+                                         hbm_bytes_algorithmic=train_bytes, hbm_bytes_model="every MLP's activations stored once and read once, gradients of the same size: 12 B x (in + h1 + h2 + out) per row "
+                                         "(the GNN-shaped MLPs recompute theirs since round 6 and move less)", traffic=None,
+                                         samples_x_epochs_per_s=n * mbs / train["num_batches"] / (t2 - t1))
             rec["collect_roofline"] = {"bound": "mfma", "kernel": "the collection's Decima passes (one per step over the active envs)", "achieved": cost["flops"] / (t1 - t0) / 1e12,
                                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": cost["flops"] / (t1 - t0) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "flops": cost["flops"],
                                        "note": "the collection is latency-bound: ~7500 dependent steps of graph + GNN + sampling + sss_step launches over <= 1024 envs (DESIGN.md section 9.2)"}
@@ -523,6 +536,7 @@ class Bench:
 
 
 BOUNDED_EVENTS = {"c2": 48, "c3": 32, "c1": 48, "e100": 32}
+BOUNDED_EVENTS_DEEP = {"c2": 768, "c3": 768}  # the "deep" trace regime: ~530-630 events per step
 
 
 def bounded_record(bench: "Bench", args, config: str, steps: int, warmup: int):
@@ -531,7 +545,8 @@ def bounded_record(bench: "Bench", args, config: str, steps: int, warmup: int):
     next steps - the envs run at their own pace, as the reference's do in their worker processes. Env-steps per second of
     completed steps (per-env trajectories are the same bit for bit: tests/test_{emu,gpu}_bounded.py). NOT the headline `value`,
     which stays the lock-step one."""
-    budget = BOUNDED_EVENTS.get(config, 24) if args.bounded_events is None else args.bounded_events
+    table = BOUNDED_EVENTS_DEEP if getattr(bench, "pack_profile", "default") == "deep" else BOUNDED_EVENTS
+    budget = table.get(config, 24) if args.bounded_events is None else args.bounded_events
     if budget <= 0:
         return None
     saved = args.bounded_events
@@ -565,9 +580,15 @@ def deep_record(args, B: int, dev, rank: int, world: int) -> dict:
                    "fast_path_event_frac": r["fast_path_event_frac"], "batched_event_frac": r["batched_event_frac"], "roofline": r["roofline"],
                    "step_tail": b.step_tail(8), "fused": {"value": f["value"], "ms_per_step": f["ms_per_step"], "events_per_s": f["events_per_s"], "roofline": f["roofline"]},
                    "mean_last_episode_return": b.header_field("last_ep_return").mean().item(), "envs_in_error_state": int((b.shards[0].obs_i32[:, 7] != 0).sum())}
+            bd = bounded_record(b, args, config, k, w)
+            if bd is not None:
+                rec["bounded_launches"] = bd
             b.close()
             if not args.no_cpu_baseline:
                 rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS[config], DEFAULT_POLICY[config], min(4.0, args.cpu_budget / 2), "deep")
+                ref_py = reference_python_baseline(config, "deep")
+                if ref_py is not None:
+                    rec["cpu_baseline_reference_python"] = ref_py
             out[config] = rec
         except Exception as e:  # never let the extra record take the bench line down
             out[config] = {"error": repr(e)}
@@ -721,7 +742,7 @@ def main() -> None:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, policy, min(4.0, args.cpu_budget / 2), args.pack)
             except Exception as e:  # never let the extra baseline take the bench line down
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
-            ref_py = reference_python_baseline(args.config) if args.pack == "default" else None
+            ref_py = reference_python_baseline(args.config, args.pack)
             if ref_py is not None:
                 out["cpu_baseline_reference_python"] = ref_py
     pack = bench.pack
@@ -756,7 +777,7 @@ def main() -> None:
             if not args.no_cpu_baseline:
                 rec["cpu_baseline"] = cpu_baseline(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2), args.pack)
                 rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["c3"], "fair", min(4.0, args.cpu_budget / 2), args.pack)
-                ref_py = reference_python_baseline("c3") if args.pack == "default" else None
+                ref_py = reference_python_baseline("c3", args.pack)
                 if ref_py is not None:
                     rec["cpu_baseline_reference_python"] = ref_py
             out["c3"] = rec

@@ -33,6 +33,10 @@ CONFIGS = {
 }
 
 
+# the "deep" trace regime (workload.PROFILES): fewer, much longer episodes (hundreds of task completions per decision)
+DEEP_CONFIGS = {"c1": (CONFIGS["c1"][0], [0, 1]), "c3": (CONFIGS["c3"][0], [0])}
+
+
 def worker(config: str, seed_offset: int, data_dir: str) -> dict:
     """one process: the config's episodes, one after the other; times env.step alone, env + scheduler, and with reset"""
     sys.path.insert(0, ROOT)
@@ -43,7 +47,7 @@ def worker(config: str, seed_offset: int, data_dir: str) -> dict:
     from make_golden import import_reference
 
     gym, sched_cls, _ = import_reference()
-    env_cfg, seeds = CONFIGS[config]
+    env_cfg, seeds = (DEEP_CONFIGS if os.environ.get("SSS_TRACE_PROFILE") == "deep" else CONFIGS)[config]
     t_step = t_sched = t_reset = 0.0
     steps = 0
     for seed in seeds:
@@ -85,12 +89,15 @@ def main() -> None:
     sys.path.insert(0, ROOT)
     from spark_sched_sim_amd import workload
 
+    profile = "deep" if "--deep" in sys.argv else "default"
+    if profile == "deep":  # a second record next to the default one: profiles/reference_python.json "deep"
+        os.environ["SSS_TRACE_PROFILE"] = "deep"
     n_proc = len(os.sched_getaffinity(0))
     out = {"what": "the reference Python env (spark_sched_sim/spark_sched_sim.py, imported unmodified) with its fair scheduler on the build's "
                    "frozen synthetic trace set; loop of examples.py:84-102; time.perf_counter around env.step / scheduler.schedule / env.reset",
            "hardware": f"build container: {cpu_model()}, {n_proc} vCPU (not the GPU box's host)", "python": platform.python_version(),
            "unit": "env-steps/s", "configs": {}}
-    raw = workload.make_raw_workload()
+    raw = workload.make_raw_workload(profile=profile)
     out["pack_sha256"] = workload.pack_digest(workload.build_pack(raw))
     with tempfile.TemporaryDirectory() as tmp:
         workload.write_reference_layout(raw, tmp)
@@ -117,6 +124,16 @@ def main() -> None:
             out["configs"][config] = rec
             print(config, json.dumps(rec), flush=True)
     path = osp.join(ROOT, "profiles", "reference_python.json")
+    if profile == "deep":
+        whole = json.load(open(path))
+        whole["deep"] = dict(out, trace_profile="deep")
+        out = whole
+    else:
+        try:  # keep the records other tools added (tools/time_reference_decima.py, --deep)
+            old = json.load(open(path))
+            out.update({k: v for k, v in old.items() if k in ("decima_c1", "ppo_config5", "deep")})
+        except Exception:
+            pass
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 
