@@ -536,7 +536,9 @@ class Bench:
 
 
 BOUNDED_EVENTS = {"c2": 48, "c3": 32, "c1": 48, "e100": 32}
-BOUNDED_EVENTS_DEEP = {"c2": 768, "c3": 768}  # the "deep" trace regime: ~530-630 events per step
+# the "deep" trace regime: ~530-630 events per step; swept 768 .. 4096 (profiles/r06_bench.md section 2): a budget only cuts between
+# event-loop rounds and a round is a run of hundreds of events there - at best equal to lock-step
+BOUNDED_EVENTS_DEEP = {"c2": 2048, "c3": 2048}
 
 
 def bounded_record(bench: "Bench", args, config: str, steps: int, warmup: int):
