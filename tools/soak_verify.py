@@ -33,6 +33,13 @@ CASES = [
     ("e128_hash0_wide", dict(num_executors=128, job_arrival_cap=60, job_arrival_rate=2.0e-4, moving_delay=500.0, warmup_delay=100.0), "hash", 1, 10000),
     ("e65_fair_wide", dict(num_executors=65, job_arrival_cap=100, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 12000),
     ("e90_zero_delays_hash0_wide", dict(num_executors=90, job_arrival_cap=80, job_arrival_rate=1.5e-4, moving_delay=0.0, warmup_delay=0.0), "hash", 1, 10000),
+    # round 6: the "deep" trace set (a sixth element names the pack profile) - fast runs over jobs without a cache slot (more jobs with pending
+    # events than LDS slots), 32-bit task counters in the thousands, both instantiations
+    ("deep_c2_hash0", dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "hash", 1, 6000, "deep"),
+    ("deep_c3_fair", dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 12000, "deep"),
+    ("deep_e50_burst_hash0", dict(num_executors=50, job_arrival_cap=60, job_arrival_rate=1.0e-3, moving_delay=500.0, warmup_delay=100.0), "hash", 1, 6000, "deep"),
+    ("deep_e100_fair_wide", dict(num_executors=100, job_arrival_cap=80, job_arrival_rate=2.0e-4, moving_delay=2000.0, warmup_delay=1000.0), "fair", 0, 5000, "deep"),
+    ("deep_e128_burst_hash0_wide", dict(num_executors=128, job_arrival_cap=60, job_arrival_rate=1.0e-3, moving_delay=500.0, warmup_delay=100.0), "hash", 1, 4000, "deep"),
 ]
 
 
@@ -43,11 +50,11 @@ def bits(x):
 def main():
     stride = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # every stride-th env is replayed on the oracle (usage: soak_verify.py [stride] [case name part])
     only = sys.argv[2] if len(sys.argv) > 2 else ""
-    pack = workload.default_pack()
     B, base = 4096, 777
-    for name, cfg, policy, pid, steps in CASES:
+    for name, cfg, policy, pid, steps, *rest in CASES:
         if only not in name:
             continue
+        pack = workload.profile_pack(rest[0] if rest else "default")
         env = VecSparkSchedSimEnv(cfg, B, device="cuda:0", pack=pack, auto_reset=True)
         env.reset(seed=base)
         for _ in range(steps // 1000):
