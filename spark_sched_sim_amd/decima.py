@@ -267,12 +267,27 @@ def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, A
         r = [ranges(g[k]) for k in ("node_obs", "job_obs", "edge_obs")]
         cache = g["_ranges"] = r if all(x is not None for x in r) else False
     if cache:
+        # Members of an observation are a RANGE of the arena's rows, so ids can be re-labelled by arithmetic on minibatch-sized
+        # arrays: member m of observation o (new id o') that sat at arena row r sits at new row r - first_old[o] + first_new[o'].
+        # (The general form below builds arena-sized look-up tables per minibatch - 211 M + 32 M entries at BASELINE config 5, 2 GB
+        # written and then read through at random for every minibatch.)
+        k = obs_idx.numel()
+
         def cut(cnt_off):
             cnt, off = cnt_off[0][obs_idx], cnt_off[1][obs_idx]
             total = int(cnt.sum())
-            start = torch.repeat_interleave(off - (torch.cumsum(cnt, 0) - cnt), cnt, output_size=total)
-            return start + torch.arange(total, device=dev)
-        kn, kj, ke = cut(cache[0]), cut(cache[1]), cut(cache[2])
+            first_new = torch.cumsum(cnt, 0) - cnt
+            which = torch.repeat_interleave(torch.arange(k, device=dev), cnt, output_size=total)  # new observation id of every member
+            shift = off - first_new                                                              # old row - new row, per observation
+            return shift[which] + torch.arange(total, device=dev), which, shift
+        (kn, wn, sn), (kj, wj, sj), (ke, we, _) = cut(cache[0]), cut(cache[1]), cut(cache[2])
+        T = _take
+        return {"x": T(g["x"], kn), "node_obs": wn, "node_loc": T(g["node_loc"], kn), "node_job": T(g["node_job"], kn) - sj[wn],
+                "gen": T(g["gen"], kn), "stage_mask": g["stage_mask"][kn], "sched_rank": T(g["sched_rank"], kn), "n_pad": g["n_pad"],
+                "src": T(g["src"], ke) - sn[we], "dst": T(g["dst"], ke) - sn[we], "edge_obs": we,
+                "job_obs": wj, "job_cap": T(g["job_cap"], kj), "job_first": T(g["job_first"], kj) - sn[wj],
+                "n_obs": int(k), "obs_nodes": g["obs_nodes"][obs_idx], "obs_jobs": g["obs_jobs"][obs_idx], "obs_depth": g["obs_depth"][obs_idx],
+                **({"edge_layers": T(g["edge_layers"], ke), "node_recv": T(g["node_recv"], kn)} if "edge_layers" in g else {})}
     else:
         kn, kj, ke = pick(g["node_obs"]), pick(g["job_obs"]), pick(g["edge_obs"])
     node_new = torch.full((g["x"].shape[0],), -1, dtype=torch.long, device=dev)

@@ -387,3 +387,34 @@ def test_sum_order_of_the_baseline_mean_is_numpys():
             M = rng.standard_normal((R, 13)) * 10.0 ** rng.integers(-3, 6)
             for col in M.T[:4]:
                 assert np.float64(numpy_sum_order([np.float64(v) for v in col])) / R == col.mean(), R
+
+
+def test_minibatch_cut_by_ranges_equals_the_general_cut():
+    """decima.select_observations: a record stored observation by observation is cut by ranges with arithmetic re-labelling (round 6)
+    - the same sub-graph, field by field, as the general form (arena-sized look-up tables), for selections in any order"""
+    import torch
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd import VecSparkSchedSimEnv
+    from spark_sched_sim_amd.decima import concat_graphs, select_observations
+
+    cfg = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 6, device="cpu", auto_reset=True, _lib=load_emu())
+    env.reset(seed=30)
+    graphs = []
+    for _ in range(5):
+        env.rollout("fair", 37)
+        graphs.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in env.decima_graph().items() if not k.startswith("_")})
+    g = concat_graphs(graphs)
+    gen = torch.Generator().manual_seed(3)
+    for n in (1, 7, g["n_obs"]):
+        idx = torch.randperm(g["n_obs"], generator=gen)[:n]
+        a = select_observations(dict(g), idx)                       # ranges (checked once per graph, cached in the dict)
+        b = select_observations(dict(g, _ranges=False), idx)        # the general form
+        assert set(a) == set(b)
+        for k in a:
+            if isinstance(a[k], torch.Tensor):
+                assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k], k
+    env.close()
