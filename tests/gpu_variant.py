@@ -25,6 +25,7 @@ VARIANTS = {"vecforms": ("-DSSS_TEST_VECTOR_FORMS",),
             # csrc/sss_rows.h: the atomic additions with 16 bytes per lane (A/B timing, tools/debug/rows_time.py)
             "vecatom": ("-DSSS_ROWS_VEC_ATOMICS=1",),
             # job-cache slots at large job capacities (csrc/sss_layout.h; A/B timing at small env counts, profiles/r04_bench.md section 9)
+            "slots6": ("-DSSS_FALLBACK_SLOTS=6",), "slots8": ("-DSSS_FALLBACK_SLOTS=8",),
             "slots16": ("-DSSS_FALLBACK_SLOTS=16",), "slots24": ("-DSSS_FALLBACK_SLOTS=24",), "slots32": ("-DSSS_FALLBACK_SLOTS=32",), "slots48": ("-DSSS_FALLBACK_SLOTS=48",)}
 
 
