@@ -286,8 +286,11 @@ def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
                  num_batches=10, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3, opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4),
                  max_grad_norm=0.5, artifacts_dir="/tmp/sss_ppo_bench")
     env = dict(num_executors=50, job_arrival_cap=200, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
+    base_alloc = torch.cuda.memory_allocated(dev)  # (what the earlier legs of this bench run still hold: not this record's)
     tr = Trainer(agent, env, train, device=str(dev))
     rec = None
     for it in range(2):
@@ -335,6 +338,10 @@ def ppo_config5_share(dev, sequences: int = 256, rollouts: int = 4) -> dict:
         del ro
     rec["peak_memory_allocated_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
     rec["peak_memory_reserved_gb"] = torch.cuda.max_memory_reserved(dev) / 1e9
+    rec["allocated_before_this_record_gb"] = base_alloc / 1e9
+    rec["peak_memory_allocated_by_this_record_gb"] = (torch.cuda.max_memory_allocated(dev) - base_alloc) / 1e9
+    rec["memory_note"] = ("peaks over both iterations incl. this record's own accounting pass over the whole record (algorithmic_cost); per phase "
+                          "(tools/debug/ppo_memory_phases.py, a process of its own): ~31 GB while collecting, ~50 GB while updating")
     rec["what"] = ("one rank's share of BASELINE config 5 (PPO, decima_tpch.yaml): whole episodes of 1024 envs under sampled Decima actions, then 3 epochs x 10 "
                    "minibatches; second of two iterations")
     tr.close()
