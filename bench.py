@@ -756,6 +756,7 @@ def main() -> None:
                 out["cpu_baseline_reference_python"] = ref_py
     pack = bench.pack
     bench.close()
+    del bench  # (the env's arenas are torch tensors: dropped with the last reference, not by close())
 
     # BASELINE config 3 next to the headline (N = 1): same measurements, its own roofline and CPU baseline
     if world == 1 and args.config == "c2" and not args.no_deep and args.shards == 1 and args.pack == "default":
@@ -781,6 +782,7 @@ def main() -> None:
             if bd3 is not None:
                 rec["bounded_launches"] = bd3
             b3.close()
+            del b3
             if s3 is not None:
                 rec["sustained"] = s3
             if not args.no_cpu_baseline:
@@ -807,6 +809,7 @@ def main() -> None:
                                      "batched_event_frac": re_["batched_event_frac"], "roofline": re_["roofline"], "step_tail": be.step_tail(8),
                                      "fused": {"value": fe["value"], "ms_per_step": fe["ms_per_step"]}}
                 be.close()
+                del be
             if not args.no_cpu_baseline:
                 rec["cpu_baseline_all_cores"] = cpu_baseline_all_cores(CONFIGS["e100"], "fair", min(4.0, args.cpu_budget / 2))
             out["e100"] = rec
