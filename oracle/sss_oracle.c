@@ -8,7 +8,7 @@
  * Python containers the trajectory depends on modelled explicitly: `set` (pyset.h), insertion
  * ordered `dict` (small vectors), `heapq` (binary heap on the unique (t, counter) key) and the
  * numpy Generator stream (np_random.h). Pinned against trajectories recorded from the reference
- * itself: tests/golden/*.npz via tests/test_oracle_golden.py.
+ * itself: tests/golden/<set>.npz via tests/test_oracle_golden.py.
  *
  * Citations "ENV:n" = reference spark_sched_sim/spark_sched_sim.py line n, "TRK:n" =
  * components/executor_tracker.py, "JOB:n" = components/job.py, "STG:n" = components/stage.py,
