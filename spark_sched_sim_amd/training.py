@@ -129,8 +129,8 @@ class GraphArena:
             return
         sync()
         for k in short():
-            # (x 1.3, not x 2: at BASELINE config 5 the record is ~25 GB per rank - a doubled arena held up to 50 GB for it, which
-            # was the peak of the whole PPO iteration's memory; a growth step is one device copy of the arrays of that kind, ~10 ms)
+            # (x 1.3, not x 2: at BASELINE config 5 the record is ~21 GB per rank and a doubled arena can hold twice that during a first
+            # collection; a growth step is one device copy of the arrays of that kind, ~10 ms)
             new_cap = max(int(1.3 * self.capacity[k]), self.seen[k] + 8 * self.step_max[k])
             for name, dt, per, kind, _ in self.ARRAYS:
                 if kind == k:
