@@ -88,6 +88,9 @@ SETS = {
     "deep_e50_hash": (dict(C3, job_arrival_cap=60), "hash", [1], None, DEEP),
     "deep_e100_fair": (E100, "fair", [0], None, DEEP),
     "deep_e100_hash": (E100, "hash", [1], None, DEEP),
+    # ... with discounted rewards, and bounded by a time limit instead of a job cap (episodes end in the middle of long stages)
+    "deep_c1_fair_beta": (dict(C1, job_arrival_cap=20, beta=5.0e-3), "fair", [4], None, DEEP),
+    "deep_tlimit_hash": (dict(C1, job_arrival_cap=None, job_arrival_rate=2.0e-6), "hash", [5, 6], {"time_limit": 2.0e7}, DEEP),
 }
 
 

@@ -9,7 +9,8 @@ GOLDEN_DIR = osp.join(osp.dirname(osp.abspath(__file__)), "golden")
 ALL_SETS = ["tiny_hash", "tiny_fair_tlimit", "c1_fair", "c1_hash", "c1_fifo", "c3_fair", "c3_hash",
             "testyaml_fair", "bige_hash", "e100_fair", "e100_hash", "e120_hash", "q5s2_fair", "q5s2_hash"]
 # recorded on the "deep" trace regime (workload.PROFILES["deep"], a 60 MB pack)
-DEEP_SETS = ["deep_c1_fair", "deep_c1_hash", "deep_c1_fifo", "deep_e50_fair", "deep_e50_hash", "deep_e100_fair", "deep_e100_hash"]
+DEEP_SETS = ["deep_c1_fair", "deep_c1_hash", "deep_c1_fifo", "deep_e50_fair", "deep_e50_hash", "deep_e100_fair", "deep_e100_hash",
+             "deep_tlimit_hash", "deep_c1_fair_beta"]
 
 
 _PACKS: dict = {}

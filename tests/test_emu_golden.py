@@ -31,12 +31,18 @@ CASES = [
     ("deep_e50_hash", [1], 150),
     ("deep_e100_fair", [0], 150),
     ("deep_e100_hash", [1], 150),
+    ("deep_tlimit_hash", [5, 6], None),   # a time limit instead of a job cap: truncated in the middle of long stages
 ]
 
 
 @pytest.mark.parametrize("name,seeds,max_steps", CASES)
 def test_kernel_source_matches_reference_under_emulation(name, seeds, max_steps, pack):
     bad = replay_golden(name, seeds, pack, device="cpu", lib=load_emu(), full_obs_steps=10, max_steps=max_steps)
+    assert not bad, "\n".join(bad[:10])
+
+
+def test_discounted_rewards_beta_on_the_deep_trace_set(pack):
+    bad = replay_golden("deep_c1_fair_beta", [4], pack, device="cpu", lib=load_emu(), reward_rtol=1e-12, max_steps=120)
     assert not bad, "\n".join(bad[:10])
 
 

@@ -31,6 +31,7 @@ CASES = [
     ("deep_e50_hash", [1], None),
     ("deep_e100_fair", [0], None),
     ("deep_e100_hash", [1], None),
+    ("deep_tlimit_hash", [5, 6], None),
 ]
 
 
@@ -50,6 +51,11 @@ def test_hip_library_is_the_one_loaded():
 @pytest.mark.parametrize("name,seeds,max_steps", CASES)
 def test_hip_matches_reference_golden(name, seeds, max_steps, pack):
     bad = replay_golden(name, seeds, pack, device="cuda:0", full_obs_steps=40, max_steps=max_steps)
+    assert not bad, "\n".join(bad[:10])
+
+
+def test_hip_discounted_rewards_beta_on_the_deep_trace_set(pack):
+    bad = replay_golden("deep_c1_fair_beta", [4], pack, device="cuda:0", reward_rtol=1e-12)
     assert not bad, "\n".join(bad[:10])
 
 
