@@ -245,8 +245,7 @@ def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, A
     re-labelled - a PPO minibatch out of a `GraphArena`"""
     dev = g["x"].device
     n_obs = g["n_obs"]
-    new_of_old = torch.full((n_obs,), -1, dtype=torch.long, device=dev)
-    new_of_old[obs_idx] = torch.arange(obs_idx.numel(), device=dev)
+    new_of_old = None  # (the general form's look-up table, built below when it is needed)
 
     def pick(owner):  # members of the selected observations, grouped by new observation id (stable)
         new_owner = new_of_old[owner]
@@ -289,6 +288,8 @@ def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, A
                 "n_obs": int(k), "obs_nodes": g["obs_nodes"][obs_idx], "obs_jobs": g["obs_jobs"][obs_idx], "obs_depth": g["obs_depth"][obs_idx],
                 **({"edge_layers": T(g["edge_layers"], ke), "node_recv": T(g["node_recv"], kn)} if "edge_layers" in g else {})}
     else:
+        new_of_old = torch.full((n_obs,), -1, dtype=torch.long, device=dev)
+        new_of_old[obs_idx] = torch.arange(obs_idx.numel(), device=dev)
         kn, kj, ke = pick(g["node_obs"]), pick(g["job_obs"]), pick(g["edge_obs"])
     node_new = torch.full((g["x"].shape[0],), -1, dtype=torch.long, device=dev)
     node_new[kn] = torch.arange(kn.numel(), device=dev)
