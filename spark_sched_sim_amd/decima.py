@@ -258,12 +258,18 @@ def select_observations(g: dict[str, Any], obs_idx: torch.Tensor) -> dict[str, A
     # arena is 211 M nodes and a minibatch 2.5 M, and `pick` reads the whole arena three times per minibatch.
     cache = g.get("_ranges")
     if cache is None:
-        def ranges(owner):
-            if owner.numel() > 1 and not bool((owner[1:] >= owner[:-1]).all()):
+        # (`_by_observation`: the graph says of itself that its members are stored observation by observation - a GraphArena's
+        # record is, by construction - and its per-observation node / job counts are its own `obs_nodes` / `obs_jobs`: no pass over
+        # the 211 M node ids of a config-5 record to find that out)
+        known = bool(g.get("_by_observation"))
+
+        def ranges(owner, cnt=None):
+            if not known and owner.numel() > 1 and not bool((owner[1:] >= owner[:-1]).all()):
                 return None
-            cnt = torch.bincount(owner, minlength=n_obs)
+            if cnt is None:
+                cnt = torch.bincount(owner, minlength=n_obs)
             return cnt, torch.cumsum(cnt, 0) - cnt
-        r = [ranges(g[k]) for k in ("node_obs", "job_obs", "edge_obs")]
+        r = [ranges(g["node_obs"], g["obs_nodes"] if known else None), ranges(g["job_obs"], g["obs_jobs"] if known else None), ranges(g["edge_obs"])]
         cache = g["_ranges"] = r if all(x is not None for x in r) else False
     if cache:
         # Members of an observation are a RANGE of the arena's rows, so ids can be re-labelled by arithmetic on minibatch-sized

@@ -166,6 +166,7 @@ class GraphArena:
         out: dict[str, Any] = {name: self.buf[name][: sizes[kind]] for name, _, _, kind, _ in self.ARRAYS}
         out["gen"] = out["gen"].long()
         out["n_obs"], out["n_pad"] = n_steps * self.B, self.env.dims.node_cap
+        out["_by_observation"] = True  # (appended step by step, env by env: decima.select_observations cuts such a record by ranges)
         return out
 
 
