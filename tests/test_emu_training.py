@@ -62,6 +62,28 @@ def test_trainer_iteration_at_100_executors(tmp_path):
     tr.close()
 
 
+def test_trainer_iteration_on_the_deep_trace_set(tmp_path):
+    """the trainer on the second trace regime (workload.PROFILES["deep"]: jobs of up to 40 stages and 12 DAG layers - more stage slots
+    per job than the graph kernel's old limit of 24, which now is the templates' DAG depth): one iteration through the device-side
+    record, parameters move"""
+    import torch
+
+    from decima_util import AGENT
+    from spark_sched_sim_amd import workload
+    from spark_sched_sim_amd.training import Trainer
+
+    env = dict(num_executors=10, job_arrival_cap=4, job_arrival_rate=1.0e-4, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=6.0e5)
+    tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), env, dict(TRAIN, num_iterations=1, artifacts_dir=str(tmp_path)), device="cpu", _lib=load_emu(),
+                 pack=workload.profile_pack("deep"))
+    assert tr.env.graph_kernel_fits and tr.env.dims.stage_stride > 24
+    before = {k: v.clone() for k, v in tr.policy.state_dict().items()}
+    hist = tr.train(verbose=False)
+    assert len(hist) == 1 and hist[0]["samples"] > 0 and hist[0]["env_errors"] == 0
+    assert torch.isfinite(torch.tensor([hist[0]["policy loss"], hist[0]["entropy"], hist[0]["approx kl div"]])).all()
+    assert any(not torch.equal(v, before[k]) for k, v in tr.policy.state_dict().items())
+    tr.close()
+
+
 def test_train(tmp_path):
     """the reference's one integration test (reference test/test_train.py:5-7): load the YAML,
     `make_trainer(cfg).train()`, pass if nothing raises - same configuration, on the batched env"""
