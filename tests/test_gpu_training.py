@@ -66,12 +66,12 @@ def test_trainer_iteration_on_the_deep_trace_set_gpu(tmp_path):
     train = dict(trainer_cls="PPO", num_iterations=1, num_sequences=8, num_rollouts=4, seed=11, checkpointing_freq=50,
                  num_epochs=2, num_batches=4, clip_range=0.2, target_kl=0.01, entropy_coeff=0.04, beta_discount=5.0e-3,
                  opt_cls="Adam", opt_kwargs=dict(lr=3.0e-4), max_grad_norm=0.5, artifacts_dir=str(tmp_path))
-    env = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=4.0e6)
+    env = dict(num_executors=10, job_arrival_cap=20, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0, mean_time_limit=2.0e7)
     tr = Trainer(dict(AGENT, agent_cls="DecimaScheduler"), env, train, device="cuda:0", pack=workload.profile_pack("deep"))
     assert tr.env.graph_kernel_fits and tr.env.dims.stage_stride > 24
     before = {k: v.clone() for k, v in tr.policy.state_dict().items()}
     hist = tr.train(verbose=False)
-    assert len(hist) == 1 and hist[0]["samples"] > 1000
+    assert len(hist) == 1 and hist[0]["samples"] > 200
     assert torch.isfinite(torch.tensor([hist[0]["policy loss"], hist[0]["entropy"], hist[0]["approx kl div"]])).all()
     assert any(not torch.equal(v, before[k]) for k, v in tr.policy.state_dict().items())
     tr.close()
