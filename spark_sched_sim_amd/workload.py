@@ -168,7 +168,7 @@ def make_raw_workload(seed: int = DEFAULT_SEED, query_sizes: list[str] | None = 
     """-> {(size, query_num): (adj_mat int64[S,S], {stage: {wave: {level: [int]}}})}; by default the reference's grid of
     7 sizes x 22 queries (the frozen set the fixtures were recorded on); other grids for tests of other trace-set shapes;
     `profile`: the regime of DAG shapes / task counts / durations (PROFILES)"""
-    prof = PROFILES[profile]
+    prof = PROFILES[profile] if isinstance(profile, str) else dict(profile)  # (a dict: generator parameters of one's own, e.g. the tests' random regimes)
     rng = np.random.default_rng(seed)
     raw: dict[tuple[str, int], tuple[np.ndarray, dict]] = {}
     query_sizes = list(QUERY_SIZES) if query_sizes is None else list(query_sizes)

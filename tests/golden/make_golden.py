@@ -217,7 +217,32 @@ def run_episode(gym, metrics, env_cfg, policy, seed, options, sched_cls, sizes=t
     return out
 
 
+def random_regime(seed: int):
+    """a trace-set regime, env configuration and policy drawn from `seed`: generator parameters far from the two committed profiles
+    (tests/test_oracle_vs_live_reference.py: the oracle against the reference itself on regimes nobody looked at)"""
+    rng = np.random.default_rng(1000 + seed)
+    lo = int(rng.integers(2, 5))
+    levels_all = [2, 5, 10, 20, 40, 50, 60, 80, 100]
+    keep = sorted(rng.choice(len(levels_all), size=int(rng.integers(3, len(levels_all) + 1)), replace=False).tolist())
+    prof = dict(stages=(lo, int(rng.integers(lo + 2, 31))), max_in=int(rng.integers(1, 6)), parent_window=[None, 2, 4, 8][int(rng.integers(0, 4))],
+                tasks=(1, int(rng.integers(3, 60))), tasks_div=int(rng.integers(1, 4)), base=(int(rng.integers(20, 100)), int(rng.integers(500, 20000))),
+                levels=[levels_all[i] for i in keep])
+    cfg = dict(num_executors=int(rng.choice([3, 5, 8, 10, 16, 24, 37, 50, 64, 65, 100, 128])), job_arrival_cap=int(rng.integers(4, 11)), job_arrival_rate=float(10 ** rng.uniform(-4.3, -3.3)),
+               moving_delay=float(rng.choice([0.0, 500.0, 2000.0])), warmup_delay=float(rng.choice([0.0, 300.0, 1000.0])), data_sampler_cls="TPCHDataSampler")
+    policy = ["fair", "hash", "fifo"][int(rng.integers(0, 3))]
+    shape = (["2g", "10g", "100g"], 4, 9000 + seed, prof)
+    return cfg, policy, [int(rng.integers(0, 1000))], shape
+
+
 def main(argv):
+    if argv and argv[0] == "--random":  # python make_golden.py --random SEED OUT.npz
+        seed, out_path = int(argv[1]), argv[2]
+        SETS["random"] = (*random_regime(seed)[:3], None, random_regime(seed)[3])
+        global HERE
+        HERE, argv = osp.dirname(osp.abspath(out_path)), ["random"]
+        main(argv)
+        os.replace(osp.join(HERE, "random.npz"), out_path)
+        return
     names = argv or list(SETS)
     cwd0 = os.getcwd()
     gym = sched_cls = metrics = None
@@ -254,7 +279,10 @@ def main(argv):
         blob["pack_sha256"] = np.asarray(workload.pack_digest(pack))
         if shape:  # what tests/golden_util.py needs to rebuild the set's pack
             blob["trace_sizes"], blob["trace_queries"], blob["trace_seed"] = np.asarray(sizes), np.int64(n_queries), np.int64(raw_seed)
-            if profile != "default":
+            if isinstance(profile, dict):
+                import json
+                blob["trace_profile_json"] = np.asarray(json.dumps(profile))
+            elif profile != "default":
                 blob["trace_profile"] = np.asarray(profile)
         blob["cfg_keys"] = np.asarray(sorted(k for k in env_cfg if k != "data_sampler_cls"))
         blob["cfg_vals"] = np.asarray(

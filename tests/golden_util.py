@@ -17,9 +17,9 @@ _PACKS: dict = {}
 
 
 class Golden:
-    def __init__(self, name: str):
+    def __init__(self, name: str, path: str | None = None):
         self.name = name
-        self.z = np.load(osp.join(GOLDEN_DIR, f"{name}.npz"))
+        self.z = np.load(path if path is not None else osp.join(GOLDEN_DIR, f"{name}.npz"))
         keys = self.z["cfg_keys"].tolist()
         vals = self.z["cfg_vals"].tolist()
         self.cfg = {}
@@ -39,6 +39,12 @@ class Golden:
         if "trace_sizes" not in self.z:
             return default
         from spark_sched_sim_amd import workload
+        if "trace_profile_json" in self.z:  # generator parameters of the set's own (tests/test_oracle_vs_live_reference.py)
+            import json
+            prof = json.loads(str(self.z["trace_profile_json"]))
+            prof = {k: (tuple(v) if isinstance(v, list) and k != "levels" else v) for k, v in prof.items()}
+            sizes, n_q, seed = [str(x) for x in self.z["trace_sizes"]], int(self.z["trace_queries"]), int(self.z["trace_seed"])
+            return workload.build_pack(workload.make_raw_workload(seed, sizes, n_q, profile=prof), query_sizes=sizes, num_queries=n_q)
         profile = str(self.z["trace_profile"]) if "trace_profile" in self.z else "default"
         key = (tuple(str(x) for x in self.z["trace_sizes"]), int(self.z["trace_queries"]), int(self.z["trace_seed"]), profile)
         if key not in _PACKS:
