@@ -15,8 +15,8 @@ AGENT = dict(embed_dim=16,
 SCORE_ATOL = 2e-5
 
 
-def check_decima_fixture(name, device, lib, n_steps):
-    g = np.load(osp.join(HERE, "golden", f"{name}.npz"))
+def check_decima_fixture(name, device, lib, n_steps, path=None):
+    g = np.load(path if path is not None else osp.join(HERE, "golden", f"{name}.npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
     cfg["num_executors"] = int(cfg["num_executors"])
     cfg["job_arrival_cap"] = int(cfg["job_arrival_cap"])
@@ -24,6 +24,11 @@ def check_decima_fixture(name, device, lib, n_steps):
     E = cfg["num_executors"]
     from spark_sched_sim_amd import workload
     pack = workload.profile_pack(str(g["trace_profile"])) if "trace_profile" in g.files else None  # (None: the frozen default pack)
+    if "trace_profile_json" in g.files:  # a regime of the fixture's own (tests/test_oracle_vs_live_reference.py)
+        import json
+        sizes, n_q = [str(x) for x in g["trace_sizes"]], int(g["trace_queries"])
+        pack = workload.build_pack(workload.make_raw_workload(int(g["trace_seed"]), sizes, n_q, profile=json.loads(str(g["trace_profile_json"]))),
+                                   query_sizes=sizes, num_queries=n_q)
     env = VecSparkSchedSimEnv(cfg, len(seeds), device=device, _lib=lib, pack=pack)
     dev = env.device
     policy = DecimaPolicy(num_executors=E, **AGENT)

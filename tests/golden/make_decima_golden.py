@@ -53,6 +53,22 @@ AGENT = dict(embed_dim=16,
 
 def main(argv):
     cwd0 = os.getcwd()
+    if argv and argv[0] == "--random":  # python make_decima_golden.py --random SEED OUT.npz (tests/test_oracle_vs_live_reference.py)
+        global STEPS, HERE
+        seed, out_path = int(argv[1]), osp.abspath(argv[2])
+        sys.path.insert(0, HERE)
+        from make_golden import random_regime
+        cfg, _, seeds, (sizes, n_q, raw_seed, prof) = random_regime(seed)
+        CFGS.clear()
+        CFGS["random"] = (cfg, seeds, ("random", sizes, n_q, raw_seed, prof))
+        STEPS, HERE = 40, osp.dirname(out_path)
+        with tempfile.TemporaryDirectory() as tmp:
+            try:
+                record(["random"], CFGS["random"][2], tmp)
+            finally:
+                os.chdir(cwd0)
+        os.replace(osp.join(HERE, "random.npz"), out_path)
+        return
     for profile in sorted({(c[2] if len(c) > 2 else "default") for c in CFGS.values()}):
         names = [n for n, c in CFGS.items() if (c[2] if len(c) > 2 else "default") == profile and (not argv or n in argv)]
         if names:
@@ -64,12 +80,20 @@ def main(argv):
 
 
 def record(names, profile, tmp):
-    raw = workload.make_raw_workload(profile=profile)
+    shape = None
+    if isinstance(profile, tuple):  # ("random", sizes, number of queries, generator seed, generator parameters)
+        _, sizes, n_q, raw_seed, prof = profile
+        raw, shape = workload.make_raw_workload(raw_seed, sizes, n_q, profile=prof), (sizes, n_q, raw_seed, prof)
+    else:
+        raw = workload.make_raw_workload(profile=profile)
     if True:
         workload.write_reference_layout(raw, tmp)
         os.chdir(tmp)  # the reference reads data/tpch relative to cwd (tpch.py:48,119)
         import gymnasium as gym
         import spark_sched_sim  # noqa: F401
+        if shape is not None:  # (a trace set of another shape: the sampler's two module constants, tpch.py:14-15)
+            from spark_sched_sim.data_samplers import tpch
+            tpch.QUERY_SIZES, tpch.NUM_QUERIES = list(shape[0]), shape[1]
         from schedulers.decima import utils as dutils
         from schedulers.decima.env_wrapper import DecimaEnvWrapper
         from schedulers.decima.scheduler import DecimaScheduler
@@ -86,7 +110,11 @@ def record(names, profile, tmp):
             sched.eval()
             blob = {f"w_{k}": v.numpy() for k, v in sched.state_dict().items()}
             blob["seeds"] = np.asarray(seeds)
-            if profile != "default":
+            if shape is not None:
+                import json
+                blob["trace_sizes"], blob["trace_queries"], blob["trace_seed"] = np.asarray(shape[0]), np.int64(shape[1]), np.int64(shape[2])
+                blob["trace_profile_json"] = np.asarray(json.dumps(shape[3]))
+            elif profile != "default":
                 blob["trace_profile"] = np.asarray(profile)
             blob["cfg_keys"] = np.asarray(sorted(k for k in env_cfg if k != "data_sampler_cls"))
             blob["cfg_vals"] = np.asarray([float(env_cfg[k]) for k in sorted(env_cfg) if k != "data_sampler_cls"])

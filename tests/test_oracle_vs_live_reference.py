@@ -51,3 +51,17 @@ def test_oracle_and_kernel_source_match_the_live_reference_on_a_random_regime(se
         golden_util.Golden = keep
         replay_util.Golden = keep
     assert not bad, "\n".join(bad[:8])
+
+
+@pytest.mark.parametrize("seed", [1, 4, 8])
+def test_decima_features_and_scores_match_the_live_reference_on_a_random_regime(seed, tmp_path):
+    """the same for SURVEY 8(f) next-1: the reference's own DecimaEnvWrapper / DecimaScheduler (functional PyG stand-ins) record 40 steps
+    on a random regime; node features, masks, DAG-layer edge masks identical, scores within 2e-5, graph kernel == tensor-op graph"""
+    from decima_util import check_decima_fixture
+    from emu_util import load_emu
+
+    out = str(tmp_path / f"decima_random_{seed}.npz")
+    res = subprocess.run([sys.executable, osp.join(HERE, "golden", "make_decima_golden.py"), "--random", str(seed), out], capture_output=True, text=True,
+                         timeout=900, cwd=str(tmp_path))
+    assert res.returncode == 0 and osp.exists(out), res.stdout[-1500:] + res.stderr[-3000:]
+    check_decima_fixture("random", "cpu", load_emu(), 40, path=out)
