@@ -533,12 +533,14 @@ int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act);
 int sss_mlp_recompute_supported(int in_dim);
 int sss_mlp_forward(const sss_mlp_args* a, void* stream);
 int sss_mlp_backward(const sss_mlp_args* a, void* stream);
-/* sss_mlp_backward with the six parameter gradients in the same pass, for the (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs:
- * x_dev, a1_dev, a2_dev (both NULL: recomputed from x_dev, see sss_mlp_recompute_supported), dy_dev in, dx_dev out (nullable); g1 / g2 are
- * not written. The weight / bias gradients are ADDED to
- * per-workgroup slots of acc_dev (f32[sss_mlp_wgrad_scratch(in_dim)], zeroed by the caller before the first call of a group of
- * calls whose gradients belong together - the layers of the message passing); sss_mlp_wgrad_finish adds the slots in a fixed
- * order into gw1 [32][in_dim], gb1 [32], gw2 [16][32], gb2 [16], gw3 [16][16], gb3 [16]. Same inputs, same bits. */
+/* sss_mlp_backward with the six parameter gradients in the same pass, for the (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs and
+ * (sss_mlp_wgrad_scratch(in_dim) > 0 says whether this build does) the two policy heads (53 | 36) -> 64 -> 64 -> 1 Tanh:
+ * x_dev, a1_dev, a2_dev (both NULL: recomputed from x_dev, see sss_mlp_recompute_supported - the GNN-shaped MLPs only), dy_dev in,
+ * dx_dev out (nullable); g1 / g2 are not written. The weight / bias gradients are ADDED to
+ * per-workgroup slots of acc_dev (f32[sss_mlp_wgrad_scratch(in_dim)], 0 for any other input width; zeroed by the caller before the
+ * first call of a group of calls whose gradients belong together - the layers of the message passing); sss_mlp_wgrad_finish adds
+ * the slots in a fixed order into gw1 [h1][in_dim], gb1 [h1], gw2 [h2][h1], gb2 [h2], gw3 [out][h2], gb3 [out]. Same inputs, same
+ * bits. What the reference runs here: autograd's AddmmBackward / TanhBackward chain inside loss.backward() (trainers/ppo.py:129-131). */
 int64_t sss_mlp_wgrad_scratch(int in_dim);
 int sss_mlp_backward_wgrad(const sss_mlp_args* a, float* acc_dev, void* stream);
 int sss_mlp_wgrad_finish(int in_dim, const float* acc_dev, float* gw1_dev, float* gb1_dev, float* gw2_dev, float* gb2_dev, float* gw3_dev, float* gb3_dev, void* stream);

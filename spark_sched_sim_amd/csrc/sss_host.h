@@ -854,31 +854,47 @@ extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
 #ifndef SSS_MLPW_SLOTS
 #define SSS_MLPW_SLOTS 2048
 #endif
-static bool sss_mlpw_ok(int in_dim) { return in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16; }
+#ifndef SSS_MLPW_HEAD_SLOTS
+#define SSS_MLPW_HEAD_SLOTS 512
+#endif
+static int be_mlp_head_bwdw_supported();
+// the MLP shapes sss_mlp_backward_wgrad takes, by input width (the architecture's five MLPs have five different ones)
+struct SssMlpwShape {
+  int h1, h2, out, act, slots;
+};
+static bool sss_mlpw_shape(int in_dim, SssMlpwShape* s) {
+  if (in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16) return *s = SssMlpwShape{32, 16, 16, 0, SSS_MLPW_SLOTS}, true;
+  if ((in_dim == GNN_NF + 48 || in_dim == GNN_DF + 33) && be_mlp_head_bwdw_supported()) return *s = SssMlpwShape{64, 64, 1, 1, SSS_MLPW_HEAD_SLOTS}, true;
+  return false;
+}
 extern "C" int64_t sss_mlp_wgrad_scratch(int in_dim) {
-  return sss_mlpw_ok(in_dim) ? (int64_t)SSS_MLPW_SLOTS * ((16 * 16 + 16) + (16 * 32 + 16) + (32 * in_dim + 32)) : 0;
+  SssMlpwShape s;
+  return sss_mlpw_shape(in_dim, &s) ? (int64_t)s.slots * ((s.out * s.h2 + s.out) + (s.h2 * s.h1 + s.h2) + (s.h1 * in_dim + s.h1)) : 0;
 }
 extern "C" int sss_mlp_backward_wgrad(const sss_mlp_args* a, float* acc_dev, void* stream) {
   if (!a || !a->w_dev || !a->dy_dev || !a->x_dev || !acc_dev) return sss_fail(-1, "NULL argument");
   if (!a->a1_dev != !a->a2_dev) return sss_fail(-1, "sss_mlp_backward_wgrad: a1_dev and a2_dev are given together or not at all");
-  if (!a->a1_dev && !be_mlp_recompute_supported(a->in_dim)) return sss_fail(-31, "sss_mlp_backward_wgrad: this build cannot recompute the hidden activations (a1_dev / a2_dev required)");
   if (a->rows < 0) return sss_fail(-31, "sss_mlp: negative row count");
-  if (!(a->h1 == 32 && a->h2 == 16 && a->out_dim == 16 && a->act == 0 && sss_mlpw_ok(a->in_dim)))
-    return sss_fail(-31, "sss_mlp_backward_wgrad: (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs only");
+  SssMlpwShape s;
+  if (!sss_mlpw_shape(a->in_dim, &s) || a->h1 != s.h1 || a->h2 != s.h2 || a->out_dim != s.out || a->act != s.act)
+    return sss_fail(-31, "sss_mlp_backward_wgrad: (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU and (53 | 36) -> 64 -> 64 -> 1 Tanh MLPs only");
+  if (!a->a1_dev && (s.act != 0 || !be_mlp_recompute_supported(a->in_dim)))
+    return sss_fail(-31, "sss_mlp_backward_wgrad: this build cannot recompute this MLP's hidden activations (a1_dev / a2_dev required)");
   if (int rc = be_launch_mlp_bwdw(sss_mlp_args_of(a), acc_dev, stream)) return sss_fail(-30, std::string("mlp backward launch failed: ") + be_error(rc));
   return 0;
 }
 extern "C" int sss_mlp_wgrad_finish(int in_dim, const float* acc_dev, float* gw1_dev, float* gb1_dev, float* gw2_dev, float* gb2_dev, float* gw3_dev, float* gb3_dev,
                                     void* stream) {
   if (!acc_dev || !gw1_dev || !gb1_dev || !gw2_dev || !gb2_dev || !gw3_dev || !gb3_dev) return sss_fail(-1, "NULL argument");
-  if (!sss_mlpw_ok(in_dim)) return sss_fail(-31, "sss_mlp_wgrad_finish: not one of the GNN-shaped MLPs");
+  SssMlpwShape s;
+  if (!sss_mlpw_shape(in_dim, &s)) return sss_fail(-31, "sss_mlp_wgrad_finish: not one of the MLPs sss_mlp_backward_wgrad takes");
   const float* l3 = acc_dev;
-  const float* l2 = l3 + (size_t)SSS_MLPW_SLOTS * (16 * 16 + 16);
-  const float* l1 = l2 + (size_t)SSS_MLPW_SLOTS * (16 * 32 + 16);
-  const struct { const float* part; int N, M; float* gw; float* gb; } job[3] = {{l3, 16, 16, gw3_dev, gb3_dev}, {l2, 16, 32, gw2_dev, gb2_dev}, {l1, 32, in_dim, gw1_dev, gb1_dev}};
+  const float* l2 = l3 + (size_t)s.slots * (s.out * s.h2 + s.out);
+  const float* l1 = l2 + (size_t)s.slots * (s.h2 * s.h1 + s.h2);
+  const struct { const float* part; int N, M; float* gw; float* gb; } job[3] = {{l3, s.out, s.h2, gw3_dev, gb3_dev}, {l2, s.h2, s.h1, gw2_dev, gb2_dev}, {l1, s.h1, in_dim, gw1_dev, gb1_dev}};
   for (int k = 0; k < 3; k++) {
     SssWgradArgs r;
-    r.x = nullptr, r.dy = nullptr, r.K = 0, r.ldx = 0, r.ldy = 0, r.M = job[k].M, r.N = job[k].N, r.partial = const_cast<float*>(job[k].part), r.n_partials = SSS_MLPW_SLOTS;
+    r.x = nullptr, r.dy = nullptr, r.K = 0, r.ldx = 0, r.ldy = 0, r.M = job[k].M, r.N = job[k].N, r.partial = const_cast<float*>(job[k].part), r.n_partials = s.slots;
     r.gw = job[k].gw, r.gb = job[k].gb;
     if (int rc = be_launch_wgrad_reduce(r, stream)) return sss_fail(-30, std::string("wgrad reduce launch failed: ") + be_error(rc));
   }

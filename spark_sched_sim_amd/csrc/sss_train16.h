@@ -634,6 +634,223 @@ __global__ __launch_bounds__(256) void sss_mlp_head_mfma_bwd_kernel(SssMlpArgs a
   }
 }
 
+// ---- the heads' backward pass with the weight gradients in the same pass (round 6) --------------------------------------------
+// sss_mlp_head_mfma_bwd_kernel writes g1 / g2 (128 floats per row) for three sss_linear_wgrad launches that read them back together
+// with x, a1, a2, dy: 620 floats of traffic per row over four launches, a fifth of an update's device time (profiles/r06_ppo.md).
+// Here a workgroup takes 64 rows at a time: each of its four waves runs the chain of the kernel above on 16 of them (dx to memory,
+// g2 / g1 into an LDS tile, its rows' a1 and x copied to LDS as well), and after a barrier each wave accumulates ITS sixteen output
+// neurons of dW2 = G2^T A1 and dW1 = G1^T X over all 64 rows (K-step = rows {4 s + q} of a tile; A operand = the gradient's element
+// 16 wave + i of that row, B = the input's; a1 comes as ONE 16-byte read per lane: component c of it is column 4 i + c, so output
+// tile c holds the columns {4 i + c}) - 4 + U accumulator tiles per wave, no reduction between waves. dW3 = sum dy a2 and db3 are
+// summed in the chain's layout on the vector unit, db2 / db1 from the A operands. x 53 + a1 64 + a2 64 + dy 1 floats in, dx 53 out -
+// g1 and g2 never reach HBM, and every input is read from HBM once: the next block's rows are asked for right after the barrier and
+// arrive while the matrix cores work through the weight-gradient phase, which itself reads LDS only. (A first form re-read a1 / x /
+// a2 from global memory in the second phase, two workgroups per CU: every tile's inputs were an exposed round trip, 2.5 ms for 5 M
+// rows against 3.6 ms for the four launches; loads under `valid ? ... : 0` - a branch and a wait each - made it 5.0 ms.)
+// The workgroup adds its sums to its slot (SSS_MLPW_HEAD_SLOTS of them, zeroed by the caller); sss_wgrad_reduce_kernel adds the
+// slots in a fixed order.
+#define SSS_MLPW_HEAD_SLOTS 512
+template <int IN>
+struct MlpHeadW {
+  static constexpr int U = (IN + 15) / 16;
+  static constexpr int TS = 144;  // floats per row of a gradient tile: g2 (64) | g1 (64) | pad (144 = 16 mod 32)
+  static constexpr int AS = 68;   // ... of the a1 copy (68 = 4 mod 32: the four rows of a K-step's 16-byte reads start on different banks)
+  static constexpr int XN = (16 * IN + 63) / 64;  // floats of a tile's x per lane
+  static constexpr int T2 = 0, T1 = T2 + 4 * 16 * 64, TT = T1 + U * 16 * 64, XA = TT + 4 * 16 * TS, XX = XA + 64 * AS, TOTAL = XX + 64 * IN + 64;
+};
+template <int IN>
+__global__ __launch_bounds__(256) void sss_mlp_head_mfma_bwdw_kernel(SssMlpArgs a, SssMlpWgradAcc acc) {
+  using L = MlpHeadW<IN>;
+  constexpr int U = L::U, TS = L::TS, AS = L::AS, XN = L::XN;
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];
+  {
+    const float* W1 = a.w;
+    const float* W2T = W1 + 64 * IN + 64;  // [n][m] = W2[m][n]
+    for (int t = threadIdx.x; t < 4 * 16 * 64; t += 256) {  // T2[(tp, s)][lane] = W2^T[16 tp + i][16 (s >> 2) + 4 q + (s & 3)]
+      const int lane = t & 63, s = (t >> 6) & 15, tp = t >> 10;
+      w_lds[L::T2 + t] = W2T[(16 * tp + (lane & 15)) * 64 + 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3)];
+    }
+    for (int t = threadIdx.x; t < U * 16 * 64; t += 256) {  // T1[(u, s)][lane] = W1^T[16 u + i][16 (s >> 2) + 4 q + (s & 3)]
+      const int lane = t & 63, s = (t >> 6) & 15, u = t >> 10;
+      const int c = 16 * u + (lane & 15);
+      w_lds[L::T1 + t] = c < IN ? W1[(16 * (s >> 2) + 4 * (lane >> 4) + (s & 3)) * IN + c] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float* W3 = a.w + 64 * IN + 64 + 64 * 64 + 64;
+  float w3[16];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) w3[4 * t + r] = W3[16 * t + 4 * q + r];
+  float* Tw = w_lds + L::TT + wave * 16 * TS;
+  float* Aw = w_lds + L::XA + wave * 16 * AS;
+  float* Xw = w_lds + L::XX + wave * 16 * IN;
+  const mfma_f4 zero = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  mfma_f4 w2a[4] = {zero, zero, zero, zero}, w1a[U], w3a[4] = {zero, zero, zero, zero};
+#pragma unroll
+  for (int u = 0; u < U; u++) w1a[u] = zero;
+  float b2s = 0.0f, b1s = 0.0f, b3s = 0.0f;
+  const int64_t n_blocks = (a.rows + 63) / 64;
+  const int64_t x_last = a.rows * IN - 1;
+  // (every load is unconditional - what lies behind the end reads the last row / element instead, and dy = 0 there makes g2 / g1 zero)
+  float n_dy, n_x[XN];
+  mfma_f4 n_a2[4], n_a1[4];
+  auto fetch = [&](int64_t block) {
+    const int64_t r0 = (block * 4 + wave) * 16;
+    const int64_t rc = r0 + j < a.rows ? r0 + j : a.rows - 1;
+    n_dy = a.dy[rc];
+#pragma unroll
+    for (int t = 0; t < 4; t++) n_a2[t] = *(const mfma_f4*)(a.a2 + rc * 64 + 16 * t + 4 * q), n_a1[t] = *(const mfma_f4*)(a.a1 + rc * 64 + 16 * t + 4 * q);
+#pragma unroll
+    for (int k = 0; k < XN; k++) {  // the tile's 16 x IN floats of x are contiguous: lane l takes the elements l, l + 64, ...
+      const int64_t e = r0 * IN + lane + 64 * k;
+      n_x[k] = a.x[e < x_last ? e : x_last];
+    }
+  };
+  if ((int64_t)blockIdx.x < n_blocks) fetch(blockIdx.x);
+  for (int64_t block = blockIdx.x; block < n_blocks; block += gridDim.x) {
+    {  // the chain of sss_mlp_head_mfma_bwd_kernel on this wave's 16 rows
+      const int64_t row = (block * 4 + wave) * 16 + j;
+      const bool valid = row < a.rows;
+      const float dy = valid ? n_dy : 0.0f;
+      mfma_f4 g2[4], g1[4], a1[4];
+#pragma unroll
+      for (int k = 0; k < XN; k++)
+        if (lane + 64 * k < 16 * IN) Xw[lane + 64 * k] = n_x[k];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const mfma_f4 a2 = n_a2[t];
+        a1[t] = n_a1[t];
+        *(mfma_f4*)(Aw + j * AS + 16 * t + 4 * q) = a1[t];
+        w3a[t] += mfma_f4{dy * a2.x, dy * a2.y, dy * a2.z, dy * a2.w};
+        g2[t] = mfma_f4{w3[4 * t] * dy * (1.0f - a2.x * a2.x), w3[4 * t + 1] * dy * (1.0f - a2.y * a2.y), w3[4 * t + 2] * dy * (1.0f - a2.z * a2.z),
+                        w3[4 * t + 3] * dy * (1.0f - a2.w * a2.w)};
+        *(mfma_f4*)(Tw + j * TS + 16 * t + 4 * q) = g2[t];
+      }
+      if (q == 0) b3s += dy;
+#pragma unroll
+      for (int tp = 0; tp < 4; tp++) {
+        mfma_f4 s = zero;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const float* ap = w_lds + L::T2 + ((tp * 16 + 4 * t) * 64) + lane;
+          s = mfma16(ap[0], g2[t].x, s), s = mfma16(ap[64], g2[t].y, s), s = mfma16(ap[128], g2[t].z, s), s = mfma16(ap[192], g2[t].w, s);
+        }
+        g1[tp] = mfma_f4{s.x * (1.0f - a1[tp].x * a1[tp].x), s.y * (1.0f - a1[tp].y * a1[tp].y), s.z * (1.0f - a1[tp].z * a1[tp].z), s.w * (1.0f - a1[tp].w * a1[tp].w)};
+        *(mfma_f4*)(Tw + j * TS + 64 + 16 * tp + 4 * q) = g1[tp];
+      }
+      if (a.dx) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          mfma_f4 dx = zero;
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const float* ap = w_lds + L::T1 + ((u * 16 + 4 * t) * 64) + lane;
+            dx = mfma16(ap[0], g1[t].x, dx), dx = mfma16(ap[64], g1[t].y, dx), dx = mfma16(ap[128], g1[t].z, dx), dx = mfma16(ap[192], g1[t].w, dx);
+          }
+          if (valid) {
+            float* o = a.dx + row * IN + 16 * u + 4 * q;
+            if (16 * u + 4 * q + 0 < IN) o[0] = dx.x;
+            if (16 * u + 4 * q + 1 < IN) o[1] = dx.y;
+            if (16 * u + 4 * q + 2 < IN) o[2] = dx.z;
+            if (16 * u + 4 * q + 3 < IN) o[3] = dx.w;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    fetch(block + gridDim.x);  // (behind the last block: the last row again, unused)
+    // this wave's sixteen neurons (16 wave + i) of the weight gradients over the workgroup's 64 rows, from LDS
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) {
+      const float* Tt = w_lds + L::TT + tt * 16 * TS;
+      const float* At = w_lds + L::XA + tt * 16 * AS;
+      const float* Xt = w_lds + L::XX + tt * 16 * IN;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const int r = 4 * s4 + q;
+        const float A2 = Tt[r * TS + 16 * wave + j], A1 = Tt[r * TS + 64 + 16 * wave + j];
+        const mfma_f4 B2 = *(const mfma_f4*)(At + r * AS + 4 * j);  // columns 4 i .. 4 i + 3: one per output tile
+        b2s += A2, b1s += A1;
+        w2a[0] = mfma16(A2, B2.x, w2a[0]), w2a[1] = mfma16(A2, B2.y, w2a[1]), w2a[2] = mfma16(A2, B2.z, w2a[2]), w2a[3] = mfma16(A2, B2.w, w2a[3]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int col = 16 * u + j;
+          const float xv = Xt[r * IN + (col < IN ? col : IN - 1)];
+          w1a[u] = mfma16(A1, col < IN ? xv : 0.0f, w1a[u]);
+        }
+      }
+    }
+    __syncthreads();  // (the next block's stores to the tiles come after these reads)
+  }
+  // register v of lane l of an accumulator tile = D[4 (l / 16) + v][l % 16]: neuron 16 wave + 4 q + v, input column per the tile's mapping
+  float* o3 = acc.l3 + (size_t)blockIdx.x * (64 + 1);
+  float* o2 = acc.l2 + (size_t)blockIdx.x * (64 * 64 + 64);
+  float* o1 = acc.l1 + (size_t)blockIdx.x * (64 * IN + 64);
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const float vv[4] = {w2a[c].x, w2a[c].y, w2a[c].z, w2a[c].w};
+#pragma unroll
+    for (int v = 0; v < 4; v++) o2[(16 * wave + 4 * q + v) * 64 + 4 * j + c] += vv[v];
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const float vv[4] = {w1a[u].x, w1a[u].y, w1a[u].z, w1a[u].w};
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+      if (16 * u + j < IN) o1[(16 * wave + 4 * q + v) * IN + 16 * u + j] += vv[v];
+  }
+  float sb[2] = {b2s, b1s};
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    sb[k] += __shfl_xor(sb[k], 16, 64);
+    sb[k] += __shfl_xor(sb[k], 32, 64);
+  }
+  if (q == 0) o2[64 * 64 + 16 * wave + j] += sb[0], o1[64 * IN + 16 * wave + j] += sb[1];
+  // dW3 / db3: a lane holds the sums over its row (j) of the four waves' tiles - over the 16 rows of a quarter-wave, then the waves
+  // one after the other through LDS (the tiles are free now: the loop's last barrier is behind every wave)
+  float* red = w_lds + L::TT;  // [wave][64 + 1]
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    float vv[4] = {w3a[t].x, w3a[t].y, w3a[t].z, w3a[t].w};
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) vv[v] += __shfl_xor(vv[v], m, 64);
+      if (j == 0) red[wave * 65 + 16 * t + 4 * q + v] = vv[v];
+    }
+  }
+  {
+    float v = b3s;  // (lanes q == 0 hold their row's share)
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) red[wave * 65 + 64] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 65) o3[threadIdx.x] += ((red[threadIdx.x] + red[65 + threadIdx.x]) + red[130 + threadIdx.x]) + red[195 + threadIdx.x];
+}
+
+template <int IN>
+static int mlp_head_mfma_bwdw_launch(const SssMlpArgs& a, const SssMlpWgradAcc& acc, void* stream) {
+  if (a.rows <= 0) return 0;
+  const size_t lds = (size_t)MlpHeadW<IN>::TOTAL * sizeof(float);
+  static GnnGridCap cache;
+  static bool attr_set = false;
+  if (!attr_set) {  // (more than 64 KB of dynamic LDS per workgroup)
+    (void)hipFuncSetAttribute((const void*)sss_mlp_head_mfma_bwdw_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int64_t blocks = (a.rows + 63) / 64;
+  int64_t cap = gnn_resident_workgroups(cache, (const void*)sss_mlp_head_mfma_bwdw_kernel<IN>, 256, lds, 256);
+  if (cap > SSS_MLPW_HEAD_SLOTS) cap = SSS_MLPW_HEAD_SLOTS;
+  const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+  hipLaunchKernelGGL(sss_mlp_head_mfma_bwdw_kernel<IN>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, acc);
+  return (int)hipGetLastError();
+}
+
 template <int IN>
 static int mlp_head_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
   if (a.rows <= 0) return 0;
@@ -651,6 +868,14 @@ static int mlp_head_mfma_launch(const SssMlpArgs& a, bool backward, void* stream
 // backward + weight gradients of a GNN-shaped MLP (acc: SSS_MLPW_SLOTS slots per Linear, see sss_mlp_mfma_bwdw_kernel)
 static int be_launch_mlp_bwdw(const SssMlpArgs& a, float* acc, void* stream) {
   SssMlpWgradAcc w;
+#ifndef SSS_TEST_VECTOR_FORMS
+  if (a.h1 == 64) {  // the two policy heads (SSS_MLPW_HEAD_SLOTS slots per Linear)
+    w.l3 = acc, w.l2 = w.l3 + (size_t)SSS_MLPW_HEAD_SLOTS * (64 + 1), w.l1 = w.l2 + (size_t)SSS_MLPW_HEAD_SLOTS * (64 * 64 + 64);
+    if (a.in_dim == GNN_NF + 48) return mlp_head_mfma_bwdw_launch<GNN_NF + 48>(a, w, stream);
+    if (a.in_dim == GNN_DF + 33) return mlp_head_mfma_bwdw_launch<GNN_DF + 33>(a, w, stream);
+    return -1;
+  }
+#endif
   w.l3 = acc, w.l2 = w.l3 + (size_t)SSS_MLPW_SLOTS * (16 * 16 + 16), w.l1 = w.l2 + (size_t)SSS_MLPW_SLOTS * (16 * 32 + 16);
   if (a.in_dim == GNN_NF) return mlp_mfma_bwdw_launch<GNN_NF>(a, w, stream);
   if (a.in_dim == 16) return mlp_mfma_bwdw_launch<16>(a, w, stream);
@@ -664,6 +889,14 @@ static int be_mlp_recompute_supported(int in_dim) {
   return 0;  // (the 16-lanes-per-row comparison kernels keep the stored-activation form)
 #else
   return in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16;
+#endif
+}
+// whether sss_mlp_backward_wgrad takes the two policy heads (IN -> 64 -> 64 -> 1, Tanh; stored activations) as well
+static int be_mlp_head_bwdw_supported() {
+#ifdef SSS_TEST_VECTOR_FORMS
+  return 0;  // (the comparison build keeps the backward + three weight-gradient launches)
+#else
+  return 1;
 #endif
 }
 static int be_launch_wgrad_reduce(const SssWgradArgs& a, void* stream) {

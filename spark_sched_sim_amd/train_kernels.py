@@ -307,6 +307,9 @@ FUSED_WGRAD = True  # the GNN-shaped MLPs' backward pass with the parameter grad
 # matrix cores (bit-identical). The kernels are bound by exactly that traffic (profiles/r06_ppo.md), and the stored activations were
 # ~25 GB of a config-5 minibatch's peak memory.
 RECOMPUTE_HIDDEN = True
+# the two policy heads' backward pass likewise in one kernel with their parameter gradients (sss_mlp_head_mfma_bwdw_kernel) instead of
+# a backward launch that writes g1 / g2 and three weight-gradient launches that read them back
+FUSED_HEAD_WGRAD = True
 
 
 def mlp_wgrad_acc(in_dim: int, dev, binding=None) -> torch.Tensor | None:
@@ -318,8 +321,9 @@ def mlp_wgrad_acc(in_dim: int, dev, binding=None) -> torch.Tensor | None:
 
 
 def mlp_backward_wgrad(dy: torch.Tensor, x: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: torch.Tensor, dims, slope: float, acc: torch.Tensor,
-                       want_dx: bool = True, binding=None):
-    """`sss_mlp_backward_wgrad`: dx f32[rows, IN] | None for dy f32[rows, 16]; the six parameter gradients are added to `acc`"""
+                       want_dx: bool = True, binding=None, act: int = 0):
+    """`sss_mlp_backward_wgrad`: dx f32[rows, IN] | None for dy f32[rows, OUT]; the six parameter gradients are added to `acc`
+    (`act`: 0 LeakyReLU - the GNN-shaped MLPs; 1 Tanh - the two policy heads, stored activations required)"""
     import ctypes
 
     from .binding import device_of
@@ -331,7 +335,7 @@ def mlp_backward_wgrad(dy: torch.Tensor, x: torch.Tensor, a1: torch.Tensor, a2: 
     dx = torch.empty((rows, dims[0]), dtype=torch.float32, device=dev) if want_dx else None
     if rows == 0:
         return dx
-    a = _mlp_args(dims, 0, slope, rows, packed, x=x, a1=a1, a2=a2, dy=dy, dx=dx)
+    a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, dy=dy, dx=dx)
     with device_of(dev):
         b.check(b.lib.sss_mlp_backward_wgrad(ctypes.byref(a), acc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
     return dx
@@ -372,9 +376,10 @@ class _MlpFn(torch.autograd.Function):
         else:
             x, a1, a2, packed = ctx.saved_tensors
         dy = dy.contiguous()
-        acc = mlp_wgrad_acc(ctx.dims[0], dy.device) if (FUSED_WGRAD and ctx.act == 0 and tuple(ctx.dims[1:]) == (32, 16, 16)) else None
+        fused_shape = (ctx.act == 0 and tuple(ctx.dims[1:]) == (32, 16, 16)) or (FUSED_HEAD_WGRAD and ctx.act == 1 and tuple(ctx.dims[1:]) == (64, 64, 1))
+        acc = mlp_wgrad_acc(ctx.dims[0], dy.device) if (FUSED_WGRAD and fused_shape) else None
         if acc is not None:  # one kernel: dx and the six parameter gradients (g1 / g2 never leave the chip)
-            dx = mlp_backward_wgrad(dy, x, a1, a2, packed, ctx.dims, ctx.slope, acc, want_dx=ctx.needs_input_grad[0])
+            dx = mlp_backward_wgrad(dy, x, a1, a2, packed, ctx.dims, ctx.slope, acc, want_dx=ctx.needs_input_grad[0], act=ctx.act)
             return (dx, *mlp_wgrad_finish(ctx.dims, acc), None, None, None)
         g1, g2, dx = mlp_backward(dy, a1, a2, packed, ctx.dims, ctx.act, ctx.slope, want_dx=ctx.needs_input_grad[0])
         gw3, gb3 = linear_wgrad(a2, dy)

@@ -193,9 +193,10 @@ static int be_launch_mlp_bwdw(const SssMlpArgs& a0, float* acc, void*) {
     a.a1 = r1.data(), a.a2 = r2.data();
   }
   if (int rc = be_launch_mlp(a, 1, nullptr)) return rc;
+  const size_t slots = H1 == 64 ? 512 : 2048;  // (csrc/sss_host.h SSS_MLPW_HEAD_SLOTS / SSS_MLPW_SLOTS)
   float* l3 = acc;
-  float* l2 = l3 + (size_t)2048 * (OUT * H2 + OUT);
-  float* l1 = l2 + (size_t)2048 * (H2 * H1 + H2);
+  float* l2 = l3 + slots * (OUT * H2 + OUT);
+  float* l1 = l2 + slots * (H2 * H1 + H2);
   for (int64_t r = 0; r < a.rows; r++) {
     for (int o = 0; o < OUT; o++) {
       for (int m = 0; m < H2; m++) l3[o * H2 + m] += a.dy[r * OUT + o] * a.a2[r * H2 + m];
@@ -212,6 +213,7 @@ static int be_launch_mlp_bwdw(const SssMlpArgs& a0, float* acc, void*) {
   }
   return 0;
 }
+static int be_mlp_head_bwdw_supported() { return 1; }
 static int be_launch_wgrad_reduce(const SssWgradArgs& a, void*) {
   const int n_out = a.N * a.M + a.N;
   for (int i = 0; i < n_out; i++) {

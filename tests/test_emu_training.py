@@ -258,9 +258,11 @@ def test_fused_backward_entry_points_on_the_host_backend():
 
     b = Binding(load_emu())
     torch.manual_seed(6)
-    for in_dim in (5, 16, 21):
-        dims = (in_dim, 32, 16, 16)
-        mlp = make_mlp(in_dim, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2))
+    for in_dim, hid, out, act_cls, kw, act, slope in ((5, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), (16, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2), 0, 0.2),
+                                                     (21, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), (53, [64, 64], 1, "Tanh", {}, 1, 0.0),
+                                                     (36, [64, 64], 1, "Tanh", {}, 1, 0.0)):  # (the two policy heads: stored activations)
+        dims = (in_dim, hid[0], hid[1], out)
+        mlp = make_mlp(in_dim, hid, out, act_cls, kw)
         packed = pack_mlp(mlp[0], mlp[2], mlp[4])
         acc = mlp_wgrad_acc(in_dim, "cpu", binding=b)
         xs = [torch.randn((n, in_dim), requires_grad=True) for n in (37, 5)]
@@ -268,14 +270,16 @@ def test_fused_backward_entry_points_on_the_host_backend():
             y = mlp(x)
             dy = torch.randn_like(y)
             y.backward(dy)
-            a1, a2, _ = mlp_forward(x.detach(), packed, dims, 0, 0.2, binding=b)
-            dx = mlp_backward_wgrad(dy, x.detach(), a1, a2, packed, dims, 0.2, acc, binding=b)
+            a1, a2, _ = mlp_forward(x.detach(), packed, dims, act, slope, binding=b)
+            dx = mlp_backward_wgrad(dy, x.detach(), a1, a2, packed, dims, slope, acc, binding=b, act=act)
             assert torch.allclose(dx, x.grad, rtol=1e-4, atol=1e-5)
         got = mlp_wgrad_finish(dims, acc, binding=b)
         want = (mlp[0].weight.grad, mlp[0].bias.grad, mlp[2].weight.grad, mlp[2].bias.grad, mlp[4].weight.grad, mlp[4].bias.grad)
         for g_, w_ in zip(got, want):
             assert g_.shape == w_.shape and torch.allclose(g_, w_, rtol=1e-4, atol=1e-4)
-    assert mlp_wgrad_acc(53, "cpu", binding=b) is None
+    assert mlp_wgrad_acc(7, "cpu", binding=b) is None
+    with pytest.raises(ValueError):  # a head without its stored activations: refused (only the GNN-shaped MLPs are recomputed)
+        mlp_backward_wgrad(torch.zeros((4, 1)), torch.zeros((4, 53)), None, None, torch.zeros(8000), (53, 64, 64, 1), 0.0, mlp_wgrad_acc(53, "cpu", binding=b), binding=b, act=1)
 
 
 def test_recompute_entry_points_on_the_host_backend():

@@ -320,37 +320,40 @@ def test_take_moves_rows_of_any_dtype():
 
 @pytest.mark.gpu
 def test_fused_backward_with_weight_gradients():
-    """sss_mlp_mfma_bwdw_kernel (backward + the six parameter gradients in one pass, csrc/sss_train16.h) against fp64 autograd for
-    the three GNN-shaped MLPs: row counts that are not multiples of 16 / 64 and exceed one grid pass, two calls adding up in one
+    """sss_mlp_mfma_bwdw_kernel / sss_mlp_head_mfma_bwdw_kernel (backward + the six parameter gradients in one pass,
+    csrc/sss_train16.h) against fp64 autograd for the three GNN-shaped MLPs and the two policy heads: row counts that are not multiples of 16 / 64 and exceed one grid pass, two calls adding up in one
     accumulator, and the same bits when repeated"""
     from spark_sched_sim_amd.decima import make_mlp
     from spark_sched_sim_amd.train_kernels import mlp_backward_wgrad, mlp_forward, mlp_wgrad_acc, mlp_wgrad_finish, pack_mlp
 
     dev = torch.device("cuda:0")
     torch.manual_seed(8)
-    for in_dim in (5, 16, 21):
-        dims = (in_dim, 32, 16, 16)
-        mlp = make_mlp(in_dim, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2)).to(dev)
+    for in_dim, hid, out, act_cls, kw, act, slope in ((5, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2), 0, 0.2), (16, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2), 0, 0.2),
+                                                     (21, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2), 0, 0.2),
+                                                     # the two policy heads (sss_mlp_head_mfma_bwdw_kernel)
+                                                     (53, [64, 64], 1, "Tanh", {}, 1, 0.0), (36, [64, 64], 1, "Tanh", {}, 1, 0.0)):
+        dims = (in_dim, hid[0], hid[1], out)
+        mlp = make_mlp(in_dim, hid, out, act_cls, kw).to(dev)
         with torch.no_grad():
             for lin in (mlp[0], mlp[2], mlp[4]):
                 lin.bias.normal_(0.0, 0.1)
-        ref = make_mlp(in_dim, [32, 16], 16, "LeakyReLU", dict(negative_slope=0.2)).to(dev).double()
+        ref = make_mlp(in_dim, hid, out, act_cls, kw).to(dev).double()
         ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
         packed = pack_mlp(mlp[0], mlp[2], mlp[4])
         outs = []
         for rep in range(2):
             acc = mlp_wgrad_acc(in_dim, dev)
             ref.zero_grad()
-            for n in (200_003, 1_037):
+            for n in (200_003, 1_037, 63):
                 gen = torch.Generator(device=dev).manual_seed(100 + n)
                 x = torch.randn((n, in_dim), device=dev, generator=gen)
-                dy = torch.randn((n, 16), device=dev, generator=gen)
+                dy = torch.randn((n, out), device=dev, generator=gen)
                 xr = x.double().requires_grad_(True)
                 ref(xr).backward(dy.double())
-                a1, a2, _ = mlp_forward(x, packed, dims, 0, 0.2)
-                dx = mlp_backward_wgrad(dy, x, a1, a2, packed, dims, 0.2, acc)
+                a1, a2, _ = mlp_forward(x, packed, dims, act, slope)
+                dx = mlp_backward_wgrad(dy, x, a1, a2, packed, dims, slope, acc, act=act)
                 assert torch.allclose(dx.double(), xr.grad, rtol=1e-4, atol=1e-5)
-                assert mlp_backward_wgrad(dy, x, a1, a2, packed, dims, 0.2, torch.zeros_like(acc), want_dx=False) is None
+                assert mlp_backward_wgrad(dy, x, a1, a2, packed, dims, slope, torch.zeros_like(acc), want_dx=False, act=act) is None
             got = mlp_wgrad_finish(dims, acc)
             want = (ref[0].weight.grad, ref[0].bias.grad, ref[2].weight.grad, ref[2].bias.grad, ref[4].weight.grad, ref[4].bias.grad)
             for g_, w_ in zip(got, want):
