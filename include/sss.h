@@ -630,6 +630,26 @@ typedef struct sss_rows_args {
 } sss_rows_args;
 int sss_rows_op(const sss_rows_args* a, void* stream);
 
+/* Several tables side by side - the score networks' input rows torch.cat([t_0[idx_0], t_1[idx_1], ...], -1) of
+ * schedulers/decima/scheduler.py:289-318 / :337-385 - in ONE launch that walks `out` as a flat array (csrc/sss_rows.h):
+ *   op 0  out[i][off_k + j] = table_k[idx_k[i]][j]       for every part k (idx_k NULL: row i itself)
+ *   op 1  table_k[idx_k[i]][j] += out[i][off_k + j]      (the backward pass; float atomics; parts with table_dev NULL are skipped)
+ * off_k = the widths of the parts before k; out_dev f32[n][sum of widths <= 64] contiguous, table_k f32[rows_k][width_k] contiguous. */
+typedef struct sss_concat_part {
+  float* table_dev;
+  const int64_t* idx_dev; /* i64[n], nullable */
+  int32_t width;          /* floats per row of the table, 1..64 */
+  int32_t pad_;
+} sss_concat_part;
+typedef struct sss_concat_args {
+  int64_t n;       /* rows */
+  int32_t n_parts; /* 1..4 */
+  int32_t op;
+  float* out_dev;
+  sss_concat_part parts[4];
+} sss_concat_args;
+int sss_rows_concat(const sss_concat_args* a, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

@@ -322,7 +322,7 @@ extern "C" int sss_abi_sizeof(const char* name) {
   SSS_ABI_SIZE(sss_cfg) SSS_ABI_SIZE(sss_dims) SSS_ABI_SIZE(sss_buffers) SSS_ABI_SIZE(sss_decima_graph) SSS_ABI_SIZE(sss_decima_lists)
   SSS_ABI_SIZE(sss_bit_list_args) SSS_ABI_SIZE(sss_gnn_args) SSS_ABI_SIZE(sss_decima_policy_args) SSS_ABI_SIZE(sss_decima_sample_args)
   SSS_ABI_SIZE(sss_gnn_encode_args) SSS_ABI_SIZE(sss_collect_args) SSS_ABI_SIZE(sss_mlp_args) SSS_ABI_SIZE(sss_arena_array)
-  SSS_ABI_SIZE(sss_arena_args) SSS_ABI_SIZE(sss_returns_args) SSS_ABI_SIZE(sss_baseline_args) SSS_ABI_SIZE(sss_rows_args)
+  SSS_ABI_SIZE(sss_arena_args) SSS_ABI_SIZE(sss_returns_args) SSS_ABI_SIZE(sss_baseline_args) SSS_ABI_SIZE(sss_rows_args) SSS_ABI_SIZE(sss_concat_part) SSS_ABI_SIZE(sss_concat_args)
 #undef SSS_ABI_SIZE
   return -1;
 }
@@ -848,6 +848,30 @@ extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
   r.n = a->n, r.ld_a = a->ld_a, r.width = a->width, r.op = a->op, r.idx = a->idx_dev, r.a = a->a_dev, r.b = a->b_dev, r.c = a->c_dev;
   if (r.n == 0) return 0;
   if (int rc = be_launch_rows(r, stream)) return sss_fail(-30, std::string("rows launch failed: ") + be_error(rc));
+  return 0;
+}
+
+static int be_launch_concat(const SssConcatArgs& r, void* stream);
+extern "C" int sss_rows_concat(const sss_concat_args* a, void* stream) {
+  if (!a || !a->out_dev) return sss_fail(-1, "NULL argument");
+  if (a->op != 0 && a->op != 1) return sss_fail(-33, "sss_rows_concat: unknown operation");
+  if (a->n < 0 || a->n_parts < 1 || a->n_parts > SSS_CONCAT_MAX_PARTS) return sss_fail(-33, "sss_rows_concat: n >= 0 and 1..4 parts");
+  SssConcatArgs r;
+  r.n = a->n, r.n_parts = a->n_parts, r.op = a->op, r.out = a->out_dev;
+  int w = 0;
+  for (int k = 0; k < SSS_CONCAT_MAX_PARTS; k++) {
+    const bool used = k < a->n_parts;
+    if (used && (a->parts[k].width < 1 || a->parts[k].width > 64)) return sss_fail(-33, "sss_rows_concat: a part has 1..64 floats per row");
+    if (used && !a->parts[k].table_dev && a->op == 0) return sss_fail(-1, "NULL argument");
+    r.table[k] = used ? a->parts[k].table_dev : nullptr, r.idx[k] = used ? a->parts[k].idx_dev : nullptr, r.pw[k] = used ? a->parts[k].width : 0;
+    w += r.pw[k], r.end[k] = w;
+  }
+  if (w > 64) return sss_fail(-33, "sss_rows_concat: at most 64 floats per row");
+  r.width = w, r.inv = ((1 << 20) + w - 1) / w;
+  for (uint32_t t = 0; t < 64u * (uint32_t)w; t++)  // (the kernel's division: exact for every width up to 64 - kept as a check of the constant)
+    if (((t * (uint32_t)r.inv) >> 20) != t / (uint32_t)w) return sss_fail(-33, "sss_rows_concat: internal (division constant)");
+  if (r.n == 0) return 0;
+  if (int rc = be_launch_concat(r, stream)) return sss_fail(-30, std::string("concat launch failed: ") + be_error(rc));
   return 0;
 }
 

@@ -53,6 +53,38 @@ static inline void sss_rows_element(const SssRowsArgs& r, int64_t i, int j, AddF
   }
 }
 
+// ---- several tables side by side (round 6): the score networks' input rows `cat([t_0[idx_0], t_1[idx_1], ...], -1)` --------------
+// Built part by part with GATHER into column slices, a 53-float row is written in four launches of 20 / 64-byte pieces that no
+// memory transaction is aligned with (1.6 ms for 5 M rows, as much as the head's forward kernel; the backward pass read the
+// gradient rows three times, 64 bytes of every 212 each). Here ONE launch walks the output as a flat array - a wave's instruction
+// stores (loads) 64 consecutive floats - and every element finds its part by its column:
+//   CONCAT_GATHER       out[i][off_k + j] = table_k[idx_k[i]][j]        (idx_k NULL: row i itself)
+//   CONCAT_SCATTER_ADD  table_k[idx_k[i]][j] += out[i][off_k + j]      (float atomics; parts with table_k NULL are skipped)
+#define SSS_CONCAT_MAX_PARTS 4
+enum { CONCAT_GATHER = 0, CONCAT_SCATTER_ADD = 1 };
+struct SssConcatArgs {
+  int64_t n;       // rows
+  int32_t n_parts;
+  int32_t width;   // floats per row of `out` = the sum of the parts' widths, 1..64
+  int32_t op;
+  int32_t inv;     // ceil(2^20 / width): (t * inv) >> 20 == t / width for every t < 64 * width (checked by the host)
+  float* out;      // [n][width], contiguous
+  float* table[SSS_CONCAT_MAX_PARTS];          // [rows_k][pw[k]], contiguous
+  const int64_t* idx[SSS_CONCAT_MAX_PARTS];    // i64[n] or NULL
+  int32_t pw[SSS_CONCAT_MAX_PARTS];            // floats per row of the part
+  int32_t end[SSS_CONCAT_MAX_PARTS];           // first column behind the part
+};
+template <class AddFn>
+static inline void sss_concat_element(const SssConcatArgs& r, int64_t i, int c, AddFn&& atomic_add) {
+  int k = 0;
+  while (k + 1 < r.n_parts && c >= r.end[k]) k++;
+  if (!r.table[k]) return;
+  const int j = c - (r.end[k] - r.pw[k]);
+  float* t = r.table[k] + (r.idx[k] ? r.idx[k][i] : i) * (int64_t)r.pw[k] + j;
+  if (r.op == CONCAT_GATHER) r.out[i * (int64_t)r.width + c] = *t;
+  else atomic_add(t, r.out[i * (int64_t)r.width + c]);
+}
+
 #if defined(__HIPCC__)
 #ifndef SSS_ROWS_VEC_ATOMICS
 #define SSS_ROWS_VEC_ATOMICS 0
@@ -126,6 +158,65 @@ __global__ __launch_bounds__(256) void sss_rows_kernel(SssRowsArgs r, int lanes_
       else *(T*)(r.a + row[u] * r.ld_a + col[u]) = v[u], *(T*)(r.b + tab[u]) = SssRowsVec<VEC>::zero(), *(T*)(r.c + tab[u]) = w[u] + v[u];
     }
   }
+}
+
+// a wave takes 64 rows at a time: 64 * width consecutive floats of `out`, 64 per instruction. The rows' indices come in first, one
+// coalesced load per part into the wave's corner of LDS (an element then finds its source row with an LDS read instead of a
+// second dependent trip to memory); eight elements per lane are in flight.
+template <int OP>
+__global__ __launch_bounds__(256) void sss_concat_kernel(SssConcatArgs r) {
+  __shared__ int64_t sidx[4][SSS_CONCAT_MAX_PARTS][64];
+  constexpr int F = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_blocks = (r.n + 63) >> 6;
+  const uint32_t W = (uint32_t)r.width, inv = (uint32_t)r.inv;
+  for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blocks; blk += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = blk << 6;
+    const int64_t left = r.n - row0;
+    const uint32_t elems = (uint32_t)(left < 64 ? left : 64) * W;
+    float* o = r.out + row0 * (int64_t)W;
+    {
+      const int64_t me = row0 + lane < r.n ? row0 + lane : r.n - 1;
+#pragma unroll
+      for (int k = 0; k < SSS_CONCAT_MAX_PARTS; k++)
+        if (k < r.n_parts) sidx[wave][k][lane] = r.idx[k] ? r.idx[k][me] : me;
+    }
+    for (uint32_t t0 = 0; t0 < elems; t0 += 64 * F) {
+      float v[F];
+      float* tp[F];
+      bool ok[F];
+#pragma unroll
+      for (int u = 0; u < F; u++) {
+        const uint32_t t = t0 + 64 * u + lane;
+        const bool in = t < elems;
+        const uint32_t tc = in ? t : 0;
+        const uint32_t i = (tc * inv) >> 20, c = tc - i * W;
+        int k = 0;
+#pragma unroll
+        for (int p = 0; p + 1 < SSS_CONCAT_MAX_PARTS; p++) k += (p + 1 < r.n_parts && (int)c >= r.end[p]) ? 1 : 0;
+        const int j = (int)c - (r.end[k] - r.pw[k]);
+        ok[u] = in && r.table[k] != nullptr;
+        tp[u] = r.table[k] + sidx[wave][k][i] * (int64_t)r.pw[k] + j;
+        v[u] = 0.0f;
+        if (ok[u]) v[u] = OP == CONCAT_GATHER ? *tp[u] : o[t];
+      }
+#pragma unroll
+      for (int u = 0; u < F; u++) {
+        if (!ok[u]) continue;
+        if (OP == CONCAT_GATHER) o[t0 + 64 * u + lane] = v[u];
+        else sss_rows_fadd(tp[u], v[u]);
+      }
+    }
+  }
+}
+static int sss_concat_launch(const SssConcatArgs& r, void* stream) {
+  const int64_t waves = (r.n + 63) >> 6;
+  int64_t blocks = (waves + 3) / 4;
+  if (blocks > 65536) blocks = 65536;  // (the loop strides)
+  if (blocks < 1) return 0;
+  if (r.op == CONCAT_GATHER) hipLaunchKernelGGL(sss_concat_kernel<CONCAT_GATHER>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r);
+  else hipLaunchKernelGGL(sss_concat_kernel<CONCAT_SCATTER_ADD>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r);
+  return (int)hipGetLastError();
 }
 
 template <int VEC>

@@ -188,19 +188,52 @@ def segment_sum(y: torch.Tensor, idx: torch.Tensor, n_seg: int, mode: str = "") 
     return torch.zeros((n_seg, y.shape[-1]), dtype=y.dtype, device=y.device).index_add_(0, idx, y)
 
 
+CONCAT_ONE_LAUNCH = True  # the rows of a concatenation written / read back by ONE launch over the flat output (sss_rows_concat)
+
+
+def rows_concat(op: int, out: torch.Tensor, tables, idxs, binding=None) -> None:
+    """`sss_rows_concat` (include/sss.h; csrc/sss_rows.h sss_concat_kernel): op 0 out[i] = cat_k(tables[k][idxs[k][i]]);
+    op 1 tables[k][idxs[k][i]] += the k-th column range of out[i] (tables[k] None: skipped). out f32[n, sum of widths] contiguous"""
+    import ctypes
+
+    from .binding import SssConcatArgs, device_of
+    bnd = binding if binding is not None else _binding()
+    n = out.shape[0]
+    if n == 0:
+        return
+    assert out.dtype == torch.float32 and out.is_contiguous() and 1 <= len(tables) <= 4 and len(tables) == len(idxs)
+    a = SssConcatArgs()
+    a.n, a.n_parts, a.op, a.out_dev = n, len(tables), op, out.data_ptr()
+    for k, (t, ix) in enumerate(zip(tables, idxs)):
+        width = t.shape[1] if not isinstance(t, int) else t
+        if not isinstance(t, int):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2
+        assert ix is None or (ix.dtype == torch.int64 and ix.is_contiguous() and ix.numel() == n)
+        a.parts[k].table_dev, a.parts[k].idx_dev, a.parts[k].width = (None if isinstance(t, int) else t.data_ptr()), (ix.data_ptr() if ix is not None else None), width
+    dev = out.device
+    with device_of(dev):
+        bnd.check(bnd.lib.sss_rows_concat(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+
+
 class _ConcatRowsFn(torch.autograd.Function):
-    """cat([t_0[idx_0], t_1[idx_1], ...], -1) written in place by one gather per part (no intermediate rows, no copy into the
-    concatenation); backward: one scatter-add per part straight from the column slice of the gradient"""
+    """cat([t_0[idx_0], t_1[idx_1], ...], -1) written by one launch over the flat result (no intermediate rows, no copy into the
+    concatenation, whole memory transactions); backward: one launch that reads the gradient rows once and adds every part's
+    columns into its table. (`CONCAT_ONE_LAUNCH = False`, or more than four parts: one gather / scatter-add per part on column
+    slices - the form of rounds 4-5.)"""
 
     @staticmethod
     def forward(ctx, n_parts, *args):
         tables, idxs = [t.contiguous() for t in args[:n_parts]], list(args[n_parts:])
         n = idxs[0].numel()
         out = torch.empty((n, sum(t.shape[1] for t in tables)), dtype=torch.float32, device=tables[0].device)
-        off = 0
-        for t, ix in zip(tables, idxs):
-            rows_op(ROWS_GATHER, ix, out[:, off:off + t.shape[1]], t)
-            off += t.shape[1]
+        ctx.one = CONCAT_ONE_LAUNCH and n_parts <= 4
+        if ctx.one:
+            rows_concat(0, out, tables, idxs)
+        else:
+            off = 0
+            for t, ix in zip(tables, idxs):
+                rows_op(ROWS_GATHER, ix, out[:, off:off + t.shape[1]], t)
+                off += t.shape[1]
         ctx.save_for_backward(*idxs)
         ctx.shapes = [tuple(t.shape) for t in tables]
         return out
@@ -208,6 +241,12 @@ class _ConcatRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         idxs = ctx.saved_tensors
+        if ctx.one:
+            g = g.contiguous()
+            grads = [torch.zeros(shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1 + k] else None for k, shape in enumerate(ctx.shapes)]
+            if any(t is not None for t in grads):
+                rows_concat(1, g, [t if t is not None else shape[1] for t, shape in zip(grads, ctx.shapes)], list(idxs))
+            return (None, *grads, *([None] * len(idxs)))
         if g.stride(1) != 1:
             g = g.contiguous()
         grads, off = [], 0

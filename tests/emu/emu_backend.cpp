@@ -83,6 +83,11 @@ static int be_launch_rows(const SssRowsArgs& r, void*) {
     for (int j = 0; j < r.width; j++) sss_rows_element(r, i, j, [](float* p, float v) { *p += v; });
   return 0;
 }
+static int be_launch_concat(const SssConcatArgs& r, void*) {
+  for (int64_t i = 0; i < r.n; i++)
+    for (int c = 0; c < r.width; c++) sss_concat_element(r, i, c, [](float* p, float v) { *p += v; });
+  return 0;
+}
 // sss_discounted_returns / sss_sequence_baselines on the host: the per-env / per-query functions of sss_returns.h in plain loops
 #include "sss_returns.h"
 static int be_launch_returns(const SssReturnsArgs& a, void*) {

@@ -209,6 +209,27 @@ def check_rows_ops(binding, device, n):
             sums = torch.full((rows, width), 7.0, device=device)
             rows_op(ROWS_SEGMENT_SUM, ptr, a2, sums, binding=binding)
             assert torch.allclose(sums, torch.zeros((rows, width), device=device).index_add_(0, owner, a2), rtol=1e-5, atol=1e-5)
+    # several tables side by side in one launch (sss_rows_concat): the two score networks' input rows and others, row counts on both
+    # sides of a wave's 64 rows, a part without indices, a part without a gradient
+    from spark_sched_sim_amd.train_kernels import rows_concat
+    for widths in ((5, 16, 16, 16), (35, 1), (3, 16, 16, 1), (64,), (1, 1, 1, 1), (21, 43)):
+        for m in sorted({1, 63, 64, 65, n}):
+            tabs = [rnd(max(3, m // 2) if k else m, w) for k, w in enumerate(widths)]
+            idxs = [None] + [torch.randint(0, t.shape[0], (m,), generator=gen).to(device) for t in tabs[1:]]
+            out = torch.full((m, sum(widths)), -3.0, device=device)
+            rows_concat(0, out, tabs, idxs, binding=binding)
+            assert torch.equal(out, torch.cat([t if ix is None else t[ix] for t, ix in zip(tabs, idxs)], -1)), (widths, m)
+            g = rnd(m, sum(widths))
+            accs = [t.clone() for t in tabs]
+            skip = len(widths) - 1 if len(widths) > 1 else -1
+            rows_concat(1, g, [a if k != skip else a.shape[1] for k, a in enumerate(accs)], idxs, binding=binding)
+            off = 0
+            for k, (t, a, ix) in enumerate(zip(tabs, accs, idxs)):
+                want = t if k == skip else (t + g[:, off:off + t.shape[1]] if ix is None else t.clone().index_add_(0, ix, g[:, off:off + t.shape[1]]))
+                assert torch.allclose(a, want, rtol=1e-5, atol=1e-5), (widths, m, k)
+                off += t.shape[1]
+    with pytest.raises(ValueError):
+        rows_concat(0, torch.empty((2, 70), device=device), [rnd(2, 35), rnd(2, 35)], [None, None], binding=binding)
     empty = torch.zeros((0,), dtype=torch.long, device=device)
     rows_op(ROWS_GATHER, empty, torch.empty((0, 16), device=device), rnd(4, 16), binding=binding)  # nothing to do: no launch
     with pytest.raises(ValueError):
