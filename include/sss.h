@@ -524,6 +524,12 @@ typedef struct sss_mlp_args {
   float* g1_dev;       /* backward */
   float* g2_dev;       /* backward */
   float* dx_dev;       /* backward, nullable */
+  /* the input rows in two pieces (sss_mlp_split_supported(in_dim); NULL otherwise): columns 0 .. in_dim - 17 from x_dev (rows of
+   * in_dim - 16 floats), the last 16 columns from x2_dev (rows of 16 floats) - the DAG encoder's torch.cat([x, h_node], -1)
+   * (schedulers/decima/scheduler.py:246-262) is never built. sss_mlp_forward and sss_mlp_backward_wgrad without stored activations
+   * only; dx2_dev (sss_mlp_backward_wgrad, instead of dx_dev): the gradient w.r.t. the x2 piece, f32[rows][16] */
+  const float* x2_dev;
+  float* dx2_dev;
 } sss_mlp_args;
 int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act);
 /* 1: for the (in_dim) -> 32 -> 16 -> 16 LeakyReLU MLP sss_mlp_forward may be called with a1_dev == a2_dev == NULL (the hidden
@@ -531,6 +537,8 @@ int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act);
  * instructions, same bits as the stored ones. Stored activations are two thirds of these kernels' memory traffic and 48 floats
  * per row of the update's memory (what autograd keeps alive for nn.Sequential in the reference, ppo.py:104-138). 0: this build keeps them. */
 int sss_mlp_recompute_supported(int in_dim);
+/* 1: sss_mlp_forward / sss_mlp_backward_wgrad of the (in_dim) -> 32 -> 16 -> 16 MLP take x2_dev / dx2_dev (see sss_mlp_args) */
+int sss_mlp_split_supported(int in_dim);
 int sss_mlp_forward(const sss_mlp_args* a, void* stream);
 int sss_mlp_backward(const sss_mlp_args* a, void* stream);
 /* sss_mlp_backward with the six parameter gradients in the same pass, for the (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU MLPs and

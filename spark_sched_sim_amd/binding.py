@@ -117,7 +117,7 @@ class SssCollectArgs(C.Structure):  # include/sss.h sss_collect_args
 class SssMlpArgs(C.Structure):  # include/sss.h sss_mlp_args
     _fields_ = [("rows", C.c_int64), ("in_dim", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
                 ("w_dev", C.c_void_p), ("x_dev", C.c_void_p), ("a1_dev", C.c_void_p), ("a2_dev", C.c_void_p), ("y_dev", C.c_void_p), ("dy_dev", C.c_void_p),
-                ("g1_dev", C.c_void_p), ("g2_dev", C.c_void_p), ("dx_dev", C.c_void_p)]
+                ("g1_dev", C.c_void_p), ("g2_dev", C.c_void_p), ("dx_dev", C.c_void_p), ("x2_dev", C.c_void_p), ("dx2_dev", C.c_void_p)]
 
 
 class SssRowsArgs(C.Structure):  # include/sss.h sss_rows_args
@@ -159,7 +159,7 @@ class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_step_bounded", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_recompute_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_rows_concat", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy", "sss_abi_sizeof"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_recompute_supported", "sss_mlp_split_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_rows_concat", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy", "sss_abi_sizeof"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 # the argument structures of include/sss.h and their mirrors here (Binding.check_abi)
 ABI_STRUCTS = {"sss_cfg": SssCfg, "sss_dims": SssDims, "sss_buffers": SssBuffers, "sss_decima_graph": SssDecimaGraph, "sss_decima_lists": SssDecimaLists,
@@ -204,6 +204,7 @@ class Binding:
         L.sss_collect_step.argtypes = [C.POINTER(SssCollectArgs), C.c_int, C.c_void_p]
         L.sss_mlp_supported.argtypes = [C.c_int] * 5
         L.sss_mlp_recompute_supported.argtypes = [C.c_int]
+        L.sss_mlp_split_supported.argtypes = [C.c_int]
         L.sss_mlp_forward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
         L.sss_mlp_backward.argtypes = [C.POINTER(SssMlpArgs), C.c_void_p]
         L.sss_mlp_wgrad_scratch.argtypes = [C.c_int]

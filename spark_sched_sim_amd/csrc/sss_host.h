@@ -763,7 +763,18 @@ static SssMlpArgs sss_mlp_args_of(const sss_mlp_args* a) {
   SssMlpArgs m;
   m.rows = a->rows, m.in_dim = a->in_dim, m.h1 = a->h1, m.h2 = a->h2, m.out_dim = a->out_dim, m.act = a->act, m.slope = a->slope;
   m.w = a->w_dev, m.x = a->x_dev, m.a1 = a->a1_dev, m.a2 = a->a2_dev, m.y = a->y_dev, m.dy = a->dy_dev, m.g1 = a->g1_dev, m.g2 = a->g2_dev, m.dx = a->dx_dev;
+  m.x2 = a->x2_dev, m.dx2 = a->dx2_dev;
   return m;
+}
+static int be_mlp_split_supported(int in_dim);
+extern "C" int sss_mlp_split_supported(int in_dim) { return be_mlp_split_supported(in_dim) && be_mlp_recompute_supported(in_dim); }
+// x2_dev / dx2_dev: only where sss_mlp_split_supported says so, only without stored hidden activations, dx2 only with x2 and without dx
+static int sss_mlp_check_split(const sss_mlp_args* a, bool forward) {
+  if (!a->x2_dev && !a->dx2_dev) return 0;
+  if (!sss_mlp_split_supported(a->in_dim) || a->a1_dev || a->a2_dev || !a->x2_dev || (forward && a->dx2_dev) || (a->dx2_dev && a->dx_dev))
+    return sss_fail(-31, "sss_mlp: an input in two pieces (x2_dev / dx2_dev) is for sss_mlp_forward / sss_mlp_backward_wgrad of the 21 -> 32 -> 16 -> 16 MLP without stored "
+                         "activations (sss_mlp_split_supported); dx2_dev excludes dx_dev");
+  return 0;
 }
 extern "C" int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int act) {
   const bool gnn = h1 == 32 && h2 == 16 && out_dim == 16 && act == 0, head = h1 == 64 && h2 == 64 && out_dim == 1 && act == 1;
@@ -771,12 +782,14 @@ extern "C" int sss_mlp_supported(int in_dim, int h1, int h2, int out_dim, int ac
 }
 extern "C" int sss_mlp_forward(const sss_mlp_args* a, void* stream) {
   if (int rc = sss_mlp_check(a, false)) return rc;
+  if (int rc = sss_mlp_check_split(a, true)) return rc;
   if (!sss_mlp_supported(a->in_dim, a->h1, a->h2, a->out_dim, a->act)) return sss_fail(-31, "sss_mlp: not one of the architecture's MLP shapes");
   if (int rc = be_launch_mlp(sss_mlp_args_of(a), 0, stream)) return sss_fail(-30, std::string("mlp forward launch failed: ") + be_error(rc));
   return 0;
 }
 extern "C" int sss_mlp_backward(const sss_mlp_args* a, void* stream) {
   if (int rc = sss_mlp_check(a, true)) return rc;
+  if (a->x2_dev || a->dx2_dev) return sss_fail(-31, "sss_mlp_backward: x2_dev / dx2_dev are for sss_mlp_backward_wgrad");
   if (!sss_mlp_supported(a->in_dim, a->h1, a->h2, a->out_dim, a->act)) return sss_fail(-31, "sss_mlp: not one of the architecture's MLP shapes");
   if (int rc = be_launch_mlp(sss_mlp_args_of(a), 1, stream)) return sss_fail(-30, std::string("mlp backward launch failed: ") + be_error(rc));
   return 0;
@@ -902,6 +915,7 @@ extern "C" int sss_mlp_backward_wgrad(const sss_mlp_args* a, float* acc_dev, voi
   SssMlpwShape s;
   if (!sss_mlpw_shape(a->in_dim, &s) || a->h1 != s.h1 || a->h2 != s.h2 || a->out_dim != s.out || a->act != s.act)
     return sss_fail(-31, "sss_mlp_backward_wgrad: (5 | 16 | 21) -> 32 -> 16 -> 16 LeakyReLU and (53 | 36) -> 64 -> 64 -> 1 Tanh MLPs only");
+  if (int rc = sss_mlp_check_split(a, false)) return rc;
   if (!a->a1_dev && (s.act != 0 || !be_mlp_recompute_supported(a->in_dim)))
     return sss_fail(-31, "sss_mlp_backward_wgrad: this build cannot recompute this MLP's hidden activations (a1_dev / a2_dev required)");
   if (int rc = be_launch_mlp_bwdw(sss_mlp_args_of(a), acc_dev, stream)) return sss_fail(-30, std::string("mlp backward launch failed: ") + be_error(rc));

@@ -27,6 +27,10 @@ struct SssMlpArgs {
   float* g1;         // backward: f32[rows, H1]
   float* g2;         // backward: f32[rows, H2]
   float* dx;         // backward: f32[rows, IN], or null (the input needs no gradient)
+  // a row of the input in two pieces (the DAG encoder's cat([x, h_node], -1) never built): columns 0 .. IN - 17 from x (rows of
+  // IN - 16 floats), columns IN - 16 .. IN - 1 from x2 (rows of 16 floats); dx2: the gradient of the x2 piece only (dx unused)
+  const float* x2;
+  float* dx2;
 };
 
 

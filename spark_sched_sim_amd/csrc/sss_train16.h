@@ -172,6 +172,12 @@ static int mlp16_launch(const SssMlpArgs& a, bool backward, void* stream) {
 // activations (a lane holds four consecutive neurons of its row: 16-byte stores); backward runs the chain the other way with
 // the transposed weights as A operands: G2^T = W3^T dY^T, G1^T = W2^T G2^T, dX^T = W1^T G1^T, each followed by the
 // activation's derivative taken from the stored activations - all in registers.
+// element c of input row `row`: from the one matrix x, or (x2 given, IN > 16) from the two pieces [x (IN - 16 wide) | x2 (16 wide)]
+template <int IN>
+SSS_DEV float mlp_x_at(const SssMlpArgs& a, int64_t row, int c) {
+  if (IN > 16 && a.x2) return c < IN - 16 ? a.x[row * (IN - 16) + c] : a.x2[row * 16 + c - (IN - 16)];
+  return a.x[row * IN + c];
+}
 template <int IN>
 __global__ __launch_bounds__(256) void sss_mlp_mfma_fwd_kernel(SssMlpArgs a) {
   constexpr int U = (IN + 15) / 16;
@@ -192,12 +198,11 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_fwd_kernel(SssMlpArgs a) {
     const bool valid = row < a.rows;
     mfma_f4 x0 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f}, x1 = x0;
     if (valid) {
-      const float* xr = a.x + row * IN;
       float v[4];
-      for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? xr[4 * q + r] : 0.0f;
+      for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? mlp_x_at<IN>(a, row, 4 * q + r) : 0.0f;
       x0 = mfma_f4{v[0], v[1], v[2], v[3]};
       if (U > 1) {
-        for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? xr[16 + 4 * q + r] : 0.0f;
+        for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? mlp_x_at<IN>(a, row, 16 + 4 * q + r) : 0.0f;
         x1 = mfma_f4{v[0], v[1], v[2], v[3]};
       }
     }
@@ -360,12 +365,11 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
       // the forward pass again, exactly as sss_mlp_mfma_fwd_kernel runs it
       mfma_f4 x0 = zero, x1 = zero;
       if (valid) {
-        const float* xr = a.x + row * IN;
         float v[4];
-        for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? xr[4 * q + r] : 0.0f;
+        for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? mlp_x_at<IN>(a, row, 4 * q + r) : 0.0f;
         x0 = mfma_f4{v[0], v[1], v[2], v[3]};
         if (U > 1) {
-          for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? xr[16 + 4 * q + r] : 0.0f;
+          for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? mlp_x_at<IN>(a, row, 16 + 4 * q + r) : 0.0f;
           x1 = mfma_f4{v[0], v[1], v[2], v[3]};
         }
       }
@@ -404,13 +408,20 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
     // (rows behind the end: dy = 0 -> g2 = g1 = 0, they add nothing below)
     *(mfma_f4*)(T + i * TS + 4 * q) = g2, *(mfma_f4*)(T + i * TS + 16 + 4 * q) = g10, *(mfma_f4*)(T + i * TS + 32 + 4 * q) = g11;
     if (RECOMPUTE) *(mfma_f4*)(T + i * TS + 48 + 4 * q) = a2, *(mfma_f4*)(T + i * TS + 64 + 4 * q) = a10, *(mfma_f4*)(T + i * TS + 80 + 4 * q) = a11;
-    if (a.dx) {
+    if (a.dx || (IN > 16 && a.dx2)) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         mfma_f4 dx = zero;
         dx = mfma16(t1[u][0][0], g10.x, dx), dx = mfma16(t1[u][0][1], g10.y, dx), dx = mfma16(t1[u][0][2], g10.z, dx), dx = mfma16(t1[u][0][3], g10.w, dx);
         dx = mfma16(t1[u][1][0], g11.x, dx), dx = mfma16(t1[u][1][1], g11.y, dx), dx = mfma16(t1[u][1][2], g11.z, dx), dx = mfma16(t1[u][1][3], g11.w, dx);
-        if (valid) {
+        if (valid && IN > 16 && a.dx2) {  // the gradient of the second piece only: columns IN - 16 .. IN - 1 -> dx2[row][0 .. 15]
+          const float vv[4] = {dx.x, dx.y, dx.z, dx.w};
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int c = 16 * u + 4 * q + r;
+            if (c >= IN - 16 && c < IN) a.dx2[row * 16 + c - (IN - 16)] = vv[r];
+          }
+        } else if (valid) {
           float* o = a.dx + row * IN + 16 * u + 4 * q;
           if (16 * u + 4 * q + 0 < IN) o[0] = dx.x;
           if (16 * u + 4 * q + 1 < IN) o[1] = dx.y;
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
       b1s[0] += A10, b1s[1] += A11;
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const float B1 = (ok && 16 * u + i < IN) ? a.x[grow * IN + 16 * u + i] : 0.0f;
+        const float B1 = (ok && 16 * u + i < IN) ? mlp_x_at<IN>(a, grow, 16 * u + i) : 0.0f;
         w1a[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A10, B1, w1a[0][u], 0, 0, 0), w1a[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A11, B1, w1a[1][u], 0, 0, 0);
       }
     }
@@ -889,6 +900,15 @@ static int be_mlp_recompute_supported(int in_dim) {
   return 0;  // (the 16-lanes-per-row comparison kernels keep the stored-activation form)
 #else
   return in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16;
+#endif
+}
+// whether the (GNN_NF + 16)-wide MLP takes its input rows in two pieces (SssMlpArgs.x2 / dx2): the matrix-core kernels with recomputation
+static int be_mlp_split_supported(int in_dim) {
+#ifdef SSS_TEST_VECTOR_FORMS
+  (void)in_dim;
+  return 0;
+#else
+  return in_dim == GNN_NF + 16;
 #endif
 }
 // whether sss_mlp_backward_wgrad takes the two policy heads (IN -> 64 -> 64 -> 1, Tanh; stored activations) as well

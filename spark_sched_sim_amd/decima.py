@@ -448,7 +448,9 @@ class _DagEncoder(nn.Module):
     def forward(self, h_node: torch.Tensor, g: dict[str, Any]) -> torch.Tensor:
         """per-job sums f32[J,emb] (scheduler.py:246-262)"""
         from .train_kernels import segment_sum
-        y = self.mlp(torch.cat([g["x"], h_node], -1))
+        from .train_kernels import KernelMLP
+        # (the update's kernels read a row's two pieces where they are: the [M, 21] concatenation and the slices of its gradient are never built)
+        y = self.mlp.forward_cat(g["x"], h_node) if isinstance(self.mlp, KernelMLP) else self.mlp(torch.cat([g["x"], h_node], -1))
         return segment_sum(y, g["node_job"], g["job_obs"].numel(), "sorted")  # (an observation's nodes are stored job by job)
 
 

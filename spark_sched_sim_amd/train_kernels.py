@@ -275,10 +275,10 @@ def pack_mlp(lin1: nn.Linear, lin2: nn.Linear, lin3: nn.Linear) -> torch.Tensor:
     return torch.cat([t.detach().float().contiguous().reshape(-1) for t in parts]).contiguous()
 
 
-def _mlp_args(dims, act, slope, rows, w, x=None, a1=None, a2=None, y=None, dy=None, g1=None, g2=None, dx=None):
+def _mlp_args(dims, act, slope, rows, w, x=None, a1=None, a2=None, y=None, dy=None, g1=None, g2=None, dx=None, x2=None, dx2=None):
     from .binding import SssMlpArgs
     p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    return SssMlpArgs(rows, dims[0], dims[1], dims[2], dims[3], act, slope, p(w), p(x), p(a1), p(a2), p(y), p(dy), p(g1), p(g2), p(dx))
+    return SssMlpArgs(rows, dims[0], dims[1], dims[2], dims[3], act, slope, p(w), p(x), p(a1), p(a2), p(y), p(dy), p(g1), p(g2), p(dx), p(x2), p(dx2))
 
 
 def _out(t, rows, width, dev):
@@ -301,22 +301,37 @@ def mlp_recompute(in_dim: int, binding=None) -> bool:
     return _RECOMPUTE[key]
 
 
-def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None, a1=None, a2=None, y=None, keep_hidden: bool = True):
+_SPLIT: dict = {}
+
+
+def mlp_split(in_dim: int, binding=None) -> bool:
+    """whether the library takes the (in_dim) -> 32 -> 16 -> 16 MLP's input rows in two pieces [x (in_dim - 16) | x2 (16)]
+    (include/sss.h sss_mlp_split_supported) - the concatenation is then never built"""
+    b = binding if binding is not None else _binding()
+    key = (id(b.lib), in_dim)
+    if key not in _SPLIT:
+        _SPLIT[key] = bool(SPLIT_INPUT and mlp_recompute(in_dim, b) and b.lib.sss_mlp_split_supported(in_dim))
+    return _SPLIT[key]
+
+
+def mlp_forward(x: torch.Tensor, packed: torch.Tensor, dims, act: int, slope: float, binding=None, a1=None, a2=None, y=None, keep_hidden: bool = True, x2=None):
     """(a1 f32[rows, H1], a2 f32[rows, H2], y f32[rows, OUT]) of `sss_mlp_forward` for x f32[rows, IN] (contiguous); written
     into the tensors given, or into new ones. `keep_hidden=False` (only where `mlp_recompute` says so): a1 / a2 are not stored
-    (returned as None) - the backward pass computes them again"""
+    (returned as None) - the backward pass computes them again. `x2` (only where `mlp_split` says so, with keep_hidden=False): the
+    input rows are [x f32[rows, IN - 16] | x2 f32[rows, 16]]"""
     import ctypes
 
     from .binding import device_of
     b = binding if binding is not None else _binding()
     rows, dev = x.shape[0], x.device
-    assert x.dim() == 2 and x.shape[1] == dims[0] and x.is_contiguous() and x.dtype == torch.float32
+    assert x.dim() == 2 and x.shape[1] == dims[0] - (16 if x2 is not None else 0) and x.is_contiguous() and x.dtype == torch.float32
+    assert x2 is None or (x2.shape == (rows, 16) and x2.is_contiguous() and x2.dtype == torch.float32 and not keep_hidden)
     if keep_hidden:
         a1, a2 = _out(a1, rows, dims[1], dev), _out(a2, rows, dims[2], dev)
     else:
         assert a1 is None and a2 is None
     y = _out(y, rows, dims[3], dev)
-    a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, y=y)
+    a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, y=y, x2=x2)
     with device_of(dev):
         b.check(b.lib.sss_mlp_forward(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
     return a1, a2, y
@@ -349,6 +364,9 @@ RECOMPUTE_HIDDEN = True
 # the two policy heads' backward pass likewise in one kernel with their parameter gradients (sss_mlp_head_mfma_bwdw_kernel) instead of
 # a backward launch that writes g1 / g2 and three weight-gradient launches that read them back
 FUSED_HEAD_WGRAD = True
+# the DAG encoder's MLP reads its input rows [x | h_node] from the two tensors (the 21-wide concatenation and the slices of its gradient
+# are never built)
+SPLIT_INPUT = True
 
 
 def mlp_wgrad_acc(in_dim: int, dev, binding=None) -> torch.Tensor | None:
@@ -360,21 +378,25 @@ def mlp_wgrad_acc(in_dim: int, dev, binding=None) -> torch.Tensor | None:
 
 
 def mlp_backward_wgrad(dy: torch.Tensor, x: torch.Tensor, a1: torch.Tensor, a2: torch.Tensor, packed: torch.Tensor, dims, slope: float, acc: torch.Tensor,
-                       want_dx: bool = True, binding=None, act: int = 0):
+                       want_dx: bool = True, binding=None, act: int = 0, x2=None):
     """`sss_mlp_backward_wgrad`: dx f32[rows, IN] | None for dy f32[rows, OUT]; the six parameter gradients are added to `acc`
-    (`act`: 0 LeakyReLU - the GNN-shaped MLPs; 1 Tanh - the two policy heads, stored activations required)"""
+    (`act`: 0 LeakyReLU - the GNN-shaped MLPs; 1 Tanh - the two policy heads, stored activations required). `x2` (see
+    `mlp_forward`): the input rows in two pieces; what is returned is then the gradient w.r.t. x2, f32[rows, 16]"""
     import ctypes
 
     from .binding import device_of
     b = binding if binding is not None else _binding()
     rows, dev = x.shape[0], x.device   # (a1 / a2 None: recomputed from x by the kernel)
     dy = dy.contiguous()
-    assert dy.shape == (rows, dims[3]) and x.shape == (rows, dims[0]) and x.is_contiguous() and dy.dtype == x.dtype == torch.float32
-    assert (a1 is None) == (a2 is None)
-    dx = torch.empty((rows, dims[0]), dtype=torch.float32, device=dev) if want_dx else None
+    assert dy.shape == (rows, dims[3]) and x.shape == (rows, dims[0] - (16 if x2 is not None else 0)) and x.is_contiguous() and dy.dtype == x.dtype == torch.float32
+    assert (a1 is None) == (a2 is None) and (x2 is None or (a1 is None and x2.shape == (rows, 16) and x2.is_contiguous() and x2.dtype == torch.float32))
+    dx = torch.empty((rows, 16 if x2 is not None else dims[0]), dtype=torch.float32, device=dev) if want_dx else None
     if rows == 0:
         return dx
-    a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, dy=dy, dx=dx)
+    if x2 is not None:
+        a = _mlp_args(dims, act, slope, rows, packed, x=x, dy=dy, x2=x2, dx2=dx)
+    else:
+        a = _mlp_args(dims, act, slope, rows, packed, x=x, a1=a1, a2=a2, dy=dy, dx=dx)
     with device_of(dev):
         b.check(b.lib.sss_mlp_backward_wgrad(ctypes.byref(a), acc.data_ptr(), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
     return dx
@@ -427,6 +449,26 @@ class _MlpFn(torch.autograd.Function):
         return dx, gw1, gb1, gw2, gb2, gw3, gb3, None, None, None
 
 
+class _MlpSplitFn(torch.autograd.Function):
+    """`_MlpFn` on rows [xa | xb] that exist as two tensors (xa f32[rows, IN - 16] without a gradient, xb f32[rows, 16]): no stored
+    hidden activations, the backward pass returns the gradient w.r.t. xb only"""
+
+    @staticmethod
+    def forward(ctx, xa, xb, w1, b1, w2, b2, w3, b3, packed, slope):
+        dims = (w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0])
+        _, _, y = mlp_forward(xa, packed, dims, 0, slope, keep_hidden=False, x2=xb)
+        ctx.save_for_backward(xa, xb, packed)
+        ctx.dims, ctx.slope = dims, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, packed = ctx.saved_tensors
+        acc = mlp_wgrad_acc(ctx.dims[0], dy.device)
+        dxb = mlp_backward_wgrad(dy.contiguous(), xa, None, None, packed, ctx.dims, ctx.slope, acc, want_dx=ctx.needs_input_grad[1], x2=xb)
+        return (None, dxb, *mlp_wgrad_finish(ctx.dims, acc), None, None)
+
+
 class KernelMLP(nn.Sequential):
     """Linear - act - Linear - act - Linear with the reference's module numbering; large float32 minibatches on the GPU go
     through the fused forward / backward kernels when the shape is one of the architecture's (`sss_mlp_supported`)"""
@@ -459,6 +501,18 @@ class KernelMLP(nn.Sequential):
         if getattr(self, "_pack_ver", None) != ver:
             self._pack, self._pack_ver = pack_mlp(l1, l2, l3), ver
         return self._pack
+
+    def forward_cat(self, xa: torch.Tensor, xb: torch.Tensor) -> torch.Tensor:
+        """`self(torch.cat([xa, xb], -1))` for 2-D xa (no gradient) and xb f32[rows, 16]: on the kernels without building the
+        concatenation where the library can (`mlp_split`), else exactly that"""
+        if (xa.is_cuda and xa.dtype == xb.dtype == torch.float32 and xa.dim() == xb.dim() == 2 and xb.shape[1] == 16 and xa.shape[0] >= MIN_ROWS and torch.is_grad_enabled()
+                and self[0].weight.requires_grad and not xa.requires_grad and FUSED_WGRAD):
+            spec = self._fused_spec()
+            dims = (self[0].in_features, self[0].out_features, self[2].out_features, self[4].out_features)
+            if spec and spec[0] == 0 and tuple(dims[1:]) == (32, 16, 16) and dims[0] == xa.shape[1] + 16 and mlp_split(dims[0]):
+                l1, l2, l3 = self[0], self[2], self[4]
+                return _MlpSplitFn.apply(xa.contiguous(), xb.contiguous(), l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, self._packed_for_step(), spec[1])
+        return self(torch.cat([xa, xb], -1))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS and torch.is_grad_enabled()

@@ -132,9 +132,20 @@ static int be_launch_wgrad(const SssWgradArgs& a, void*) {
 static float emu_act(int act, float v, float slope) { return act == 0 ? (v > 0.0f ? v : v * slope) : tanhf(v); }
 static float emu_act_grad(int act, float a, float slope) { return act == 0 ? (a > 0.0f ? 1.0f : slope) : 1.0f - a * a; }
 static int be_mlp_recompute_supported(int in_dim) { return in_dim == GNN_NF || in_dim == 16 || in_dim == GNN_NF + 16; }
+static int be_mlp_split_supported(int in_dim) { return in_dim == GNN_NF + 16; }
+// (an input in two pieces, SssMlpArgs.x2: the rows put together on the host, then the loops below)
+static std::vector<float> emu_mlp_joined_x(const SssMlpArgs& a) {
+  const int IN = a.in_dim, P = IN - 16;
+  std::vector<float> x((size_t)std::max<int64_t>(a.rows, 1) * IN);
+  for (int64_t r = 0; r < a.rows; r++)
+    for (int c = 0; c < IN; c++) x[r * IN + c] = c < P ? a.x[r * P + c] : a.x2[r * 16 + c - P];
+  return x;
+}
 static int be_launch_mlp(const SssMlpArgs& a0, int backward, void*) {
   // (forward without a1 / a2: the hidden activations are not kept - the backward pass recomputes them, sss_mlp_recompute_supported)
   SssMlpArgs a = a0;
+  std::vector<float> joined;
+  if (a.x2) joined = emu_mlp_joined_x(a0), a.x = joined.data(), a.x2 = nullptr;
   std::vector<float> tmp1, tmp2;
   if (!backward && !a.a1) tmp1.resize((size_t)std::max<int64_t>(a.rows, 1) * a.h1), tmp2.resize((size_t)std::max<int64_t>(a.rows, 1) * a.h2), a.a1 = tmp1.data(), a.a2 = tmp2.data();
   const int IN = a.in_dim, H1 = a.h1, H2 = a.h2, OUT = a.out_dim;
@@ -189,15 +200,23 @@ static int be_launch_mlp_bwdw(const SssMlpArgs& a0, float* acc, void*) {
   std::vector<float> g1((size_t)std::max<int64_t>(a0.rows, 1) * H1), g2((size_t)std::max<int64_t>(a0.rows, 1) * H2);
   SssMlpArgs a = a0;
   a.g1 = g1.data(), a.g2 = g2.data();
+  std::vector<float> joined, dx_full;
+  if (a.x2) {  // an input in two pieces: joined rows in, the second piece's columns of dx out (below)
+    joined = emu_mlp_joined_x(a0), a.x = joined.data(), a.x2 = nullptr;
+    if (a.dx2) dx_full.resize(joined.size()), a.dx = dx_full.data(), a.dx2 = nullptr;
+  }
   std::vector<float> r1, r2, ry;
   if (!a.a1) {  // the hidden activations were not stored: the forward pass again (same loops, same order)
     r1.resize(g1.size()), r2.resize(g2.size()), ry.resize((size_t)std::max<int64_t>(a0.rows, 1) * OUT);
-    SssMlpArgs f = a0;
+    SssMlpArgs f = a;
     f.a1 = r1.data(), f.a2 = r2.data(), f.y = ry.data();
     if (int rc = be_launch_mlp(f, 0, nullptr)) return rc;
     a.a1 = r1.data(), a.a2 = r2.data();
   }
   if (int rc = be_launch_mlp(a, 1, nullptr)) return rc;
+  if (a0.dx2)
+    for (int64_t r = 0; r < a.rows; r++)
+      for (int c = 0; c < 16; c++) a0.dx2[r * 16 + c] = dx_full[r * IN + IN - 16 + c];
   const size_t slots = H1 == 64 ? 512 : 2048;  // (csrc/sss_host.h SSS_MLPW_HEAD_SLOTS / SSS_MLPW_SLOTS)
   float* l3 = acc;
   float* l2 = l3 + slots * (OUT * H2 + OUT);

@@ -308,6 +308,26 @@ def test_recompute_entry_points_on_the_host_backend():
         assert torch.equal(mlp_backward_wgrad(dy, x, a1, a2, packed, dims, 0.2, acc_s, binding=b), mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_r, binding=b))
         for g_s, g_r in zip(mlp_wgrad_finish(dims, acc_s, binding=b), mlp_wgrad_finish(dims, acc_r, binding=b)):
             assert torch.equal(g_s, g_r)
+        # the input rows in two pieces (sss_mlp_split_supported: the DAG encoder's 21-wide MLP): the same y, the last 16 columns of dx,
+        # the same parameter gradients; refused for the other widths and together with stored activations
+        from spark_sched_sim_amd.train_kernels import mlp_split
+        assert mlp_split(in_dim, binding=b) == (in_dim == 21)
+        if in_dim == 21:
+            xa, xb = x[:, :5].contiguous(), x[:, 5:].contiguous()
+            assert torch.equal(mlp_forward(xa, packed, dims, 0, 0.2, binding=b, keep_hidden=False, x2=xb)[2], y)
+            acc_p = mlp_wgrad_acc(in_dim, "cpu", binding=b)
+            dxb = mlp_backward_wgrad(dy, xa, None, None, packed, dims, 0.2, acc_p, binding=b, x2=xb)
+            acc_j = mlp_wgrad_acc(in_dim, "cpu", binding=b)
+            assert torch.equal(dxb, mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_j, binding=b)[:, 5:])
+            for g_p, g_j in zip(mlp_wgrad_finish(dims, acc_p, binding=b), mlp_wgrad_finish(dims, acc_j, binding=b)):
+                assert torch.equal(g_p, g_j)
+            assert mlp_backward_wgrad(dy, xa, None, None, packed, dims, 0.2, acc_p, binding=b, x2=xb, want_dx=False) is None
+        else:
+            import ctypes
+
+            from spark_sched_sim_amd.train_kernels import _mlp_args
+            a = _mlp_args(dims, 0, 0.2, 41, packed, x=x, y=torch.empty((41, 16)), x2=torch.zeros((41, 16)))
+            assert b.lib.sss_mlp_forward(ctypes.byref(a), None) == -31
 
 
 def test_rows_entry_point_on_the_host_backend():

@@ -392,6 +392,32 @@ def test_recomputed_hidden_activations_give_the_stored_forms_bits():
             assert torch.equal(dx_s, dx_r), (in_dim, n)
         for g_s, g_r in zip(mlp_wgrad_finish(dims, acc_s), mlp_wgrad_finish(dims, acc_r)):
             assert torch.equal(g_s, g_r), in_dim
+        if in_dim == 21:  # the input rows in two pieces [x (5) | x2 (16)] (the DAG encoder; sss_mlp_split_supported): the same bits again
+            from spark_sched_sim_amd.train_kernels import mlp_split
+            assert mlp_split(21) and not mlp_split(16)
+            acc_p, acc_j = mlp_wgrad_acc(in_dim, dev), mlp_wgrad_acc(in_dim, dev)
+            for n in (300_007, 1_037, 15):
+                gen = torch.Generator(device=dev).manual_seed(400 + n)
+                x = torch.randn((n, in_dim), device=dev, generator=gen)
+                dy = torch.randn((n, 16), device=dev, generator=gen)
+                xa, xb = x[:, :5].contiguous(), x[:, 5:].contiguous()
+                assert torch.equal(mlp_forward(xa, packed, dims, 0, 0.2, keep_hidden=False, x2=xb)[2], mlp_forward(x, packed, dims, 0, 0.2, keep_hidden=False)[2])
+                dxb = mlp_backward_wgrad(dy, xa, None, None, packed, dims, 0.2, acc_p, x2=xb)
+                assert torch.equal(dxb, mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_j)[:, 5:]), n
+            for g_p, g_j in zip(mlp_wgrad_finish(dims, acc_p), mlp_wgrad_finish(dims, acc_j)):
+                assert torch.equal(g_p, g_j)
+            # ... and through autograd: KernelMLP.forward_cat against the module on the concatenation
+            xa = torch.randn((30_000, 5), device=dev)
+            xb = torch.randn((30_000, 16), device=dev, requires_grad=True)
+            xc = xb.detach().clone().requires_grad_(True)
+            w = torch.randn((30_000, 16), device=dev)
+            (mlp.forward_cat(xa, xb) * w).sum().backward()
+            got = {k: p.grad.clone() for k, p in mlp.named_parameters()}
+            mlp.zero_grad()
+            (mlp(torch.cat([xa, xc], -1)) * w).sum().backward()
+            assert torch.equal(xb.grad, xc.grad)
+            for k, p in mlp.named_parameters():
+                assert torch.equal(got[k], p.grad), k
 
 
 @pytest.mark.gpu
