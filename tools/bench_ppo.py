@@ -32,8 +32,15 @@ def main():
     ap.add_argument("--device-index", type=int, default=None)
     ap.add_argument("--collector-groups", type=int, default=1)
     ap.add_argument("--no-train", action="store_true", help="collections only (for a rocprofv3 kernel trace of the collection alone: tools/profile_ppo_rocprof.sh)")
+    ap.add_argument("--kernel-switch", action="append", default=[], metavar="NAME=0|1",
+                    help="set a module-level switch of spark_sched_sim_amd.train_kernels (FUSED_HEAD_WGRAD, CONCAT_ONE_LAUNCH, SPLIT_INPUT, INDEXED_ROWS, ...): A/B timing")
     a = ap.parse_args()
     import os
+    for sw in a.kernel_switch:
+        from spark_sched_sim_amd import train_kernels
+        name, val = sw.split("=")
+        assert hasattr(train_kernels, name), name
+        setattr(train_kernels, name, bool(int(val)))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # BASELINE config 5: `python tools/bench_ppo.py --gpus 8 --sequences 256 --rollouts 4`
         from spark_sched_sim_amd.distributed import launch_ranks
         raise SystemExit(launch_ranks(a.gpus, [osp.abspath(__file__)] + sys.argv[1:]))
