@@ -848,11 +848,12 @@ template <int IN>
 static int mlp_head_mfma_bwdw_launch(const SssMlpArgs& a, const SssMlpWgradAcc& acc, void* stream) {
   if (a.rows <= 0) return 0;
   const size_t lds = (size_t)MlpHeadW<IN>::TOTAL * sizeof(float);
-  static GnnGridCap cache;
-  static bool attr_set = false;
-  if (!attr_set) {  // (more than 64 KB of dynamic LDS per workgroup)
-    (void)hipFuncSetAttribute((const void*)sss_mlp_head_mfma_bwdw_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static GnnGridCap cache, attr;  // (per device, like the grid cap: a process may drive more than one GPU)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  if (dev < 0 || dev >= 16 || !__atomic_load_n(&attr.per_device[dev], __ATOMIC_RELAXED)) {  // more than 64 KB of dynamic LDS per workgroup: asked for once per device
+    if (hipFuncSetAttribute((const void*)sss_mlp_head_mfma_bwdw_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
+    if (dev >= 0 && dev < 16) __atomic_store_n(&attr.per_device[dev], 1, __ATOMIC_RELAXED);
   }
   const int64_t blocks = (a.rows + 63) / 64;
   int64_t cap = gnn_resident_workgroups(cache, (const void*)sss_mlp_head_mfma_bwdw_kernel<IN>, 256, lds, 256);
