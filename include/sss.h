@@ -526,7 +526,8 @@ typedef struct sss_mlp_args {
   float* dx_dev;       /* backward, nullable */
   /* the input rows in two pieces (sss_mlp_split_supported(in_dim); NULL otherwise): columns 0 .. in_dim - 17 from x_dev (rows of
    * in_dim - 16 floats), the last 16 columns from x2_dev (rows of 16 floats) - the DAG encoder's torch.cat([x, h_node], -1)
-   * (schedulers/decima/scheduler.py:246-262) is never built. sss_mlp_forward and sss_mlp_backward_wgrad without stored activations
+   * (schedulers/decima/scheduler.py:246-262) is never built; the first Linear then adds the x2 features first (the MLP on the
+   * concatenation up to the order of fp32 additions). sss_mlp_forward and sss_mlp_backward_wgrad without stored activations
    * only; dx2_dev (sss_mlp_backward_wgrad, instead of dx_dev): the gradient w.r.t. the x2 piece, f32[rows][16] */
   const float* x2_dev;
   float* dx2_dev;

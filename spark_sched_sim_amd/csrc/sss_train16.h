@@ -172,23 +172,46 @@ static int mlp16_launch(const SssMlpArgs& a, bool backward, void* stream) {
 // activations (a lane holds four consecutive neurons of its row: 16-byte stores); backward runs the chain the other way with
 // the transposed weights as A operands: G2^T = W3^T dY^T, G1^T = W2^T G2^T, dX^T = W1^T G1^T, each followed by the
 // activation's derivative taken from the stored activations - all in registers.
-// element c of input row `row`: from the one matrix x, or (x2 given, IN > 16) from the two pieces [x (IN - 16 wide) | x2 (16 wide)]
-template <int IN>
-SSS_DEV float mlp_x_at(const SssMlpArgs& a, int64_t row, int c) {
-  if (IN > 16 && a.x2) return c < IN - 16 ? a.x[row * (IN - 16) + c] : a.x2[row * 16 + c - (IN - 16)];
-  return a.x[row * IN + c];
-}
-template <int IN>
+// The input's 16-feature segments. One matrix x: segment u = columns 16 u .. 16 u + 15. Two pieces (SPLIT: x2 given, IN > 16 - the DAG
+// encoder's [x (IN - 16 wide) | x2 (16 wide)]): segment 0 = the 16 columns of x2 (one aligned 16-byte load per lane, and the only
+// segment whose gradient is wanted), segment 1 = the IN - 16 columns of x. The first Linear's sum then runs over the features in
+// that order (x2's first): the same numbers as the MLP on the concatenation up to the order of fp32 additions, forward and
+// recomputation alike.
+template <int IN, bool SPLIT>
+struct MlpSeg {
+  static constexpr int P = IN - 16;  // (SPLIT) width of the first piece
+  // column of W1 / of the joined row for feature f of segment u, or -1 behind the end
+  static SSS_DEV int col(int u, int f) { return SPLIT ? (u == 0 ? P + f : (f < P ? f : -1)) : (16 * u + f < IN ? 16 * u + f : -1); }
+  // feature f of segment u of row `row` (0 behind the end; no load under a condition)
+  static SSS_DEV float at(const SssMlpArgs& a, int64_t row, int u, int f) {
+    if (SPLIT) {
+      if (u == 0) return a.x2[row * 16 + f];
+      const float l = a.x[row * P + (f < P ? f : P - 1)];
+      return f < P ? l : 0.0f;
+    }
+    const int c = 16 * u + f;
+    const float l = a.x[row * IN + (c < IN ? c : IN - 1)];
+    return c < IN ? l : 0.0f;
+  }
+  // the lane's four features 4 q .. 4 q + 3 of segment u
+  static SSS_DEV mfma_f4 at4(const SssMlpArgs& a, int64_t row, int u, int q) {
+    if (SPLIT && u == 0) return *(const mfma_f4*)(a.x2 + row * 16 + 4 * q);
+    if (!SPLIT && IN % 4 == 0 && 16 * u + 16 <= IN) return *(const mfma_f4*)(a.x + row * IN + 16 * u + 4 * q);  // (a whole, aligned segment)
+    return mfma_f4{at(a, row, u, 4 * q), at(a, row, u, 4 * q + 1), at(a, row, u, 4 * q + 2), at(a, row, u, 4 * q + 3)};
+  }
+};
+template <int IN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void sss_mlp_mfma_fwd_kernel(SssMlpArgs a) {
   constexpr int U = (IN + 15) / 16;
+  using Seg = MlpSeg<IN, SPLIT>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   MfmaGnnMlp m;
-  m.load(a.w, lane, IN, 0, IN < 16 ? IN : 16);
+  m.load(a.w, lane, IN, SPLIT ? IN - 16 : 0, IN < 16 ? IN : 16);
   float s1[2][4];  // second input segment (IN > 16)
   if (U > 1) {
     MfmaGnnMlp m2;
-    m2.load(a.w, lane, IN, 16, IN - 16);
+    m2.load(a.w, lane, IN, SPLIT ? 0 : 16, IN - 16);
     for (int t = 0; t < 2; t++)
       for (int r = 0; r < 4; r++) s1[t][r] = m2.a1[t][r];
   }
@@ -197,14 +220,12 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_fwd_kernel(SssMlpArgs a) {
     const int64_t row = tile * 16 + j;
     const bool valid = row < a.rows;
     mfma_f4 x0 = mfma_f4{0.0f, 0.0f, 0.0f, 0.0f}, x1 = x0;
-    if (valid) {
-      float v[4];
-      for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? mlp_x_at<IN>(a, row, 4 * q + r) : 0.0f;
-      x0 = mfma_f4{v[0], v[1], v[2], v[3]};
-      if (U > 1) {
-        for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? mlp_x_at<IN>(a, row, 16 + 4 * q + r) : 0.0f;
-        x1 = mfma_f4{v[0], v[1], v[2], v[3]};
-      }
+    {
+      // (no load under a condition: a row behind the end reads the last row and is not stored, a column behind the end reads the last
+      // column and is replaced by 0 - a load inside `if (valid)` is a branch with a wait of its own behind it)
+      const int64_t rc = valid ? row : a.rows - 1;
+      x0 = Seg::at4(a, rc, 0, q);
+      if (U > 1) x1 = Seg::at4(a, rc, 1, q);
     }
     // the first Linear and its activation (kept: the backward pass needs them), then the rest of the chain
     mfma_f4 d0 = m.b1[0], d1 = m.b1[1];
@@ -319,9 +340,10 @@ struct SssMlpWgradAcc {  // per-workgroup slots: [SLOTS][N * M + N] per Linear
 // traffic, which is what bounds these kernels (profiles/r06_ppo.md), and 48 floats per MLP row of the update's peak memory. The
 // recomputed tiles come out in the layout the chain below wants (lane (i, q): neurons 4 q .. 4 q + 3 of row i) and go through the
 // per-wave LDS tile into the weight-gradient operand layout like g1 / g2 do.
-template <int IN, bool RECOMPUTE = false>
+template <int IN, bool RECOMPUTE = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, SssMlpWgradAcc acc) {
   constexpr int U = (IN + 15) / 16;
+  using Seg = MlpSeg<IN, SPLIT>;
   constexpr int NT = 3 + 2 * U;  // accumulator tiles: dW3, dW2 (two column tiles), dW1 (two row tiles x U column tiles)
   constexpr int TS = RECOMPUTE ? 112 : 48;  // floats per row of the LDS tile (112 = 16 mod 32: rows r, r + 1 of a half-wave's read sit on different banks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -329,10 +351,10 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
   MfmaGnnMlp fw;       // (RECOMPUTE only) the forward chain's operands
   float fs1[2][4];     // ... second input segment (IN > 16)
   if (RECOMPUTE) {
-    fw.load(a.w, lane, IN, 0, IN < 16 ? IN : 16);
+    fw.load(a.w, lane, IN, SPLIT ? IN - 16 : 0, IN < 16 ? IN : 16);
     if (U > 1) {
       MfmaGnnMlp m2;
-      m2.load(a.w, lane, IN, 16, IN - 16);
+      m2.load(a.w, lane, IN, SPLIT ? 0 : 16, IN - 16);
       for (int t = 0; t < 2; t++)
         for (int r = 0; r < 4; r++) fs1[t][r] = m2.a1[t][r];
     }
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
     for (int r = 0; r < 4; r++) t2[tp][r] = W2T[(16 * tp + i) * 16 + 4 * q + r];
   for (int u = 0; u < U; u++)
     for (int t = 0; t < 2; t++)
-      for (int r = 0; r < 4; r++) t1[u][t][r] = 16 * u + i < IN ? W1[(16 * t + 4 * q + r) * IN + 16 * u + i] : 0.0f;
+      for (int r = 0; r < 4; r++) t1[u][t][r] = Seg::col(u, i) >= 0 ? W1[(16 * t + 4 * q + r) * IN + Seg::col(u, i)] : 0.0f;
   __shared__ __attribute__((aligned(16))) float tr[4][16 * TS];  // per wave: [row][g2 (16) | g1 (32) | RECOMPUTE: a2 (16) | a1 (32)] of the tile
   __shared__ float red[NT * 256 + 64];
   float* T = tr[wave];
@@ -359,20 +381,17 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t row = tile * 16 + i;
     const bool valid = row < a.rows;
-    const mfma_f4 dy = valid ? *(const mfma_f4*)(a.dy + row * 16 + 4 * q) : zero;
+    // (no load under a condition - each would be a branch with a wait of its own behind it, one exposed round trip after the other: a row
+    // behind the end reads the last row, and dy = 0 there makes everything it contributes zero)
+    const int64_t rc = valid ? row : a.rows - 1;
+    const mfma_f4 dyl = *(const mfma_f4*)(a.dy + rc * 16 + 4 * q);
+    const mfma_f4 dy = valid ? dyl : zero;
     mfma_f4 a2, a10, a11;
     if (RECOMPUTE) {
       // the forward pass again, exactly as sss_mlp_mfma_fwd_kernel runs it
       mfma_f4 x0 = zero, x1 = zero;
-      if (valid) {
-        float v[4];
-        for (int r = 0; r < 4; r++) v[r] = 4 * q + r < IN ? mlp_x_at<IN>(a, row, 4 * q + r) : 0.0f;
-        x0 = mfma_f4{v[0], v[1], v[2], v[3]};
-        if (U > 1) {
-          for (int r = 0; r < 4; r++) v[r] = 16 + 4 * q + r < IN ? mlp_x_at<IN>(a, row, 16 + 4 * q + r) : 0.0f;
-          x1 = mfma_f4{v[0], v[1], v[2], v[3]};
-        }
-      }
+      x0 = Seg::at4(a, rc, 0, q);
+      if (U > 1) x1 = Seg::at4(a, rc, 1, q);
       mfma_f4 d0 = fw.b1[0], d1 = fw.b1[1];
       d0 = mfma16(fw.a1[0][0], x0.x, d0), d1 = mfma16(fw.a1[1][0], x0.x, d1);
       d0 = mfma16(fw.a1[0][1], x0.y, d0), d1 = mfma16(fw.a1[1][1], x0.y, d1);
@@ -392,9 +411,9 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
       e0 = mfma16(fw.a2[0][3], d0.w, e0), e1 = mfma16(fw.a2[1][3], d1.w, e1);
       a2 = leaky4(e0 + e1, a.slope), a10 = d0, a11 = d1;
     } else {
-      a2 = valid ? *(const mfma_f4*)(a.a2 + row * 16 + 4 * q) : zero;
-      a10 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 4 * q) : zero;
-      a11 = valid ? *(const mfma_f4*)(a.a1 + row * 32 + 16 + 4 * q) : zero;
+      a2 = *(const mfma_f4*)(a.a2 + rc * 16 + 4 * q);
+      a10 = *(const mfma_f4*)(a.a1 + rc * 32 + 4 * q);
+      a11 = *(const mfma_f4*)(a.a1 + rc * 32 + 16 + 4 * q);
     }
     mfma_f4 g2 = zero;
     g2 = mfma16(t3[0], dy.x, g2), g2 = mfma16(t3[1], dy.y, g2), g2 = mfma16(t3[2], dy.z, g2), g2 = mfma16(t3[3], dy.w, g2);
@@ -408,19 +427,14 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
     // (rows behind the end: dy = 0 -> g2 = g1 = 0, they add nothing below)
     *(mfma_f4*)(T + i * TS + 4 * q) = g2, *(mfma_f4*)(T + i * TS + 16 + 4 * q) = g10, *(mfma_f4*)(T + i * TS + 32 + 4 * q) = g11;
     if (RECOMPUTE) *(mfma_f4*)(T + i * TS + 48 + 4 * q) = a2, *(mfma_f4*)(T + i * TS + 64 + 4 * q) = a10, *(mfma_f4*)(T + i * TS + 80 + 4 * q) = a11;
-    if (a.dx || (IN > 16 && a.dx2)) {
+    if (SPLIT ? a.dx2 != nullptr : a.dx != nullptr) {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int u = 0; u < (SPLIT ? 1 : U); u++) {  // (SPLIT: the gradient of the x2 piece = segment 0 only)
         mfma_f4 dx = zero;
         dx = mfma16(t1[u][0][0], g10.x, dx), dx = mfma16(t1[u][0][1], g10.y, dx), dx = mfma16(t1[u][0][2], g10.z, dx), dx = mfma16(t1[u][0][3], g10.w, dx);
         dx = mfma16(t1[u][1][0], g11.x, dx), dx = mfma16(t1[u][1][1], g11.y, dx), dx = mfma16(t1[u][1][2], g11.z, dx), dx = mfma16(t1[u][1][3], g11.w, dx);
-        if (valid && IN > 16 && a.dx2) {  // the gradient of the second piece only: columns IN - 16 .. IN - 1 -> dx2[row][0 .. 15]
-          const float vv[4] = {dx.x, dx.y, dx.z, dx.w};
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int c = 16 * u + 4 * q + r;
-            if (c >= IN - 16 && c < IN) a.dx2[row * 16 + c - (IN - 16)] = vv[r];
-          }
+        if (SPLIT) {
+          if (valid) *(mfma_f4*)(a.dx2 + row * 16 + 4 * q) = dx;
         } else if (valid) {
           float* o = a.dx + row * IN + 16 * u + 4 * q;
           if (16 * u + 4 * q + 0 < IN) o[0] = dx.x;
@@ -435,19 +449,19 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) {
       const int r = 4 * s4 + q;
-      const int64_t grow = tile * 16 + r;
-      const bool ok = grow < a.rows;
-      // (RECOMPUTE: a row behind the end has dy = g = 0, so whatever its recomputed activations are multiplies zero)
-      const float A3 = ok ? a.dy[grow * 16 + i] : 0.0f, B3 = RECOMPUTE ? T[r * TS + 48 + i] : (ok ? a.a2[grow * 16 + i] : 0.0f);
+      const bool ok = tile * 16 + r < a.rows;
+      const int64_t grow = ok ? tile * 16 + r : a.rows - 1;  // (a row behind the end: the last row's finite values times its own zero gradients)
+      const float dyl3 = a.dy[grow * 16 + i];
+      const float A3 = ok ? dyl3 : 0.0f, B3 = RECOMPUTE ? T[r * TS + 48 + i] : a.a2[grow * 16 + i];
       w3a = __builtin_amdgcn_mfma_f32_16x16x4f32(A3, B3, w3a, 0, 0, 0), b3s += A3;
       const float A2 = T[r * TS + i];
-      const float B20 = RECOMPUTE ? T[r * TS + 64 + i] : (ok ? a.a1[grow * 32 + i] : 0.0f), B21 = RECOMPUTE ? T[r * TS + 80 + i] : (ok ? a.a1[grow * 32 + 16 + i] : 0.0f);
+      const float B20 = RECOMPUTE ? T[r * TS + 64 + i] : a.a1[grow * 32 + i], B21 = RECOMPUTE ? T[r * TS + 80 + i] : a.a1[grow * 32 + 16 + i];
       w2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, B20, w2a[0], 0, 0, 0), w2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, B21, w2a[1], 0, 0, 0), b2s += A2;
       const float A10 = T[r * TS + 16 + i], A11 = T[r * TS + 32 + i];
       b1s[0] += A10, b1s[1] += A11;
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const float B1 = (ok && 16 * u + i < IN) ? mlp_x_at<IN>(a, grow, 16 * u + i) : 0.0f;
+        const float B1 = Seg::at(a, grow, u, i);
         w1a[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A10, B1, w1a[0][u], 0, 0, 0), w1a[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A11, B1, w1a[1][u], 0, 0, 0);
       }
     }
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(256) void sss_mlp_mfma_bwdw_kernel(SssMlpArgs a, Ss
     else if (tile_id < 3) o2[n * 32 + 16 * (tile_id - 1) + m] += red[e];
     else {
       const int t = (tile_id - 3) / U, u = (tile_id - 3) % U;
-      if (16 * u + m < IN) o1[(16 * t + n) * IN + 16 * u + m] += red[e];
+      if (Seg::col(u, m) >= 0) o1[(16 * t + n) * IN + Seg::col(u, m)] += red[e];
     }
   }
   if (threadIdx.x < 16) o3[16 * 16 + threadIdx.x] += red[NT * 256 + threadIdx.x];
@@ -504,7 +518,9 @@ static int mlp_mfma_bwdw_launch(const SssMlpArgs& a, const SssMlpWgradAcc& acc, 
   if (a.rows <= 0) return 0;
   const int64_t wgs = (a.rows + 63) / 64;
   const unsigned grid = (unsigned)(wgs < SSS_MLPW_SLOTS ? wgs : SSS_MLPW_SLOTS);
-  if (!a.a1)  // the forward pass did not store the hidden activations: recompute them from x
+  if (IN > 16 && a.x2)  // (the input rows in two pieces: always without stored activations - sss_host.h sss_mlp_check_split)
+    hipLaunchKernelGGL((sss_mlp_mfma_bwdw_kernel<IN, true, (IN > 16)>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
+  else if (!a.a1)  // the forward pass did not store the hidden activations: recompute them from x
     hipLaunchKernelGGL((sss_mlp_mfma_bwdw_kernel<IN, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
   else
     hipLaunchKernelGGL((sss_mlp_mfma_bwdw_kernel<IN, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, acc);
@@ -517,14 +533,16 @@ static int mlp_mfma_launch(const SssMlpArgs& a, bool backward, void* stream) {
   const int64_t wgs = (a.rows + 63) / 64;
   // (one resident set of workgroups striding over the tiles, as the inference launches: sss_gnn_mfma.h gnn_resident_workgroups)
   static GnnGridCap cache_f, cache_b;
-  const int64_t cap_f = gnn_resident_workgroups(cache_f, (const void*)sss_mlp_mfma_fwd_kernel<IN>, 256, 0);
+  const int64_t cap_f = gnn_resident_workgroups(cache_f, (const void*)sss_mlp_mfma_fwd_kernel<IN, false>, 256, 0);
   const int64_t cap_b = gnn_resident_workgroups(cache_b, (const void*)sss_mlp_mfma_bwd_kernel<IN>, 256, 0);
   const int64_t cap = backward ? cap_b : cap_f;
   const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
   if (backward)
     hipLaunchKernelGGL(sss_mlp_mfma_bwd_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (IN > 16 && a.x2)
+    hipLaunchKernelGGL((sss_mlp_mfma_fwd_kernel<IN, (IN > 16)>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(sss_mlp_mfma_fwd_kernel<IN>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((sss_mlp_mfma_fwd_kernel<IN, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -557,7 +575,11 @@ __global__ __launch_bounds__(256) void sss_mlp_head_mfma_fwd_kernel(SssMlpArgs a
     for (int u = 0; u < U; u++) {
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = (valid && 16 * u + 4 * q + r < IN) ? a.x[row * IN + 16 * u + 4 * q + r] : 0.0f;
+      for (int r = 0; r < 4; r++) {  // (unconditional loads: see sss_mlp_mfma_fwd_kernel)
+        const int c = 16 * u + 4 * q + r;
+        const float l = a.x[(valid ? row : a.rows - 1) * IN + (c < IN ? c : IN - 1)];
+        v[r] = c < IN ? l : 0.0f;
+      }
       x[u] = mfma_f4{v[0], v[1], v[2], v[3]};
     }
     mfma_f4 d[4], e[4];

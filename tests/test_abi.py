@@ -103,7 +103,9 @@ def test_matrix_core_kernels_are_in_the_library_without_scratch(hip_lib):
             assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0 and m["sgpr_spill_count"] == 0, (k, m)
             assert m["vgpr_count"] <= vgpr_max, (k, m["vgpr_count"])
     # the recomputing backward kernels (round 6) are there for the three GNN shapes
-    assert sum("sss_mlp_mfma_bwdw_kernelILi" in k and "ELb1E" in k for k in md) == 3
+    assert sum("sss_mlp_mfma_bwdw_kernelILi" in k and "ELb1ELb0E" in k for k in md) == 3
+    # ... and the two-piece form of the 21-wide one (forward and backward)
+    assert any("sss_mlp_mfma_bwdw_kernelILi21ELb1ELb1E" in k for k in md) and any("sss_mlp_mfma_fwd_kernelILi21ELb1E" in k for k in md)
     # ... and the code really is matrix-core code (a build that silently lost the builtin would fall back to nothing: there is none)
     dis = subprocess.run([osp.join(LLVM_BIN, "llvm-objdump"), "-d", "--offloading", so], capture_output=True, text=True).stdout
     if "v_mfma" not in dis:  # (llvm-objdump of the host library does not show device code: look into the unbundled code objects)

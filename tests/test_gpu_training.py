@@ -392,7 +392,8 @@ def test_recomputed_hidden_activations_give_the_stored_forms_bits():
             assert torch.equal(dx_s, dx_r), (in_dim, n)
         for g_s, g_r in zip(mlp_wgrad_finish(dims, acc_s), mlp_wgrad_finish(dims, acc_r)):
             assert torch.equal(g_s, g_r), in_dim
-        if in_dim == 21:  # the input rows in two pieces [x (5) | x2 (16)] (the DAG encoder; sss_mlp_split_supported): the same bits again
+        if in_dim == 21:  # the input rows in two pieces [x (5) | x2 (16)] (the DAG encoder; sss_mlp_split_supported): the same numbers - the
+            # first Linear sums x2's features first (csrc/sss_train16.h MlpSeg), so equal up to the order of fp32 additions, not bit for bit
             from spark_sched_sim_amd.train_kernels import mlp_split
             assert mlp_split(21) and not mlp_split(16)
             acc_p, acc_j = mlp_wgrad_acc(in_dim, dev), mlp_wgrad_acc(in_dim, dev)
@@ -401,11 +402,14 @@ def test_recomputed_hidden_activations_give_the_stored_forms_bits():
                 x = torch.randn((n, in_dim), device=dev, generator=gen)
                 dy = torch.randn((n, 16), device=dev, generator=gen)
                 xa, xb = x[:, :5].contiguous(), x[:, 5:].contiguous()
-                assert torch.equal(mlp_forward(xa, packed, dims, 0, 0.2, keep_hidden=False, x2=xb)[2], mlp_forward(x, packed, dims, 0, 0.2, keep_hidden=False)[2])
+                close = lambda u, v: torch.allclose(u, v, rtol=1e-5, atol=1e-5 * max(1.0, float(v.abs().max())))  # noqa: E731
+                y_p = mlp_forward(xa, packed, dims, 0, 0.2, keep_hidden=False, x2=xb)[2]
+                assert close(y_p, mlp_forward(x, packed, dims, 0, 0.2, keep_hidden=False)[2])
+                assert torch.equal(y_p, mlp_forward(xa, packed, dims, 0, 0.2, keep_hidden=False, x2=xb)[2])
                 dxb = mlp_backward_wgrad(dy, xa, None, None, packed, dims, 0.2, acc_p, x2=xb)
-                assert torch.equal(dxb, mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_j)[:, 5:]), n
+                assert close(dxb, mlp_backward_wgrad(dy, x, None, None, packed, dims, 0.2, acc_j)[:, 5:]), n
             for g_p, g_j in zip(mlp_wgrad_finish(dims, acc_p), mlp_wgrad_finish(dims, acc_j)):
-                assert torch.equal(g_p, g_j)
+                assert g_p.shape == g_j.shape and torch.allclose(g_p, g_j, rtol=1e-4, atol=1e-4 * max(1.0, float(g_j.abs().max())))
             # ... and through autograd: KernelMLP.forward_cat against the module on the concatenation
             xa = torch.randn((30_000, 5), device=dev)
             xb = torch.randn((30_000, 16), device=dev, requires_grad=True)
@@ -415,9 +419,9 @@ def test_recomputed_hidden_activations_give_the_stored_forms_bits():
             got = {k: p.grad.clone() for k, p in mlp.named_parameters()}
             mlp.zero_grad()
             (mlp(torch.cat([xa, xc], -1)) * w).sum().backward()
-            assert torch.equal(xb.grad, xc.grad)
+            assert torch.allclose(xb.grad, xc.grad, rtol=1e-5, atol=1e-5)
             for k, p in mlp.named_parameters():
-                assert torch.equal(got[k], p.grad), k
+                assert torch.allclose(got[k], p.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(p.grad.abs().max()))), k
 
 
 @pytest.mark.gpu
