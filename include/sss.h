@@ -659,6 +659,27 @@ typedef struct sss_concat_args {
 } sss_concat_args;
 int sss_rows_concat(const sss_concat_args* a, void* stream);
 
+/* Log-probability of the recorded action and entropy of a categorical distribution per SEGMENT of a flat score array - the PPO
+ * update's evaluate_actions (schedulers/decima/utils.py:26-41 `evaluate`: segment softmax, torch.distributions' clamp of the
+ * probabilities to [eps, 1 - eps], log, the chosen entry, -sum p log p; scheduler.py:101-139 the same over the executor counts
+ * a job allows), forward (backward = 0: lg_dev, ent_dev written) and backward (backward = 1: g_scores_dev written from g_lg_dev,
+ * g_ent_dev). Segment s = rows ptr[s] .. ptr[s + 1] - 1 of scores_dev; chosen[s] counts inside the segment; an empty segment
+ * gives lg = ent = 0. den_eps is added to the sum of exponentials (1e-16 in decima/utils.py:35, 0 for torch.softmax). */
+typedef struct sss_segcat_args {
+  int64_t n_seg;
+  const float* scores_dev;   /* f32[rows] */
+  const int64_t* ptr_dev;    /* i64[n_seg + 1], non-decreasing */
+  const int64_t* chosen_dev; /* i64[n_seg] */
+  float den_eps;
+  int32_t pad_;
+  float* lg_dev;             /* forward out f32[n_seg] */
+  float* ent_dev;            /* forward out f32[n_seg] */
+  const float* g_lg_dev;     /* backward in f32[n_seg] */
+  const float* g_ent_dev;    /* backward in f32[n_seg] */
+  float* g_scores_dev;       /* backward out f32[rows] */
+} sss_segcat_args;
+int sss_segment_categorical(const sss_segcat_args* a, int backward, void* stream);
+
 const char* sss_last_error(void);
 void sss_destroy(sss_handle* h);
 

@@ -133,6 +133,11 @@ class SssConcatArgs(C.Structure):  # include/sss.h sss_concat_args
     _fields_ = [("n", C.c_int64), ("n_parts", C.c_int32), ("op", C.c_int32), ("out_dev", C.c_void_p), ("parts", SssConcatPart * 4)]
 
 
+class SssSegcatArgs(C.Structure):  # include/sss.h sss_segcat_args
+    _fields_ = [("n_seg", C.c_int64), ("scores_dev", C.c_void_p), ("ptr_dev", C.c_void_p), ("chosen_dev", C.c_void_p), ("den_eps", C.c_float), ("pad_", C.c_int32),
+                ("lg_dev", C.c_void_p), ("ent_dev", C.c_void_p), ("g_lg_dev", C.c_void_p), ("g_ent_dev", C.c_void_p), ("g_scores_dev", C.c_void_p)]
+
+
 class SssBitListArgs(C.Structure):  # include/sss.h sss_bit_list_args
     _fields_ = [("bits_dev", C.c_void_p), ("n", C.c_int64), ("n_layers", C.c_int32), ("chunk", C.c_int32), ("n_chunks", C.c_int32), ("phase", C.c_int32),
                 ("cnt_dev", C.c_void_p), ("off_dev", C.c_void_p), ("base", C.c_int64 * 32), ("out_dev", C.c_void_p)]
@@ -159,14 +164,14 @@ class SssArenaArgs(C.Structure):  # include/sss.h sss_arena_args
 
 EXPORTS = ["sss_query_dims", "sss_create", "sss_bind_buffers", "sss_reset", "sss_step", "sss_step_bounded", "sss_policy", "sss_rollout",
            "sss_decima_graph_build", "sss_decima_layer_lists", "sss_prefix_rows", "sss_decima_policy", "sss_decima_sample", "sss_gnn_launch",
-           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_recompute_supported", "sss_mlp_split_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_rows_concat", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy", "sss_abi_sizeof"]
+           "sss_linear_wgrad_scratch", "sss_linear_wgrad", "sss_mlp_supported", "sss_mlp_recompute_supported", "sss_mlp_split_supported", "sss_mlp_forward", "sss_mlp_backward", "sss_mlp_wgrad_scratch", "sss_mlp_backward_wgrad", "sss_mlp_wgrad_finish", "sss_collect_step", "sss_gnn_encode", "sss_rows_op", "sss_rows_concat", "sss_segment_categorical", "sss_bit_lists", "sss_arena_append", "sss_discounted_returns", "sss_sequence_baselines", "sss_last_error", "sss_destroy", "sss_abi_sizeof"]
 POLICY_IDS = {"fair": 0, "fifo": 1, "hash": 2}
 # the argument structures of include/sss.h and their mirrors here (Binding.check_abi)
 ABI_STRUCTS = {"sss_cfg": SssCfg, "sss_dims": SssDims, "sss_buffers": SssBuffers, "sss_decima_graph": SssDecimaGraph, "sss_decima_lists": SssDecimaLists,
                "sss_bit_list_args": SssBitListArgs, "sss_gnn_args": SssGnnArgs, "sss_decima_policy_args": SssDecimaPolicyArgs,
                "sss_decima_sample_args": SssDecimaSampleArgs, "sss_gnn_encode_args": SssGnnEncodeArgs, "sss_collect_args": SssCollectArgs,
                "sss_mlp_args": SssMlpArgs, "sss_arena_array": SssArenaArray, "sss_arena_args": SssArenaArgs, "sss_returns_args": SssReturnsArgs,
-               "sss_baseline_args": SssBaselineArgs, "sss_rows_args": SssRowsArgs, "sss_concat_part": SssConcatPart, "sss_concat_args": SssConcatArgs}
+               "sss_baseline_args": SssBaselineArgs, "sss_rows_args": SssRowsArgs, "sss_concat_part": SssConcatPart, "sss_concat_args": SssConcatArgs, "sss_segcat_args": SssSegcatArgs}
 
 
 def load_library(path: str | None = None) -> C.CDLL:
@@ -217,6 +222,7 @@ class Binding:
         L.sss_arena_append.argtypes = [C.POINTER(SssArenaArgs), C.c_void_p]
         L.sss_rows_op.argtypes = [C.POINTER(SssRowsArgs), C.c_void_p]
         L.sss_rows_concat.argtypes = [C.POINTER(SssConcatArgs), C.c_void_p]
+        L.sss_segment_categorical.argtypes = [C.POINTER(SssSegcatArgs), C.c_int, C.c_void_p]
         L.sss_last_error.restype = C.c_char_p
         L.sss_destroy.argtypes = [C.c_void_p]
         L.sss_abi_sizeof.argtypes = [C.c_char_p]

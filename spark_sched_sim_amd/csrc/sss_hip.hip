@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256) void sss_collect_kernel(SssCollectArgs a, int 
 }
 static int be_launch_rows(const SssRowsArgs& r, void* stream) { return sss_rows_launch(r, stream); }
 static int be_launch_concat(const SssConcatArgs& r, void* stream) { return sss_concat_launch(r, stream); }
+#include "sss_segcat.h"
+static int be_launch_segcat(const SssSegcatArgs& a, int backward, void* stream) { return sss_segcat_launch(a, backward, stream); }
 #include "sss_returns.h"
 static int be_launch_returns(const SssReturnsArgs& a, void* stream) {
   hipLaunchKernelGGL(sss_returns_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);

@@ -322,7 +322,7 @@ extern "C" int sss_abi_sizeof(const char* name) {
   SSS_ABI_SIZE(sss_cfg) SSS_ABI_SIZE(sss_dims) SSS_ABI_SIZE(sss_buffers) SSS_ABI_SIZE(sss_decima_graph) SSS_ABI_SIZE(sss_decima_lists)
   SSS_ABI_SIZE(sss_bit_list_args) SSS_ABI_SIZE(sss_gnn_args) SSS_ABI_SIZE(sss_decima_policy_args) SSS_ABI_SIZE(sss_decima_sample_args)
   SSS_ABI_SIZE(sss_gnn_encode_args) SSS_ABI_SIZE(sss_collect_args) SSS_ABI_SIZE(sss_mlp_args) SSS_ABI_SIZE(sss_arena_array)
-  SSS_ABI_SIZE(sss_arena_args) SSS_ABI_SIZE(sss_returns_args) SSS_ABI_SIZE(sss_baseline_args) SSS_ABI_SIZE(sss_rows_args) SSS_ABI_SIZE(sss_concat_part) SSS_ABI_SIZE(sss_concat_args)
+  SSS_ABI_SIZE(sss_arena_args) SSS_ABI_SIZE(sss_returns_args) SSS_ABI_SIZE(sss_baseline_args) SSS_ABI_SIZE(sss_rows_args) SSS_ABI_SIZE(sss_concat_part) SSS_ABI_SIZE(sss_concat_args) SSS_ABI_SIZE(sss_segcat_args)
 #undef SSS_ABI_SIZE
   return -1;
 }
@@ -861,6 +861,20 @@ extern "C" int sss_rows_op(const sss_rows_args* a, void* stream) {
   r.n = a->n, r.ld_a = a->ld_a, r.width = a->width, r.op = a->op, r.idx = a->idx_dev, r.a = a->a_dev, r.b = a->b_dev, r.c = a->c_dev;
   if (r.n == 0) return 0;
   if (int rc = be_launch_rows(r, stream)) return sss_fail(-30, std::string("rows launch failed: ") + be_error(rc));
+  return 0;
+}
+
+#include "sss_segcat.h"
+static int be_launch_segcat(const SssSegcatArgs& a, int backward, void* stream);
+extern "C" int sss_segment_categorical(const sss_segcat_args* a, int backward, void* stream) {
+  if (!a || !a->scores_dev || !a->ptr_dev || !a->chosen_dev) return sss_fail(-1, "NULL argument");
+  if (a->n_seg < 0) return sss_fail(-38, "sss_segment_categorical: negative segment count");
+  if (backward ? (!a->g_lg_dev || !a->g_ent_dev || !a->g_scores_dev) : (!a->lg_dev || !a->ent_dev)) return sss_fail(-1, "NULL argument");
+  if (a->n_seg == 0) return 0;
+  SssSegcatArgs r;
+  r.n_seg = a->n_seg, r.scores = a->scores_dev, r.ptr = a->ptr_dev, r.chosen = a->chosen_dev, r.den_eps = a->den_eps, r.lg = a->lg_dev, r.ent = a->ent_dev;
+  r.g_lg = a->g_lg_dev, r.g_ent = a->g_ent_dev, r.g_scores = a->g_scores_dev;
+  if (int rc = be_launch_segcat(r, backward, stream)) return sss_fail(-30, std::string("segment categorical launch failed: ") + be_error(rc));
   return 0;
 }
 

@@ -892,6 +892,12 @@ class DecimaPolicy(nn.Module):
         (count <= the job's cap) reach the softmax or carry a gradient, so only those rows are built and evaluated here - at
         BASELINE config 5 a job allows 7 of 50 counts on average, and the k x E form was a fifth of a PPO update's device time
         (profiles/r04_ppo.md). A row's score does not depend on the other rows of the call: the values are the same."""
+        s, owner, count, caps = self.exec_score_rows(g, h, job_gid)
+        return torch.full((job_gid.numel(), self.num_executors), float("-inf"), dtype=s.dtype, device=s.device).index_put((owner, count), s)
+
+    def exec_score_rows(self, g: dict[str, Any], h: dict[str, torch.Tensor], job_gid: torch.Tensor):
+        """the allowed (job, count) pairs of `exec_scores` as flat rows, job after job: (scores f32[rows], owner i64[rows] = index into
+        job_gid, count i64[rows] = executor count - 1, caps i64[k] = rows per job)"""
         from .train_kernels import concat_rows
         E = self.num_executors
         base = torch.cat([g["x"][g["job_first"][job_gid], :NUM_DAG_FEATURES], h["dag"].index_select(0, job_gid), h["glob"].index_select(0, g["job_obs"][job_gid])], -1)
@@ -902,8 +908,7 @@ class DecimaPolicy(nn.Module):
         owner = torch.repeat_interleave(torch.arange(k, device=dev), caps, output_size=total)
         count = torch.arange(total, device=dev) - (torch.cumsum(caps, 0) - caps)[owner]
         inp = concat_rows([(base, owner), (acts[:, None], count)])
-        s = self.exec_policy_network.mlp_score(inp).squeeze(-1)
-        return torch.full((k, E), float("-inf"), dtype=s.dtype, device=dev).index_put((owner, count), s)
+        return self.exec_policy_network.mlp_score(inp).squeeze(-1), owner, count, caps
 
     @torch.no_grad()
     def act(self, g: dict[str, Any], generator: torch.Generator | None = None, greedy: bool = False, fresh_outputs: bool = False) -> dict[str, torch.Tensor]:
@@ -1053,11 +1058,23 @@ class DecimaPolicy(nn.Module):
         h = self.encode(g, per_obs_skip=False)
         s, idx = self.stage_scores(g, h)
         owner = g["node_obs"][idx]
+        job_gid = _excl_cumsum(g["obs_jobs"]) + job_idx
+        norm = (self.num_executors * g["obs_nodes"]).to(s.dtype).log()
+        from . import train_kernels as tk
+        if tk.SEGMENT_CATEGORICAL and s.is_cuda and s.dtype == torch.float32 and s.numel() >= tk.MIN_ROWS:
+            # one launch per softmax and pass (csrc/sss_segcat.h): the schedulable stages of an observation are consecutive rows of s (idx
+            # ascends), the allowed executor counts of its job consecutive rows of the flat executor scores
+            from .train_kernels import segment_offsets
+            stage_lg, stage_ent = tk.segment_categorical(s, segment_offsets(owner, n_obs), stage_sel, 1e-16)
+            se, _, _, caps = self.exec_score_rows(g, h, job_gid)
+            ptr_e = torch.zeros(caps.numel() + 1, dtype=torch.int64, device=s.device)
+            ptr_e[1:] = torch.cumsum(caps, 0)
+            exec_lg, exec_ent = tk.segment_categorical(se, ptr_e, exec_sel, 0.0)
+            return {"lgprobs": stage_lg + exec_lg, "entropies": (stage_ent + exec_ent) / norm}
         p, lp = _segment_log_softmax(s, owner, n_obs)
         n_acts = torch.zeros(n_obs, dtype=torch.long, device=s.device).index_add_(0, owner, torch.ones_like(owner))
         stage_lg = lp[_excl_cumsum(n_acts) + stage_sel]
         stage_ent = -torch.zeros(n_obs, dtype=s.dtype, device=s.device).index_add_(0, owner, lp * p)
-        job_gid = _excl_cumsum(g["obs_jobs"]) + job_idx
         es = self.exec_scores(g, h, job_gid)
         allowed = torch.isfinite(es)
         pe = torch.softmax(es, 1)
@@ -1066,7 +1083,6 @@ class DecimaPolicy(nn.Module):
         lpe = pe.log()
         exec_lg = lpe.gather(1, exec_sel[:, None])[:, 0]
         exec_ent = -(lpe * pe * allowed).sum(1)
-        norm = (self.num_executors * g["obs_nodes"]).to(s.dtype).log()
         return {"lgprobs": stage_lg + exec_lg, "entropies": (stage_ent + exec_ent) / norm}
 
     def update_parameters(self, loss: torch.Tensor | None = None) -> None:

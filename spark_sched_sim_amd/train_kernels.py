@@ -269,6 +269,49 @@ def concat_rows(parts) -> torch.Tensor:
     return torch.cat([t.index_select(0, ix) for t, ix in parts], -1)
 
 
+SEGMENT_CATEGORICAL = True  # evaluate_actions' log-probabilities and entropies by one launch per pass over the segments (sss_segment_categorical)
+
+
+def _segcat_call(backward: int, scores, ptr, chosen, den_eps, lg=None, ent=None, g_lg=None, g_ent=None, g_scores=None, binding=None) -> None:
+    import ctypes
+
+    from .binding import SssSegcatArgs, device_of
+    b = binding if binding is not None else _binding()
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    a = SssSegcatArgs(chosen.numel(), p(scores), p(ptr), p(chosen), den_eps, 0, p(lg), p(ent), p(g_lg), p(g_ent), p(g_scores))
+    dev = scores.device
+    with device_of(dev):
+        b.check(b.lib.sss_segment_categorical(ctypes.byref(a), backward, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0))
+
+
+class _SegmentCategoricalFn(torch.autograd.Function):
+    """(log of the clamped probability of row ptr[s] + chosen[s], -sum p log p) of the softmax inside every segment s of `scores`
+    (include/sss.h sss_segment_categorical; csrc/sss_segcat.h) - decima/utils.py:26-41 `evaluate` with torch.distributions' clamp"""
+
+    @staticmethod
+    def forward(ctx, scores, ptr, chosen, den_eps, binding):
+        scores = scores.contiguous()
+        n = chosen.numel()
+        lg, ent = torch.empty(n, dtype=torch.float32, device=scores.device), torch.empty(n, dtype=torch.float32, device=scores.device)
+        _segcat_call(0, scores, ptr, chosen, den_eps, lg=lg, ent=ent, binding=binding)
+        ctx.save_for_backward(scores, ptr, chosen)
+        ctx.den_eps, ctx.binding = den_eps, binding
+        return lg, ent
+
+    @staticmethod
+    def backward(ctx, g_lg, g_ent):
+        scores, ptr, chosen = ctx.saved_tensors
+        g = torch.zeros_like(scores)  # (rows outside every segment - there are none when ptr covers the array - keep 0)
+        _segcat_call(1, scores, ptr, chosen, ctx.den_eps, g_lg=g_lg.contiguous().float(), g_ent=g_ent.contiguous().float(), g_scores=g, binding=ctx.binding)
+        return g, None, None, None, None
+
+
+def segment_categorical(scores: torch.Tensor, ptr: torch.Tensor, chosen: torch.Tensor, den_eps: float, binding=None):
+    """(lg f32[n_seg], ent f32[n_seg]) for scores f32[rows], ptr i64[n_seg + 1] (row offsets), chosen i64[n_seg]"""
+    assert scores.dtype == torch.float32 and scores.dim() == 1 and ptr.dtype == chosen.dtype == torch.int64 and ptr.numel() == chosen.numel() + 1
+    return _SegmentCategoricalFn.apply(scores, ptr.contiguous(), chosen.contiguous(), float(den_eps), binding)
+
+
 def pack_mlp(lin1: nn.Linear, lin2: nn.Linear, lin3: nn.Linear) -> torch.Tensor:
     """[W1, b1, W2^T, b2, W3, b3] as one flat tensor (include/sss.h sss_gnn_launch / sss_mlp_forward)"""
     parts = [lin1.weight, lin1.bias, lin2.weight.t(), lin2.bias, lin3.weight, lin3.bias]

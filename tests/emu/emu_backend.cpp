@@ -88,6 +88,12 @@ static int be_launch_concat(const SssConcatArgs& r, void*) {
     for (int c = 0; c < r.width; c++) sss_concat_element(r, i, c, [](float* p, float v) { *p += v; });
   return 0;
 }
+// sss_segment_categorical on the host: the per-segment function of sss_segcat.h in a plain loop
+#include "sss_segcat.h"
+static int be_launch_segcat(const SssSegcatArgs& a, int backward, void*) {
+  for (int64_t s = 0; s < a.n_seg; s++) segcat_segment(a, s, backward != 0);
+  return 0;
+}
 // sss_discounted_returns / sss_sequence_baselines on the host: the per-env / per-query functions of sss_returns.h in plain loops
 #include "sss_returns.h"
 static int be_launch_returns(const SssReturnsArgs& a, void*) {

@@ -189,7 +189,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     pairs = {"sss_cfg": B.SssCfg, "sss_dims": B.SssDims, "sss_buffers": B.SssBuffers, "sss_decima_graph": B.SssDecimaGraph,
              "sss_decima_lists": B.SssDecimaLists, "sss_decima_policy_args": B.SssDecimaPolicyArgs,
              "sss_decima_sample_args": B.SssDecimaSampleArgs, "sss_gnn_args": B.SssGnnArgs, "sss_mlp_args": B.SssMlpArgs, "sss_collect_args": B.SssCollectArgs, "sss_gnn_encode_args": B.SssGnnEncodeArgs, "sss_rows_args": B.SssRowsArgs, "sss_arena_args": B.SssArenaArgs, "sss_arena_array": B.SssArenaArray, "sss_returns_args": B.SssReturnsArgs, "sss_baseline_args": B.SssBaselineArgs, "sss_bit_list_args": B.SssBitListArgs,
-             "sss_concat_part": B.SssConcatPart, "sss_concat_args": B.SssConcatArgs}
+             "sss_concat_part": B.SssConcatPart, "sss_concat_args": B.SssConcatArgs, "sss_segcat_args": B.SssSegcatArgs}
     header = open(osp.join(ROOT, "include", "sss.h")).read()
     assert set(re.findall(r"}\s*(sss_[a-z_]+);", header)) == set(pairs), "a struct of the header has no ctypes mirror (or vice versa)"
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{osp.join(ROOT, "include", "sss.h")}"', "int main(void) {"]

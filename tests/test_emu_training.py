@@ -342,6 +342,17 @@ def test_rows_entry_point_on_the_host_backend():
     check_rows_ops(Binding(load_emu()), "cpu", n=300)
 
 
+def test_segment_categorical_entry_point_on_the_host_backend():
+    """include/sss.h sss_segment_categorical through the emulator library's host loop (the per-segment function the gfx950 kernel runs,
+    csrc/sss_segcat.h) against the tensor-op forms of evaluate_actions"""
+    from training_util import check_segment_categorical
+
+    from emu_util import load_emu
+    from spark_sched_sim_amd.binding import Binding
+
+    check_segment_categorical(Binding(load_emu()), "cpu", n_seg=500)
+
+
 def test_collection_recorded_on_the_device_equals_the_synchronous_one():
     """training_util.check_record_on_device on the emulator library"""
     from training_util import check_record_on_device

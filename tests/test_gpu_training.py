@@ -425,6 +425,52 @@ def test_recomputed_hidden_activations_give_the_stored_forms_bits():
 
 
 @pytest.mark.gpu
+def test_segment_categorical_matches_the_tensor_op_forms():
+    """sss_segcat_kernel (csrc/sss_segcat.h) against the tensor-op forms of evaluate_actions; then evaluate_actions itself with and
+    without it on a recorded minibatch: log-probabilities, entropies and every parameter's gradient"""
+    from training_util import check_segment_categorical
+
+    from spark_sched_sim_amd.binding import Binding
+
+    check_segment_categorical(Binding(), "cuda:0", n_seg=70_001)
+    # evaluate_actions on a recorded graph (2048 observations, > 8192 schedulable stages), the kernel form against the tensor-op form
+    from decima_util import AGENT
+    from spark_sched_sim_amd import VecSparkSchedSimEnv, train_kernels, workload
+    from spark_sched_sim_amd.decima import DecimaPolicy
+
+    dev = torch.device("cuda:0")
+    cfg = dict(num_executors=10, job_arrival_cap=50, job_arrival_rate=4.0e-5, moving_delay=2000.0, warmup_delay=1000.0)
+    env = VecSparkSchedSimEnv(cfg, 2048, device="cuda:0", pack=workload.default_pack(), auto_reset=True)
+    env.reset(seed=11)
+    env.rollout("fair", 150)
+    g = env.decima_graph(None)
+    torch.manual_seed(5)
+    pol = DecimaPolicy(num_executors=10, **AGENT).to(dev)
+    a = pol.act(g, torch.Generator(device=dev).manual_seed(1), fresh_outputs=True)
+    keep = a["any_stage"].nonzero(as_tuple=True)[0]
+    from spark_sched_sim_amd.decima import select_observations
+    sub = select_observations(g, keep)
+    acts = [a[k][keep].long() for k in ("stage_sel", "job_idx", "exec_sel")]
+    assert int(sub["stage_mask"].sum()) >= train_kernels.MIN_ROWS
+    w1, w2 = torch.randn(keep.numel(), device=dev), torch.randn(keep.numel(), device=dev)
+    out = {}
+    for flag in (True, False):
+        train_kernels.SEGMENT_CATEGORICAL = flag
+        pol.zero_grad()
+        res = pol.evaluate_actions(sub, *acts)
+        (res["lgprobs"] * w1 + res["entropies"] * w2).sum().backward()
+        out[flag] = (res["lgprobs"].detach().clone(), res["entropies"].detach().clone(), {k: p.grad.clone() for k, p in pol.named_parameters()})
+    train_kernels.SEGMENT_CATEGORICAL = True
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-5, atol=2e-5) and torch.allclose(out[True][1], out[False][1], rtol=1e-5, atol=2e-5)
+    # (the sampled log-probabilities of pol.act are those of evaluate_actions on the same actions)
+    assert torch.allclose(out[True][0], a["lgprob"][keep], rtol=1e-4, atol=1e-4)
+    for k in out[True][2]:
+        x, y = out[True][2][k], out[False][2][k]
+        assert torch.allclose(x, y, rtol=2e-3, atol=2e-3 * max(1.0, float(y.abs().max()))), (k, float((x - y).abs().max()), float(y.abs().max()))
+    env.close()
+
+
+@pytest.mark.gpu
 def test_record_kernels_match_the_tensor_op_forms():
     """sss_returns_kernel / sss_baseline_kernel (csrc/sss_returns.h) against the tensor-op forms, bit for bit"""
     from training_util import check_record_kernels

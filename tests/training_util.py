@@ -416,3 +416,49 @@ def check_record_on_device_with_a_failing_env(device, lib, num_envs=6):
             assert torch.equal(getattr(ra, name), getattr(rb, name)), name
     assert int(two[True][2].active.sum()) > 0
     num_envs = num_envs_saved
+
+
+def check_segment_categorical(binding, device, n_seg):
+    """`train_kernels.segment_categorical` (include/sss.h sss_segment_categorical) against the tensor-op forms of
+    `DecimaPolicy.evaluate_actions` - decima._segment_log_softmax + index_add_ for the stage softmax (den_eps 1e-16), torch.softmax +
+    clamp + log for the executor softmax (den_eps 0) - values and, through a random linear functional of (lg, ent), the gradients
+    w.r.t. the scores; empty segments, one-row segments, a probability small enough for the clamp to bite"""
+    from spark_sched_sim_amd.decima import _excl_cumsum, _segment_log_softmax
+    from spark_sched_sim_amd.train_kernels import segment_categorical
+
+    gen = torch.Generator().manual_seed(23)
+    sizes = torch.randint(0, 12, (n_seg,), generator=gen)
+    sizes[0], sizes[1], sizes[-1] = 1, 0, 0
+    ptr = torch.zeros(n_seg + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(sizes, 0)
+    rows = int(ptr[-1])
+    scores = (torch.randn(rows, generator=gen) * 3.0)
+    big = int(torch.argmax(sizes))
+    scores[int(ptr[big])] = -40.0  # (its probability falls below eps: the clamp bites, no gradient through it)
+    chosen = (torch.rand(n_seg, generator=gen) * sizes.clamp(min=1)).long().clamp(max=(sizes - 1).clamp(min=0))
+    owner = torch.repeat_interleave(torch.arange(n_seg), sizes)
+    w_lg, w_ent = torch.randn(n_seg, generator=gen), torch.randn(n_seg, generator=gen)
+    full = sizes > 0
+    ptr_d, chosen_d = ptr.to(device), chosen.to(device)
+    for den_eps in (1e-16, 0.0):
+        s_ref = scores.clone().to(device).requires_grad_(True)
+        if den_eps:
+            p, lp = _segment_log_softmax(s_ref, owner.to(device), n_seg)
+        else:  # torch.softmax over the padded [n_seg, max] matrix, as evaluate_actions does for the executor counts
+            width = int(sizes.max())
+            col = torch.arange(rows) - _excl_cumsum(sizes)[owner]
+            mat = torch.full((n_seg, width), float("-inf"), device=device).index_put((owner.to(device), col.to(device)), s_ref)
+            pe = torch.softmax(mat, 1)
+            eps = torch.finfo(pe.dtype).eps
+            pe = torch.where(torch.isfinite(mat), pe.clamp(min=eps, max=1 - eps), torch.ones_like(pe))
+            p, lp = pe[owner.to(device), col.to(device)], pe.log()[owner.to(device), col.to(device)]
+        lg_ref = torch.zeros(n_seg, device=device)
+        lg_ref[full.to(device)] = lp[(ptr[:-1] + chosen)[full].to(device)]
+        ent_ref = -torch.zeros(n_seg, device=device).index_add_(0, owner.to(device), lp * p)
+        (lg_ref * w_lg.to(device) + ent_ref * w_ent.to(device)).sum().backward()
+        s_k = scores.clone().to(device).requires_grad_(True)
+        lg, ent = segment_categorical(s_k, ptr_d, chosen_d, den_eps, binding=binding)
+        (lg * w_lg.to(device) + ent * w_ent.to(device)).sum().backward()
+        assert torch.allclose(lg, lg_ref.detach(), rtol=1e-5, atol=1e-5) and torch.allclose(ent, ent_ref.detach(), rtol=1e-5, atol=1e-5), den_eps
+        assert torch.allclose(s_k.grad, s_ref.grad, rtol=1e-4, atol=1e-5), (den_eps, float((s_k.grad - s_ref.grad).abs().max()))
+        assert float(s_k.grad[int(ptr[big])]) == 0.0 or abs(float(s_k.grad[int(ptr[big])])) < 1e-12
