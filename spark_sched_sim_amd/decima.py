@@ -427,7 +427,7 @@ class _NodeEncoder(nn.Module):
             # messages are summed as a RANGE of the layer's edge rows - which they are when the edges are stored source node by
             # source node (every graph built here; checked once per graph for graphs from elsewhere, else the form below)
             from .train_kernels import message_passing
-            plan = [(dst[e], torch.searchsorted(recv, src[e]), recv) for e, recv in reversed(layers)]
+            plan = [(_take(dst, e), torch.searchsorted(recv, _take(src, e)), recv) for e, recv in reversed(layers)]  # (_take: the row kernel's gather)
             h = message_passing(h_init, h, plan, self.mlp_msg, self.mlp_update)
         else:
             # (row gathers as index_select: its backward is one index_add_, the advanced-indexing form sorts its indices first)
