@@ -193,7 +193,8 @@ CONCAT_ONE_LAUNCH = True  # the rows of a concatenation written / read back by O
 
 def rows_concat(op: int, out: torch.Tensor, tables, idxs, binding=None) -> None:
     """`sss_rows_concat` (include/sss.h; csrc/sss_rows.h sss_concat_kernel): op 0 out[i] = cat_k(tables[k][idxs[k][i]]);
-    op 1 tables[k][idxs[k][i]] += the k-th column range of out[i] (tables[k] None: skipped). out f32[n, sum of widths] contiguous"""
+    op 1 tables[k][idxs[k][i]] += the k-th column range of out[i] (tables[k] an int - the part's width - instead of a tensor: that part
+    gets no gradient, its columns are skipped). out f32[n, sum of widths] contiguous"""
     import ctypes
 
     from .binding import SssConcatArgs, device_of
