@@ -102,6 +102,13 @@ struct SssRowsVec<4> {
   static __device__ T zero() { return (T){0.0f, 0.0f, 0.0f, 0.0f}; }
   static __device__ void atomic_add(float* p, T v) { sss_rows_fadd(p, v.x), sss_rows_fadd(p + 1, v.y), sss_rows_fadd(p + 2, v.z), sss_rows_fadd(p + 3, v.w); }
 };
+typedef float sss_rows_v2 __attribute__((ext_vector_type(2)));
+template <>
+struct SssRowsVec<2> {  // 8 bytes per lane: rows of 64-bit values moved as two floats each (decima._take of index arrays)
+  typedef sss_rows_v2 T;
+  static __device__ T zero() { return (T){0.0f, 0.0f}; }
+  static __device__ void atomic_add(float* p, T v) { sss_rows_fadd(p, v.x), sss_rows_fadd(p + 1, v.y); }
+};
 template <>
 struct SssRowsVec<1> {
   typedef float T;
@@ -235,7 +242,10 @@ static int sss_rows_launch(const SssRowsArgs& r, void* stream) {
   // (atomics: one float per lane - a wave's instruction then covers whole rows, 64 bytes per request; with 16 bytes per lane it
   // takes four instructions that each touch a quarter of four times as many rows: measured 2x slower, profiles/r04_ppo.md)
   const bool vec = r.width % 4 == 0 && r.ld_a % 4 == 0 && aligned(r.a) && aligned(r.b) && (!r.c || aligned(r.c)) && (r.op != ROWS_SCATTER_ADD || SSS_ROWS_VEC_ATOMICS);
-  const int per_row = vec ? r.width / 4 : r.width;
+  auto aligned8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
+  // (the data-moving operations only: 8 bytes per lane where 16 do not divide the row - the gathers of 64-bit index arrays)
+  const bool vec2 = !vec && (r.op == ROWS_GATHER || r.op == ROWS_SCATTER) && r.width % 2 == 0 && r.ld_a % 2 == 0 && aligned8(r.a) && aligned8(r.b);
+  const int per_row = vec ? r.width / 4 : vec2 ? r.width / 2 : r.width;
   int lanes_log = 0;
   while ((1 << lanes_log) < per_row) lanes_log++;
   const int64_t total = r.n << lanes_log, per_block = 256 * 4;
@@ -243,6 +253,8 @@ static int sss_rows_launch(const SssRowsArgs& r, void* stream) {
   if (blocks > 65536 * 16) blocks = 65536 * 16;  // (the loop strides)
   if (blocks < 1) return 0;
   if (vec) sss_rows_launch_op<4>(r, lanes_log, dim3((unsigned)blocks), (hipStream_t)stream);
+  else if (vec2 && r.op == ROWS_GATHER) hipLaunchKernelGGL((sss_rows_kernel<2, ROWS_GATHER>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, lanes_log);
+  else if (vec2) hipLaunchKernelGGL((sss_rows_kernel<2, ROWS_SCATTER>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, lanes_log);
   else sss_rows_launch_op<1>(r, lanes_log, dim3((unsigned)blocks), (hipStream_t)stream);
   return (int)hipGetLastError();
 }

@@ -169,7 +169,7 @@ def check_rows_ops(binding, device, n):
 
     gen = torch.Generator().manual_seed(11)
     rnd = lambda *shape: torch.randn(shape, generator=gen).to(device)  # noqa: E731
-    for width in (1, 5, 16, 21, 35, 36, 64):
+    for width in (1, 2, 5, 6, 16, 21, 35, 36, 64):  # (2, 6: the 8-bytes-per-lane form of GATHER / SCATTER where the pointers allow it)
         rows = max(3, n // 3)
         table = rnd(rows, width)
         idx = torch.randint(0, rows, (n,), generator=gen).to(device)
