@@ -594,7 +594,13 @@ class _MessagePassFn(torch.autograd.Function):
         mx, ma1, ma2 = f(ne, 16), f(ne, 32) if keep else None, f(ne, 16) if keep else None  # message MLP: inputs (and hidden activations) of every edge, layer after layer
         ux, ua1, ua2 = f(nr, 16), f(nr, 32) if keep else None, f(nr, 16) if keep else None  # update MLP: the same per receiving node
         sl = lambda t, lo, n: t[lo:lo + n] if t is not None else None  # noqa: E731
-        h = h0.clone()
+        # the embeddings are updated IN h0 (the caller's fresh per-leaf sums: marked dirty for autograd, returned as the result) - a copy of
+        # the whole [M, 16] table per minibatch otherwise
+        if h0.is_contiguous():
+            ctx.mark_dirty(h0)
+            h = h0
+        else:
+            h = h0.contiguous()
         h_init = h_init.contiguous()
         eo = ro = 0
         for child, pos, recv in layers:
